@@ -1,0 +1,122 @@
+"""Shared fixtures for the parity tests: parameter sets, seeded key material.
+
+Parameter constants restate tfhe-rs' own:
+  C1      = PARAM_MESSAGE_2_CARRY_2 (= V1_4_PARAM_MESSAGE_2_CARRY_2_KS_PBS_TUNIFORM_2M128,
+            tfhe/src/shortint/parameters/v1_4/classic/tuniform/p_fail_2_minus_128/ks_pbs.rs:28-47)
+  C1P     = V1_4_PARAM_MESSAGE_1_CARRY_2_KS_PBS_GAUSSIAN_2M128 shape (N=1024, k=2)
+            (.../v1_4/classic/gaussian/p_fail_2_minus_128/ks_pbs.rs:57-80); noise restated as
+            TUniform bounds of similar magnitude (our PRNG is not the reference's anyway)
+  C4      = V1_1_PARAM_MULTI_BIT_GROUP_3_MESSAGE_2_CARRY_2_KS_PBS_TUNIFORM_2M128
+            (.../v1_1/multi_bit/tuniform/p_fail_2_minus_128/ks_pbs.rs:118-137)
+  TOY_*   = small sets in the spirit of core_crypto/algorithms/test/mod.rs:56-200
+"""
+import dataclasses
+import functools
+
+import numpy as np
+
+from . import oracle as orc
+
+
+@dataclasses.dataclass(frozen=True)
+class Params:
+    name: str
+    n: int              # small LWE dimension
+    k: int              # GLWE dimension
+    N: int              # polynomial size
+    pbs_base_log: int
+    pbs_level: int
+    ks_base_log: int
+    ks_level: int
+    lwe_noise: int      # TUniform bound_log2 for the small key
+    glwe_noise: int     # TUniform bound_log2 for the GLWE key
+    plaintext_modulus: int  # message_modulus * carry_modulus (padding bit on top)
+    ms_type: int = 0    # 0 standard, 1 centered mean (PBS_MS_REDUCTION_T)
+    grouping: int = 0   # multi-bit grouping factor (0 = classic)
+
+    @property
+    def big_n(self):
+        return self.k * self.N
+
+    @property
+    def delta(self):
+        return (1 << 63) // self.plaintext_modulus
+
+    @property
+    def log2N2(self):
+        return (2 * self.N).bit_length() - 1
+
+
+C1 = Params("PARAM_MESSAGE_2_CARRY_2", 918, 1, 2048, 23, 1, 4, 4, 45, 17, 16, ms_type=1)
+C1P = Params("PARAM_MESSAGE_1_CARRY_2_N1024", 885, 2, 1024, 23, 1, 3, 5, 46, 24, 8, ms_type=0)
+C4 = Params("PARAM_MULTI_BIT_GROUP_3_MESSAGE_2_CARRY_2", 918, 1, 2048, 15, 2, 3, 6, 45, 17, 16,
+            grouping=3)
+
+TOY_K1 = Params("toy_k1_N256", 24, 1, 256, 15, 2, 4, 5, 40, 20, 4, ms_type=1)
+TOY_K1_L1 = Params("toy_k1_N512_l1", 32, 1, 512, 23, 1, 4, 5, 40, 12, 4, ms_type=0)
+TOY_K2 = Params("toy_k2_N256", 20, 2, 256, 12, 3, 3, 6, 40, 20, 4, ms_type=1)
+TOY_K3 = Params("toy_k3_N512", 16, 3, 512, 18, 2, 4, 5, 40, 18, 8, ms_type=0)
+TOY_2048 = Params("toy_k1_N2048_l1", 12, 1, 2048, 23, 1, 4, 4, 45, 17, 16, ms_type=1)
+TOY_2048_L2 = Params("toy_k1_N2048_l2", 9, 1, 2048, 15, 2, 3, 6, 45, 17, 16, ms_type=0)
+TOY_1024_K2 = Params("toy_k2_N1024_l1", 10, 2, 1024, 23, 1, 3, 5, 46, 24, 8, ms_type=0)
+TOY_MB = Params("toy_multibit_g3", 18, 1, 256, 15, 2, 4, 5, 40, 20, 4, grouping=3)
+TOY_MB2 = Params("toy_multibit_g2", 16, 1, 512, 15, 2, 4, 5, 40, 20, 4, grouping=2)
+
+
+@dataclasses.dataclass
+class Keys:
+    p: Params
+    lwe_sk: np.ndarray      # n bits (small key)
+    glwe_sk: np.ndarray     # k*N bits (== big LWE key)
+    bsk: np.ndarray         # standard-domain BSK (classic or multi-bit layout)
+    ksk: np.ndarray         # big -> small
+
+
+@functools.lru_cache(maxsize=8)
+def make_keys(p: Params, seed: int = 0x74666865, with_ksk: bool = True) -> Keys:
+    rng = orc.Rng(seed)
+    lwe_sk = rng.binary_key(p.n)
+    glwe_sk = rng.binary_key(p.k * p.N)
+    if p.grouping:
+        bsk = orc.gen_multi_bit_bsk(seed + 1, lwe_sk, glwe_sk, p.k, p.N, p.pbs_base_log,
+                                    p.pbs_level, p.grouping, p.glwe_noise)
+    else:
+        bsk = orc.gen_bsk(seed + 1, lwe_sk, glwe_sk, p.k, p.N, p.pbs_base_log, p.pbs_level,
+                          p.glwe_noise)
+    ksk = (orc.gen_ksk(seed + 2, glwe_sk, lwe_sk, p.ks_base_log, p.ks_level, p.lwe_noise)
+           if with_ksk else np.zeros(0, dtype=np.uint64))
+    return Keys(p, lwe_sk, glwe_sk, bsk, ksk)
+
+
+def encrypt_small(p: Params, keys: Keys, msgs, seed=1):
+    """Fresh encryptions under the SMALL key (what the PBS consumes)."""
+    rng = orc.Rng(seed)
+    return np.stack([orc.lwe_encrypt(rng, keys.lwe_sk, (int(m) * p.delta) % (1 << 64), p.lwe_noise)
+                     for m in msgs])
+
+
+def encrypt_big(p: Params, keys: Keys, msgs, seed=2):
+    """Fresh encryptions under the BIG key (what KS->PBS consumes)."""
+    rng = orc.Rng(seed)
+    return np.stack([orc.lwe_encrypt(rng, keys.glwe_sk, (int(m) * p.delta) % (1 << 64), p.glwe_noise)
+                     for m in msgs])
+
+
+def decode(p: Params, raw):
+    """round_decode: nearest multiple of delta, modulo 2*plaintext_modulus (padding bit kept)."""
+    raw = int(raw)
+    return ((raw + p.delta // 2) // p.delta) % (2 * p.plaintext_modulus)
+
+
+def decrypt_big(p: Params, keys: Keys, ct):
+    return decode(p, orc.lwe_decrypt(ct, keys.glwe_sk))
+
+
+def decrypt_small(p: Params, keys: Keys, ct):
+    return decode(p, orc.lwe_decrypt(ct, keys.lwe_sk))
+
+
+def torus_distance(a, b):
+    """max |a-b| on the 2^64 torus, element-wise wrapped to signed."""
+    d = (np.asarray(a, dtype=np.uint64) - np.asarray(b, dtype=np.uint64)).astype(np.int64)
+    return np.abs(d.astype(np.float64)).max() if d.size else 0.0
