@@ -1,0 +1,209 @@
+/*
+ * tfhe_hip_backend.h — C ABI of the MI355X (gfx950) TFHE programmable-bootstrapping backend.
+ *
+ * This is the drop-in boundary for the PBS hot path of tfhe-rs (keyswitch -> modulus switch
+ * -> blind rotation -> sample extract).  Every prototype below is EXACTLY the prototype the
+ * reference's Rust FFI binds for this path (bindgen over
+ * backends/tfhe-cuda-backend/cuda/include/ — build.rs:78-137 — and
+ * backends/tfhe-cuda-common/src/cuda_bind.rs), with the same symbol name, argument meaning,
+ * asynchrony and error behaviour, so `tfhe::core_crypto::gpu` links against
+ * libtfhe_hip_backend.so unchanged for this path (INTEGRATION.md shows the binding).
+ *
+ * Conventions inherited from the reference boundary:
+ *   - `stream` is an opaque handle made by cuda_create_stream_ffi (a hipStream_t here);
+ *     `*_async` functions only enqueue on it; `cleanup_*` frees then synchronises;
+ *     non-`_async` `cuda_*` functions synchronise internally
+ *     (scripts/check_scratch_cleanup.py:1-20).
+ *   - all ciphertext / key pointers are DEVICE pointers owned by the caller, except the
+ *     `src` of the key-conversion functions, which is a HOST pointer
+ *     (tfhe/src/core_crypto/gpu/ffi.rs:744-787).
+ *   - no error codes: misuse prints to stderr and abort()s
+ *     (backends/tfhe-cuda-common/cuda/include/device.h:13-41).
+ *   - `*_indexes` are u64 arrays ON THE DEVICE selecting list element i
+ *     (cuda/src/pbs/programmable_bootstrap_classic.cuh:821-826).
+ *   - the bootstrap-key device buffer is opaque to the caller and has the reference's byte
+ *     size: n*(k+1)^2*l*N doubles (gpu/entities/lwe_bootstrap_key.rs:57-104).
+ *
+ * Functions prefixed `hip_` are extensions with no counterpart in the reference GPU ABI
+ * (the Goldilocks-NTT engine of cc/algorithms/lwe_programmable_bootstrapping/ntt64_bnf_pbs.rs
+ * exists only on the reference's CPU side) plus test hooks.
+ */
+#ifndef TFHE_HIP_BACKEND_H
+#define TFHE_HIP_BACKEND_H
+
+#include <stdbool.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* backends/tfhe-cuda-backend/cuda/include/pbs/pbs_enums.h:4-6 */
+enum PBS_TYPE { MULTI_BIT = 0, CLASSICAL = 1 };
+enum PBS_VARIANT { DEFAULT = 0, CG = 1, TBC = 2 };
+enum PBS_MS_REDUCTION_T { NO_REDUCTION = 0, CENTERED = 1 };
+
+/* ------------------------------------------------------------------ device runtime
+ * backends/tfhe-cuda-common/cuda/include/device.h:58-92 (cuda_bind.rs:5-150) */
+void *cuda_create_stream_ffi(uint32_t gpu_index);
+void cuda_destroy_stream(void *stream, uint32_t gpu_index);
+void cuda_synchronize_stream(void *stream, uint32_t gpu_index);
+uint32_t cuda_is_available(void);
+void *cuda_malloc(uint64_t size, uint32_t gpu_index);
+void *cuda_malloc_async(uint64_t size, void *stream, uint32_t gpu_index);
+bool cuda_check_valid_malloc(uint64_t size, uint32_t gpu_index);
+uint64_t cuda_device_total_memory(uint32_t gpu_index);
+void cuda_memcpy_async_to_gpu(void *dest, const void *src, uint64_t size, void *stream, uint32_t gpu_index);
+void cuda_memcpy_async_gpu_to_gpu(void *dest, void const *src, uint64_t size, void *stream, uint32_t gpu_index);
+void cuda_memcpy_gpu_to_gpu(void *dest, void const *src, uint64_t size, uint32_t gpu_index);
+void cuda_memcpy_async_to_cpu(void *dest, const void *src, uint64_t size, void *stream, uint32_t gpu_index);
+void cuda_memset_async(void *dest, uint64_t val, uint64_t size, void *stream, uint32_t gpu_index);
+int cuda_get_number_of_gpus(void);
+int cuda_get_number_of_sms(void);
+void cuda_synchronize_device(uint32_t gpu_index);
+void cuda_drop(void *ptr, uint32_t gpu_index);
+
+/* ------------------------------------------------------------------ classic PBS
+ * backends/tfhe-cuda-backend/cuda/include/pbs/programmable_bootstrap.h:52-55,62-66,83-90,99-100
+ * called from tfhe/src/core_crypto/gpu/ffi.rs:21-92 */
+void cuda_convert_lwe_programmable_bootstrap_key_64_async(
+    void *stream, uint32_t gpu_index, void *dest, void const *src,
+    uint32_t input_lwe_dim, uint32_t glwe_dim, uint32_t level_count,
+    uint32_t polynomial_size);
+
+uint64_t scratch_cuda_programmable_bootstrap_64_async(
+    void *stream, uint32_t gpu_index, int8_t **buffer, uint32_t lwe_dimension,
+    uint32_t glwe_dimension, uint32_t polynomial_size, uint32_t level_count,
+    uint32_t input_lwe_ciphertext_count, bool allocate_gpu_memory,
+    enum PBS_MS_REDUCTION_T noise_reduction_type);
+
+void cuda_programmable_bootstrap_64_async(
+    void *stream, uint32_t gpu_index, void *lwe_array_out,
+    void const *lwe_output_indexes, void const *lut_vector,
+    void const *lut_vector_indexes, void const *lwe_array_in,
+    void const *lwe_input_indexes, void const *bootstrapping_key,
+    int8_t *buffer, uint32_t lwe_dimension, uint32_t glwe_dimension,
+    uint32_t polynomial_size, uint32_t base_log, uint32_t level_count,
+    uint32_t num_samples, uint32_t num_many_lut, uint32_t lut_stride);
+
+void cleanup_cuda_programmable_bootstrap_64(void *stream, uint32_t gpu_index, int8_t **pbs_buffer);
+
+/* ------------------------------------------------------------------ multi-bit PBS
+ * backends/tfhe-cuda-backend/cuda/include/pbs/programmable_bootstrap_multibit.h:9-40
+ * called from tfhe/src/core_crypto/gpu/ffi.rs:208-309,789-835 */
+bool has_support_to_cuda_programmable_bootstrap_cg_multi_bit(
+    uint32_t glwe_dimension, uint32_t polynomial_size, uint32_t level_count,
+    uint32_t num_samples, uint32_t max_shared_memory);
+
+void cuda_convert_lwe_multi_bit_programmable_bootstrap_key_64_async(
+    void *stream, uint32_t gpu_index, void *dest, void const *src,
+    uint32_t input_lwe_dim, uint32_t glwe_dim, uint32_t level_count,
+    uint32_t polynomial_size, uint32_t grouping_factor);
+
+uint64_t scratch_cuda_multi_bit_programmable_bootstrap_64_async(
+    void *stream, uint32_t gpu_index, int8_t **pbs_buffer,
+    uint32_t glwe_dimension, uint32_t polynomial_size, uint32_t level_count,
+    uint32_t input_lwe_ciphertext_count, bool allocate_gpu_memory);
+
+void cuda_multi_bit_programmable_bootstrap_64_async(
+    void *stream, uint32_t gpu_index, void *lwe_array_out,
+    void const *lwe_output_indexes, void const *lut_vector,
+    void const *lut_vector_indexes, void const *lwe_array_in,
+    void const *lwe_input_indexes, void const *bootstrapping_key,
+    int8_t *buffer, uint32_t lwe_dimension, uint32_t glwe_dimension,
+    uint32_t polynomial_size, uint32_t grouping_factor, uint32_t base_log,
+    uint32_t level_count, uint32_t num_samples, uint32_t num_many_lut,
+    uint32_t lut_stride);
+
+void cleanup_cuda_multi_bit_programmable_bootstrap_64(void *stream, uint32_t gpu_index, int8_t **pbs_buffer);
+
+/* ------------------------------------------------------------------ keyswitch
+ * backends/tfhe-cuda-backend/cuda/include/keyswitch/keyswitch.h:16-21,35-41,69-72
+ * called from tfhe/src/core_crypto/gpu/ffi.rs:503-618 (KSK upload is a plain memcpy, :620-627) */
+void cuda_keyswitch_lwe_ciphertext_vector_64_64_async(
+    void *stream, uint32_t gpu_index, void *lwe_array_out,
+    void const *lwe_output_indexes, void const *lwe_array_in,
+    void const *lwe_input_indexes, void const *ksk, uint32_t lwe_dimension_in,
+    uint32_t lwe_dimension_out, uint32_t base_log, uint32_t level_count,
+    uint32_t num_samples);
+
+void cuda_keyswitch_gemm_64_64_async(
+    void *stream, uint32_t gpu_index, void *lwe_array_out,
+    void const *lwe_output_indexes, void const *lwe_array_in,
+    void const *lwe_input_indexes, void const *ksk, uint32_t lwe_dimension_in,
+    uint32_t lwe_dimension_out, uint32_t base_log, uint32_t level_count,
+    uint32_t num_samples, bool uses_trivial_indexes);
+
+void cuda_closest_representable_64_async(void *stream, uint32_t gpu_index,
+                                         void const *input, void *output,
+                                         uint32_t base_log, uint32_t level_count);
+
+/* ------------------------------------------------------------------ ciphertext helpers
+ * backends/tfhe-cuda-backend/cuda/include/ciphertext.h:5-42
+ * called from tfhe/src/core_crypto/gpu/ffi.rs:838-898 */
+void cuda_convert_lwe_ciphertext_vector_to_gpu_64_async(
+    void *stream, uint32_t gpu_index, void *dest, void const *src,
+    uint32_t number_of_cts, uint32_t lwe_dimension);
+void cuda_convert_lwe_ciphertext_vector_to_cpu_64_async(
+    void *stream, uint32_t gpu_index, void *dest, void const *src,
+    uint32_t number_of_cts, uint32_t lwe_dimension);
+void cuda_glwe_sample_extract_64_async(
+    void *stream, uint32_t gpu_index, void *lwe_array_out,
+    void const *glwe_array_in, uint32_t const *nth_array, uint32_t num_nths,
+    uint32_t num_lwes_to_extract_per_glwe, uint32_t num_lwes_stored_per_glwe,
+    uint32_t glwe_dimension, uint32_t polynomial_size);
+void cuda_modulus_switch_inplace_64_async(void *stream, uint32_t gpu_index,
+                                          void *lwe_array_out, uint32_t size,
+                                          uint32_t log_modulus);
+void cuda_modulus_switch_64_async(void *stream, uint32_t gpu_index,
+                                  void *lwe_out, const void *lwe_in,
+                                  uint32_t size, uint32_t log_modulus);
+void cuda_centered_modulus_switch_64_async(void *stream, uint32_t gpu_index,
+                                           void *lwe_out, const void *lwe_in,
+                                           uint32_t lwe_dimension,
+                                           uint32_t log_modulus);
+
+/* ------------------------------------------------------------------ extensions (hip_*)
+ * Goldilocks-NTT engine: same argument meaning as the classic PBS triple above, the key
+ * buffer has the same byte size (n*(k+1)^2*l*N u64).  Semantics:
+ * cc/algorithms/lwe_programmable_bootstrapping/ntt64_bnf_pbs.rs:469-539 and
+ * cc/algorithms/lwe_bootstrap_key_conversion.rs:367-434 (bit-exact, integer only). */
+void hip_convert_lwe_programmable_bootstrap_key_ntt64_async(
+    void *stream, uint32_t gpu_index, void *dest, void const *src,
+    uint32_t input_lwe_dim, uint32_t glwe_dim, uint32_t level_count,
+    uint32_t polynomial_size);
+void hip_programmable_bootstrap_ntt64_async(
+    void *stream, uint32_t gpu_index, void *lwe_array_out,
+    void const *lwe_output_indexes, void const *lut_vector,
+    void const *lut_vector_indexes, void const *lwe_array_in,
+    void const *lwe_input_indexes, void const *bootstrapping_key,
+    int8_t *buffer, uint32_t lwe_dimension, uint32_t glwe_dimension,
+    uint32_t polynomial_size, uint32_t base_log, uint32_t level_count,
+    uint32_t num_samples, uint32_t num_many_lut, uint32_t lut_stride);
+
+/* Select which f64 kernel serves cuda_programmable_bootstrap_64_async:
+ * 0 = automatic (throughput kernel when the parameter set supports it), 1 = generic LDS
+ * kernel, 2 = throughput kernel (abort if unsupported).  Both give identical bits. */
+void hip_backend_set_fft_kernel(uint32_t which);
+/* last launched PBS kernel, for tests: 1 generic f64, 2 wave f64, 3 generic ntt */
+uint32_t hip_backend_last_pbs_kernel(void);
+const char *hip_backend_version(void);
+
+/* HIP events recorded on a backend stream (used by bench.py to time launches) */
+void *hip_event_create(void);
+void hip_event_record(void *event, void *stream);
+float hip_event_elapsed_ms(void *start, void *stop); /* synchronises `stop` */
+void hip_event_destroy(void *event);
+
+/* test hooks: run single device functions / transforms so that tests can compare them with
+ * the oracle (ops documented in tfhe-rs_amd/csrc/testhooks.hip) */
+void hip_test_arith_async(void *stream, uint32_t gpu_index, uint32_t op, void const *in,
+                          void *out, uint32_t count, uint32_t p0, uint32_t p1);
+void hip_test_transform_async(void *stream, uint32_t gpu_index, uint32_t op,
+                              uint32_t polynomial_size, void const *in, void *out);
+void hip_test_fft_tables_host(uint32_t polynomial_size, double *fwd, double *inv, double *untwist);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TFHE_HIP_BACKEND_H */

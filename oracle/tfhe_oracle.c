@@ -439,13 +439,22 @@ uint64_t orc_gl_pow(uint64_t a, uint64_t e) {
   return r;
 }
 
-/* A primitive 2N-th root of unity.  7 generates Z_p^* for p = 2^64-2^32+1, so
- * 7^((p-1)/2N) has order exactly 2N.  The reference derives its root from a
- * table of fixed constants (tfhe-ntt/src/prime64.rs:159-204); ANY primitive
- * 2N-th root yields the same negacyclic products, hence the same PBS outputs
- * (only the private NTT-domain key layout differs). */
+/* The primitive 2N-th root of unity the reference uses for the Goldilocks prime:
+ * fixed constants of tfhe-ntt/src/prime64.rs:162-179 (so the NTT-domain key is the
+ * reference's, value for value); other sizes fall back to 7^((p-1)/2N) (7 generates Z_p^*). */
 uint64_t orc_gl_primitive_root_2N(uint32_t N) {
-  return orc_gl_pow(7, (ORC_GOLDILOCKS_P - 1) / (2ull * N));
+  switch (N) {
+    case 32: return 8ull;
+    case 64: return 2198989700608ull;
+    case 128: return 14041890976876060974ull;
+    case 256: return 14430643036723656017ull;
+    case 512: return 4440654710286119610ull;
+    case 1024: return 8816101479115663336ull;
+    case 2048: return 10974926054405199669ull;
+    case 4096: return 1206500561358145487ull;
+    case 8192: return 10930245224889659871ull;
+    default: return orc_gl_pow(7, (ORC_GOLDILOCKS_P - 1) / (2ull * N));
+  }
 }
 
 static uint32_t bitrev(uint32_t x, uint32_t bits) {
@@ -741,9 +750,11 @@ static void fft_inverse_inplace(double *v, uint32_t N) {
   }
 }
 
-/* Rust `f64 as i64` saturates */
+/* f64 -> i64 of an integer-valued double in [-2^63, 2^63]: +2^63 folds onto -2^63, the
+ * two's-complement torus value (what the reference's SIMD conversions do and its test
+ * fft/x86.rs:1030-1112 asserts; the scalar `as i64` would saturate to 2^63-1 instead). */
 int64_t orc_f64_to_i64_sat(double x) {
-  if (x >= 9223372036854775808.0) return INT64_MAX;
+  if (x >= 9223372036854775808.0) return INT64_MIN;
   if (x <= -9223372036854775808.0) return INT64_MIN;
   return (int64_t)x;
 }

@@ -1,0 +1,12 @@
+"""tfhe-rs_amd — MI355X-native TFHE programmable-bootstrapping backend (host-side package).
+
+The product is libtfhe_hip_backend.so (tfhe-rs_amd/csrc, C ABI in include/tfhe_hip_backend.h);
+this package is the thin host side: `ffi` (raw binding) and `core_crypto_gpu` (mirror of
+tfhe::core_crypto::gpu).  Import name: `tfhe_rs_amd` (see ../tfhe_rs_amd/__init__.py — a
+hyphen cannot appear in a Python module name).
+"""
+from . import ffi  # noqa: F401
+from . import core_crypto_gpu  # noqa: F401
+from . import multi_gpu  # noqa: F401
+
+__all__ = ["ffi", "core_crypto_gpu", "multi_gpu"]

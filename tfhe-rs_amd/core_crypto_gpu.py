@@ -1,0 +1,337 @@
+"""Host-side mirror of `tfhe::core_crypto::gpu` for the PBS hot path, over the C ABI.
+
+Same names, argument meaning and error behaviour (assertions on mismatched dimensions) as
+the Rust module it mirrors:
+  CudaStreams                 tfhe/src/core_crypto/gpu/mod.rs:33-150
+  CudaVec                     tfhe/src/core_crypto/gpu/vec.rs
+  CudaLweCiphertextList       tfhe/src/core_crypto/gpu/entities/lwe_ciphertext_list.rs
+  CudaGlweCiphertextList      tfhe/src/core_crypto/gpu/entities/glwe_ciphertext_list.rs
+  CudaLweBootstrapKey         tfhe/src/core_crypto/gpu/entities/lwe_bootstrap_key.rs:57-104
+  CudaLweMultiBitBootstrapKey tfhe/src/core_crypto/gpu/entities/lwe_multi_bit_bootstrap_key.rs
+  CudaLweKeyswitchKey         tfhe/src/core_crypto/gpu/entities/lwe_keyswitch_key.rs
+  cuda_programmable_bootstrap_lwe_ciphertext           gpu/algorithms/lwe_programmable_bootstrapping.rs:10-136
+  cuda_multi_bit_programmable_bootstrap_lwe_ciphertext gpu/algorithms/lwe_multi_bit_programmable_bootstrapping.rs:10-145
+  cuda_keyswitch_lwe_ciphertext                        gpu/algorithms/lwe_keyswitch.rs:12-143
+  cuda_extract_lwe_samples_from_glwe_ciphertext_list   gpu/algorithms/glwe_sample_extraction.rs:12
+The Rust original is the reference's host language; no Rust toolchain exists in this image,
+so the mirror is Python (INTEGRATION.md shows the Rust binding a maintainer would add).
+numpy arrays are the "CPU containers".
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import ffi
+
+U64 = np.uint64
+
+
+def _lib():
+    return ffi.default_library()
+
+
+class CudaStreams:
+    """One stream per GPU (mod.rs:33-150)."""
+
+    def __init__(self, gpu_indexes):
+        self.gpu_indexes = [int(g) for g in gpu_indexes]
+        self.ptr = [_lib().cuda_create_stream_ffi(g) for g in self.gpu_indexes]
+
+    @classmethod
+    def new_single_gpu(cls, gpu_index=0):
+        return cls([gpu_index])
+
+    @classmethod
+    def new_multi_gpu(cls):
+        return cls(range(_lib().cuda_get_number_of_gpus()))
+
+    def synchronize(self):
+        for s, g in zip(self.ptr, self.gpu_indexes):
+            _lib().cuda_synchronize_stream(s, g)
+
+    def synchronize_one(self, i):
+        _lib().cuda_synchronize_stream(self.ptr[i], self.gpu_indexes[i])
+
+    def __len__(self):
+        return len(self.ptr)
+
+    def destroy(self):
+        for s, g in zip(self.ptr, self.gpu_indexes):
+            _lib().cuda_destroy_stream(s, g)
+        self.ptr = []
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+class CudaVec:
+    """Device array of one dtype on the GPU of streams[stream_index] (vec.rs)."""
+
+    def __init__(self, length, streams, stream_index=0, dtype=U64):
+        self.len = int(length)
+        self.dtype = np.dtype(dtype)
+        self.gpu_index = streams.gpu_indexes[stream_index]
+        nbytes = max(self.len * self.dtype.itemsize, 8)
+        self.ptr = _lib().cuda_malloc(nbytes, self.gpu_index)
+        _lib().cuda_memset_async(self.ptr, 0, nbytes, streams.ptr[stream_index], self.gpu_index)
+
+    @classmethod
+    def from_cpu_async(cls, src, streams, stream_index=0):
+        src = np.ascontiguousarray(src)
+        v = cls(src.size, streams, stream_index, src.dtype)
+        v.copy_from_cpu_async(src, streams, stream_index)
+        return v
+
+    def copy_from_cpu_async(self, src, streams, stream_index=0):
+        src = np.ascontiguousarray(src, dtype=self.dtype)
+        assert src.size <= self.len, "CudaVec: source larger than the device vector"
+        _lib().cuda_memcpy_async_to_gpu(self.ptr, src.ctypes.data_as(C.c_void_p), src.nbytes,
+                                        streams.ptr[stream_index], self.gpu_index)
+        # the source is pageable host memory: keep it alive until the stream is drained
+        streams.synchronize_one(stream_index)
+
+    def copy_to_cpu(self, streams, stream_index=0):
+        out = np.empty(self.len, dtype=self.dtype)
+        _lib().cuda_memcpy_async_to_cpu(out.ctypes.data_as(C.c_void_p), self.ptr, out.nbytes,
+                                        streams.ptr[stream_index], self.gpu_index)
+        streams.synchronize_one(stream_index)
+        return out
+
+    def drop(self):
+        if self.ptr:
+            _lib().cuda_drop(self.ptr, self.gpu_index)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.drop()
+        except Exception:
+            pass
+
+
+class CudaLweCiphertextList:
+    def __init__(self, d_vec, lwe_ciphertext_count, lwe_dimension):
+        self.d_vec = d_vec
+        self.lwe_ciphertext_count = int(lwe_ciphertext_count)
+        self.lwe_dimension = int(lwe_dimension)
+
+    @classmethod
+    def new(cls, lwe_dimension, lwe_ciphertext_count, streams):
+        return cls(CudaVec((lwe_dimension + 1) * lwe_ciphertext_count, streams), lwe_ciphertext_count,
+                   lwe_dimension)
+
+    @classmethod
+    def from_lwe_ciphertext_list(cls, h_ct, streams):
+        h_ct = np.ascontiguousarray(h_ct, dtype=U64)
+        assert h_ct.ndim == 2, "expected [count][lwe_size]"
+        return cls(CudaVec.from_cpu_async(h_ct.reshape(-1), streams), h_ct.shape[0], h_ct.shape[1] - 1)
+
+    def to_lwe_ciphertext_list(self, streams):
+        return self.d_vec.copy_to_cpu(streams).reshape(self.lwe_ciphertext_count, self.lwe_dimension + 1)
+
+
+class CudaGlweCiphertextList:
+    def __init__(self, d_vec, glwe_ciphertext_count, glwe_dimension, polynomial_size):
+        self.d_vec = d_vec
+        self.glwe_ciphertext_count = int(glwe_ciphertext_count)
+        self.glwe_dimension = int(glwe_dimension)
+        self.polynomial_size = int(polynomial_size)
+
+    @classmethod
+    def from_glwe_ciphertext_list(cls, h_ct, glwe_dimension, polynomial_size, streams):
+        h_ct = np.ascontiguousarray(h_ct, dtype=U64).reshape(-1, (glwe_dimension + 1) * polynomial_size)
+        return cls(CudaVec.from_cpu_async(h_ct.reshape(-1), streams), h_ct.shape[0], glwe_dimension,
+                   polynomial_size)
+
+    def to_glwe_ciphertext_list(self, streams):
+        return self.d_vec.copy_to_cpu(streams).reshape(self.glwe_ciphertext_count, -1)
+
+
+class CudaLweBootstrapKey:
+    """Bootstrap key converted once per GPU of `streams` (lwe_bootstrap_key.rs:57-104,
+    gpu/ffi.rs:744-787).  engine 'fft64' is the reference GPU path; 'ntt64' is the
+    Goldilocks extension (bit-exact integer path)."""
+
+    def __init__(self):
+        self.d_vec = None
+
+    @classmethod
+    def from_lwe_bootstrap_key(cls, h_bsk, input_lwe_dimension, glwe_dimension, polynomial_size,
+                               decomp_base_log, decomp_level_count, streams, ms_noise_reduction=False,
+                               engine="fft64"):
+        self = cls()
+        self.input_lwe_dimension = int(input_lwe_dimension)
+        self.glwe_dimension = int(glwe_dimension)
+        self.polynomial_size = int(polynomial_size)
+        self.decomp_base_log = int(decomp_base_log)
+        self.decomp_level_count = int(decomp_level_count)
+        self.ms_noise_reduction = bool(ms_noise_reduction)
+        self.engine = engine
+        h_bsk = np.ascontiguousarray(h_bsk, dtype=U64)
+        elems = (self.input_lwe_dimension * (glwe_dimension + 1) ** 2 * decomp_level_count * polynomial_size)
+        assert h_bsk.size == elems, "bootstrap key container has the wrong size"
+        # n*(k+1)^2*l*N f64 per GPU — same byte size for both engines
+        self.d_vecs = []
+        for i in range(len(streams)):
+            d = CudaVec(elems, streams, i, np.float64)
+            conv = (_lib().cuda_convert_lwe_programmable_bootstrap_key_64_async if engine == "fft64"
+                    else _lib().hip_convert_lwe_programmable_bootstrap_key_ntt64_async)
+            conv(streams.ptr[i], streams.gpu_indexes[i], d.ptr, h_bsk.ctypes.data_as(C.c_void_p),
+                 self.input_lwe_dimension, glwe_dimension, decomp_level_count, polynomial_size)
+            self.d_vecs.append(d)
+        streams.synchronize()
+        self.d_vec = self.d_vecs[0]
+        return self
+
+    @property
+    def output_lwe_dimension(self):
+        return self.glwe_dimension * self.polynomial_size
+
+
+class CudaLweMultiBitBootstrapKey:
+    @classmethod
+    def from_lwe_multi_bit_bootstrap_key(cls, h_bsk, input_lwe_dimension, glwe_dimension, polynomial_size,
+                                         decomp_base_log, decomp_level_count, grouping_factor, streams):
+        self = cls()
+        self.input_lwe_dimension = int(input_lwe_dimension)
+        self.glwe_dimension = int(glwe_dimension)
+        self.polynomial_size = int(polynomial_size)
+        self.decomp_base_log = int(decomp_base_log)
+        self.decomp_level_count = int(decomp_level_count)
+        self.grouping_factor = int(grouping_factor)
+        h_bsk = np.ascontiguousarray(h_bsk, dtype=U64)
+        self.d_vecs = []
+        for i in range(len(streams)):
+            d = CudaVec(h_bsk.size, streams, i, U64)
+            _lib().cuda_convert_lwe_multi_bit_programmable_bootstrap_key_64_async(
+                streams.ptr[i], streams.gpu_indexes[i], d.ptr, h_bsk.ctypes.data_as(C.c_void_p),
+                self.input_lwe_dimension, glwe_dimension, decomp_level_count, polynomial_size, grouping_factor)
+            self.d_vecs.append(d)
+        streams.synchronize()
+        self.d_vec = self.d_vecs[0]
+        return self
+
+    @property
+    def output_lwe_dimension(self):
+        return self.glwe_dimension * self.polynomial_size
+
+
+class CudaLweKeyswitchKey:
+    @classmethod
+    def from_lwe_keyswitch_key(cls, h_ksk, input_key_lwe_dimension, output_key_lwe_dimension, decomp_base_log,
+                               decomp_level_count, streams):
+        self = cls()
+        self.input_key_lwe_dimension = int(input_key_lwe_dimension)
+        self.output_key_lwe_dimension = int(output_key_lwe_dimension)
+        self.decomp_base_log = int(decomp_base_log)
+        self.decomp_level_count = int(decomp_level_count)
+        h_ksk = np.ascontiguousarray(h_ksk, dtype=U64)
+        assert h_ksk.size == input_key_lwe_dimension * decomp_level_count * (output_key_lwe_dimension + 1)
+        self.d_vecs = [CudaVec.from_cpu_async(h_ksk, streams, i) for i in range(len(streams))]
+        self.d_vec = self.d_vecs[0]
+        return self
+
+
+def _trivial_indexes(count, streams):
+    return CudaVec.from_cpu_async(np.arange(count, dtype=U64), streams)
+
+
+def cuda_programmable_bootstrap_lwe_ciphertext(input, output, accumulator, lut_indexes, output_indexes,
+                                               input_indexes, bsk, streams, num_many_lut=1, lut_stride=0):
+    """gpu/algorithms/lwe_programmable_bootstrapping.rs:10-136 + gpu/ffi.rs:21-92
+    (scratch -> launch -> cleanup on streams.ptr[0])."""
+    assert input.lwe_dimension == bsk.input_lwe_dimension, (
+        f"Mismatched input LweDimension. LweCiphertext input LweDimension {input.lwe_dimension}. "
+        f"BootstrapKey input LweDimension {bsk.input_lwe_dimension}.")
+    assert output.lwe_dimension == bsk.output_lwe_dimension, (
+        f"Mismatched output LweDimension. LweCiphertext output LweDimension {output.lwe_dimension}. "
+        f"BootstrapKey output LweDimension {bsk.output_lwe_dimension}.")
+    assert accumulator.glwe_dimension == bsk.glwe_dimension, "Mismatched GlweSize"
+    assert accumulator.polynomial_size == bsk.polynomial_size, "Mismatched PolynomialSize"
+    num_samples = input.lwe_ciphertext_count
+    assert output.lwe_ciphertext_count >= num_samples * num_many_lut
+    lib = _lib()
+    buf = C.c_void_p()
+    s, g = streams.ptr[0], streams.gpu_indexes[0]
+    lib.scratch_cuda_programmable_bootstrap_64_async(
+        s, g, C.byref(buf), bsk.input_lwe_dimension, bsk.glwe_dimension, bsk.polynomial_size,
+        bsk.decomp_level_count, num_samples, True, 1 if bsk.ms_noise_reduction else 0)
+    launch = (lib.cuda_programmable_bootstrap_64_async if bsk.engine == "fft64"
+              else lib.hip_programmable_bootstrap_ntt64_async)
+    launch(s, g, output.d_vec.ptr, output_indexes.ptr, accumulator.d_vec.ptr, lut_indexes.ptr,
+           input.d_vec.ptr, input_indexes.ptr, bsk.d_vec.ptr, buf, bsk.input_lwe_dimension, bsk.glwe_dimension,
+           bsk.polynomial_size, bsk.decomp_base_log, bsk.decomp_level_count, num_samples, num_many_lut, lut_stride)
+    lib.cleanup_cuda_programmable_bootstrap_64(s, g, C.byref(buf))
+
+
+def cuda_multi_bit_programmable_bootstrap_lwe_ciphertext(input, output, accumulator, lut_indexes, output_indexes,
+                                                         input_indexes, multi_bit_bsk, streams):
+    """gpu/algorithms/lwe_multi_bit_programmable_bootstrapping.rs:10-145 + gpu/ffi.rs:208-309"""
+    bsk = multi_bit_bsk
+    assert input.lwe_dimension == bsk.input_lwe_dimension, "Mismatched input LweDimension"
+    assert output.lwe_dimension == bsk.output_lwe_dimension, "Mismatched output LweDimension"
+    assert accumulator.glwe_dimension == bsk.glwe_dimension, "Mismatched GlweSize"
+    assert accumulator.polynomial_size == bsk.polynomial_size, "Mismatched PolynomialSize"
+    num_samples = input.lwe_ciphertext_count
+    lib = _lib()
+    buf = C.c_void_p()
+    s, g = streams.ptr[0], streams.gpu_indexes[0]
+    lib.scratch_cuda_multi_bit_programmable_bootstrap_64_async(
+        s, g, C.byref(buf), bsk.glwe_dimension, bsk.polynomial_size, bsk.decomp_level_count, num_samples, True)
+    lib.cuda_multi_bit_programmable_bootstrap_64_async(
+        s, g, output.d_vec.ptr, output_indexes.ptr, accumulator.d_vec.ptr, lut_indexes.ptr, input.d_vec.ptr,
+        input_indexes.ptr, bsk.d_vec.ptr, buf, bsk.input_lwe_dimension, bsk.glwe_dimension, bsk.polynomial_size,
+        bsk.grouping_factor, bsk.decomp_base_log, bsk.decomp_level_count, num_samples, 1, 0)
+    lib.cleanup_cuda_multi_bit_programmable_bootstrap_64(s, g, C.byref(buf))
+
+
+def cuda_keyswitch_lwe_ciphertext(ksk, input, output, input_indexes, output_indexes, uses_trivial_indices,
+                                  streams, use_gemm_ks=False):
+    """gpu/algorithms/lwe_keyswitch.rs:12-143 + gpu/ffi.rs:503-618"""
+    assert ksk.input_key_lwe_dimension == input.lwe_dimension, (
+        f"Mismatched input LweDimension. LweKeyswitchKey input LweDimension: {ksk.input_key_lwe_dimension}, "
+        f"input LweCiphertext LweDimension {input.lwe_dimension}.")
+    assert ksk.output_key_lwe_dimension == output.lwe_dimension, (
+        f"Mismatched output LweDimension. LweKeyswitchKey output LweDimension: {ksk.output_key_lwe_dimension}, "
+        f"output LweCiphertext LweDimension {output.lwe_dimension}.")
+    lib = _lib()
+    s, g = streams.ptr[0], streams.gpu_indexes[0]
+    args = (s, g, output.d_vec.ptr, output_indexes.ptr, input.d_vec.ptr, input_indexes.ptr, ksk.d_vec.ptr,
+            ksk.input_key_lwe_dimension, ksk.output_key_lwe_dimension, ksk.decomp_base_log,
+            ksk.decomp_level_count, input.lwe_ciphertext_count)
+    if use_gemm_ks:
+        lib.cuda_keyswitch_gemm_64_64_async(*args, bool(uses_trivial_indices))
+    else:
+        lib.cuda_keyswitch_lwe_ciphertext_vector_64_64_async(*args)
+
+
+def cuda_extract_lwe_samples_from_glwe_ciphertext_list(input_glwe_list, output_lwe_list, vec_nth, lwe_per_glwe,
+                                                       streams):
+    """gpu/algorithms/glwe_sample_extraction.rs:12 + gpu/ffi.rs:838-883"""
+    nth = np.ascontiguousarray(vec_nth, dtype=np.uint32)
+    d_nth = CudaVec.from_cpu_async(nth, streams)
+    _lib().cuda_glwe_sample_extract_64_async(
+        streams.ptr[0], streams.gpu_indexes[0], output_lwe_list.d_vec.ptr, input_glwe_list.d_vec.ptr, d_nth.ptr,
+        nth.size, lwe_per_glwe, input_glwe_list.polynomial_size, input_glwe_list.glwe_dimension,
+        input_glwe_list.polynomial_size)
+    streams.synchronize()
+
+
+def cuda_modulus_switch_ciphertext(output_vec, input_vec, lwe_dimension, log_modulus, centered, streams):
+    """gpu/ffi.rs:885-898 (plain) / cuda_centered_modulus_switch_64_async (centered, one LWE)."""
+    s, g = streams.ptr[0], streams.gpu_indexes[0]
+    if centered:
+        _lib().cuda_centered_modulus_switch_64_async(s, g, output_vec.ptr, input_vec.ptr, lwe_dimension, log_modulus)
+    else:
+        _lib().cuda_modulus_switch_64_async(s, g, output_vec.ptr, input_vec.ptr, lwe_dimension + 1, log_modulus)
+
+
+def get_number_of_gpus():
+    return _lib().cuda_get_number_of_gpus()
+
+
+def is_cuda_available():
+    return bool(_lib().cuda_is_available())

@@ -1,0 +1,495 @@
+// abi.hip — extern "C" entry points of libtfhe_hip_backend.so (declared, with the reference
+// interface each one replaces, in include/tfhe_hip_backend.h).
+#include "../../include/tfhe_hip_backend.h"
+#include "kernels.h"
+
+#include <atomic>
+#include <cstring>
+
+using namespace tfhe_hip;
+
+namespace {
+inline hipStream_t S(void *stream) { return static_cast<hipStream_t>(stream); }
+inline void set_device(uint32_t gpu_index) { HX_CHECK(hipSetDevice((int)gpu_index)); }
+
+std::atomic<uint32_t> g_fft_kernel_choice{0};
+std::atomic<uint32_t> g_last_pbs_kernel{0};
+
+constexpr uint32_t kPbsMagic = 0x50425331;   // "PBS1"
+constexpr uint32_t kMbMagic = 0x4d425031;    // "MBP1"
+
+// Host-side descriptor behind the opaque `int8_t *buffer` of the scratch/cleanup triple
+// (the reference's pbs_buffer<Torus, CLASSICAL>, cuda/include/pbs/pbs_utilities.h:100-260).
+// The whole CMUX loop runs on-chip, so the classic PBS needs no global scratch at all.
+struct PbsBuffer {
+  uint32_t magic;
+  uint32_t lwe_dimension, glwe_dimension, polynomial_size, level_count, max_samples;
+  uint32_t ms_type;
+  bool gpu_memory_allocated;
+  FftTables fft;
+  NttTables ntt;
+};
+struct MultiBitBuffer {
+  uint32_t magic;
+  uint32_t glwe_dimension, polynomial_size, level_count, max_samples;
+  bool gpu_memory_allocated;
+  FftTables fft;
+  uint32_t chunk;
+  cplx *keybundle;
+  uint64_t *acc;
+};
+
+void check_pow2_poly(uint32_t N) {
+  HX_PANIC_IF_FALSE(N >= 256 && N <= 4096 && (N & (N - 1)) == 0,
+                    "polynomial_size %u not supported by the MI355X PBS (256..4096, power of two)", N);
+}
+
+PbsArgs make_args(void *lwe_array_out, void const *lwe_output_indexes, void const *lut_vector,
+                  void const *lut_vector_indexes, void const *lwe_array_in, void const *lwe_input_indexes,
+                  void const *bootstrapping_key, uint32_t lwe_dimension, uint32_t base_log, uint32_t level_count,
+                  uint32_t num_samples, uint32_t num_many_lut, uint32_t lut_stride, uint32_t ms_type) {
+  PbsArgs a;
+  a.lwe_out = (uint64_t *)lwe_array_out;
+  a.out_idx = (const uint64_t *)lwe_output_indexes;
+  a.lut = (const uint64_t *)lut_vector;
+  a.lut_idx = (const uint64_t *)lut_vector_indexes;
+  a.lwe_in = (const uint64_t *)lwe_array_in;
+  a.in_idx = (const uint64_t *)lwe_input_indexes;
+  a.bsk = bootstrapping_key;
+  a.n = lwe_dimension;
+  a.base_log = base_log;
+  a.level = level_count;
+  a.num_samples = num_samples;
+  a.num_many_lut = num_many_lut;
+  a.lut_stride = lut_stride;
+  a.ms_type = ms_type;
+  return a;
+}
+}  // namespace
+
+extern "C" {
+
+// =========================================================================== device runtime
+void *cuda_create_stream_ffi(uint32_t gpu_index) {
+  set_device(gpu_index);
+  hipStream_t s;
+  HX_CHECK(hipStreamCreate(&s));
+  return s;
+}
+void cuda_destroy_stream(void *stream, uint32_t gpu_index) {
+  set_device(gpu_index);
+  HX_CHECK(hipStreamDestroy(S(stream)));
+}
+void cuda_synchronize_stream(void *stream, uint32_t gpu_index) {
+  set_device(gpu_index);
+  HX_CHECK(hipStreamSynchronize(S(stream)));
+}
+uint32_t cuda_is_available(void) { return hipSetDevice(0) == hipSuccess; }
+void *cuda_malloc(uint64_t size, uint32_t gpu_index) {
+  set_device(gpu_index);
+  void *p = nullptr;
+  HX_CHECK(hipMalloc(&p, size));
+  return p;
+}
+void *cuda_malloc_async(uint64_t size, void *stream, uint32_t gpu_index) {
+  set_device(gpu_index);
+  void *p = nullptr;
+  HX_CHECK(hipMallocAsync(&p, size, S(stream)));
+  return p;
+}
+bool cuda_check_valid_malloc(uint64_t size, uint32_t gpu_index) {
+  set_device(gpu_index);
+  size_t free_mem = 0, total_mem = 0;
+  HX_CHECK(hipMemGetInfo(&free_mem, &total_mem));
+  return size <= free_mem;
+}
+uint64_t cuda_device_total_memory(uint32_t gpu_index) {
+  set_device(gpu_index);
+  size_t free_mem = 0, total_mem = 0;
+  HX_CHECK(hipMemGetInfo(&free_mem, &total_mem));
+  return total_mem;
+}
+void cuda_memcpy_async_to_gpu(void *dest, const void *src, uint64_t size, void *stream, uint32_t gpu_index) {
+  if (size == 0) return;
+  set_device(gpu_index);
+  HX_PANIC_IF_FALSE(dest != nullptr && src != nullptr, "memcpy to gpu: null pointer");
+  HX_CHECK(hipMemcpyAsync(dest, src, size, hipMemcpyHostToDevice, S(stream)));
+}
+void cuda_memcpy_async_gpu_to_gpu(void *dest, void const *src, uint64_t size, void *stream, uint32_t gpu_index) {
+  if (size == 0) return;
+  set_device(gpu_index);
+  HX_PANIC_IF_FALSE(dest != nullptr && src != nullptr, "memcpy gpu to gpu: null pointer");
+  HX_CHECK(hipMemcpyAsync(dest, src, size, hipMemcpyDeviceToDevice, S(stream)));
+}
+void cuda_memcpy_gpu_to_gpu(void *dest, void const *src, uint64_t size, uint32_t gpu_index) {
+  if (size == 0) return;
+  set_device(gpu_index);
+  HX_CHECK(hipMemcpy(dest, src, size, hipMemcpyDeviceToDevice));
+}
+void cuda_memcpy_async_to_cpu(void *dest, const void *src, uint64_t size, void *stream, uint32_t gpu_index) {
+  if (size == 0) return;
+  set_device(gpu_index);
+  HX_PANIC_IF_FALSE(dest != nullptr && src != nullptr, "memcpy to cpu: null pointer");
+  HX_CHECK(hipMemcpyAsync(dest, src, size, hipMemcpyDeviceToHost, S(stream)));
+}
+void cuda_memset_async(void *dest, uint64_t val, uint64_t size, void *stream, uint32_t gpu_index) {
+  if (size == 0) return;
+  set_device(gpu_index);
+  HX_CHECK(hipMemsetAsync(dest, (int)val, size, S(stream)));
+}
+int cuda_get_number_of_gpus(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+int cuda_get_number_of_sms(void) {
+  hipDeviceProp_t prop;
+  HX_CHECK(hipGetDeviceProperties(&prop, 0));
+  return prop.multiProcessorCount;  // compute units
+}
+void cuda_synchronize_device(uint32_t gpu_index) {
+  set_device(gpu_index);
+  HX_CHECK(hipDeviceSynchronize());
+}
+void cuda_drop(void *ptr, uint32_t gpu_index) {
+  set_device(gpu_index);
+  HX_CHECK(hipFree(ptr));
+}
+
+// =========================================================================== classic PBS
+static void convert_bsk_common(bool ntt, void *stream, uint32_t gpu_index, void *dest, void const *src,
+                               uint32_t input_lwe_dim, uint32_t glwe_dim, uint32_t level_count,
+                               uint32_t polynomial_size) {
+  set_device(gpu_index);
+  check_pow2_poly(polynomial_size);
+  HX_PANIC_IF_FALSE(dest != nullptr && src != nullptr, "bootstrap key conversion: null pointer");
+  const size_t polys = (size_t)input_lwe_dim * level_count * (glwe_dim + 1) * (glwe_dim + 1);
+  const size_t bytes = polys * polynomial_size * sizeof(uint64_t);
+  // stage the standard-domain key on the device, transform polynomial by polynomial
+  void *tmp = nullptr;
+  HX_CHECK(hipMalloc(&tmp, bytes));
+  HX_CHECK(hipMemcpyAsync(tmp, src, bytes, hipMemcpyHostToDevice, S(stream)));
+  if (ntt) {
+    const NttTables tb = get_ntt_tables(gpu_index, S(stream), polynomial_size);
+    launch_bsk_to_ntt(S(stream), polynomial_size, (const uint64_t *)tmp, dest, polys, tb);
+  } else {
+    const FftTables tb = get_fft_tables(gpu_index, S(stream), polynomial_size);
+    launch_bsk_to_fourier(S(stream), polynomial_size, (const uint64_t *)tmp, dest, polys, tb);
+  }
+  // the staging buffer must outlive the kernel: release it once the stream reaches here
+  HX_CHECK(hipStreamSynchronize(S(stream)));
+  HX_CHECK(hipFree(tmp));
+}
+
+void cuda_convert_lwe_programmable_bootstrap_key_64_async(void *stream, uint32_t gpu_index, void *dest,
+                                                          void const *src, uint32_t input_lwe_dim,
+                                                          uint32_t glwe_dim, uint32_t level_count,
+                                                          uint32_t polynomial_size) {
+  convert_bsk_common(false, stream, gpu_index, dest, src, input_lwe_dim, glwe_dim, level_count, polynomial_size);
+}
+void hip_convert_lwe_programmable_bootstrap_key_ntt64_async(void *stream, uint32_t gpu_index, void *dest,
+                                                            void const *src, uint32_t input_lwe_dim,
+                                                            uint32_t glwe_dim, uint32_t level_count,
+                                                            uint32_t polynomial_size) {
+  convert_bsk_common(true, stream, gpu_index, dest, src, input_lwe_dim, glwe_dim, level_count, polynomial_size);
+}
+
+uint64_t scratch_cuda_programmable_bootstrap_64_async(void *stream, uint32_t gpu_index, int8_t **buffer,
+                                                      uint32_t lwe_dimension, uint32_t glwe_dimension,
+                                                      uint32_t polynomial_size, uint32_t level_count,
+                                                      uint32_t input_lwe_ciphertext_count, bool allocate_gpu_memory,
+                                                      enum PBS_MS_REDUCTION_T noise_reduction_type) {
+  set_device(gpu_index);
+  check_pow2_poly(polynomial_size);
+  HX_PANIC_IF_FALSE(glwe_dimension >= 1 && glwe_dimension <= 3, "glwe_dimension %u not supported", glwe_dimension);
+  auto *b = new PbsBuffer();
+  b->magic = kPbsMagic;
+  b->lwe_dimension = lwe_dimension;
+  b->glwe_dimension = glwe_dimension;
+  b->polynomial_size = polynomial_size;
+  b->level_count = level_count;
+  b->max_samples = input_lwe_ciphertext_count;
+  b->ms_type = (uint32_t)noise_reduction_type;
+  b->gpu_memory_allocated = allocate_gpu_memory;
+  if (allocate_gpu_memory) {
+    // constant tables are built here (not in the launch) so the launch stays capture-safe
+    b->fft = get_fft_tables(gpu_index, S(stream), polynomial_size);
+    b->ntt = get_ntt_tables(gpu_index, S(stream), polynomial_size);
+  }
+  *buffer = reinterpret_cast<int8_t *>(b);
+  return 0;  // bytes of device scratch: the accumulator never leaves the chip
+}
+
+static PbsBuffer *checked_buffer(int8_t *buffer, uint32_t lwe_dimension, uint32_t glwe_dimension,
+                                 uint32_t polynomial_size, uint32_t level_count, uint32_t num_samples) {
+  auto *b = reinterpret_cast<PbsBuffer *>(buffer);
+  HX_PANIC_IF_FALSE(b != nullptr && b->magic == kPbsMagic, "PBS buffer was not created by scratch_cuda_programmable_bootstrap_64_async");
+  HX_PANIC_IF_FALSE(b->gpu_memory_allocated, "PBS buffer was created with allocate_gpu_memory=false");
+  HX_PANIC_IF_FALSE(b->lwe_dimension == lwe_dimension && b->glwe_dimension == glwe_dimension &&
+                        b->polynomial_size == polynomial_size && b->level_count == level_count,
+                    "PBS buffer parameters do not match the call");
+  HX_PANIC_IF_FALSE(num_samples <= b->max_samples, "num_samples %u exceeds the scratch capacity %u", num_samples,
+                    b->max_samples);
+  return b;
+}
+
+void cuda_programmable_bootstrap_64_async(void *stream, uint32_t gpu_index, void *lwe_array_out,
+                                          void const *lwe_output_indexes, void const *lut_vector,
+                                          void const *lut_vector_indexes, void const *lwe_array_in,
+                                          void const *lwe_input_indexes, void const *bootstrapping_key,
+                                          int8_t *buffer, uint32_t lwe_dimension, uint32_t glwe_dimension,
+                                          uint32_t polynomial_size, uint32_t base_log, uint32_t level_count,
+                                          uint32_t num_samples, uint32_t num_many_lut, uint32_t lut_stride) {
+  set_device(gpu_index);
+  PbsBuffer *b = checked_buffer(buffer, lwe_dimension, glwe_dimension, polynomial_size, level_count, num_samples);
+  HX_PANIC_IF_FALSE(base_log >= 1 && base_log * level_count < 64, "invalid decomposition (base_log=%u, level=%u)",
+                    base_log, level_count);
+  HX_PANIC_IF_FALSE(num_many_lut >= 1, "num_many_lut must be >= 1");
+  if (num_samples == 0) return;
+  const PbsArgs a = make_args(lwe_array_out, lwe_output_indexes, lut_vector, lut_vector_indexes, lwe_array_in,
+                              lwe_input_indexes, bootstrapping_key, lwe_dimension, base_log, level_count,
+                              num_samples, num_many_lut, lut_stride, b->ms_type);
+  const uint32_t choice = g_fft_kernel_choice.load();
+  const bool wave_ok = pbs_fft_wave_supported(polynomial_size, glwe_dimension, level_count) && base_log <= 31;
+  if (choice == 2) HX_PANIC_IF_FALSE(wave_ok, "throughput kernel requested for an unsupported parameter set");
+  if ((choice == 0 && wave_ok) || choice == 2) {
+    launch_pbs_fft_wave(S(stream), a, b->fft);
+    g_last_pbs_kernel.store(2);
+  } else {
+    launch_pbs_fft_generic(S(stream), polynomial_size, glwe_dimension, a, b->fft);
+    g_last_pbs_kernel.store(1);
+  }
+}
+
+void hip_programmable_bootstrap_ntt64_async(void *stream, uint32_t gpu_index, void *lwe_array_out,
+                                            void const *lwe_output_indexes, void const *lut_vector,
+                                            void const *lut_vector_indexes, void const *lwe_array_in,
+                                            void const *lwe_input_indexes, void const *bootstrapping_key,
+                                            int8_t *buffer, uint32_t lwe_dimension, uint32_t glwe_dimension,
+                                            uint32_t polynomial_size, uint32_t base_log, uint32_t level_count,
+                                            uint32_t num_samples, uint32_t num_many_lut, uint32_t lut_stride) {
+  set_device(gpu_index);
+  PbsBuffer *b = checked_buffer(buffer, lwe_dimension, glwe_dimension, polynomial_size, level_count, num_samples);
+  HX_PANIC_IF_FALSE(base_log >= 1 && base_log * level_count < 64, "invalid decomposition (base_log=%u, level=%u)",
+                    base_log, level_count);
+  if (num_samples == 0) return;
+  const PbsArgs a = make_args(lwe_array_out, lwe_output_indexes, lut_vector, lut_vector_indexes, lwe_array_in,
+                              lwe_input_indexes, bootstrapping_key, lwe_dimension, base_log, level_count,
+                              num_samples, num_many_lut, lut_stride, b->ms_type);
+  launch_pbs_ntt_generic(S(stream), polynomial_size, glwe_dimension, a, b->ntt);
+  g_last_pbs_kernel.store(3);
+}
+
+void cleanup_cuda_programmable_bootstrap_64(void *stream, uint32_t gpu_index, int8_t **pbs_buffer) {
+  set_device(gpu_index);
+  auto *b = reinterpret_cast<PbsBuffer *>(*pbs_buffer);
+  HX_PANIC_IF_FALSE(b != nullptr && b->magic == kPbsMagic, "cleanup of a foreign PBS buffer");
+  HX_CHECK(hipStreamSynchronize(S(stream)));  // cleanup_* synchronises (pbs_utilities.h:261-271)
+  b->magic = 0;
+  delete b;
+  *pbs_buffer = nullptr;
+}
+
+// =========================================================================== multi-bit PBS
+bool has_support_to_cuda_programmable_bootstrap_cg_multi_bit(uint32_t, uint32_t, uint32_t, uint32_t, uint32_t) {
+  return false;  // no cooperative-groups variant: one persistent launch per group step is used instead
+}
+
+void cuda_convert_lwe_multi_bit_programmable_bootstrap_key_64_async(void *stream, uint32_t gpu_index, void *dest,
+                                                                    void const *src, uint32_t input_lwe_dim,
+                                                                    uint32_t glwe_dim, uint32_t level_count,
+                                                                    uint32_t polynomial_size,
+                                                                    uint32_t grouping_factor) {
+  // The multi-bit key stays in the standard (u64) domain on the device, like the reference
+  // backend (cuda/src/pbs/bootstrapping_key.cu:78-93); the layout is the host layout.
+  set_device(gpu_index);
+  HX_PANIC_IF_FALSE(grouping_factor >= 1 && input_lwe_dim % grouping_factor == 0,
+                    "input_lwe_dim %u not a multiple of grouping_factor %u", input_lwe_dim, grouping_factor);
+  const size_t elems = (size_t)(input_lwe_dim / grouping_factor) * ((size_t)1 << grouping_factor) * level_count *
+                       (glwe_dim + 1) * (glwe_dim + 1) * polynomial_size;
+  HX_CHECK(hipMemcpyAsync(dest, src, elems * sizeof(uint64_t), hipMemcpyHostToDevice, S(stream)));
+}
+
+uint64_t scratch_cuda_multi_bit_programmable_bootstrap_64_async(void *stream, uint32_t gpu_index,
+                                                                int8_t **pbs_buffer, uint32_t glwe_dimension,
+                                                                uint32_t polynomial_size, uint32_t level_count,
+                                                                uint32_t input_lwe_ciphertext_count,
+                                                                bool allocate_gpu_memory) {
+  set_device(gpu_index);
+  check_pow2_poly(polynomial_size);
+  auto *b = new MultiBitBuffer();
+  b->magic = kMbMagic;
+  b->glwe_dimension = glwe_dimension;
+  b->polynomial_size = polynomial_size;
+  b->level_count = level_count;
+  b->max_samples = input_lwe_ciphertext_count;
+  b->gpu_memory_allocated = allocate_gpu_memory;
+  b->keybundle = nullptr;
+  b->acc = nullptr;
+  const size_t k1 = glwe_dimension + 1;
+  const size_t kb_per_sample = (size_t)level_count * k1 * k1 * (polynomial_size / 2) * sizeof(cplx);
+  const size_t acc_per_sample = 2 * k1 * polynomial_size * sizeof(uint64_t);
+  b->chunk = input_lwe_ciphertext_count ? input_lwe_ciphertext_count : 1;
+  const uint64_t bytes = (uint64_t)b->chunk * (kb_per_sample + acc_per_sample);
+  if (allocate_gpu_memory) {
+    b->fft = get_fft_tables(gpu_index, S(stream), polynomial_size);
+    HX_CHECK(hipMalloc((void **)&b->keybundle, (size_t)b->chunk * kb_per_sample));
+    HX_CHECK(hipMalloc((void **)&b->acc, (size_t)b->chunk * acc_per_sample));
+  }
+  *pbs_buffer = reinterpret_cast<int8_t *>(b);
+  return bytes;
+}
+
+void cuda_multi_bit_programmable_bootstrap_64_async(void *stream, uint32_t gpu_index, void *lwe_array_out,
+                                                    void const *lwe_output_indexes, void const *lut_vector,
+                                                    void const *lut_vector_indexes, void const *lwe_array_in,
+                                                    void const *lwe_input_indexes, void const *bootstrapping_key,
+                                                    int8_t *buffer, uint32_t lwe_dimension, uint32_t glwe_dimension,
+                                                    uint32_t polynomial_size, uint32_t grouping_factor,
+                                                    uint32_t base_log, uint32_t level_count, uint32_t num_samples,
+                                                    uint32_t num_many_lut, uint32_t lut_stride) {
+  set_device(gpu_index);
+  auto *b = reinterpret_cast<MultiBitBuffer *>(buffer);
+  HX_PANIC_IF_FALSE(b != nullptr && b->magic == kMbMagic, "multi-bit PBS buffer was not created by its scratch function");
+  HX_PANIC_IF_FALSE(b->gpu_memory_allocated, "multi-bit PBS buffer was created with allocate_gpu_memory=false");
+  HX_PANIC_IF_FALSE(b->glwe_dimension == glwe_dimension && b->polynomial_size == polynomial_size &&
+                        b->level_count == level_count && num_samples <= b->max_samples,
+                    "multi-bit PBS buffer parameters do not match the call");
+  HX_PANIC_IF_FALSE(grouping_factor >= 1 && grouping_factor <= 4 && lwe_dimension % grouping_factor == 0,
+                    "unsupported grouping_factor %u for lwe_dimension %u", grouping_factor, lwe_dimension);
+  if (num_samples == 0) return;
+  MultiBitArgs m;
+  m.pbs = make_args(lwe_array_out, lwe_output_indexes, lut_vector, lut_vector_indexes, lwe_array_in,
+                    lwe_input_indexes, bootstrapping_key, lwe_dimension, base_log, level_count, num_samples,
+                    num_many_lut, lut_stride, 0);
+  m.grouping_factor = grouping_factor;
+  m.keybundle = b->keybundle;
+  m.chunk = b->chunk;
+  launch_pbs_multi_bit(S(stream), polynomial_size, glwe_dimension, m, b->fft, b->acc);
+  g_last_pbs_kernel.store(4);
+}
+
+void cleanup_cuda_multi_bit_programmable_bootstrap_64(void *stream, uint32_t gpu_index, int8_t **pbs_buffer) {
+  set_device(gpu_index);
+  auto *b = reinterpret_cast<MultiBitBuffer *>(*pbs_buffer);
+  HX_PANIC_IF_FALSE(b != nullptr && b->magic == kMbMagic, "cleanup of a foreign multi-bit PBS buffer");
+  HX_CHECK(hipStreamSynchronize(S(stream)));
+  if (b->keybundle) HX_CHECK(hipFree(b->keybundle));
+  if (b->acc) HX_CHECK(hipFree(b->acc));
+  b->magic = 0;
+  delete b;
+  *pbs_buffer = nullptr;
+}
+
+// =========================================================================== keyswitch
+void cuda_keyswitch_lwe_ciphertext_vector_64_64_async(void *stream, uint32_t gpu_index, void *lwe_array_out,
+                                                      void const *lwe_output_indexes, void const *lwe_array_in,
+                                                      void const *lwe_input_indexes, void const *ksk,
+                                                      uint32_t lwe_dimension_in, uint32_t lwe_dimension_out,
+                                                      uint32_t base_log, uint32_t level_count,
+                                                      uint32_t num_samples) {
+  set_device(gpu_index);
+  launch_keyswitch(S(stream), (uint64_t *)lwe_array_out, (const uint64_t *)lwe_output_indexes,
+                   (const uint64_t *)lwe_array_in, (const uint64_t *)lwe_input_indexes, (const uint64_t *)ksk,
+                   lwe_dimension_in, lwe_dimension_out, base_log, level_count, num_samples);
+}
+void cuda_keyswitch_gemm_64_64_async(void *stream, uint32_t gpu_index, void *lwe_array_out,
+                                     void const *lwe_output_indexes, void const *lwe_array_in,
+                                     void const *lwe_input_indexes, void const *ksk, uint32_t lwe_dimension_in,
+                                     uint32_t lwe_dimension_out, uint32_t base_log, uint32_t level_count,
+                                     uint32_t num_samples, bool uses_trivial_indexes) {
+  // one tiled kernel serves both entry points (it already reuses each key row across a tile
+  // of samples); indexes are honoured whether trivial or not
+  (void)uses_trivial_indexes;
+  cuda_keyswitch_lwe_ciphertext_vector_64_64_async(stream, gpu_index, lwe_array_out, lwe_output_indexes,
+                                                   lwe_array_in, lwe_input_indexes, ksk, lwe_dimension_in,
+                                                   lwe_dimension_out, base_log, level_count, num_samples);
+}
+void cuda_closest_representable_64_async(void *stream, uint32_t gpu_index, void const *input, void *output,
+                                         uint32_t base_log, uint32_t level_count) {
+  set_device(gpu_index);
+  launch_closest_representable(S(stream), (const uint64_t *)input, (uint64_t *)output, base_log, level_count);
+}
+
+// =========================================================================== ciphertext helpers
+void cuda_convert_lwe_ciphertext_vector_to_gpu_64_async(void *stream, uint32_t gpu_index, void *dest,
+                                                        void const *src, uint32_t number_of_cts,
+                                                        uint32_t lwe_dimension) {
+  cuda_memcpy_async_to_gpu(dest, src, (uint64_t)number_of_cts * (lwe_dimension + 1) * sizeof(uint64_t), stream,
+                           gpu_index);
+}
+void cuda_convert_lwe_ciphertext_vector_to_cpu_64_async(void *stream, uint32_t gpu_index, void *dest,
+                                                        void const *src, uint32_t number_of_cts,
+                                                        uint32_t lwe_dimension) {
+  cuda_memcpy_async_to_cpu(dest, src, (uint64_t)number_of_cts * (lwe_dimension + 1) * sizeof(uint64_t), stream,
+                           gpu_index);
+}
+void cuda_glwe_sample_extract_64_async(void *stream, uint32_t gpu_index, void *lwe_array_out,
+                                       void const *glwe_array_in, uint32_t const *nth_array, uint32_t num_nths,
+                                       uint32_t num_lwes_to_extract_per_glwe, uint32_t num_lwes_stored_per_glwe,
+                                       uint32_t glwe_dimension, uint32_t polynomial_size) {
+  set_device(gpu_index);
+  launch_sample_extract(S(stream), (uint64_t *)lwe_array_out, (const uint64_t *)glwe_array_in, nth_array, num_nths,
+                        num_lwes_to_extract_per_glwe, num_lwes_stored_per_glwe, glwe_dimension, polynomial_size);
+}
+void cuda_modulus_switch_inplace_64_async(void *stream, uint32_t gpu_index, void *lwe_array_out, uint32_t size,
+                                          uint32_t log_modulus) {
+  set_device(gpu_index);
+  launch_modulus_switch(S(stream), (uint64_t *)lwe_array_out, (const uint64_t *)lwe_array_out, size, log_modulus);
+}
+void cuda_modulus_switch_64_async(void *stream, uint32_t gpu_index, void *lwe_out, const void *lwe_in, uint32_t size,
+                                  uint32_t log_modulus) {
+  set_device(gpu_index);
+  HX_PANIC_IF_FALSE(lwe_out != lwe_in, "Output and input pointers must be different for out-of-place operations");
+  launch_modulus_switch(S(stream), (uint64_t *)lwe_out, (const uint64_t *)lwe_in, size, log_modulus);
+}
+void cuda_centered_modulus_switch_64_async(void *stream, uint32_t gpu_index, void *lwe_out, const void *lwe_in,
+                                           uint32_t lwe_dimension, uint32_t log_modulus) {
+  set_device(gpu_index);
+  HX_PANIC_IF_FALSE(lwe_out != lwe_in, "Output and input pointers must be different for out-of-place operations");
+  launch_centered_modulus_switch(S(stream), (uint64_t *)lwe_out, (const uint64_t *)lwe_in, lwe_dimension,
+                                 log_modulus);
+}
+
+// =========================================================================== extensions
+void hip_backend_set_fft_kernel(uint32_t which) { g_fft_kernel_choice.store(which); }
+uint32_t hip_backend_last_pbs_kernel(void) { return g_last_pbs_kernel.load(); }
+const char *hip_backend_version(void) {
+#if defined(TFHE_HIPEMU)
+  return "tfhe-hip-backend 0.1 (HOST EMULATION - test build, not a product)";
+#else
+  return "tfhe-hip-backend 0.1 (gfx950)";
+#endif
+}
+// HIP events on the caller's stream: bench.py times the kernels with these (torch.cuda.Event
+// only sees torch's current stream).
+void *hip_event_create(void) {
+  hipEvent_t e;
+  HX_CHECK(hipEventCreate(&e));
+  return e;
+}
+void hip_event_record(void *event, void *stream) { HX_CHECK(hipEventRecord((hipEvent_t)event, S(stream))); }
+float hip_event_elapsed_ms(void *start, void *stop) {
+  float ms = 0.f;
+  HX_CHECK(hipEventSynchronize((hipEvent_t)stop));
+  HX_CHECK(hipEventElapsedTime(&ms, (hipEvent_t)start, (hipEvent_t)stop));
+  return ms;
+}
+void hip_event_destroy(void *event) { HX_CHECK(hipEventDestroy((hipEvent_t)event)); }
+
+void hip_test_arith_async(void *stream, uint32_t gpu_index, uint32_t op, void const *in, void *out, uint32_t count,
+                          uint32_t p0, uint32_t p1) {
+  set_device(gpu_index);
+  launch_test_arith(S(stream), op, (const uint64_t *)in, (uint64_t *)out, count, p0, p1);
+}
+void hip_test_transform_async(void *stream, uint32_t gpu_index, uint32_t op, uint32_t polynomial_size,
+                              void const *in, void *out) {
+  set_device(gpu_index);
+  check_pow2_poly(polynomial_size);
+  launch_test_transform(S(stream), op, polynomial_size, in, out, gpu_index);
+}
+void hip_test_fft_tables_host(uint32_t polynomial_size, double *fwd, double *inv, double *untwist) {
+  fill_fft_tables_host(polynomial_size, fwd, inv, untwist);
+}
+
+}  // extern "C"

@@ -1,0 +1,194 @@
+// arith.h — device-side torus / decomposer / transform arithmetic of the PBS hot path.
+//
+// Each function states the tfhe-rs routine whose semantics it implements ("cc/" =
+// tfhe/src/core_crypto/).  All integer work is exact u64 wrapping arithmetic; the f64
+// pieces follow the fixed operation order of DESIGN.md §4 (explicit fma, compiled with
+// -ffp-contract=off) so results do not depend on the kernel's stage grouping.
+#pragma once
+#include "hx.h"
+
+namespace tfhe_hip {
+
+// usable from host code too (table generation)
+#define HX_HD __host__ __device__ __forceinline__
+HX_HD uint64_t mulhi64(uint64_t a, uint64_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __umul64hi(a, b);
+#else
+  return (uint64_t)(((unsigned __int128)a * b) >> 64);
+#endif
+}
+
+// ------------------------------------------------------------------ modulus switch
+// cc/fft_impl/common.rs:10-23
+HX_DEV uint64_t modulus_switch(uint64_t x, uint32_t log_modulus) {
+  uint64_t t = x + (1ull << (64 - log_modulus - 1));
+  return t >> (64 - log_modulus);
+}
+
+// per-mask-element terms of cc/algorithms/modulus_switch.rs:57-103; the caller sums
+// `half` (wrapping u64) and `halving_doubled` (i64) over the mask — integer sums, so any
+// reduction order is exact.
+HX_DEV void centered_ms_terms(uint64_t a, uint32_t log_modulus, uint64_t &half, int64_t &halving_doubled) {
+  uint64_t rounded = modulus_switch(a, log_modulus) << (64 - log_modulus);
+  int64_t err = (int64_t)(rounded - a);
+  int64_t h = err / 2;  // truncation toward zero
+  half = (uint64_t)h;
+  halving_doubled = 2 * h - err;
+}
+HX_DEV uint64_t centered_ms_finish(uint64_t sum_half, int64_t sum_halving_doubled, uint32_t log_modulus) {
+  uint64_t sum_halving = (uint64_t)(sum_halving_doubled / 2);
+  return sum_half - sum_halving - (1ull << (64 - log_modulus - 1));
+}
+
+// ------------------------------------------------------------------ signed decomposer
+// cc/commons/math/decomposition/decomposer.rs:156-185
+HX_DEV uint64_t decomp_init_state(uint64_t x, uint32_t base_log, uint32_t level) {
+  const uint32_t rep = base_log * level;
+  uint64_t res = x >> (64 - rep - 1);
+  const uint64_t rounding_bit = res & 1;
+  res += 1;
+  res >>= 1;
+  res &= ~0ull >> (64 - rep);
+  const uint64_t need_balance = (((res - 1) | (rounding_bit << (rep - 1))) & res) >> (rep - 1);
+  return res - (need_balance << rep);
+}
+// cc/commons/math/decomposition/iter.rs:122-151
+HX_DEV int64_t decompose_one_level(uint32_t base_log, uint64_t &state) {
+  const uint64_t res = state & ((1ull << base_log) - 1);
+  state = (uint64_t)((int64_t)state >> base_log);
+  const uint64_t carry = (((res - 1) | state) & res) >> (base_log - 1);
+  state += carry;
+  return (int64_t)(res - (carry << base_log));
+}
+// digit of level-matrix index `idx` (idx 0 <-> level l): run the iterator idx+1 times
+HX_DEV int64_t decomp_digit(uint64_t x, uint32_t base_log, uint32_t level, uint32_t idx) {
+  uint64_t st = decomp_init_state(x, base_log, level);
+  int64_t d = 0;
+  for (uint32_t t = 0; t <= idx; ++t) d = decompose_one_level(base_log, st);
+  return d;
+}
+
+// ------------------------------------------------------------------ monomial indexing
+// coefficient j of  in * X^{deg}  (negacyclic), cc/algorithms/polynomial_algorithms.rs:662-727:
+// returns the source index and whether the source is negated.
+HX_DEV uint32_t monomial_mul_src(uint32_t j, uint32_t deg, uint32_t N, bool &neg) {
+  const uint32_t r = deg & (N - 1);
+  const bool odd = (deg & N) != 0;  // deg < 2N
+  if (j < r) { neg = !odd; return N - r + j; }
+  neg = odd;
+  return j - r;
+}
+// coefficient j of  in * X^{-deg}, cc/algorithms/polynomial_algorithms.rs:544-583
+HX_DEV uint32_t monomial_div_src(uint32_t j, uint32_t deg, uint32_t N, bool &neg) {
+  const uint32_t r = deg & (N - 1);
+  const bool odd = (deg & N) != 0;
+  if (j < N - r) { neg = odd; return j + r; }
+  neg = !odd;
+  return j - (N - r);
+}
+
+// ------------------------------------------------------------------ f64 conversions
+// exact i64 -> f64 (round to nearest even): hi*2^32 is exact, one rounding in the fma
+HX_DEV double i64_to_f64(int64_t v) {
+  const int32_t hi = (int32_t)(v >> 32);
+  const uint32_t lo = (uint32_t)v;
+  return fma((double)hi, 4294967296.0, (double)lo);
+}
+// integer-valued double in [-2^63, 2^63] -> i64; +2^63 folds onto -2^63 (two's complement
+// torus value, the reference's SIMD conversion semantics, fft/x86.rs:1030-1112)
+HX_DEV int64_t f64_to_i64_sat(double x) {
+  if (x >= 9223372036854775808.0) return INT64_MIN;
+  if (x <= -9223372036854775808.0) return INT64_MIN;
+  return (int64_t)x;
+}
+// cc/commons/math/torus/mod.rs:73-79 (FromTorus) with nearest-even rounding
+HX_DEV uint64_t from_torus(double t) {
+  double f = t - rint(t);
+  f = f * 18446744073709551616.0;
+  f = rint(f);
+  return (uint64_t)f64_to_i64_sat(f);
+}
+
+struct cplx {
+  double re, im;
+};
+
+// DESIGN.md §4 butterfly: (a, b) -> (a + s*b, 2a - (a + s*b))
+HX_DEV void bfly(cplx &a, cplx &b, const cplx s) {
+  const double o1r = fma(-b.im, s.im, fma(b.re, s.re, a.re));
+  const double o1i = fma(b.im, s.re, fma(b.re, s.im, a.im));
+  b.re = fma(2.0, a.re, -o1r);
+  b.im = fma(2.0, a.im, -o1i);
+  a.re = o1r;
+  a.im = o1i;
+}
+// first MAC term / following MAC terms, cc/fft_impl/fft64/crypto/ggsw.rs:652-676
+HX_DEV cplx cmul_first(const cplx x, const cplx y) {
+  return cplx{fma(-x.im, y.im, x.re * y.re), fma(x.im, y.re, x.re * y.im)};
+}
+HX_DEV cplx cmul_add(const cplx x, const cplx y, const cplx acc) {
+  return cplx{fma(-x.im, y.im, fma(x.re, y.re, acc.re)), fma(x.im, y.re, fma(x.re, y.im, acc.im))};
+}
+
+// ------------------------------------------------------------------ Goldilocks field
+// p = 2^64 - 2^32 + 1, tfhe-ntt/src/prime64/generic_solinas.rs:77-129 (fully reduced)
+static constexpr uint64_t GL_P = 0xFFFFFFFF00000001ull;
+
+HX_HD uint64_t gl_add(uint64_t a, uint64_t b) {
+  const uint64_t neg_b = GL_P - b;
+  return a >= neg_b ? a - neg_b : a + b;
+}
+HX_HD uint64_t gl_sub(uint64_t a, uint64_t b) { return a >= b ? a - b : a + (GL_P - b); }
+HX_HD uint64_t gl_mul(uint64_t a, uint64_t b) {
+  const uint64_t lo = a * b;
+  uint64_t hi = mulhi64(a, b);
+  const uint64_t mid = hi & 0xFFFFFFFFull;
+  hi >>= 32;
+  uint64_t low2 = lo - hi;
+  if (hi > lo) low2 += GL_P;
+  const uint64_t product = (mid << 32) - mid;
+  uint64_t result = low2 + product;
+  if (result < product || result >= GL_P) result -= GL_P;
+  return result;
+}
+// cc/commons/math/ntt/ntt64.rs:144-160, width 64:  (x*p + 2^63) >> 64
+HX_HD uint64_t gl_modswitch_from_pow2(uint64_t x) {
+  const uint64_t lo = x * GL_P;
+  const uint64_t hi = mulhi64(x, GL_P);
+  const uint64_t s = lo + (1ull << 63);
+  return hi + (s < lo ? 1 : 0);
+}
+// cc/commons/math/ntt/ntt64.rs:162-177, width 64:  floor((v*2^64 + (p>>1)) / p), v < p.
+// Division-free: with e = 2^32-1 (p = 2^64 - e), v*2^64 = v*p + v*e, so
+//   q = v + floor(w / p),  w = v*e + (p>>1) < 2^97;  w = wh*2^64 + wl = wh*p + (wh*e + wl)
+//   => floor(w/p) = wh + floor(r/p), r = wh*e + wl < 3*2^64  (wh < 2^33).
+HX_HD uint64_t gl_modswitch_to_pow2(uint64_t v) {
+  const uint64_t e = 0xFFFFFFFFull;
+  const uint64_t h = GL_P >> 1;
+  // w = v*e + h  (128-bit)
+  uint64_t wl = v * e;
+  uint64_t wh = mulhi64(v, e);
+  const uint64_t t = wl + h;
+  wh += (t < wl) ? 1 : 0;
+  wl = t;
+  // r = wh*e + wl  (up to 66 bits): rh:rl
+  const uint64_t m = wh * e;  // wh < 2^33, e < 2^32 -> < 2^65: may overflow 64 bits
+  const uint64_t mh = mulhi64(wh, e);
+  uint64_t rl = m + wl;
+  uint64_t rh = mh + ((rl < m) ? 1 : 0);
+  // q2 = floor(r / p), r < 3*2^64 -> q2 in 0..3 ; subtract p while r >= p
+  uint64_t q2 = 0;
+  for (int it = 0; it < 4; ++it) {
+    const bool ge = (rh > 0) || (rl >= GL_P);
+    if (ge) {
+      const uint64_t nl = rl - GL_P;
+      rh -= (rl < GL_P) ? 1 : 0;
+      rl = nl;
+      ++q2;
+    }
+  }
+  return v + wh + q2;
+}
+
+}  // namespace tfhe_hip

@@ -1,0 +1,68 @@
+// ciphertext.hip — stand-alone modulus switch / sample extraction helpers of the boundary
+// (backends/tfhe-cuda-backend/cuda/include/ciphertext.h; used by tests and by callers that
+// run the PBS stages separately).
+#include "kernels.h"
+
+namespace tfhe_hip {
+
+// cc/fft_impl/common.rs:10-23 applied element-wise (cuda/src/crypto/torus.cuh:133-147)
+__global__ void modulus_switch_kernel(uint64_t *out, const uint64_t *in, uint32_t size, uint32_t log_modulus) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < size) out[i] = modulus_switch(in[i], log_modulus);
+}
+
+// one LWE: mask with the plain switch, body with the centered-mean correction
+// (cc/algorithms/modulus_switch.rs:35-103; cuda/src/crypto/torus.cuh:364-433)
+__global__ void __launch_bounds__(256) centered_modulus_switch_kernel(uint64_t *out, const uint64_t *in,
+                                                                     uint32_t lwe_dim, uint32_t log_modulus) {
+  HX_DYN_SMEM(smem);
+  const int tid = threadIdx.x;
+  const uint32_t b = block_body_modulus_switch<256>(in, lwe_dim, log_modulus, 1, (uint64_t *)smem, tid);
+  if (tid == 0) out[lwe_dim] = b;
+  for (uint32_t i = tid; i < lwe_dim; i += 256) out[i] = modulus_switch(in[i], log_modulus);
+}
+
+// cc/algorithms/glwe_sample_extraction.rs:89-164 ; indexing of cuda/src/crypto/ciphertext.cuh:32-54
+__global__ void sample_extract_kernel(uint64_t *lwe_out, const uint64_t *glwe_in, const uint32_t *nth_array,
+                                      uint32_t lwe_per_glwe, uint32_t stored_per_glwe, uint32_t glwe_dim, uint32_t N) {
+  const uint32_t id = blockIdx.x;
+  const size_t glwe_sz = (size_t)(glwe_dim + 1) * N, lwe_sz = (size_t)glwe_dim * N + 1;
+  uint64_t *out = lwe_out + id * lwe_sz;
+  const uint64_t *g = glwe_in + (size_t)(id / lwe_per_glwe) * glwe_sz;
+  const uint32_t nth = nth_array[id] % stored_per_glwe;
+  for (uint32_t p = 0; p < glwe_dim; ++p)
+    for (uint32_t j = threadIdx.x; j < N; j += blockDim.x)
+      out[(size_t)p * N + j] = (j <= nth) ? g[(size_t)p * N + nth - j] : (uint64_t)0 - g[(size_t)p * N + N + nth - j];
+  if (threadIdx.x == 0) out[(size_t)glwe_dim * N] = g[(size_t)glwe_dim * N + nth];
+}
+
+// cc/commons/math/decomposition/decomposer.rs:25-50 on one value
+__global__ void closest_representable_kernel(const uint64_t *in, uint64_t *out, uint32_t base_log, uint32_t level) {
+  const uint32_t shift = 64 - base_log * level - 1;
+  uint64_t res = in[0] >> shift;
+  res += 1;
+  res &= ~1ull;
+  out[0] = res << shift;
+}
+
+void launch_modulus_switch(hipStream_t st, uint64_t *out, const uint64_t *in, uint32_t size, uint32_t log_modulus) {
+  if (!size) return;
+  HX_LAUNCH(modulus_switch_kernel, dim3((size + 255) / 256), dim3(256), 0, st, out, in, size, log_modulus);
+}
+void launch_centered_modulus_switch(hipStream_t st, uint64_t *out, const uint64_t *in, uint32_t lwe_dim,
+                                    uint32_t log_modulus) {
+  HX_LAUNCH(centered_modulus_switch_kernel, dim3(1), dim3(256), 2 * 256 * sizeof(uint64_t), st, out, in, lwe_dim,
+            log_modulus);
+}
+void launch_sample_extract(hipStream_t st, uint64_t *lwe_out, const uint64_t *glwe_in, const uint32_t *nth,
+                           uint32_t num_nths, uint32_t lwe_per_glwe, uint32_t stored_per_glwe, uint32_t glwe_dim,
+                           uint32_t N) {
+  if (!num_nths) return;
+  HX_LAUNCH(sample_extract_kernel, dim3(num_nths), dim3(256), 0, st, lwe_out, glwe_in, nth, lwe_per_glwe,
+            stored_per_glwe, glwe_dim, N);
+}
+void launch_closest_representable(hipStream_t st, const uint64_t *in, uint64_t *out, uint32_t base_log, uint32_t level) {
+  HX_LAUNCH(closest_representable_kernel, dim3(1), dim3(1), 0, st, in, out, base_log, level);
+}
+
+}  // namespace tfhe_hip

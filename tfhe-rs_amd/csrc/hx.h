@@ -1,0 +1,57 @@
+// hx.h — platform header of the MI355X backend.
+//
+// Product build: hipcc --offload-arch=gfx950 (HIP runtime, CDNA4 device code).
+// TFHE_HIPEMU build (tests/emu only): the same sources compiled by g++ against the host-side
+// kernel-language emulation so the kernel logic can be checked without a GPU.  The emulation
+// is test infrastructure; it is never a fallback of the product library.
+#pragma once
+#include <stdint.h>
+#include <stddef.h>
+
+#if defined(TFHE_HIPEMU)
+#include "hipemu.h"
+#include "hipemu_runtime.h"
+#define HX_WAVE_SYNC() hx_wave_sync_emu()
+#define HX_UNROLL _Pragma("GCC unroll 64")
+#else
+#include <hip/hip_runtime.h>
+#define HX_LAUNCH(kern, grid, block, smem, stream, ...) \
+  hipLaunchKernelGGL(kern, grid, block, smem, stream, __VA_ARGS__)
+#define HX_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) char name[]
+// Lanes of one wave exchanging data through LDS need no s_barrier (they execute in lock
+// step); they do need the compiler not to reorder the LDS accesses across this point.
+#define HX_WAVE_SYNC()                                   \
+  do {                                                   \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
+    __builtin_amdgcn_wave_barrier();                     \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
+  } while (0)
+#define HX_UNROLL _Pragma("unroll")
+#endif
+
+#define HX_DEV __device__ __forceinline__
+
+#include <cstdio>
+#include <cstdlib>
+
+// Error convention of the boundary we replace: misuse => message on stderr + abort()
+// (backends/tfhe-cuda-common/cuda/include/device.h:13-41).
+#define HX_PANIC(format, ...)                                                            \
+  do {                                                                                   \
+    std::fprintf(stderr, "%s::%d::%s: panic.\n" format "\n", __FILE__, __LINE__, __func__, \
+                 ##__VA_ARGS__);                                                         \
+    std::abort();                                                                        \
+  } while (0)
+#define HX_PANIC_IF_FALSE(cond, format, ...)                        \
+  do {                                                              \
+    if (!(cond)) HX_PANIC(format "\n\n %s\n", ##__VA_ARGS__, #cond); \
+  } while (0)
+#define HX_CHECK(ans)                                                                     \
+  do {                                                                                    \
+    hipError_t hx_code_ = (ans);                                                          \
+    if (hx_code_ != hipSuccess) {                                                         \
+      std::fprintf(stderr, "HIP error: %s %s %d\n", hipGetErrorString(hx_code_), __FILE__, \
+                   __LINE__);                                                             \
+      std::abort();                                                                       \
+    }                                                                                     \
+  } while (0)

@@ -1,0 +1,44 @@
+// kernels.h — host-callable launchers of the backend's kernels (internal to the library).
+#pragma once
+#include "pbs_common.h"
+
+namespace tfhe_hip {
+
+// generic (any supported N,k,l) engines — pbs_generic.hip
+void launch_pbs_fft_generic(hipStream_t st, uint32_t N, uint32_t glwe_dim, const PbsArgs &a, const FftTables &tb);
+void launch_pbs_ntt_generic(hipStream_t st, uint32_t N, uint32_t glwe_dim, const PbsArgs &a, const NttTables &tb);
+void launch_bsk_to_fourier(hipStream_t st, uint32_t N, const uint64_t *src_dev, void *dst, size_t polys, const FftTables &tb);
+void launch_bsk_to_ntt(hipStream_t st, uint32_t N, const uint64_t *src_dev, void *dst, size_t polys, const NttTables &tb);
+
+// throughput kernel for N=2048, k=1 (any l) — pbs_fft_wave.hip
+bool pbs_fft_wave_supported(uint32_t N, uint32_t glwe_dim, uint32_t level);
+void launch_pbs_fft_wave(hipStream_t st, const PbsArgs &a, const FftTables &tb);
+
+// keyswitch — keyswitch.hip
+void launch_keyswitch(hipStream_t st, uint64_t *lwe_out, const uint64_t *out_idx, const uint64_t *lwe_in,
+                      const uint64_t *in_idx, const uint64_t *ksk, uint32_t n_in, uint32_t n_out,
+                      uint32_t base_log, uint32_t level, uint32_t num_samples);
+
+// small helpers — ciphertext.hip
+void launch_modulus_switch(hipStream_t st, uint64_t *out, const uint64_t *in, uint32_t size, uint32_t log_modulus);
+void launch_centered_modulus_switch(hipStream_t st, uint64_t *out, const uint64_t *in, uint32_t lwe_dim, uint32_t log_modulus);
+void launch_sample_extract(hipStream_t st, uint64_t *lwe_out, const uint64_t *glwe_in, const uint32_t *nth,
+                           uint32_t num_nths, uint32_t lwe_per_glwe, uint32_t stored_per_glwe, uint32_t glwe_dim,
+                           uint32_t N);
+void launch_closest_representable(hipStream_t st, const uint64_t *in, uint64_t *out, uint32_t base_log, uint32_t level);
+
+// multi-bit — multibit.hip
+struct MultiBitArgs {
+  PbsArgs pbs;             // bsk = standard-domain multi-bit key on the device
+  uint32_t grouping_factor;
+  cplx *keybundle;         // scratch: num_samples * level*(k+1)^2 * n complex per group step
+  uint32_t chunk;          // samples processed per pass
+};
+void launch_pbs_multi_bit(hipStream_t st, uint32_t N, uint32_t glwe_dim, const MultiBitArgs &a, const FftTables &tb,
+                          uint64_t *acc_scratch);
+
+// unit-test kernels (device functions exposed for parity tests) — testhooks.hip
+void launch_test_arith(hipStream_t st, uint32_t op, const uint64_t *in, uint64_t *out, uint32_t count, uint32_t p0, uint32_t p1);
+void launch_test_transform(hipStream_t st, uint32_t op, uint32_t N, const void *in, void *out, uint32_t gpu_index);
+
+}  // namespace tfhe_hip

@@ -1,0 +1,168 @@
+// pbs_common.h — pieces shared by the PBS kernels: launch arguments, the LDS-resident
+// reference transforms (one workgroup per polynomial, barrier per stage), prologue/epilogue.
+#pragma once
+#include "arith.h"
+#include "tables.h"
+
+namespace tfhe_hip {
+
+// Arguments of one batched PBS launch.  Index conventions are those of the interface we
+// replace: lwe_in / lwe_out / lut are flat lists, *_idx are u64 arrays on the device
+// (backends/tfhe-cuda-backend/cuda/src/pbs/programmable_bootstrap_classic.cuh:821-826);
+// many-LUT output t lives at offset t*num_samples*(k*N+1) and extracts coefficient
+// t*lut_stride (:990-1001).
+struct PbsArgs {
+  uint64_t *lwe_out;
+  const uint64_t *out_idx;
+  const uint64_t *lut;
+  const uint64_t *lut_idx;
+  const uint64_t *lwe_in;
+  const uint64_t *in_idx;
+  const void *bsk;
+  uint32_t n;          // input (small) LWE dimension
+  uint32_t base_log;
+  uint32_t level;
+  uint32_t num_samples;
+  uint32_t num_many_lut;
+  uint32_t lut_stride;
+  uint32_t ms_type;    // PBS_MS_REDUCTION_T: 0 none, 1 centered
+};
+
+constexpr int ilog2_c(int x) { return x <= 1 ? 0 : 1 + ilog2_c(x / 2); }
+template <int N> struct GenericCfg {
+  static constexpr int TPB = (N / 4 < 256) ? N / 4 : 256;
+};
+
+// ---------------------------------------------------------------- LDS transforms (generic)
+// forward: DESIGN.md §4 merged-twist tree, in place over buf[0..n)
+template <int N, int TPB>
+HX_DEV void lds_fft_forward(cplx *buf, const double *__restrict__ fwd, int tid) {
+  constexpr int n = N / 2;
+  for (int m = n, cnt = 1; m >= 2; m >>= 1, cnt <<= 1) {
+    const int half = m >> 1;
+    for (int b = tid; b < n / 2; b += TPB) {
+      const int g = b / half, j = b - g * half;
+      const int p0 = g * m + j, p1 = p0 + half;
+      const cplx s{fwd[2 * (cnt + g)], fwd[2 * (cnt + g) + 1]};
+      cplx x = buf[p0], y = buf[p1];
+      bfly(x, y, s);
+      buf[p0] = x;
+      buf[p1] = y;
+    }
+    __syncthreads();
+  }
+}
+// backward (unnormalised DIT over the tree order), stages m=2,4 plain, m>=8 fma butterfly
+template <int N, int TPB>
+HX_DEV void lds_fft_inverse(cplx *buf, const double *__restrict__ inv, int tid) {
+  constexpr int n = N / 2;
+  for (int half = 1; half < n; half <<= 1) {
+    const int m = half << 1;
+    for (int b = tid; b < n / 2; b += TPB) {
+      const int q = b / half, j = b - q * half;
+      const int p0 = q * m + j, p1 = p0 + half;
+      cplx x = buf[p0], y = buf[p1];
+      if (half == 1 || (half == 2 && j == 0)) {
+        const cplx o1{x.re + y.re, x.im + y.im}, o2{x.re - y.re, x.im - y.im};
+        x = o1;
+        y = o2;
+      } else if (half == 2) {  // w = -i
+        const cplx o1{x.re + y.im, x.im - y.re}, o2{x.re - y.im, x.im + y.re};
+        x = o1;
+        y = o2;
+      } else {
+        bfly(x, y, cplx{inv[2 * (half + j)], inv[2 * (half + j) + 1]});
+      }
+      buf[p0] = x;
+      buf[p1] = y;
+    }
+    __syncthreads();
+  }
+}
+// Goldilocks negacyclic NTT, Cooley–Tukey / Gentleman–Sande (tfhe-ntt generic_solinas.rs:449-514)
+template <int N, int TPB>
+HX_DEV void lds_ntt_forward(uint64_t *buf, const uint64_t *__restrict__ tw, int tid) {
+  for (int t = N / 2, m = 1; m < N; t >>= 1, m <<= 1) {
+    for (int b = tid; b < N / 2; b += TPB) {
+      const int g = b / t, j = b - g * t;
+      const int p0 = 2 * g * t + j, p1 = p0 + t;
+      const uint64_t zw = gl_mul(buf[p1], tw[m + g]);
+      const uint64_t a = buf[p0];
+      buf[p0] = gl_add(a, zw);
+      buf[p1] = gl_sub(a, zw);
+    }
+    __syncthreads();
+  }
+}
+template <int N, int TPB>
+HX_DEV void lds_ntt_inverse(uint64_t *buf, const uint64_t *__restrict__ itw, int tid) {
+  for (int t = 1, m = N / 2; m >= 1; t <<= 1, m >>= 1) {
+    for (int b = tid; b < N / 2; b += TPB) {
+      const int g = b / t, j = b - g * t;
+      const int p0 = 2 * g * t + j, p1 = p0 + t;
+      const uint64_t a = buf[p0], c = buf[p1];
+      buf[p0] = gl_add(a, c);
+      buf[p1] = gl_mul(gl_sub(a, c), itw[m + g]);
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------- prologue / epilogue
+// b_hat = ms(body + correction); the centered correction is an exact integer reduction
+// over the mask (cc/algorithms/modulus_switch.rs:57-103).  scratch: 2*TPB u64 in LDS.
+template <int TPB>
+HX_DEV uint32_t block_body_modulus_switch(const uint64_t *__restrict__ lwe, uint32_t n, uint32_t log_modulus,
+                                          uint32_t ms_type, uint64_t *scratch, int tid) {
+  uint64_t corr = 0;
+  if (ms_type == 1) {
+    uint64_t sh = 0;
+    int64_t sd = 0;
+    for (uint32_t i = tid; i < n; i += TPB) {
+      uint64_t h;
+      int64_t d;
+      centered_ms_terms(lwe[i], log_modulus, h, d);
+      sh += h;
+      sd += d;
+    }
+    scratch[tid] = sh;
+    scratch[TPB + tid] = (uint64_t)sd;
+    __syncthreads();
+    for (int s = TPB / 2; s > 0; s >>= 1) {
+      if (tid < s) {
+        scratch[tid] += scratch[tid + s];
+        scratch[TPB + tid] += scratch[TPB + tid + s];
+      }
+      __syncthreads();
+    }
+    corr = centered_ms_finish(scratch[0], (int64_t)scratch[TPB], log_modulus);
+    __syncthreads();
+  }
+  return (uint32_t)modulus_switch(lwe[n] + corr, log_modulus);
+}
+
+// sample extraction of coefficient nth, optionally through a final division by X^{post_div}
+// (the NTT-bnf order rotates by -b_hat last).  cc/algorithms/glwe_sample_extraction.rs:119-146
+template <int N, int K1, int TPB>
+HX_DEV void block_sample_extract(const PbsArgs &a, const uint64_t *acc, uint32_t sample, uint32_t post_div,
+                                 bool use_post_div, int tid) {
+  constexpr int k = K1 - 1;
+  const size_t out_sz = (size_t)k * N + 1;
+  auto coeff = [&](int p, uint32_t j) -> uint64_t {
+    if (!use_post_div) return acc[p * N + j];
+    bool neg;
+    const uint32_t src = monomial_div_src(j, post_div, N, neg);
+    const uint64_t v = acc[p * N + src];
+    return neg ? (uint64_t)0 - v : v;
+  };
+  for (uint32_t t = 0; t < a.num_many_lut; ++t) {
+    const uint32_t nth = t * a.lut_stride;
+    uint64_t *out = a.lwe_out + (size_t)t * a.num_samples * out_sz + (size_t)a.out_idx[sample] * out_sz;
+    for (int p = 0; p < k; ++p)
+      for (uint32_t j = tid; j < (uint32_t)N; j += TPB)
+        out[(size_t)p * N + j] = (j <= nth) ? coeff(p, nth - j) : (uint64_t)0 - coeff(p, N + nth - j);
+    if (tid == 0) out[(size_t)k * N] = coeff(k, nth);
+  }
+}
+
+}  // namespace tfhe_hip

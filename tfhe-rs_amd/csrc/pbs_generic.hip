@@ -1,0 +1,244 @@
+// pbs_generic.hip — reference-shaped PBS kernels for every supported (N, k, l): one
+// workgroup per LWE, accumulator resident in LDS for all n CMUX iterations, one transform
+// buffer in LDS, Fourier/NTT-domain output accumulators in registers.
+//
+// Path restated: cc/fft_impl/fft64/crypto/bootstrap.rs:294-380,480-520 (f64 engine) and
+// cc/algorithms/lwe_programmable_bootstrapping/ntt64_bnf_pbs.rs:208-280,541-705 (NTT engine);
+// replaces backends/tfhe-cuda-backend/cuda/src/pbs/programmable_bootstrap_classic.cuh:783-1033
+// (two launches per iteration there; the whole loop is one launch here).
+//
+// These kernels favour generality; the throughput kernel for the headline parameter set lives
+// in pbs_fft_wave.hip and produces bit-identical results (same butterfly dataflow).
+#include "pbs_common.h"
+#include "kernels.h"
+
+namespace tfhe_hip {
+
+template <int N>
+HX_DEV uint64_t rot_sub(const uint64_t *poly, uint32_t j, uint32_t a_hat) {
+  bool neg;
+  const uint32_t src = monomial_mul_src(j, a_hat, N, neg);
+  const uint64_t s = poly[src];
+  return (neg ? (uint64_t)0 - s : s) - poly[j];
+}
+
+// ------------------------------------------------------------------------- f64 engine
+template <int N, int K1>
+__global__ void __launch_bounds__(GenericCfg<N>::TPB) pbs_fft_generic_kernel(PbsArgs a, FftTables tb) {
+  constexpr int n = N / 2, TPB = GenericCfg<N>::TPB, PER = n / TPB, LOG2N2 = ilog2_c(2 * N);
+  HX_DYN_SMEM(smem);
+  uint64_t *acc = (uint64_t *)smem;                  // K1*N torus words
+  cplx *fbuf = (cplx *)(smem + (size_t)K1 * N * 8);  // n complex points
+  const int tid = threadIdx.x;
+  const uint32_t sample = blockIdx.x;
+  const uint64_t *lwe = a.lwe_in + (size_t)a.in_idx[sample] * (a.n + 1);
+  const uint64_t *lut = a.lut + (size_t)a.lut_idx[sample] * K1 * N;
+  const cplx *bsk = (const cplx *)a.bsk;
+
+  const uint32_t b_hat = block_body_modulus_switch<TPB>(lwe, a.n, LOG2N2, a.ms_type, (uint64_t *)fbuf, tid);
+  // acc <- LUT * X^{-b_hat}
+  for (int p = 0; p < K1; ++p)
+    for (uint32_t j = tid; j < (uint32_t)N; j += TPB) {
+      bool neg;
+      const uint32_t src = monomial_div_src(j, b_hat, N, neg);
+      const uint64_t v = lut[p * N + src];
+      acc[p * N + j] = neg ? (uint64_t)0 - v : v;
+    }
+  __syncthreads();
+
+  for (uint32_t i = 0; i < a.n; ++i) {
+    const uint32_t a_hat = (uint32_t)modulus_switch(lwe[i], LOG2N2);
+    if (a_hat == 0) continue;  // uniform across the workgroup (bootstrap.rs:334)
+    cplx facc[K1][PER];
+    bool first = true;
+    for (uint32_t idx = 0; idx < a.level; ++idx) {
+      for (int row = 0; row < K1; ++row) {
+        // ct1 = acc*X^a_hat - acc, decomposed on the fly; fold N reals into n complex
+        for (int q = 0; q < PER; ++q) {
+          const uint32_t j = tid + q * TPB;
+          const int64_t d0 = decomp_digit(rot_sub<N>(acc + row * N, j, a_hat), a.base_log, a.level, idx);
+          const int64_t d1 = decomp_digit(rot_sub<N>(acc + row * N, j + n, a_hat), a.base_log, a.level, idx);
+          fbuf[j] = cplx{i64_to_f64(d0), i64_to_f64(d1)};
+        }
+        __syncthreads();
+        lds_fft_forward<N, TPB>(fbuf, tb.fwd, tid);
+        const cplx *brow = bsk + ((((size_t)i * a.level + idx) * K1 + row) * K1) * n;
+        for (int c = 0; c < K1; ++c)
+          for (int q = 0; q < PER; ++q) {
+            const int pos = tid + q * TPB;
+            const cplx y = brow[(size_t)c * n + pos];
+            facc[c][q] = first ? cmul_first(fbuf[pos], y) : cmul_add(fbuf[pos], y, facc[c][q]);
+          }
+        first = false;
+        __syncthreads();
+      }
+    }
+    for (int c = 0; c < K1; ++c) {
+      for (int q = 0; q < PER; ++q) fbuf[tid + q * TPB] = facc[c][q];
+      __syncthreads();
+      lds_fft_inverse<N, TPB>(fbuf, tb.inv, tid);
+      for (int q = 0; q < PER; ++q) {
+        const int j = tid + q * TPB;
+        const cplx y = fbuf[j];
+        const double ur = tb.untw[2 * j], ui = tb.untw[2 * j + 1];
+        const double tr = fma(-y.im, ui, y.re * ur);
+        const double ti = fma(y.im, ur, y.re * ui);
+        acc[c * N + j] += from_torus(tr);
+        acc[c * N + j + n] += from_torus(ti);
+      }
+      __syncthreads();
+    }
+  }
+  block_sample_extract<N, K1, TPB>(a, acc, sample, 0, false, tid);
+}
+
+// ------------------------------------------------------------------------- NTT engine
+template <int N, int K1>
+__global__ void __launch_bounds__(GenericCfg<N>::TPB) pbs_ntt_generic_kernel(PbsArgs a, NttTables tb) {
+  constexpr int TPB = GenericCfg<N>::TPB, PER = N / TPB, LOG2N2 = ilog2_c(2 * N);
+  HX_DYN_SMEM(smem);
+  uint64_t *acc = (uint64_t *)smem;    // K1*N
+  uint64_t *nbuf = acc + (size_t)K1 * N;  // N
+  const int tid = threadIdx.x;
+  const uint32_t sample = blockIdx.x;
+  const uint64_t *lwe = a.lwe_in + (size_t)a.in_idx[sample] * (a.n + 1);
+  const uint64_t *lut = a.lut + (size_t)a.lut_idx[sample] * K1 * N;
+  const uint64_t *bsk = (const uint64_t *)a.bsk;
+
+  const uint32_t b_hat = block_body_modulus_switch<TPB>(lwe, a.n, LOG2N2, a.ms_type, nbuf, tid);
+  for (int p = 0; p < K1; ++p)
+    for (uint32_t j = tid; j < (uint32_t)N; j += TPB) acc[p * N + j] = lut[p * N + j];
+  __syncthreads();
+
+  for (uint32_t i = 0; i < a.n; ++i) {
+    const uint32_t a_hat = (uint32_t)modulus_switch(lwe[i], LOG2N2);
+    if (a_hat == 0) continue;
+    uint64_t nacc[K1][PER];
+    for (int c = 0; c < K1; ++c)
+      for (int q = 0; q < PER; ++q) nacc[c][q] = 0;
+    for (uint32_t idx = 0; idx < a.level; ++idx) {
+      for (int row = 0; row < K1; ++row) {
+        for (int q = 0; q < PER; ++q) {
+          const uint32_t j = tid + q * TPB;
+          const int64_t d = decomp_digit(rot_sub<N>(acc + row * N, j, a_hat), a.base_log, a.level, idx);
+          nbuf[j] = d < 0 ? (uint64_t)d + GL_P : (uint64_t)d;  // ntt64.rs:199-220
+        }
+        __syncthreads();
+        lds_ntt_forward<N, TPB>(nbuf, tb.tw, tid);
+        const uint64_t *brow = bsk + ((((size_t)i * a.level + idx) * K1 + row) * K1) * N;
+        for (int c = 0; c < K1; ++c)
+          for (int q = 0; q < PER; ++q) {
+            const int pos = tid + q * TPB;
+            nacc[c][q] = gl_add(nacc[c][q], gl_mul(brow[(size_t)c * N + pos], nbuf[pos]));
+          }
+        __syncthreads();
+      }
+    }
+    for (int c = 0; c < K1; ++c) {
+      for (int q = 0; q < PER; ++q) nbuf[tid + q * TPB] = gl_mul(nacc[c][q], tb.n_inv);  // normalize
+      __syncthreads();
+      lds_ntt_inverse<N, TPB>(nbuf, tb.itw, tid);
+      for (int q = 0; q < PER; ++q) {
+        const int j = tid + q * TPB;
+        acc[c * N + j] += gl_modswitch_to_pow2(nbuf[j]);
+      }
+      __syncthreads();
+    }
+  }
+  // rotation by -b_hat is applied last on this path (ntt64_bnf_pbs.rs:262-271)
+  block_sample_extract<N, K1, TPB>(a, acc, sample, b_hat, true, tid);
+}
+
+// ------------------------------------------------------------------------- BSK conversion
+// one workgroup per polynomial: torus -> f64 tree order / Goldilocks NTT domain
+// (cc/algorithms/lwe_bootstrap_key_conversion.rs:20-150, 367-434)
+template <int N>
+__global__ void __launch_bounds__(GenericCfg<N>::TPB) bsk_to_fourier_kernel(const uint64_t *src, cplx *dst, FftTables tb) {
+  constexpr int n = N / 2, TPB = GenericCfg<N>::TPB;
+  HX_DYN_SMEM(smem);
+  cplx *fbuf = (cplx *)smem;
+  const int tid = threadIdx.x;
+  const uint64_t *p = src + (size_t)blockIdx.x * N;
+  for (int j = tid; j < n; j += TPB)
+    fbuf[j] = cplx{i64_to_f64((int64_t)p[j]) * 5.421010862427522e-20, i64_to_f64((int64_t)p[j + n]) * 5.421010862427522e-20};
+  __syncthreads();
+  lds_fft_forward<N, TPB>(fbuf, tb.fwd, tid);
+  cplx *o = dst + (size_t)blockIdx.x * n;
+  for (int j = tid; j < n; j += TPB) o[j] = fbuf[j];
+}
+
+template <int N>
+__global__ void __launch_bounds__(GenericCfg<N>::TPB) bsk_to_ntt_kernel(const uint64_t *src, uint64_t *dst, NttTables tb) {
+  constexpr int TPB = GenericCfg<N>::TPB;
+  HX_DYN_SMEM(smem);
+  uint64_t *nbuf = (uint64_t *)smem;
+  const int tid = threadIdx.x;
+  const uint64_t *p = src + (size_t)blockIdx.x * N;
+  for (int j = tid; j < N; j += TPB) nbuf[j] = gl_modswitch_from_pow2(p[j]);
+  __syncthreads();
+  lds_ntt_forward<N, TPB>(nbuf, tb.tw, tid);
+  uint64_t *o = dst + (size_t)blockIdx.x * N;
+  for (int j = tid; j < N; j += TPB) o[j] = nbuf[j];
+}
+
+// ------------------------------------------------------------------------- launchers
+template <int N, int K1>
+static void launch_fft(hipStream_t st, const PbsArgs &a, const FftTables &tb) {
+  const size_t smem = (size_t)(K1 + 1) * N * 8;
+  HX_CHECK(hipFuncSetAttribute((const void *)pbs_fft_generic_kernel<N, K1>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  HX_LAUNCH((pbs_fft_generic_kernel<N, K1>), dim3(a.num_samples), dim3(GenericCfg<N>::TPB), smem, st, a, tb);
+}
+template <int N, int K1>
+static void launch_ntt(hipStream_t st, const PbsArgs &a, const NttTables &tb) {
+  const size_t smem = (size_t)(K1 + 1) * N * 8;
+  HX_CHECK(hipFuncSetAttribute((const void *)pbs_ntt_generic_kernel<N, K1>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  HX_LAUNCH((pbs_ntt_generic_kernel<N, K1>), dim3(a.num_samples), dim3(GenericCfg<N>::TPB), smem, st, a, tb);
+}
+
+#define HX_DISPATCH_NK(FN, ...)                                                              \
+  do {                                                                                       \
+    const uint32_t k1_ = glwe_dim + 1;                                                       \
+    bool ok_ = true;                                                                         \
+    switch (N) {                                                                             \
+      case 256: if (k1_ == 2) FN<256, 2>(__VA_ARGS__); else if (k1_ == 3) FN<256, 3>(__VA_ARGS__); else if (k1_ == 4) FN<256, 4>(__VA_ARGS__); else ok_ = false; break; \
+      case 512: if (k1_ == 2) FN<512, 2>(__VA_ARGS__); else if (k1_ == 3) FN<512, 3>(__VA_ARGS__); else if (k1_ == 4) FN<512, 4>(__VA_ARGS__); else ok_ = false; break; \
+      case 1024: if (k1_ == 2) FN<1024, 2>(__VA_ARGS__); else if (k1_ == 3) FN<1024, 3>(__VA_ARGS__); else if (k1_ == 4) FN<1024, 4>(__VA_ARGS__); else ok_ = false; break; \
+      case 2048: if (k1_ == 2) FN<2048, 2>(__VA_ARGS__); else if (k1_ == 3) FN<2048, 3>(__VA_ARGS__); else ok_ = false; break; \
+      case 4096: if (k1_ == 2) FN<4096, 2>(__VA_ARGS__); else ok_ = false; break;             \
+      default: ok_ = false;                                                                  \
+    }                                                                                        \
+    if (!ok_) HX_PANIC("unsupported (polynomial_size=%u, glwe_dimension=%u) for the MI355X PBS", N, glwe_dim); \
+  } while (0)
+
+void launch_pbs_fft_generic(hipStream_t st, uint32_t N, uint32_t glwe_dim, const PbsArgs &a, const FftTables &tb) {
+  HX_DISPATCH_NK(launch_fft, st, a, tb);
+}
+void launch_pbs_ntt_generic(hipStream_t st, uint32_t N, uint32_t glwe_dim, const PbsArgs &a, const NttTables &tb) {
+  HX_DISPATCH_NK(launch_ntt, st, a, tb);
+}
+
+template <int N> static void launch_conv_f(hipStream_t st, const uint64_t *src, void *dst, size_t polys, const FftTables &tb) {
+  HX_LAUNCH((bsk_to_fourier_kernel<N>), dim3((unsigned)polys), dim3(GenericCfg<N>::TPB), (size_t)N * 8, st, src, (cplx *)dst, tb);
+}
+template <int N> static void launch_conv_n(hipStream_t st, const uint64_t *src, void *dst, size_t polys, const NttTables &tb) {
+  HX_LAUNCH((bsk_to_ntt_kernel<N>), dim3((unsigned)polys), dim3(GenericCfg<N>::TPB), (size_t)N * 8, st, src, (uint64_t *)dst, tb);
+}
+#define HX_DISPATCH_N(FN, ...)                                              \
+  switch (N) {                                                              \
+    case 256: FN<256>(__VA_ARGS__); break;                                  \
+    case 512: FN<512>(__VA_ARGS__); break;                                  \
+    case 1024: FN<1024>(__VA_ARGS__); break;                                \
+    case 2048: FN<2048>(__VA_ARGS__); break;                                \
+    case 4096: FN<4096>(__VA_ARGS__); break;                                \
+    default: HX_PANIC("unsupported polynomial_size=%u", N);                 \
+  }
+void launch_bsk_to_fourier(hipStream_t st, uint32_t N, const uint64_t *src_dev, void *dst, size_t polys, const FftTables &tb) {
+  HX_DISPATCH_N(launch_conv_f, st, src_dev, dst, polys, tb);
+}
+void launch_bsk_to_ntt(hipStream_t st, uint32_t N, const uint64_t *src_dev, void *dst, size_t polys, const NttTables &tb) {
+  HX_DISPATCH_N(launch_conv_n, st, src_dev, dst, polys, tb);
+}
+
+}  // namespace tfhe_hip

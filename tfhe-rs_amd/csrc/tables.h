@@ -1,0 +1,34 @@
+// tables.h — per-device constant tables (f64 transform twiddles, Goldilocks NTT twiddles).
+#pragma once
+#include "hx.h"
+
+namespace tfhe_hip {
+
+// f64 transform tables for polynomial size N (n = N/2 complex points), DESIGN.md §4:
+//   fwd[(1<<d)+g]  = exp(i*pi*(1+4*bitrev_d(g)) / 2^(d+2))       d = 0..log2(n)-1
+//   inv[half+j]    = exp(-2*pi*i*j / (2*half))                   half = 1,2,..,n/2 ; j < half
+//   untw[j]        = conj(exp(i*pi*j/N)) / n
+// each entry (re, im) as two doubles; index 0 of fwd/inv unused.
+struct FftTables {
+  const double *fwd;
+  const double *inv;
+  const double *untw;
+};
+
+// Goldilocks tables: tw[m+g] = psi^bitrev(m+g), itw likewise for psi^-1; n_inv = N^-1 mod p
+struct NttTables {
+  const uint64_t *tw;
+  const uint64_t *itw;
+  uint64_t n_inv;
+};
+
+// Lazily built, cached per (device, N); `stream` orders the upload before first use.
+FftTables get_fft_tables(uint32_t gpu_index, hipStream_t stream, uint32_t N);
+NttTables get_ntt_tables(uint32_t gpu_index, hipStream_t stream, uint32_t N);
+
+// host-side generators (also exported through the test ABI so the tables can be compared
+// with the oracle's independently computed ones)
+void fill_fft_tables_host(uint32_t N, double *fwd, double *inv, double *untw);
+void fill_ntt_tables_host(uint32_t N, uint64_t *tw, uint64_t *itw, uint64_t *n_inv);
+
+}  // namespace tfhe_hip

@@ -1,0 +1,152 @@
+// tables.hip — host-side generation + per-device caching of the transform tables.
+#include "tables.h"
+#include "arith.h"
+
+#include <cmath>
+#include <map>
+#include <mutex>
+#include <tuple>
+#include <vector>
+
+namespace tfhe_hip {
+
+static uint32_t ilog2(uint32_t x) {
+  uint32_t l = 0;
+  while ((1u << l) < x) ++l;
+  return l;
+}
+static uint32_t bitrev(uint32_t x, uint32_t bits) {
+  uint32_t r = 0;
+  for (uint32_t i = 0; i < bits; ++i) {
+    r = (r << 1) | (x & 1);
+    x >>= 1;
+  }
+  return r;
+}
+
+// DESIGN.md §4.  Angles are evaluated in long double and rounded once to double.
+void fill_fft_tables_host(uint32_t N, double *fwd, double *inv, double *untw) {
+  const uint32_t n = N / 2, D = ilog2(n);
+  const long double PI = 3.14159265358979323846264338327950288L;
+  fwd[0] = fwd[1] = 0.0;
+  for (uint32_t d = 0; d < D; ++d)
+    for (uint32_t g = 0; g < (1u << d); ++g) {
+      const uint32_t r = 1 + 4 * bitrev(g, d);
+      const long double ang = PI * (long double)r / (long double)(1u << (d + 2));
+      fwd[2 * ((1u << d) + g)] = (double)cosl(ang);
+      fwd[2 * ((1u << d) + g) + 1] = (double)sinl(ang);
+    }
+  inv[0] = inv[1] = 0.0;
+  for (uint32_t half = 1; half < n; half *= 2)
+    for (uint32_t j = 0; j < half; ++j) {
+      double c, s;
+      if (j == 0) {
+        c = 1.0;
+        s = 0.0;
+      } else if (2 * j == half) {
+        c = 0.0;
+        s = -1.0;
+      } else {
+        const long double ang = -PI * (long double)j / (long double)half;
+        c = (double)cosl(ang);
+        s = (double)sinl(ang);
+      }
+      inv[2 * (half + j)] = c;
+      inv[2 * (half + j) + 1] = s;
+    }
+  for (uint32_t j = 0; j < n; ++j) {
+    const long double ang = PI * (long double)j / (long double)N;
+    untw[2 * j] = (double)cosl(ang) / (double)n;
+    untw[2 * j + 1] = -((double)sinl(ang)) / (double)n;
+  }
+}
+
+static uint64_t gl_pow_host(uint64_t a, uint64_t e) {
+  uint64_t r = 1;
+  while (e) {
+    if (e & 1) r = gl_mul(r, a);
+    a = gl_mul(a, a);
+    e >>= 1;
+  }
+  return r;
+}
+
+// psi: the reference's fixed Goldilocks roots (tfhe-ntt/src/prime64.rs:162-179), so the
+// NTT-domain key equals the reference's NttLweBootstrapKey value for value.
+static uint64_t gl_root_2N(uint32_t N) {
+  switch (N) {
+    case 256: return 14430643036723656017ull;
+    case 512: return 4440654710286119610ull;
+    case 1024: return 8816101479115663336ull;
+    case 2048: return 10974926054405199669ull;
+    case 4096: return 1206500561358145487ull;
+    default: return gl_pow_host(7, (GL_P - 1) / (2ull * N));  // 7 generates Z_p^*
+  }
+}
+void fill_ntt_tables_host(uint32_t N, uint64_t *tw, uint64_t *itw, uint64_t *n_inv) {
+  const uint32_t lg = ilog2(N);
+  const uint64_t psi = gl_root_2N(N);
+  const uint64_t psi_inv = gl_pow_host(psi, GL_P - 2);
+  for (uint32_t i = 0; i < N; ++i) {
+    const uint32_t e = bitrev(i, lg);
+    tw[i] = gl_pow_host(psi, e);
+    itw[i] = gl_pow_host(psi_inv, e);
+  }
+  *n_inv = gl_pow_host(N, GL_P - 2);
+}
+
+namespace {
+struct FftEntry {
+  double *fwd, *inv, *untw;
+};
+struct NttEntry {
+  uint64_t *tw, *itw;
+  uint64_t n_inv;
+};
+std::mutex g_mu;
+std::map<std::pair<uint32_t, uint32_t>, FftEntry> g_fft;
+std::map<std::pair<uint32_t, uint32_t>, NttEntry> g_ntt;
+}  // namespace
+
+FftTables get_fft_tables(uint32_t gpu_index, hipStream_t stream, uint32_t N) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  auto key = std::make_pair(gpu_index, N);
+  auto it = g_fft.find(key);
+  if (it == g_fft.end()) {
+    std::vector<double> fwd(N), inv(N), untw(N);
+    fill_fft_tables_host(N, fwd.data(), inv.data(), untw.data());
+    FftEntry e;
+    HX_CHECK(hipSetDevice((int)gpu_index));
+    HX_CHECK(hipMalloc((void **)&e.fwd, sizeof(double) * N));
+    HX_CHECK(hipMalloc((void **)&e.inv, sizeof(double) * N));
+    HX_CHECK(hipMalloc((void **)&e.untw, sizeof(double) * N));
+    // synchronous copies from pageable host memory: complete before we return
+    HX_CHECK(hipMemcpy(e.fwd, fwd.data(), sizeof(double) * N, hipMemcpyHostToDevice));
+    HX_CHECK(hipMemcpy(e.inv, inv.data(), sizeof(double) * N, hipMemcpyHostToDevice));
+    HX_CHECK(hipMemcpy(e.untw, untw.data(), sizeof(double) * N, hipMemcpyHostToDevice));
+    (void)stream;
+    it = g_fft.emplace(key, e).first;
+  }
+  return FftTables{it->second.fwd, it->second.inv, it->second.untw};
+}
+
+NttTables get_ntt_tables(uint32_t gpu_index, hipStream_t stream, uint32_t N) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  auto key = std::make_pair(gpu_index, N);
+  auto it = g_ntt.find(key);
+  if (it == g_ntt.end()) {
+    std::vector<uint64_t> tw(N), itw(N);
+    NttEntry e;
+    fill_ntt_tables_host(N, tw.data(), itw.data(), &e.n_inv);
+    HX_CHECK(hipSetDevice((int)gpu_index));
+    HX_CHECK(hipMalloc((void **)&e.tw, sizeof(uint64_t) * N));
+    HX_CHECK(hipMalloc((void **)&e.itw, sizeof(uint64_t) * N));
+    HX_CHECK(hipMemcpy(e.tw, tw.data(), sizeof(uint64_t) * N, hipMemcpyHostToDevice));
+    HX_CHECK(hipMemcpy(e.itw, itw.data(), sizeof(uint64_t) * N, hipMemcpyHostToDevice));
+    (void)stream;
+    it = g_ntt.emplace(key, e).first;
+  }
+  return NttTables{it->second.tw, it->second.itw, it->second.n_inv};
+}
+
+}  // namespace tfhe_hip

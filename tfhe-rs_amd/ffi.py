@@ -1,0 +1,110 @@
+"""Raw ctypes binding of libtfhe_hip_backend.so — the Python twin of the Rust FFI the
+reference generates with bindgen (backends/tfhe-cuda-backend/src/bindings.rs and
+backends/tfhe-cuda-common/src/cuda_bind.rs).  One entry per symbol declared in
+include/tfhe_hip_backend.h; plain pointers and sizes only.
+
+There is NO CPU fallback here: if the HIP library is missing the import fails loudly.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(_HERE, "lib", "libtfhe_hip_backend.so")
+
+_v, _u32, _u64, _i8pp, _b = C.c_void_p, C.c_uint32, C.c_uint64, C.POINTER(C.c_void_p), C.c_bool
+
+# symbol -> (restype, argtypes); mirrors include/tfhe_hip_backend.h line by line
+SIGNATURES = {
+    # device runtime
+    "cuda_create_stream_ffi": (_v, [_u32]),
+    "cuda_destroy_stream": (None, [_v, _u32]),
+    "cuda_synchronize_stream": (None, [_v, _u32]),
+    "cuda_is_available": (_u32, []),
+    "cuda_malloc": (_v, [_u64, _u32]),
+    "cuda_malloc_async": (_v, [_u64, _v, _u32]),
+    "cuda_check_valid_malloc": (_b, [_u64, _u32]),
+    "cuda_device_total_memory": (_u64, [_u32]),
+    "cuda_memcpy_async_to_gpu": (None, [_v, _v, _u64, _v, _u32]),
+    "cuda_memcpy_async_gpu_to_gpu": (None, [_v, _v, _u64, _v, _u32]),
+    "cuda_memcpy_gpu_to_gpu": (None, [_v, _v, _u64, _u32]),
+    "cuda_memcpy_async_to_cpu": (None, [_v, _v, _u64, _v, _u32]),
+    "cuda_memset_async": (None, [_v, _u64, _u64, _v, _u32]),
+    "cuda_get_number_of_gpus": (C.c_int, []),
+    "cuda_get_number_of_sms": (C.c_int, []),
+    "cuda_synchronize_device": (None, [_u32]),
+    "cuda_drop": (None, [_v, _u32]),
+    # classic PBS
+    "cuda_convert_lwe_programmable_bootstrap_key_64_async": (None, [_v, _u32, _v, _v, _u32, _u32, _u32, _u32]),
+    "scratch_cuda_programmable_bootstrap_64_async":
+        (_u64, [_v, _u32, _i8pp, _u32, _u32, _u32, _u32, _u32, _b, _u32]),
+    "cuda_programmable_bootstrap_64_async":
+        (None, [_v, _u32, _v, _v, _v, _v, _v, _v, _v, _v, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _u32]),
+    "cleanup_cuda_programmable_bootstrap_64": (None, [_v, _u32, _i8pp]),
+    # multi-bit PBS
+    "has_support_to_cuda_programmable_bootstrap_cg_multi_bit": (_b, [_u32, _u32, _u32, _u32, _u32]),
+    "cuda_convert_lwe_multi_bit_programmable_bootstrap_key_64_async":
+        (None, [_v, _u32, _v, _v, _u32, _u32, _u32, _u32, _u32]),
+    "scratch_cuda_multi_bit_programmable_bootstrap_64_async": (_u64, [_v, _u32, _i8pp, _u32, _u32, _u32, _u32, _b]),
+    "cuda_multi_bit_programmable_bootstrap_64_async":
+        (None, [_v, _u32, _v, _v, _v, _v, _v, _v, _v, _v, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _u32]),
+    "cleanup_cuda_multi_bit_programmable_bootstrap_64": (None, [_v, _u32, _i8pp]),
+    # keyswitch
+    "cuda_keyswitch_lwe_ciphertext_vector_64_64_async":
+        (None, [_v, _u32, _v, _v, _v, _v, _v, _u32, _u32, _u32, _u32, _u32]),
+    "cuda_keyswitch_gemm_64_64_async": (None, [_v, _u32, _v, _v, _v, _v, _v, _u32, _u32, _u32, _u32, _u32, _b]),
+    "cuda_closest_representable_64_async": (None, [_v, _u32, _v, _v, _u32, _u32]),
+    # ciphertext helpers
+    "cuda_convert_lwe_ciphertext_vector_to_gpu_64_async": (None, [_v, _u32, _v, _v, _u32, _u32]),
+    "cuda_convert_lwe_ciphertext_vector_to_cpu_64_async": (None, [_v, _u32, _v, _v, _u32, _u32]),
+    "cuda_glwe_sample_extract_64_async": (None, [_v, _u32, _v, _v, _v, _u32, _u32, _u32, _u32, _u32]),
+    "cuda_modulus_switch_inplace_64_async": (None, [_v, _u32, _v, _u32, _u32]),
+    "cuda_modulus_switch_64_async": (None, [_v, _u32, _v, _v, _u32, _u32]),
+    "cuda_centered_modulus_switch_64_async": (None, [_v, _u32, _v, _v, _u32, _u32]),
+    # extensions
+    "hip_convert_lwe_programmable_bootstrap_key_ntt64_async": (None, [_v, _u32, _v, _v, _u32, _u32, _u32, _u32]),
+    "hip_programmable_bootstrap_ntt64_async":
+        (None, [_v, _u32, _v, _v, _v, _v, _v, _v, _v, _v, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _u32]),
+    "hip_backend_set_fft_kernel": (None, [_u32]),
+    "hip_backend_last_pbs_kernel": (_u32, []),
+    "hip_backend_version": (C.c_char_p, []),
+    "hip_event_create": (_v, []),
+    "hip_event_record": (None, [_v, _v]),
+    "hip_event_elapsed_ms": (C.c_float, [_v, _v]),
+    "hip_event_destroy": (None, [_v]),
+    "hip_test_arith_async": (None, [_v, _u32, _u32, _v, _v, _u32, _u32, _u32]),
+    "hip_test_transform_async": (None, [_v, _u32, _u32, _u32, _v, _v]),
+    "hip_test_fft_tables_host": (None, [_u32, _v, _v, _v]),
+}
+
+
+class Library:
+    """Loaded backend library with typed symbols."""
+
+    def __init__(self, path=None):
+        self.path = path or DEFAULT_LIB
+        if not os.path.exists(self.path):
+            raise ImportError(
+                f"{self.path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+        self.cdll = C.CDLL(self.path)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(self.cdll, name)  # AttributeError if the export is missing
+            fn.restype = res
+            fn.argtypes = args
+            setattr(self, name, fn)
+
+
+_default = None
+
+
+def default_library():
+    global _default
+    if _default is None:
+        _default = Library()
+    return _default
+
+
+def set_default_library(lib):
+    """Used by the test-suite to run the host-emulation build through the same wrappers."""
+    global _default
+    _default = lib
