@@ -651,32 +651,45 @@ static int g_nfplans = 0;
 static void fft_fill_tables(uint32_t N, double *fwd, double *inv, double *untw) {
   uint32_t n = N / 2, D = orc_log2_u32(n);
   const long double PI = 3.14159265358979323846264338327950288L;
+  /* forward: even g evaluated, odd sibling = i * even (exact quarter turn) */
   fwd[0] = fwd[1] = 0.0;
   for (uint32_t d = 0; d < D; ++d)
     for (uint32_t g = 0; g < (1u << d); ++g) {
-      uint32_t r = 1 + 4 * bitrev(g, d);
-      long double ang = PI * (long double)r / (long double)(1u << (d + 2));
-      fwd[2 * ((1u << d) + g)] = (double)cosl(ang);
-      fwd[2 * ((1u << d) + g) + 1] = (double)sinl(ang);
+      double c, s;
+      if (g & 1) { c = -fwd[2 * ((1u << d) + g - 1) + 1]; s = fwd[2 * ((1u << d) + g - 1)]; }
+      else {
+        uint32_t r = 1 + 4 * bitrev(g, d);
+        long double ang = PI * (long double)r / (long double)(1u << (d + 2));
+        c = (double)cosl(ang); s = (double)sinl(ang);
+      }
+      fwd[2 * ((1u << d) + g)] = c;
+      fwd[2 * ((1u << d) + g) + 1] = s;
     }
+  /* backward: w = exp(-2*pi*i*j/(2*half)); j >= half/2 derived as -i * w[j - half/2] */
   inv[0] = inv[1] = 0.0;
   for (uint32_t half = 1; half < n; half *= 2)
     for (uint32_t j = 0; j < half; ++j) {
-      /* w = exp(-2*pi*i*j/(2*half)) ; exact values at j = 0 and j = half/2 */
       double c, s;
       if (j == 0) { c = 1.0; s = 0.0; }
-      else if (2 * j == half) { c = 0.0; s = -1.0; }
-      else {
+      else if (half >= 2 && j >= half / 2) {
+        c = inv[2 * (half + j - half / 2) + 1]; s = -inv[2 * (half + j - half / 2)];
+      } else {
         long double ang = -PI * (long double)j / (long double)half;
         c = (double)cosl(ang); s = (double)sinl(ang);
       }
       inv[2 * (half + j)] = c;
       inv[2 * (half + j) + 1] = s;
     }
+  /* untwist: conj(exp(i*pi*j/N))/n for j <= n/2, mirrored (cos <-> sin) above */
   for (uint32_t j = 0; j < n; ++j) {
-    long double ang = PI * (long double)j / (long double)N;
-    untw[2 * j] = (double)cosl(ang) / (double)n;     /* power-of-two scaling: exact */
-    untw[2 * j + 1] = -((double)sinl(ang)) / (double)n;
+    if (j <= n / 2) {
+      long double ang = PI * (long double)j / (long double)N;
+      untw[2 * j] = (double)cosl(ang) / (double)n;     /* power-of-two scaling: exact */
+      untw[2 * j + 1] = -((double)sinl(ang)) / (double)n;
+    } else {
+      untw[2 * j] = -untw[2 * (n - j) + 1];
+      untw[2 * j + 1] = -untw[2 * (n - j)];
+    }
   }
 }
 

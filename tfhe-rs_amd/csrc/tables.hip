@@ -28,14 +28,22 @@ static uint32_t bitrev(uint32_t x, uint32_t bits) {
 void fill_fft_tables_host(uint32_t N, double *fwd, double *inv, double *untw) {
   const uint32_t n = N / 2, D = ilog2(n);
   const long double PI = 3.14159265358979323846264338327950288L;
+  // forward: even g evaluated, odd sibling = i * even (an exact quarter turn)
   fwd[0] = fwd[1] = 0.0;
   for (uint32_t d = 0; d < D; ++d)
     for (uint32_t g = 0; g < (1u << d); ++g) {
-      const uint32_t r = 1 + 4 * bitrev(g, d);
-      const long double ang = PI * (long double)r / (long double)(1u << (d + 2));
-      fwd[2 * ((1u << d) + g)] = (double)cosl(ang);
-      fwd[2 * ((1u << d) + g) + 1] = (double)sinl(ang);
+      const uint32_t idx = (1u << d) + g;
+      if (g & 1) {
+        fwd[2 * idx] = -fwd[2 * (idx - 1) + 1];
+        fwd[2 * idx + 1] = fwd[2 * (idx - 1)];
+      } else {
+        const uint32_t r = 1 + 4 * bitrev(g, d);
+        const long double ang = PI * (long double)r / (long double)(1u << (d + 2));
+        fwd[2 * idx] = (double)cosl(ang);
+        fwd[2 * idx + 1] = (double)sinl(ang);
+      }
     }
+  // backward: w = exp(-2*pi*i*j/(2*half)); j >= half/2 derived as -i * w[j - half/2]
   inv[0] = inv[1] = 0.0;
   for (uint32_t half = 1; half < n; half *= 2)
     for (uint32_t j = 0; j < half; ++j) {
@@ -43,9 +51,9 @@ void fill_fft_tables_host(uint32_t N, double *fwd, double *inv, double *untw) {
       if (j == 0) {
         c = 1.0;
         s = 0.0;
-      } else if (2 * j == half) {
-        c = 0.0;
-        s = -1.0;
+      } else if (half >= 2 && j >= half / 2) {
+        c = inv[2 * (half + j - half / 2) + 1];
+        s = -inv[2 * (half + j - half / 2)];
       } else {
         const long double ang = -PI * (long double)j / (long double)half;
         c = (double)cosl(ang);
@@ -54,10 +62,16 @@ void fill_fft_tables_host(uint32_t N, double *fwd, double *inv, double *untw) {
       inv[2 * (half + j)] = c;
       inv[2 * (half + j) + 1] = s;
     }
+  // untwist: conj(exp(i*pi*j/N))/n for j <= n/2, mirrored (cos <-> sin) above
   for (uint32_t j = 0; j < n; ++j) {
-    const long double ang = PI * (long double)j / (long double)N;
-    untw[2 * j] = (double)cosl(ang) / (double)n;
-    untw[2 * j + 1] = -((double)sinl(ang)) / (double)n;
+    if (j <= n / 2) {
+      const long double ang = PI * (long double)j / (long double)N;
+      untw[2 * j] = (double)cosl(ang) / (double)n;
+      untw[2 * j + 1] = -((double)sinl(ang)) / (double)n;
+    } else {
+      untw[2 * j] = -untw[2 * (n - j) + 1];
+      untw[2 * j + 1] = -untw[2 * (n - j)];
+    }
   }
 }
 
