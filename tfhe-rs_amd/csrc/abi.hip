@@ -174,7 +174,7 @@ static void convert_bsk_common(bool ntt, void *stream, uint32_t gpu_index, void 
     launch_bsk_to_ntt(S(stream), polynomial_size, (const uint64_t *)tmp, dest, polys, tb);
   } else {
     const FftTables tb = get_fft_tables(gpu_index, S(stream), polynomial_size);
-    launch_bsk_to_fourier(S(stream), polynomial_size, (const uint64_t *)tmp, dest, polys, tb);
+    launch_bsk_to_fourier(S(stream), polynomial_size, glwe_dim, (const uint64_t *)tmp, dest, polys, tb);
   }
   // the staging buffer must outlive the kernel: release it once the stream reaches here
   HX_CHECK(hipStreamSynchronize(S(stream)));

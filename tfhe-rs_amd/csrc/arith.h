@@ -110,7 +110,7 @@ HX_DEV uint64_t from_torus(double t) {
   return (uint64_t)f64_to_i64_sat(f);
 }
 
-struct cplx {
+struct alignas(16) cplx {
   double re, im;
 };
 

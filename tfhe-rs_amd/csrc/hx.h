@@ -13,6 +13,9 @@
 #include "hipemu_runtime.h"
 #define HX_WAVE_SYNC() hx_wave_sync_emu()
 #define HX_UNROLL _Pragma("GCC unroll 64")
+#define HX_SCHED_FENCE() do { } while (0)
+#define HX_OPAQUE(v) do { } while (0)
+#define HX_UNIFORM(v) (v)
 #else
 #include <hip/hip_runtime.h>
 #define HX_LAUNCH(kern, grid, block, smem, stream, ...) \
@@ -27,6 +30,14 @@
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
   } while (0)
 #define HX_UNROLL _Pragma("unroll")
+// compile-time scheduling fence: keeps the instruction scheduler from hoisting loads of a later
+// chunk across this point (bounds live ranges, hence VGPR pressure)
+#define HX_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+// makes the compiler forget what it knows about a VGPR value: address arithmetic derived from it
+// is recomputed where it is used instead of being hoisted out of the loop and kept (or spilled)
+#define HX_OPAQUE(v) asm volatile("" : "+v"(v))
+// wave-uniform value into an SGPR
+#define HX_UNIFORM(v) __builtin_amdgcn_readfirstlane(v)
 #endif
 
 #define HX_DEV __device__ __forceinline__

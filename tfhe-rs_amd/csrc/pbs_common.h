@@ -33,6 +33,16 @@ template <int N> struct GenericCfg {
   static constexpr int TPB = (N / 4 < 256) ? N / 4 : 256;
 };
 
+// Storage slot of transform position `pos` inside one Fourier-domain key polynomial.  The
+// key buffer is opaque to callers (gpu/entities/lwe_bootstrap_key.rs:57-104), so for the
+// headline ring (N = 2048, k = 1) it is stored in the order the throughput kernel reads it:
+// lane L of a wave owns positions L*16..L*16+15 and element r of every lane is contiguous.
+template <int N, int K1>
+HX_DEV int bsk_slot(int pos) {
+  if constexpr (N == 2048 && K1 == 2) return (pos & 15) * 64 + (pos >> 4);
+  return pos;
+}
+
 // ---------------------------------------------------------------- LDS transforms (generic)
 // forward: DESIGN.md §4 merged-twist tree, in place over buf[0..n)
 template <int N, int TPB>

@@ -1,6 +1,505 @@
-// placeholder until the throughput kernel lands
+// pbs_fft_wave.hip — throughput PBS kernel for N = 2048, k = 1 (PARAM_MESSAGE_2_CARRY_2 and
+// every other (n, l, base_log) on that ring).
+//
+// Replaces backends/tfhe-cuda-backend/cuda/src/pbs/programmable_bootstrap_classic.cuh:214-745
+// (the "specialized 2_2" kernels).  Same results, bit for bit, as pbs_generic.hip and the
+// oracle: the butterfly dataflow of DESIGN.md §4 is kept, only its grouping changes.
+//
+// CDNA4 mapping
+//   * one WAVE per polynomial: a GLWE (k+1 = 2 polynomials) is a wave pair, a workgroup is 8
+//     waves = 4 LWEs, one workgroup per CU (2 waves per SIMD, <= 256 VGPRs each).
+//   * the torus accumulator (2048 u64 per polynomial) lives in VGPRs for all n iterations
+//     (32 u64 per lane); the 1024-point complex transform holds 16 points per lane.
+//   * every transform is 3 register passes (radix 16, 16, 4) with two wave-private LDS
+//     transposes in between — lanes of one wave run in lock step, so those exchanges need no
+//     s_barrier.  XOR swizzles make every ds_read_b128/ds_write_b128 bank-conflict free.
+//   * the only cross-wave traffic is the exchange of the two forward transforms before the
+//     multiply-accumulate; the pair synchronises through two LDS flags (no workgroup barrier,
+//     so the four LWEs of a CU drift apart and overlap their LDS- and VALU-heavy phases).
+//   * twiddles whose index depends on the lane sit in a 25 KB LDS table shared by the 8 waves;
+//     wave-uniform ones come through the scalar cache.
+//   * the bootstrap key is stored in the order this kernel consumes it (lane-contiguous
+//     16-byte elements), so each of the 32 key loads per wave-iteration is one fully
+//     coalesced 1 KiB request; all workgroups stream GGSW_i at about the same time, so the
+//     60 MB key is served from L2 / Infinity Cache.
 #include "kernels.h"
+
 namespace tfhe_hip {
-bool pbs_fft_wave_supported(uint32_t, uint32_t, uint32_t) { return false; }
-void launch_pbs_fft_wave(hipStream_t, const PbsArgs &, const FftTables &) { HX_PANIC("throughput kernel not built"); }
+namespace wavek {
+
+constexpr int N = 2048, n = 1024, LOG2N2 = 12;
+constexpr int LWES_PER_BLOCK = 4, WAVES = 8, TPB = WAVES * 64;
+
+// One wave's exchange buffer: 1024 complex points in 16-byte slots, PADDED so that every
+// transpose is (one VGPR base) + (compile-time offset) and every ds_read/write_b128 is bank
+// conflict free:
+//   P_A(q) = q + 4*(q >> 6)   M1 <-> M2 transposes   (1084 slots)
+//   P_B(q) = q + (q >> 4)     M2 <-> M3 transposes and the pair's F exchange (1087 slots)
+// with M1: q = r*64 + lane ; M2: q = hi4*64 + r*4 + lo2 (lane = hi4*4 + lo2) ; M3: q = lane*16 + r
+//   M1/P_A : slot = lane + 68*r                      M2/P_A : slot = (hi4*68 + lo2) + 4*r
+//   M2/P_B : slot = (hi4*68 + lo2) + 4*r + (r >> 2)  M3/P_B : slot = lane*17 + r
+// (slot mod 16 = (lane + const) mod 16 in all four forms, distinct inside every b128 lane group)
+constexpr int BUF_SLOTS = 1087;
+constexpr int BUF_BYTES = BUF_SLOTS * 16;
+
+// compact LDS twiddle table (entries of 16 bytes), shared by the 8 waves
+constexpr int T_F1 = 0;      // forward d = 0..3, even groups: fwd[1], fwd[2], fwd[4], fwd[6], fwd[8..14 step 2]
+constexpr int T_F2 = 8;      // forward d = 4..7: 16 + 16 + 32 + 64
+constexpr int T_F3 = 136;    // forward d = 8, 9, even groups: 128 + 256
+constexpr int T_INV = 520;   // E[J] = inv[512 + J], J < 256; every inverse twiddle is E[j*512/half] or -i*E[.]
+constexpr int T_U = 776;     // untwist, j <= 512 (mirrored above): 513 entries
+constexpr int T_TOTAL = 1289;
+constexpr int FLAGS_BYTES = 64;
+constexpr size_t SMEM_BYTES = (size_t)WAVES * BUF_BYTES + (size_t)T_TOTAL * 16 + FLAGS_BYTES;
+
+HX_DEV cplx times_i(const cplx c) { return cplx{-c.im, c.re}; }
+HX_DEV cplx times_mi(const cplx c) { return cplx{c.im, -c.re}; }
+HX_DEV cplx ldg_c(const double *t, int idx) { return cplx{t[2 * idx], t[2 * idx + 1]}; }
+
+#if defined(TFHE_HIPEMU)
+HX_DEV void flag_set(volatile uint32_t *f, uint32_t v) { *f = v; }
+HX_DEV void flag_wait(volatile uint32_t *f, uint32_t v) {
+  while (*f < v) hipemu::yield_barrier(0);
 }
+#else
+HX_DEV void flag_set(uint32_t *f, uint32_t v) {
+  __hip_atomic_store(f, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+HX_DEV void flag_wait(uint32_t *f, uint32_t v) {
+  while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < v) __builtin_amdgcn_s_sleep(1);
+}
+#endif
+
+// one radix-2 stage of the §4 butterfly over register-index bit BIT; TW(r) gives the twiddle
+// of the butterfly whose first element is d[r]
+template <int BIT, class TW>
+HX_DEV void stage(cplx (&d)[16], TW tw) {
+  HX_UNROLL
+  for (int r = 0; r < 16; ++r)
+    if (!(r & (1 << BIT))) bfly(d[r], d[r | (1 << BIT)], tw(r));
+}
+
+// Everything a wave needs to know about its place in the workgroup
+struct WaveCtx {
+  cplx *buf;         // my exchange buffer
+  const cplx *obuf;  // my partner's
+  const cplx *T;     // compact twiddle table
+  int lane, hi4, lo2, w;
+};
+
+// slot bases of the three register<->lane mappings (see BUF_SLOTS comment)
+HX_DEV int base_m1(const WaveCtx &c) { return c.lane; }
+HX_DEV int base_m2(const WaveCtx &c) { return c.hi4 * 68 + c.lo2; }
+HX_DEV int base_m3(const WaveCtx &c) { return c.lane * 17; }
+
+// ---- forward transform of 16 points per lane: mapping M1 in, mapping M3 out
+HX_DEV void wave_forward(cplx (&d)[16], WaveCtx c) {
+  HX_OPAQUE(c.lane);
+  c.hi4 = c.lane >> 2;
+  c.lo2 = c.lane & 3;
+  const int lane = c.lane, hi4 = c.hi4;
+  const cplx *T = c.T;
+  // pass F1: stages 0..3 over position bits 9..6 (= r bits 3..0); wave-uniform twiddles (LDS broadcast)
+  {
+    const cplx w0 = T[T_F1 + 0];
+    stage<3>(d, [&](int) { return w0; });
+    const cplx e1 = T[T_F1 + 1];
+    stage<2>(d, [&](int r) { return (r >> 3) ? times_i(e1) : e1; });
+    HX_SCHED_FENCE();
+    const cplx e2[2] = {T[T_F1 + 2], T[T_F1 + 3]};
+    stage<1>(d, [&](int r) { return ((r >> 2) & 1) ? times_i(e2[r >> 3]) : e2[r >> 3]; });
+    HX_SCHED_FENCE();
+    const cplx e3[4] = {T[T_F1 + 4], T[T_F1 + 5], T[T_F1 + 6], T[T_F1 + 7]};
+    stage<0>(d, [&](int r) { return ((r >> 1) & 1) ? times_i(e3[r >> 2]) : e3[r >> 2]; });
+  }
+  HX_SCHED_FENCE();
+  // transpose M1 -> M2
+  {
+    cplx *p1 = c.buf + base_m1(c);
+    HX_UNROLL
+    for (int r = 0; r < 16; ++r) p1[68 * r] = d[r];
+    HX_WAVE_SYNC();
+    const cplx *p2 = c.buf + base_m2(c);
+    HX_UNROLL
+    for (int r = 0; r < 16; ++r) d[r] = p2[4 * r];
+    HX_WAVE_SYNC();
+  }
+  // pass F2: stages 4..7 over position bits 5..2; group index = hi4 . (r bits)
+  {
+    const cplx w4 = T[T_F2 + hi4];
+    stage<3>(d, [&](int) { return w4; });
+    const cplx e5 = T[T_F2 + 16 + hi4];
+    stage<2>(d, [&](int r) { return (r >> 3) ? times_i(e5) : e5; });
+    HX_SCHED_FENCE();
+    const cplx e6[2] = {T[T_F2 + 32 + hi4 * 2], T[T_F2 + 32 + hi4 * 2 + 1]};
+    stage<1>(d, [&](int r) { return ((r >> 2) & 1) ? times_i(e6[r >> 3]) : e6[r >> 3]; });
+    HX_SCHED_FENCE();
+    const cplx e7[4] = {T[T_F2 + 64 + hi4 * 4], T[T_F2 + 64 + hi4 * 4 + 1], T[T_F2 + 64 + hi4 * 4 + 2],
+                        T[T_F2 + 64 + hi4 * 4 + 3]};
+    stage<0>(d, [&](int r) { return ((r >> 1) & 1) ? times_i(e7[r >> 2]) : e7[r >> 2]; });
+  }
+  HX_SCHED_FENCE();
+  // transpose M2 -> M3
+  {
+    cplx *p2 = c.buf + base_m2(c);
+    HX_UNROLL
+    for (int r = 0; r < 16; ++r) p2[4 * r + (r >> 2)] = d[r];
+    HX_WAVE_SYNC();
+    const cplx *p3 = c.buf + base_m3(c);
+    HX_UNROLL
+    for (int r = 0; r < 16; ++r) d[r] = p3[r];
+    HX_WAVE_SYNC();
+  }
+  // pass F3: stages 8, 9 over position bits 1, 0
+  {
+    const cplx e8[2] = {T[T_F3 + lane * 2], T[T_F3 + lane * 2 + 1]};
+    stage<1>(d, [&](int r) { return ((r >> 2) & 1) ? times_i(e8[r >> 3]) : e8[r >> 3]; });
+    HX_SCHED_FENCE();
+    const cplx e9[4] = {T[T_F3 + 128 + lane * 4], T[T_F3 + 128 + lane * 4 + 1], T[T_F3 + 128 + lane * 4 + 2],
+                        T[T_F3 + 128 + lane * 4 + 3]};
+    stage<0>(d, [&](int r) { return ((r >> 1) & 1) ? times_i(e9[r >> 2]) : e9[r >> 2]; });
+  }
+  HX_SCHED_FENCE();
+}
+
+// ---- inverse transform (mapping M3 in, M1 out), untwist and accumulation into the torus regs.
+// Twiddle of DIT stage `half`, butterfly offset j: inv[half + j] = E[j*512/half] (nested tables),
+// E[J] = T_INV[J] for J < 256 and -i*T_INV[J-256] above.
+HX_DEV void wave_inverse_accumulate(cplx (&o)[16], uint64_t (&acc_re)[16], uint64_t (&acc_im)[16], WaveCtx c) {
+  HX_OPAQUE(c.lane);
+  c.hi4 = c.lane >> 2;
+  c.lo2 = c.lane & 3;
+  const int lane = c.lane, lo2 = c.lo2;
+  const cplx *T = c.T;
+  // pass I1: stages half = 1, 2 (plain), mapping M3
+  HX_UNROLL
+  for (int r = 0; r < 16; r += 2) {
+    const cplx x = o[r], y = o[r + 1];
+    o[r] = cplx{x.re + y.re, x.im + y.im};
+    o[r + 1] = cplx{x.re - y.re, x.im - y.im};
+  }
+  HX_UNROLL
+  for (int r = 0; r < 16; ++r)
+    if (!(r & 2)) {
+      const cplx x = o[r], y = o[r | 2];
+      if (r & 1) {  // j = 1: w = -i
+        o[r] = cplx{x.re + y.im, x.im - y.re};
+        o[r | 2] = cplx{x.re - y.im, x.im + y.re};
+      } else {
+        o[r] = cplx{x.re + y.re, x.im + y.im};
+        o[r | 2] = cplx{x.re - y.re, x.im - y.im};
+      }
+    }
+  HX_SCHED_FENCE();
+  // transpose M3 -> M2
+  {
+    cplx *p3 = c.buf + base_m3(c);
+    HX_UNROLL
+    for (int r = 0; r < 16; ++r) p3[r] = o[r];
+    HX_WAVE_SYNC();
+    const cplx *p2 = c.buf + base_m2(c);
+    HX_UNROLL
+    for (int r = 0; r < 16; ++r) o[r] = p2[4 * r + (r >> 2)];
+    HX_WAVE_SYNC();
+  }
+  // pass I2: stages half = 4, 8, 16, 32 over position bits 2..5 (= r bits 0..3); j = (r bits).lo2
+  {
+    cplx w3 = T[T_INV + (lo2 & 1) * 128];
+    if (lo2 & 2) w3 = times_mi(w3);
+    stage<0>(o, [&](int) { return w3; });
+    const cplx e4 = T[T_INV + lo2 * 64];
+    stage<1>(o, [&](int r) { return (r & 1) ? times_mi(e4) : e4; });
+    HX_SCHED_FENCE();
+    const cplx e5[2] = {T[T_INV + lo2 * 32], T[T_INV + (4 + lo2) * 32]};
+    stage<2>(o, [&](int r) { return (r & 2) ? times_mi(e5[r & 1]) : e5[r & 1]; });
+    HX_SCHED_FENCE();
+    const cplx e6[4] = {T[T_INV + lo2 * 16], T[T_INV + (4 + lo2) * 16], T[T_INV + (8 + lo2) * 16],
+                        T[T_INV + (12 + lo2) * 16]};
+    stage<3>(o, [&](int r) { return (r & 4) ? times_mi(e6[r & 3]) : e6[r & 3]; });
+  }
+  HX_SCHED_FENCE();
+  // transpose M2 -> M1
+  {
+    cplx *p2 = c.buf + base_m2(c);
+    HX_UNROLL
+    for (int r = 0; r < 16; ++r) p2[4 * r] = o[r];
+    HX_WAVE_SYNC();
+    const cplx *p1 = c.buf + base_m1(c);
+    HX_UNROLL
+    for (int r = 0; r < 16; ++r) o[r] = p1[68 * r];
+    HX_WAVE_SYNC();
+  }
+  // pass I3: stages half = 64..512 over position bits 6..9 (= r bits 0..3); j = (r bits).lane
+  {
+    int lane = c.lane;
+    HX_OPAQUE(lane);
+    cplx w7 = T[T_INV + (lane & 31) * 8];
+    if (lane & 32) w7 = times_mi(w7);
+    stage<0>(o, [&](int) { return w7; });
+    const cplx e8 = T[T_INV + lane * 4];
+    stage<1>(o, [&](int r) { return (r & 1) ? times_mi(e8) : e8; });
+    HX_SCHED_FENCE();
+    const cplx e9[2] = {T[T_INV + lane * 2], T[T_INV + (64 + lane) * 2]};
+    stage<2>(o, [&](int r) { return (r & 2) ? times_mi(e9[r & 1]) : e9[r & 1]; });
+    HX_SCHED_FENCE();
+    const cplx e10[4] = {T[T_INV + lane], T[T_INV + 64 + lane], T[T_INV + 128 + lane], T[T_INV + 192 + lane]};
+    stage<3>(o, [&](int r) { return (r & 4) ? times_mi(e10[r & 3]) : e10[r & 3]; });
+  }
+  HX_SCHED_FENCE();
+  // untwist, back to the torus, accumulate (fft/mod.rs:311-330)
+  int lane_u = c.lane;
+  HX_OPAQUE(lane_u);
+  const cplx *Tu_lo = T + T_U + lane_u;         // u[r*64 + lane]           (r < 8)
+  const cplx *Tu_hi = T + T_U + 1024 - lane_u;  // u[1024 - (r*64 + lane)]  (r >= 8), mirrored
+  HX_UNROLL
+  for (int r = 0; r < 16; ++r) {
+    cplx u;
+    if (r < 8) {
+      u = Tu_lo[r * 64];
+    } else {
+      const cplx e = Tu_hi[-r * 64];
+      u = (r == 8 && lane_u == 0) ? e : cplx{-e.im, -e.re};  // j = 512 is stored directly
+    }
+    const double tr = fma(-o[r].im, u.im, o[r].re * u.re);
+    const double ti = fma(o[r].im, u.re, o[r].re * u.im);
+    acc_re[r] += from_torus(tr);
+    acc_im[r] += from_torus(ti);
+    if ((r & 3) == 3) HX_SCHED_FENCE();
+  }
+}
+
+template <int LEVEL_CT, int BASE_LOG_CT>
+__global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables tb) {
+  HX_DYN_SMEM(smem);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = HX_UNIFORM(tid >> 6);
+  const int w = wave & 1;         // polynomial of the GLWE this wave owns (0 = mask, 1 = body)
+  const int pair = wave >> 1;     // which of the block's 4 LWEs
+  cplx *buf = (cplx *)(smem + (size_t)wave * BUF_BYTES);
+  const cplx *obuf = (const cplx *)(smem + (size_t)(wave ^ 1) * BUF_BYTES);
+  uint64_t *buf64 = (uint64_t *)buf;
+  const cplx *T = (const cplx *)(smem + (size_t)WAVES * BUF_BYTES);
+#if defined(TFHE_HIPEMU)
+  volatile uint32_t *flags = (volatile uint32_t *)(smem + (size_t)WAVES * BUF_BYTES + (size_t)T_TOTAL * 16);
+#else
+  uint32_t *flags = (uint32_t *)(smem + (size_t)WAVES * BUF_BYTES + (size_t)T_TOTAL * 16);
+#endif
+  auto *f_ready_me = flags + (pair * 2 + w) * 2, *f_ready_ot = flags + (pair * 2 + (w ^ 1)) * 2;
+  auto *r_done_me = f_ready_me + 1, *r_done_ot = f_ready_ot + 1;
+
+  const uint32_t level = LEVEL_CT ? (uint32_t)LEVEL_CT : a.level;
+  const uint32_t base_log = BASE_LOG_CT ? (uint32_t)BASE_LOG_CT : a.base_log;
+
+  // ---- one-time: compact twiddle table into LDS, flags to zero
+  {
+    cplx *Tw = (cplx *)(smem + (size_t)WAVES * BUF_BYTES);
+    for (int e = tid; e < T_TOTAL; e += TPB) {
+      cplx v{0.0, 0.0};
+      if (e < T_F2) {             // forward d = 0..3, even groups
+        const int x = e - T_F1;
+        v = ldg_c(tb.fwd, x == 0 ? 1 : x == 1 ? 2 : x < 4 ? 4 + 2 * (x - 2) : 8 + 2 * (x - 4));
+      } else if (e < T_F3) {      // forward d = 4..7
+        const int x = e - T_F2;
+        if (x < 16) v = ldg_c(tb.fwd, 16 + x);
+        else if (x < 32) v = ldg_c(tb.fwd, 32 + 2 * (x - 16));
+        else if (x < 64) v = ldg_c(tb.fwd, 64 + 2 * (x - 32));
+        else v = ldg_c(tb.fwd, 128 + 2 * (x - 64));
+      } else if (e < T_INV) {     // forward d = 8, 9, even groups only
+        const int x = e - T_F3;
+        v = (x < 128) ? ldg_c(tb.fwd, 256 + 2 * x) : ldg_c(tb.fwd, 512 + 2 * (x - 128));
+      } else if (e < T_U) {       // E[J] = inv[512 + J], J < 256
+        v = ldg_c(tb.inv, 512 + (e - T_INV));
+      } else {
+        v = ldg_c(tb.untw, e - T_U);
+      }
+      Tw[e] = v;
+    }
+    if (tid < FLAGS_BYTES / 4) flags[tid] = 0;
+  }
+  __syncthreads();
+
+  const uint32_t sample = blockIdx.x * LWES_PER_BLOCK + pair;
+  if (sample >= a.num_samples) return;  // whole pair leaves together; no later block barrier
+  const uint64_t *lwe = a.lwe_in + (size_t)a.in_idx[sample] * (a.n + 1);
+  const uint64_t *lut = a.lut + (size_t)a.lut_idx[sample] * 2 * N + (size_t)w * N;
+  const cplx *bsk = (const cplx *)a.bsk;
+  const WaveCtx ctx0{buf, obuf, T, lane, lane >> 2, lane & 3, w};
+  const WaveCtx &ctx = ctx0;
+
+  // ---- body modulus switch (with the centered-mean correction), redundantly per wave
+  uint64_t corr = 0;
+  if (a.ms_type == 1) {
+    uint64_t sh = 0;
+    int64_t sd = 0;
+    for (uint32_t i = lane; i < a.n; i += 64) {
+      uint64_t h;
+      int64_t dd;
+      centered_ms_terms(lwe[i], LOG2N2, h, dd);
+      sh += h;
+      sd += dd;
+    }
+    buf64[lane] = sh;
+    buf64[64 + lane] = (uint64_t)sd;
+    HX_WAVE_SYNC();
+    uint64_t th = 0, td = 0;
+    for (int l = 0; l < 64; ++l) {
+      th += buf64[l];
+      td += buf64[64 + l];
+    }
+    HX_WAVE_SYNC();
+    corr = centered_ms_finish(th, (int64_t)td, LOG2N2);
+  }
+  const uint32_t b_hat = (uint32_t)modulus_switch(lwe[a.n] + corr, LOG2N2);
+
+  // ---- accumulator registers: coefficient (r*64 + lane) and (1024 + r*64 + lane)
+  uint64_t acc_re[16], acc_im[16];
+  HX_UNROLL
+  for (int r = 0; r < 16; ++r) {
+    bool neg;
+    uint32_t src = monomial_div_src(r * 64 + lane, b_hat, N, neg);
+    uint64_t v = lut[src];
+    acc_re[r] = neg ? (uint64_t)0 - v : v;
+    src = monomial_div_src(1024 + r * 64 + lane, b_hat, N, neg);
+    v = lut[src];
+    acc_im[r] = neg ? (uint64_t)0 - v : v;
+  }
+
+  // ct1 = acc * X^a_hat - acc for my polynomial, decomposed at level index idx, as f64 points
+  // (polynomial_algorithms.rs:662-727: coefficient c takes +/- acc[(c - r) mod N], negated when
+  //  c < r, all signs flipped when a_hat >= N)
+  auto make_digits = [&](cplx (&d)[16], uint32_t a_hat, uint32_t idx) {
+    int lane = ctx.lane;
+    HX_OPAQUE(lane);
+    {
+      uint64_t *p = buf64 + lane;
+      HX_UNROLL
+      for (int r = 0; r < 16; ++r) {
+        p[r * 64] = acc_re[r];
+        p[1024 + r * 64] = acc_im[r];
+      }
+    }
+    HX_WAVE_SYNC();
+    const uint32_t rr = a_hat & (N - 1);
+    const bool odd = (a_hat & N) != 0;
+    const uint32_t t0 = (uint32_t)lane - rr;  // (c - rr) for c = lane; wraps mod 2^32, masked below
+    HX_UNROLL
+    for (int r = 0; r < 16; ++r) {
+      const uint32_t c0 = r * 64 + lane, c1 = 1024 + r * 64 + lane;
+      uint64_t s = buf64[(t0 + r * 64) & (N - 1)];
+      const uint64_t x0 = (((c0 < rr) != odd) ? (uint64_t)0 - s : s) - acc_re[r];
+      s = buf64[(t0 + 1024 + r * 64) & (N - 1)];
+      const uint64_t x1 = (((c1 < rr) != odd) ? (uint64_t)0 - s : s) - acc_im[r];
+      const int64_t d0 = decomp_digit(x0, base_log, level, idx);
+      const int64_t d1 = decomp_digit(x1, base_log, level, idx);
+      if constexpr (BASE_LOG_CT != 0 && BASE_LOG_CT <= 31)
+        d[r] = cplx{(double)(int32_t)d0, (double)(int32_t)d1};  // |digit| <= 2^(base_log-1): exact
+      else
+        d[r] = cplx{i64_to_f64(d0), i64_to_f64(d1)};
+      if ((r & 3) == 3) HX_SCHED_FENCE();
+    }
+    HX_WAVE_SYNC();
+  };
+
+  // publish my transform, fetch the partner's, multiply-accumulate with GGSW_i rows into dst
+  // (cc/fft_impl/fft64/crypto/ggsw.rs:616-697 order: row 0 then row 1 within a level)
+  auto mac = [&](cplx (&dst)[16], cplx (&d)[16], uint32_t i, uint32_t idx, uint32_t epoch) {
+    WaveCtx ctx = ctx0;
+    HX_OPAQUE(ctx.lane);
+    const int lane = ctx.lane;
+    {
+      cplx *p3 = buf + base_m3(ctx);
+      HX_UNROLL
+      for (int r = 0; r < 16; ++r) p3[r] = d[r];
+    }
+    HX_WAVE_SYNC();
+    if (lane == 0) flag_set(f_ready_me, epoch);
+    // key rows: [i][idx][row][c = w][storage s = r*64 + lane]
+    const cplx *b0 = bsk + ((((size_t)i * level + idx) * 2 + 0) * 2 + w) * n + lane;
+    const cplx *b1 = bsk + ((((size_t)i * level + idx) * 2 + 1) * 2 + w) * n + lane;
+    flag_wait(f_ready_ot, epoch);
+    const cplx *q3 = obuf + base_m3(ctx);
+    HX_UNROLL
+    for (int r = 0; r < 16; ++r) {
+      const cplx x = q3[r];          // partner's point at the same position
+      const cplx f0 = w ? x : d[r];  // row 0 transform
+      const cplx f1 = w ? d[r] : x;  // row 1 transform
+      const cplx t = (idx == 0) ? cmul_first(f0, b0[r * 64]) : cmul_add(f0, b0[r * 64], dst[r]);
+      dst[r] = cmul_add(f1, b1[r * 64], t);
+      if ((r & 3) == 3) HX_SCHED_FENCE();
+    }
+    HX_WAVE_SYNC();
+    if (lane == 0) flag_set(r_done_me, epoch);
+    flag_wait(r_done_ot, epoch);  // the partner must be done with my buffer before I reuse it
+  };
+
+  uint32_t it = 0;  // executed iterations (flag epoch)
+  for (uint32_t i = 0; i < a.n; ++i) {
+    const uint32_t a_hat = (uint32_t)modulus_switch(lwe[i], LOG2N2);
+    if (a_hat == 0) continue;  // uniform over the pair (bootstrap.rs:334)
+    ++it;
+    if constexpr (LEVEL_CT == 1) {
+      cplx d[16];
+      make_digits(d, a_hat, 0);
+      wave_forward(d, ctx);
+      mac(d, d, i, 0, it);  // in place: d becomes the Fourier-domain output of polynomial w
+      wave_inverse_accumulate(d, acc_re, acc_im, ctx);
+    } else {
+      cplx o[16];
+      for (uint32_t idx = 0; idx < level; ++idx) {
+        cplx d[16];
+        make_digits(d, a_hat, idx);
+        wave_forward(d, ctx);
+        mac(o, d, i, idx, (it - 1) * level + idx + 1);
+      }
+      wave_inverse_accumulate(o, acc_re, acc_im, ctx);
+    }
+  }
+
+  // ---- sample extraction (cc/algorithms/glwe_sample_extraction.rs:119-146); many-LUT outputs
+  const size_t out_sz = (size_t)N + 1;
+  for (uint32_t t = 0; t < a.num_many_lut; ++t) {
+    const uint32_t nth = t * a.lut_stride;
+    uint64_t *out = a.lwe_out + (size_t)t * a.num_samples * out_sz + (size_t)a.out_idx[sample] * out_sz;
+    if (w == 0) {
+      // mask: out[j] = A[nth - j] (j <= nth), -A[N + nth - j] otherwise; I hold A[c]
+      HX_UNROLL
+      for (int r = 0; r < 16; ++r) {
+        uint32_t c = r * 64 + lane;
+        out[c <= nth ? nth - c : N + nth - c] = c <= nth ? acc_re[r] : (uint64_t)0 - acc_re[r];
+        c += 1024;
+        out[c <= nth ? nth - c : N + nth - c] = c <= nth ? acc_im[r] : (uint64_t)0 - acc_im[r];
+      }
+    } else {
+      HX_UNROLL
+      for (int r = 0; r < 16; ++r) {
+        if ((uint32_t)(r * 64 + lane) == nth) out[N] = acc_re[r];
+        if ((uint32_t)(1024 + r * 64 + lane) == nth) out[N] = acc_im[r];
+      }
+    }
+  }
+}
+
+}  // namespace wavek
+
+bool pbs_fft_wave_supported(uint32_t N, uint32_t glwe_dim, uint32_t level) {
+  return N == 2048 && glwe_dim == 1 && level >= 1 && level <= 4;
+}
+
+template <int L, int B>
+static void launch_wave_t(hipStream_t st, const PbsArgs &a, const FftTables &tb) {
+  using namespace wavek;
+  HX_CHECK(hipFuncSetAttribute((const void *)pbs_fft_wave_kernel<L, B>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)SMEM_BYTES));
+  const unsigned blocks = (a.num_samples + LWES_PER_BLOCK - 1) / LWES_PER_BLOCK;
+  HX_LAUNCH((pbs_fft_wave_kernel<L, B>), dim3(blocks), dim3(TPB), SMEM_BYTES, st, a, tb);
+}
+
+void launch_pbs_fft_wave(hipStream_t st, const PbsArgs &a, const FftTables &tb) {
+  if (a.level == 1 && a.base_log == 23) launch_wave_t<1, 23>(st, a, tb);       // PARAM_MESSAGE_2_CARRY_2
+  else if (a.level == 1 && a.base_log == 22) launch_wave_t<1, 22>(st, a, tb);  // multi-bit g=4 GPU sets
+  else if (a.level == 2 && a.base_log == 15) launch_wave_t<2, 15>(st, a, tb);
+  else launch_wave_t<0, 0>(st, a, tb);                                          // any (base_log, level)
+}
+
+}  // namespace tfhe_hip

@@ -66,7 +66,7 @@ __global__ void __launch_bounds__(GenericCfg<N>::TPB) pbs_fft_generic_kernel(Pbs
         for (int c = 0; c < K1; ++c)
           for (int q = 0; q < PER; ++q) {
             const int pos = tid + q * TPB;
-            const cplx y = brow[(size_t)c * n + pos];
+            const cplx y = brow[(size_t)c * n + bsk_slot<N, K1>(pos)];
             facc[c][q] = first ? cmul_first(fbuf[pos], y) : cmul_add(fbuf[pos], y, facc[c][q]);
           }
         first = false;
@@ -153,7 +153,8 @@ __global__ void __launch_bounds__(GenericCfg<N>::TPB) pbs_ntt_generic_kernel(Pbs
 // one workgroup per polynomial: torus -> f64 tree order / Goldilocks NTT domain
 // (cc/algorithms/lwe_bootstrap_key_conversion.rs:20-150, 367-434)
 template <int N>
-__global__ void __launch_bounds__(GenericCfg<N>::TPB) bsk_to_fourier_kernel(const uint64_t *src, cplx *dst, FftTables tb) {
+__global__ void __launch_bounds__(GenericCfg<N>::TPB) bsk_to_fourier_kernel(const uint64_t *src, cplx *dst, FftTables tb,
+                                                                           bool wave_order) {
   constexpr int n = N / 2, TPB = GenericCfg<N>::TPB;
   HX_DYN_SMEM(smem);
   cplx *fbuf = (cplx *)smem;
@@ -164,7 +165,7 @@ __global__ void __launch_bounds__(GenericCfg<N>::TPB) bsk_to_fourier_kernel(cons
   __syncthreads();
   lds_fft_forward<N, TPB>(fbuf, tb.fwd, tid);
   cplx *o = dst + (size_t)blockIdx.x * n;
-  for (int j = tid; j < n; j += TPB) o[j] = fbuf[j];
+  for (int j = tid; j < n; j += TPB) o[wave_order ? bsk_slot<2048, 2>(j) : j] = fbuf[j];
 }
 
 template <int N>
@@ -219,8 +220,8 @@ void launch_pbs_ntt_generic(hipStream_t st, uint32_t N, uint32_t glwe_dim, const
   HX_DISPATCH_NK(launch_ntt, st, a, tb);
 }
 
-template <int N> static void launch_conv_f(hipStream_t st, const uint64_t *src, void *dst, size_t polys, const FftTables &tb) {
-  HX_LAUNCH((bsk_to_fourier_kernel<N>), dim3((unsigned)polys), dim3(GenericCfg<N>::TPB), (size_t)N * 8, st, src, (cplx *)dst, tb);
+template <int N> static void launch_conv_f(hipStream_t st, const uint64_t *src, void *dst, size_t polys, const FftTables &tb, bool wave_order) {
+  HX_LAUNCH((bsk_to_fourier_kernel<N>), dim3((unsigned)polys), dim3(GenericCfg<N>::TPB), (size_t)N * 8, st, src, (cplx *)dst, tb, wave_order);
 }
 template <int N> static void launch_conv_n(hipStream_t st, const uint64_t *src, void *dst, size_t polys, const NttTables &tb) {
   HX_LAUNCH((bsk_to_ntt_kernel<N>), dim3((unsigned)polys), dim3(GenericCfg<N>::TPB), (size_t)N * 8, st, src, (uint64_t *)dst, tb);
@@ -234,8 +235,9 @@ template <int N> static void launch_conv_n(hipStream_t st, const uint64_t *src, 
     case 4096: FN<4096>(__VA_ARGS__); break;                                \
     default: HX_PANIC("unsupported polynomial_size=%u", N);                 \
   }
-void launch_bsk_to_fourier(hipStream_t st, uint32_t N, const uint64_t *src_dev, void *dst, size_t polys, const FftTables &tb) {
-  HX_DISPATCH_N(launch_conv_f, st, src_dev, dst, polys, tb);
+void launch_bsk_to_fourier(hipStream_t st, uint32_t N, uint32_t glwe_dim, const uint64_t *src_dev, void *dst, size_t polys, const FftTables &tb) {
+  const bool wave_order = (N == 2048 && glwe_dim == 1);  // must agree with bsk_slot<N, K1>
+  HX_DISPATCH_N(launch_conv_f, st, src_dev, dst, polys, tb, wave_order);
 }
 void launch_bsk_to_ntt(hipStream_t st, uint32_t N, const uint64_t *src_dev, void *dst, size_t polys, const NttTables &tb) {
   HX_DISPATCH_N(launch_conv_n, st, src_dev, dst, polys, tb);
