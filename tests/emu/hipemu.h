@@ -55,6 +55,8 @@ void run_grid(dim3 grid, dim3 block, size_t smem, const std::function<void()> &b
 
 static inline void __syncthreads() { hipemu::yield_barrier(1); }
 static inline void hx_wave_sync_emu() { hipemu::yield_barrier(2); }
+static inline void __threadfence_block() {}
+static inline void __threadfence() {}
 
 static inline uint64_t __umul64hi(uint64_t a, uint64_t b) {
   return (uint64_t)(((unsigned __int128)a * b) >> 64);
