@@ -1,0 +1,72 @@
+"""CPU-only checks of the drop-in boundary: the product shared object must export every symbol
+that include/tfhe_hip_backend.h declares (no compute calls here — there is no GPU), the ctypes
+binding must cover exactly that set, and the product package must not depend on the oracle."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), os.pardir))
+HEADER = os.path.join(ROOT, "include", "tfhe_hip_backend.h")
+LIB = os.path.join(ROOT, "tfhe-rs_amd", "lib", "libtfhe_hip_backend.so")
+
+
+def declared_symbols():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = re.findall(r"\b((?:cuda|scratch_cuda|cleanup_cuda|has_support_to_cuda|hip)_[a-z0-9_]+)\s*\(", text)
+    return sorted(set(names))
+
+
+def test_header_declares_the_reference_entry_points():
+    syms = declared_symbols()
+    for must in ("cuda_create_stream_ffi", "cuda_malloc_async", "cuda_drop",
+                 "cuda_convert_lwe_programmable_bootstrap_key_64_async",
+                 "scratch_cuda_programmable_bootstrap_64_async", "cuda_programmable_bootstrap_64_async",
+                 "cleanup_cuda_programmable_bootstrap_64", "cuda_multi_bit_programmable_bootstrap_64_async",
+                 "cuda_keyswitch_lwe_ciphertext_vector_64_64_async", "cuda_keyswitch_gemm_64_64_async",
+                 "cuda_glwe_sample_extract_64_async", "cuda_centered_modulus_switch_64_async"):
+        assert must in syms
+
+
+def test_shared_object_exports_every_declared_symbol():
+    if not os.path.exists(LIB):
+        import __graft_entry__ as g
+        g.build()
+    out = subprocess.check_output(["nm", "-D", "--defined-only", LIB], text=True)
+    exported = {line.split()[-1] for line in out.splitlines() if " T " in line}
+    missing = [s for s in declared_symbols() if s not in exported]
+    assert not missing, f"declared in the header but not exported: {missing}"
+
+
+def test_ctypes_binding_matches_header():
+    import tfhe_rs_amd  # noqa: F401
+    from tfhe_rs_amd import ffi
+    assert sorted(ffi.SIGNATURES) == declared_symbols()
+    # loading the product library resolves every symbol (dlopen only, nothing is launched)
+    if os.path.exists(LIB):
+        lib = ffi.Library(LIB)
+        assert b"gfx950" in lib.hip_backend_version()
+
+
+def test_product_package_does_not_touch_the_oracle():
+    """No file of the product package imports, includes, links or opens anything of oracle/ or
+    tests/ (comments may mention the word)."""
+    pkg = os.path.join(ROOT, "tfhe-rs_amd")
+    bad = re.compile(r"tfhe_oracle|libtfhe_oracle|orc_[a-z]|oracle/|from tests|import tests|tests\.oracle|"
+                     r"#include\s*[\"<][^\">]*oracle|_emu\.so")
+    for dirpath, dirs, files in os.walk(pkg):
+        dirs[:] = [d for d in dirs if d not in ("build", "__pycache__")]
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp", "Makefile")):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                m = bad.search(text)
+                assert not m, f"{os.path.join(dirpath, f)}: {m.group(0)}"
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    import tfhe_rs_amd  # noqa: F401
+    from tfhe_rs_amd import ffi
+    with pytest.raises(ImportError):
+        ffi.Library(str(tmp_path / "nope.so"))
