@@ -414,10 +414,14 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
     }
     HX_WAVE_SYNC();
     if (lane == 0) flag_set(f_ready_me, epoch);
-    // key rows: [i][idx][row][c = w][storage s = r*64 + lane]
-    const cplx *b0 = bsk + ((((size_t)i * level + idx) * 2 + 0) * 2 + w) * n + lane;
-    const cplx *b1 = bsk + ((((size_t)i * level + idx) * 2 + 1) * 2 + w) * n + lane;
     flag_wait(f_ready_ot, epoch);
+    // key rows: [i][idx][row][c = w][storage s = r*64 + lane].  The lane offset is made opaque
+    // AFTER the wait so the 32 key loads are not all hoisted above it (that costs 128 VGPRs and
+    // pushes the accumulator into scratch); they are issued chunk by chunk below.
+    int lane_k = ctx.lane;
+    HX_OPAQUE(lane_k);
+    const cplx *b0 = bsk + ((((size_t)i * level + idx) * 2 + 0) * 2 + w) * n + lane_k;
+    const cplx *b1 = bsk + ((((size_t)i * level + idx) * 2 + 1) * 2 + w) * n + lane_k;
     const cplx *q3 = obuf + base_m3(ctx);
     HX_UNROLL
     for (int r = 0; r < 16; ++r) {
@@ -426,6 +430,10 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
       const cplx f1 = w ? d[r] : x;  // row 1 transform
       const cplx t = (idx == 0) ? cmul_first(f0, b0[r * 64]) : cmul_add(f0, b0[r * 64], dst[r]);
       dst[r] = cmul_add(f1, b1[r * 64], t);
+      // pin the product here: otherwise the FMAs are sunk below the flag wait that follows and
+      // all 32 key loads stay live across it
+      HX_OPAQUE(dst[r].re);
+      HX_OPAQUE(dst[r].im);
       if ((r & 3) == 3) HX_SCHED_FENCE();
     }
     HX_WAVE_SYNC();

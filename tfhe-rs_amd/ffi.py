@@ -81,7 +81,8 @@ class Library:
     """Loaded backend library with typed symbols."""
 
     def __init__(self, path=None):
-        self.path = path or DEFAULT_LIB
+        # TFHE_HIP_BACKEND_LIB: alternative build of the same library (kernel experiments)
+        self.path = path or os.environ.get("TFHE_HIP_BACKEND_LIB") or DEFAULT_LIB
         if not os.path.exists(self.path):
             raise ImportError(
                 f"{self.path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
