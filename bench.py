@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH, help="LWEs per GPU per step (default: the metric's 4096)")
     ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 generic LDS kernel, 2 throughput kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-verify", action="store_true", help="skip the decrypt check (timing-ablation builds only)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="PBS count of the CPU baseline sample (0 = auto)")
     args = ap.parse_args()
 
@@ -127,7 +128,7 @@ def main():
     out = d_out.to_lwe_ciphertext_list(streams)
     check = rng.choice(B, size=min(B, 256), replace=False)
     bad = [int(i) for i in check if decrypt_big(p, keys, out[i]) != f(msgs[i])]
-    assert not bad, f"PBS outputs failed to decrypt at rows {bad[:8]}"
+    assert args.no_verify or not bad, f"PBS outputs failed to decrypt at rows {bad[:8]}"
     lib.cleanup_cuda_programmable_bootstrap_64(s, g, C.byref(buf))
 
     if rank != 0:

@@ -65,6 +65,10 @@ def test_arith_hooks_match_oracle(kind):
         got = run_arith(lib, st, 2, xs, p0=bl, p1=lv, out_per=lv).reshape(-1, lv)
         for g, x in zip(got, xs):
             assert [int(v) for v in g.astype(np.int64)] == [int(v) for v in orc.decompose(int(x), bl, lv)]
+    # single-level fast path used by the throughput kernel == the two-step decomposer
+    for bl in (23, 22, 15, 30, 1, 2):
+        got = run_arith(lib, st, 11, xs, p0=bl).astype(np.int64)
+        assert all(int(g) == int(orc.decompose(int(x), bl, 1)[0]) for g, x in zip(got, xs))
     # f64 conversions: reference KAT values + random torus fractions + exact halves
     fl = np.array([0.0, -0.0, 0.5, -0.5, 1.5, 2.5, 0.25, 1e-310, 37.1242161, -37.1242161, 2.0 ** 52 + 0.5, 1e15 / 3,
                    0.49999999999999994, 0.5000000000000001] + list(rng.normal(0, 1e6, size=1500)), dtype=np.float64)

@@ -69,6 +69,19 @@ HX_DEV int64_t decomp_digit(uint64_t x, uint32_t base_log, uint32_t level, uint3
   return d;
 }
 
+// Single-level decomposition (level == 1, base_log <= 31) from the HIGH dword of x only.
+// With one level the digit returned by decompose_one_level equals the initial state:
+//   res2 = state mod B = res; state' = state >> b is 0 or -1; carry = need_balance  =>  digit = res - nb*B,
+// and x >> (63 - b) reads bits of the high dword only.  Checked against the two-step form by
+// the test hooks (op 11) and by every l = 1 parity test.
+HX_DEV int32_t decomp_digit_l1_hi(uint32_t x_hi, uint32_t base_log) {
+  const uint32_t t = x_hi >> (31 - base_log);
+  const uint32_t rb = t & 1;
+  const uint32_t res = ((t + 1) >> 1) & ((1u << base_log) - 1);
+  const uint32_t nb = (((res - 1) | (rb << (base_log - 1))) & res) >> (base_log - 1);
+  return (int32_t)(res - (nb << base_log));
+}
+
 // ------------------------------------------------------------------ monomial indexing
 // coefficient j of  in * X^{deg}  (negacyclic), cc/algorithms/polynomial_algorithms.rs:662-727:
 // returns the source index and whether the source is negated.

@@ -390,12 +390,18 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
       const uint64_t x0 = (((c0 < rr) != odd) ? (uint64_t)0 - s : s) - acc_re[r];
       s = buf64[(t0 + 1024 + r * 64) & (N - 1)];
       const uint64_t x1 = (((c1 < rr) != odd) ? (uint64_t)0 - s : s) - acc_im[r];
-      const int64_t d0 = decomp_digit(x0, base_log, level, idx);
-      const int64_t d1 = decomp_digit(x1, base_log, level, idx);
-      if constexpr (BASE_LOG_CT != 0 && BASE_LOG_CT <= 31)
-        d[r] = cplx{(double)(int32_t)d0, (double)(int32_t)d1};  // |digit| <= 2^(base_log-1): exact
-      else
-        d[r] = cplx{i64_to_f64(d0), i64_to_f64(d1)};
+      if constexpr (LEVEL_CT == 1 && BASE_LOG_CT != 0 && BASE_LOG_CT <= 30) {
+        // one level: the digit is the decomposer's initial state and depends on the high dword only
+        d[r] = cplx{(double)decomp_digit_l1_hi((uint32_t)(x0 >> 32), BASE_LOG_CT),
+                    (double)decomp_digit_l1_hi((uint32_t)(x1 >> 32), BASE_LOG_CT)};
+      } else {
+        const int64_t d0 = decomp_digit(x0, base_log, level, idx);
+        const int64_t d1 = decomp_digit(x1, base_log, level, idx);
+        if constexpr (BASE_LOG_CT != 0 && BASE_LOG_CT <= 31)
+          d[r] = cplx{(double)(int32_t)d0, (double)(int32_t)d1};  // |digit| <= 2^(base_log-1): exact
+        else
+          d[r] = cplx{i64_to_f64(d0), i64_to_f64(d1)};
+      }
       if ((r & 3) == 3) HX_SCHED_FENCE();
     }
     HX_WAVE_SYNC();
@@ -414,27 +420,54 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
     }
     HX_WAVE_SYNC();
     if (lane == 0) flag_set(f_ready_me, epoch);
+    // key rows: [i][idx][row][c = w][storage s = r*64 + lane], consumed in 4 chunks of 4 points;
+    // chunk c+1 is in flight while chunk c is multiplied, chunk 0 is requested before the wait.
+    const cplx *b0 = bsk + ((((size_t)i * level + idx) * 2 + 0) * 2 + w) * n + lane;
+    const cplx *b1 = bsk + ((((size_t)i * level + idx) * 2 + 1) * 2 + w) * n + lane;
+    cplx k0[4], k1[4];
+    HX_UNROLL
+    for (int j = 0; j < 4; ++j) {
+      k0[j] = b0[j * 64];
+      k1[j] = b1[j * 64];
+    }
+    HX_SCHED_FENCE();
     flag_wait(f_ready_ot, epoch);
-    // key rows: [i][idx][row][c = w][storage s = r*64 + lane].  The lane offset is made opaque
-    // AFTER the wait so the 32 key loads are not all hoisted above it (that costs 128 VGPRs and
-    // pushes the accumulator into scratch); they are issued chunk by chunk below.
-    int lane_k = ctx.lane;
-    HX_OPAQUE(lane_k);
-    const cplx *b0 = bsk + ((((size_t)i * level + idx) * 2 + 0) * 2 + w) * n + lane_k;
-    const cplx *b1 = bsk + ((((size_t)i * level + idx) * 2 + 1) * 2 + w) * n + lane_k;
     const cplx *q3 = obuf + base_m3(ctx);
     HX_UNROLL
-    for (int r = 0; r < 16; ++r) {
-      const cplx x = q3[r];          // partner's point at the same position
-      const cplx f0 = w ? x : d[r];  // row 0 transform
-      const cplx f1 = w ? d[r] : x;  // row 1 transform
-      const cplx t = (idx == 0) ? cmul_first(f0, b0[r * 64]) : cmul_add(f0, b0[r * 64], dst[r]);
-      dst[r] = cmul_add(f1, b1[r * 64], t);
-      // pin the product here: otherwise the FMAs are sunk below the flag wait that follows and
-      // all 32 key loads stay live across it
-      HX_OPAQUE(dst[r].re);
-      HX_OPAQUE(dst[r].im);
-      if ((r & 3) == 3) HX_SCHED_FENCE();
+    for (int ch = 0; ch < 4; ++ch) {
+      cplx n0[4], n1[4];
+      if (ch < 3) {
+        HX_UNROLL
+        for (int j = 0; j < 4; ++j) {
+          n0[j] = b0[((ch + 1) * 4 + j) * 64];
+          n1[j] = b1[((ch + 1) * 4 + j) * 64];
+        }
+      }
+      HX_UNROLL
+      for (int j = 0; j < 4; ++j) {
+        const int r = ch * 4 + j;
+        const cplx x = q3[r];  // partner's point at the same position
+        cplx t;
+        if (w == 0) {          // I hold row 0, the partner row 1
+          t = (idx == 0) ? cmul_first(d[r], k0[j]) : cmul_add(d[r], k0[j], dst[r]);
+          dst[r] = cmul_add(x, k1[j], t);
+        } else {
+          t = (idx == 0) ? cmul_first(x, k0[j]) : cmul_add(x, k0[j], dst[r]);
+          dst[r] = cmul_add(d[r], k1[j], t);
+        }
+        // pin the product here: otherwise the FMAs are sunk below the flag wait that follows and
+        // the key loads stay live across it
+        HX_OPAQUE(dst[r].re);
+        HX_OPAQUE(dst[r].im);
+      }
+      if (ch < 3) {
+        HX_UNROLL
+        for (int j = 0; j < 4; ++j) {
+          k0[j] = n0[j];
+          k1[j] = n1[j];
+        }
+      }
+      HX_SCHED_FENCE();
     }
     HX_WAVE_SYNC();
     if (lane == 0) flag_set(r_done_me, epoch);

@@ -9,6 +9,7 @@ namespace tfhe_hip {
 //     3 from_torus(bits-as-f64)          4 f64_to_i64_sat(bits-as-f64)
 //     5 i64_to_f64(x) (out = f64 bits)   6 gl_modswitch_from_pow2   7 gl_modswitch_to_pow2
 //     8 gl_mul(in[2i], in[2i+1])         9 gl_add   10 gl_sub
+//     11 decomp_digit_l1_hi(hi32(x), base_log=p0)  (single-level fast path of the wave kernel)
 __global__ void test_arith_kernel(uint32_t op, const uint64_t *in, uint64_t *out, uint32_t count, uint32_t p0,
                                   uint32_t p1) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -26,6 +27,7 @@ __global__ void test_arith_kernel(uint32_t op, const uint64_t *in, uint64_t *out
     case 8: out[i] = gl_mul(in[2 * i], in[2 * i + 1]); break;
     case 9: out[i] = gl_add(in[2 * i], in[2 * i + 1]); break;
     case 10: out[i] = gl_sub(in[2 * i], in[2 * i + 1]); break;
+    case 11: out[i] = (uint64_t)(int64_t)decomp_digit_l1_hi((uint32_t)(in[i] >> 32), p0); break;
     default: out[i] = 0;
   }
 }
