@@ -86,6 +86,24 @@ def main():
     kats["param_message_2_carry_2"] = {"cite": src + ":28-47", "n": 918, "k": 1, "N": 2048, "pbs_base_log": 23,
                                        "pbs_level": 1, "ks_base_log": 4, "ks_level": 4}
 
+    # ---- SHA-256 of the reference's golden PBS vectors (toy parameter set), apps/test-vectors/checksums.sha256
+    src = "apps/test-vectors/checksums.sha256"
+    sums = {}
+    full = os.path.join(REF, src)
+    if os.path.exists(full):
+        for line in open(full):
+            h, path = line.split()
+            if "/toy_params/" in path:
+                sums[os.path.basename(path).replace(".cbor", "")] = h
+        kats["sources"][src] = "read from the reference tree"
+    else:  # keep what is already committed
+        sums = json.load(open(OUT))["test_vector_sha256_toy"]["sha256"]
+        kats["sources"][src] = "unverified (reference tree absent)"
+    kats["test_vector_sha256_toy"] = {
+        "cite": src + ":1-36 ; generator apps/test-vectors/src/main.rs:121-365 (RAND_SEED 0x74666865, toy params "
+                      "n=10,k=1,N=256, PBS 24x1, KS 37x1, noise stddev 0)",
+        "sha256": sums}
+
     with open(OUT, "w") as f:
         json.dump(kats, f, indent=1, sort_keys=True)
     print("wrote", OUT)

@@ -282,3 +282,12 @@ def ntt_inverse(data, normalize=True):
         lib().orc_ntt_normalize(_p(data), u32(len(data)))
     lib().orc_ntt_inverse(_p(data), u32(len(data)))
     return data
+
+
+def blind_rotate_exact(lut, msed, bsk_std, n, k, N, base_log, level):
+    """acc <- blind rotation of `lut` by the modulus-switched LWE `msed` (n+1 words), exact products."""
+    acc = _u64(lut).copy()
+    msed = _u64(msed)
+    bsk_std = _u64(bsk_std)
+    lib().orc_blind_rotate_exact(_p(acc), _p(msed), _p(bsk_std), u32(n), u32(k), u32(N), u32(base_log), u32(level))
+    return acc

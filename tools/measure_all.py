@@ -1,0 +1,131 @@
+#!/usr/bin/env python3
+"""Secondary measurements on one MI355X (everything except the headline bench.py line):
+keyswitch, KS->PBS pipeline, NTT engine, multi-bit PBS, N=1024/k=2 datapoint, batch sweep.
+Throughput-only runs use uniform-random key material like the reference's own benches
+(tfhe-benchmark/benches/core_crypto/pbs_bench.rs:45-58): timing is data independent.
+Prints one JSON object per line."""
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), os.pardir))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import tfhe_rs_amd  # noqa: E402,F401
+from tfhe_rs_amd import core_crypto_gpu as gpu  # noqa: E402
+from tfhe_rs_amd import ffi  # noqa: E402
+from tests.common import C1, C1P, C4  # noqa: E402
+
+lib = ffi.default_library()
+streams = gpu.CudaStreams.new_single_gpu(0)
+S, G = streams.ptr[0], 0
+rng = np.random.default_rng(7)
+
+
+def rand_u64(n):
+    return rng.integers(0, 1 << 64, size=n, dtype=np.uint64)
+
+
+def timed(fn, steps=3, warmup=1):
+    for _ in range(warmup):
+        fn()
+    lib.cuda_synchronize_device(G)
+    e0, e1 = lib.hip_event_create(), lib.hip_event_create()
+    lib.hip_event_record(e0, S)
+    for _ in range(steps):
+        fn()
+    lib.hip_event_record(e1, S)
+    ms = lib.hip_event_elapsed_ms(e0, e1) / steps
+    lib.hip_event_destroy(e0)
+    lib.hip_event_destroy(e1)
+    return ms
+
+
+def emit(**kw):
+    print(json.dumps(kw), flush=True)
+
+
+def pbs_case(p, B, engine="fft64", kernel=0, steps=3):
+    k1 = p.k + 1
+    if p.grouping:
+        bsk_h = rand_u64((p.n // p.grouping) * (1 << p.grouping) * p.pbs_level * k1 * k1 * p.N)
+        bsk = gpu.CudaLweMultiBitBootstrapKey.from_lwe_multi_bit_bootstrap_key(
+            bsk_h, p.n, p.k, p.N, p.pbs_base_log, p.pbs_level, p.grouping, streams)
+    else:
+        bsk_h = rand_u64(p.n * p.pbs_level * k1 * k1 * p.N)
+        bsk = gpu.CudaLweBootstrapKey.from_lwe_bootstrap_key(bsk_h, p.n, p.k, p.N, p.pbs_base_log, p.pbs_level,
+                                                             streams, ms_noise_reduction=bool(p.ms_type),
+                                                             engine=engine)
+    d_in = gpu.CudaLweCiphertextList.from_lwe_ciphertext_list(rand_u64(B * (p.n + 1)).reshape(B, -1), streams)
+    d_out = gpu.CudaLweCiphertextList.new(p.k * p.N, B, streams)
+    d_lut = gpu.CudaGlweCiphertextList.from_glwe_ciphertext_list(rand_u64(k1 * p.N), p.k, p.N, streams)
+    idx = gpu.CudaVec.from_cpu_async(np.arange(B, dtype=np.uint64), streams)
+    lidx = gpu.CudaVec.from_cpu_async(np.zeros(B, dtype=np.uint64), streams)
+    buf = C.c_void_p()
+    lib.hip_backend_set_fft_kernel(kernel)
+    if p.grouping:
+        lib.scratch_cuda_multi_bit_programmable_bootstrap_64_async(S, G, C.byref(buf), p.k, p.N, p.pbs_level, B, True)
+
+        def run():
+            lib.cuda_multi_bit_programmable_bootstrap_64_async(
+                S, G, d_out.d_vec.ptr, idx.ptr, d_lut.d_vec.ptr, lidx.ptr, d_in.d_vec.ptr, idx.ptr, bsk.d_vec.ptr,
+                buf, p.n, p.k, p.N, p.grouping, p.pbs_base_log, p.pbs_level, B, 1, 0)
+    else:
+        lib.scratch_cuda_programmable_bootstrap_64_async(S, G, C.byref(buf), p.n, p.k, p.N, p.pbs_level, B, True,
+                                                         p.ms_type)
+        launch = (lib.cuda_programmable_bootstrap_64_async if engine == "fft64"
+                  else lib.hip_programmable_bootstrap_ntt64_async)
+
+        def run():
+            launch(S, G, d_out.d_vec.ptr, idx.ptr, d_lut.d_vec.ptr, lidx.ptr, d_in.d_vec.ptr, idx.ptr, bsk.d_vec.ptr,
+                   buf, p.n, p.k, p.N, p.pbs_base_log, p.pbs_level, B, 1, 0)
+    ms = timed(run, steps=steps)
+    kid = lib.hip_backend_last_pbs_kernel()
+    if p.grouping:
+        lib.cleanup_cuda_multi_bit_programmable_bootstrap_64(S, G, C.byref(buf))
+    else:
+        lib.cleanup_cuda_programmable_bootstrap_64(S, G, C.byref(buf))
+    lib.hip_backend_set_fft_kernel(0)
+    emit(what="pbs", params=p.name, engine=engine if not p.grouping else "multi_bit_fft64", kernel_id=kid, batch=B,
+         ms=ms, pbs_per_s=B / ms * 1e3)
+    return ms
+
+
+def ks_case(p, B, steps=5):
+    n_in, n_out = p.k * p.N, p.n
+    ksk = gpu.CudaLweKeyswitchKey.from_lwe_keyswitch_key(rand_u64(n_in * p.ks_level * (n_out + 1)), n_in, n_out,
+                                                         p.ks_base_log, p.ks_level, streams)
+    d_in = gpu.CudaLweCiphertextList.from_lwe_ciphertext_list(rand_u64(B * (n_in + 1)).reshape(B, -1), streams)
+    d_out = gpu.CudaLweCiphertextList.new(n_out, B, streams)
+    idx = gpu.CudaVec.from_cpu_async(np.arange(B, dtype=np.uint64), streams)
+    ms = timed(lambda: gpu.cuda_keyswitch_lwe_ciphertext(ksk, d_in, d_out, idx, idx, True, streams), steps=steps)
+    ksk_bytes = n_in * p.ks_level * (n_out + 1) * 8
+    emit(what="keyswitch", params=p.name, batch=B, ms=ms, ks_per_s=B / ms * 1e3,
+         algorithmic_GBps=(ksk_bytes + (n_in + 1 + n_out + 1) * 8) * B / ms / 1e6,
+         ksk_once_GBps=(ksk_bytes + B * (n_in + n_out + 2) * 8) / ms / 1e6)
+    return ms
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["ks", "wave", "generic", "ntt", "mb", "n1024", "sweep"]
+    if "ks" in which:
+        ks_ms = ks_case(C1, 4096)
+    if "wave" in which:
+        w_ms = pbs_case(C1, 4096, kernel=2, steps=5)
+        if "ks" in which:
+            emit(what="ks+pbs pipeline (sum of the two launches)", params=C1.name, batch=4096, ms=ks_ms + w_ms,
+                 ks_pbs_per_s=4096 / (ks_ms + w_ms) * 1e3)
+    if "generic" in which:
+        pbs_case(C1, 4096, kernel=1)
+    if "ntt" in which:
+        pbs_case(C1, 1024, engine="ntt64", steps=2)
+    if "mb" in which:
+        pbs_case(C4, 512, steps=2)
+    if "n1024" in which:
+        pbs_case(C1P, 4096, steps=3)
+    if "sweep" in which:
+        for B in (1, 4, 64, 256, 1024, 2048, 8192):
+            pbs_case(C1, B, kernel=2, steps=3)
