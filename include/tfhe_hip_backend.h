@@ -181,11 +181,27 @@ void hip_programmable_bootstrap_ntt64_async(
     uint32_t polynomial_size, uint32_t base_log, uint32_t level_count,
     uint32_t num_samples, uint32_t num_many_lut, uint32_t lut_stride);
 
+/* Exact-integer engine (negacyclic convolution mod 2^64 on the standard-domain key,
+ * cc/algorithms/lwe_programmable_bootstrapping/karatsuba_pbs.rs:71-116,199-413).  O(N^2): a
+ * verification engine; it reproduces the reference's golden *_karatsuba vectors bit for bit. */
+void hip_convert_lwe_programmable_bootstrap_key_exact64_async(
+    void *stream, uint32_t gpu_index, void *dest, void const *src,
+    uint32_t input_lwe_dim, uint32_t glwe_dim, uint32_t level_count,
+    uint32_t polynomial_size);
+void hip_programmable_bootstrap_exact64_async(
+    void *stream, uint32_t gpu_index, void *lwe_array_out,
+    void const *lwe_output_indexes, void const *lut_vector,
+    void const *lut_vector_indexes, void const *lwe_array_in,
+    void const *lwe_input_indexes, void const *bootstrapping_key,
+    int8_t *buffer, uint32_t lwe_dimension, uint32_t glwe_dimension,
+    uint32_t polynomial_size, uint32_t base_log, uint32_t level_count,
+    uint32_t num_samples, uint32_t num_many_lut, uint32_t lut_stride);
+
 /* Select which f64 kernel serves cuda_programmable_bootstrap_64_async:
  * 0 = automatic (throughput kernel when the parameter set supports it), 1 = generic LDS
  * kernel, 2 = throughput kernel (abort if unsupported).  Both give identical bits. */
 void hip_backend_set_fft_kernel(uint32_t which);
-/* last launched PBS kernel, for tests: 1 generic f64, 2 wave f64, 3 generic ntt */
+/* last launched PBS kernel, for tests: 1 generic f64, 2 wave f64, 3 generic ntt, 4 multi-bit, 5 exact */
 uint32_t hip_backend_last_pbs_kernel(void);
 const char *hip_backend_version(void);
 

@@ -131,7 +131,8 @@ def test_transforms_match_oracle(kind, N):
 # ------------------------------------------------------------------ PBS, classic
 PBS_CASES = [(TOY_K1, "fft64"), (TOY_K1, "ntt64"), (TOY_K1_L1, "fft64"), (TOY_K2, "fft64"), (TOY_K2, "ntt64"),
              (TOY_K3, "fft64"), (TOY_K3, "ntt64"), (TOY_2048, "fft64"), (TOY_2048, "ntt64"),
-             (TOY_2048_L2, "fft64"), (TOY_1024_K2, "fft64"), (TOY_1024_K2, "ntt64")]
+             (TOY_2048_L2, "fft64"), (TOY_1024_K2, "fft64"), (TOY_1024_K2, "ntt64"),
+             (TOY_K1, "exact64"), (TOY_K2, "exact64"), (TOY_K3, "exact64")]
 
 
 @pytest.mark.parametrize("kind", BACKENDS)

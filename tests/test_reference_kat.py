@@ -57,3 +57,60 @@ def test_f64_path_agrees_in_phase_with_the_pinned_exact_path(vectors):
         d = (pf - pe) % (1 << 64)
         assert min(d, (1 << 64) - d) < (1 << 50)
         assert ((pe + (1 << 58)) >> 59) % 32 == f(kv.MSG_A)
+
+
+# ------------------------------------------------------------------ the BACKEND against the reference's bytes
+# Same golden vectors, but keyswitch / modulus switch / blind rotation + sample extraction are now
+# computed by the backend through the C ABI ([emu] = kernel sources on the host, [hip] = MI355X)
+# and the SHA-256 of ITS outputs must equal the reference's checksums.
+BACKENDS = [pytest.param("emu", id="emu"), pytest.param("hip", id="hip", marks=pytest.mark.gpu)]
+
+
+@pytest.mark.parametrize("kind", BACKENDS)
+def test_backend_reproduces_reference_golden_vectors(kind, vectors):
+    from tfhe_rs_amd import core_crypto_gpu as gpu
+    from .harness import use_backend
+    _, m = vectors
+    P = kv.TOY
+    n, k, N = P["n"], P["k"], P["N"]
+    lib = use_backend(kind)
+    st = gpu.CudaStreams.new_single_gpu(0)
+
+    # keyswitch (big -> small) of lwe_a with the regenerated ksk  ==> lwe_ks.cbor
+    ksk = gpu.CudaLweKeyswitchKey.from_lwe_keyswitch_key(m["ksk"], k * N, n, P["ks_base_log"], P["ks_level"], st)
+    d_in = gpu.CudaLweCiphertextList.from_lwe_ciphertext_list(m["lwe_a"][None, :], st)
+    d_ks = gpu.CudaLweCiphertextList.new(n, 1, st)
+    idx = gpu.CudaVec.from_cpu_async(np.zeros(1, dtype=np.uint64), st)
+    gpu.cuda_keyswitch_lwe_ciphertext(ksk, d_in, d_ks, idx, idx, True, st)
+    lwe_ks = d_ks.to_lwe_ciphertext_list(st)[0]
+    assert kv.sha256_hex(kv.ser_lwe_ciphertext(lwe_ks)) == SUMS["lwe_ks"]
+
+    # modulus switch helper  ==> lwe_ms.cbor (values re-aligned on the MSBs as the reference stores them)
+    log_mod = (2 * N).bit_length() - 1
+    d_ms = gpu.CudaVec(n + 1, st)
+    gpu.cuda_modulus_switch_ciphertext(d_ms, d_ks.d_vec, n, log_mod, False, st)
+    msed = d_ms.copy_to_cpu(st)
+    assert kv.sha256_hex(kv.ser_lwe_ciphertext(msed << np.uint64(64 - log_mod), native=False,
+                                               modulus=1 << log_mod)) == SUMS["lwe_ms"]
+
+    # PBS with the exact engine (MS -> blind rotation -> sample extract) ==> lwe_after_*_pbs_karatsuba.cbor
+    bsk = gpu.CudaLweBootstrapKey.from_lwe_bootstrap_key(m["bsk"], n, k, N, P["pbs_base_log"], P["pbs_level"], st,
+                                                         ms_noise_reduction=False, engine="exact64")
+    p = 1 << P["msg_bits"]
+    for name, f in (("id", lambda x: x), ("spec", lambda x: (2 * x) % p)):
+        lut = orc.generate_lut(k, N, p, 1 << 59, f)
+        d_lut = gpu.CudaGlweCiphertextList.from_glwe_ciphertext_list(lut, k, N, st)
+        d_out = gpu.CudaLweCiphertextList.new(k * N, 1, st)
+        gpu.cuda_programmable_bootstrap_lwe_ciphertext(d_ks, d_out, d_lut, idx, idx, idx, bsk, st)
+        assert lib.hip_backend_last_pbs_kernel() == 5
+        out = d_out.to_lwe_ciphertext_list(st)[0]
+        assert kv.sha256_hex(kv.ser_lwe_ciphertext(out)) == SUMS[f"lwe_after_{name}_pbs_karatsuba"]
+        # and the production engines land on the same message, within 2^50 in phase
+        for engine in ("fft64", "ntt64"):
+            b2 = gpu.CudaLweBootstrapKey.from_lwe_bootstrap_key(m["bsk"], n, k, N, P["pbs_base_log"],
+                                                                P["pbs_level"], st, engine=engine)
+            d_o2 = gpu.CudaLweCiphertextList.new(k * N, 1, st)
+            gpu.cuda_programmable_bootstrap_lwe_ciphertext(d_ks, d_o2, d_lut, idx, idx, idx, b2, st)
+            o2 = d_o2.to_lwe_ciphertext_list(st)[0]
+            d = (int(orc.lwe_decrypt(o2, m["glwe_sk"])) - int(orc.lwe_decrypt(out, m["glwe_sk"]))) % (1 << 64)
+            assert min(d, (1 << 64) - d) < (1 << 50), engine

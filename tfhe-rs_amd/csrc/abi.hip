@@ -280,6 +280,35 @@ void hip_programmable_bootstrap_ntt64_async(void *stream, uint32_t gpu_index, vo
   g_last_pbs_kernel.store(3);
 }
 
+void hip_convert_lwe_programmable_bootstrap_key_exact64_async(void *stream, uint32_t gpu_index, void *dest,
+                                                              void const *src, uint32_t input_lwe_dim,
+                                                              uint32_t glwe_dim, uint32_t level_count,
+                                                              uint32_t polynomial_size) {
+  // the exact engine consumes the key in the standard domain: plain upload
+  set_device(gpu_index);
+  const size_t bytes = (size_t)input_lwe_dim * level_count * (glwe_dim + 1) * (glwe_dim + 1) * polynomial_size * 8;
+  HX_CHECK(hipMemcpyAsync(dest, src, bytes, hipMemcpyHostToDevice, S(stream)));
+}
+
+void hip_programmable_bootstrap_exact64_async(void *stream, uint32_t gpu_index, void *lwe_array_out,
+                                              void const *lwe_output_indexes, void const *lut_vector,
+                                              void const *lut_vector_indexes, void const *lwe_array_in,
+                                              void const *lwe_input_indexes, void const *bootstrapping_key,
+                                              int8_t *buffer, uint32_t lwe_dimension, uint32_t glwe_dimension,
+                                              uint32_t polynomial_size, uint32_t base_log, uint32_t level_count,
+                                              uint32_t num_samples, uint32_t num_many_lut, uint32_t lut_stride) {
+  set_device(gpu_index);
+  PbsBuffer *b = checked_buffer(buffer, lwe_dimension, glwe_dimension, polynomial_size, level_count, num_samples);
+  HX_PANIC_IF_FALSE(base_log >= 1 && base_log * level_count < 64, "invalid decomposition (base_log=%u, level=%u)",
+                    base_log, level_count);
+  if (num_samples == 0) return;
+  const PbsArgs a = make_args(lwe_array_out, lwe_output_indexes, lut_vector, lut_vector_indexes, lwe_array_in,
+                              lwe_input_indexes, bootstrapping_key, lwe_dimension, base_log, level_count,
+                              num_samples, num_many_lut, lut_stride, b->ms_type);
+  launch_pbs_exact_generic(S(stream), polynomial_size, glwe_dimension, a);
+  g_last_pbs_kernel.store(5);
+}
+
 void cleanup_cuda_programmable_bootstrap_64(void *stream, uint32_t gpu_index, int8_t **pbs_buffer) {
   set_device(gpu_index);
   auto *b = reinterpret_cast<PbsBuffer *>(*pbs_buffer);

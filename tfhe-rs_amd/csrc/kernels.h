@@ -7,6 +7,7 @@ namespace tfhe_hip {
 // generic (any supported N,k,l) engines — pbs_generic.hip
 void launch_pbs_fft_generic(hipStream_t st, uint32_t N, uint32_t glwe_dim, const PbsArgs &a, const FftTables &tb);
 void launch_pbs_ntt_generic(hipStream_t st, uint32_t N, uint32_t glwe_dim, const PbsArgs &a, const NttTables &tb);
+void launch_pbs_exact_generic(hipStream_t st, uint32_t N, uint32_t glwe_dim, const PbsArgs &a);
 void launch_bsk_to_fourier(hipStream_t st, uint32_t N, uint32_t glwe_dim, const uint64_t *src_dev, void *dst, size_t polys, const FftTables &tb);
 void launch_bsk_to_ntt(hipStream_t st, uint32_t N, const uint64_t *src_dev, void *dst, size_t polys, const NttTables &tb);
 

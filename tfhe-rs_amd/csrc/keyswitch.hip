@@ -19,12 +19,14 @@ constexpr int KS_TB = 16;    // samples per workgroup
 constexpr int KS_IC = 32;    // mask elements decomposed per LDS stage
 constexpr int KS_MAXL = 8;   // max levels staged (level_count <= 8 for every shortint set)
 
+// DigitT: int32_t when base_log <= 31 (every shortint set), int64_t for wider bases
+template <typename DigitT>
 __global__ void __launch_bounds__(KS_TPB) keyswitch_kernel(uint64_t *lwe_out, const uint64_t *out_idx,
                                                            const uint64_t *lwe_in, const uint64_t *in_idx,
                                                            const uint64_t *ksk, uint32_t n_in, uint32_t n_out,
                                                            uint32_t base_log, uint32_t level, uint32_t num_samples) {
   HX_DYN_SMEM(smem);
-  int32_t *dig = (int32_t *)smem;  // [KS_IC][level][KS_TB]
+  DigitT *dig = (DigitT *)smem;  // [KS_IC][level][KS_TB]
   const int tid = threadIdx.x;
   const uint32_t col = blockIdx.x * KS_TPB + tid;
   const uint32_t s0 = blockIdx.y * KS_TB;
@@ -48,7 +50,7 @@ __global__ void __launch_bounds__(KS_TPB) keyswitch_kernel(uint64_t *lwe_out, co
       }
       for (uint32_t lv = 0; lv < level; ++lv) {
         const int64_t d = valid ? decompose_one_level(base_log, st) : 0;
-        dig[(ii * level + lv) * KS_TB + s] = (int32_t)d;
+        dig[(ii * level + lv) * KS_TB + s] = (DigitT)d;
       }
     }
     __syncthreads();
@@ -56,7 +58,7 @@ __global__ void __launch_bounds__(KS_TPB) keyswitch_kernel(uint64_t *lwe_out, co
       for (uint32_t ii = 0; ii < ic; ++ii)
         for (uint32_t lv = 0; lv < level; ++lv) {
           const uint64_t w = ksk[((size_t)(i0 + ii) * level + lv) * (n_out + 1) + col];
-          const int32_t *d = dig + (ii * level + lv) * KS_TB;
+          const DigitT *d = dig + (ii * level + lv) * KS_TB;
           HX_UNROLL
           for (int s = 0; s < KS_TB; ++s) accv[s] -= w * (uint64_t)(int64_t)d[s];
         }
@@ -75,13 +77,19 @@ __global__ void __launch_bounds__(KS_TPB) keyswitch_kernel(uint64_t *lwe_out, co
 void launch_keyswitch(hipStream_t st, uint64_t *lwe_out, const uint64_t *out_idx, const uint64_t *lwe_in,
                       const uint64_t *in_idx, const uint64_t *ksk, uint32_t n_in, uint32_t n_out,
                       uint32_t base_log, uint32_t level, uint32_t num_samples) {
-  HX_PANIC_IF_FALSE(base_log >= 1 && base_log <= 31 && level >= 1 && level <= KS_MAXL && base_log * level < 64,
+  HX_PANIC_IF_FALSE(base_log >= 1 && level >= 1 && level <= KS_MAXL && base_log * level < 64,
                     "keyswitch: unsupported decomposition (base_log=%u, level=%u)", base_log, level);
   if (num_samples == 0) return;
   const dim3 grid((n_out + 1 + KS_TPB - 1) / KS_TPB, (num_samples + KS_TB - 1) / KS_TB);
-  const size_t smem = sizeof(int32_t) * KS_IC * level * KS_TB;
-  HX_LAUNCH(keyswitch_kernel, grid, dim3(KS_TPB), smem, st, lwe_out, out_idx, lwe_in, in_idx, ksk, n_in, n_out,
-            base_log, level, num_samples);
+  if (base_log <= 31) {
+    const size_t smem = sizeof(int32_t) * KS_IC * level * KS_TB;
+    HX_LAUNCH((keyswitch_kernel<int32_t>), grid, dim3(KS_TPB), smem, st, lwe_out, out_idx, lwe_in, in_idx, ksk, n_in,
+              n_out, base_log, level, num_samples);
+  } else {
+    const size_t smem = sizeof(int64_t) * KS_IC * level * KS_TB;
+    HX_LAUNCH((keyswitch_kernel<int64_t>), grid, dim3(KS_TPB), smem, st, lwe_out, out_idx, lwe_in, in_idx, ksk, n_in,
+              n_out, base_log, level, num_samples);
+  }
 }
 
 }  // namespace tfhe_hip

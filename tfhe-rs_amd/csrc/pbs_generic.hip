@@ -92,6 +92,65 @@ __global__ void __launch_bounds__(GenericCfg<N>::TPB) pbs_fft_generic_kernel(Pbs
   block_sample_extract<N, K1, TPB>(a, acc, sample, 0, false, tid);
 }
 
+// ------------------------------------------------------------------------- exact engine
+// External products by exact negacyclic convolution mod 2^64 on the standard-domain key
+// (cc/algorithms/lwe_programmable_bootstrapping/karatsuba_pbs.rs:199-413; any exact product gives
+// the same bits).  O(N^2) per polynomial product: a verification engine — it lets the GPU path
+// reproduce the reference's own golden vectors (apps/test-vectors, *_karatsuba files) bit for bit.
+template <int N, int K1>
+__global__ void __launch_bounds__(GenericCfg<N>::TPB) pbs_exact_generic_kernel(PbsArgs a) {
+  constexpr int TPB = GenericCfg<N>::TPB, PER = N / TPB, LOG2N2 = ilog2_c(2 * N);
+  HX_DYN_SMEM(smem);
+  uint64_t *acc = (uint64_t *)smem;          // K1*N
+  int64_t *dig = (int64_t *)(acc + (size_t)K1 * N);  // N digits of one (level, row)
+  const int tid = threadIdx.x;
+  const uint32_t sample = blockIdx.x;
+  const uint64_t *lwe = a.lwe_in + (size_t)a.in_idx[sample] * (a.n + 1);
+  const uint64_t *lut = a.lut + (size_t)a.lut_idx[sample] * K1 * N;
+  const uint64_t *bsk = (const uint64_t *)a.bsk;
+
+  const uint32_t b_hat = block_body_modulus_switch<TPB>(lwe, a.n, LOG2N2, a.ms_type, (uint64_t *)dig, tid);
+  for (int p = 0; p < K1; ++p)
+    for (uint32_t j = tid; j < (uint32_t)N; j += TPB) {
+      bool neg;
+      const uint32_t src = monomial_div_src(j, b_hat, N, neg);
+      const uint64_t v = lut[p * N + src];
+      acc[p * N + j] = neg ? (uint64_t)0 - v : v;
+    }
+  __syncthreads();
+
+  for (uint32_t i = 0; i < a.n; ++i) {
+    const uint32_t a_hat = (uint32_t)modulus_switch(lwe[i], LOG2N2);
+    if (a_hat == 0) continue;
+    uint64_t oacc[K1][PER];
+    for (int c = 0; c < K1; ++c)
+      for (int q = 0; q < PER; ++q) oacc[c][q] = 0;
+    for (uint32_t idx = 0; idx < a.level; ++idx) {
+      for (int row = 0; row < K1; ++row) {
+        for (int q = 0; q < PER; ++q) {
+          const uint32_t j = tid + q * TPB;
+          dig[j] = decomp_digit(rot_sub<N>(acc + row * N, j, a_hat), a.base_log, a.level, idx);
+        }
+        __syncthreads();
+        const uint64_t *brow = bsk + ((((size_t)i * a.level + idx) * K1 + row) * K1) * N;
+        for (int c = 0; c < K1; ++c)
+          for (int q = 0; q < PER; ++q) {
+            const int m = tid + q * TPB;
+            uint64_t sum = 0;
+            for (int j = 0; j <= m; ++j) sum += (uint64_t)dig[j] * brow[(size_t)c * N + (m - j)];
+            for (int j = m + 1; j < N; ++j) sum -= (uint64_t)dig[j] * brow[(size_t)c * N + (N + m - j)];
+            oacc[c][q] += sum;
+          }
+        __syncthreads();
+      }
+    }
+    for (int c = 0; c < K1; ++c)
+      for (int q = 0; q < PER; ++q) acc[c * N + tid + q * TPB] += oacc[c][q];
+    __syncthreads();
+  }
+  block_sample_extract<N, K1, TPB>(a, acc, sample, 0, false, tid);
+}
+
 // ------------------------------------------------------------------------- NTT engine
 template <int N, int K1>
 __global__ void __launch_bounds__(GenericCfg<N>::TPB) pbs_ntt_generic_kernel(PbsArgs a, NttTables tb) {
@@ -215,6 +274,16 @@ static void launch_ntt(hipStream_t st, const PbsArgs &a, const NttTables &tb) {
 
 void launch_pbs_fft_generic(hipStream_t st, uint32_t N, uint32_t glwe_dim, const PbsArgs &a, const FftTables &tb) {
   HX_DISPATCH_NK(launch_fft, st, a, tb);
+}
+template <int N, int K1>
+static void launch_exact(hipStream_t st, const PbsArgs &a) {
+  const size_t smem = (size_t)(K1 + 1) * N * 8;
+  HX_CHECK(hipFuncSetAttribute((const void *)pbs_exact_generic_kernel<N, K1>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  HX_LAUNCH((pbs_exact_generic_kernel<N, K1>), dim3(a.num_samples), dim3(GenericCfg<N>::TPB), smem, st, a);
+}
+void launch_pbs_exact_generic(hipStream_t st, uint32_t N, uint32_t glwe_dim, const PbsArgs &a) {
+  HX_DISPATCH_NK(launch_exact, st, a);
 }
 void launch_pbs_ntt_generic(hipStream_t st, uint32_t N, uint32_t glwe_dim, const PbsArgs &a, const NttTables &tb) {
   HX_DISPATCH_NK(launch_ntt, st, a, tb);
