@@ -10,17 +10,20 @@
  * the tfhe-rs tree).
  *
  * PARITY STATUS:
- *   - integer pieces (modulus switch, decomposer, monomial ops, sample extract,
- *     keyswitch, LUT generator, Goldilocks arithmetic, f64<->i64 conversions) are
- *     pinned against the value tables / doc-test vectors the reference's own
- *     tests hold (tests/golden/ JSON files, generated by tests/golden/make_golden.py
- *     from the reference sources' literal test values).
- *   - whole-PBS raw output bits: "parity unpinned" — the reference's only
- *     golden PBS vectors (apps/test-vectors/data) are Git-LFS stubs in this
- *     tree and no Rust toolchain exists here.  The exact (Karatsuba-semantics)
- *     and NTT paths are nevertheless mathematically determined by the pinned
- *     pieces (exact ring arithmetic); the f64 FFT path is pinned only to this
- *     file's fixed operation order plus the tolerance gates of SURVEY §8(c).
+ *   - PINNED to bytes the reference produced: tests/test_reference_kat.py regenerates the
+ *     reference's golden PBS test vectors (apps/test-vectors, toy parameter set: keys, KSK, BSK,
+ *     keyswitch, modulus switch, blind rotation with exact products, sample extraction, id and
+ *     2x LUTs) through THIS oracle and matches all 14 integer-path SHA-256 digests of
+ *     apps/test-vectors/checksums.sha256 (the .cbor payloads are Git-LFS stubs, the digests are
+ *     not).  This pins modulus switch, decomposer, monomial ops, keyswitch, GGSW/GLWE encryption
+ *     layout, blind rotation order and sample extraction.
+ *   - integer pieces are additionally pinned against the value tables / doc-test vectors of the
+ *     reference's unit tests (tests/golden/reference_kats.json, tests/golden/make_golden.py).
+ *   - NTT path: exact ring arithmetic over the pinned pieces + the reference's fixed Goldilocks
+ *     roots; no reference output bytes exist for it ("unpinned" beyond its pieces).
+ *   - f64 FFT path: the reference's own bits are not reproducible (runtime-planned FFT order,
+ *     SURVEY D3); pinned only to this file's fixed operation order plus the phase tolerance
+ *     against the pinned exact path.
  */
 #ifndef TFHE_ORACLE_H
 #define TFHE_ORACLE_H
