@@ -11,9 +11,10 @@
  *
  * PARITY STATUS:
  *   - PINNED to bytes the reference produced: tests/test_reference_kat.py regenerates the
- *     reference's golden PBS test vectors (apps/test-vectors, toy parameter set: keys, KSK, BSK,
+ *     reference's golden PBS test vectors (apps/test-vectors, BOTH parameter sets — toy and the
+ *     production-size valid_params_128 with Gaussian noise: keys, KSK, BSK,
  *     keyswitch, modulus switch, blind rotation with exact products, sample extraction, id and
- *     2x LUTs) through THIS oracle and matches all 14 integer-path SHA-256 digests of
+ *     2x LUTs) through THIS oracle and matches all 14 integer-path SHA-256 digests per set of
  *     apps/test-vectors/checksums.sha256 (the .cbor payloads are Git-LFS stubs, the digests are
  *     not).  This pins modulus switch, decomposer, monomial ops, keyswitch, GGSW/GLWE encryption
  *     layout, blind rotation order and sample extraction.

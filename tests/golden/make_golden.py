@@ -86,23 +86,30 @@ def main():
     kats["param_message_2_carry_2"] = {"cite": src + ":28-47", "n": 918, "k": 1, "N": 2048, "pbs_base_log": 23,
                                        "pbs_level": 1, "ks_base_log": 4, "ks_level": 4}
 
-    # ---- SHA-256 of the reference's golden PBS vectors (toy parameter set), apps/test-vectors/checksums.sha256
+    # ---- SHA-256 of the reference's golden PBS vectors, apps/test-vectors/checksums.sha256
     src = "apps/test-vectors/checksums.sha256"
-    sums = {}
+    sums = {"toy_params": {}, "valid_params_128": {}}
     full = os.path.join(REF, src)
     if os.path.exists(full):
         for line in open(full):
             h, path = line.split()
-            if "/toy_params/" in path:
-                sums[os.path.basename(path).replace(".cbor", "")] = h
+            for which in sums:
+                if f"/{which}/" in path:
+                    sums[which][os.path.basename(path).replace(".cbor", "")] = h
         kats["sources"][src] = "read from the reference tree"
     else:  # keep what is already committed
-        sums = json.load(open(OUT))["test_vector_sha256_toy"]["sha256"]
+        old = json.load(open(OUT))
+        sums = {"toy_params": old["test_vector_sha256_toy"]["sha256"],
+                "valid_params_128": old["test_vector_sha256_valid"]["sha256"]}
         kats["sources"][src] = "unverified (reference tree absent)"
+    gen = "generator apps/test-vectors/src/main.rs:121-365 (RAND_SEED 0x74666865"
     kats["test_vector_sha256_toy"] = {
-        "cite": src + ":1-36 ; generator apps/test-vectors/src/main.rs:121-365 (RAND_SEED 0x74666865, toy params "
-                      "n=10,k=1,N=256, PBS 24x1, KS 37x1, noise stddev 0)",
-        "sha256": sums}
+        "cite": src + ":1-36 ; " + gen + ", toy params n=10,k=1,N=256, PBS 24x1, KS 37x1, noise stddev 0)",
+        "sha256": sums["toy_params"]}
+    kats["test_vector_sha256_valid"] = {
+        "cite": src + ":1-36 ; " + gen + ", valid params n=833,k=1,N=2048, PBS 23x1, KS 3x5, Gaussian noise "
+                      "3.6158408373309336e-06 / 2.845267479601915e-15; main.rs:17-25)",
+        "sha256": sums["valid_params_128"]}
 
     with open(OUT, "w") as f:
         json.dump(kats, f, indent=1, sort_keys=True)

@@ -1,4 +1,4 @@
-"""Regenerates the reference's golden PBS test vectors (apps/test-vectors, toy parameter set) and
+"""Regenerates the reference's golden PBS test vectors (apps/test-vectors, toy and valid_params_128) and
 hashes them, so the CPU oracle is pinned to bytes the reference itself produced.
 
 What is restated here (test infrastructure, CPU only):
@@ -8,8 +8,11 @@ What is restated here (test infrastructure, CPU only):
     implem/soft/block_cipher.rs:27-40,70-80); forks hand consecutive exact-size byte ranges
     to their children (generic.rs:142-176), so generation is sequential in stream order.
   * sampling: binary key = (byte & 1) per element (commons/math/random/uniform_binary.rs:9-21),
-    uniform u64 = 8 bytes little-endian (uniform.rs:15-23); the toy set's Gaussian noise has
-    standard deviation 0, i.e. the noise term is exactly 0 (apps/test-vectors/src/main.rs:29-30).
+    uniform u64 = 8 bytes little-endian (uniform.rs:15-23); Gaussian noise = Marsaglia polar
+    method on i64 pairs, first output, FromTorus (gaussian.rs:40-69,151-163; oracle/tfhe_oracle_kat.c);
+    the noise generator is keyed by DeterministicSeeder(RAND_SEED).seed() (generators/seeder.rs:48-51,
+    encryption/mod.rs) and forked children reserve 16*ceil(-128/log2(1-pi/4)) bytes per sample
+    (noise_random_generator.rs:33-57).
   * the generation order of apps/test-vectors/src/main.rs:121-365: secret generator and the
     encryption generator's mask stream are both keyed with RAND_SEED = 0x74666865.
   * serde/ciborium encoding of the entities (struct -> definite map with text keys in field
@@ -20,6 +23,7 @@ Everything between key material and hashes (keyswitch, modulus switch, blind rot
 polynomial products, sample extraction) is computed by the ORACLE under test.
 """
 import hashlib
+import math
 import struct
 
 import numpy as np
@@ -126,12 +130,31 @@ def _head(major, v):
     return bytes([major << 5 | 27]) + struct.pack(">Q", v)
 
 
+def _cbor_u64_array_body(a) -> bytes:
+    """Vectorised shortest-form unsigned encoding of every element (same bytes as _head(0, v))."""
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    be = a.astype(">u8").view(np.uint8).reshape(-1, 8)
+    nbytes = np.where(a < 24, 0, np.where(a < 1 << 8, 1, np.where(a < 1 << 16, 2, np.where(a < 1 << 32, 4, 8))))
+    first = np.where(a < 24, a, np.where(a < 1 << 8, 24, np.where(a < 1 << 16, 25, np.where(a < 1 << 32, 26, 27))))
+    rec = np.zeros((len(a), 9), dtype=np.uint8)
+    rec[:, 0] = first.astype(np.uint8)
+    keep = np.zeros((len(a), 9), dtype=bool)
+    keep[:, 0] = True
+    for j in range(8):  # payload byte j of a w-byte big-endian value is be[:, 8 - w + j]
+        sel = nbytes > j
+        rec[sel, 1 + j] = be[sel, (8 - nbytes[sel] + j)]
+        keep[:, 1 + j] = sel
+    return rec[keep].tobytes()
+
+
 def cbor(obj) -> bytes:
     if isinstance(obj, (int, np.integer)):
         return _head(0, int(obj))
     if isinstance(obj, str):
         b = obj.encode()
         return _head(3, len(b)) + b
+    if isinstance(obj, np.ndarray) and len(obj) > 4096:
+        return _head(4, len(obj)) + _cbor_u64_array_body(obj)
     if isinstance(obj, (list, np.ndarray)):
         return _head(4, len(obj)) + b"".join(_head(0, int(v)) for v in obj)
     if isinstance(obj, dict):  # insertion order = struct field order
@@ -167,31 +190,68 @@ def ser_bsk(data, glwe_size, polynomial_size, base_log, level):
 
 
 # ------------------------------------------------------------------ the generation pipeline
-TOY = dict(n=10, k=1, N=256, pbs_base_log=24, pbs_level=1, ks_base_log=37, ks_level=1, msg_bits=4)
+TOY = dict(n=10, k=1, N=256, pbs_base_log=24, pbs_level=1, ks_base_log=37, ks_level=1, msg_bits=4,
+           lwe_std=0.0, glwe_std=0.0)
+# apps/test-vectors/src/main.rs:17-25 (VALID_*): a production-size set with Gaussian noise
+VALID = dict(n=833, k=1, N=2048, pbs_base_log=23, pbs_level=1, ks_base_log=3, ks_level=5, msg_bits=4,
+             lwe_std=3.6158408373309336e-06, glwe_std=2.845267479601915e-15)
+
+# Forked noise generators reserve, per sample, 16 bytes x ceil(-128 / log2(1 - pi/4)) attempts
+# (commons/generators/encryption/{mod.rs:23,noise_random_generator.rs:33-57}; gaussian.rs:71-89).
+NOISE_BYTES_PER_FORKED_SAMPLE = 16 * math.ceil(-128.0 / math.log2(1.0 - math.pi / 4.0))
 
 
-def _lwe_encrypt_noiseless(mask_stream, sk, pt):
+class FastStream:
+    """CsprngStream with random access, generated by the oracle library's C AES (same byte table)."""
+
+    def __init__(self, seed: int):
+        self.seed, self.pos = seed, 0
+
+    def take(self, n):
+        out = orc.csprng_bytes(self.seed, self.pos, n)
+        self.pos += n
+        return out
+
+    def binary(self, n):
+        return self.take(n).astype(np.uint64) & np.uint64(1)
+
+    def uniform_u64(self, n):
+        return self.take(8 * n).view("<u8").astype(np.uint64)
+
+    def gaussian(self, std, count, forked):
+        """`count` noise samples.  A forked child owns count*NOISE_BYTES_PER_FORKED_SAMPLE bytes and leaves
+        the unused tail behind; an unforked draw advances by what the rejection loop consumed."""
+        out, used = orc.csprng_gaussian_u64(self.seed, self.pos, std, count)
+        self.pos += count * NOISE_BYTES_PER_FORKED_SAMPLE if forked else used
+        return out
+
+
+def _lwe_encrypt(mask_stream, noise_stream, sk, pt, std, forked):
+    """cc/algorithms/lwe_encryption.rs: uniform mask, body = <mask, sk> + noise + plaintext."""
     mask = mask_stream.uniform_u64(len(sk))
-    body = (int(np.sum(mask[sk == 1].astype(object))) + pt) & M64
-    return np.concatenate([mask, np.array([body], dtype=np.uint64)])
-
-
-def _glwe_encrypt_noiseless(mask_stream, glwe_sk, k, N, body_pt):
-    """body = sum_j A_j * S_j + plaintext (negacyclic), noise 0."""
-    mask = mask_stream.uniform_u64(k * N)
-    body = np.array(body_pt, dtype=np.uint64).copy()
-    for j in range(k):
-        orc.negacyclic_mul_add(body, glwe_sk[j * N:(j + 1) * N].astype(np.int64), mask[j * N:(j + 1) * N], naive=True)
+    body = noise_stream.gaussian(std, 1, forked)                       # wrapping u64 array arithmetic
+    body += mask[sk == 1].sum(dtype=np.uint64) + np.array([pt], dtype=np.uint64)
     return np.concatenate([mask, body])
 
 
-def generate_toy_vectors():
-    """Returns {name: cbor bytes} for data/toy_params (files whose bits do not depend on f64)."""
-    P = TOY
+def _glwe_encrypt(mask_stream, noise_stream, glwe_sk, k, N, body_pt, std):
+    """body = sum_j A_j * S_j + noise + plaintext (negacyclic); always a forked child (GGSW row)."""
+    mask = mask_stream.uniform_u64(k * N)
+    body = np.array(body_pt, dtype=np.uint64) + noise_stream.gaussian(std, N, True)
+    for j in range(k):
+        orc.negacyclic_mul_add(body, glwe_sk[j * N:(j + 1) * N].astype(np.int64), mask[j * N:(j + 1) * N])
+    return np.concatenate([mask, body])
+
+
+def generate_vectors(P):
+    """Returns ({name: cbor bytes}, intermediates) for one parameter set of apps/test-vectors
+    (the files whose bits do not depend on the f64 FFT)."""
     n, k, N = P["n"], P["k"], P["N"]
     log_delta = 64 - P["msg_bits"] - 1
-    secret = CsprngStream(RAND_SEED)
-    mask = CsprngStream(RAND_SEED)          # EncryptionRandomGenerator::new(Seed(RAND_SEED), ..).mask
+    secret = FastStream(RAND_SEED)
+    mask = FastStream(RAND_SEED)            # EncryptionRandomGenerator::new(Seed(RAND_SEED), ..).mask
+    # .noise is keyed by DeterministicSeeder(Seed(RAND_SEED)).seed() = the first uniform u128 of that stream
+    noise = FastStream(int.from_bytes(FastStream(RAND_SEED).take(16).tobytes(), "little"))
     out = {}
 
     glwe_sk = secret.binary(k * N)          # GlweSecretKey::generate_new_binary
@@ -199,19 +259,20 @@ def generate_toy_vectors():
     out["large_lwe_secret_key"] = ser_lwe_secret_key(glwe_sk)
     out["small_lwe_secret_key"] = ser_lwe_secret_key(small_sk)
 
-    lwe_a = _lwe_encrypt_noiseless(mask, glwe_sk, MSG_A << log_delta)
-    lwe_b = _lwe_encrypt_noiseless(mask, glwe_sk, MSG_B << log_delta)
+    lwe_a = _lwe_encrypt(mask, noise, glwe_sk, MSG_A << log_delta, P["glwe_std"], False)
+    lwe_b = _lwe_encrypt(mask, noise, glwe_sk, MSG_B << log_delta, P["glwe_std"], False)
     out["lwe_a"] = ser_lwe_ciphertext(lwe_a)
     out["lwe_b"] = ser_lwe_ciphertext(lwe_b)
     out["lwe_sum"] = ser_lwe_ciphertext(lwe_a + lwe_b)
     out["lwe_prod"] = ser_lwe_ciphertext(lwe_a * np.uint64(MSG_B))
 
-    # keyswitch key: block i, level index (level l first) encrypts s_i * 2^(64 - base_log*level)
+    # keyswitch key: block i, level index (level l first) encrypts s_i * 2^(64 - base_log*level);
+    # each block is an encrypt_lwe_ciphertext_list, i.e. one forked child per level
     ksk = []
     for i in range(k * N):
         for lvl in range(P["ks_level"], 0, -1):
             pt = (int(glwe_sk[i]) << (64 - P["ks_base_log"] * lvl)) & M64
-            ksk.append(_lwe_encrypt_noiseless(mask, small_sk, pt))
+            ksk.append(_lwe_encrypt(mask, noise, small_sk, pt, P["lwe_std"], True))
     ksk = np.concatenate(ksk)
     out["ksk"] = ser_ksk(ksk, P["ks_base_log"], P["ks_level"], n + 1)
 
@@ -229,7 +290,7 @@ def generate_toy_vectors():
                     body = (glwe_sk[row * N:(row + 1) * N] * np.uint64(factor)).astype(np.uint64)
                 else:
                     body[0] = (-factor) & M64
-                bsk.append(_glwe_encrypt_noiseless(mask, glwe_sk, k, N, body))
+                bsk.append(_glwe_encrypt(mask, noise, glwe_sk, k, N, body, P["glwe_std"]))
     bsk = np.concatenate(bsk)
     out["bsk"] = ser_bsk(bsk, k + 1, N, P["pbs_base_log"], P["pbs_level"])
 
@@ -244,6 +305,14 @@ def generate_toy_vectors():
         out[f"glwe_after_{name}_br_karatsuba"] = ser_glwe_ciphertext(acc, N)
         out[f"lwe_after_{name}_pbs_karatsuba"] = ser_lwe_ciphertext(orc.sample_extract(acc, k, N, 0))  # ORACLE
     return out, dict(glwe_sk=glwe_sk, small_sk=small_sk, lwe_a=lwe_a, ksk=ksk, bsk=bsk, lwe_ks=lwe_ks, msed=msed)
+
+
+def generate_toy_vectors():
+    return generate_vectors(TOY)
+
+
+def generate_valid_vectors():
+    return generate_vectors(VALID)
 
 
 def sha256_hex(b: bytes) -> str:

@@ -62,6 +62,9 @@ def lib():
         L.orc_rng_next.restype = u64
         L.orc_rng_tuniform.restype = i64
         L.orc_max_threads.restype = u32
+        L.orc_csprng_gaussian_u64.restype = u64
+        L.orc_csprng_gaussian_u64.argtypes = [P, u64, f64, u64, P]
+        L.orc_csprng_bytes.argtypes = [P, u64, u64, P]
     return _lib
 
 
@@ -291,3 +294,19 @@ def blind_rotate_exact(lut, msed, bsk_std, n, k, N, base_log, level):
     bsk_std = _u64(bsk_std)
     lib().orc_blind_rotate_exact(_p(acc), _p(msed), _p(bsk_std), u32(n), u32(k), u32(N), u32(base_log), u32(level))
     return acc
+
+
+def csprng_bytes(seed, offset, n):
+    """Bytes [offset, offset+n) of tfhe-csprng's AES-CTR byte table for Seed(seed)."""
+    key = np.frombuffer(int(seed).to_bytes(16, "little"), dtype=np.uint8).copy()
+    out = np.zeros(n, dtype=np.uint8)
+    lib().orc_csprng_bytes(_p(key), u64(offset), u64(n), _p(out))
+    return out
+
+
+def csprng_gaussian_u64(seed, offset, std, count):
+    """`count` Gaussian torus samples read sequentially from byte `offset`; returns (samples, bytes used)."""
+    key = np.frombuffer(int(seed).to_bytes(16, "little"), dtype=np.uint8).copy()
+    out = np.zeros(count, dtype=np.uint64)
+    used = lib().orc_csprng_gaussian_u64(_p(key), u64(offset), f64(std), u64(count), _p(out))
+    return out, int(used)

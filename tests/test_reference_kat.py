@@ -1,7 +1,8 @@
 """Pins the oracle's integer path to bytes produced by the reference itself: regenerates the
-reference's golden test vectors (apps/test-vectors, toy parameter set: KS -> MS -> blind rotation
-with exact products -> sample extract, identity and 2x LUTs) and compares SHA-256 digests with
-apps/test-vectors/checksums.sha256 (transcribed into tests/golden/reference_kats.json).
+reference's golden test vectors (apps/test-vectors; BOTH parameter sets: toy n=10/N=256 without
+noise, and valid_params_128 n=833/N=2048/PBS 23x1/KS 3x5 with Gaussian noise: KS -> MS -> blind
+rotation with exact products -> sample extract, identity and 2x LUTs) and compares SHA-256 digests
+with apps/test-vectors/checksums.sha256 (transcribed into tests/golden/reference_kats.json).
 The key material comes from a restatement of tfhe-csprng (tests/kat_vectors.py); everything after
 it — keyswitch, modulus switch, blind rotation, sample extraction — is the oracle under test."""
 import json
@@ -14,16 +15,26 @@ from . import kat_vectors as kv
 from . import oracle as orc
 
 KATS = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_kats.json")))
-SUMS = KATS["test_vector_sha256_toy"]["sha256"]
+SUMS = {"toy": KATS["test_vector_sha256_toy"]["sha256"], "valid": KATS["test_vector_sha256_valid"]["sha256"]}
+PARAMS = {"toy": kv.TOY, "valid": kv.VALID}
 
 INTEGER_FILES = ["large_lwe_secret_key", "small_lwe_secret_key", "lwe_a", "lwe_b", "lwe_sum", "lwe_prod", "ksk",
                  "lwe_ks", "bsk", "lwe_ms", "glwe_after_id_br_karatsuba", "lwe_after_id_pbs_karatsuba",
                  "glwe_after_spec_br_karatsuba", "lwe_after_spec_pbs_karatsuba"]
 
 
+_CACHE = {}
+
+
+def _vectors(which):
+    if which not in _CACHE:
+        _CACHE[which] = kv.generate_vectors(PARAMS[which])
+    return _CACHE[which]
+
+
 @pytest.fixture(scope="module")
 def vectors():
-    return kv.generate_toy_vectors()
+    return _vectors("toy")
 
 
 def test_aes128_fips197_vector():
@@ -31,18 +42,26 @@ def test_aes128_fips197_vector():
     assert ct.hex() == "69c4e0d86a7b0430d8cdb78070b4c55a"   # FIPS-197 appendix C.1
 
 
+def test_c_and_python_csprng_agree():
+    py = kv.CsprngStream(kv.RAND_SEED).take(200)
+    assert orc.csprng_bytes(kv.RAND_SEED, 0, 200).tobytes() == py
+    assert orc.csprng_bytes(kv.RAND_SEED, 37, 50).tobytes() == py[37:87]
+
+
+@pytest.mark.parametrize("which", ["toy", "valid"])
 @pytest.mark.parametrize("name", INTEGER_FILES)
-def test_regenerated_vector_matches_reference_sha256(vectors, name):
-    out, _ = vectors
-    assert kv.sha256_hex(out[name]) == SUMS[name], f"{name}.cbor differs from the reference's golden vector"
+def test_regenerated_vector_matches_reference_sha256(which, name):
+    out, _ = _vectors(which)
+    assert kv.sha256_hex(out[name]) == SUMS[which][name], f"{which}/{name}.cbor differs from the reference's"
 
 
-def test_f64_path_agrees_in_phase_with_the_pinned_exact_path(vectors):
+@pytest.mark.parametrize("which", ["toy", "valid"])
+def test_f64_path_agrees_in_phase_with_the_pinned_exact_path(which):
     """The reference's FFT vectors (glwe_after_*_br.cbor) depend on its runtime-planned FFT order and
     cannot be reproduced bit-for-bit; our fixed-order f64 path must decrypt to the same
     message and sit within 2^50 of the pinned exact result in phase."""
-    _, m = vectors
-    P = kv.TOY
+    _, m = _vectors(which)
+    P = PARAMS[which]
     n, k, N = P["n"], P["k"], P["N"]
     p = 1 << P["msg_bits"]
     bsk_f = orc.convert_bsk_fft(m["bsk"], n, k, N, P["pbs_level"])
@@ -66,12 +85,14 @@ def test_f64_path_agrees_in_phase_with_the_pinned_exact_path(vectors):
 BACKENDS = [pytest.param("emu", id="emu"), pytest.param("hip", id="hip", marks=pytest.mark.gpu)]
 
 
+@pytest.mark.parametrize("which", ["toy", "valid"])
 @pytest.mark.parametrize("kind", BACKENDS)
-def test_backend_reproduces_reference_golden_vectors(kind, vectors):
+def test_backend_reproduces_reference_golden_vectors(kind, which):
     from tfhe_rs_amd import core_crypto_gpu as gpu
     from .harness import use_backend
-    _, m = vectors
-    P = kv.TOY
+    _, m = _vectors(which)
+    P = PARAMS[which]
+    SUMS = globals()["SUMS"][which]
     n, k, N = P["n"], P["k"], P["N"]
     lib = use_backend(kind)
     st = gpu.CudaStreams.new_single_gpu(0)
@@ -93,6 +114,8 @@ def test_backend_reproduces_reference_golden_vectors(kind, vectors):
     assert kv.sha256_hex(kv.ser_lwe_ciphertext(msed << np.uint64(64 - log_mod), native=False,
                                                modulus=1 << log_mod)) == SUMS["lwe_ms"]
 
+    if kind == "emu" and which == "valid":
+        return  # 833 exact N=2048 products per output are minutes on the host emulation; the MI355X runs them
     # PBS with the exact engine (MS -> blind rotation -> sample extract) ==> lwe_after_*_pbs_karatsuba.cbor
     bsk = gpu.CudaLweBootstrapKey.from_lwe_bootstrap_key(m["bsk"], n, k, N, P["pbs_base_log"], P["pbs_level"], st,
                                                          ms_noise_reduction=False, engine="exact64")
