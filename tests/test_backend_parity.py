@@ -70,8 +70,14 @@ def test_arith_hooks_match_oracle(kind):
         got = run_arith(lib, st, 11, xs, p0=bl).astype(np.int64)
         assert all(int(g) == int(orc.decompose(int(x), bl, 1)[0]) for g, x in zip(got, xs))
     # f64 conversions: reference KAT values + random torus fractions + exact halves
+    e = 2.0 ** -64
+    ties = [(k + 0.5) * e for k in (0, 1, 2, 3, 2 ** 31 - 1, 2 ** 31, 2 ** 32 - 1, 2 ** 32, 2 ** 32 + 1, 2 ** 51 - 1)]
+    ties += [-x for x in ties] + [k * 2.0 ** -32 + s * 2.0 ** -33 for k in (0, 1, 5, 2 ** 20) for s in (1, -1)]
+    ties += [0.5 - 2.0 ** -54, -0.5 + 2.0 ** -54, 0.25 + 2.0 ** -33, 0.75 - 2.0 ** -33, 2.0 ** -65, 3 * 2.0 ** -65]
     fl = np.array([0.0, -0.0, 0.5, -0.5, 1.5, 2.5, 0.25, 1e-310, 37.1242161, -37.1242161, 2.0 ** 52 + 0.5, 1e15 / 3,
-                   0.49999999999999994, 0.5000000000000001] + list(rng.normal(0, 1e6, size=1500)), dtype=np.float64)
+                   0.49999999999999994, 0.5000000000000001] + ties + list(rng.normal(0, 1e6, size=1500)) +
+                  list(rng.uniform(-0.5, 0.5, size=1500)) + list(rng.normal(0, 1e-12, size=500)) +
+                  list(rng.integers(-2 ** 40, 2 ** 40, size=300) * 2.0 ** -41), dtype=np.float64)
     got = run_arith(lib, st, 3, fl.view(np.uint64))
     assert all(int(g) == L.orc_from_torus(float(x)) for g, x in zip(got, fl))
     iv = np.array([2.0 ** 63, -(2.0 ** 63), 2.0 ** 62, -(2.0 ** 62), 0.0, 1.0, -1.0, 1.1 * 2 ** 62] +

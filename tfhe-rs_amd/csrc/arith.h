@@ -115,12 +115,30 @@ HX_DEV int64_t f64_to_i64_sat(double x) {
   if (x <= -9223372036854775808.0) return INT64_MIN;
   return (int64_t)x;
 }
-// cc/commons/math/torus/mod.rs:73-79 (FromTorus) with nearest-even rounding
+// cc/commons/math/torus/mod.rs:73-79 (FromTorus) with nearest-even rounding:
+//   g = rint((t - rint(t)) * 2^64) as a two's-complement u64 (+2^63 folds onto -2^63).
+// Evaluated without an f64 -> i64 conversion: with f = t - rint(t) in [-1/2, 1/2] and F = f * 2^64,
+//   h = rint(f * 2^32)  (|h| <= 2^31)  and  l = F - h * 2^32  (|l| <= 2^31, exact)
+// give g = h * 2^32 + rint(l) exactly (h * 2^32 is even, so the tie rule is unchanged).  Both
+// roundings are "add 1.5 * 2^52" tricks whose low mantissa dword is the two's-complement integer; the
+// high dword of l + 1.5 * 2^52 is 0x43380000 + (rint(l) < 0 ? -1 : 0), i.e. the sign extension of
+// rint(l) up to the constant that the first magic number cancels (2^32 - 0x43380000 added to it).
+HX_DEV uint64_t f64_bits(double x) {
+  uint64_t u;
+  __builtin_memcpy(&u, &x, 8);
+  return u;
+}
 HX_DEV uint64_t from_torus(double t) {
-  double f = t - rint(t);
-  f = f * 18446744073709551616.0;
-  f = rint(f);
-  return (uint64_t)f64_to_i64_sat(f);
+  const double MAGIC = 6755399441055744.0;               // 1.5 * 2^52
+  const double MAGIC_H = 6755399441055744.0 + 3167223808.0;  // + (2^32 - 0x43380000)
+  const double f = t - rint(t);
+  const double hm = fma(f, 4294967296.0, MAGIC_H);
+  const double h = hm - MAGIC_H;
+  const double F = f * 18446744073709551616.0;
+  const double l = fma(h, -4294967296.0, F);
+  const uint64_t lb = f64_bits(l + MAGIC);
+  const uint32_t hi = (uint32_t)f64_bits(hm) + (uint32_t)(lb >> 32);
+  return ((uint64_t)hi << 32) | (uint64_t)(uint32_t)lb;
 }
 
 struct alignas(16) cplx {

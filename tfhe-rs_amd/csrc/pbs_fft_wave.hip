@@ -166,6 +166,7 @@ HX_DEV void wave_forward(cplx (&d)[16], WaveCtx c) {
 // Twiddle of DIT stage `half`, butterfly offset j: inv[half + j] = E[j*512/half] (nested tables),
 // E[J] = T_INV[J] for J < 256 and -i*T_INV[J-256] above.
 HX_DEV void wave_inverse_accumulate(cplx (&o)[16], uint64_t (&acc_re)[16], uint64_t (&acc_im)[16], WaveCtx c) {
+  uint64_t *stg = (uint64_t *)c.buf;
   HX_OPAQUE(c.lane);
   c.hi4 = c.lane >> 2;
   c.lo2 = c.lane & 3;
@@ -264,8 +265,14 @@ HX_DEV void wave_inverse_accumulate(cplx (&o)[16], uint64_t (&acc_re)[16], uint6
     const double ti = fma(o[r].im, u.re, o[r].re * u.im);
     acc_re[r] += from_torus(tr);
     acc_im[r] += from_torus(ti);
+    // stage the updated coefficients (c = r*64 + lane, 1024 + c) for the next iteration's rotation;
+    // the buffer is free (the M2 -> M1 reads above are complete) and these stores issue under the
+    // conversion arithmetic instead of in front of the next rotation
+    stg[lane_u + r * 64] = acc_re[r];
+    stg[lane_u + 1024 + r * 64] = acc_im[r];
     if ((r & 3) == 3) HX_SCHED_FENCE();
   }
+  HX_WAVE_SYNC();
 }
 
 template <int LEVEL_CT, int BASE_LOG_CT>
@@ -368,18 +375,23 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
   // ct1 = acc * X^a_hat - acc for my polynomial, decomposed at level index idx, as f64 points
   // (polynomial_algorithms.rs:662-727: coefficient c takes +/- acc[(c - r) mod N], negated when
   //  c < r, all signs flipped when a_hat >= N)
+  auto stage_acc = [&]() {
+    int lane = ctx.lane;
+    HX_OPAQUE(lane);
+    uint64_t *p = buf64 + lane;
+    HX_UNROLL
+    for (int r = 0; r < 16; ++r) {
+      p[r * 64] = acc_re[r];
+      p[1024 + r * 64] = acc_im[r];
+    }
+    HX_WAVE_SYNC();
+  };
   auto make_digits = [&](cplx (&d)[16], uint32_t a_hat, uint32_t idx) {
     int lane = ctx.lane;
     HX_OPAQUE(lane);
-    {
-      uint64_t *p = buf64 + lane;
-      HX_UNROLL
-      for (int r = 0; r < 16; ++r) {
-        p[r * 64] = acc_re[r];
-        p[1024 + r * 64] = acc_im[r];
-      }
-    }
-    HX_WAVE_SYNC();
+    // the accumulator is already staged in buf64 (stage_acc at start, then by every
+    // wave_inverse_accumulate); later levels of one iteration re-stage, the transposes reused the buffer
+    if (idx != 0) stage_acc();
     const uint32_t rr = a_hat & (N - 1);
     const bool odd = (a_hat & N) != 0;
     const uint32_t t0 = (uint32_t)lane - rr;  // (c - rr) for c = lane; wraps mod 2^32, masked below
@@ -474,9 +486,14 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
     flag_wait(r_done_ot, epoch);  // the partner must be done with my buffer before I reuse it
   };
 
+  stage_acc();
   uint32_t it = 0;  // executed iterations (flag epoch)
+  uint64_t mask_next = lwe[0];
   for (uint32_t i = 0; i < a.n; ++i) {
-    const uint32_t a_hat = (uint32_t)modulus_switch(lwe[i], LOG2N2);
+    // mask element i was requested one iteration ago (lwe has n + 1 words, so i + 1 is in range)
+    const uint64_t mask_cur = mask_next;
+    mask_next = lwe[i + 1];
+    const uint32_t a_hat = (uint32_t)modulus_switch(mask_cur, LOG2N2);
     if (a_hat == 0) continue;  // uniform over the pair (bootstrap.rs:334)
     ++it;
     if constexpr (LEVEL_CT == 1) {
