@@ -28,6 +28,20 @@ ALGO_BYTES_PER_PBS = 918 * 4 * 1 * 2048 * 8 + 919 * 8 + 2 * 2048 * 8 + 2049 * 8 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
 
+def pmc_traffic_bytes(kernel_id):
+    """HBM bytes per launch of the dominant kernel, from the PMC passes committed with this kernel build
+    (tools/pmc.sh -> profiles/pmc_latest.json; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for
+    16-byte coalesced reads on gfx950).  None when no measurement of this kernel is on file."""
+    try:
+        import json
+        m = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_latest.json")))
+        if m.get("pbs_kernel_id") != kernel_id:
+            return None
+        return 2 * m["FETCH_SIZE_KB"] * 1024 + m["WRITE_SIZE_KB"] * 1024
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -151,10 +165,13 @@ def main():
                    "pbs_kernel": {1: "generic_lds", 2: "wave_throughput"}.get(kernel_id, str(kernel_id)),
                    "parallelism": f"batch-sharded x{world}, key replicas, no collective"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                     "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc_traffic_bytes(kernel_id),
                      "algorithmic_bytes_per_launch": ALGO_BYTES_PER_PBS * B,
                      "kernel_ms_avg": avg_kernel_s * 1e3,
-                     "note": "streaming model (key re-read per LWE, SURVEY §8d); fp64 ceiling see DESIGN.md"},
+                     "note": "achieved = streaming model (key re-read per LWE, SURVEY §8d); traffic = HBM bytes per "
+                             "launch from the committed PMC passes of this kernel (profiles/pmc_latest.json: "
+                             "2 x FETCH_SIZE + WRITE_SIZE, tools/pmc.sh), not re-measured in this run; "
+                             "fp64 ceiling see DESIGN.md"},
     }
     if world == 1 and not args.no_cpu_baseline:
         # CPU leg: the oracle's f64 path on the host cores actually available to this process

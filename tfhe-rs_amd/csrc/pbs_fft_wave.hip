@@ -23,6 +23,15 @@
 //     coalesced 1 KiB request; all workgroups stream GGSW_i at about the same time, so the
 //     60 MB key is served from L2 / Infinity Cache.
 #include "kernels.h"
+#include <type_traits>
+
+// tuning knobs (tools/build_variants.py rebuilds this file with other values)
+#ifndef WAVE_EARLY_CHUNKS
+#define WAVE_EARLY_CHUNKS 1  // key chunks requested at the top of an iteration (0, 1 or 2); the rest at the MAC
+#endif
+#ifndef WAVE_FUSE_PASS1
+#define WAVE_FUSE_PASS1 1    // first inverse pass interleaved with the MAC chunks
+#endif
 
 namespace tfhe_hip {
 namespace wavek {
@@ -78,6 +87,29 @@ HX_DEV void stage(cplx (&d)[16], TW tw) {
   for (int r = 0; r < 16; ++r)
     if (!(r & (1 << BIT))) bfly(d[r], d[r | (1 << BIT)], tw(r));
 }
+// the last stage of a pass: every finished point goes straight to LDS (st(r) stores d[r]), so the 16
+// stores issue under the butterflies instead of as one burst behind them
+template <int BIT, class TW, class ST>
+HX_DEV void stage_store(cplx (&d)[16], TW tw, ST st) {
+  HX_UNROLL
+  for (int r = 0; r < 16; ++r)
+    if (!(r & (1 << BIT))) {
+      bfly(d[r], d[r | (1 << BIT)], tw(r));
+      st(r);
+      st(r | (1 << BIT));
+    }
+}
+// loads of a pass, in the order the butterflies of its first stage (register bit BIT) consume them;
+// LDS returns in order, so the first butterfly starts after two loads, not sixteen
+template <int BIT, class LD>
+HX_DEV void load_pairs(LD ld) {
+  HX_UNROLL
+  for (int r = 0; r < 16; ++r)
+    if (!(r & (1 << BIT))) {
+      ld(r);
+      ld(r | (1 << BIT));
+    }
+}
 
 // Everything a wave needs to know about its place in the workgroup
 struct WaveCtx {
@@ -110,23 +142,17 @@ HX_DEV void wave_forward(cplx (&d)[16], WaveCtx c) {
     stage<1>(d, [&](int r) { return ((r >> 2) & 1) ? times_i(e2[r >> 3]) : e2[r >> 3]; });
     HX_SCHED_FENCE();
     const cplx e3[4] = {T[T_F1 + 4], T[T_F1 + 5], T[T_F1 + 6], T[T_F1 + 7]};
-    stage<0>(d, [&](int r) { return ((r >> 1) & 1) ? times_i(e3[r >> 2]) : e3[r >> 2]; });
+    cplx *p1 = c.buf + base_m1(c);  // transpose M1 -> M2, store side
+    stage_store<0>(d, [&](int r) { return ((r >> 1) & 1) ? times_i(e3[r >> 2]) : e3[r >> 2]; },
+                   [&](int r) { p1[68 * r] = d[r]; });
   }
-  HX_SCHED_FENCE();
-  // transpose M1 -> M2
-  {
-    cplx *p1 = c.buf + base_m1(c);
-    HX_UNROLL
-    for (int r = 0; r < 16; ++r) p1[68 * r] = d[r];
-    HX_WAVE_SYNC();
-    const cplx *p2 = c.buf + base_m2(c);
-    HX_UNROLL
-    for (int r = 0; r < 16; ++r) d[r] = p2[4 * r];
-    HX_WAVE_SYNC();
-  }
+  HX_WAVE_SYNC();
   // pass F2: stages 4..7 over position bits 5..2; group index = hi4 . (r bits)
   {
     const cplx w4 = T[T_F2 + hi4];
+    const cplx *p2 = c.buf + base_m2(c);  // transpose M1 -> M2, load side
+    load_pairs<3>([&](int r) { d[r] = p2[4 * r]; });
+    HX_WAVE_SYNC();
     stage<3>(d, [&](int) { return w4; });
     const cplx e5 = T[T_F2 + 16 + hi4];
     stage<2>(d, [&](int r) { return (r >> 3) ? times_i(e5) : e5; });
@@ -136,35 +162,53 @@ HX_DEV void wave_forward(cplx (&d)[16], WaveCtx c) {
     HX_SCHED_FENCE();
     const cplx e7[4] = {T[T_F2 + 64 + hi4 * 4], T[T_F2 + 64 + hi4 * 4 + 1], T[T_F2 + 64 + hi4 * 4 + 2],
                         T[T_F2 + 64 + hi4 * 4 + 3]};
-    stage<0>(d, [&](int r) { return ((r >> 1) & 1) ? times_i(e7[r >> 2]) : e7[r >> 2]; });
+    cplx *p2w = c.buf + base_m2(c);  // transpose M2 -> M3, store side
+    stage_store<0>(d, [&](int r) { return ((r >> 1) & 1) ? times_i(e7[r >> 2]) : e7[r >> 2]; },
+                   [&](int r) { p2w[4 * r + (r >> 2)] = d[r]; });
   }
-  HX_SCHED_FENCE();
-  // transpose M2 -> M3
-  {
-    cplx *p2 = c.buf + base_m2(c);
-    HX_UNROLL
-    for (int r = 0; r < 16; ++r) p2[4 * r + (r >> 2)] = d[r];
-    HX_WAVE_SYNC();
-    const cplx *p3 = c.buf + base_m3(c);
-    HX_UNROLL
-    for (int r = 0; r < 16; ++r) d[r] = p3[r];
-    HX_WAVE_SYNC();
-  }
-  // pass F3: stages 8, 9 over position bits 1, 0
+  HX_WAVE_SYNC();
+  // pass F3: stages 8, 9 over position bits 1, 0; the result also goes to my buffer (mapping M3) for
+  // the partner wave
   {
     const cplx e8[2] = {T[T_F3 + lane * 2], T[T_F3 + lane * 2 + 1]};
+    cplx *p3 = c.buf + base_m3(c);  // transpose M2 -> M3, load side
+    load_pairs<1>([&](int r) { d[r] = p3[r]; });
+    HX_WAVE_SYNC();
     stage<1>(d, [&](int r) { return ((r >> 2) & 1) ? times_i(e8[r >> 3]) : e8[r >> 3]; });
     HX_SCHED_FENCE();
     const cplx e9[4] = {T[T_F3 + 128 + lane * 4], T[T_F3 + 128 + lane * 4 + 1], T[T_F3 + 128 + lane * 4 + 2],
                         T[T_F3 + 128 + lane * 4 + 3]};
-    stage<0>(d, [&](int r) { return ((r >> 1) & 1) ? times_i(e9[r >> 2]) : e9[r >> 2]; });
+    stage_store<0>(d, [&](int r) { return ((r >> 1) & 1) ? times_i(e9[r >> 2]) : e9[r >> 2]; },
+                   [&](int r) { p3[r] = d[r]; });
   }
-  HX_SCHED_FENCE();
+  HX_WAVE_SYNC();
 }
 
 // ---- inverse transform (mapping M3 in, M1 out), untwist and accumulation into the torus regs.
 // Twiddle of DIT stage `half`, butterfly offset j: inv[half + j] = E[j*512/half] (nested tables),
 // E[J] = T_INV[J] for J < 256 and -i*T_INV[J-256] above.
+// pass I1 of the inverse on registers o[g*4 .. g*4+3]: stages half = 1, 2 (plain), mapping M3
+HX_DEV void inverse_pass1_group(cplx (&o)[16], int g) {
+  HX_UNROLL
+  for (int r = g * 4; r < g * 4 + 4; r += 2) {
+    const cplx x = o[r], y = o[r + 1];
+    o[r] = cplx{x.re + y.re, x.im + y.im};
+    o[r + 1] = cplx{x.re - y.re, x.im - y.im};
+  }
+  HX_UNROLL
+  for (int r = g * 4; r < g * 4 + 2; ++r) {
+    const cplx x = o[r], y = o[r | 2];
+    if (r & 1) {  // j = 1: w = -i
+      o[r] = cplx{x.re + y.im, x.im - y.re};
+      o[r | 2] = cplx{x.re - y.im, x.im + y.re};
+    } else {
+      o[r] = cplx{x.re + y.re, x.im + y.im};
+      o[r | 2] = cplx{x.re - y.re, x.im - y.im};
+    }
+  }
+}
+
+template <bool PASS1_DONE>
 HX_DEV void wave_inverse_accumulate(cplx (&o)[16], uint64_t (&acc_re)[16], uint64_t (&acc_im)[16], WaveCtx c) {
   uint64_t *stg = (uint64_t *)c.buf;
   HX_OPAQUE(c.lane);
@@ -172,40 +216,24 @@ HX_DEV void wave_inverse_accumulate(cplx (&o)[16], uint64_t (&acc_re)[16], uint6
   c.lo2 = c.lane & 3;
   const int lane = c.lane, lo2 = c.lo2;
   const cplx *T = c.T;
-  // pass I1: stages half = 1, 2 (plain), mapping M3
-  HX_UNROLL
-  for (int r = 0; r < 16; r += 2) {
-    const cplx x = o[r], y = o[r + 1];
-    o[r] = cplx{x.re + y.re, x.im + y.im};
-    o[r + 1] = cplx{x.re - y.re, x.im - y.im};
+  if constexpr (!PASS1_DONE) {
+    HX_UNROLL
+    for (int g = 0; g < 4; ++g) inverse_pass1_group(o, g);
   }
-  HX_UNROLL
-  for (int r = 0; r < 16; ++r)
-    if (!(r & 2)) {
-      const cplx x = o[r], y = o[r | 2];
-      if (r & 1) {  // j = 1: w = -i
-        o[r] = cplx{x.re + y.im, x.im - y.re};
-        o[r | 2] = cplx{x.re - y.im, x.im + y.re};
-      } else {
-        o[r] = cplx{x.re + y.re, x.im + y.im};
-        o[r | 2] = cplx{x.re - y.re, x.im - y.im};
-      }
-    }
   HX_SCHED_FENCE();
-  // transpose M3 -> M2
+  // transpose M3 -> M2, store side
   {
     cplx *p3 = c.buf + base_m3(c);
     HX_UNROLL
     for (int r = 0; r < 16; ++r) p3[r] = o[r];
-    HX_WAVE_SYNC();
-    const cplx *p2 = c.buf + base_m2(c);
-    HX_UNROLL
-    for (int r = 0; r < 16; ++r) o[r] = p2[4 * r + (r >> 2)];
-    HX_WAVE_SYNC();
   }
+  HX_WAVE_SYNC();
   // pass I2: stages half = 4, 8, 16, 32 over position bits 2..5 (= r bits 0..3); j = (r bits).lo2
   {
     cplx w3 = T[T_INV + (lo2 & 1) * 128];
+    const cplx *p2r = c.buf + base_m2(c);  // transpose M3 -> M2, load side
+    load_pairs<0>([&](int r) { o[r] = p2r[4 * r + (r >> 2)]; });
+    HX_WAVE_SYNC();
     if (lo2 & 2) w3 = times_mi(w3);
     stage<0>(o, [&](int) { return w3; });
     const cplx e4 = T[T_INV + lo2 * 64];
@@ -216,25 +244,19 @@ HX_DEV void wave_inverse_accumulate(cplx (&o)[16], uint64_t (&acc_re)[16], uint6
     HX_SCHED_FENCE();
     const cplx e6[4] = {T[T_INV + lo2 * 16], T[T_INV + (4 + lo2) * 16], T[T_INV + (8 + lo2) * 16],
                         T[T_INV + (12 + lo2) * 16]};
-    stage<3>(o, [&](int r) { return (r & 4) ? times_mi(e6[r & 3]) : e6[r & 3]; });
+    cplx *p2 = c.buf + base_m2(c);  // transpose M2 -> M1, store side
+    stage_store<3>(o, [&](int r) { return (r & 4) ? times_mi(e6[r & 3]) : e6[r & 3]; },
+                   [&](int r) { p2[4 * r] = o[r]; });
   }
-  HX_SCHED_FENCE();
-  // transpose M2 -> M1
-  {
-    cplx *p2 = c.buf + base_m2(c);
-    HX_UNROLL
-    for (int r = 0; r < 16; ++r) p2[4 * r] = o[r];
-    HX_WAVE_SYNC();
-    const cplx *p1 = c.buf + base_m1(c);
-    HX_UNROLL
-    for (int r = 0; r < 16; ++r) o[r] = p1[68 * r];
-    HX_WAVE_SYNC();
-  }
+  HX_WAVE_SYNC();
   // pass I3: stages half = 64..512 over position bits 6..9 (= r bits 0..3); j = (r bits).lane
   {
     int lane = c.lane;
     HX_OPAQUE(lane);
     cplx w7 = T[T_INV + (lane & 31) * 8];
+    const cplx *p1 = c.buf + base_m1(c);  // transpose M2 -> M1, load side
+    load_pairs<0>([&](int r) { o[r] = p1[68 * r]; });
+    HX_WAVE_SYNC();
     if (lane & 32) w7 = times_mi(w7);
     stage<0>(o, [&](int) { return w7; });
     const cplx e8 = T[T_INV + lane * 4];
@@ -419,42 +441,46 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
     HX_WAVE_SYNC();
   };
 
+  // key rows of GGSW_i: [i][idx][row][c = w][storage s = r*64 + lane], consumed in 4 chunks of 4 points
+  auto key_rows = [&](uint32_t i, uint32_t idx, const cplx *&b0, const cplx *&b1) {
+    int lane = ctx.lane;
+    HX_OPAQUE(lane);
+    b0 = bsk + ((((size_t)i * level + idx) * 2 + 0) * 2 + w) * n + lane;
+    b1 = bsk + ((((size_t)i * level + idx) * 2 + 1) * 2 + w) * n + lane;
+  };
+  auto key_request = [&](cplx (&k0)[4], cplx (&k1)[4], const cplx *b0, const cplx *b1, int ch) {
+    HX_UNROLL
+    for (int j = 0; j < 4; ++j) {
+      k0[j] = b0[(ch * 4 + j) * 64];
+      k1[j] = b1[(ch * 4 + j) * 64];
+    }
+  };
+
   // publish my transform, fetch the partner's, multiply-accumulate with GGSW_i rows into dst
-  // (cc/fft_impl/fft64/crypto/ggsw.rs:616-697 order: row 0 then row 1 within a level)
-  auto mac = [&](cplx (&dst)[16], cplx (&d)[16], uint32_t i, uint32_t idx, uint32_t epoch) {
+  // (cc/fft_impl/fft64/crypto/ggsw.rs:616-697 order: row 0 then row 1 within a level).
+  // Chunks 0 and 1 of the key were requested by the caller at the top of the iteration (ka*, kb*);
+  // chunk c + 2 is requested into the registers chunk c has just released.  With FUSE_PASS1 the
+  // first inverse pass (which only mixes the 4 points of one chunk) runs right behind each chunk.
+  auto mac = [&](cplx (&dst)[16], cplx (&d)[16], cplx (&ka0)[4], cplx (&ka1)[4], cplx (&kb0)[4], cplx (&kb1)[4],
+                 const cplx *b0, const cplx *b1, uint32_t idx, uint32_t epoch, auto fuse_pass1) {
     WaveCtx ctx = ctx0;
     HX_OPAQUE(ctx.lane);
     const int lane = ctx.lane;
-    {
-      cplx *p3 = buf + base_m3(ctx);
-      HX_UNROLL
-      for (int r = 0; r < 16; ++r) p3[r] = d[r];
-    }
-    HX_WAVE_SYNC();
+    // wave_forward left my transform in my buffer (mapping M3)
     if (lane == 0) flag_set(f_ready_me, epoch);
-    // key rows: [i][idx][row][c = w][storage s = r*64 + lane], consumed in 4 chunks of 4 points;
-    // chunk c+1 is in flight while chunk c is multiplied, chunk 0 is requested before the wait.
-    const cplx *b0 = bsk + ((((size_t)i * level + idx) * 2 + 0) * 2 + w) * n + lane;
-    const cplx *b1 = bsk + ((((size_t)i * level + idx) * 2 + 1) * 2 + w) * n + lane;
-    cplx k0[4], k1[4];
-    HX_UNROLL
-    for (int j = 0; j < 4; ++j) {
-      k0[j] = b0[j * 64];
-      k1[j] = b1[j * 64];
-    }
+    constexpr int early = (LEVEL_CT == 1) ? WAVE_EARLY_CHUNKS : 0;  // more levels: no registers to spare
+    if (early < 1) key_request(ka0, ka1, b0, b1, 0);
+    if (early < 2) key_request(kb0, kb1, b0, b1, 1);
     HX_SCHED_FENCE();
     flag_wait(f_ready_ot, epoch);
     const cplx *q3 = obuf + base_m3(ctx);
+    // the key pointers must not be known before the wait, or the later requests are hoisted above it
+    HX_OPAQUE(b0);
+    HX_OPAQUE(b1);
     HX_UNROLL
     for (int ch = 0; ch < 4; ++ch) {
-      cplx n0[4], n1[4];
-      if (ch < 3) {
-        HX_UNROLL
-        for (int j = 0; j < 4; ++j) {
-          n0[j] = b0[((ch + 1) * 4 + j) * 64];
-          n1[j] = b1[((ch + 1) * 4 + j) * 64];
-        }
-      }
+      cplx(&k0)[4] = (ch & 1) ? kb0 : ka0;
+      cplx(&k1)[4] = (ch & 1) ? kb1 : ka1;
       HX_UNROLL
       for (int j = 0; j < 4; ++j) {
         const int r = ch * 4 + j;
@@ -472,11 +498,14 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
         HX_OPAQUE(dst[r].re);
         HX_OPAQUE(dst[r].im);
       }
-      if (ch < 3) {
+      HX_SCHED_FENCE();
+      if (ch < 2) key_request(k0, k1, b0, b1, ch + 2);
+      if constexpr (decltype(fuse_pass1)::value) {
+        inverse_pass1_group(dst, ch);
         HX_UNROLL
         for (int j = 0; j < 4; ++j) {
-          k0[j] = n0[j];
-          k1[j] = n1[j];
+          HX_OPAQUE(dst[ch * 4 + j].re);
+          HX_OPAQUE(dst[ch * 4 + j].im);
         }
       }
       HX_SCHED_FENCE();
@@ -497,20 +526,29 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
     if (a_hat == 0) continue;  // uniform over the pair (bootstrap.rs:334)
     ++it;
     if constexpr (LEVEL_CT == 1) {
-      cplx d[16];
+      cplx d[16], ka0[4], ka1[4], kb0[4], kb1[4];
+      const cplx *b0, *b1;
+      key_rows(i, 0, b0, b1);
+      if (WAVE_EARLY_CHUNKS >= 1) key_request(ka0, ka1, b0, b1, 0);
+      if (WAVE_EARLY_CHUNKS >= 2) key_request(kb0, kb1, b0, b1, 1);
+      HX_SCHED_FENCE();
       make_digits(d, a_hat, 0);
       wave_forward(d, ctx);
-      mac(d, d, i, 0, it);  // in place: d becomes the Fourier-domain output of polynomial w
-      wave_inverse_accumulate(d, acc_re, acc_im, ctx);
+      // in place: d becomes the Fourier-domain output of polynomial w, first inverse pass applied
+      mac(d, d, ka0, ka1, kb0, kb1, b0, b1, 0, it, std::integral_constant<bool, WAVE_FUSE_PASS1 != 0>{});
+      wave_inverse_accumulate<WAVE_FUSE_PASS1 != 0>(d, acc_re, acc_im, ctx);
     } else {
       cplx o[16];
       for (uint32_t idx = 0; idx < level; ++idx) {
-        cplx d[16];
+        cplx d[16], ka0[4], ka1[4], kb0[4], kb1[4];
+        const cplx *b0, *b1;
+        key_rows(i, idx, b0, b1);
+        HX_SCHED_FENCE();
         make_digits(d, a_hat, idx);
         wave_forward(d, ctx);
-        mac(o, d, i, idx, (it - 1) * level + idx + 1);
+        mac(o, d, ka0, ka1, kb0, kb1, b0, b1, idx, (it - 1) * level + idx + 1, std::false_type{});
       }
-      wave_inverse_accumulate(o, acc_re, acc_im, ctx);
+      wave_inverse_accumulate<false>(o, acc_re, acc_im, ctx);
     }
   }
 
