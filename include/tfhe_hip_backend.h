@@ -197,6 +197,101 @@ void hip_programmable_bootstrap_exact64_async(
     uint32_t polynomial_size, uint32_t base_log, uint32_t level_count,
     uint32_t num_samples, uint32_t num_many_lut, uint32_t lut_stride);
 
+/* ------------------------------------------------------------------ radix integers ("next" row N1)
+ * backends/tfhe-cuda-backend/cuda/include/integer/integer.h:52-65,100-113 (FFI structs),
+ * :127-148 (apply_univariate_lut), :173-187 (integer_mult_inplace), :383-413 (propagate_single_carry,
+ * add_and_propagate_single_carry); include/keyswitch/keyswitch.h:7-12; include/linear_algebra.h:26-28.
+ * Called from tfhe/src/integer/gpu/mod.rs (cuda_backend_apply_univariate_lut,
+ * cuda_backend_propagate_single_carry_assign, cuda_backend_unchecked_mul_assign, ...).
+ *
+ * Subset wired: classic PBS (pbs_type = CLASSICAL), one GPU (streams[0]), no carry-in / overflow
+ * flags, no boolean operands.  Extension: a CudaRadixCiphertextFFI may hold a batch of integers
+ * ([integer][block]); the scratch's num_blocks is the blocks PER integer and the launch handles
+ * num_radix_blocks / num_blocks integers in the same rounds (capacity: hip_integer_scratch_batch). */
+typedef struct {
+  void *const *streams;
+  uint32_t const *gpu_indexes;
+  uint32_t gpu_count;
+} CudaStreamsFFI;
+
+typedef struct {
+  void *ptr;
+  uint64_t *degrees;
+  uint64_t *noise_levels;
+  uint32_t num_radix_blocks;
+  uint32_t max_num_radix_blocks;
+  uint32_t lwe_dimension;
+} CudaRadixCiphertextFFI;
+
+typedef struct {
+  uint32_t input_lwe_dimension;
+  uint32_t glwe_dimension;
+  uint32_t polynomial_size;
+  uint32_t base_log;
+  uint32_t level_count;
+  uint32_t big_lwe_dimension;
+  uint32_t pbs_type; /* PBS_TYPE: MULTI_BIT = 0, CLASSICAL = 1 (pbs/pbs_enums.h:4) */
+  uint32_t grouping_factor;
+} CudaLweBootstrapKeyParamsFFI;
+
+typedef struct {
+  uint32_t input_lwe_dimension;
+  uint32_t output_lwe_dimension;
+  uint32_t base_log;
+  uint32_t level_count;
+} CudaLweKeyswitchKeyParamsFFI;
+
+uint64_t scratch_cuda_apply_univariate_lut_64_async(
+    CudaStreamsFFI streams, int8_t **mem_ptr, void const *input_lut,
+    CudaLweBootstrapKeyParamsFFI bsk_params, CudaLweKeyswitchKeyParamsFFI ksk_params,
+    uint32_t input_lwe_ciphertext_count, uint32_t message_modulus, uint32_t carry_modulus,
+    uint64_t lut_degree, bool allocate_gpu_memory, enum PBS_MS_REDUCTION_T noise_reduction_type);
+void cuda_apply_univariate_lut_64_async(
+    CudaStreamsFFI streams, CudaRadixCiphertextFFI *output_radix_lwe,
+    CudaRadixCiphertextFFI const *input_radix_lwe, int8_t *mem_ptr, void *const *ksks, void *const *bsks);
+void cleanup_cuda_apply_univariate_lut_64(CudaStreamsFFI streams, int8_t **mem_ptr_void);
+
+void cuda_add_lwe_ciphertext_vector_inplace_64(
+    void *stream, uint32_t gpu_index, CudaRadixCiphertextFFI *lwe_array_inout,
+    CudaRadixCiphertextFFI const *input_2);
+
+uint64_t scratch_cuda_propagate_single_carry_64_inplace_async(
+    CudaStreamsFFI streams, int8_t **mem_ptr, CudaLweBootstrapKeyParamsFFI bsk_params,
+    CudaLweKeyswitchKeyParamsFFI ksk_params, uint32_t num_blocks, uint32_t message_modulus,
+    uint32_t carry_modulus, uint32_t requested_flag, bool allocate_gpu_memory,
+    enum PBS_MS_REDUCTION_T noise_reduction_type);
+uint64_t scratch_cuda_add_and_propagate_single_carry_64_inplace_async(
+    CudaStreamsFFI streams, int8_t **mem_ptr, CudaLweBootstrapKeyParamsFFI bsk_params,
+    CudaLweKeyswitchKeyParamsFFI ksk_params, uint32_t num_blocks, uint32_t message_modulus,
+    uint32_t carry_modulus, uint32_t requested_flag, bool allocate_gpu_memory,
+    enum PBS_MS_REDUCTION_T noise_reduction_type);
+void cuda_propagate_single_carry_64_inplace_async(
+    CudaStreamsFFI streams, CudaRadixCiphertextFFI *lwe_array, CudaRadixCiphertextFFI *carry_out,
+    const CudaRadixCiphertextFFI *carry_in, int8_t *mem_ptr, void *const *bsks, void *const *ksks,
+    uint32_t requested_flag, uint32_t uses_carry);
+void cuda_add_and_propagate_single_carry_64_inplace_async(
+    CudaStreamsFFI streams, CudaRadixCiphertextFFI *lhs_array, const CudaRadixCiphertextFFI *rhs_array,
+    CudaRadixCiphertextFFI *carry_out, const CudaRadixCiphertextFFI *carry_in, int8_t *mem_ptr,
+    void *const *bsks, void *const *ksks, uint32_t requested_flag, uint32_t uses_carry);
+void cleanup_cuda_propagate_single_carry_64_inplace(CudaStreamsFFI streams, int8_t **mem_ptr_void);
+void cleanup_cuda_add_and_propagate_single_carry_64_inplace(CudaStreamsFFI streams, int8_t **mem_ptr_void);
+
+uint64_t scratch_cuda_integer_mult_inplace_64_async(
+    CudaStreamsFFI streams, int8_t **mem_ptr, bool const is_boolean_left, bool const is_boolean_right,
+    uint32_t message_modulus, uint32_t carry_modulus, CudaLweBootstrapKeyParamsFFI bsk_params,
+    CudaLweKeyswitchKeyParamsFFI ksk_params, uint32_t num_blocks, bool allocate_gpu_memory,
+    enum PBS_MS_REDUCTION_T noise_reduction_type);
+void cuda_integer_mult_inplace_64_async(
+    CudaStreamsFFI streams, CudaRadixCiphertextFFI *radix_lwe_inout, bool const is_bool_left,
+    CudaRadixCiphertextFFI const *radix_lwe_right, bool const is_bool_right, void *const *bsks,
+    void *const *ksks, int8_t *mem_ptr, uint32_t polynomial_size, uint32_t num_blocks);
+void cleanup_cuda_integer_mult_inplace_64(CudaStreamsFFI streams, int8_t **mem_ptr_void);
+
+/* extensions: integers per launch the NEXT scratch_* call is sized for (default 1), and the number
+ * of PBS one multiplication issues per integer (for throughput accounting) */
+void hip_integer_scratch_batch(uint32_t num_integers);
+uint64_t hip_integer_mult_pbs_count(int8_t *mem_ptr);
+
 /* Select which f64 kernel serves cuda_programmable_bootstrap_64_async:
  * 0 = automatic (throughput kernel when the parameter set supports it), 1 = generic LDS
  * kernel, 2 = throughput kernel (abort if unsupported).  Both give identical bits. */

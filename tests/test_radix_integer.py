@@ -1,0 +1,101 @@
+"""Radix-integer layer ("next" row N1): batched apply-LUT rounds, carry propagation, add, mul.
+
+The checker is clear arithmetic on the decrypted blocks (decryption by the oracle): the reference's
+own tests for these operations do the same (tfhe/src/integer/gpu/server_key/radix/tests_unsigned/
+{test_add.rs,test_mul.rs}: encrypt, operate, decrypt, compare with the clear result).
+[emu] runs the kernel sources on the host with a toy key, [hip] on the MI355X with
+PARAM_MESSAGE_2_CARRY_2 and 64-bit integers."""
+import numpy as np
+import pytest
+
+from . import oracle as orc
+from .common import C1, TOY_2048, decrypt_big, encrypt_big, make_keys
+from .harness import use_backend
+
+BACKENDS = [pytest.param("emu", id="emu"), pytest.param("hip", id="hip", marks=pytest.mark.gpu)]
+MSG = 4  # message_modulus = carry_modulus = 4
+
+
+def setup(kind):
+    from tfhe_rs_amd import core_crypto_gpu as gpu
+    from tfhe_rs_amd import integer_gpu as igpu
+    use_backend(kind)
+    p = TOY_2048 if kind == "emu" else C1
+    keys = make_keys(p)
+    st = gpu.CudaStreams.new_single_gpu(0)
+    ksk = gpu.CudaLweKeyswitchKey.from_lwe_keyswitch_key(keys.ksk, p.big_n, p.n, p.ks_base_log, p.ks_level, st)
+    bsk = gpu.CudaLweBootstrapKey.from_lwe_bootstrap_key(keys.bsk, p.n, p.k, p.N, p.pbs_base_log, p.pbs_level, st,
+                                                         ms_noise_reduction=bool(p.ms_type))
+    return p, keys, st, igpu.CudaServerKey(ksk, bsk, MSG, MSG), igpu
+
+
+def encrypt_radix(p, keys, values, num_blocks, seed):
+    """[integer][block] big-key encryptions of the base-4 digits, least significant first."""
+    digits = [[(int(v) >> (2 * j)) & 3 for j in range(num_blocks)] for v in values]
+    flat = encrypt_big(p, keys, [d for row in digits for d in row], seed=seed)
+    return flat.reshape(len(values), num_blocks, -1)
+
+
+def decrypt_blocks(p, keys, blocks):
+    return [[decrypt_big(p, keys, b) for b in row] for row in blocks]
+
+
+def recompose(rows):
+    return [sum(int(d) << (2 * j) for j, d in enumerate(row)) for row in rows]
+
+
+@pytest.mark.parametrize("kind", BACKENDS)
+def test_apply_lookup_table_on_every_block(kind):
+    p, keys, st, sks, igpu = setup(kind)
+    vals = [0x1B, 0xE4, 0x39]
+    ct = igpu.CudaUnsignedRadixCiphertext.from_blocks(encrypt_radix(p, keys, vals, 4, 11), st)
+    lut = orc.generate_lut(p.k, p.N, 16, p.delta, lambda x: (3 * x + 1) % 16)
+    out = sks.apply_lookup_table(ct, lut, st, degree=15)
+    got = decrypt_blocks(p, keys, out.to_blocks(st))
+    want = [[(3 * ((v >> (2 * j)) & 3) + 1) % 16 for j in range(4)] for v in vals]
+    assert got == want
+
+
+@pytest.mark.parametrize("kind", BACKENDS)
+def test_add_and_carry_propagation(kind):
+    p, keys, st, sks, igpu = setup(kind)
+    L = 4 if kind == "emu" else 32
+    bits = 2 * L
+    rng = np.random.default_rng(5)
+    a = [int(x) for x in rng.integers(0, 1 << 62, size=3)] + [(1 << bits) - 1, 0x5555555555555555]
+    b = [int(x) for x in rng.integers(0, 1 << 62, size=3)] + [1, 0xAAAAAAAAAAAAAAAB]
+    a = [x & ((1 << bits) - 1) for x in a]
+    b = [x & ((1 << bits) - 1) for x in b]
+    ca = igpu.CudaUnsignedRadixCiphertext.from_blocks(encrypt_radix(p, keys, a, L, 21), st)
+    cb = igpu.CudaUnsignedRadixCiphertext.from_blocks(encrypt_radix(p, keys, b, L, 22), st)
+    # unchecked add leaves carries in the blocks ...
+    tmp = ca.duplicate(st)
+    sks.unchecked_add_assign(tmp, cb, st)
+    raw = decrypt_blocks(p, keys, tmp.to_blocks(st))
+    assert raw == [[((x >> (2 * j)) & 3) + ((y >> (2 * j)) & 3) for j in range(L)] for x, y in zip(a, b)]
+    # ... which one propagation resolves; the ripple cases (all-ones + 1, 0101.. + 1010..1) cross every block
+    sks.propagate_single_carry_assign(tmp, st)
+    rows = decrypt_blocks(p, keys, tmp.to_blocks(st))
+    assert all(d < MSG for r in rows for d in r)
+    assert recompose(rows) == [(x + y) % (1 << bits) for x, y in zip(a, b)]
+    # fused entry point
+    sks.add_assign(ca, cb, st)
+    assert recompose(decrypt_blocks(p, keys, ca.to_blocks(st))) == [(x + y) % (1 << bits) for x, y in zip(a, b)]
+
+
+@pytest.mark.parametrize("kind", BACKENDS)
+def test_mul(kind):
+    p, keys, st, sks, igpu = setup(kind)
+    L = 9 if kind == "emu" else 32   # 9 blocks: columns of up to 17 terms, several reduction steps
+    bits = 2 * L
+    mask = (1 << bits) - 1
+    rng = np.random.default_rng(9)
+    a = [int(x) & mask for x in rng.integers(0, 1 << 62, size=2)] + [mask]
+    b = [int(x) & mask for x in rng.integers(0, 1 << 62, size=2)] + [mask]
+    ca = igpu.CudaUnsignedRadixCiphertext.from_blocks(encrypt_radix(p, keys, a, L, 31), st)
+    cb = igpu.CudaUnsignedRadixCiphertext.from_blocks(encrypt_radix(p, keys, b, L, 32), st)
+    pbs = sks.mul_assign(ca, cb, st, return_pbs_count=True)
+    rows = decrypt_blocks(p, keys, ca.to_blocks(st))
+    assert all(d < MSG for r in rows for d in r)
+    assert recompose(rows) == [(x * y) & mask for x, y in zip(a, b)]
+    assert pbs > L * L

@@ -214,7 +214,7 @@ HX_DEV void wave_inverse_accumulate(cplx (&o)[16], uint64_t (&acc_re)[16], uint6
   HX_OPAQUE(c.lane);
   c.hi4 = c.lane >> 2;
   c.lo2 = c.lane & 3;
-  const int lane = c.lane, lo2 = c.lo2;
+  const int lo2 = c.lo2;
   const cplx *T = c.T;
   if constexpr (!PASS1_DONE) {
     HX_UNROLL

@@ -13,6 +13,30 @@ DEFAULT_LIB = os.path.join(_HERE, "lib", "libtfhe_hip_backend.so")
 
 _v, _u32, _u64, _i8pp, _b = C.c_void_p, C.c_uint32, C.c_uint64, C.POINTER(C.c_void_p), C.c_bool
 
+
+
+# FFI structs of the radix-integer layer (include/tfhe_hip_backend.h, "radix integers")
+class CudaStreamsFFI(C.Structure):
+    _fields_ = [("streams", C.POINTER(C.c_void_p)), ("gpu_indexes", C.POINTER(C.c_uint32)), ("gpu_count", C.c_uint32)]
+
+
+class CudaRadixCiphertextFFI(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("degrees", C.POINTER(C.c_uint64)), ("noise_levels", C.POINTER(C.c_uint64)),
+                ("num_radix_blocks", C.c_uint32), ("max_num_radix_blocks", C.c_uint32), ("lwe_dimension", C.c_uint32)]
+
+
+class CudaLweBootstrapKeyParamsFFI(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("input_lwe_dimension", "glwe_dimension", "polynomial_size", "base_log",
+                                          "level_count", "big_lwe_dimension", "pbs_type", "grouping_factor")]
+
+
+class CudaLweKeyswitchKeyParamsFFI(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("input_lwe_dimension", "output_lwe_dimension", "base_log", "level_count")]
+
+
+_S, _BK, _KK = CudaStreamsFFI, CudaLweBootstrapKeyParamsFFI, CudaLweKeyswitchKeyParamsFFI
+_R = C.POINTER(CudaRadixCiphertextFFI)
+
 # symbol -> (restype, argtypes); mirrors include/tfhe_hip_backend.h line by line
 SIGNATURES = {
     # device runtime
@@ -77,6 +101,25 @@ SIGNATURES = {
     "hip_test_arith_async": (None, [_v, _u32, _u32, _v, _v, _u32, _u32, _u32]),
     "hip_test_transform_async": (None, [_v, _u32, _u32, _u32, _v, _v]),
     "hip_test_fft_tables_host": (None, [_u32, _v, _v, _v]),
+    # radix integers
+    "scratch_cuda_apply_univariate_lut_64_async": (_u64, [_S, _i8pp, _v, _BK, _KK, _u32, _u32, _u32, _u64, _b, _u32]),
+    "cuda_apply_univariate_lut_64_async": (None, [_S, _R, _R, _v, _i8pp, _i8pp]),
+    "cleanup_cuda_apply_univariate_lut_64": (None, [_S, _i8pp]),
+    "cuda_add_lwe_ciphertext_vector_inplace_64": (None, [_v, _u32, _R, _R]),
+    "scratch_cuda_propagate_single_carry_64_inplace_async":
+        (_u64, [_S, _i8pp, _BK, _KK, _u32, _u32, _u32, _u32, _b, _u32]),
+    "scratch_cuda_add_and_propagate_single_carry_64_inplace_async":
+        (_u64, [_S, _i8pp, _BK, _KK, _u32, _u32, _u32, _u32, _b, _u32]),
+    "cuda_propagate_single_carry_64_inplace_async": (None, [_S, _R, _R, _R, _v, _i8pp, _i8pp, _u32, _u32]),
+    "cuda_add_and_propagate_single_carry_64_inplace_async":
+        (None, [_S, _R, _R, _R, _R, _v, _i8pp, _i8pp, _u32, _u32]),
+    "cleanup_cuda_propagate_single_carry_64_inplace": (None, [_S, _i8pp]),
+    "cleanup_cuda_add_and_propagate_single_carry_64_inplace": (None, [_S, _i8pp]),
+    "scratch_cuda_integer_mult_inplace_64_async": (_u64, [_S, _i8pp, _b, _b, _u32, _u32, _BK, _KK, _u32, _b, _u32]),
+    "cuda_integer_mult_inplace_64_async": (None, [_S, _R, _b, _R, _b, _i8pp, _i8pp, _v, _u32, _u32]),
+    "cleanup_cuda_integer_mult_inplace_64": (None, [_S, _i8pp]),
+    "hip_integer_scratch_batch": (None, [_u32]),
+    "hip_integer_mult_pbs_count": (_u64, [_v]),
 }
 
 

@@ -1,0 +1,158 @@
+"""Host-side mirror of tfhe/src/integer/gpu for the radix operations the backend wires ("next" row N1):
+CudaServerKey (keys + parameters on the device), CudaUnsignedRadixCiphertext (here: a BATCH of
+integers, [integer][block] on the device) and the operations
+
+    unchecked_add_assign / add_assign   integer/gpu/server_key/radix/add.rs
+    propagate_single_carry_assign       integer/gpu/mod.rs (cuda_backend_propagate_single_carry_assign)
+    mul_assign                          integer/gpu/server_key/radix/mul.rs
+    apply_lookup_table                  integer/gpu/mod.rs (cuda_backend_apply_univariate_lut)
+
+Each call is scratch -> launch -> cleanup through the C ABI, as the Rust wrappers do
+(integer/gpu/mod.rs).  No CPU fallback: everything runs in libtfhe_hip_backend.so.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import ffi
+from .core_crypto_gpu import CudaLweBootstrapKey, CudaLweKeyswitchKey, CudaVec, _lib
+
+U64 = np.uint64
+PBS_TYPE_CLASSICAL = 1
+
+
+class CudaServerKey:
+    """integer/gpu/server_key/mod.rs:26-60: keyswitch key, bootstrap key and the shortint parameters."""
+
+    def __init__(self, ksk: CudaLweKeyswitchKey, bsk: CudaLweBootstrapKey, message_modulus, carry_modulus):
+        assert ksk.output_key_lwe_dimension == bsk.input_lwe_dimension
+        assert ksk.input_key_lwe_dimension == bsk.output_lwe_dimension
+        self.key_switching_key, self.bootstrapping_key = ksk, bsk
+        self.message_modulus, self.carry_modulus = int(message_modulus), int(carry_modulus)
+
+    # ---- FFI views
+    def _bsk_params(self):
+        b = self.bootstrapping_key
+        return ffi.CudaLweBootstrapKeyParamsFFI(b.input_lwe_dimension, b.glwe_dimension, b.polynomial_size,
+                                                b.decomp_base_log, b.decomp_level_count, b.output_lwe_dimension,
+                                                PBS_TYPE_CLASSICAL, 0)
+
+    def _ksk_params(self):
+        k = self.key_switching_key
+        return ffi.CudaLweKeyswitchKeyParamsFFI(k.input_key_lwe_dimension, k.output_key_lwe_dimension,
+                                                k.decomp_base_log, k.decomp_level_count)
+
+    def _key_ptrs(self):
+        ksks = (C.c_void_p * 1)(self.key_switching_key.d_vec.ptr)
+        bsks = (C.c_void_p * 1)(self.bootstrapping_key.d_vec.ptr)
+        return ksks, bsks
+
+    @staticmethod
+    def _streams(streams):
+        ptrs = (C.c_void_p * len(streams))(*streams.ptr)
+        idx = (C.c_uint32 * len(streams))(*streams.gpu_indexes)
+        return ffi.CudaStreamsFFI(ptrs, idx, len(streams)), (ptrs, idx)
+
+    def _noise_reduction(self):
+        return 1 if self.bootstrapping_key.ms_noise_reduction else 0
+
+    # ---- operations
+    def apply_lookup_table(self, ct, lut, streams, degree=None):
+        """Every block of every integer goes through KS -> PBS with `lut` (a (k+1)*N accumulator)."""
+        s, keep = self._streams(streams)
+        ksks, bsks = self._key_ptrs()
+        lut = np.ascontiguousarray(lut, dtype=U64)
+        mem = C.c_void_p()
+        n = ct.total_blocks
+        _lib().scratch_cuda_apply_univariate_lut_64_async(
+            s, C.byref(mem), lut.ctypes.data_as(C.c_void_p), self._bsk_params(), self._ksk_params(), n,
+            self.message_modulus, self.carry_modulus, degree if degree is not None else self.message_modulus - 1, True,
+            self._noise_reduction())
+        out = CudaUnsignedRadixCiphertext.zeros_like(ct, streams)
+        _lib().cuda_apply_univariate_lut_64_async(s, C.byref(out._ffi()), C.byref(ct._ffi()), mem, ksks, bsks)
+        _lib().cleanup_cuda_apply_univariate_lut_64(s, C.byref(mem))
+        return out
+
+    def unchecked_add_assign(self, lhs, rhs, streams):
+        """Block-wise LWE addition, no carry handling (radix/add.rs unchecked_add_assign)."""
+        assert lhs.total_blocks == rhs.total_blocks
+        _lib().cuda_add_lwe_ciphertext_vector_inplace_64(streams.ptr[0], streams.gpu_indexes[0], C.byref(lhs._ffi()),
+                                                         C.byref(rhs._ffi()))
+
+    def propagate_single_carry_assign(self, ct, streams):
+        s, keep = self._streams(streams)
+        ksks, bsks = self._key_ptrs()
+        mem = C.c_void_p()
+        _lib().hip_integer_scratch_batch(ct.num_integers)
+        _lib().scratch_cuda_propagate_single_carry_64_inplace_async(
+            s, C.byref(mem), self._bsk_params(), self._ksk_params(), ct.num_blocks, self.message_modulus,
+            self.carry_modulus, 0, True, self._noise_reduction())
+        _lib().cuda_propagate_single_carry_64_inplace_async(s, C.byref(ct._ffi()), None, None, mem, bsks, ksks, 0, 0)
+        _lib().cleanup_cuda_propagate_single_carry_64_inplace(s, C.byref(mem))
+
+    def add_assign(self, lhs, rhs, streams):
+        """lhs += rhs on clean (carry-free) operands: block additions, then one carry propagation."""
+        s, keep = self._streams(streams)
+        ksks, bsks = self._key_ptrs()
+        mem = C.c_void_p()
+        _lib().hip_integer_scratch_batch(lhs.num_integers)
+        _lib().scratch_cuda_add_and_propagate_single_carry_64_inplace_async(
+            s, C.byref(mem), self._bsk_params(), self._ksk_params(), lhs.num_blocks, self.message_modulus,
+            self.carry_modulus, 0, True, self._noise_reduction())
+        _lib().cuda_add_and_propagate_single_carry_64_inplace_async(s, C.byref(lhs._ffi()), C.byref(rhs._ffi()), None,
+                                                                    None, mem, bsks, ksks, 0, 0)
+        _lib().cleanup_cuda_add_and_propagate_single_carry_64_inplace(s, C.byref(mem))
+
+    def mul_assign(self, lhs, rhs, streams, return_pbs_count=False):
+        """lhs *= rhs (mod 2^bits) on clean operands: schoolbook block products, column sums, propagation."""
+        s, keep = self._streams(streams)
+        ksks, bsks = self._key_ptrs()
+        mem = C.c_void_p()
+        _lib().hip_integer_scratch_batch(lhs.num_integers)
+        _lib().scratch_cuda_integer_mult_inplace_64_async(
+            s, C.byref(mem), False, False, self.message_modulus, self.carry_modulus, self._bsk_params(),
+            self._ksk_params(), lhs.num_blocks, True, self._noise_reduction())
+        pbs = int(_lib().hip_integer_mult_pbs_count(mem))
+        _lib().cuda_integer_mult_inplace_64_async(s, C.byref(lhs._ffi()), False, C.byref(rhs._ffi()), False, bsks, ksks,
+                                                  mem, self.bootstrapping_key.polynomial_size, lhs.num_blocks)
+        _lib().cleanup_cuda_integer_mult_inplace_64(s, C.byref(mem))
+        return pbs if return_pbs_count else None
+
+
+class CudaUnsignedRadixCiphertext:
+    """A batch of unsigned radix integers on the device: [integer][block][lwe_size] u64, least
+    significant block first (integer/gpu/ciphertext/mod.rs; one reference ciphertext = batch of 1)."""
+
+    def __init__(self, d_blocks: CudaVec, num_integers, num_blocks, lwe_dimension):
+        self.d_blocks = d_blocks
+        self.num_integers, self.num_blocks, self.lwe_dimension = int(num_integers), int(num_blocks), int(lwe_dimension)
+        self._info = np.ones(self.total_blocks, dtype=U64), np.ones(self.total_blocks, dtype=U64)
+
+    @property
+    def total_blocks(self):
+        return self.num_integers * self.num_blocks
+
+    @classmethod
+    def from_blocks(cls, h_blocks, streams):
+        """h_blocks: [integer][block][lwe_size] ciphertext words produced by the client key."""
+        h = np.ascontiguousarray(h_blocks, dtype=U64)
+        assert h.ndim == 3
+        return cls(CudaVec.from_cpu_async(h.reshape(-1), streams), h.shape[0], h.shape[1], h.shape[2] - 1)
+
+    @classmethod
+    def zeros_like(cls, other, streams):
+        return cls(CudaVec(other.total_blocks * (other.lwe_dimension + 1), streams), other.num_integers,
+                   other.num_blocks, other.lwe_dimension)
+
+    def duplicate(self, streams):
+        h = self.to_blocks(streams)
+        return CudaUnsignedRadixCiphertext.from_blocks(h, streams)
+
+    def to_blocks(self, streams):
+        return self.d_blocks.copy_to_cpu(streams).reshape(self.num_integers, self.num_blocks, self.lwe_dimension + 1)
+
+    def _ffi(self):
+        deg, noise = self._info
+        return ffi.CudaRadixCiphertextFFI(self.d_blocks.ptr, deg.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                          noise.ctypes.data_as(C.POINTER(C.c_uint64)), self.total_blocks,
+                                          self.total_blocks, self.lwe_dimension)
