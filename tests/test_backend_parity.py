@@ -377,6 +377,33 @@ def test_multi_bit_pbs_bit_exact_and_decrypts(kind, p):
     assert torus_distance(ph(out), ph(exact)) < 2.0 ** 50
 
 
+@pytest.mark.parametrize("kind", BACKENDS)
+@pytest.mark.parametrize("which", ["g3_l2", "g4_l1"])
+def test_multi_bit_throughput_kernel_equals_generic_and_oracle(kind, which):
+    """N=2048, k=1: the multi-bit mode of the wave kernel (kernel id 6) against the generic multi-bit
+    kernel (id 4) and the oracle, bit for bit."""
+    from .common import TOY_MB_2048, TOY_MB4_2048
+    p = TOY_MB_2048 if which == "g3_l2" else TOY_MB4_2048
+    c = ctx(kind, p, "fft64")
+    lib = use_backend(kind)
+    msgs = [m % 16 for m in range(6)]
+    cts = encrypt_small(p, c.keys, msgs, seed=17)
+    f = lambda x: (5 * x + 3) % 16
+    lut = orc.generate_lut(p.k, p.N, p.plaintext_modulus, p.delta, f)
+    lib.hip_backend_set_fft_kernel(2)
+    try:
+        out = c.pbs(cts, lut)
+        assert lib.hip_backend_last_pbs_kernel() == 6
+        lib.hip_backend_set_fft_kernel(1)
+        gen = c.pbs(cts, lut)
+        assert lib.hip_backend_last_pbs_kernel() == 4
+    finally:
+        lib.hip_backend_set_fft_kernel(0)
+    assert np.array_equal(out, gen)
+    assert np.array_equal(out, oracle_pbs(p, c.keys, "fft64", cts, lut))
+    assert [decrypt_big(p, c.keys, o) for o in out] == [f(m) for m in msgs]
+
+
 @pytest.mark.gpu
 def test_multi_bit_full_size_group3():
     """PARAM_MULTI_BIT_GROUP_3_MESSAGE_2_CARRY_2 (n=918, N=2048, l=2, base_log=15, g=3)."""

@@ -394,8 +394,19 @@ void cuda_multi_bit_programmable_bootstrap_64_async(void *stream, uint32_t gpu_i
   m.grouping_factor = grouping_factor;
   m.keybundle = b->keybundle;
   m.chunk = b->chunk;
-  launch_pbs_multi_bit(S(stream), polynomial_size, glwe_dimension, m, b->fft, b->acc);
-  g_last_pbs_kernel.store(4);
+  const uint32_t choice = g_fft_kernel_choice.load();
+  const bool wave_ok = pbs_multi_bit_wave_supported(polynomial_size, glwe_dimension, level_count, base_log,
+                                                    grouping_factor);
+  if (choice == 2) HX_PANIC_IF_FALSE(wave_ok, "throughput kernel requested for an unsupported parameter set");
+  if ((choice == 0 && wave_ok) || choice == 2) {
+    m.pbs.grouping = grouping_factor;
+    m.pbs.keybundle = b->keybundle;
+    launch_pbs_multi_bit_wave(S(stream), m.pbs, b->fft);
+    g_last_pbs_kernel.store(6);
+  } else {
+    launch_pbs_multi_bit(S(stream), polynomial_size, glwe_dimension, m, b->fft, b->acc);
+    g_last_pbs_kernel.store(4);
+  }
 }
 
 void cleanup_cuda_multi_bit_programmable_bootstrap_64(void *stream, uint32_t gpu_index, int8_t **pbs_buffer) {

@@ -26,6 +26,9 @@ struct PbsArgs {
   uint32_t num_many_lut;
   uint32_t lut_stride;
   uint32_t ms_type;    // PBS_MS_REDUCTION_T: 0 none, 1 centered
+  // multi-bit PBS only (0 / null otherwise): grouping factor, per-sample Fourier keybundle scratch
+  uint32_t grouping = 0;
+  void *keybundle = nullptr;
 };
 
 constexpr int ilog2_c(int x) { return x <= 1 ? 0 : 1 + ilog2_c(x / 2); }

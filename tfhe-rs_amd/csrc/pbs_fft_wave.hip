@@ -208,7 +208,8 @@ HX_DEV void inverse_pass1_group(cplx (&o)[16], int g) {
   }
 }
 
-template <bool PASS1_DONE>
+// OVERWRITE (multi-bit: dst = 0 + src (x) GGSW): the result replaces the accumulator and is not staged
+template <bool PASS1_DONE, bool OVERWRITE = false>
 HX_DEV void wave_inverse_accumulate(cplx (&o)[16], uint64_t (&acc_re)[16], uint64_t (&acc_im)[16], WaveCtx c) {
   uint64_t *stg = (uint64_t *)c.buf;
   HX_OPAQUE(c.lane);
@@ -285,19 +286,30 @@ HX_DEV void wave_inverse_accumulate(cplx (&o)[16], uint64_t (&acc_re)[16], uint6
     }
     const double tr = fma(-o[r].im, u.im, o[r].re * u.re);
     const double ti = fma(o[r].im, u.re, o[r].re * u.im);
-    acc_re[r] += from_torus(tr);
-    acc_im[r] += from_torus(ti);
-    // stage the updated coefficients (c = r*64 + lane, 1024 + c) for the next iteration's rotation;
-    // the buffer is free (the M2 -> M1 reads above are complete) and these stores issue under the
-    // conversion arithmetic instead of in front of the next rotation
-    stg[lane_u + r * 64] = acc_re[r];
-    stg[lane_u + 1024 + r * 64] = acc_im[r];
+    if constexpr (OVERWRITE) {
+      acc_re[r] = from_torus(tr);
+      acc_im[r] = from_torus(ti);
+    } else {
+      acc_re[r] += from_torus(tr);
+      acc_im[r] += from_torus(ti);
+      // stage the updated coefficients (c = r*64 + lane, 1024 + c) for the next iteration's rotation;
+      // the buffer is free (the M2 -> M1 reads above are complete) and these stores issue under the
+      // conversion arithmetic instead of in front of the next rotation
+      stg[lane_u + r * 64] = acc_re[r];
+      stg[lane_u + 1024 + r * 64] = acc_im[r];
+    }
     if ((r & 3) == 3) HX_SCHED_FENCE();
   }
   HX_WAVE_SYNC();
 }
 
-template <int LEVEL_CT, int BASE_LOG_CT>
+// MULTIBIT: multi-bit PBS on the same machinery (cc/algorithms/lwe_multi_bit_programmable_bootstrapping.rs
+// :647-880, integer keybundle as multibit.hip): per group of g mask elements each wave builds the 2*level
+// keybundle polynomials of its column with exact integer monomial products, transforms them and parks
+// them in the per-sample scratch (a.keybundle, classic key layout of ONE GGSW), then runs the external
+// product  acc <- acc (x) keybundle  with the classic digit / MAC / inverse code (no rotation, result
+// overwrites the accumulator).
+template <int LEVEL_CT, int BASE_LOG_CT, bool MULTIBIT = false>
 __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables tb) {
   HX_DYN_SMEM(smem);
   const int tid = threadIdx.x;
@@ -352,7 +364,7 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
   if (sample >= a.num_samples) return;  // whole pair leaves together; no later block barrier
   const uint64_t *lwe = a.lwe_in + (size_t)a.in_idx[sample] * (a.n + 1);
   const uint64_t *lut = a.lut + (size_t)a.lut_idx[sample] * 2 * N + (size_t)w * N;
-  const cplx *bsk = (const cplx *)a.bsk;
+  const cplx *bsk = MULTIBIT ? (const cplx *)a.keybundle + (size_t)sample * level * 4 * n : (const cplx *)a.bsk;
   const WaveCtx ctx0{buf, obuf, T, lane, lane >> 2, lane & 3, w};
   const WaveCtx &ctx = ctx0;
 
@@ -413,17 +425,23 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
     HX_OPAQUE(lane);
     // the accumulator is already staged in buf64 (stage_acc at start, then by every
     // wave_inverse_accumulate); later levels of one iteration re-stage, the transposes reused the buffer
-    if (idx != 0) stage_acc();
+    if (!MULTIBIT && idx != 0) stage_acc();
     const uint32_t rr = a_hat & (N - 1);
     const bool odd = (a_hat & N) != 0;
     const uint32_t t0 = (uint32_t)lane - rr;  // (c - rr) for c = lane; wraps mod 2^32, masked below
     HX_UNROLL
     for (int r = 0; r < 16; ++r) {
       const uint32_t c0 = r * 64 + lane, c1 = 1024 + r * 64 + lane;
-      uint64_t s = buf64[(t0 + r * 64) & (N - 1)];
-      const uint64_t x0 = (((c0 < rr) != odd) ? (uint64_t)0 - s : s) - acc_re[r];
-      s = buf64[(t0 + 1024 + r * 64) & (N - 1)];
-      const uint64_t x1 = (((c1 < rr) != odd) ? (uint64_t)0 - s : s) - acc_im[r];
+      uint64_t x0, x1;
+      if constexpr (MULTIBIT) {  // external product of the accumulator itself
+        x0 = acc_re[r];
+        x1 = acc_im[r];
+      } else {
+        uint64_t s = buf64[(t0 + r * 64) & (N - 1)];
+        x0 = (((c0 < rr) != odd) ? (uint64_t)0 - s : s) - acc_re[r];
+        s = buf64[(t0 + 1024 + r * 64) & (N - 1)];
+        x1 = (((c1 < rr) != odd) ? (uint64_t)0 - s : s) - acc_im[r];
+      }
       if constexpr (LEVEL_CT == 1 && BASE_LOG_CT != 0 && BASE_LOG_CT <= 30) {
         // one level: the digit is the decomposer's initial state and depends on the high dword only
         d[r] = cplx{(double)decomp_digit_l1_hi((uint32_t)(x0 >> 32), BASE_LOG_CT),
@@ -468,7 +486,7 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
     const int lane = ctx.lane;
     // wave_forward left my transform in my buffer (mapping M3)
     if (lane == 0) flag_set(f_ready_me, epoch);
-    constexpr int early = (LEVEL_CT == 1) ? WAVE_EARLY_CHUNKS : 0;  // more levels: no registers to spare
+    constexpr int early = (LEVEL_CT == 1 && !MULTIBIT) ? WAVE_EARLY_CHUNKS : 0;  // otherwise requested here
     if (early < 1) key_request(ka0, ka1, b0, b1, 0);
     if (early < 2) key_request(kb0, kb1, b0, b1, 1);
     HX_SCHED_FENCE();
@@ -515,40 +533,117 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
     flag_wait(r_done_ot, epoch);  // the partner must be done with my buffer before I reuse it
   };
 
-  stage_acc();
-  uint32_t it = 0;  // executed iterations (flag epoch)
-  uint64_t mask_next = lwe[0];
-  for (uint32_t i = 0; i < a.n; ++i) {
-    // mask element i was requested one iteration ago (lwe has n + 1 words, so i + 1 is in range)
-    const uint64_t mask_cur = mask_next;
-    mask_next = lwe[i + 1];
-    const uint32_t a_hat = (uint32_t)modulus_switch(mask_cur, LOG2N2);
-    if (a_hat == 0) continue;  // uniform over the pair (bootstrap.rs:334)
-    ++it;
-    if constexpr (LEVEL_CT == 1) {
-      cplx d[16], ka0[4], ka1[4], kb0[4], kb1[4];
-      const cplx *b0, *b1;
-      key_rows(i, 0, b0, b1);
-      if (WAVE_EARLY_CHUNKS >= 1) key_request(ka0, ka1, b0, b1, 0);
-      if (WAVE_EARLY_CHUNKS >= 2) key_request(kb0, kb1, b0, b1, 1);
-      HX_SCHED_FENCE();
-      make_digits(d, a_hat, 0);
-      wave_forward(d, ctx);
-      // in place: d becomes the Fourier-domain output of polynomial w, first inverse pass applied
-      mac(d, d, ka0, ka1, kb0, kb1, b0, b1, 0, it, std::integral_constant<bool, WAVE_FUSE_PASS1 != 0>{});
-      wave_inverse_accumulate<WAVE_FUSE_PASS1 != 0>(d, acc_re, acc_im, ctx);
-    } else {
+  if constexpr (MULTIBIT) {
+    const uint32_t g = a.grouping, per = 1u << g, groups = a.n / g;
+    const uint64_t *key = (const uint64_t *)a.bsk;  // standard domain: [group][subset][level][row][col][N]
+    const size_t ggsw_sz = (size_t)level * 4 * N;
+    cplx *kbs = (cplx *)a.keybundle + (size_t)sample * level * 4 * n;
+    for (uint32_t grp = 0; grp < groups; ++grp) {
+      // monomial degrees of the 2^g - 1 non-empty subsets (:30-65): subset s selects mask element m of
+      // the group when bit (g-1-m) of s is set
+      uint32_t deg[16];
+      {
+        uint64_t m[4] = {0, 0, 0, 0};
+        for (uint32_t q = 0; q < g; ++q) m[q] = lwe[(size_t)grp * g + q];
+        for (uint32_t sidx = 1; sidx < per; ++sidx) {
+          uint64_t sum = 0;
+          for (uint32_t q = 0; q < g; ++q)
+            if ((sidx >> (g - 1 - q)) & 1) sum += m[q];
+          deg[sidx] = (uint32_t)modulus_switch(sum, LOG2N2);
+        }
+      }
+      const uint64_t *gk = key + (size_t)grp * per * ggsw_sz;
+      // ---- keybundle polynomials [idx][row][col = w]: integer combine, to the torus, transform, park
+      for (uint32_t idx = 0; idx < level; ++idx)
+        for (uint32_t row = 0; row < 2; ++row) {
+          const size_t poly = ((size_t)idx * 2 + row) * 2 + w;
+          int ln = ctx.lane;
+          HX_OPAQUE(ln);
+          uint64_t v_re[16], v_im[16];
+          {
+            const uint64_t *p0 = gk + poly * N + ln;  // subset 0 is not rotated
+            HX_UNROLL
+            for (int r = 0; r < 16; ++r) {
+              v_re[r] = p0[r * 64];
+              v_im[r] = p0[1024 + r * 64];
+            }
+          }
+          for (uint32_t sidx = 1; sidx < per; ++sidx) {
+            const uint64_t *ps = gk + (size_t)sidx * ggsw_sz + poly * N;
+            const uint32_t rr = deg[sidx] & (N - 1);
+            const bool odd = (deg[sidx] & N) != 0;
+            const uint32_t t0 = (uint32_t)ln - rr;
+            HX_UNROLL
+            for (int r = 0; r < 16; ++r) {
+              const uint32_t c0 = r * 64 + ln, c1 = 1024 + r * 64 + ln;
+              const uint64_t x0 = ps[(t0 + r * 64) & (N - 1)];
+              const uint64_t x1 = ps[(t0 + 1024 + r * 64) & (N - 1)];
+              v_re[r] += ((c0 < rr) != odd) ? (uint64_t)0 - x0 : x0;
+              v_im[r] += ((c1 < rr) != odd) ? (uint64_t)0 - x1 : x1;
+            }
+            HX_SCHED_FENCE();
+          }
+          cplx d[16];
+          HX_UNROLL
+          for (int r = 0; r < 16; ++r)  // fold + scale to the torus (fft/mod.rs:201-222)
+            d[r] = cplx{i64_to_f64((int64_t)v_re[r]) * 5.421010862427522e-20,
+                        i64_to_f64((int64_t)v_im[r]) * 5.421010862427522e-20};
+          wave_forward(d, ctx);
+          cplx *dst = kbs + poly * n + ln;  // storage slot r*64 + lane = the classic key order (bsk_slot)
+          HX_UNROLL
+          for (int r = 0; r < 16; ++r) dst[r * 64] = d[r];
+        }
+      __threadfence_block();  // my parked polynomials are read back below by this wave only
+      HX_WAVE_SYNC();
+      // ---- acc <- acc (x) keybundle
       cplx o[16];
       for (uint32_t idx = 0; idx < level; ++idx) {
         cplx d[16], ka0[4], ka1[4], kb0[4], kb1[4];
         const cplx *b0, *b1;
-        key_rows(i, idx, b0, b1);
+        key_rows(0, idx, b0, b1);
         HX_SCHED_FENCE();
-        make_digits(d, a_hat, idx);
+        make_digits(d, 0, idx);
         wave_forward(d, ctx);
-        mac(o, d, ka0, ka1, kb0, kb1, b0, b1, idx, (it - 1) * level + idx + 1, std::false_type{});
+        mac(o, d, ka0, ka1, kb0, kb1, b0, b1, idx, grp * level + idx + 1, std::false_type{});
       }
-      wave_inverse_accumulate<false>(o, acc_re, acc_im, ctx);
+      wave_inverse_accumulate<false, true>(o, acc_re, acc_im, ctx);
+    }
+  } else {
+    stage_acc();
+    uint32_t it = 0;  // executed iterations (flag epoch)
+    uint64_t mask_next = lwe[0];
+    for (uint32_t i = 0; i < a.n; ++i) {
+      // mask element i was requested one iteration ago (lwe has n + 1 words, so i + 1 is in range)
+      const uint64_t mask_cur = mask_next;
+      mask_next = lwe[i + 1];
+      const uint32_t a_hat = (uint32_t)modulus_switch(mask_cur, LOG2N2);
+      if (a_hat == 0) continue;  // uniform over the pair (bootstrap.rs:334)
+      ++it;
+      if constexpr (LEVEL_CT == 1) {
+        cplx d[16], ka0[4], ka1[4], kb0[4], kb1[4];
+        const cplx *b0, *b1;
+        key_rows(i, 0, b0, b1);
+        if (WAVE_EARLY_CHUNKS >= 1) key_request(ka0, ka1, b0, b1, 0);
+        if (WAVE_EARLY_CHUNKS >= 2) key_request(kb0, kb1, b0, b1, 1);
+        HX_SCHED_FENCE();
+        make_digits(d, a_hat, 0);
+        wave_forward(d, ctx);
+        // in place: d becomes the Fourier-domain output of polynomial w, first inverse pass applied
+        mac(d, d, ka0, ka1, kb0, kb1, b0, b1, 0, it, std::integral_constant<bool, WAVE_FUSE_PASS1 != 0>{});
+        wave_inverse_accumulate<WAVE_FUSE_PASS1 != 0>(d, acc_re, acc_im, ctx);
+      } else {
+        cplx o[16];
+        for (uint32_t idx = 0; idx < level; ++idx) {
+          cplx d[16], ka0[4], ka1[4], kb0[4], kb1[4];
+          const cplx *b0, *b1;
+          key_rows(i, idx, b0, b1);
+          HX_SCHED_FENCE();
+          make_digits(d, a_hat, idx);
+          wave_forward(d, ctx);
+          mac(o, d, ka0, ka1, kb0, kb1, b0, b1, idx, (it - 1) * level + idx + 1, std::false_type{});
+        }
+        wave_inverse_accumulate<false>(o, acc_re, acc_im, ctx);
+      }
     }
   }
 
@@ -589,6 +684,26 @@ static void launch_wave_t(hipStream_t st, const PbsArgs &a, const FftTables &tb)
                                (int)SMEM_BYTES));
   const unsigned blocks = (a.num_samples + LWES_PER_BLOCK - 1) / LWES_PER_BLOCK;
   HX_LAUNCH((pbs_fft_wave_kernel<L, B>), dim3(blocks), dim3(TPB), SMEM_BYTES, st, a, tb);
+}
+
+bool pbs_multi_bit_wave_supported(uint32_t N, uint32_t glwe_dim, uint32_t level, uint32_t base_log, uint32_t grouping) {
+  return N == 2048 && glwe_dim == 1 && level >= 1 && level <= 4 && base_log <= 31 && grouping >= 1 && grouping <= 4;
+}
+
+template <int L, int B>
+static void launch_wave_mb_t(hipStream_t st, const PbsArgs &a, const FftTables &tb) {
+  using namespace wavek;
+  HX_CHECK(hipFuncSetAttribute((const void *)pbs_fft_wave_kernel<L, B, true>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM_BYTES));
+  const unsigned blocks = (a.num_samples + LWES_PER_BLOCK - 1) / LWES_PER_BLOCK;
+  HX_LAUNCH((pbs_fft_wave_kernel<L, B, true>), dim3(blocks), dim3(TPB), SMEM_BYTES, st, a, tb);
+}
+
+// a.grouping and a.keybundle set; a.bsk = standard-domain multi-bit key
+void launch_pbs_multi_bit_wave(hipStream_t st, const PbsArgs &a, const FftTables &tb) {
+  if (a.level == 2 && a.base_log == 15) launch_wave_mb_t<2, 15>(st, a, tb);  // PARAM_MULTI_BIT_GROUP_3_MESSAGE_2_CARRY_2
+  else if (a.level == 1 && a.base_log == 22) launch_wave_mb_t<1, 22>(st, a, tb);  // the GPU group-4 sets
+  else launch_wave_mb_t<0, 0>(st, a, tb);
 }
 
 void launch_pbs_fft_wave(hipStream_t st, const PbsArgs &a, const FftTables &tb) {

@@ -123,7 +123,7 @@ if __name__ == "__main__":
     if "ntt" in which:
         pbs_case(C1, 1024, engine="ntt64", steps=2)
     if "mb" in which:
-        pbs_case(C4, 512, steps=2)
+        pbs_case(C4, 4096, steps=2)
     if "n1024" in which:
         pbs_case(C1P, 4096, steps=3)
     if "sweep" in which:
