@@ -188,6 +188,10 @@ def main():
         t0 = time.perf_counter()
         orc.pbs_batch(orc.ENGINE_FFT, cts[:cores], lut, bsk_f, p.n, p.k, p.N, p.pbs_base_log, p.pbs_level, 1,
                       threads=cores)
+        # second calibration pass: the first one pays thread start-up and cold caches
+        t0 = time.perf_counter()
+        orc.pbs_batch(orc.ENGINE_FFT, cts[:cores], lut, bsk_f, p.n, p.k, p.N, p.pbs_base_log, p.pbs_level, 1,
+                      threads=cores)
         calib = time.perf_counter() - t0
         count = args.cpu_sample or int(max(cores, min(B, cores * max(1, round(15.0 / max(calib, 1e-3))))))
         t0 = time.perf_counter()
