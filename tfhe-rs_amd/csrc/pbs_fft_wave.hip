@@ -335,7 +335,7 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
   // ---- one-time: compact twiddle table into LDS, flags to zero
   {
     cplx *Tw = (cplx *)(smem + (size_t)WAVES * BUF_BYTES);
-    for (int e = tid; e < T_TOTAL; e += TPB) {
+    for (int e = tid; e < T_TOTAL; e += (int)blockDim.x) {
       cplx v{0.0, 0.0};
       if (e < T_F2) {             // forward d = 0..3, even groups
         const int x = e - T_F1;
@@ -360,7 +360,8 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
   }
   __syncthreads();
 
-  const uint32_t sample = blockIdx.x * LWES_PER_BLOCK + pair;
+  // the launch picks 1..4 LWEs per workgroup (blockDim.x = 128 per LWE): small batches spread over the CUs
+  const uint32_t sample = blockIdx.x * (blockDim.x >> 7) + pair;
   if (sample >= a.num_samples) return;  // whole pair leaves together; no later block barrier
   const uint64_t *lwe = a.lwe_in + (size_t)a.in_idx[sample] * (a.n + 1);
   const uint64_t *lut = a.lut + (size_t)a.lut_idx[sample] * 2 * N + (size_t)w * N;
@@ -673,6 +674,13 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
 
 }  // namespace wavek
 
+// LWEs per workgroup (= per CU): as few as keeps every one of the 256 CUs busy — a lone wave pair runs an
+// iteration in 7.6 us, four pairs sharing a CU need 12.4 us each
+static unsigned lwes_per_block(uint32_t num_samples) {
+  const unsigned want = (num_samples + 255) / 256;
+  return want < 1 ? 1 : (want > (unsigned)wavek::LWES_PER_BLOCK ? (unsigned)wavek::LWES_PER_BLOCK : want);
+}
+
 bool pbs_fft_wave_supported(uint32_t N, uint32_t glwe_dim, uint32_t level) {
   return N == 2048 && glwe_dim == 1 && level >= 1 && level <= 4;
 }
@@ -682,8 +690,9 @@ static void launch_wave_t(hipStream_t st, const PbsArgs &a, const FftTables &tb)
   using namespace wavek;
   HX_CHECK(hipFuncSetAttribute((const void *)pbs_fft_wave_kernel<L, B>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)SMEM_BYTES));
-  const unsigned blocks = (a.num_samples + LWES_PER_BLOCK - 1) / LWES_PER_BLOCK;
-  HX_LAUNCH((pbs_fft_wave_kernel<L, B>), dim3(blocks), dim3(TPB), SMEM_BYTES, st, a, tb);
+  const unsigned per_block = lwes_per_block(a.num_samples);
+  const unsigned blocks = (a.num_samples + per_block - 1) / per_block;
+  HX_LAUNCH((pbs_fft_wave_kernel<L, B>), dim3(blocks), dim3(128 * per_block), SMEM_BYTES, st, a, tb);
 }
 
 bool pbs_multi_bit_wave_supported(uint32_t N, uint32_t glwe_dim, uint32_t level, uint32_t base_log, uint32_t grouping) {
@@ -695,8 +704,9 @@ static void launch_wave_mb_t(hipStream_t st, const PbsArgs &a, const FftTables &
   using namespace wavek;
   HX_CHECK(hipFuncSetAttribute((const void *)pbs_fft_wave_kernel<L, B, true>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM_BYTES));
-  const unsigned blocks = (a.num_samples + LWES_PER_BLOCK - 1) / LWES_PER_BLOCK;
-  HX_LAUNCH((pbs_fft_wave_kernel<L, B, true>), dim3(blocks), dim3(TPB), SMEM_BYTES, st, a, tb);
+  const unsigned per_block = lwes_per_block(a.num_samples);
+  const unsigned blocks = (a.num_samples + per_block - 1) / per_block;
+  HX_LAUNCH((pbs_fft_wave_kernel<L, B, true>), dim3(blocks), dim3(128 * per_block), SMEM_BYTES, st, a, tb);
 }
 
 // a.grouping and a.keybundle set; a.bsk = standard-domain multi-bit key

@@ -30,6 +30,8 @@ def rand_u64(n):
 
 
 def timed(fn, steps=3, warmup=1):
+    if "mb1" in sys.argv:
+        warmup = 0
     for _ in range(warmup):
         fn()
     lib.cuda_synchronize_device(G)
@@ -124,8 +126,14 @@ if __name__ == "__main__":
         pbs_case(C1, 1024, engine="ntt64", steps=2)
     if "mb" in which:
         pbs_case(C4, 4096, steps=2)
+    if "mb1" in which:   # one launch, no warm-up (PMC passes)
+        pbs_case(C4, 4096, steps=1)
     if "n1024" in which:
         pbs_case(C1P, 4096, steps=3)
+    if "latency" in which:
+        for kern in (1, 2):
+            for B in (1, 2, 8, 32):
+                pbs_case(C1, B, kernel=kern, steps=5)
     if "sweep" in which:
         for B in (1, 4, 64, 256, 1024, 2048, 8192):
             pbs_case(C1, B, kernel=2, steps=3)
