@@ -44,6 +44,8 @@ void check_pow2_poly(uint32_t N) {
                     "polynomial_size %u not supported by the MI355X PBS (256..4096, power of two)", N);
 }
 
+constexpr uint32_t kLatencyKernelMaxBatch = 256;  // measured (tools/measure_all.py latency): 4.3 ms vs 7.1 ms up to 256 LWEs, slower beyond
+
 PbsArgs make_args(void *lwe_array_out, void const *lwe_output_indexes, void const *lut_vector,
                   void const *lut_vector_indexes, void const *lwe_array_in, void const *lwe_input_indexes,
                   void const *bootstrapping_key, uint32_t lwe_dimension, uint32_t base_log, uint32_t level_count,
@@ -251,8 +253,14 @@ void cuda_programmable_bootstrap_64_async(void *stream, uint32_t gpu_index, void
                               num_samples, num_many_lut, lut_stride, b->ms_type);
   const uint32_t choice = g_fft_kernel_choice.load();
   const bool wave_ok = pbs_fft_wave_supported(polynomial_size, glwe_dimension, level_count) && base_log <= 31;
+  const bool block_ok = pbs_fft_block_supported(polynomial_size, glwe_dimension, level_count);
   if (choice == 2) HX_PANIC_IF_FALSE(wave_ok, "throughput kernel requested for an unsupported parameter set");
-  if ((choice == 0 && wave_ok) || choice == 2) {
+  if (choice == 3) HX_PANIC_IF_FALSE(block_ok, "latency kernel requested for an unsupported parameter set");
+  // automatic choice: up to one LWE per CU the latency kernel finishes first; beyond, the throughput kernel
+  if (choice == 3 || (choice == 0 && block_ok && num_samples <= kLatencyKernelMaxBatch)) {
+    launch_pbs_fft_block(S(stream), a, b->fft);
+    g_last_pbs_kernel.store(7);
+  } else if ((choice == 0 && wave_ok) || choice == 2) {
     launch_pbs_fft_wave(S(stream), a, b->fft);
     g_last_pbs_kernel.store(2);
   } else {

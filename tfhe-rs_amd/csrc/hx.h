@@ -16,6 +16,7 @@
 #define HX_SCHED_FENCE() do { } while (0)
 #define HX_OPAQUE(v) do { } while (0)
 #define HX_UNIFORM(v) (v)
+#define HX_BLOCK_SYNC_LDS() __syncthreads()
 #else
 #include <hip/hip_runtime.h>
 #define HX_LAUNCH(kern, grid, block, smem, stream, ...) \
@@ -38,6 +39,10 @@
 #define HX_OPAQUE(v) asm volatile("" : "+v"(v))
 // wave-uniform value into an SGPR
 #define HX_UNIFORM(v) __builtin_amdgcn_readfirstlane(v)
+// workgroup barrier for data exchanged through LDS only: waits for this wave's LDS traffic, not for its
+// outstanding global loads (__syncthreads() drains vmcnt too, which would expose the latency of key
+// loads that were deliberately issued early)
+#define HX_BLOCK_SYNC_LDS() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #endif
 
 #define HX_DEV __device__ __forceinline__

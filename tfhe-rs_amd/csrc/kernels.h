@@ -18,6 +18,10 @@ void launch_pbs_fft_wave(hipStream_t st, const PbsArgs &a, const FftTables &tb);
 bool pbs_multi_bit_wave_supported(uint32_t N, uint32_t glwe_dim, uint32_t level, uint32_t base_log, uint32_t grouping);
 void launch_pbs_multi_bit_wave(hipStream_t st, const PbsArgs &a, const FftTables &tb);
 
+// latency kernel for N=2048, k=1: one workgroup per LWE — pbs_fft_block.hip
+bool pbs_fft_block_supported(uint32_t N, uint32_t glwe_dim, uint32_t level);
+void launch_pbs_fft_block(hipStream_t st, const PbsArgs &a, const FftTables &tb);
+
 // keyswitch — keyswitch.hip
 void launch_keyswitch(hipStream_t st, uint64_t *lwe_out, const uint64_t *out_idx, const uint64_t *lwe_in,
                       const uint64_t *in_idx, const uint64_t *ksk, uint32_t n_in, uint32_t n_out,
