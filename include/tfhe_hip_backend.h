@@ -292,11 +292,14 @@ void cleanup_cuda_integer_mult_inplace_64(CudaStreamsFFI streams, int8_t **mem_p
 void hip_integer_scratch_batch(uint32_t num_integers);
 uint64_t hip_integer_mult_pbs_count(int8_t *mem_ptr);
 
-/* Select which f64 kernel serves cuda_programmable_bootstrap_64_async:
- * 0 = automatic (throughput kernel when the parameter set supports it), 1 = generic LDS
- * kernel, 2 = throughput kernel (abort if unsupported).  Both give identical bits. */
+/* Select which f64 kernel serves cuda_programmable_bootstrap_64_async (all give identical bits):
+ * 0 = automatic (N=2048,k=1: latency kernel up to 256 LWEs, throughput kernel beyond; generic otherwise),
+ * 1 = generic LDS kernel, 2 = throughput (wave) kernel, 3 = latency (block) kernel, 4 = its dual-stream
+ * variant; 2..4 abort on unsupported parameter sets.  For the multi-bit entry point 2 selects the
+ * multi-bit mode of the throughput kernel, 1 the generic multi-bit kernel. */
 void hip_backend_set_fft_kernel(uint32_t which);
-/* last launched PBS kernel, for tests: 1 generic f64, 2 wave f64, 3 generic ntt, 4 multi-bit, 5 exact */
+/* last launched PBS kernel, for tests: 1 generic f64, 2 wave f64, 3 generic ntt, 4 generic multi-bit,
+ * 5 exact, 6 wave multi-bit, 7 block (latency), 8 block dual-stream */
 uint32_t hip_backend_last_pbs_kernel(void);
 const char *hip_backend_version(void);
 

@@ -278,7 +278,7 @@ def test_wave_kernel_equals_generic_and_oracle(kind, p):
     ref = oracle_pbs(p, c.keys, "fft64", cts, lut)
     outs = {}
     try:
-        for which, kid in ((1, 1), (2, 2), (3, 7)):   # generic, throughput (wave), latency (block) kernels
+        for which, kid in ((1, 1), (2, 2), (3, 7), (4, 8)):   # generic, throughput (wave), latency (block) x2
             c.lib.hip_backend_set_fft_kernel(which)
             outs[which] = c.pbs(cts, lut)
             assert c.lib.hip_backend_last_pbs_kernel() == kid
@@ -287,6 +287,7 @@ def test_wave_kernel_equals_generic_and_oracle(kind, p):
     assert np.array_equal(outs[1], ref)
     assert np.array_equal(outs[2], ref)
     assert np.array_equal(outs[3], ref)
+    assert np.array_equal(outs[4], ref)
     assert [decrypt_big(p, c.keys, o) for o in outs[2]] == [f(m) for m in msgs]
 
 
@@ -300,7 +301,7 @@ def test_wave_kernel_many_lut_and_indexes(kind):
     stride = p.N // (2 * p.plaintext_modulus)
     res = {}
     try:
-        for which in (1, 2, 3):
+        for which in (1, 2, 3, 4):
             c.lib.hip_backend_set_fft_kernel(which)
             res[which] = c.pbs(cts, lut, in_indexes=[4, 2, 0], out_indexes=[1, 2, 0], out_count=6,
                                num_many_lut=2, lut_stride=stride)
@@ -308,6 +309,7 @@ def test_wave_kernel_many_lut_and_indexes(kind):
         c.lib.hip_backend_set_fft_kernel(0)
     assert np.array_equal(res[1], res[2])
     assert np.array_equal(res[1], res[3])
+    assert np.array_equal(res[1], res[4])
 
 
 @pytest.mark.gpu
@@ -324,7 +326,7 @@ def test_full_size_param_message_2_carry_2_bit_exact():
     c = Ctx("hip", p, keys, "fft64")
     ref = oracle_pbs(p, keys, "fft64", cts, lut)
     try:
-        for which in (3, 2, 1):
+        for which in (4, 3, 2, 1):
             c.lib.hip_backend_set_fft_kernel(which)
             out = c.pbs(cts, lut)
             assert np.array_equal(out, ref), f"f64 kernel {which} differs from the oracle at full size"

@@ -20,7 +20,7 @@ void launch_pbs_multi_bit_wave(hipStream_t st, const PbsArgs &a, const FftTables
 
 // latency kernel for N=2048, k=1: one workgroup per LWE — pbs_fft_block.hip
 bool pbs_fft_block_supported(uint32_t N, uint32_t glwe_dim, uint32_t level);
-void launch_pbs_fft_block(hipStream_t st, const PbsArgs &a, const FftTables &tb);
+void launch_pbs_fft_block(hipStream_t st, const PbsArgs &a, const FftTables &tb, int variant);
 
 // keyswitch — keyswitch.hip
 void launch_keyswitch(hipStream_t st, uint64_t *lwe_out, const uint64_t *out_idx, const uint64_t *lwe_in,

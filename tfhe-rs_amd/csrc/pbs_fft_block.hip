@@ -292,6 +292,212 @@ __global__ void __launch_bounds__(TPB) pbs_fft_block_kernel(PbsArgs a, FftTables
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Dual-stream variant: 256 threads, every thread carries its 4 points of BOTH polynomials.  The two
+// transforms are independent instruction streams inside one wave (the LDS round trip of one is covered by
+// the butterflies of the other), the twiddles are shared, and the multiply-accumulate needs no exchange at
+// all: a thread already holds both transforms at its positions.  3 s_barrier per CMUX iteration.
+constexpr int TPB2 = 256;
+constexpr size_t SMEM2_BYTES = STAGE_BYTES + WORK_BYTES + 64;
+
+template <int LEVEL_CT, int BASE_LOG_CT>
+__global__ void __launch_bounds__(TPB2) pbs_fft_block2_kernel(PbsArgs a, FftTables tb) {
+  HX_DYN_SMEM(smem);
+  const int t = threadIdx.x;
+  uint64_t *stage = (uint64_t *)smem;                   // [polynomial][N]
+  cplx *work = (cplx *)(smem + STAGE_BYTES);            // [polynomial][BUF_SLOTS]
+  uint64_t *red = (uint64_t *)(smem + STAGE_BYTES);     // reduction scratch before the loop
+
+  const uint32_t level = LEVEL_CT ? (uint32_t)LEVEL_CT : a.level;
+  const uint32_t base_log = BASE_LOG_CT ? (uint32_t)BASE_LOG_CT : a.base_log;
+  const uint32_t sample = blockIdx.x;
+  const uint64_t *lwe = a.lwe_in + (size_t)a.in_idx[sample] * (a.n + 1);
+  const uint64_t *lut = a.lut + (size_t)a.lut_idx[sample] * 2 * N;
+  const cplx *bsk = (const cplx *)a.bsk;
+
+  cplx fw[5][3], iw[5][3], un[4];
+  HX_UNROLL
+  for (int P = 0; P < 5; ++P) {
+    const int hi = t >> (8 - 2 * P);
+    fw[P][0] = ldc(tb.fwd, (1 << (2 * P)) + hi);
+    fw[P][1] = ldc(tb.fwd, (2 << (2 * P)) + 2 * hi);
+    fw[P][2] = ldc(tb.fwd, (2 << (2 * P)) + 2 * hi + 1);
+  }
+  HX_UNROLL
+  for (int Q = 1; Q < 5; ++Q) {
+    const int lo = t & ((1 << (2 * Q)) - 1);
+    iw[Q][0] = ldc(tb.inv, (1 << (2 * Q)) + lo);
+    iw[Q][1] = ldc(tb.inv, (2 << (2 * Q)) + lo);
+    iw[Q][2] = ldc(tb.inv, (2 << (2 * Q)) + (1 << (2 * Q)) + lo);
+  }
+  HX_UNROLL
+  for (int r = 0; r < 4; ++r) un[r] = ldc(tb.untw, r * 256 + t);
+
+  uint64_t corr = 0;
+  if (a.ms_type == 1) {
+    uint64_t sh = 0;
+    int64_t sd = 0;
+    for (uint32_t i = t; i < a.n; i += TPB2) {
+      uint64_t h;
+      int64_t dd;
+      centered_ms_terms(lwe[i], LOG2N2, h, dd);
+      sh += h;
+      sd += dd;
+    }
+    red[t] = sh;
+    red[TPB2 + t] = (uint64_t)sd;
+    __syncthreads();
+    uint64_t th = 0, td = 0;
+    for (int l = 0; l < TPB2; ++l) {
+      th += red[l];
+      td += red[TPB2 + l];
+    }
+    __syncthreads();
+    corr = centered_ms_finish(th, (int64_t)td, LOG2N2);
+  }
+  const uint32_t b_hat = (uint32_t)modulus_switch(lwe[a.n] + corr, LOG2N2);
+
+  uint64_t acc_re[2][4], acc_im[2][4];
+  HX_UNROLL
+  for (int w = 0; w < 2; ++w)
+    HX_UNROLL
+    for (int r = 0; r < 4; ++r) {
+      bool neg;
+      uint32_t src = monomial_div_src(r * 256 + t, b_hat, N, neg);
+      uint64_t v = lut[w * N + src];
+      acc_re[w][r] = neg ? (uint64_t)0 - v : v;
+      src = monomial_div_src(1024 + r * 256 + t, b_hat, N, neg);
+      v = lut[w * N + src];
+      acc_im[w][r] = neg ? (uint64_t)0 - v : v;
+      stage[w * N + r * 256 + t] = acc_re[w][r];
+      stage[w * N + 1024 + r * 256 + t] = acc_im[w][r];
+    }
+  __syncthreads();
+
+  uint64_t mask_next = lwe[0];
+  for (uint32_t i = 0; i < a.n; ++i) {
+    const uint64_t mask_cur = mask_next;  // requested one iteration ago (lwe has n + 1 words)
+    mask_next = lwe[i + 1];
+    const uint32_t a_hat = (uint32_t)modulus_switch(mask_cur, LOG2N2);
+    if (a_hat == 0) continue;  // uniform over the workgroup (bootstrap.rs:334)
+    const uint32_t rr = a_hat & (N - 1);
+    const bool odd = (a_hat & N) != 0;
+    cplx o[2][4];
+    for (uint32_t idx = 0; idx < level; ++idx) {
+      // key rows [i][idx][row][col] at the storage slots of my 4 positions (pos = 4t + r)
+      cplx key[2][2][4];
+      HX_UNROLL
+      for (int row = 0; row < 2; ++row)
+        HX_UNROLL
+        for (int col = 0; col < 2; ++col) {
+          const cplx *b = bsk + ((((size_t)i * level + idx) * 2 + row) * 2 + col) * n;
+          HX_UNROLL
+          for (int r = 0; r < 4; ++r) key[row][col][r] = b[bsk_slot<N, 2>(4 * t + r)];
+        }
+      // ---- digits of (acc * X^a_hat - acc) at level idx, map pos = 256 r + t, both polynomials
+      cplx d[2][4];
+      HX_UNROLL
+      for (int w = 0; w < 2; ++w)
+        HX_UNROLL
+        for (int r = 0; r < 4; ++r) {
+          const uint32_t c0 = r * 256 + t, c1 = 1024 + r * 256 + t;
+          uint64_t s = stage[w * N + ((c0 - rr) & (N - 1))];
+          const uint64_t x0 = (((c0 < rr) != odd) ? (uint64_t)0 - s : s) - acc_re[w][r];
+          s = stage[w * N + ((c1 - rr) & (N - 1))];
+          const uint64_t x1 = (((c1 < rr) != odd) ? (uint64_t)0 - s : s) - acc_im[w][r];
+          if constexpr (LEVEL_CT == 1 && BASE_LOG_CT != 0 && BASE_LOG_CT <= 30) {
+            d[w][r] = cplx{(double)decomp_digit_l1_hi((uint32_t)(x0 >> 32), BASE_LOG_CT),
+                           (double)decomp_digit_l1_hi((uint32_t)(x1 >> 32), BASE_LOG_CT)};
+          } else {
+            d[w][r] = cplx{i64_to_f64(decomp_digit(x0, base_log, level, idx)),
+                           i64_to_f64(decomp_digit(x1, base_log, level, idx))};
+          }
+        }
+      // ---- forward transforms: 5 passes, the two polynomials interleaved
+      HX_UNROLL
+      for (int P = 0; P < 5; ++P) {
+        if (P > 0) {
+          HX_UNROLL
+          for (int w = 0; w < 2; ++w)
+            HX_UNROLL
+            for (int r = 0; r < 4; ++r) d[w][r] = work[w * BUF_SLOTS + lay(4 - P, fwd_pos(P, t, r))];
+          HX_WAVE_SYNC();  // the next exchange reuses these slots in another layout
+        }
+        HX_UNROLL
+        for (int w = 0; w < 2; ++w) {
+          fwd_pass(d[w], fw[P][0], fw[P][1], fw[P][2]);
+          if (P < 4) {
+            HX_UNROLL
+            for (int r = 0; r < 4; ++r) work[w * BUF_SLOTS + lay(3 - P, fwd_pos(P, t, r))] = d[w][r];
+          }
+        }
+        if (P < 4) {
+          // pass P+1 regroups threads whose index differs in bits (7-2P, 6-2P): other waves only for P = 0
+          if (P == 0) HX_BLOCK_SYNC_LDS();
+          else HX_WAVE_SYNC();
+        }
+      }
+      // ---- multiply-accumulate: both transforms are here (cc/fft_impl/fft64/crypto/ggsw.rs:616-697 order)
+      HX_UNROLL
+      for (int col = 0; col < 2; ++col)
+        HX_UNROLL
+        for (int r = 0; r < 4; ++r) {
+          const cplx tt = (idx == 0) ? cmul_first(d[0][r], key[0][col][r]) : cmul_add(d[0][r], key[0][col][r], o[col][r]);
+          o[col][r] = cmul_add(d[1][r], key[1][col][r], tt);
+        }
+    }
+    // ---- inverse transforms: pass 0 in place, then 4 exchanges
+    HX_UNROLL
+    for (int w = 0; w < 2; ++w) inv_pass0(o[w]);
+    HX_UNROLL
+    for (int Q = 1; Q < 5; ++Q) {
+      HX_UNROLL
+      for (int w = 0; w < 2; ++w)
+        HX_UNROLL
+        for (int r = 0; r < 4; ++r) work[w * BUF_SLOTS + lay(Q - 1, inv_pos(Q - 1, t, r))] = o[w][r];
+      // pass Q regroups threads whose index differs in bits (2Q-1, 2Q-2): other waves only for Q = 4
+      if (Q == 4) HX_BLOCK_SYNC_LDS();
+      else HX_WAVE_SYNC();
+      HX_UNROLL
+      for (int w = 0; w < 2; ++w)
+        HX_UNROLL
+        for (int r = 0; r < 4; ++r) o[w][r] = work[w * BUF_SLOTS + lay(Q - 1, inv_pos(Q, t, r))];
+      HX_WAVE_SYNC();  // the next exchange reuses these slots in another layout
+      HX_UNROLL
+      for (int w = 0; w < 2; ++w) inv_pass(o[w], iw[Q][0], iw[Q][1], iw[Q][2]);
+    }
+    // ---- untwist, back to the torus, accumulate, restage (fft/mod.rs:311-330); map pos = 256 r + t
+    HX_UNROLL
+    for (int w = 0; w < 2; ++w)
+      HX_UNROLL
+      for (int r = 0; r < 4; ++r) {
+        const double tr = fma(-o[w][r].im, un[r].im, o[w][r].re * un[r].re);
+        const double ti = fma(o[w][r].im, un[r].re, o[w][r].re * un[r].im);
+        acc_re[w][r] += from_torus(tr);
+        acc_im[w][r] += from_torus(ti);
+        stage[w * N + r * 256 + t] = acc_re[w][r];
+        stage[w * N + 1024 + r * 256 + t] = acc_im[w][r];
+      }
+    HX_BLOCK_SYNC_LDS();
+  }
+
+  // ---- sample extraction (cc/algorithms/glwe_sample_extraction.rs:119-146); many-LUT outputs
+  const size_t out_sz = (size_t)N + 1;
+  for (uint32_t m = 0; m < a.num_many_lut; ++m) {
+    const uint32_t nth = m * a.lut_stride;
+    uint64_t *out = a.lwe_out + (size_t)m * a.num_samples * out_sz + (size_t)a.out_idx[sample] * out_sz;
+    HX_UNROLL
+    for (int r = 0; r < 4; ++r) {
+      uint32_t c = r * 256 + t;
+      out[c <= nth ? nth - c : N + nth - c] = c <= nth ? acc_re[0][r] : (uint64_t)0 - acc_re[0][r];
+      if (c == nth) out[N] = acc_re[1][r];
+      c += 1024;
+      out[c <= nth ? nth - c : N + nth - c] = c <= nth ? acc_im[0][r] : (uint64_t)0 - acc_im[0][r];
+      if (c == nth) out[N] = acc_im[1][r];
+    }
+  }
+}
+
 }  // namespace blockk
 
 bool pbs_fft_block_supported(uint32_t N, uint32_t glwe_dim, uint32_t level) {
@@ -306,9 +512,23 @@ static void launch_block_t(hipStream_t st, const PbsArgs &a, const FftTables &tb
   HX_LAUNCH((pbs_fft_block_kernel<L, B>), dim3(a.num_samples), dim3(TPB), SMEM_BYTES, st, a, tb);
 }
 
-void launch_pbs_fft_block(hipStream_t st, const PbsArgs &a, const FftTables &tb) {
-  if (a.level == 1 && a.base_log == 23) launch_block_t<1, 23>(st, a, tb);  // PARAM_MESSAGE_2_CARRY_2
-  else launch_block_t<0, 0>(st, a, tb);
+template <int L, int B>
+static void launch_block2_t(hipStream_t st, const PbsArgs &a, const FftTables &tb) {
+  using namespace blockk;
+  HX_CHECK(hipFuncSetAttribute((const void *)pbs_fft_block2_kernel<L, B>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)SMEM2_BYTES));
+  HX_LAUNCH((pbs_fft_block2_kernel<L, B>), dim3(a.num_samples), dim3(TPB2), SMEM2_BYTES, st, a, tb);
+}
+
+// variant 0: dual-stream (256 threads), 1: one polynomial per half workgroup (512 threads)
+void launch_pbs_fft_block(hipStream_t st, const PbsArgs &a, const FftTables &tb, int variant) {
+  if (variant == 0) {
+    if (a.level == 1 && a.base_log == 23) launch_block2_t<1, 23>(st, a, tb);  // PARAM_MESSAGE_2_CARRY_2
+    else launch_block2_t<0, 0>(st, a, tb);
+  } else {
+    if (a.level == 1 && a.base_log == 23) launch_block_t<1, 23>(st, a, tb);
+    else launch_block_t<0, 0>(st, a, tb);
+  }
 }
 
 }  // namespace tfhe_hip

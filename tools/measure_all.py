@@ -131,8 +131,8 @@ if __name__ == "__main__":
     if "n1024" in which:
         pbs_case(C1P, 4096, steps=3)
     if "latency" in which:
-        for kern in (3, 2):
-            for B in (1, 16, 128, 256, 512, 1024):
+        for kern in (3, 4, 2):
+            for B in (1, 128, 256, 512):
                 pbs_case(C1, B, kernel=kern, steps=5)
     if "sweep" in which:
         for B in (1, 4, 64, 256, 1024, 2048, 8192):
