@@ -138,6 +138,27 @@ def main():
         elapsed = float(t.item())
     kernel_id = lib.hip_backend_last_pbs_kernel()
 
+    # ---- single-PBS latency (outside the timed region; the reference publishes this figure)
+    latency_ms = None
+    if rank == 0 and args.kernel == 0:
+        d_o1 = gpu.CudaLweCiphertextList.new(p.k * p.N, 1, streams)
+
+        def one():
+            lib.cuda_programmable_bootstrap_64_async(s, g, d_o1.d_vec.ptr, idx.ptr, d_lut.d_vec.ptr, lidx.ptr,
+                                                     d_in.d_vec.ptr, idx.ptr, bsk.d_vec.ptr, buf, p.n, p.k, p.N,
+                                                     p.pbs_base_log, p.pbs_level, 1, 1, 0)
+        one()
+        lib.cuda_synchronize_device(g)
+        e0, e1 = lib.hip_event_create(), lib.hip_event_create()
+        lib.hip_event_record(e0, s)
+        for _ in range(5):
+            one()
+        lib.hip_event_record(e1, s)
+        lib.cuda_synchronize_device(g)
+        latency_ms = lib.hip_event_elapsed_ms(e0, e1) / 5
+        latency_kernel = lib.hip_backend_last_pbs_kernel()
+        assert decrypt_big(p, keys, d_o1.to_lwe_ciphertext_list(streams)[0]) == f(msgs[0])
+
     # ---- validity (outside the timed region): every output of this rank decrypts to f(m)
     out = d_out.to_lwe_ciphertext_list(streams)
     check = rng.choice(B, size=min(B, 256), replace=False)
@@ -173,6 +194,12 @@ def main():
                              "2 x FETCH_SIZE + WRITE_SIZE, tools/pmc.sh), not re-measured in this run; "
                              "fp64 ceiling see DESIGN.md"},
     }
+    if latency_ms is not None:
+        result["extra"] = {"single_pbs_latency_ms": latency_ms,
+                           "single_pbs_kernel": {7: "block_latency", 2: "wave_throughput"}.get(latency_kernel,
+                                                                                              str(latency_kernel)),
+                           "note": "one PBS, batch 1, same key; not part of `value` (the reference publishes "
+                                   "4.21 ms on an H100, BASELINE.md)"}
     if world == 1 and not args.no_cpu_baseline:
         # CPU leg: the oracle's f64 path on the host cores actually available to this process
         # (affinity mask and cgroup quota, not the machine's nominal thread count), on a sample

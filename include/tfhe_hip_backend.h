@@ -298,6 +298,10 @@ uint64_t hip_integer_mult_pbs_count(int8_t *mem_ptr);
  * variant; 2..4 abort on unsupported parameter sets.  For the multi-bit entry point 2 selects the
  * multi-bit mode of the throughput kernel, 1 the generic multi-bit kernel. */
 void hip_backend_set_fft_kernel(uint32_t which);
+/* keyswitch kernel: 0 = automatic (int8 matrix-core GEMM for >= 64 LWEs when level is a power of two <= 16,
+ * base_log <= 6 and n_in*level is a multiple of 32; scalar kernels otherwise), 1 = scalar kernels only.
+ * Identical bits either way. */
+void hip_backend_set_keyswitch_kernel(uint32_t which);
 /* last launched PBS kernel, for tests: 1 generic f64, 2 wave f64, 3 generic ntt, 4 generic multi-bit,
  * 5 exact, 6 wave multi-bit, 7 block (latency), 8 block dual-stream */
 uint32_t hip_backend_last_pbs_kernel(void);

@@ -8,7 +8,7 @@ thread_local dim3 g_threadIdx, g_blockIdx, g_blockDim, g_gridDim;
 thread_local ThreadCtx *g_cur = nullptr;
 thread_local ucontext_t g_sched;
 thread_local char *g_dyn_smem = nullptr;
-thread_local uint64_t g_wave_xchg[64 * 4];
+thread_local uint64_t g_wave_xchg[32][64 * 4];
 static thread_local const std::function<void()> *g_body = nullptr;
 
 static constexpr size_t kStack = 256 * 1024;

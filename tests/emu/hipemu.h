@@ -43,7 +43,7 @@ extern thread_local dim3 g_threadIdx, g_blockIdx, g_blockDim, g_gridDim;
 extern thread_local ThreadCtx *g_cur;
 extern thread_local ucontext_t g_sched;
 extern thread_local char *g_dyn_smem;
-extern thread_local uint64_t g_wave_xchg[64 * 4];  // per-wave exchange for shuffles (one wave runs a shuffle at a time)
+extern thread_local uint64_t g_wave_xchg[32][64 * 4];  // per-wave exchange area for cross-lane collectives
 void yield_barrier(int kind);
 void run_grid(dim3 grid, dim3 block, size_t smem, const std::function<void()> &body);
 }  // namespace hipemu
@@ -55,6 +55,10 @@ void run_grid(dim3 grid, dim3 block, size_t smem, const std::function<void()> &b
 
 static inline void __syncthreads() { hipemu::yield_barrier(1); }
 static inline void hx_wave_sync_emu() { hipemu::yield_barrier(2); }
+// blocks of a grid run on different host threads: a real atomic
+static inline unsigned long long atomicAdd(unsigned long long *p, unsigned long long v) {
+  return __atomic_fetch_add(p, v, __ATOMIC_RELAXED);
+}
 static inline void __threadfence_block() {}
 static inline void __threadfence() {}
 

@@ -218,6 +218,28 @@ def test_keyswitch_bit_exact(kind, p, gemm):
 
 
 @pytest.mark.parametrize("kind", BACKENDS)
+def test_keyswitch_matrix_core_path_equals_scalar_kernels_and_oracle(kind):
+    """>= 64 LWEs, 4 levels of base 2^4 on N = 2048: the int8-MFMA GEMM path (byte planes of the key, shifted
+    digits) against the scalar kernels and the oracle, bit for bit; ragged batch (70 = 2 tiles + 6 rows)."""
+    p = TOY_2048
+    c = ctx(kind, p, "fft64", with_ksk=True)
+    msgs = [m % p.plaintext_modulus for m in range(70)]
+    cts = encrypt_big(p, c.keys, msgs, seed=8)
+    lib = use_backend(kind)
+    try:
+        lib.hip_backend_set_keyswitch_kernel(0)
+        out = c.keyswitch(cts)
+        lib.hip_backend_set_keyswitch_kernel(1)
+        scalar = c.keyswitch(cts)
+    finally:
+        lib.hip_backend_set_keyswitch_kernel(0)
+    ref = orc.keyswitch_batch(cts, c.keys.ksk, p.k * p.N, p.n, p.ks_base_log, p.ks_level)
+    assert np.array_equal(scalar, ref)
+    assert np.array_equal(out, ref)
+    assert [decrypt_small(p, c.keys, o) for o in out] == msgs
+
+
+@pytest.mark.parametrize("kind", BACKENDS)
 def test_ks_then_pbs_pipeline(kind):
     # the shortint atomic pattern: keyswitch -> PBS (shortint/atomic_pattern/standard.rs:162-199)
     p = TOY_K1

@@ -47,6 +47,51 @@
 
 #define HX_DEV __device__ __forceinline__
 
+// ---- int8 matrix core: D(32x32, i32) = A(32x32, i8) * B(32x32, i8) + C, one instruction per wave.
+// Lane l supplies 16 bytes of row (l & 31) of A and of column (l & 31) of B, both for the same 16 values of
+// k (the half selected by l >> 5); it receives D[row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)][col = l & 31]
+// in v[r], r = 0..15 (cdna_hip_programming.md, "Fragment layout").
+struct hx_i8x16 {
+  int32_t w[4];
+};
+struct hx_i32x16 {
+  int32_t v[16];
+};
+#if defined(TFHE_HIPEMU)
+static inline hx_i32x16 hx_mfma_i32_32x32x32_i8(const hx_i8x16 a, const hx_i8x16 b, hx_i32x16 c) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint64_t *x = hipemu::g_wave_xchg[wave];
+  memcpy(&x[lane * 4], &a, 16);
+  memcpy(&x[lane * 4 + 2], &b, 16);
+  hipemu::yield_barrier(2);
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), col = lane & 31;
+    int32_t acc = c.v[r];
+    for (int h = 0; h < 2; ++h) {
+      const int8_t *pa = (const int8_t *)&x[(h * 32 + row) * 4];
+      const int8_t *pb = (const int8_t *)&x[(h * 32 + col) * 4 + 2];
+      for (int j = 0; j < 16; ++j) acc += (int32_t)pa[j] * (int32_t)pb[j];
+    }
+    c.v[r] = acc;
+  }
+  hipemu::yield_barrier(2);
+  return c;
+}
+#else
+__device__ __forceinline__ hx_i32x16 hx_mfma_i32_32x32x32_i8(const hx_i8x16 a, const hx_i8x16 b, hx_i32x16 c) {
+  typedef int v4i __attribute__((ext_vector_type(4)));
+  typedef int v16i __attribute__((ext_vector_type(16)));
+  v4i va = {a.w[0], a.w[1], a.w[2], a.w[3]}, vb = {b.w[0], b.w[1], b.w[2], b.w[3]};
+  v16i vc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) vc[i] = c.v[i];
+  vc = __builtin_amdgcn_mfma_i32_32x32x32_i8(va, vb, vc, 0, 0, 0);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) c.v[i] = vc[i];
+  return c;
+}
+#endif
+
 #include <cstdio>
 #include <cstdlib>
 

@@ -27,6 +27,8 @@ void launch_keyswitch(hipStream_t st, uint64_t *lwe_out, const uint64_t *out_idx
                       const uint64_t *in_idx, const uint64_t *ksk, uint32_t n_in, uint32_t n_out,
                       uint32_t base_log, uint32_t level, uint32_t num_samples);
 
+extern bool g_keyswitch_use_mfma;
+
 // small helpers — ciphertext.hip
 void launch_modulus_switch(hipStream_t st, uint64_t *out, const uint64_t *in, uint32_t size, uint32_t log_modulus);
 void launch_centered_modulus_switch(hipStream_t st, uint64_t *out, const uint64_t *in, uint32_t lwe_dim, uint32_t log_modulus);

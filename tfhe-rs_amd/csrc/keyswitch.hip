@@ -18,6 +18,7 @@ constexpr int KS_TPB = 256;  // output columns per workgroup
 constexpr int KS_TB = 16;    // samples per workgroup
 constexpr int KS_IC = 32;    // mask elements decomposed per LDS stage
 constexpr int KS_MAXL = 8;   // max levels staged (level_count <= 8 for every shortint set)
+bool g_keyswitch_use_mfma = true;  // hip_backend_set_keyswitch_kernel: matrix-core path when its conditions hold
 
 // DigitT: int32_t when base_log <= 31 (every shortint set), int64_t for wider bases
 template <typename DigitT>
@@ -144,12 +145,173 @@ __global__ void __launch_bounds__(KS_TPB) keyswitch_small_base_kernel(uint64_t *
   }
 }
 
+// ------------------------------------------------------------------ keyswitch on the int8 matrix cores
+// The keyswitch is a GEMM: out[s][col] = -sum_k digit[s][k] * KSK[k][col], k = (mask element, level).  With
+// shifted digits d' = d + B/2 in [0, B] (an i8) and the key split in its 8 byte planes, re-centred to
+// b' = byte - 128 (an i8),
+//   sum_k d'*w = sum_p 2^(8p) * ( sum_k d'*b'_p  +  128 * sum_k d' ),      sum_k d*w = sum_k d'*w - (B/2) * sum_k w
+// and sum_k d'*b'_p is exactly what v_mfma_i32_32x32x32_i8 computes (|.| <= B * 128 * K < 2^31).  All integer,
+// so the result equals the scalar kernels' bit for bit.
+//   * ksk_planes_kernel: key -> [k block of 16][column tile][plane][column][16 bytes]  (+ column sums), so that a
+//     lane's B operand is one 16-byte load and a wave's loads are contiguous; redone at every call (60 MB in,
+//     60 MB out, ~40 us) because the C ABI hands the key over as a plain device array.
+//   * ks_mfma_kernel: a wave owns 32 samples x 32 columns x 8 planes (8 accumulators of 16 VGPRs); per step of
+//     32 k it decomposes 16/level mask words of its row into the A operand (no LDS: a lane's 16 consecutive k
+//     ARE the digits of consecutive mask words) and issues 8 MFMAs.
+constexpr int KSM_CT = 32;  // columns per tile
+
+__global__ void __launch_bounds__(256) ksk_planes_kernel(int8_t *planes, uint64_t *colsum, const uint64_t *ksk,
+                                                         uint32_t K, uint32_t ncols, uint32_t col_tiles) {
+  // one thread per (k block, column): 16 key words down the column
+  const uint32_t col = blockIdx.x * 256 + threadIdx.x, kb = blockIdx.y;
+  if (col >= col_tiles * KSM_CT) return;
+  uint64_t wv[16], sum = 0;
+  for (int j = 0; j < 16; ++j) {
+    wv[j] = col < ncols ? ksk[((size_t)kb * 16 + j) * ncols + col] : 0;
+    sum += wv[j];
+  }
+  if (col < ncols && sum) atomicAdd((unsigned long long *)&colsum[col], (unsigned long long)sum);
+  const uint32_t ct = col / KSM_CT, cl = col % KSM_CT;
+  for (int p = 0; p < 8; ++p) {
+    uint32_t pk[4];
+    for (int q = 0; q < 4; ++q) {
+      uint32_t v = 0;
+      for (int j = 0; j < 4; ++j) v |= (uint32_t)(uint8_t)((int)((wv[q * 4 + j] >> (8 * p)) & 0xFF) - 128) << (8 * j);
+      pk[q] = v;
+    }
+    uint32_t *dst = (uint32_t *)(planes + ((((size_t)kb * col_tiles + ct) * 8 + p) * KSM_CT + cl) * 16);
+    dst[0] = pk[0];
+    dst[1] = pk[1];
+    dst[2] = pk[2];
+    dst[3] = pk[3];
+  }
+}
+
+template <int LEVEL>
+__global__ void __launch_bounds__(256) ks_mfma_kernel(uint64_t *lwe_out, const uint64_t *out_idx, const uint64_t *lwe_in,
+                                                      const uint64_t *in_idx, const int8_t *planes,
+                                                      const uint64_t *colsum, uint32_t n_in, uint32_t n_out,
+                                                      uint32_t base_log, uint32_t num_samples, uint32_t col_tiles) {
+  __shared__ int32_t sa[4][2][32];  // per wave: sum of the shifted digits of every row, per k half
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row = lane & 31, h = lane >> 5;
+  const uint32_t ct = blockIdx.x;
+  const uint32_t stile = blockIdx.y * 4 + wave;
+  const uint32_t s = stile * 32 + row;
+  const bool live = stile * 32 < num_samples;       // whole wave
+  const uint32_t s_ld = s < num_samples ? s : 0;    // rows past the batch compute on sample 0 and store nothing
+  const uint64_t *x = lwe_in + (size_t)in_idx[s_ld] * (n_in + 1);
+  const uint32_t half_b = 1u << (base_log - 1);
+  constexpr int WORDS = 16 / LEVEL;                 // mask words per lane per step
+  hx_i32x16 acc[8];
+  for (int p = 0; p < 8; ++p)
+    for (int r = 0; r < 16; ++r) acc[p].v[r] = 0;
+  int32_t my_sa = 0;
+  const uint32_t steps = n_in * LEVEL / 32;
+  if (live) {
+    for (uint32_t st = 0; st < steps; ++st) {
+      // A operand: k = st*32 + h*16 + j  <->  mask word (k / LEVEL), level index (k % LEVEL), level l first
+      hx_i8x16 av;
+      uint32_t bytes[16];
+      const uint32_t w0 = (st * 32 + h * 16) / LEVEL;
+      HX_UNROLL
+      for (int q = 0; q < WORDS; ++q) {
+        uint64_t state = decomp_init_state(x[w0 + q], base_log, LEVEL);
+        HX_UNROLL
+        for (int lv = 0; lv < LEVEL; ++lv) {
+          const int32_t d = (int32_t)decompose_one_level(base_log, state) + (int32_t)half_b;
+          bytes[q * LEVEL + lv] = (uint32_t)d;
+          my_sa += d;
+        }
+      }
+      HX_UNROLL
+      for (int q = 0; q < 4; ++q)
+        av.w[q] = (int32_t)(bytes[4 * q] | (bytes[4 * q + 1] << 8) | (bytes[4 * q + 2] << 16) | (bytes[4 * q + 3] << 24));
+      const int8_t *bp = planes + ((((size_t)(st * 2 + h) * col_tiles + ct) * 8) * KSM_CT + row) * 16;
+      HX_UNROLL
+      for (int p = 0; p < 8; ++p) {
+        hx_i8x16 bv;
+        const int32_t *src = (const int32_t *)(bp + (size_t)p * KSM_CT * 16);
+        bv.w[0] = src[0];
+        bv.w[1] = src[1];
+        bv.w[2] = src[2];
+        bv.w[3] = src[3];
+        acc[p] = hx_mfma_i32_32x32x32_i8(av, bv, acc[p]);
+      }
+    }
+  }
+  sa[wave][h][row] = my_sa;
+  __syncthreads();
+  if (!live) return;
+  const uint32_t col = ct * KSM_CT + (lane & 31);
+  if (col > n_out) return;
+  const uint64_t corr = (uint64_t)half_b * colsum[col];
+  HX_UNROLL
+  for (int r = 0; r < 16; ++r) {
+    const int orow = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    const uint32_t so = stile * 32 + orow;
+    if (so >= num_samples) continue;
+    const int64_t sum_a = (int64_t)sa[wave][0][orow] + sa[wave][1][orow];
+    uint64_t v = 0;
+    HX_UNROLL
+    for (int p = 0; p < 8; ++p) v += (uint64_t)((int64_t)acc[p].v[r] + 128 * sum_a) << (8 * p);
+    uint64_t o = corr - v;
+    if (col == n_out) o += lwe_in[(size_t)in_idx[so] * (n_in + 1) + n_in];
+    lwe_out[(size_t)out_idx[so] * (n_out + 1) + col] = o;
+  }
+}
+
+// workspace of the matrix-core path (byte planes + column sums), one per device, grown on demand
+static void *g_ksm_ws[64] = {nullptr};
+static size_t g_ksm_ws_bytes[64] = {0};
+
+static bool keyswitch_mfma(hipStream_t st, uint64_t *lwe_out, const uint64_t *out_idx, const uint64_t *lwe_in,
+                           const uint64_t *in_idx, const uint64_t *ksk, uint32_t n_in, uint32_t n_out,
+                           uint32_t base_log, uint32_t level, uint32_t num_samples) {
+  const uint32_t K = n_in * level;
+  uint32_t log_k = 0;
+  while (((uint64_t)1 << log_k) < K) ++log_k;
+  const bool level_ok = level == 1 || level == 2 || level == 4 || level == 8 || level == 16;
+  if (!level_ok || K % 32 != 0 || base_log > 6 || base_log + 7 + log_k > 31 || num_samples < 64) return false;
+  int dev = 0;
+  HX_CHECK(hipGetDevice(&dev));
+  const uint32_t ncols = n_out + 1, col_tiles = (ncols + KSM_CT - 1) / KSM_CT;
+  const size_t plane_bytes = (size_t)(K / 16) * col_tiles * 8 * KSM_CT * 16;
+  const size_t need = plane_bytes + (size_t)col_tiles * KSM_CT * sizeof(uint64_t);
+  if (g_ksm_ws_bytes[dev] < need) {
+    if (g_ksm_ws[dev]) HX_CHECK(hipFree(g_ksm_ws[dev]));
+    HX_CHECK(hipMalloc(&g_ksm_ws[dev], need));
+    g_ksm_ws_bytes[dev] = need;
+  }
+  int8_t *planes = (int8_t *)g_ksm_ws[dev];
+  uint64_t *colsum = (uint64_t *)((char *)g_ksm_ws[dev] + plane_bytes);
+  HX_CHECK(hipMemsetAsync(colsum, 0, (size_t)col_tiles * KSM_CT * sizeof(uint64_t), st));
+  HX_LAUNCH(ksk_planes_kernel, dim3((col_tiles * KSM_CT + 255) / 256, K / 16), dim3(256), 0, st, planes, colsum, ksk, K,
+            ncols, col_tiles);
+  const dim3 grid(col_tiles, (num_samples + 127) / 128);
+#define KSM_LAUNCH(L)                                                                                              \
+  HX_LAUNCH((ks_mfma_kernel<L>), grid, dim3(256), 0, st, lwe_out, out_idx, lwe_in, in_idx, planes, colsum, n_in, \
+            n_out, base_log, num_samples, col_tiles)
+  switch (level) {
+    case 1: KSM_LAUNCH(1); break;
+    case 2: KSM_LAUNCH(2); break;
+    case 4: KSM_LAUNCH(4); break;
+    case 8: KSM_LAUNCH(8); break;
+    default: KSM_LAUNCH(16); break;
+  }
+#undef KSM_LAUNCH
+  return true;
+}
+
 void launch_keyswitch(hipStream_t st, uint64_t *lwe_out, const uint64_t *out_idx, const uint64_t *lwe_in,
                       const uint64_t *in_idx, const uint64_t *ksk, uint32_t n_in, uint32_t n_out,
                       uint32_t base_log, uint32_t level, uint32_t num_samples) {
   HX_PANIC_IF_FALSE(base_log >= 1 && level >= 1 && level <= KS_MAXL && base_log * level < 64,
                     "keyswitch: unsupported decomposition (base_log=%u, level=%u)", base_log, level);
   if (num_samples == 0) return;
+  if (g_keyswitch_use_mfma &&
+      keyswitch_mfma(st, lwe_out, out_idx, lwe_in, in_idx, ksk, n_in, n_out, base_log, level, num_samples))
+    return;
   const dim3 grid((n_out + 1 + KS_TPB - 1) / KS_TPB, (num_samples + KS_TB - 1) / KS_TB);
   uint32_t log_terms = 0;
   while (((uint64_t)1 << log_terms) < (uint64_t)n_in * level) ++log_terms;
