@@ -209,14 +209,37 @@ __global__ void __launch_bounds__(256) ks_mfma_kernel(uint64_t *lwe_out, const u
   int32_t my_sa = 0;
   const uint32_t steps = n_in * LEVEL / 32;
   if (live) {
+    // mask words of step st+1 are requested before step st is decomposed (n_in + 1 words per LWE: the last
+    // request of the last step reads at most the body, in range)
+    uint64_t xn[WORDS];
+    HX_UNROLL
+    for (int q = 0; q < WORDS; ++q) xn[q] = x[(h * 16) / LEVEL + q];
     for (uint32_t st = 0; st < steps; ++st) {
       // A operand: k = st*32 + h*16 + j  <->  mask word (k / LEVEL), level index (k % LEVEL), level l first
       hx_i8x16 av;
       uint32_t bytes[16];
-      const uint32_t w0 = (st * 32 + h * 16) / LEVEL;
+      uint64_t xc[WORDS];
+      HX_UNROLL
+      for (int q = 0; q < WORDS; ++q) xc[q] = xn[q];
+      if (st + 1 < steps) {
+        const uint32_t w1 = ((st + 1) * 32 + h * 16) / LEVEL;
+        HX_UNROLL
+        for (int q = 0; q < WORDS; ++q) xn[q] = x[w1 + q];
+      }
+      // B operands of this step: one 16-byte load per plane
+      const int8_t *bp = planes + ((((size_t)(st * 2 + h) * col_tiles + ct) * 8) * KSM_CT + row) * 16;
+      hx_i8x16 bv[8];
+      HX_UNROLL
+      for (int p = 0; p < 8; ++p) {
+        const int32_t *src = (const int32_t *)(bp + (size_t)p * KSM_CT * 16);
+        bv[p].w[0] = src[0];
+        bv[p].w[1] = src[1];
+        bv[p].w[2] = src[2];
+        bv[p].w[3] = src[3];
+      }
       HX_UNROLL
       for (int q = 0; q < WORDS; ++q) {
-        uint64_t state = decomp_init_state(x[w0 + q], base_log, LEVEL);
+        uint64_t state = decomp_init_state(xc[q], base_log, LEVEL);
         HX_UNROLL
         for (int lv = 0; lv < LEVEL; ++lv) {
           const int32_t d = (int32_t)decompose_one_level(base_log, state) + (int32_t)half_b;
@@ -227,17 +250,8 @@ __global__ void __launch_bounds__(256) ks_mfma_kernel(uint64_t *lwe_out, const u
       HX_UNROLL
       for (int q = 0; q < 4; ++q)
         av.w[q] = (int32_t)(bytes[4 * q] | (bytes[4 * q + 1] << 8) | (bytes[4 * q + 2] << 16) | (bytes[4 * q + 3] << 24));
-      const int8_t *bp = planes + ((((size_t)(st * 2 + h) * col_tiles + ct) * 8) * KSM_CT + row) * 16;
       HX_UNROLL
-      for (int p = 0; p < 8; ++p) {
-        hx_i8x16 bv;
-        const int32_t *src = (const int32_t *)(bp + (size_t)p * KSM_CT * 16);
-        bv.w[0] = src[0];
-        bv.w[1] = src[1];
-        bv.w[2] = src[2];
-        bv.w[3] = src[3];
-        acc[p] = hx_mfma_i32_32x32x32_i8(av, bv, acc[p]);
-      }
+      for (int p = 0; p < 8; ++p) acc[p] = hx_mfma_i32_32x32x32_i8(av, bv[p], acc[p]);
     }
   }
   sa[wave][h][row] = my_sa;
