@@ -395,10 +395,11 @@ struct MulMem {
     }
     drv.p = p;
     plan();
-    // integers per pass: keep the pool of one pass around 2 GiB and the rounds <= 2^16 blocks
+    // integers per pass: the term pool of one pass may take 12 GiB of the 288 GB (32-block integers: 37 MB
+    // each, ~340 per pass) — the later reduction rounds shrink fast, so passes should be as wide as possible
     const size_t w = p.big_n + 1;
     const size_t per_ct = (size_t)slots * w * sizeof(uint64_t);
-    sub = (uint32_t)std::max<size_t>(1, std::min<size_t>(cts, ((size_t)2 << 30) / per_ct));
+    sub = (uint32_t)std::max<size_t>(1, std::min<size_t>(cts, ((size_t)12 << 30) / per_ct));
     drv.init(st, gpu, p, 1u << 16, luts);
     HX_CHECK(hipMalloc((void **)&d_pool, (size_t)sub * per_ct));
     const size_t n_prod = prod_slot.size();
