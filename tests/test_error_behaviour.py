@@ -1,0 +1,111 @@
+"""Error behaviour of the boundary: the reference's GPU backend reports misuse with a message on stderr and
+abort() (backends/tfhe-cuda-common/cuda/include/device.h:13-41, PANIC / check_cuda_error), and its Rust
+wrappers assert on mismatched dimensions before calling in (tfhe/src/core_crypto/gpu/algorithms/
+lwe_programmable_bootstrapping.rs:29-86).  The library and the host mirror keep both behaviours.
+
+Each misuse runs in its own interpreter (an abort must not take pytest down) against the host-emulation
+build of the library — same ABI layer, no GPU needed."""
+import os
+import signal
+import subprocess
+import sys
+import textwrap
+
+import pytest
+
+from .harness import EMU_LIB, build_emu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+PRELUDE = """
+import ctypes as C, numpy as np, sys
+sys.path.insert(0, %r)
+import tfhe_rs_amd
+from tfhe_rs_amd import core_crypto_gpu as gpu, ffi
+lib = ffi.default_library()
+st = gpu.CudaStreams.new_single_gpu(0)
+S, G = st.ptr[0], 0
+""" % ROOT
+
+
+def run(snippet):
+    build_emu()
+    env = dict(os.environ, TFHE_HIP_BACKEND_LIB=EMU_LIB)
+    return subprocess.run([sys.executable, "-c", PRELUDE + textwrap.dedent(snippet)], env=env, capture_output=True,
+                          text=True, timeout=300)
+
+
+ABORTS = {
+    "polynomial size not a power of two": ("""
+        buf = C.c_void_p()
+        lib.scratch_cuda_programmable_bootstrap_64_async(S, G, C.byref(buf), 10, 1, 1000, 1, 4, True, 0)
+        """, "polynomial_size 1000 not supported"),
+    "launch does not match its scratch": ("""
+        buf = C.c_void_p()
+        lib.scratch_cuda_programmable_bootstrap_64_async(S, G, C.byref(buf), 10, 1, 256, 1, 4, True, 0)
+        v = gpu.CudaVec(4 * 600, st)
+        lib.cuda_programmable_bootstrap_64_async(S, G, v.ptr, v.ptr, v.ptr, v.ptr, v.ptr, v.ptr, v.ptr, buf,
+                                                 10, 1, 512, 4, 1, 4, 1, 0)
+        """, "PBS buffer parameters do not match"),
+    "more samples than the scratch was sized for": ("""
+        buf = C.c_void_p()
+        lib.scratch_cuda_programmable_bootstrap_64_async(S, G, C.byref(buf), 10, 1, 256, 1, 4, True, 0)
+        v = gpu.CudaVec(4 * 600, st)
+        lib.cuda_programmable_bootstrap_64_async(S, G, v.ptr, v.ptr, v.ptr, v.ptr, v.ptr, v.ptr, v.ptr, buf,
+                                                 10, 1, 256, 4, 1, 5, 1, 0)
+        """, "exceeds the scratch capacity"),
+    "decomposition wider than the torus": ("""
+        buf = C.c_void_p()
+        lib.scratch_cuda_programmable_bootstrap_64_async(S, G, C.byref(buf), 10, 1, 256, 4, 4, True, 0)
+        v = gpu.CudaVec(4 * 600, st)
+        lib.cuda_programmable_bootstrap_64_async(S, G, v.ptr, v.ptr, v.ptr, v.ptr, v.ptr, v.ptr, v.ptr, buf,
+                                                 10, 1, 256, 16, 4, 4, 1, 0)
+        """, "invalid decomposition"),
+    "keyswitch decomposition wider than the torus": ("""
+        v = gpu.CudaVec(4096, st)
+        lib.cuda_keyswitch_lwe_ciphertext_vector_64_64_async(S, G, v.ptr, v.ptr, v.ptr, v.ptr, v.ptr, 16, 4, 16, 4, 1)
+        """, "keyswitch: unsupported decomposition"),
+    "cleanup of a foreign buffer": ("""
+        junk = (C.c_uint64 * 64)()
+        p = C.c_void_p(C.addressof(junk))
+        lib.cleanup_cuda_programmable_bootstrap_64(S, G, C.byref(p))
+        """, "PBS buffer"),
+    "radix layer on a multi-bit key": ("""
+        s = ffi.CudaStreamsFFI((C.c_void_p * 1)(S), (C.c_uint32 * 1)(0), 1)
+        mem = C.c_void_p()
+        lib.scratch_cuda_propagate_single_carry_64_inplace_async(
+            s, C.byref(mem), ffi.CudaLweBootstrapKeyParamsFFI(10, 1, 256, 4, 1, 256, 0, 3),
+            ffi.CudaLweKeyswitchKeyParamsFFI(256, 10, 4, 4), 4, 4, 4, 0, True, 0)
+        """, "only the classic PBS is wired"),
+}
+
+
+@pytest.mark.parametrize("name", sorted(ABORTS))
+def test_misuse_prints_and_aborts(name):
+    snippet, needle = ABORTS[name]
+    r = run(snippet)
+    assert r.returncode == -signal.SIGABRT, (r.returncode, r.stderr[-400:])
+    assert needle in r.stderr, r.stderr[-400:]
+
+
+def test_host_mirror_asserts_like_the_rust_wrappers():
+    r = run("""
+        bsk = gpu.CudaLweBootstrapKey.from_lwe_bootstrap_key(np.zeros(10 * 4 * 256, dtype=np.uint64), 10, 1, 256, 4, 1, st)
+        d_in = gpu.CudaLweCiphertextList.new(11, 2, st)      # wrong input dimension (key expects 10)
+        d_out = gpu.CudaLweCiphertextList.new(256, 2, st)
+        d_lut = gpu.CudaGlweCiphertextList.from_glwe_ciphertext_list(np.zeros(512, dtype=np.uint64), 1, 256, st)
+        idx = gpu.CudaVec.from_cpu_async(np.arange(2, dtype=np.uint64), st)
+        try:
+            gpu.cuda_programmable_bootstrap_lwe_ciphertext(d_in, d_out, d_lut, idx, idx, idx, bsk, st)
+        except AssertionError as e:
+            print("ASSERT:", e)
+        """)
+    assert r.returncode == 0, r.stderr[-400:]
+    assert "ASSERT: Mismatched input LweDimension" in r.stdout
+
+
+def test_missing_library_fails_loudly_instead_of_falling_back():
+    env = dict(os.environ, TFHE_HIP_BACKEND_LIB="/nonexistent/libtfhe_hip_backend.so")
+    r = subprocess.run([sys.executable, "-c", PRELUDE], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0
+    assert "no CPU fallback" in r.stderr.lower() or "There is no CPU fallback" in r.stderr

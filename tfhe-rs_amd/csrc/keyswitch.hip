@@ -11,6 +11,7 @@
 // and reused across the TB samples held in registers; the signed digits of a chunk of IC mask
 // elements are staged in LDS and broadcast-read.
 #include "kernels.h"
+#include <mutex>
 
 namespace tfhe_hip {
 
@@ -275,9 +276,13 @@ __global__ void __launch_bounds__(256) ks_mfma_kernel(uint64_t *lwe_out, const u
   }
 }
 
-// workspace of the matrix-core path (byte planes + column sums), one per device, grown on demand
+// workspace of the matrix-core path (byte planes + column sums), one per device, grown on demand.  The two
+// kernels of one call use it back to back on the caller's stream; calls on different streams of one device
+// are serialised on this mutex only for the (rare) growth, so concurrent keyswitches on ONE device must use
+// one stream — the reference has the same restriction for its per-call `ks_tmp` scratch.
 static void *g_ksm_ws[64] = {nullptr};
 static size_t g_ksm_ws_bytes[64] = {0};
+static std::mutex g_ksm_mutex;
 
 static bool keyswitch_mfma(hipStream_t st, uint64_t *lwe_out, const uint64_t *out_idx, const uint64_t *lwe_in,
                            const uint64_t *in_idx, const uint64_t *ksk, uint32_t n_in, uint32_t n_out,
@@ -292,10 +297,16 @@ static bool keyswitch_mfma(hipStream_t st, uint64_t *lwe_out, const uint64_t *ou
   const uint32_t ncols = n_out + 1, col_tiles = (ncols + KSM_CT - 1) / KSM_CT;
   const size_t plane_bytes = (size_t)(K / 16) * col_tiles * 8 * KSM_CT * 16;
   const size_t need = plane_bytes + (size_t)col_tiles * KSM_CT * sizeof(uint64_t);
-  if (g_ksm_ws_bytes[dev] < need) {
-    if (g_ksm_ws[dev]) HX_CHECK(hipFree(g_ksm_ws[dev]));
-    HX_CHECK(hipMalloc(&g_ksm_ws[dev], need));
-    g_ksm_ws_bytes[dev] = need;
+  {
+    std::lock_guard<std::mutex> lock(g_ksm_mutex);
+    if (g_ksm_ws_bytes[dev] < need) {
+      if (g_ksm_ws[dev]) {
+        HX_CHECK(hipDeviceSynchronize());  // nobody may still be reading the old planes
+        HX_CHECK(hipFree(g_ksm_ws[dev]));
+      }
+      HX_CHECK(hipMalloc(&g_ksm_ws[dev], need));
+      g_ksm_ws_bytes[dev] = need;
+    }
   }
   int8_t *planes = (int8_t *)g_ksm_ws[dev];
   uint64_t *colsum = (uint64_t *)((char *)g_ksm_ws[dev] + plane_bytes);
