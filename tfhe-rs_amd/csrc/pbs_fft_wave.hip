@@ -569,19 +569,38 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
               v_im[r] = p0[1024 + r * 64];
             }
           }
-          for (uint32_t sidx = 1; sidx < per; ++sidx) {
+          // the 2*(2^g - 1) rotated half polynomials (low / high coefficients of each subset) are streamed
+          // with one half in flight while the previous one is accumulated
+          const uint32_t halves = 2 * (per - 1);
+          auto half_request = [&](uint64_t (&x)[16], uint32_t hh) {
+            const uint32_t sidx = 1 + (hh >> 1);
             const uint64_t *ps = gk + (size_t)sidx * ggsw_sz + poly * N;
+            const uint32_t t0 = (uint32_t)ln - (deg[sidx] & (N - 1)) + ((hh & 1) ? 1024u : 0u);
+            HX_UNROLL
+            for (int r = 0; r < 16; ++r) x[r] = ps[(t0 + r * 64) & (N - 1)];
+          };
+          uint64_t cur[16], nxt[16];  // (two halves ahead measured slower: register pressure)
+          half_request(cur, 0);
+          for (uint32_t hh = 0; hh < halves; ++hh) {
+            if (hh + 1 < halves) half_request(nxt, hh + 1);
+            const uint32_t sidx = 1 + (hh >> 1);
             const uint32_t rr = deg[sidx] & (N - 1);
             const bool odd = (deg[sidx] & N) != 0;
-            const uint32_t t0 = (uint32_t)ln - rr;
-            HX_UNROLL
-            for (int r = 0; r < 16; ++r) {
-              const uint32_t c0 = r * 64 + ln, c1 = 1024 + r * 64 + ln;
-              const uint64_t x0 = ps[(t0 + r * 64) & (N - 1)];
-              const uint64_t x1 = ps[(t0 + 1024 + r * 64) & (N - 1)];
-              v_re[r] += ((c0 < rr) != odd) ? (uint64_t)0 - x0 : x0;
-              v_im[r] += ((c1 < rr) != odd) ? (uint64_t)0 - x1 : x1;
+            if (hh & 1) {
+              HX_UNROLL
+              for (int r = 0; r < 16; ++r) {
+                const uint32_t c1 = 1024 + r * 64 + ln;
+                v_im[r] += ((c1 < rr) != odd) ? (uint64_t)0 - cur[r] : cur[r];
+              }
+            } else {
+              HX_UNROLL
+              for (int r = 0; r < 16; ++r) {
+                const uint32_t c0 = r * 64 + ln;
+                v_re[r] += ((c0 < rr) != odd) ? (uint64_t)0 - cur[r] : cur[r];
+              }
             }
+            HX_UNROLL
+            for (int r = 0; r < 16; ++r) cur[r] = nxt[r];
             HX_SCHED_FENCE();
           }
           cplx d[16];
