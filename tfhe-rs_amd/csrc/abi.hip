@@ -504,6 +504,7 @@ void cuda_centered_modulus_switch_64_async(void *stream, uint32_t gpu_index, voi
 // =========================================================================== extensions
 void hip_backend_set_fft_kernel(uint32_t which) { g_fft_kernel_choice.store(which); }
 void hip_backend_set_keyswitch_kernel(uint32_t which) { g_keyswitch_use_mfma = (which != 1); }
+void hip_backend_set_ntt_kernel(uint32_t which) { g_ntt_kernel_serial = (which == 1); }
 uint32_t hip_backend_last_pbs_kernel(void) { return g_last_pbs_kernel.load(); }
 const char *hip_backend_version(void) {
 #if defined(TFHE_HIPEMU)

@@ -28,6 +28,7 @@ void launch_keyswitch(hipStream_t st, uint64_t *lwe_out, const uint64_t *out_idx
                       uint32_t base_log, uint32_t level, uint32_t num_samples);
 
 extern bool g_keyswitch_use_mfma;
+extern bool g_ntt_kernel_serial;
 
 // small helpers — ciphertext.hip
 void launch_modulus_switch(hipStream_t st, uint64_t *out, const uint64_t *in, uint32_t size, uint32_t log_modulus);

@@ -13,6 +13,7 @@
 #include "kernels.h"
 
 namespace tfhe_hip {
+bool g_ntt_kernel_serial = false;
 
 template <int N>
 HX_DEV uint64_t rot_sub(const uint64_t *poly, uint32_t j, uint32_t a_hat) {
@@ -208,6 +209,86 @@ __global__ void __launch_bounds__(GenericCfg<N>::TPB) pbs_ntt_generic_kernel(Pbs
   block_sample_extract<N, K1, TPB>(a, acc, sample, b_hat, true, tid);
 }
 
+// Same engine, one thread group per GLWE polynomial: the k+1 forward transforms of a level (one per row) and
+// the k+1 inverse transforms (one per column) run side by side, which halves (k = 1) the number of
+// barrier-separated stages per CMUX.  Exact arithmetic mod p: identical bits to the kernel above.
+template <int N, int K1>
+__global__ void __launch_bounds__(K1 *GenericCfg<N>::TPB) pbs_ntt_par_kernel(PbsArgs a, NttTables tb) {
+  constexpr int TPB = GenericCfg<N>::TPB, TPBT = K1 * TPB, PER = N / TPB, LOG2N2 = ilog2_c(2 * N);
+  HX_DYN_SMEM(smem);
+  uint64_t *acc = (uint64_t *)smem;          // K1*N torus words
+  uint64_t *nbuf = acc + (size_t)K1 * N;     // K1*N field elements (one transform buffer per group)
+  const int tid = threadIdx.x;
+  const int grp = tid / TPB, lt = tid - grp * TPB;  // my row (forward) / column (inverse), thread inside it
+  const uint32_t sample = blockIdx.x;
+  const uint64_t *lwe = a.lwe_in + (size_t)a.in_idx[sample] * (a.n + 1);
+  const uint64_t *lut = a.lut + (size_t)a.lut_idx[sample] * K1 * N;
+  const uint64_t *bsk = (const uint64_t *)a.bsk;
+  uint64_t *mybuf = nbuf + (size_t)grp * N;
+
+  // body modulus switch; TPBT need not be a power of two (k = 2), so the reduction is a plain sum
+  uint64_t corr = 0;
+  if (a.ms_type == 1) {
+    uint64_t sh = 0;
+    int64_t sd = 0;
+    for (uint32_t i = tid; i < a.n; i += TPBT) {
+      uint64_t h;
+      int64_t d;
+      centered_ms_terms(lwe[i], LOG2N2, h, d);
+      sh += h;
+      sd += d;
+    }
+    nbuf[tid] = sh;
+    nbuf[TPBT + tid] = (uint64_t)sd;
+    __syncthreads();
+    uint64_t th = 0, td = 0;
+    for (int l = 0; l < TPBT; ++l) {
+      th += nbuf[l];
+      td += nbuf[TPBT + l];
+    }
+    __syncthreads();
+    corr = centered_ms_finish(th, (int64_t)td, LOG2N2);
+  }
+  const uint32_t b_hat = (uint32_t)modulus_switch(lwe[a.n] + corr, LOG2N2);
+  for (uint32_t j = lt; j < (uint32_t)N; j += TPB) acc[grp * N + j] = lut[grp * N + j];
+  __syncthreads();
+
+  for (uint32_t i = 0; i < a.n; ++i) {
+    const uint32_t a_hat = (uint32_t)modulus_switch(lwe[i], LOG2N2);
+    if (a_hat == 0) continue;
+    uint64_t nacc[PER];
+    for (int q = 0; q < PER; ++q) nacc[q] = 0;
+    for (uint32_t idx = 0; idx < a.level; ++idx) {
+      for (int q = 0; q < PER; ++q) {
+        const uint32_t j = lt + q * TPB;
+        const int64_t d = decomp_digit(rot_sub<N>(acc + grp * N, j, a_hat), a.base_log, a.level, idx);
+        mybuf[j] = d < 0 ? (uint64_t)d + GL_P : (uint64_t)d;  // ntt64.rs:199-220
+      }
+      __syncthreads();
+      lds_ntt_forward<N, TPB>(mybuf, tb.tw, lt);
+      for (int row = 0; row < K1; ++row) {  // column `grp` of the external product
+        const uint64_t *brow = bsk + ((((size_t)i * a.level + idx) * K1 + row) * K1 + grp) * N;
+        const uint64_t *f = nbuf + (size_t)row * N;
+        for (int q = 0; q < PER; ++q) {
+          const int pos = lt + q * TPB;
+          nacc[q] = gl_add(nacc[q], gl_mul(brow[pos], f[pos]));
+        }
+      }
+      __syncthreads();
+    }
+    for (int q = 0; q < PER; ++q) mybuf[lt + q * TPB] = gl_mul(nacc[q], tb.n_inv);  // normalize
+    __syncthreads();
+    lds_ntt_inverse<N, TPB>(mybuf, tb.itw, lt);
+    for (int q = 0; q < PER; ++q) {
+      const int j = lt + q * TPB;
+      acc[grp * N + j] += gl_modswitch_to_pow2(mybuf[j]);
+    }
+    __syncthreads();
+  }
+  // rotation by -b_hat is applied last on this path (ntt64_bnf_pbs.rs:262-271)
+  block_sample_extract<N, K1, TPBT>(a, acc, sample, b_hat, true, tid);
+}
+
 // ------------------------------------------------------------------------- BSK conversion
 // one workgroup per polynomial: torus -> f64 tree order / Goldilocks NTT domain
 // (cc/algorithms/lwe_bootstrap_key_conversion.rs:20-150, 367-434)
@@ -251,10 +332,17 @@ static void launch_fft(hipStream_t st, const PbsArgs &a, const FftTables &tb) {
 }
 template <int N, int K1>
 static void launch_ntt(hipStream_t st, const PbsArgs &a, const NttTables &tb) {
-  const size_t smem = (size_t)(K1 + 1) * N * 8;
-  HX_CHECK(hipFuncSetAttribute((const void *)pbs_ntt_generic_kernel<N, K1>,
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-  HX_LAUNCH((pbs_ntt_generic_kernel<N, K1>), dim3(a.num_samples), dim3(GenericCfg<N>::TPB), smem, st, a, tb);
+  if (g_ntt_kernel_serial) {  // the one-group kernel, kept for comparison (hip_backend_set_ntt_kernel(1))
+    const size_t smem = (size_t)(K1 + 1) * N * 8;
+    HX_CHECK(hipFuncSetAttribute((const void *)pbs_ntt_generic_kernel<N, K1>,
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    HX_LAUNCH((pbs_ntt_generic_kernel<N, K1>), dim3(a.num_samples), dim3(GenericCfg<N>::TPB), smem, st, a, tb);
+    return;
+  }
+  const size_t smem = (size_t)2 * K1 * N * 8;
+  HX_CHECK(hipFuncSetAttribute((const void *)pbs_ntt_par_kernel<N, K1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)smem));
+  HX_LAUNCH((pbs_ntt_par_kernel<N, K1>), dim3(a.num_samples), dim3(K1 * GenericCfg<N>::TPB), smem, st, a, tb);
 }
 
 #define HX_DISPATCH_NK(FN, ...)                                                              \

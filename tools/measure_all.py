@@ -123,7 +123,7 @@ if __name__ == "__main__":
     if "generic" in which:
         pbs_case(C1, 4096, kernel=1)
     if "ntt" in which:
-        pbs_case(C1, 1024, engine="ntt64", steps=2)
+        pbs_case(C1, 4096, engine="ntt64", steps=2)
     if "mb" in which:
         pbs_case(C4, 4096, steps=2)
     if "lat1" in which:  # one launch of the latency kernel, no warm-up (PMC passes)
