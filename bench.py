@@ -220,7 +220,7 @@ def main():
         orc.pbs_batch(orc.ENGINE_FFT, cts[:cores], lut, bsk_f, p.n, p.k, p.N, p.pbs_base_log, p.pbs_level, 1,
                       threads=cores)
         calib = time.perf_counter() - t0
-        count = args.cpu_sample or int(max(cores, min(B, cores * max(1, round(15.0 / max(calib, 1e-3))))))
+        count = args.cpu_sample or int(max(cores, min(B, cores * max(1, round(25.0 / max(calib, 1e-3))))))
         t0 = time.perf_counter()
         ref = orc.pbs_batch(orc.ENGINE_FFT, cts[:count], lut, bsk_f, p.n, p.k, p.N, p.pbs_base_log, p.pbs_level, 1,
                             threads=cores)
