@@ -291,6 +291,7 @@ void cleanup_cuda_integer_mult_inplace_64(CudaStreamsFFI streams, int8_t **mem_p
  * of PBS one multiplication issues per integer (for throughput accounting) */
 void hip_integer_scratch_batch(uint32_t num_integers);
 uint64_t hip_integer_mult_pbs_count(int8_t *mem_ptr);
+uint64_t hip_integer_propagate_pbs_count(uint32_t num_blocks);
 
 /* Select which f64 kernel serves cuda_programmable_bootstrap_64_async (all give identical bits):
  * 0 = automatic (N=2048,k=1: latency kernel up to 256 LWEs, throughput kernel beyond; generic otherwise),

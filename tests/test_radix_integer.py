@@ -59,11 +59,13 @@ def test_apply_lookup_table_on_every_block(kind):
 @pytest.mark.parametrize("kind", BACKENDS)
 def test_add_and_carry_propagation(kind):
     p, keys, st, sks, igpu = setup(kind)
-    L = 4 if kind == "emu" else 32
+    L = 10 if kind == "emu" else 32   # 10 blocks: two full groups of the carry look-ahead and a partial one
     bits = 2 * L
     rng = np.random.default_rng(5)
-    a = [int(x) for x in rng.integers(0, 1 << 62, size=3)] + [(1 << bits) - 1, 0x5555555555555555]
-    b = [int(x) for x in rng.integers(0, 1 << 62, size=3)] + [1, 0xAAAAAAAAAAAAAAAB]
+    a = [int(x) for x in rng.integers(0, 1 << 62, size=3)] + [(1 << bits) - 1, 0x5555555555555555, 0x3333333333333333,
+                                                              0x0FFF0FFF0FFF0FFF, 0]
+    b = [int(x) for x in rng.integers(0, 1 << 62, size=3)] + [1, 0xAAAAAAAAAAAAAAAB, 0xCCCCCCCCCCCCCCCD,
+                                                              0x0001000100010001, 0]
     a = [x & ((1 << bits) - 1) for x in a]
     b = [x & ((1 << bits) - 1) for x in b]
     ca = igpu.CudaUnsignedRadixCiphertext.from_blocks(encrypt_radix(p, keys, a, L, 21), st)

@@ -175,128 +175,252 @@ struct ApplyLutMem {
 };
 
 // ------------------------------------------------------------------ carry propagation
-// States as in radix_parallel/add.rs (OutputCarry): 0 none, 1 generated, 2 propagated.
-enum : uint64_t { LUT_STATE_FIRST = 0, LUT_STATE = 1, LUT_MSG = 2, LUT_SCAN = 3, LUT_FINAL = 4, LUT_CARRY = 5 };
+// In place on blocks whose value is <= 2*msg - 2 (the sum of two clean blocks): at most one carry leaves a
+// block.  Scan states use the encoding of radix_parallel/add.rs (OutputCarry): 0 none, 1 generated, 2 propagated.
+//
+// Grouped carry look-ahead (groups of G = 4 blocks; needs msg*carry >= 16), the same family as the reference's
+// advanced_add_assign_with_carry_at_least_4_bits (add.rs:828-1044).  Inside a group the carries are resolved
+// by an ordinary binary addition of the block states, which is LINEAR in the ciphertexts:
+//   w_q = (generate ? 2 : propagate ? 1 : 0) << q          for q = 0..G-2                 (one PBS per block)
+//   S_q = carry_into_group + w_0 + ... + w_(q-1)             LWE additions, no PBS
+//   carry into block q = bit q of S_q                        (one PBS per block, q >= 1)
+// because a propagating block (bit q set) forwards an incoming carry to bit q+1, a generating block has bit
+// q+1 set whatever arrives, and an absorbing block stops it.  The carry into a GROUP comes from a Hillis-Steele
+// scan over the group states; a group's state is read off U = w_0 + .. + w_(G-2) (bit G-1 of U and of U+1:
+// does a carry leave the first G-1 blocks without / with an incoming one) combined with its last block.
+// PBS for 32 blocks: 32 states + 7 + 7 group states + 14 scan + 7 carry bits + 24 inner carries + 32 results
+// = 123 in 9 rounds (a per-block Hillis-Steele scan takes 224).
+enum : uint64_t {
+  LUT_W = 0,           // + q (q = 0..2): state << q
+  LUT_W_FIRST = 3,     // block 0 of an integer: a propagate there can receive nothing
+  LUT_STATE_LAST = 4,  // last block of a group: plain state, scan encoding
+  LUT_GROUP = 5,       // U -> state of the first G-1 blocks, scan encoding
+  LUT_COMBINE = 6,     // prev * msg + cur -> cur == propagated ? prev : cur
+  LUT_IS_GEN = 7,      // state -> state == generated
+  LUT_BIT = 8,         // + q (q = 1..3): S -> bit q of S
+  LUT_MSG = 12,        // x -> x % msg
+  LUT_PROP_COUNT = 13
+};
 
 struct PropagateMem {
   static constexpr uint32_t kMagic = 0x50524F50;  // "PROP"
+  static constexpr uint32_t G = 4;
   uint32_t magic = kMagic;
   LutDriver drv;
-  uint32_t blocks = 0;      // blocks per integer
-  uint32_t max_cts = 0;     // integers the scratch was sized for
-  // scratch ciphertexts: X = [states | messages] (2T), P = packed inputs (T)
-  uint64_t *d_x = nullptr, *d_p = nullptr;
-  // cached index arrays for a batch size
+  uint32_t blocks = 0;   // blocks per integer
+  uint32_t max_cts = 0;  // integers the scratch was sized for
+  // scratch ciphertexts: pool = [W: T shifted states | C: cts*NG carries into the groups], S: T partial sums /
+  // inner carries, U and GS: cts*NG, P: packed bivariate inputs
+  uint64_t *d_pool = nullptr, *d_s = nullptr, *d_u = nullptr, *d_gs = nullptr, *d_p = nullptr;
   uint32_t cached_cts = 0;
   std::vector<uint64_t *> dev_arrays;
-  struct Round {
-    uint64_t *a_idx, *b_idx, *o_idx, *lut_idx;
-    uint32_t count;
+  struct Idx {
+    uint64_t *a = nullptr, *b = nullptr, *o = nullptr, *lut = nullptr;
+    uint32_t count = 0;
   };
-  uint64_t *r1_in = nullptr, *r1_lut = nullptr;
-  std::vector<Round> scan;
-  Round fin{};
-  uint64_t *first_src = nullptr, *first_dst = nullptr;
-  uint32_t first_count = 0;
+  Idx rA, csrU, rC1, rC2, rD, csrS, rE, addC, addS, rF;
+  std::vector<Idx> scan;
 
-  void build_indexes(hipStream_t st, uint32_t cts) {
-    for (auto *d : dev_arrays) HX_CHECK(hipFree(d));
-    dev_arrays.clear();
-    scan.clear();
-    const uint32_t L = blocks, T = cts * L;
+  static uint32_t ngroups(uint32_t L) { return (L + G - 1) / G; }
+  // PBS one propagation issues per integer
+  static uint64_t pbs_count(uint32_t L) {
+    const uint32_t NG = ngroups(L);
+    uint64_t n = 2 * (uint64_t)L + 3 * (uint64_t)(NG - 1);  // A, F, C1, C2, D'
+    for (uint32_t d = 1; d + 1 < NG; d <<= 1) n += NG - 1 - d;
+    for (uint32_t j = 0; j < L; ++j) n += (j % G != 0);
+    return n;
+  }
+
+  Idx make(hipStream_t st, const std::vector<uint64_t> &a, const std::vector<uint64_t> &b,
+           const std::vector<uint64_t> &o, const std::vector<uint64_t> &l) {
     auto up = [&](const std::vector<uint64_t> &h) {
       uint64_t *d = dev_upload(st, h);
       if (d) dev_arrays.push_back(d);
       return d;
     };
-    std::vector<uint64_t> in(2 * T), lut(2 * T);
-    for (uint32_t t = 0; t < T; ++t) {
-      in[t] = in[T + t] = t;
-      lut[t] = (t % L == 0) ? LUT_STATE_FIRST : LUT_STATE;
-      lut[T + t] = LUT_MSG;
-    }
-    r1_in = up(in);
-    r1_lut = up(lut);
-    for (uint32_t d = 1; d < L; d <<= 1) {  // Hillis-Steele inclusive scan of the carry states
-      std::vector<uint64_t> a, b, o, l;
-      for (uint32_t t = 0; t < T; ++t)
-        if (t % L >= d) {
-          a.push_back(t - d);
-          b.push_back(t);
-          o.push_back(t);
-          l.push_back(LUT_SCAN);
-        }
-      scan.push_back(Round{up(a), up(b), up(o), up(l), (uint32_t)a.size()});
-    }
-    std::vector<uint64_t> a, b, o, l, fs, fd;
-    for (uint32_t t = 0; t < T; ++t) {
-      if (t % L == 0) {
-        fs.push_back(T + t);  // message of block 0 is final
-        fd.push_back(t);
-      } else {
-        a.push_back(t - 1);   // state entering block t
-        b.push_back(T + t);   // its message
-        o.push_back(t);
-        l.push_back(LUT_FINAL);
+    Idx r;
+    r.a = up(a);
+    r.b = up(b);
+    r.o = up(o);
+    r.lut = up(l);
+    r.count = (uint32_t)std::max(o.size(), l.size());
+    return r;
+  }
+
+  void build_indexes(hipStream_t st, uint32_t cts) {
+    for (auto *d : dev_arrays) HX_CHECK(hipFree(d));
+    dev_arrays.clear();
+    scan.clear();
+    const uint32_t L = blocks, NG = ngroups(L), TT = cts * L;
+    auto T = [&](uint32_t c, uint32_t j) { return (uint64_t)c * L + j; };
+    auto GI = [&](uint32_t c, uint32_t g) { return (uint64_t)c * NG + g; };
+    auto glen = [&](uint32_t g) { return std::min(G, L - g * G); };
+    std::vector<uint64_t> a, b, o, l;
+    auto reset = [&]() { a.clear(), b.clear(), o.clear(), l.clear(); };
+    // A: v[t] -> W[t]
+    for (uint32_t c = 0; c < cts; ++c)
+      for (uint32_t j = 0; j < L; ++j) {
+        a.push_back(T(c, j));
+        o.push_back(T(c, j));
+        l.push_back(j == 0 ? LUT_W_FIRST : j % G == G - 1 ? LUT_STATE_LAST : LUT_W + j % G);
       }
+    rA = make(st, a, {}, o, l);
+    // U_g = w_0 + .. + w_(G-2) for the groups whose state is needed (all but the last of an integer): CSR
+    reset();
+    a.push_back(0);  // offsets
+    for (uint32_t c = 0; c < cts; ++c)
+      for (uint32_t g = 0; g + 1 < NG; ++g) {
+        for (uint32_t q = 0; q + 1 < G; ++q) b.push_back(T(c, g * G + q));  // members (pool index of W)
+        a.push_back(b.size());
+        o.push_back(GI(c, g));  // where the group's U / state lives
+      }
+    csrU = make(st, a, b, o, {});
+    csrU.count = (uint32_t)o.size();
+    // C1: U (dense, in CSR order) -> GS[g];  C2: GS*msg + W[last of the group] -> GS
+    reset();
+    for (uint32_t c = 0; c < cts; ++c)
+      for (uint32_t g = 0; g + 1 < NG; ++g) {
+        o.push_back(GI(c, g));
+        l.push_back(LUT_GROUP);
+      }
+    rC1 = make(st, {}, {}, o, l);
+    reset();
+    for (uint32_t c = 0; c < cts; ++c)
+      for (uint32_t g = 0; g + 1 < NG; ++g) {
+        a.push_back(GI(c, g));
+        b.push_back(T(c, g * G + G - 1));
+        o.push_back(GI(c, g));
+        l.push_back(LUT_COMBINE);
+      }
+    rC2 = make(st, a, b, o, l);
+    // D: inclusive scan of the states of groups 0..NG-2
+    for (uint32_t d = 1; d + 1 < NG; d <<= 1) {
+      reset();
+      for (uint32_t c = 0; c < cts; ++c)
+        for (uint32_t g = d; g + 1 < NG; ++g) {
+          a.push_back(GI(c, g - d));
+          b.push_back(GI(c, g));
+          o.push_back(GI(c, g));
+          l.push_back(LUT_COMBINE);
+        }
+      scan.push_back(make(st, a, b, o, l));
     }
-    fin = Round{up(a), up(b), up(o), up(l), (uint32_t)a.size()};
-    first_src = up(fs);
-    first_dst = up(fd);
-    first_count = (uint32_t)fs.size();
+    // D': carry bit entering group g >= 1 -> C (second part of the pool)
+    reset();
+    for (uint32_t c = 0; c < cts; ++c)
+      for (uint32_t g = 1; g < NG; ++g) {
+        a.push_back(GI(c, g - 1));
+        o.push_back((uint64_t)TT + GI(c, g));
+        l.push_back(LUT_IS_GEN);
+      }
+    rD = make(st, a, {}, o, l);
+    // E: S_t = C_g + w_0 + .. + w_(q-1) for q >= 1 (CSR over the pool), then bit q of it
+    reset();
+    a.push_back(0);
+    for (uint32_t c = 0; c < cts; ++c)
+      for (uint32_t g = 0; g < NG; ++g)
+        for (uint32_t q = 1; q < glen(g); ++q) {
+          if (g > 0) b.push_back((uint64_t)TT + GI(c, g));
+          for (uint32_t i = 0; i < q; ++i) b.push_back(T(c, g * G + i));
+          a.push_back(b.size());
+          o.push_back(T(c, g * G + q));
+          l.push_back(LUT_BIT + q);
+        }
+    csrS = make(st, a, b, o, l);
+    // F: v += carry (C_g for the first block of groups >= 1, the inner carry in S otherwise), message extraction
+    reset();
+    for (uint32_t c = 0; c < cts; ++c)
+      for (uint32_t g = 1; g < NG; ++g) {
+        a.push_back((uint64_t)TT + GI(c, g));
+        o.push_back(T(c, g * G));
+      }
+    addC = make(st, a, {}, o, {});
+    reset();
+    for (uint32_t c = 0; c < cts; ++c)
+      for (uint32_t j = 0; j < L; ++j)
+        if (j % G != 0) o.push_back(T(c, j));
+    addS = make(st, {}, {}, o, {});
+    reset();
+    for (uint32_t t = 0; t < TT; ++t) l.push_back(LUT_MSG);
+    rF = make(st, {}, {}, {}, l);
     cached_cts = cts;
   }
 
   void init(hipStream_t st, uint32_t gpu, const Params &p, uint32_t num_blocks, uint32_t cts) {
     blocks = num_blocks;
     max_cts = cts;
+    HX_PANIC_IF_FALSE(p.msg * p.carry >= 16 && p.carry >= p.msg,
+                      "carry propagation needs at least 4 bits per block (message_modulus * carry_modulus >= 16)");
     const uint64_t m = p.msg;
-    std::vector<std::function<uint64_t(uint64_t)>> fs = {
-        [m](uint64_t x) -> uint64_t { return x >= m ? 1 : 0; },                         // first block: no propagate
-        [m](uint64_t x) -> uint64_t { return x >= m ? 1 : (x == m - 1 ? 2 : 0); },      // state
-        [m](uint64_t x) -> uint64_t { return x % m; },                                  // message
-        [m](uint64_t x) -> uint64_t { return (x % m) == 2 ? (x / m) : (x % m); },       // scan: cur==prop ? prev : cur
-        [m](uint64_t x) -> uint64_t { return ((x % m) + ((x / m) == 1 ? 1 : 0)) % m; }, // message + incoming carry
-        [m](uint64_t x) -> uint64_t { return x / m; },                                  // carry of a block
+    std::vector<std::function<uint64_t(uint64_t)>> fs(LUT_PROP_COUNT, [](uint64_t) -> uint64_t { return 0; });
+    for (uint64_t q = 0; q + 1 < G; ++q)
+      fs[LUT_W + q] = [m, q](uint64_t x) -> uint64_t { return (x >= m ? 2 : (x == m - 1 ? 1 : 0)) << q; };
+    fs[LUT_W_FIRST] = [m](uint64_t x) -> uint64_t { return x >= m ? 2 : 0; };
+    fs[LUT_STATE_LAST] = [m](uint64_t x) -> uint64_t { return x >= m ? 1 : (x == m - 1 ? 2 : 0); };
+    fs[LUT_GROUP] = [](uint64_t u) -> uint64_t {
+      const uint64_t h0 = (u >> (G - 1)) & 1, h1 = ((u + 1) >> (G - 1)) & 1;
+      return h0 ? 1 : (h1 ? 2 : 0);
     };
+    fs[LUT_COMBINE] = [m](uint64_t x) -> uint64_t { return (x % m) == 2 ? (x / m) : (x % m); };
+    fs[LUT_IS_GEN] = [](uint64_t x) -> uint64_t { return x == 1 ? 1 : 0; };
+    for (uint64_t q = 1; q < G; ++q) fs[LUT_BIT + q] = [q](uint64_t x) -> uint64_t { return (x >> q) & 1; };
+    fs[LUT_MSG] = [m](uint64_t x) -> uint64_t { return x % m; };
     std::vector<std::vector<uint64_t>> luts;
     for (auto &f : fs) {
       luts.emplace_back((size_t)(p.k + 1) * p.N);
       generate_lut(p, luts.back().data(), f);
     }
-    const uint32_t T = cts * num_blocks;
-    drv.init(st, gpu, p, std::min<uint32_t>(2 * T, 1u << 16), luts);
+    const uint32_t T = cts * num_blocks, NG = ngroups(num_blocks);
+    drv.init(st, gpu, p, std::min<uint32_t>(T, 1u << 16), luts);
     const size_t w = p.big_n + 1;
-    HX_CHECK(hipMalloc((void **)&d_x, (size_t)2 * T * w * sizeof(uint64_t)));
+    HX_CHECK(hipMalloc((void **)&d_pool, ((size_t)T + (size_t)cts * NG) * w * sizeof(uint64_t)));
+    HX_CHECK(hipMalloc((void **)&d_s, (size_t)T * w * sizeof(uint64_t)));
     HX_CHECK(hipMalloc((void **)&d_p, (size_t)T * w * sizeof(uint64_t)));
+    HX_CHECK(hipMalloc((void **)&d_u, (size_t)cts * NG * w * sizeof(uint64_t)));
+    HX_CHECK(hipMalloc((void **)&d_gs, (size_t)cts * NG * w * sizeof(uint64_t)));
   }
 
-  // in place on `blocks_ptr` (cts integers of `blocks` blocks, every block value < 2*msg)
-  void run(hipStream_t st, uint64_t *blocks_ptr, uint32_t cts, const void *ksk, const void *bsk) {
+  void group_sum(hipStream_t st, uint64_t *out, const uint64_t *pool, const Idx &csr, uint32_t groups, uint32_t w) {
+    if (groups == 0) return;
+    HX_LAUNCH(lwe_group_sum_kernel, dim3(groups), dim3(256), 0, st, out, pool, csr.a, csr.b, w, groups);
+  }
+
+  // in place on v (cts integers of `blocks` blocks)
+  void run(hipStream_t st, uint64_t *v, uint32_t cts, const void *ksk, const void *bsk) {
     HX_PANIC_IF_FALSE(cts >= 1 && cts <= max_cts, "carry propagation: %u integers exceed the scratch capacity %u", cts,
                       max_cts);
     if (cached_cts != cts) build_indexes(st, cts);
     const Params &p = drv.p;
     const uint32_t w = p.big_n + 1, T = cts * blocks;
-    // round 1: state and message of every block (two LUTs on the same inputs, one launch)
-    drv.round(st, d_x, nullptr, blocks_ptr, r1_in, r1_lut, 2 * T, ksk, bsk);
-    // prefix scan of the states
-    for (const Round &r : scan) {
-      axpy(st, d_p, nullptr, d_x, r.a_idx, p.msg, d_x, r.b_idx, w, r.count);
-      drv.round(st, d_x, r.o_idx, d_p, nullptr, r.lut_idx, r.count, ksk, bsk);
+    // A: shifted / plain state of every block
+    drv.round(st, d_pool, rA.o, v, rA.a, rA.lut, rA.count, ksk, bsk);
+    if (csrU.count) {
+      // group states: U (dense) -> first G-1 blocks -> whole group -> prefix scan -> carry into each group
+      group_sum(st, d_u, d_pool, csrU, csrU.count, w);
+      drv.round(st, d_gs, rC1.o, d_u, nullptr, rC1.lut, rC1.count, ksk, bsk);
+      axpy(st, d_p, nullptr, d_gs, rC2.a, p.msg, d_pool, rC2.b, w, rC2.count);
+      drv.round(st, d_gs, rC2.o, d_p, nullptr, rC2.lut, rC2.count, ksk, bsk);
+      for (const Idx &r : scan) {
+        axpy(st, d_p, nullptr, d_gs, r.a, p.msg, d_gs, r.b, w, r.count);
+        drv.round(st, d_gs, r.o, d_p, nullptr, r.lut, r.count, ksk, bsk);
+      }
+      drv.round(st, d_pool, rD.o, d_gs, rD.a, rD.lut, rD.count, ksk, bsk);
     }
-    // message + carry entering each block
-    axpy(st, d_p, nullptr, d_x, fin.a_idx, p.msg, d_x, fin.b_idx, w, fin.count);
-    drv.round(st, blocks_ptr, fin.o_idx, d_p, nullptr, fin.lut_idx, fin.count, ksk, bsk);
-    axpy(st, blocks_ptr, first_dst, d_x, first_src, 1, nullptr, nullptr, w, first_count);
+    // E: inner carries (dense partial sums in P, bit q of each -> S[t])
+    group_sum(st, d_p, d_pool, csrS, csrS.count, w);
+    drv.round(st, d_s, csrS.o, d_p, nullptr, csrS.lut, csrS.count, ksk, bsk);
+    // F: add the carries, extract the messages
+    axpy(st, v, addC.o, v, addC.o, 1, d_pool, addC.a, w, addC.count);
+    axpy(st, v, addS.o, v, addS.o, 1, d_s, addS.o, w, addS.count);
+    drv.round(st, v, nullptr, v, nullptr, rF.lut, T, ksk, bsk);
   }
 
   void release(hipStream_t st) {
     drv.release(st);
     for (auto *d : dev_arrays) HX_CHECK(hipFree(d));
     dev_arrays.clear();
-    if (d_x) HX_CHECK(hipFree(d_x));
-    if (d_p) HX_CHECK(hipFree(d_p));
+    for (uint64_t *d : {d_pool, d_s, d_p, d_u, d_gs})
+      if (d) HX_CHECK(hipFree(d));
     magic = 0;
   }
 };
@@ -698,18 +822,15 @@ void cleanup_cuda_integer_mult_inplace_64(CudaStreamsFFI streams, int8_t **mem_p
   *mem_ptr_void = nullptr;
 }
 
-// number of PBS one multiplication / one carry propagation of `num_blocks` blocks issues (for benches)
+// number of PBS one carry propagation / one multiplication of `num_blocks` blocks issues (for benches)
+uint64_t hip_integer_propagate_pbs_count(uint32_t num_blocks) { return PropagateMem::pbs_count(num_blocks); }
 uint64_t hip_integer_mult_pbs_count(int8_t *mem_ptr) {
   auto *m = reinterpret_cast<MulMem *>(mem_ptr);
   HX_PANIC_IF_FALSE(m && m->magic == MulMem::kMagic, "hip_integer_mult_pbs_count: foreign scratch pointer");
   uint64_t n = m->prod_slot.size();
   for (auto &s : m->steps)
     for (size_t g = 0; g < s.msg_slot.size(); ++g) n += 1 + (s.carry_slot[g] != ~(uint64_t)0);
-  const uint32_t L = m->blocks;
-  n += 2 * (uint64_t)L;
-  for (uint32_t d = 1; d < L; d <<= 1) n += L - d;
-  n += L - 1;
-  return n;
+  return n + PropagateMem::pbs_count(m->blocks);
 }
 
 }  // extern "C"

@@ -122,6 +122,7 @@ SIGNATURES = {
     "cleanup_cuda_integer_mult_inplace_64": (None, [_S, _i8pp]),
     "hip_integer_scratch_batch": (None, [_u32]),
     "hip_integer_mult_pbs_count": (_u64, [_v]),
+    "hip_integer_propagate_pbs_count": (_u64, [_u32]),
 }
 
 

@@ -57,7 +57,8 @@ def main():
         t0 = time.perf_counter()
         if op == "add":
             sks.add_assign(ca, cb, st)
-            pbs = 2 * L + sum(L - d for d in (1 << k for k in range(L.bit_length()) if (1 << k) < L)) + L - 1
+            from tfhe_rs_amd import ffi
+            pbs = int(ffi.default_library().hip_integer_propagate_pbs_count(L))
             want = [(x + y) & mask for x, y in zip(a, b)]
         else:
             pbs = sks.mul_assign(ca, cb, st, return_pbs_count=True)
