@@ -58,7 +58,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("TFHE_BENCH_FORCE_DIST"):  # the env knob exercises this path at N = 1
         # import torch first so its HIP runtime is the process's single libamdhip64 instance
         import torch
         import torch.distributed as dist
