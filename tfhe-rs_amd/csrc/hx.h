@@ -47,6 +47,38 @@
 
 #define HX_DEV __device__ __forceinline__
 
+// ---- cross-lane swaps of gfx950: v_permlane32_swap exchanges the upper 32 lanes of `a` with the lower 32 lanes
+// of `b`; v_permlane16_swap exchanges the odd 16-lane rows of `a` with the even rows of `b`.  Applied to the
+// dwords of two registers they transpose (register select) x (lane bit 5, resp. bit 4).
+#if defined(TFHE_HIPEMU)
+static inline void hx_permlane_swap(uint32_t &a, uint32_t &b, int lane_bit) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t *x = (uint32_t *)hipemu::g_wave_xchg[wave];
+  x[lane * 2] = a;
+  x[lane * 2 + 1] = b;
+  hipemu::yield_barrier(2);
+  const int bit = (lane >> lane_bit) & 1, partner = lane ^ (1 << lane_bit);
+  const uint32_t na = bit ? x[partner * 2 + 1] : a;   // upper part of a <- lower part of b
+  const uint32_t nb = bit ? b : x[partner * 2];       // lower part of b <- upper part of a
+  hipemu::yield_barrier(2);
+  a = na;
+  b = nb;
+}
+static inline void hx_permlane32_swap(uint32_t &a, uint32_t &b) { hx_permlane_swap(a, b, 5); }
+static inline void hx_permlane16_swap(uint32_t &a, uint32_t &b) { hx_permlane_swap(a, b, 4); }
+#else
+__device__ __forceinline__ void hx_permlane32_swap(uint32_t &a, uint32_t &b) {
+  const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+  a = r[0];
+  b = r[1];
+}
+__device__ __forceinline__ void hx_permlane16_swap(uint32_t &a, uint32_t &b) {
+  const auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
+  a = r[0];
+  b = r[1];
+}
+#endif
+
 // ---- int8 matrix core: D(32x32, i32) = A(32x32, i8) * B(32x32, i8) + C, one instruction per wave.
 // Lane l supplies 16 bytes of row (l & 31) of A and of column (l & 31) of B, both for the same 16 values of
 // k (the half selected by l >> 5); it receives D[row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)][col = l & 31]

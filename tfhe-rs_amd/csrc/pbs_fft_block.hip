@@ -88,6 +88,27 @@ HX_DEV void inv_pass0(cplx (&o)[4]) {
   }
 }
 
+// 4 x 4 transpose between the register index and lane bits (5, 4): new d[a'] in the lane whose bits (5,4) are x
+// = old d[x] in the lane whose bits (5,4) are a'.  This IS the exchange between the passes that work on position
+// bits (7,6) and (5,4) (forward 1 -> 2, inverse 2 -> 3), so it needs no LDS.
+HX_DEV void swap_lane54(cplx (&d)[4]) {
+  uint32_t w[4][4];
+  HX_UNROLL
+  for (int r = 0; r < 4; ++r) __builtin_memcpy(w[r], &d[r], 16);
+  HX_UNROLL
+  for (int k = 0; k < 4; ++k) {
+    hx_permlane32_swap(w[0][k], w[2][k]);
+    hx_permlane32_swap(w[1][k], w[3][k]);
+  }
+  HX_UNROLL
+  for (int k = 0; k < 4; ++k) {
+    hx_permlane16_swap(w[0][k], w[1][k]);
+    hx_permlane16_swap(w[2][k], w[3][k]);
+  }
+  HX_UNROLL
+  for (int r = 0; r < 4; ++r) __builtin_memcpy(&d[r], w[r], 16);
+}
+
 template <int LEVEL_CT, int BASE_LOG_CT>
 __global__ void __launch_bounds__(TPB) pbs_fft_block_kernel(PbsArgs a, FftTables tb) {
   HX_DYN_SMEM(smem);
@@ -210,14 +231,15 @@ __global__ void __launch_bounds__(TPB) pbs_fft_block_kernel(PbsArgs a, FftTables
       // ---- forward transform: 5 passes, exchanges in `work` (padded slots)
       HX_UNROLL
       for (int P = 0; P < 5; ++P) {
-        if (P > 0) {
+        if (P > 0 && P != 2) {
           HX_UNROLL
           for (int r = 0; r < 4; ++r) d[r] = work[lay(4 - P, fwd_pos(P, t, r))];
           HX_WAVE_SYNC();  // the next exchange reuses these slots in another layout
         }
         fwd_pass(d, fw[P][0], fw[P][1], fw[P][2]);
-        if (P < 4) {
-          // in place: these are the slots this thread alone read in this pass
+        if (P == 1) {
+          swap_lane54(d);  // pass 2 regroups lane bits (5,4): two permlane swaps per dword, no LDS
+        } else if (P < 4) {
           HX_UNROLL
           for (int r = 0; r < 4; ++r) work[lay(3 - P, fwd_pos(P, t, r))] = d[r];
           // pass P+1 regroups threads whose index differs in bits (7-2P, 6-2P): other waves only for P = 0
@@ -242,15 +264,19 @@ __global__ void __launch_bounds__(TPB) pbs_fft_block_kernel(PbsArgs a, FftTables
     inv_pass0(o);
     HX_UNROLL
     for (int Q = 1; Q < 5; ++Q) {
-      HX_UNROLL
-      for (int r = 0; r < 4; ++r) work[lay(Q - 1, inv_pos(Q - 1, t, r))] = o[r];
-      // pass Q regroups threads whose index differs in bits (2Q-1, 2Q-2): other waves only for Q = 4
-      if (Q == 4) HX_BLOCK_SYNC_LDS();
-      else HX_WAVE_SYNC();
-      HX_UNROLL
-      for (int r = 0; r < 4; ++r) o[r] = work[lay(Q - 1, inv_pos(Q, t, r))];
-      HX_WAVE_SYNC();  // the next exchange reuses these slots in another layout
-      inv_pass(o, iw[Q][0], iw[Q][1], iw[Q][2]);  // the next write goes to the slots just read (mine alone)
+      if (Q == 3) {
+        swap_lane54(o);  // lane bits (5,4) <-> register index, as in the forward transform
+      } else {
+        HX_UNROLL
+        for (int r = 0; r < 4; ++r) work[lay(Q - 1, inv_pos(Q - 1, t, r))] = o[r];
+        // pass Q regroups threads whose index differs in bits (2Q-1, 2Q-2): other waves only for Q = 4
+        if (Q == 4) HX_BLOCK_SYNC_LDS();
+        else HX_WAVE_SYNC();
+        HX_UNROLL
+        for (int r = 0; r < 4; ++r) o[r] = work[lay(Q - 1, inv_pos(Q, t, r))];
+        HX_WAVE_SYNC();  // the next exchange reuses these slots in another layout
+      }
+      inv_pass(o, iw[Q][0], iw[Q][1], iw[Q][2]);
     }
     // ---- untwist, back to the torus, accumulate, restage (fft/mod.rs:311-330); map pos = 256 r + t
     HX_UNROLL
