@@ -70,6 +70,18 @@ ABORTS = {
         p = C.c_void_p(C.addressof(junk))
         lib.cleanup_cuda_programmable_bootstrap_64(S, G, C.byref(p))
         """, "PBS buffer"),
+    "launch on a size-only radix scratch": ("""
+        s = ffi.CudaStreamsFFI((C.c_void_p * 1)(S), (C.c_uint32 * 1)(0), 1)
+        mem = C.c_void_p()
+        nbytes = lib.scratch_cuda_propagate_single_carry_64_inplace_async(
+            s, C.byref(mem), ffi.CudaLweBootstrapKeyParamsFFI(12, 1, 2048, 23, 1, 2048, 1, 0),
+            ffi.CudaLweKeyswitchKeyParamsFFI(2048, 12, 4, 4), 8, 4, 4, 0, False, 0)
+        assert nbytes > 8 * 2049 * 8, nbytes          # the query reports the device bytes it would take
+        v = gpu.CudaVec(8 * 2049, st)
+        ct = ffi.CudaRadixCiphertextFFI(v.ptr, None, None, 8, 8, 2048)
+        one = (C.c_void_p * 1)(v.ptr)
+        lib.cuda_propagate_single_carry_64_inplace_async(s, C.byref(ct), None, None, mem, one, one, 0, 0)
+        """, "created with allocate_gpu_memory=false"),
     "radix layer on a multi-bit key": ("""
         s = ffi.CudaStreamsFFI((C.c_void_p * 1)(S), (C.c_uint32 * 1)(0), 1)
         mem = C.c_void_p()

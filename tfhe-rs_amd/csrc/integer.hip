@@ -95,10 +95,24 @@ static void generate_lut(const Params &p, uint64_t *acc, const std::function<uin
   std::rotate(body, body + half, body + p.N);
 }
 
+// scratch_* with allocate_gpu_memory = false only reports the device bytes the scratch would take
+// (gpu/ffi.rs:95-132 "size on gpu" queries): allocations are counted, not made, and nothing is uploaded
+static thread_local bool t_dry = false;
+static thread_local uint64_t t_bytes = 0;
+static void radix_alloc(void **p, size_t bytes) {
+  t_bytes += bytes;
+  *p = nullptr;
+  if (!t_dry) HX_CHECK(hipMalloc(p, bytes));
+}
+
 template <class T>
 static T *dev_upload(hipStream_t st, const std::vector<T> &h) {
   T *d = nullptr;
   if (h.empty()) return d;
+  if (t_dry) {
+    t_bytes += h.size() * sizeof(T);
+    return d;
+  }
   HX_CHECK(hipMalloc((void **)&d, h.size() * sizeof(T)));
   HX_CHECK(hipMemcpyAsync(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, st));
   HX_CHECK(hipStreamSynchronize(st));  // h may be a temporary
@@ -122,15 +136,15 @@ struct LutDriver {
     cap = capacity;
     num_luts = (uint32_t)luts.size();
     const size_t lw = (size_t)(p.k + 1) * p.N;
-    HX_CHECK(hipMalloc((void **)&d_ks, (size_t)cap * (p.small_n + 1) * sizeof(uint64_t)));
-    HX_CHECK(hipMalloc((void **)&d_luts, std::max<size_t>(1, num_luts) * lw * sizeof(uint64_t)));
-    for (uint32_t i = 0; i < num_luts; ++i)
+    radix_alloc((void **)&d_ks, (size_t)cap * (p.small_n + 1) * sizeof(uint64_t));
+    radix_alloc((void **)&d_luts, std::max<size_t>(1, num_luts) * lw * sizeof(uint64_t));
+    for (uint32_t i = 0; i < num_luts && !t_dry; ++i)
       HX_CHECK(hipMemcpyAsync(d_luts + i * lw, luts[i].data(), lw * sizeof(uint64_t), hipMemcpyHostToDevice, st));
     std::vector<uint64_t> triv(cap);
     for (uint32_t i = 0; i < cap; ++i) triv[i] = i;
     d_trivial = dev_upload(st, triv);
     HX_CHECK(hipStreamSynchronize(st));
-    scratch_cuda_programmable_bootstrap_64_async(st, gpu, &pbs_buf, p.small_n, p.k, p.N, p.pbs_level, cap, true,
+    scratch_cuda_programmable_bootstrap_64_async(st, gpu, &pbs_buf, p.small_n, p.k, p.N, p.pbs_level, cap, !t_dry,
                                                  (enum PBS_MS_REDUCTION_T)p.ms_type);
   }
   // one round, split into launches of at most `cap` blocks; a null in_idx / out_idx means "block s"
@@ -169,6 +183,7 @@ static uint32_t G0(const CudaStreamsFFI &s) { return s.gpu_indexes ? s.gpu_index
 struct ApplyLutMem {
   static constexpr uint32_t kMagic = 0x4C555431;  // "LUT1"
   uint32_t magic = kMagic;
+  bool size_only = false;
   LutDriver drv;
   uint64_t *d_lut_idx = nullptr;  // all zero
   uint64_t degree = 0;
@@ -206,6 +221,7 @@ struct PropagateMem {
   static constexpr uint32_t kMagic = 0x50524F50;  // "PROP"
   static constexpr uint32_t G = 4;
   uint32_t magic = kMagic;
+  bool size_only = false;
   LutDriver drv;
   uint32_t blocks = 0;   // blocks per integer
   uint32_t max_cts = 0;  // integers the scratch was sized for
@@ -373,11 +389,11 @@ struct PropagateMem {
     const uint32_t T = cts * num_blocks, NG = ngroups(num_blocks);
     drv.init(st, gpu, p, std::min<uint32_t>(T, 1u << 16), luts);
     const size_t w = p.big_n + 1;
-    HX_CHECK(hipMalloc((void **)&d_pool, ((size_t)T + (size_t)cts * NG) * w * sizeof(uint64_t)));
-    HX_CHECK(hipMalloc((void **)&d_s, (size_t)T * w * sizeof(uint64_t)));
-    HX_CHECK(hipMalloc((void **)&d_p, (size_t)T * w * sizeof(uint64_t)));
-    HX_CHECK(hipMalloc((void **)&d_u, (size_t)cts * NG * w * sizeof(uint64_t)));
-    HX_CHECK(hipMalloc((void **)&d_gs, (size_t)cts * NG * w * sizeof(uint64_t)));
+    radix_alloc((void **)&d_pool, ((size_t)T + (size_t)cts * NG) * w * sizeof(uint64_t));
+    radix_alloc((void **)&d_s, (size_t)T * w * sizeof(uint64_t));
+    radix_alloc((void **)&d_p, (size_t)T * w * sizeof(uint64_t));
+    radix_alloc((void **)&d_u, (size_t)cts * NG * w * sizeof(uint64_t));
+    radix_alloc((void **)&d_gs, (size_t)cts * NG * w * sizeof(uint64_t));
   }
 
   void group_sum(hipStream_t st, uint64_t *out, const uint64_t *pool, const Idx &csr, uint32_t groups, uint32_t w) {
@@ -431,6 +447,7 @@ struct PropagateMem {
 struct MulMem {
   static constexpr uint32_t kMagic = 0x4D554C31;  // "MUL1"
   uint32_t magic = kMagic;
+  bool size_only = false;
   LutDriver drv;       // LUTs: 0 product low, 1 product high, 2 message, 3 carry
   PropagateMem prop;
   uint32_t blocks = 0, max_cts = 0, sub = 0;  // sub = integers per pass
@@ -525,12 +542,12 @@ struct MulMem {
     const size_t per_ct = (size_t)slots * w * sizeof(uint64_t);
     sub = (uint32_t)std::max<size_t>(1, std::min<size_t>(cts, ((size_t)12 << 30) / per_ct));
     drv.init(st, gpu, p, 1u << 16, luts);
-    HX_CHECK(hipMalloc((void **)&d_pool, (size_t)sub * per_ct));
+    radix_alloc((void **)&d_pool, (size_t)sub * per_ct);
     const size_t n_prod = prod_slot.size();
     size_t max_groups = 0;
     for (auto &s : steps) max_groups = std::max(max_groups, s.msg_slot.size());
-    HX_CHECK(hipMalloc((void **)&d_pack, (size_t)sub * n_prod * w * sizeof(uint64_t)));
-    HX_CHECK(hipMalloc((void **)&d_sum, std::max<size_t>(1, (size_t)sub * max_groups) * w * sizeof(uint64_t)));
+    radix_alloc((void **)&d_pack, (size_t)sub * n_prod * w * sizeof(uint64_t));
+    radix_alloc((void **)&d_sum, std::max<size_t>(1, (size_t)sub * max_groups) * w * sizeof(uint64_t));
     prop.init(st, gpu, p, num_blocks, sub);
   }
 
@@ -645,8 +662,9 @@ uint64_t scratch_cuda_apply_univariate_lut_64_async(CudaStreamsFFI streams, int8
                                                     uint32_t carry_modulus, uint64_t lut_degree,
                                                     bool allocate_gpu_memory,
                                                     enum PBS_MS_REDUCTION_T noise_reduction_type) {
-  HX_PANIC_IF_FALSE(allocate_gpu_memory, "apply_univariate_lut: size-only scratch is not supported");
   HX_PANIC_IF_FALSE(input_lut != nullptr && mem_ptr != nullptr, "apply_univariate_lut: null pointer");
+  t_dry = !allocate_gpu_memory;
+  t_bytes = 0;
   const Params p = make_params(bsk_params, ksk_params, message_modulus, carry_modulus, (uint32_t)noise_reduction_type);
   auto *m = new ApplyLutMem();
   const size_t lw = (size_t)(p.k + 1) * p.N;
@@ -654,11 +672,14 @@ uint64_t scratch_cuda_apply_univariate_lut_64_async(CudaStreamsFFI streams, int8
   luts[0].assign((const uint64_t *)input_lut, (const uint64_t *)input_lut + lw);
   m->drv.init(S0(streams), G0(streams), p, std::max<uint32_t>(1, input_lwe_ciphertext_count), luts);
   m->degree = lut_degree;
-  HX_CHECK(hipMalloc((void **)&m->d_lut_idx, std::max<uint32_t>(1, input_lwe_ciphertext_count) * sizeof(uint64_t)));
-  HX_CHECK(hipMemsetAsync(m->d_lut_idx, 0, std::max<uint32_t>(1, input_lwe_ciphertext_count) * sizeof(uint64_t),
-                          S0(streams)));
+  radix_alloc((void **)&m->d_lut_idx, std::max<uint32_t>(1, input_lwe_ciphertext_count) * sizeof(uint64_t));
+  if (!t_dry)
+    HX_CHECK(hipMemsetAsync(m->d_lut_idx, 0, std::max<uint32_t>(1, input_lwe_ciphertext_count) * sizeof(uint64_t),
+                            S0(streams)));
+  m->size_only = t_dry;
+  t_dry = false;
   *mem_ptr = reinterpret_cast<int8_t *>(m);
-  return 0;
+  return t_bytes;
 }
 
 void cuda_apply_univariate_lut_64_async(CudaStreamsFFI streams, CudaRadixCiphertextFFI *output_radix_lwe,
@@ -666,6 +687,7 @@ void cuda_apply_univariate_lut_64_async(CudaStreamsFFI streams, CudaRadixCiphert
                                         void *const *ksks, void *const *bsks) {
   auto *m = reinterpret_cast<ApplyLutMem *>(mem_ptr);
   HX_PANIC_IF_FALSE(m && m->magic == ApplyLutMem::kMagic, "apply_univariate_lut: foreign scratch pointer");
+  HX_PANIC_IF_FALSE(!m->size_only, "apply_univariate_lut: scratch was created with allocate_gpu_memory=false");
   HX_PANIC_IF_FALSE(output_radix_lwe && input_radix_lwe && ksks && bsks, "apply_univariate_lut: null pointer");
   HX_PANIC_IF_FALSE(output_radix_lwe->lwe_dimension == input_radix_lwe->lwe_dimension,
                     "input and output radix ciphertexts should have the same lwe dimension");
@@ -685,7 +707,7 @@ void cleanup_cuda_apply_univariate_lut_64(CudaStreamsFFI streams, int8_t **mem_p
   auto *m = reinterpret_cast<ApplyLutMem *>(*mem_ptr_void);
   HX_PANIC_IF_FALSE(m && m->magic == ApplyLutMem::kMagic, "cleanup apply_univariate_lut: foreign scratch pointer");
   m->drv.release(S0(streams));
-  HX_CHECK(hipFree(m->d_lut_idx));
+  if (m->d_lut_idx) HX_CHECK(hipFree(m->d_lut_idx));
   m->magic = 0;
   delete m;
   *mem_ptr_void = nullptr;
@@ -722,13 +744,16 @@ uint64_t scratch_cuda_propagate_single_carry_64_inplace_async(CudaStreamsFFI str
                                                               uint32_t carry_modulus, uint32_t requested_flag,
                                                               bool allocate_gpu_memory,
                                                               enum PBS_MS_REDUCTION_T noise_reduction_type) {
-  HX_PANIC_IF_FALSE(allocate_gpu_memory, "propagate_single_carry: size-only scratch is not supported");
   HX_PANIC_IF_FALSE(requested_flag == 0, "propagate_single_carry: overflow / carry flags are not wired");
   const Params p = make_params(bsk_params, ksk_params, message_modulus, carry_modulus, (uint32_t)noise_reduction_type);
+  t_dry = !allocate_gpu_memory;
+  t_bytes = 0;
   auto *m = new PropagateMem();
   m->init(S0(streams), G0(streams), p, num_blocks, g_scratch_batch);
+  m->size_only = t_dry;
+  t_dry = false;
   *mem_ptr = reinterpret_cast<int8_t *>(m);
-  return 0;
+  return t_bytes;
 }
 uint64_t scratch_cuda_add_and_propagate_single_carry_64_inplace_async(
     CudaStreamsFFI streams, int8_t **mem_ptr, CudaLweBootstrapKeyParamsFFI bsk_params,
@@ -747,6 +772,7 @@ void cuda_propagate_single_carry_64_inplace_async(CudaStreamsFFI streams, CudaRa
   (void)carry_out;
   auto *m = reinterpret_cast<PropagateMem *>(mem_ptr);
   HX_PANIC_IF_FALSE(m && m->magic == PropagateMem::kMagic, "propagate_single_carry: foreign scratch pointer");
+  HX_PANIC_IF_FALSE(!m->size_only, "propagate_single_carry: scratch was created with allocate_gpu_memory=false");
   HX_PANIC_IF_FALSE(requested_flag == 0 && uses_carry == 0 && carry_in == nullptr,
                     "propagate_single_carry: input carry / flags are not wired");
   const uint32_t cts = batch_of(lwe_array, m->blocks, "propagate_single_carry");
@@ -787,13 +813,16 @@ uint64_t scratch_cuda_integer_mult_inplace_64_async(CudaStreamsFFI streams, int8
                                                     CudaLweKeyswitchKeyParamsFFI ksk_params, uint32_t num_blocks,
                                                     bool allocate_gpu_memory,
                                                     enum PBS_MS_REDUCTION_T noise_reduction_type) {
-  HX_PANIC_IF_FALSE(allocate_gpu_memory, "integer_mult: size-only scratch is not supported");
   HX_PANIC_IF_FALSE(!is_boolean_left && !is_boolean_right, "integer_mult: boolean operands are not wired");
   const Params p = make_params(bsk_params, ksk_params, message_modulus, carry_modulus, (uint32_t)noise_reduction_type);
+  t_dry = !allocate_gpu_memory;
+  t_bytes = 0;
   auto *m = new MulMem();
   m->init(S0(streams), G0(streams), p, num_blocks, g_scratch_batch);
+  m->size_only = t_dry;
+  t_dry = false;
   *mem_ptr = reinterpret_cast<int8_t *>(m);
-  return 0;
+  return t_bytes;
 }
 
 void cuda_integer_mult_inplace_64_async(CudaStreamsFFI streams, CudaRadixCiphertextFFI *radix_lwe_inout,
@@ -802,6 +831,7 @@ void cuda_integer_mult_inplace_64_async(CudaStreamsFFI streams, CudaRadixCiphert
                                         int8_t *mem_ptr, uint32_t polynomial_size, uint32_t num_blocks) {
   auto *m = reinterpret_cast<MulMem *>(mem_ptr);
   HX_PANIC_IF_FALSE(m && m->magic == MulMem::kMagic, "integer_mult: foreign scratch pointer");
+  HX_PANIC_IF_FALSE(!m->size_only, "integer_mult: scratch was created with allocate_gpu_memory=false");
   HX_PANIC_IF_FALSE(!is_bool_left && !is_bool_right && polynomial_size == m->drv.p.N && num_blocks == m->blocks,
                     "integer_mult: call does not match the scratch");
   const uint32_t cts = batch_of(radix_lwe_inout, m->blocks, "integer_mult");

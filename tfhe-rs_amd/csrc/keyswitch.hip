@@ -12,6 +12,7 @@
 // elements are staged in LDS and broadcast-read.
 #include "kernels.h"
 #include <mutex>
+#include <unordered_map>
 
 namespace tfhe_hip {
 
@@ -276,12 +277,14 @@ __global__ void __launch_bounds__(256) ks_mfma_kernel(uint64_t *lwe_out, const u
   }
 }
 
-// workspace of the matrix-core path (byte planes + column sums), one per device, grown on demand.  The two
-// kernels of one call use it back to back on the caller's stream; calls on different streams of one device
-// are serialised on this mutex only for the (rare) growth, so concurrent keyswitches on ONE device must use
-// one stream — the reference has the same restriction for its per-call `ks_tmp` scratch.
-static void *g_ksm_ws[64] = {nullptr};
-static size_t g_ksm_ws_bytes[64] = {0};
+// workspace of the matrix-core path (byte planes + column sums): one per stream, grown on demand, so that host
+// threads driving different streams never share it (the boundary allows concurrent calls on different streams,
+// SURVEY §8b).  Entries live until process exit.
+struct KsmWorkspace {
+  void *ptr = nullptr;
+  size_t bytes = 0;
+};
+static std::unordered_map<hipStream_t, KsmWorkspace> g_ksm_ws;
 static std::mutex g_ksm_mutex;
 
 static bool keyswitch_mfma(hipStream_t st, uint64_t *lwe_out, const uint64_t *out_idx, const uint64_t *lwe_in,
@@ -292,24 +295,25 @@ static bool keyswitch_mfma(hipStream_t st, uint64_t *lwe_out, const uint64_t *ou
   while (((uint64_t)1 << log_k) < K) ++log_k;
   const bool level_ok = level == 1 || level == 2 || level == 4 || level == 8 || level == 16;
   if (!level_ok || K % 32 != 0 || base_log > 6 || base_log + 7 + log_k > 31 || num_samples < 64) return false;
-  int dev = 0;
-  HX_CHECK(hipGetDevice(&dev));
   const uint32_t ncols = n_out + 1, col_tiles = (ncols + KSM_CT - 1) / KSM_CT;
   const size_t plane_bytes = (size_t)(K / 16) * col_tiles * 8 * KSM_CT * 16;
   const size_t need = plane_bytes + (size_t)col_tiles * KSM_CT * sizeof(uint64_t);
+  void *ws = nullptr;
   {
     std::lock_guard<std::mutex> lock(g_ksm_mutex);
-    if (g_ksm_ws_bytes[dev] < need) {
-      if (g_ksm_ws[dev]) {
-        HX_CHECK(hipDeviceSynchronize());  // nobody may still be reading the old planes
-        HX_CHECK(hipFree(g_ksm_ws[dev]));
+    KsmWorkspace &w = g_ksm_ws[st];
+    if (w.bytes < need) {
+      if (w.ptr) {
+        HX_CHECK(hipStreamSynchronize(st));  // the previous call on this stream may still read the old planes
+        HX_CHECK(hipFree(w.ptr));
       }
-      HX_CHECK(hipMalloc(&g_ksm_ws[dev], need));
-      g_ksm_ws_bytes[dev] = need;
+      HX_CHECK(hipMalloc(&w.ptr, need));
+      w.bytes = need;
     }
+    ws = w.ptr;
   }
-  int8_t *planes = (int8_t *)g_ksm_ws[dev];
-  uint64_t *colsum = (uint64_t *)((char *)g_ksm_ws[dev] + plane_bytes);
+  int8_t *planes = (int8_t *)ws;
+  uint64_t *colsum = (uint64_t *)((char *)ws + plane_bytes);
   HX_CHECK(hipMemsetAsync(colsum, 0, (size_t)col_tiles * KSM_CT * sizeof(uint64_t), st));
   HX_LAUNCH(ksk_planes_kernel, dim3((col_tiles * KSM_CT + 255) / 256, K / 16), dim3(256), 0, st, planes, colsum, ksk, K,
             ncols, col_tiles);
