@@ -445,3 +445,38 @@ def test_multi_bit_full_size_group3():
     assert [decrypt_big(p, keys, o) for o in out] == [f(m) for m in msgs]
     ref = oracle_pbs(p, keys, "fft64", cts[:3], lut)
     assert np.array_equal(out[:3], ref)
+
+
+@pytest.mark.gpu
+def test_concurrent_host_threads_on_their_own_streams():
+    """The boundary may be driven from several host threads, each on its own stream (SURVEY §8b;
+    cuda/tests_and_benchmarks/tests/test_concurrent_pbs.cpp): KS -> PBS from 4 threads at once must give the
+    bits of the sequential run."""
+    import threading
+    from .common import C1
+    p = C1
+    keys = make_keys(p)
+    lib = use_backend("hip")
+    f = lambda x: (x + 5) % 16
+    lut = orc.generate_lut(p.k, p.N, p.plaintext_modulus, p.delta, f)
+    base = Ctx("hip", p, keys, "fft64", True)
+    msgs = [[(7 * t + i) % 16 for i in range(96)] for t in range(4)]
+    cts = [encrypt_big(p, keys, m, seed=300 + t) for t, m in enumerate(msgs)]
+    want = [base.pbs(base.keyswitch(c), lut) for c in cts]
+    ctxs = [Ctx("hip", p, keys, "fft64", True) for _ in range(4)]   # own streams, own key copies
+    got, errs = [None] * 4, []
+
+    def work(t):
+        try:
+            for _ in range(3):
+                got[t] = ctxs[t].pbs(ctxs[t].keyswitch(cts[t]), lut)
+        except Exception as e:  # pragma: no cover
+            errs.append(e)
+
+    th = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+    [x.start() for x in th]
+    [x.join() for x in th]
+    assert not errs, errs
+    for t in range(4):
+        assert np.array_equal(got[t], want[t]), f"thread {t} differs from the sequential run"
+        assert [decrypt_big(p, keys, o) for o in got[t][:8]] == [f(m) for m in msgs[t][:8]]
