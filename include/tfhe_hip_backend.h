@@ -303,7 +303,8 @@ void hip_backend_set_fft_kernel(uint32_t which);
  * base_log <= 6 and n_in*level is a multiple of 32; scalar kernels otherwise), 1 = scalar kernels only.
  * Identical bits either way. */
 void hip_backend_set_keyswitch_kernel(uint32_t which);
-/* NTT engine kernel: 0 = one thread group per GLWE polynomial (default), 1 = single-group kernel. Same bits. */
+/* generic kernels (f64 and NTT engines): 0 = one thread group per GLWE polynomial (default), 1 = single-group
+ * kernels. Same bits. */
 void hip_backend_set_ntt_kernel(uint32_t which);
 /* last launched PBS kernel, for tests: 1 generic f64, 2 wave f64, 3 generic ntt, 4 generic multi-bit,
  * 5 exact, 6 wave multi-bit, 7 block (latency), 8 block dual-stream */

@@ -93,6 +93,95 @@ __global__ void __launch_bounds__(GenericCfg<N>::TPB) pbs_fft_generic_kernel(Pbs
   block_sample_extract<N, K1, TPB>(a, acc, sample, 0, false, tid);
 }
 
+// Same engine, one thread group per GLWE polynomial: the k+1 forward transforms of a level (one per row) and
+// the k+1 inverse transforms (one per column) run side by side, so a CMUX has (k+1)x fewer barrier-separated
+// stages.  Per output point the products are accumulated in the same order (level, then row): identical bits.
+template <int N, int K1>
+__global__ void __launch_bounds__(K1 *GenericCfg<N>::TPB) pbs_fft_par_kernel(PbsArgs a, FftTables tb) {
+  constexpr int n = N / 2, TPB = GenericCfg<N>::TPB, TPBT = K1 * TPB, PER = n / TPB, LOG2N2 = ilog2_c(2 * N);
+  HX_DYN_SMEM(smem);
+  uint64_t *acc = (uint64_t *)smem;                  // K1*N torus words
+  cplx *fbuf = (cplx *)(smem + (size_t)K1 * N * 8);  // K1 transform buffers of n complex points
+  const int tid = threadIdx.x;
+  const int grp = tid / TPB, lt = tid - grp * TPB;   // my row (forward) / column (inverse), thread inside it
+  const uint32_t sample = blockIdx.x;
+  const uint64_t *lwe = a.lwe_in + (size_t)a.in_idx[sample] * (a.n + 1);
+  const uint64_t *lut = a.lut + (size_t)a.lut_idx[sample] * K1 * N;
+  const cplx *bsk = (const cplx *)a.bsk;
+  cplx *mybuf = fbuf + (size_t)grp * n;
+
+  // body modulus switch; TPBT need not be a power of two (k = 2), so the reduction is a plain sum
+  uint64_t corr = 0;
+  if (a.ms_type == 1) {
+    uint64_t *scratch = (uint64_t *)fbuf;
+    uint64_t sh = 0;
+    int64_t sd = 0;
+    for (uint32_t i = tid; i < a.n; i += TPBT) {
+      uint64_t h;
+      int64_t d;
+      centered_ms_terms(lwe[i], LOG2N2, h, d);
+      sh += h;
+      sd += d;
+    }
+    scratch[tid] = sh;
+    scratch[TPBT + tid] = (uint64_t)sd;
+    __syncthreads();
+    uint64_t th = 0, td = 0;
+    for (int l = 0; l < TPBT; ++l) {
+      th += scratch[l];
+      td += scratch[TPBT + l];
+    }
+    __syncthreads();
+    corr = centered_ms_finish(th, (int64_t)td, LOG2N2);
+  }
+  const uint32_t b_hat = (uint32_t)modulus_switch(lwe[a.n] + corr, LOG2N2);
+  for (uint32_t j = lt; j < (uint32_t)N; j += TPB) {  // acc <- LUT * X^{-b_hat}
+    bool neg;
+    const uint32_t src = monomial_div_src(j, b_hat, N, neg);
+    const uint64_t v = lut[grp * N + src];
+    acc[grp * N + j] = neg ? (uint64_t)0 - v : v;
+  }
+  __syncthreads();
+
+  for (uint32_t i = 0; i < a.n; ++i) {
+    const uint32_t a_hat = (uint32_t)modulus_switch(lwe[i], LOG2N2);
+    if (a_hat == 0) continue;  // uniform across the workgroup (bootstrap.rs:334)
+    cplx facc[PER];
+    for (uint32_t idx = 0; idx < a.level; ++idx) {
+      for (int q = 0; q < PER; ++q) {  // digits of my row
+        const uint32_t j = lt + q * TPB;
+        const int64_t d0 = decomp_digit(rot_sub<N>(acc + grp * N, j, a_hat), a.base_log, a.level, idx);
+        const int64_t d1 = decomp_digit(rot_sub<N>(acc + grp * N, j + n, a_hat), a.base_log, a.level, idx);
+        mybuf[j] = cplx{i64_to_f64(d0), i64_to_f64(d1)};
+      }
+      __syncthreads();
+      lds_fft_forward<N, TPB>(mybuf, tb.fwd, lt);
+      for (int row = 0; row < K1; ++row) {  // column `grp` of the external product
+        const cplx *brow = bsk + ((((size_t)i * a.level + idx) * K1 + row) * K1 + grp) * n;
+        const cplx *f = fbuf + (size_t)row * n;
+        for (int q = 0; q < PER; ++q) {
+          const int pos = lt + q * TPB;
+          const cplx y = brow[bsk_slot<N, K1>(pos)];
+          facc[q] = (idx == 0 && row == 0) ? cmul_first(f[pos], y) : cmul_add(f[pos], y, facc[q]);
+        }
+      }
+      __syncthreads();
+    }
+    for (int q = 0; q < PER; ++q) mybuf[lt + q * TPB] = facc[q];
+    __syncthreads();
+    lds_fft_inverse<N, TPB>(mybuf, tb.inv, lt);
+    for (int q = 0; q < PER; ++q) {
+      const int j = lt + q * TPB;
+      const cplx y = mybuf[j];
+      const double ur = tb.untw[2 * j], ui = tb.untw[2 * j + 1];
+      acc[grp * N + j] += from_torus(fma(-y.im, ui, y.re * ur));
+      acc[grp * N + j + n] += from_torus(fma(y.im, ur, y.re * ui));
+    }
+    __syncthreads();
+  }
+  block_sample_extract<N, K1, TPBT>(a, acc, sample, 0, false, tid);
+}
+
 // ------------------------------------------------------------------------- exact engine
 // External products by exact negacyclic convolution mod 2^64 on the standard-domain key
 // (cc/algorithms/lwe_programmable_bootstrapping/karatsuba_pbs.rs:199-413; any exact product gives
@@ -325,10 +414,19 @@ __global__ void __launch_bounds__(GenericCfg<N>::TPB) bsk_to_ntt_kernel(const ui
 // ------------------------------------------------------------------------- launchers
 template <int N, int K1>
 static void launch_fft(hipStream_t st, const PbsArgs &a, const FftTables &tb) {
-  const size_t smem = (size_t)(K1 + 1) * N * 8;
-  HX_CHECK(hipFuncSetAttribute((const void *)pbs_fft_generic_kernel<N, K1>,
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-  HX_LAUNCH((pbs_fft_generic_kernel<N, K1>), dim3(a.num_samples), dim3(GenericCfg<N>::TPB), smem, st, a, tb);
+  // one group per polynomial pays off for k = 1 (32.3k vs 29.8k PBS/s at 2_2); with three groups (k = 2, N = 1024)
+  // the larger workgroup costs more occupancy than the shorter barrier chain returns (38k vs 46k): single group
+  if (g_ntt_kernel_serial || K1 != 2) {
+    const size_t smem = (size_t)(K1 + 1) * N * 8;
+    HX_CHECK(hipFuncSetAttribute((const void *)pbs_fft_generic_kernel<N, K1>,
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    HX_LAUNCH((pbs_fft_generic_kernel<N, K1>), dim3(a.num_samples), dim3(GenericCfg<N>::TPB), smem, st, a, tb);
+    return;
+  }
+  const size_t smem = (size_t)2 * K1 * N * 8;
+  HX_CHECK(hipFuncSetAttribute((const void *)pbs_fft_par_kernel<N, K1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)smem));
+  HX_LAUNCH((pbs_fft_par_kernel<N, K1>), dim3(a.num_samples), dim3(K1 * GenericCfg<N>::TPB), smem, st, a, tb);
 }
 template <int N, int K1>
 static void launch_ntt(hipStream_t st, const PbsArgs &a, const NttTables &tb) {
