@@ -430,7 +430,7 @@ static void launch_fft(hipStream_t st, const PbsArgs &a, const FftTables &tb) {
 }
 template <int N, int K1>
 static void launch_ntt(hipStream_t st, const PbsArgs &a, const NttTables &tb) {
-  if (g_ntt_kernel_serial) {  // the one-group kernel, kept for comparison (hip_backend_set_ntt_kernel(1))
+  if (g_ntt_kernel_serial || K1 != 2) {  // same rule as the f64 engine above
     const size_t smem = (size_t)(K1 + 1) * N * 8;
     HX_CHECK(hipFuncSetAttribute((const void *)pbs_ntt_generic_kernel<N, K1>,
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
