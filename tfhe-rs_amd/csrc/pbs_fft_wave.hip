@@ -29,6 +29,11 @@
 #ifndef WAVE_EARLY_CHUNKS
 #define WAVE_EARLY_CHUNKS 1  // key chunks requested at the top of an iteration (0, 1 or 2); the rest at the MAC
 #endif
+// 1: transforms as radix 16 -> (permlane swaps) -> radix 4 -> (one LDS transposition) -> radix 16;
+// 0: radix 16 -> LDS -> radix 16 -> LDS -> radix 4 (the first layout of this kernel).  Same bits.
+#ifndef WAVE_PERMLANE_PASS
+#define WAVE_PERMLANE_PASS 1
+#endif
 #ifndef WAVE_FUSE_PASS1
 #define WAVE_FUSE_PASS1 1    // first inverse pass interleaved with the MAC chunks
 #endif
@@ -57,7 +62,8 @@ constexpr int T_F2 = 8;      // forward d = 4..7: 16 + 16 + 32 + 64
 constexpr int T_F3 = 136;    // forward d = 8, 9, even groups: 128 + 256
 constexpr int T_INV = 520;   // E[J] = inv[512 + J], J < 256; every inverse twiddle is E[j*512/half] or -i*E[.]
 constexpr int T_U = 776;     // untwist, j <= 512 (mirrored above): 513 entries
-constexpr int T_TOTAL = 1289;
+constexpr int T_F6 = 1289;   // forward d = 6, all 64 groups: fwd[64 + x]
+constexpr int T_TOTAL = 1353;
 constexpr int FLAGS_BYTES = 64;
 constexpr size_t SMEM_BYTES = (size_t)WAVES * BUF_BYTES + (size_t)T_TOTAL * 16 + FLAGS_BYTES;
 
@@ -123,7 +129,91 @@ struct WaveCtx {
 HX_DEV int base_m1(const WaveCtx &c) { return c.lane; }
 HX_DEV int base_m2(const WaveCtx &c) { return c.hi4 * 68 + c.lo2; }
 HX_DEV int base_m3(const WaveCtx &c) { return c.lane * 17; }
+// mapping MX (after the permlane swaps): register bits (3,2,1,0) = position bits (5,4,7,6), lane bits
+// (5,4) = position bits (9,8), lane bits 3..0 = position bits 3..0.  Its slot in the M3/P_B layout is
+//   ((lane>>4)*16 + (r&3)*4 + (r>>2))*17 + (lane&15) = base_mx + mx_off(r)
+HX_DEV int base_mx(const WaveCtx &c) { return (c.lane >> 4) * 272 + (c.lane & 15); }
+constexpr int mx_off(int r) { return ((r & 3) * 4 + (r >> 2)) * 17; }
 
+// register bits (3,2) <-> lane bits (5,4): M1 <-> MX without touching LDS (two permlane swaps per dword)
+HX_DEV void swap_regs_lane54(cplx (&d)[16]) {
+  HX_UNROLL
+  for (int r = 0; r < 8; ++r) {  // register bit 3 <-> lane bit 5
+    uint32_t a[4], b[4];
+    __builtin_memcpy(a, &d[r], 16);
+    __builtin_memcpy(b, &d[r + 8], 16);
+    HX_UNROLL
+    for (int k = 0; k < 4; ++k) hx_permlane32_swap(a[k], b[k]);
+    __builtin_memcpy(&d[r], a, 16);
+    __builtin_memcpy(&d[r + 8], b, 16);
+  }
+  HX_UNROLL
+  for (int r = 0; r < 16; ++r)
+    if (!(r & 4)) {  // register bit 2 <-> lane bit 4
+      uint32_t a[4], b[4];
+      __builtin_memcpy(a, &d[r], 16);
+      __builtin_memcpy(b, &d[r + 4], 16);
+      HX_UNROLL
+      for (int k = 0; k < 4; ++k) hx_permlane16_swap(a[k], b[k]);
+      __builtin_memcpy(&d[r], a, 16);
+      __builtin_memcpy(&d[r + 4], b, 16);
+    }
+}
+
+#if WAVE_PERMLANE_PASS
+// ---- forward transform of 16 points per lane: mapping M1 in, mapping M3 out (and stored in my buffer)
+//   F1 stages 0..3 (position bits 9..6, registers) -> permlane swaps -> F2 stages 4,5 (bits 5,4, registers)
+//   -> LDS transposition MX -> M3 -> F3 stages 6..9 (bits 3..0, registers)
+HX_DEV void wave_forward(cplx (&d)[16], WaveCtx c) {
+  HX_OPAQUE(c.lane);
+  const int lane = c.lane, g4 = c.lane >> 4;
+  const cplx *T = c.T;
+  {
+    const cplx w0 = T[T_F1 + 0];
+    stage<3>(d, [&](int) { return w0; });
+    const cplx e1 = T[T_F1 + 1];
+    stage<2>(d, [&](int r) { return (r >> 3) ? times_i(e1) : e1; });
+    HX_SCHED_FENCE();
+    const cplx e2[2] = {T[T_F1 + 2], T[T_F1 + 3]};
+    stage<1>(d, [&](int r) { return ((r >> 2) & 1) ? times_i(e2[r >> 3]) : e2[r >> 3]; });
+    HX_SCHED_FENCE();
+    const cplx e3[4] = {T[T_F1 + 4], T[T_F1 + 5], T[T_F1 + 6], T[T_F1 + 7]};
+    stage<0>(d, [&](int r) { return ((r >> 1) & 1) ? times_i(e3[r >> 2]) : e3[r >> 2]; });
+  }
+  HX_SCHED_FENCE();
+  swap_regs_lane54(d);
+  HX_SCHED_FENCE();
+  {  // stage 4: group (pos >> 6) = (lane>>4)*4 + (r&3); stage 5: group (pos >> 5) = that*2 + (r>>3)
+    const cplx e4[4] = {T[T_F2 + g4 * 4], T[T_F2 + g4 * 4 + 1], T[T_F2 + g4 * 4 + 2], T[T_F2 + g4 * 4 + 3]};
+    stage<3>(d, [&](int r) { return e4[r & 3]; });
+    HX_SCHED_FENCE();
+    const cplx e5[4] = {T[T_F2 + 16 + g4 * 4], T[T_F2 + 16 + g4 * 4 + 1], T[T_F2 + 16 + g4 * 4 + 2],
+                        T[T_F2 + 16 + g4 * 4 + 3]};
+    cplx *px = c.buf + base_mx(c);  // transposition MX -> M3, store side
+    stage_store<2>(d, [&](int r) { return (r >> 3) ? times_i(e5[r & 3]) : e5[r & 3]; },
+                   [&](int r) { px[mx_off(r)] = d[r]; });
+  }
+  HX_WAVE_SYNC();
+  {  // stages 6..9 over position bits 3..0 (= r bits 3..0), group index = lane . (r bits)
+    const cplx w6 = T[T_F6 + lane];
+    cplx *p3 = c.buf + base_m3(c);  // transposition MX -> M3, load side
+    load_pairs<3>([&](int r) { d[r] = p3[r]; });
+    HX_WAVE_SYNC();
+    stage<3>(d, [&](int) { return w6; });
+    const cplx e7 = T[T_F2 + 64 + lane];
+    stage<2>(d, [&](int r) { return (r >> 3) ? times_i(e7) : e7; });
+    HX_SCHED_FENCE();
+    const cplx e8[2] = {T[T_F3 + lane * 2], T[T_F3 + lane * 2 + 1]};
+    stage<1>(d, [&](int r) { return ((r >> 2) & 1) ? times_i(e8[r >> 3]) : e8[r >> 3]; });
+    HX_SCHED_FENCE();
+    const cplx e9[4] = {T[T_F3 + 128 + lane * 4], T[T_F3 + 128 + lane * 4 + 1], T[T_F3 + 128 + lane * 4 + 2],
+                        T[T_F3 + 128 + lane * 4 + 3]};
+    stage_store<0>(d, [&](int r) { return ((r >> 1) & 1) ? times_i(e9[r >> 2]) : e9[r >> 2]; },
+                   [&](int r) { p3[r] = d[r]; });
+  }
+  HX_WAVE_SYNC();
+}
+#else
 // ---- forward transform of 16 points per lane: mapping M1 in, mapping M3 out
 HX_DEV void wave_forward(cplx (&d)[16], WaveCtx c) {
   HX_OPAQUE(c.lane);
@@ -184,6 +274,8 @@ HX_DEV void wave_forward(cplx (&d)[16], WaveCtx c) {
   HX_WAVE_SYNC();
 }
 
+#endif  // WAVE_PERMLANE_PASS (forward)
+
 // ---- inverse transform (mapping M3 in, M1 out), untwist and accumulation into the torus regs.
 // Twiddle of DIT stage `half`, butterfly offset j: inv[half + j] = E[j*512/half] (nested tables),
 // E[J] = T_INV[J] for J < 256 and -i*T_INV[J-256] above.
@@ -216,11 +308,46 @@ HX_DEV void wave_inverse_accumulate(cplx (&o)[16], uint64_t (&acc_re)[16], uint6
   c.hi4 = c.lane >> 2;
   c.lo2 = c.lane & 3;
   const int lo2 = c.lo2;
+  (void)lo2;
   const cplx *T = c.T;
   if constexpr (!PASS1_DONE) {
     HX_UNROLL
     for (int g = 0; g < 4; ++g) inverse_pass1_group(o, g);
   }
+#if WAVE_PERMLANE_PASS
+  // pass I1 (continued): stages half = 4, 8 over position bits 2, 3 (= r bits 2, 3); j = r & 3, r & 7, so the
+  // twiddles are the same in every lane: E[j*128] and E[j*64]
+  {
+    const cplx a0 = T[T_INV], a1 = T[T_INV + 128];
+    stage<2>(o, [&](int r) {
+      const cplx e = (r & 1) ? a1 : a0;
+      return (r & 2) ? times_mi(e) : e;
+    });
+    HX_SCHED_FENCE();
+    const cplx b4[4] = {a0, T[T_INV + 64], a1, T[T_INV + 192]};
+    cplx *p3 = c.buf + base_m3(c);  // transposition M3 -> MX, store side
+    stage_store<3>(o, [&](int r) { return (r & 4) ? times_mi(b4[r & 3]) : b4[r & 3]; },
+                   [&](int r) { p3[r] = o[r]; });
+  }
+  HX_WAVE_SYNC();
+  // pass I2: stages half = 16, 32 over position bits 4, 5 (= r bits 2, 3 in mapping MX); j = (r bit 2).(lane & 15)
+  {
+    int ln = c.lane;
+    HX_OPAQUE(ln);
+    const int l15 = ln & 15;
+    cplx w16 = T[T_INV + (l15 & 7) * 32];
+    const cplx e32 = T[T_INV + l15 * 16];
+    const cplx *px = c.buf + base_mx(c);  // transposition M3 -> MX, load side
+    load_pairs<2>([&](int r) { o[r] = px[mx_off(r)]; });
+    HX_WAVE_SYNC();
+    if (l15 & 8) w16 = times_mi(w16);
+    stage<2>(o, [&](int) { return w16; });
+    stage<3>(o, [&](int r) { return (r & 4) ? times_mi(e32) : e32; });
+  }
+  HX_SCHED_FENCE();
+  swap_regs_lane54(o);  // MX -> M1
+  HX_SCHED_FENCE();
+#else
   HX_SCHED_FENCE();
   // transpose M3 -> M2, store side
   {
@@ -250,14 +377,17 @@ HX_DEV void wave_inverse_accumulate(cplx (&o)[16], uint64_t (&acc_re)[16], uint6
                    [&](int r) { p2[4 * r] = o[r]; });
   }
   HX_WAVE_SYNC();
+#endif  // WAVE_PERMLANE_PASS (inverse, passes 1-2)
   // pass I3: stages half = 64..512 over position bits 6..9 (= r bits 0..3); j = (r bits).lane
   {
     int lane = c.lane;
     HX_OPAQUE(lane);
     cplx w7 = T[T_INV + (lane & 31) * 8];
+#if !WAVE_PERMLANE_PASS
     const cplx *p1 = c.buf + base_m1(c);  // transpose M2 -> M1, load side
     load_pairs<0>([&](int r) { o[r] = p1[68 * r]; });
     HX_WAVE_SYNC();
+#endif
     if (lane & 32) w7 = times_mi(w7);
     stage<0>(o, [&](int) { return w7; });
     const cplx e8 = T[T_INV + lane * 4];
@@ -351,8 +481,10 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
         v = (x < 128) ? ldg_c(tb.fwd, 256 + 2 * x) : ldg_c(tb.fwd, 512 + 2 * (x - 128));
       } else if (e < T_U) {       // E[J] = inv[512 + J], J < 256
         v = ldg_c(tb.inv, 512 + (e - T_INV));
-      } else {
+      } else if (e < T_F6) {
         v = ldg_c(tb.untw, e - T_U);
+      } else {
+        v = ldg_c(tb.fwd, 64 + (e - T_F6));
       }
       Tw[e] = v;
     }
