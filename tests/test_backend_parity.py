@@ -314,6 +314,32 @@ def test_wave_kernel_equals_generic_and_oracle(kind, p):
 
 
 @pytest.mark.parametrize("kind", BACKENDS)
+def test_decomposer_boundary_digits_in_every_fft_kernel(kind):
+    """The decomposer maps the state B/2 to +B/2 or -B/2 by its rounding bit
+    (commons/math/decomposition/decomposer.rs:156-185); the one-level kernels compute the digit from a
+    two-instruction rounding and fall back to the exact bit sequence where the two can differ.  An
+    accumulator whose neighbouring coefficients differ by 2^63 +- (less than 2^40) puts the first
+    rotations of the blind rotation exactly on those states, for both signs."""
+    p = TOY_2048
+    c = ctx(kind, p, "fft64")
+    rng = np.random.default_rng(77)
+    small = rng.integers(0, 1 << 39, size=(p.k + 1) * p.N, dtype=np.uint64)
+    lut = small.copy()
+    lut[1::2] += np.uint64(1 << 63)           # x = +-(2^63 + d), |d| < 2^39: top 24 bits 0x800000 / 0x7fffff
+    lut[2::4] -= np.uint64(1 << 40)           # ... and some a whole rounding step away on either side
+    cts = rng.integers(0, 1 << 64, size=(5, p.n + 1), dtype=np.uint64)
+    cts[:, 0] |= np.uint64(1 << 52)           # first mask element switches to an odd rotation
+    cts[:, 0] &= np.uint64(~((1 << 51) | (1 << 50)) & M64)
+    ref = oracle_pbs(p, c.keys, "fft64", cts, lut)
+    try:
+        for which in (1, 2, 3, 4):
+            c.lib.hip_backend_set_fft_kernel(which)
+            assert np.array_equal(c.pbs(cts, lut), ref), which
+    finally:
+        c.lib.hip_backend_set_fft_kernel(0)
+
+
+@pytest.mark.parametrize("kind", BACKENDS)
 def test_wave_kernel_many_lut_and_indexes(kind):
     p = TOY_2048
     c = ctx(kind, p, "fft64")

@@ -82,6 +82,13 @@ HX_DEV int32_t decomp_digit_l1_hi(uint32_t x_hi, uint32_t base_log) {
   return (int32_t)(res - (nb << base_log));
 }
 
+// Same digit from two instructions: round the high dword at bit (31 - base_log), shift arithmetically.
+// Equal to decomp_digit_l1_hi for every input except some of those where this returns -B/2 (the
+// decomposer maps the state B/2 to +B/2 or -B/2 by its rounding bit); callers that see -B/2 fall back.
+HX_DEV int32_t decomp_digit_l1_fast(uint32_t x_hi, uint32_t base_log) {
+  return (int32_t)(x_hi + (1u << (31 - base_log))) >> (32 - base_log);
+}
+
 // ------------------------------------------------------------------ monomial indexing
 // coefficient j of  in * X^{deg}  (negacyclic), cc/algorithms/polynomial_algorithms.rs:662-727:
 // returns the source index and whether the source is negated.

@@ -213,20 +213,40 @@ __global__ void __launch_bounds__(TPB) pbs_fft_block_kernel(PbsArgs a, FftTables
       }
       // ---- digits of (acc * X^a_hat - acc) at level idx, map pos = 256 r + t
       cplx d[4];
+      uint64_t x0[4], x1[4];
       HX_UNROLL
       for (int r = 0; r < 4; ++r) {
         const uint32_t c0 = r * 256 + t, c1 = 1024 + r * 256 + t;
         uint64_t s = stage[(c0 - rr) & (N - 1)];
-        const uint64_t x0 = (((c0 < rr) != odd) ? (uint64_t)0 - s : s) - acc_re[r];
+        x0[r] = (((c0 < rr) != odd) ? (uint64_t)0 - s : s) - acc_re[r];
         s = stage[(c1 - rr) & (N - 1)];
-        const uint64_t x1 = (((c1 < rr) != odd) ? (uint64_t)0 - s : s) - acc_im[r];
-        if constexpr (LEVEL_CT == 1 && BASE_LOG_CT != 0 && BASE_LOG_CT <= 30) {
-          d[r] = cplx{(double)decomp_digit_l1_hi((uint32_t)(x0 >> 32), BASE_LOG_CT),
-                      (double)decomp_digit_l1_hi((uint32_t)(x1 >> 32), BASE_LOG_CT)};
-        } else {
-          d[r] = cplx{i64_to_f64(decomp_digit(x0, base_log, level, idx)),
-                      i64_to_f64(decomp_digit(x1, base_log, level, idx))};
+        x1[r] = (((c1 < rr) != odd) ? (uint64_t)0 - s : s) - acc_im[r];
+      }
+      if constexpr (LEVEL_CT == 1 && BASE_LOG_CT != 0 && BASE_LOG_CT <= 30) {
+        // two-instruction rounding; it can differ from the decomposer only where it yields -B/2, and a
+        // thread that saw that value redoes its digits with the decomposer's own bit sequence
+        int32_t q[8], lowest = 0;
+        HX_UNROLL
+        for (int r = 0; r < 4; ++r) {
+          q[2 * r] = decomp_digit_l1_fast((uint32_t)(x0[r] >> 32), BASE_LOG_CT);
+          q[2 * r + 1] = decomp_digit_l1_fast((uint32_t)(x1[r] >> 32), BASE_LOG_CT);
+          lowest = q[2 * r] < lowest ? q[2 * r] : lowest;
+          lowest = q[2 * r + 1] < lowest ? q[2 * r + 1] : lowest;
         }
+        if (lowest == -(1 << (BASE_LOG_CT - 1))) {
+          HX_UNROLL
+          for (int r = 0; r < 4; ++r) {
+            q[2 * r] = decomp_digit_l1_hi((uint32_t)(x0[r] >> 32), BASE_LOG_CT);
+            q[2 * r + 1] = decomp_digit_l1_hi((uint32_t)(x1[r] >> 32), BASE_LOG_CT);
+          }
+        }
+        HX_UNROLL
+        for (int r = 0; r < 4; ++r) d[r] = cplx{(double)q[2 * r], (double)q[2 * r + 1]};
+      } else {
+        HX_UNROLL
+        for (int r = 0; r < 4; ++r)
+          d[r] = cplx{i64_to_f64(decomp_digit(x0[r], base_log, level, idx)),
+                      i64_to_f64(decomp_digit(x1[r], base_log, level, idx))};
       }
       // ---- forward transform: 5 passes, exchanges in `work` (padded slots)
       HX_UNROLL

@@ -553,15 +553,17 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
     }
     HX_WAVE_SYNC();
   };
-  auto make_digits = [&](cplx (&d)[16], uint32_t a_hat, uint32_t idx) {
+  // EXACT selects the decomposer's own bit sequence; the default for one level is the two-instruction
+  // rounding decomp_digit_l1_fast, which differs from it only where it returns -B/2: a lane that saw that
+  // value (about one coefficient in 2^23) redoes its points with EXACT = true
+  auto make_digits_impl = [&](cplx (&d)[16], uint32_t a_hat, uint32_t idx, auto exact_tag) -> int32_t {
+    constexpr bool EXACT = decltype(exact_tag)::value;
     int lane = ctx.lane;
     HX_OPAQUE(lane);
-    // the accumulator is already staged in buf64 (stage_acc at start, then by every
-    // wave_inverse_accumulate); later levels of one iteration re-stage, the transposes reused the buffer
-    if (!MULTIBIT && idx != 0) stage_acc();
     const uint32_t rr = a_hat & (N - 1);
     const bool odd = (a_hat & N) != 0;
     const uint32_t t0 = (uint32_t)lane - rr;  // (c - rr) for c = lane; wraps mod 2^32, masked below
+    int32_t lowest = 0;
     HX_UNROLL
     for (int r = 0; r < 16; ++r) {
       const uint32_t c0 = r * 64 + lane, c1 = 1024 + r * 64 + lane;
@@ -577,8 +579,16 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
       }
       if constexpr (LEVEL_CT == 1 && BASE_LOG_CT != 0 && BASE_LOG_CT <= 30) {
         // one level: the digit is the decomposer's initial state and depends on the high dword only
-        d[r] = cplx{(double)decomp_digit_l1_hi((uint32_t)(x0 >> 32), BASE_LOG_CT),
-                    (double)decomp_digit_l1_hi((uint32_t)(x1 >> 32), BASE_LOG_CT)};
+        if constexpr (EXACT) {
+          d[r] = cplx{(double)decomp_digit_l1_hi((uint32_t)(x0 >> 32), BASE_LOG_CT),
+                      (double)decomp_digit_l1_hi((uint32_t)(x1 >> 32), BASE_LOG_CT)};
+        } else {
+          const int32_t d0 = decomp_digit_l1_fast((uint32_t)(x0 >> 32), BASE_LOG_CT);
+          const int32_t d1 = decomp_digit_l1_fast((uint32_t)(x1 >> 32), BASE_LOG_CT);
+          lowest = d0 < lowest ? d0 : lowest;
+          lowest = d1 < lowest ? d1 : lowest;
+          d[r] = cplx{(double)d0, (double)d1};
+        }
       } else {
         const int64_t d0 = decomp_digit(x0, base_log, level, idx);
         const int64_t d1 = decomp_digit(x1, base_log, level, idx);
@@ -588,6 +598,18 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
           d[r] = cplx{i64_to_f64(d0), i64_to_f64(d1)};
       }
       if ((r & 3) == 3) HX_SCHED_FENCE();
+    }
+    return lowest;
+  };
+  auto make_digits = [&](cplx (&d)[16], uint32_t a_hat, uint32_t idx) {
+    // the accumulator is already staged in buf64 (stage_acc at start, then by every
+    // wave_inverse_accumulate); later levels of one iteration re-stage, the transposes reused the buffer
+    if (!MULTIBIT && idx != 0) stage_acc();
+    if constexpr (LEVEL_CT == 1 && BASE_LOG_CT != 0 && BASE_LOG_CT <= 30) {
+      const int32_t lowest = make_digits_impl(d, a_hat, idx, std::false_type{});
+      if (lowest == -(1 << (BASE_LOG_CT - 1))) make_digits_impl(d, a_hat, idx, std::true_type{});
+    } else {
+      make_digits_impl(d, a_hat, idx, std::true_type{});
     }
     HX_WAVE_SYNC();
   };
