@@ -141,9 +141,8 @@ HX_DEV uint64_t from_torus(double t) {
   const double f = t - rint(t);
   const double hm = fma(f, 4294967296.0, MAGIC_H);
   const double h = hm - MAGIC_H;
-  const double F = f * 18446744073709551616.0;
-  const double l = fma(h, -4294967296.0, F);
-  const uint64_t lb = f64_bits(l + MAGIC);
+  const double fl = fma(h, -2.3283064365386963e-10, f);                  // f - h 2^-32, exact
+  const uint64_t lb = f64_bits(fma(fl, 18446744073709551616.0, MAGIC));  // rounds (f 2^64 - h 2^32) + MAGIC once
   const uint32_t hi = (uint32_t)f64_bits(hm) + (uint32_t)(lb >> 32);
   return ((uint64_t)hi << 32) | (uint64_t)(uint32_t)lb;
 }

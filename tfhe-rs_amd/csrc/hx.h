@@ -47,6 +47,20 @@
 
 #define HX_DEV __device__ __forceinline__
 
+// ---- per-lane select by a wave-uniform lane mask (bit l <-> lane l) that lives in a scalar register pair:
+// one v_cndmask, no vector compare
+#if defined(TFHE_HIPEMU)
+static inline uint32_t hx_select_by_lane_mask(uint64_t mask, uint32_t if_set, uint32_t if_clear) {
+  return ((mask >> (threadIdx.x & 63)) & 1) ? if_set : if_clear;
+}
+#else
+__device__ __forceinline__ uint32_t hx_select_by_lane_mask(uint64_t mask, uint32_t if_set, uint32_t if_clear) {
+  uint32_t r;
+  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(if_clear), "v"(if_set), "s"(mask));
+  return r;
+}
+#endif
+
 // ---- cross-lane swaps of gfx950: v_permlane32_swap exchanges the upper 32 lanes of `a` with the lower 32 lanes
 // of `b`; v_permlane16_swap exchanges the odd 16-lane rows of `a` with the even rows of `b`.  Applied to the
 // dwords of two registers they transpose (register select) x (lane bit 5, resp. bit 4).

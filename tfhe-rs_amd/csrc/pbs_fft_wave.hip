@@ -300,8 +300,10 @@ HX_DEV void inverse_pass1_group(cplx (&o)[16], int g) {
   }
 }
 
-// OVERWRITE (multi-bit: dst = 0 + src (x) GGSW): the result replaces the accumulator and is not staged
-template <bool PASS1_DONE, bool OVERWRITE = false>
+// OVERWRITE (multi-bit: dst = 0 + src (x) GGSW): the result replaces the accumulator and is not staged.
+// NEG: the registers hold MINUS the accumulator (see make_digits); from_torus is odd, so the negated
+// term is the conversion of the negated real, whose sign rides on the untwist multiplication for free.
+template <bool PASS1_DONE, bool OVERWRITE = false, bool NEG = false>
 HX_DEV void wave_inverse_accumulate(cplx (&o)[16], uint64_t (&acc_re)[16], uint64_t (&acc_im)[16], WaveCtx c) {
   uint64_t *stg = (uint64_t *)c.buf;
   HX_OPAQUE(c.lane);
@@ -414,8 +416,8 @@ HX_DEV void wave_inverse_accumulate(cplx (&o)[16], uint64_t (&acc_re)[16], uint6
       const cplx e = Tu_hi[-r * 64];
       u = (r == 8 && lane_u == 0) ? e : cplx{-e.im, -e.re};  // j = 512 is stored directly
     }
-    const double tr = fma(-o[r].im, u.im, o[r].re * u.re);
-    const double ti = fma(o[r].im, u.re, o[r].re * u.im);
+    const double tr = NEG ? fma(o[r].im, u.im, -o[r].re * u.re) : fma(-o[r].im, u.im, o[r].re * u.re);
+    const double ti = NEG ? fma(-o[r].im, u.re, -o[r].re * u.im) : fma(o[r].im, u.re, o[r].re * u.im);
     if constexpr (OVERWRITE) {
       acc_re[r] = from_torus(tr);
       acc_im[r] = from_torus(ti);
@@ -526,17 +528,20 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
   }
   const uint32_t b_hat = (uint32_t)modulus_switch(lwe[a.n] + corr, LOG2N2);
 
-  // ---- accumulator registers: coefficient (r*64 + lane) and (1024 + r*64 + lane)
+  // ---- accumulator registers: coefficient (r*64 + lane) and (1024 + r*64 + lane).
+  // The classic loop keeps MINUS the accumulator (NEGACC): the rotate-and-subtract of every iteration
+  // then needs no 64-bit subtraction or negation (make_digits), additions being one instruction
+  constexpr bool NEGACC = !MULTIBIT;
   uint64_t acc_re[16], acc_im[16];
   HX_UNROLL
   for (int r = 0; r < 16; ++r) {
     bool neg;
     uint32_t src = monomial_div_src(r * 64 + lane, b_hat, N, neg);
     uint64_t v = lut[src];
-    acc_re[r] = neg ? (uint64_t)0 - v : v;
+    acc_re[r] = (neg != NEGACC) ? (uint64_t)0 - v : v;
     src = monomial_div_src(1024 + r * 64 + lane, b_hat, N, neg);
     v = lut[src];
-    acc_im[r] = neg ? (uint64_t)0 - v : v;
+    acc_im[r] = (neg != NEGACC) ? (uint64_t)0 - v : v;
   }
 
   // ct1 = acc * X^a_hat - acc for my polynomial, decomposed at level index idx, as f64 points
@@ -560,22 +565,30 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
     constexpr bool EXACT = decltype(exact_tag)::value;
     int lane = ctx.lane;
     HX_OPAQUE(lane);
-    const uint32_t rr = a_hat & (N - 1);
-    const bool odd = (a_hat & N) != 0;
-    const uint32_t t0 = (uint32_t)lane - rr;  // (c - rr) for c = lane; wraps mod 2^32, masked below
+    // ct1[c] = sign * acc[(c - a_hat) mod N] - acc[c] with sign = -1 for c < rr (rr = a_hat mod N), all
+    // signs flipped when a_hat >= N.  The registers and the staged copy hold A = -acc, so with the staged
+    // word S = A[(c - rr) mod N] the value is  A[c] - S  (sign +)  or  A[c] + S  (sign -), and both are
+    //     ((A[c] ^ M) + S) ^ M ,   M = all-ones (sign +) or zero (sign -)
+    // since ~(~A + S) = A - S: one 64-bit addition and xors, no subtraction, negation, compare or select.
+    // u = 8 (c - rr) gives the byte offset (mod 16 KiB) and, by its sign bit, the negacyclic wrap.
+    const int32_t ub = ((int32_t)lane - (int32_t)(a_hat & (N - 1))) * 8;
+    uint32_t keep = (a_hat & N) ? 0u : ~0u;  // sign + when the source did not wrap (and a_hat < N)
+    HX_OPAQUE(keep);                         // a vector register: scalar operands double the cost of the xors
     int32_t lowest = 0;
     HX_UNROLL
     for (int r = 0; r < 16; ++r) {
-      const uint32_t c0 = r * 64 + lane, c1 = 1024 + r * 64 + lane;
       uint64_t x0, x1;
       if constexpr (MULTIBIT) {  // external product of the accumulator itself
         x0 = acc_re[r];
         x1 = acc_im[r];
       } else {
-        uint64_t s = buf64[(t0 + r * 64) & (N - 1)];
-        x0 = (((c0 < rr) != odd) ? (uint64_t)0 - s : s) - acc_re[r];
-        s = buf64[(t0 + 1024 + r * 64) & (N - 1)];
-        x1 = (((c1 < rr) != odd) ? (uint64_t)0 - s : s) - acc_im[r];
+        const int32_t u0 = ub + r * 512, u1 = u0 + 8192;
+        const uint32_t m0 = keep ^ (uint32_t)(u0 >> 31), m1 = keep ^ (uint32_t)(u1 >> 31);
+        const uint64_t M0 = ((uint64_t)m0 << 32) | m0, M1 = ((uint64_t)m1 << 32) | m1;
+        const uint64_t s0 = *(const uint64_t *)((const char *)buf64 + (u0 & 0x3ff8));
+        const uint64_t s1 = *(const uint64_t *)((const char *)buf64 + (u1 & 0x3ff8));
+        x0 = ((acc_re[r] ^ M0) + s0) ^ M0;
+        x1 = ((acc_im[r] ^ M1) + s1) ^ M1;
       }
       if constexpr (LEVEL_CT == 1 && BASE_LOG_CT != 0 && BASE_LOG_CT <= 30) {
         // one level: the digit is the decomposer's initial state and depends on the high dword only
@@ -790,7 +803,8 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
       // mask element i was requested one iteration ago (lwe has n + 1 words, so i + 1 is in range)
       const uint64_t mask_cur = mask_next;
       mask_next = lwe[i + 1];
-      const uint32_t a_hat = (uint32_t)modulus_switch(mask_cur, LOG2N2);
+      // the same word in every lane: as a scalar, the rotation's bounds and signs cost no vector work
+      const uint32_t a_hat = HX_UNIFORM((uint32_t)modulus_switch(mask_cur, LOG2N2));
       if (a_hat == 0) continue;  // uniform over the pair (bootstrap.rs:334)
       ++it;
       if constexpr (LEVEL_CT == 1) {
@@ -804,7 +818,7 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
         wave_forward(d, ctx);
         // in place: d becomes the Fourier-domain output of polynomial w, first inverse pass applied
         mac(d, d, ka0, ka1, kb0, kb1, b0, b1, 0, it, std::integral_constant<bool, WAVE_FUSE_PASS1 != 0>{});
-        wave_inverse_accumulate<WAVE_FUSE_PASS1 != 0>(d, acc_re, acc_im, ctx);
+        wave_inverse_accumulate<WAVE_FUSE_PASS1 != 0, false, NEGACC>(d, acc_re, acc_im, ctx);
       } else {
         cplx o[16];
         for (uint32_t idx = 0; idx < level; ++idx) {
@@ -816,7 +830,7 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
           wave_forward(d, ctx);
           mac(o, d, ka0, ka1, kb0, kb1, b0, b1, idx, (it - 1) * level + idx + 1, std::false_type{});
         }
-        wave_inverse_accumulate<false>(o, acc_re, acc_im, ctx);
+        wave_inverse_accumulate<false, false, NEGACC>(o, acc_re, acc_im, ctx);
       }
     }
   }
@@ -831,15 +845,15 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
       HX_UNROLL
       for (int r = 0; r < 16; ++r) {
         uint32_t c = r * 64 + lane;
-        out[c <= nth ? nth - c : N + nth - c] = c <= nth ? acc_re[r] : (uint64_t)0 - acc_re[r];
+        out[c <= nth ? nth - c : N + nth - c] = ((c <= nth) != NEGACC) ? acc_re[r] : (uint64_t)0 - acc_re[r];
         c += 1024;
-        out[c <= nth ? nth - c : N + nth - c] = c <= nth ? acc_im[r] : (uint64_t)0 - acc_im[r];
+        out[c <= nth ? nth - c : N + nth - c] = ((c <= nth) != NEGACC) ? acc_im[r] : (uint64_t)0 - acc_im[r];
       }
     } else {
       HX_UNROLL
       for (int r = 0; r < 16; ++r) {
-        if ((uint32_t)(r * 64 + lane) == nth) out[N] = acc_re[r];
-        if ((uint32_t)(1024 + r * 64 + lane) == nth) out[N] = acc_im[r];
+        if ((uint32_t)(r * 64 + lane) == nth) out[N] = NEGACC ? (uint64_t)0 - acc_re[r] : acc_re[r];
+        if ((uint32_t)(1024 + r * 64 + lane) == nth) out[N] = NEGACC ? (uint64_t)0 - acc_im[r] : acc_im[r];
       }
     }
   }
