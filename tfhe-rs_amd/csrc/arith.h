@@ -147,6 +147,33 @@ HX_DEV uint64_t from_torus(double t) {
   return ((uint64_t)hi << 32) | (uint64_t)(uint32_t)lb;
 }
 
+// The same conversion for a run of values that are ADDED to 64-bit accumulators: the five constants
+// live in vector registers (as literals each use costs a move into the fma's destination), and the high
+// part h * 2^32 only touches the accumulator's high dword, so it is a 32-bit add next to one 64-bit add.
+struct TorusConsts {
+  double two32, magic_h, minus_two_m32, two64, magic;
+};
+HX_DEV TorusConsts torus_consts() {
+  TorusConsts k{4294967296.0, 6755399441055744.0 + 3167223808.0, -2.3283064365386963e-10, 18446744073709551616.0,
+                6755399441055744.0};
+  HX_OPAQUE(k.two32);
+  HX_OPAQUE(k.magic_h);
+  HX_OPAQUE(k.minus_two_m32);
+  HX_OPAQUE(k.two64);
+  HX_OPAQUE(k.magic);
+  return k;
+}
+HX_DEV void from_torus_add(uint64_t &acc, double t, const TorusConsts &k) {
+  const double f = t - rint(t);
+  const double hm = fma(f, k.two32, k.magic_h);
+  const double h = hm - k.magic_h;
+  const double fl = fma(h, k.minus_two_m32, f);
+  const uint64_t s = acc + f64_bits(fma(fl, k.two64, k.magic));
+  uint32_t s_hi = (uint32_t)(s >> 32);
+  HX_LAUNDER(s_hi);  // or the two steps are merged back into a second 64-bit addition of (h << 32)
+  acc = ((uint64_t)(s_hi + (uint32_t)f64_bits(hm)) << 32) | (uint32_t)s;
+}
+
 struct alignas(16) cplx {
   double re, im;
 };

@@ -15,6 +15,7 @@
 #define HX_UNROLL _Pragma("GCC unroll 64")
 #define HX_SCHED_FENCE() do { } while (0)
 #define HX_OPAQUE(v) do { } while (0)
+#define HX_LAUNDER(v) do { } while (0)
 #define HX_UNIFORM(v) (v)
 #define HX_BLOCK_SYNC_LDS() __syncthreads()
 #else
@@ -37,6 +38,8 @@
 // makes the compiler forget what it knows about a VGPR value: address arithmetic derived from it
 // is recomputed where it is used instead of being hoisted out of the loop and kept (or spilled)
 #define HX_OPAQUE(v) asm volatile("" : "+v"(v))
+// same, but free to move: only hides the value's origin from the optimiser's pattern matching
+#define HX_LAUNDER(v) asm("" : "+v"(v))
 // wave-uniform value into an SGPR
 #define HX_UNIFORM(v) __builtin_amdgcn_readfirstlane(v)
 // workgroup barrier for data exchanged through LDS only: waits for this wave's LDS traffic, not for its

@@ -407,6 +407,7 @@ HX_DEV void wave_inverse_accumulate(cplx (&o)[16], uint64_t (&acc_re)[16], uint6
   HX_OPAQUE(lane_u);
   const cplx *Tu_lo = T + T_U + lane_u;         // u[r*64 + lane]           (r < 8)
   const cplx *Tu_hi = T + T_U + 1024 - lane_u;  // u[1024 - (r*64 + lane)]  (r >= 8), mirrored
+  const TorusConsts kt = torus_consts();
   HX_UNROLL
   for (int r = 0; r < 16; ++r) {
     cplx u;
@@ -422,8 +423,8 @@ HX_DEV void wave_inverse_accumulate(cplx (&o)[16], uint64_t (&acc_re)[16], uint6
       acc_re[r] = from_torus(tr);
       acc_im[r] = from_torus(ti);
     } else {
-      acc_re[r] += from_torus(tr);
-      acc_im[r] += from_torus(ti);
+      from_torus_add(acc_re[r], tr, kt);
+      from_torus_add(acc_im[r], ti, kt);
       // stage the updated coefficients (c = r*64 + lane, 1024 + c) for the next iteration's rotation;
       // the buffer is free (the M2 -> M1 reads above are complete) and these stores issue under the
       // conversion arithmetic instead of in front of the next rotation
