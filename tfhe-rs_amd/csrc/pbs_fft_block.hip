@@ -172,18 +172,20 @@ __global__ void __launch_bounds__(TPB) pbs_fft_block_kernel(PbsArgs a, FftTables
   }
   const uint32_t b_hat = (uint32_t)modulus_switch(lwe[a.n] + corr, LOG2N2);
 
-  // ---- accumulator registers: coefficients (r*256 + t) and (1024 + r*256 + t)
+  // ---- accumulator registers: coefficients (r*256 + t) and (1024 + r*256 + t), held NEGATED (as the
+  // throughput kernel does): the rotate-and-subtract is then xor / one 64-bit add / xor
   uint64_t acc_re[4], acc_im[4];
   HX_UNROLL
   for (int r = 0; r < 4; ++r) {
     bool neg;
     uint32_t src = monomial_div_src(r * 256 + t, b_hat, N, neg);
     uint64_t v = lut[src];
-    acc_re[r] = neg ? (uint64_t)0 - v : v;
+    acc_re[r] = neg ? v : (uint64_t)0 - v;
     src = monomial_div_src(1024 + r * 256 + t, b_hat, N, neg);
     v = lut[src];
-    acc_im[r] = neg ? (uint64_t)0 - v : v;
+    acc_im[r] = neg ? v : (uint64_t)0 - v;
   }
+  const TorusConsts kt = torus_consts();
   HX_UNROLL
   for (int r = 0; r < 4; ++r) {
     stage[r * 256 + t] = acc_re[r];
@@ -197,8 +199,10 @@ __global__ void __launch_bounds__(TPB) pbs_fft_block_kernel(PbsArgs a, FftTables
     mask_next = lwe[i + 1];
     const uint32_t a_hat = (uint32_t)modulus_switch(mask_cur, LOG2N2);
     if (a_hat == 0) continue;  // uniform over the workgroup (bootstrap.rs:334)
-    const uint32_t rr = a_hat & (N - 1);
-    const bool odd = (a_hat & N) != 0;
+    // with A = -acc in the registers and in `stage`, S = A[(c - rr) mod N]:  ct1[c] = ((A[c] ^ M) + S) ^ M,
+    // M = all-ones where the source is not negated (no wrap, a_hat < N; both flipped together), else zero
+    const int32_t ub = ((int32_t)t - (int32_t)(a_hat & (N - 1))) * 8;
+    const uint32_t keep = (a_hat & N) ? 0u : ~0u;
     cplx o[4];
     for (uint32_t idx = 0; idx < level; ++idx) {
       // key rows [i][idx][row][c = w] at the storage slots of my 4 positions (pos = 4t + r)
@@ -216,11 +220,13 @@ __global__ void __launch_bounds__(TPB) pbs_fft_block_kernel(PbsArgs a, FftTables
       uint64_t x0[4], x1[4];
       HX_UNROLL
       for (int r = 0; r < 4; ++r) {
-        const uint32_t c0 = r * 256 + t, c1 = 1024 + r * 256 + t;
-        uint64_t s = stage[(c0 - rr) & (N - 1)];
-        x0[r] = (((c0 < rr) != odd) ? (uint64_t)0 - s : s) - acc_re[r];
-        s = stage[(c1 - rr) & (N - 1)];
-        x1[r] = (((c1 < rr) != odd) ? (uint64_t)0 - s : s) - acc_im[r];
+        const int32_t u0 = ub + r * 2048, u1 = u0 + 8192;
+        const uint32_t m0 = keep ^ (uint32_t)(u0 >> 31), m1 = keep ^ (uint32_t)(u1 >> 31);
+        const uint64_t M0 = ((uint64_t)m0 << 32) | m0, M1 = ((uint64_t)m1 << 32) | m1;
+        const uint64_t s0 = *(const uint64_t *)((const char *)stage + (u0 & 0x3ff8));
+        const uint64_t s1 = *(const uint64_t *)((const char *)stage + (u1 & 0x3ff8));
+        x0[r] = ((acc_re[r] ^ M0) + s0) ^ M0;
+        x1[r] = ((acc_im[r] ^ M1) + s1) ^ M1;
       }
       if constexpr (LEVEL_CT == 1 && BASE_LOG_CT != 0 && BASE_LOG_CT <= 30) {
         // two-instruction rounding; it can differ from the decomposer only where it yields -B/2, and a
@@ -301,10 +307,11 @@ __global__ void __launch_bounds__(TPB) pbs_fft_block_kernel(PbsArgs a, FftTables
     // ---- untwist, back to the torus, accumulate, restage (fft/mod.rs:311-330); map pos = 256 r + t
     HX_UNROLL
     for (int r = 0; r < 4; ++r) {
-      const double tr = fma(-o[r].im, un[r].im, o[r].re * un[r].re);
-      const double ti = fma(o[r].im, un[r].re, o[r].re * un[r].im);
-      acc_re[r] += from_torus(tr);
-      acc_im[r] += from_torus(ti);
+      // minus the untwisted value: from_torus is odd, the sign rides on the multiplication
+      const double tr = fma(o[r].im, un[r].im, -o[r].re * un[r].re);
+      const double ti = fma(-o[r].im, un[r].re, -o[r].re * un[r].im);
+      from_torus_add(acc_re[r], tr, kt);
+      from_torus_add(acc_im[r], ti, kt);
     }
     // the rotated reads of this iteration are many barriers behind: restage for the next one
     HX_UNROLL
@@ -324,15 +331,15 @@ __global__ void __launch_bounds__(TPB) pbs_fft_block_kernel(PbsArgs a, FftTables
       HX_UNROLL
       for (int r = 0; r < 4; ++r) {
         uint32_t c = r * 256 + t;
-        out[c <= nth ? nth - c : N + nth - c] = c <= nth ? acc_re[r] : (uint64_t)0 - acc_re[r];
+        out[c <= nth ? nth - c : N + nth - c] = c <= nth ? (uint64_t)0 - acc_re[r] : acc_re[r];
         c += 1024;
-        out[c <= nth ? nth - c : N + nth - c] = c <= nth ? acc_im[r] : (uint64_t)0 - acc_im[r];
+        out[c <= nth ? nth - c : N + nth - c] = c <= nth ? (uint64_t)0 - acc_im[r] : acc_im[r];
       }
     } else {
       HX_UNROLL
       for (int r = 0; r < 4; ++r) {
-        if ((uint32_t)(r * 256 + t) == nth) out[N] = acc_re[r];
-        if ((uint32_t)(1024 + r * 256 + t) == nth) out[N] = acc_im[r];
+        if ((uint32_t)(r * 256 + t) == nth) out[N] = (uint64_t)0 - acc_re[r];
+        if ((uint32_t)(1024 + r * 256 + t) == nth) out[N] = (uint64_t)0 - acc_im[r];
       }
     }
   }
