@@ -134,6 +134,24 @@ void cuda_keyswitch_gemm_64_64_async(
     uint32_t lwe_dimension_out, uint32_t base_log, uint32_t level_count,
     uint32_t num_samples, bool uses_trivial_indexes);
 
+/* u64 input ciphertexts, u32 key and u32 output ciphertexts (the KS32 atomic pattern):
+ * backends/tfhe-cuda-backend/cuda/include/keyswitch/keyswitch.h:23-28,42-47; semantics
+ * tfhe/src/core_crypto/algorithms/lwe_keyswitch.rs:331-447 (body rounded to 32 bits, base_log*level <= 32);
+ * called from tfhe/src/core_crypto/gpu/ffi.rs:503-618 when the key scalar is u32. */
+void cuda_keyswitch_lwe_ciphertext_vector_64_32_async(
+    void *stream, uint32_t gpu_index, void *lwe_array_out,
+    void const *lwe_output_indexes, void const *lwe_array_in,
+    void const *lwe_input_indexes, void const *ksk, uint32_t lwe_dimension_in,
+    uint32_t lwe_dimension_out, uint32_t base_log, uint32_t level_count,
+    uint32_t num_samples);
+
+void cuda_keyswitch_gemm_64_32_async(
+    void *stream, uint32_t gpu_index, void *lwe_array_out,
+    void const *lwe_output_indexes, void const *lwe_array_in,
+    void const *lwe_input_indexes, void const *ksk, uint32_t lwe_dimension_in,
+    uint32_t lwe_dimension_out, uint32_t base_log, uint32_t level_count,
+    uint32_t num_samples, bool uses_trivial_indexes);
+
 void cuda_closest_representable_64_async(void *stream, uint32_t gpu_index,
                                          void const *input, void *output,
                                          uint32_t base_log, uint32_t level_count);

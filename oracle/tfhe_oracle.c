@@ -194,6 +194,25 @@ void orc_keyswitch(uint64_t *lwe_out, const uint64_t *lwe_in, const uint64_t *ks
   }
 }
 
+/* cc/algorithms/lwe_keyswitch.rs:331-447 (keyswitch_lwe_ciphertext_with_scalar_change, u64 -> u32: the
+ * "KS32" atomic pattern, shortint/atomic_pattern/ks32.rs): the body is the input body rounded to the
+ * output width (closest representable on 32 bits, one level, then shifted down), the mask digits come
+ * from the u64 decomposer and multiply a u32 key, everything accumulates mod 2^32. */
+void orc_keyswitch_64_32(uint32_t *lwe_out, const uint64_t *lwe_in, const uint32_t *ksk,
+                         uint32_t n_in, uint32_t n_out, uint32_t base_log, uint32_t level) {
+  memset(lwe_out, 0, sizeof(uint32_t) * (n_out + 1));
+  lwe_out[n_out] = (uint32_t)(orc_closest_representable(lwe_in[n_in], 32, 1) >> 32);
+  int64_t digits[64];
+  for (uint32_t i = 0; i < n_in; ++i) {
+    orc_decompose(lwe_in[i], base_log, level, digits);
+    for (uint32_t lv = 0; lv < level; ++lv) {
+      const uint32_t *row = ksk + ((size_t)i * level + lv) * (n_out + 1);
+      uint32_t d = (uint32_t)(uint64_t)digits[lv];
+      for (uint32_t j = 0; j <= n_out; ++j) lwe_out[j] -= row[j] * d;
+    }
+  }
+}
+
 /* cc/algorithms/lwe_programmable_bootstrapping/mod.rs:26-79 */
 void orc_generate_lut(uint64_t *glwe_out, uint32_t k, uint32_t N, uint32_t message_modulus,
                       uint64_t delta, const uint64_t *f_table) {

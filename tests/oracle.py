@@ -140,6 +140,15 @@ def keyswitch(lwe_in, ksk, n_in, n_out, base_log, level):
     return out
 
 
+def keyswitch_64_32(lwe_in, ksk32, n_in, n_out, base_log, level):
+    """u64 ciphertext, u32 key -> u32 ciphertext (KS32)."""
+    lwe_in = np.ascontiguousarray(lwe_in, dtype=np.uint64)
+    ksk32 = np.ascontiguousarray(ksk32, dtype=np.uint32)
+    out = np.zeros(n_out + 1, dtype=np.uint32)
+    lib().orc_keyswitch_64_32(_p(out), _p(lwe_in), _p(ksk32), u32(n_in), u32(n_out), u32(base_log), u32(level))
+    return out
+
+
 def keyswitch_batch(lwe_in, ksk, n_in, n_out, base_log, level, threads=0):
     lwe_in = _u64(lwe_in).reshape(-1, n_in + 1)
     out = np.zeros((lwe_in.shape[0], n_out + 1), dtype=np.uint64)

@@ -506,3 +506,54 @@ def test_concurrent_host_threads_on_their_own_streams():
     for t in range(4):
         assert np.array_equal(got[t], want[t]), f"thread {t} differs from the sequential run"
         assert [decrypt_big(p, keys, o) for o in got[t][:8]] == [f(m) for m in msgs[t][:8]]
+
+
+# ------------------------------------------------------------------ KS32: u64 ciphertexts, u32 key and output
+def _ks32_key(p, keys, seed):
+    """KSK over Z_{2^32}: row (i, level) encrypts s_big[i] * 2^(32 - base_log * level) under the small key
+    (cc/algorithms/lwe_keyswitch_key_generation.rs:165-195 with a u32 scalar), level l first."""
+    rng = np.random.default_rng(seed)
+    n_in, n_out, bl, lv = p.big_n, p.n, p.ks_base_log, p.ks_level
+    s_big = np.asarray(keys.glwe_sk, dtype=np.int64).reshape(-1)
+    s_small = np.asarray(keys.lwe_sk, dtype=np.int64)
+    a = rng.integers(0, 1 << 32, size=(n_in, lv, n_out), dtype=np.uint64)
+    e = rng.integers(-4, 5, size=(n_in, lv), dtype=np.int64)
+    ksk = np.zeros((n_in, lv, n_out + 1), dtype=np.uint64)
+    ksk[:, :, :n_out] = a
+    for idx in range(lv):
+        level = lv - idx   # memory index 0 holds level l
+        plain = (s_big.astype(np.uint64) << np.uint64(32 - bl * level))
+        body = (a[:, idx, :] * s_small.astype(np.uint64)).sum(axis=1) + plain + e[:, idx].astype(np.uint64)
+        ksk[:, idx, n_out] = body
+    return (ksk & np.uint64(0xFFFFFFFF)).astype(np.uint32).reshape(-1)
+
+
+@pytest.mark.parametrize("kind", BACKENDS)
+@pytest.mark.parametrize("gemm", [False, True])
+def test_keyswitch_64_32_bit_exact_and_decrypts(kind, gemm):
+    """gpu/algorithms/test/lwe_keyswitch.rs:314-505 (lwe_encrypt_ks_decrypt_ks32_common): encrypt under the big
+    u64 key, keyswitch with a u32 key, decrypt the u32 ciphertext with the small key."""
+    p = TOY_2048
+    c = ctx(kind, p, "fft64")
+    st = c.streams
+    ksk32 = _ks32_key(p, c.keys, 99)
+    msgs = [m % p.plaintext_modulus for m in range(19)]      # ragged against the 16-sample tile
+    cts = encrypt_big(p, c.keys, msgs, seed=41)
+    ref = np.stack([orc.keyswitch_64_32(ct, ksk32, p.big_n, p.n, p.ks_base_log, p.ks_level) for ct in cts])
+    d_ksk = gpu.CudaLweKeyswitchKey.from_lwe_keyswitch_key(ksk32, p.big_n, p.n, p.ks_base_log, p.ks_level, st)
+    assert d_ksk.scalar_bits == 32
+    d_in = gpu.CudaLweCiphertextList.from_lwe_ciphertext_list(cts, st)
+    d_out = gpu.CudaLweCiphertextList.new(p.n, len(msgs), st, dtype=np.uint32)
+    order = np.arange(len(msgs), dtype=np.uint64)[::-1].copy()    # non-trivial output indexes
+    idx_in = gpu.CudaVec.from_cpu_async(np.arange(len(msgs), dtype=np.uint64), st)
+    idx_out = gpu.CudaVec.from_cpu_async(order, st)
+    gpu.cuda_keyswitch_lwe_ciphertext(d_ksk, d_in, d_out, idx_in, idx_out, False, st, use_gemm_ks=gemm)
+    got = d_out.to_lwe_ciphertext_list(st)
+    assert got.dtype == np.uint32
+    assert np.array_equal(got[order.astype(np.int64)], ref)
+    # decrypt over Z_{2^32}: phase = b - <a, s>, message in the top bits
+    s_small = np.asarray(c.keys.lwe_sk, dtype=np.uint64)
+    bits = int(np.log2(p.plaintext_modulus)) + 1          # padding bit + message
+    for m, ct in zip(msgs, ref):
+        phase = (int(ct[-1]) - int((ct[:-1].astype(np.uint64) * s_small).sum())) % (1 << 32)
+        assert ((phase + (1 << (31 - bits))) >> (32 - bits)) % p.plaintext_modulus == m

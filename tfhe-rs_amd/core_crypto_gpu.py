@@ -119,8 +119,9 @@ class CudaLweCiphertextList:
         self.lwe_dimension = int(lwe_dimension)
 
     @classmethod
-    def new(cls, lwe_dimension, lwe_ciphertext_count, streams):
-        return cls(CudaVec((lwe_dimension + 1) * lwe_ciphertext_count, streams), lwe_ciphertext_count,
+    def new(cls, lwe_dimension, lwe_ciphertext_count, streams, dtype=U64):
+        """dtype=np.uint32: the 32-bit ciphertexts a u32 keyswitch key produces (KS32 pattern)."""
+        return cls(CudaVec((lwe_dimension + 1) * lwe_ciphertext_count, streams, dtype=dtype), lwe_ciphertext_count,
                    lwe_dimension)
 
     @classmethod
@@ -229,7 +230,11 @@ class CudaLweKeyswitchKey:
         self.output_key_lwe_dimension = int(output_key_lwe_dimension)
         self.decomp_base_log = int(decomp_base_log)
         self.decomp_level_count = int(decomp_level_count)
-        h_ksk = np.ascontiguousarray(h_ksk, dtype=U64)
+        # a uint32 array is a KS32 key (gpu/ffi.rs:503-618 dispatches on the key scalar), anything else u64
+        h_ksk = np.ascontiguousarray(h_ksk)
+        if h_ksk.dtype != np.uint32:
+            h_ksk = h_ksk.astype(U64, copy=False)
+        self.scalar_bits = 8 * h_ksk.dtype.itemsize
         assert h_ksk.size == input_key_lwe_dimension * decomp_level_count * (output_key_lwe_dimension + 1)
         self.d_vecs = [CudaVec.from_cpu_async(h_ksk, streams, i) for i in range(len(streams))]
         self.d_vec = self.d_vecs[0]
@@ -304,7 +309,13 @@ def cuda_keyswitch_lwe_ciphertext(ksk, input, output, input_indexes, output_inde
     args = (s, g, output.d_vec.ptr, output_indexes.ptr, input.d_vec.ptr, input_indexes.ptr, ksk.d_vec.ptr,
             ksk.input_key_lwe_dimension, ksk.output_key_lwe_dimension, ksk.decomp_base_log,
             ksk.decomp_level_count, input.lwe_ciphertext_count)
-    if use_gemm_ks:
+    if ksk.scalar_bits == 32:
+        assert output.d_vec.dtype == np.uint32, "a u32 keyswitch key writes u32 ciphertexts"
+        if use_gemm_ks:
+            lib.cuda_keyswitch_gemm_64_32_async(*args, bool(uses_trivial_indices))
+        else:
+            lib.cuda_keyswitch_lwe_ciphertext_vector_64_32_async(*args)
+    elif use_gemm_ks:
         lib.cuda_keyswitch_gemm_64_64_async(*args, bool(uses_trivial_indices))
     else:
         lib.cuda_keyswitch_lwe_ciphertext_vector_64_64_async(*args)

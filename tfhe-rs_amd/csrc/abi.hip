@@ -455,6 +455,27 @@ void cuda_keyswitch_gemm_64_64_async(void *stream, uint32_t gpu_index, void *lwe
                                                    lwe_array_in, lwe_input_indexes, ksk, lwe_dimension_in,
                                                    lwe_dimension_out, base_log, level_count, num_samples);
 }
+void cuda_keyswitch_lwe_ciphertext_vector_64_32_async(void *stream, uint32_t gpu_index, void *lwe_array_out,
+                                                      void const *lwe_output_indexes, void const *lwe_array_in,
+                                                      void const *lwe_input_indexes, void const *ksk,
+                                                      uint32_t lwe_dimension_in, uint32_t lwe_dimension_out,
+                                                      uint32_t base_log, uint32_t level_count,
+                                                      uint32_t num_samples) {
+  set_device(gpu_index);
+  launch_keyswitch_64_32(S(stream), (uint32_t *)lwe_array_out, (const uint64_t *)lwe_output_indexes,
+                         (const uint64_t *)lwe_array_in, (const uint64_t *)lwe_input_indexes, (const uint32_t *)ksk,
+                         lwe_dimension_in, lwe_dimension_out, base_log, level_count, num_samples);
+}
+void cuda_keyswitch_gemm_64_32_async(void *stream, uint32_t gpu_index, void *lwe_array_out,
+                                     void const *lwe_output_indexes, void const *lwe_array_in,
+                                     void const *lwe_input_indexes, void const *ksk, uint32_t lwe_dimension_in,
+                                     uint32_t lwe_dimension_out, uint32_t base_log, uint32_t level_count,
+                                     uint32_t num_samples, bool uses_trivial_indexes) {
+  (void)uses_trivial_indexes;  // as for 64_64: one tiled kernel, indexes honoured either way
+  cuda_keyswitch_lwe_ciphertext_vector_64_32_async(stream, gpu_index, lwe_array_out, lwe_output_indexes,
+                                                   lwe_array_in, lwe_input_indexes, ksk, lwe_dimension_in,
+                                                   lwe_dimension_out, base_log, level_count, num_samples);
+}
 void cuda_closest_representable_64_async(void *stream, uint32_t gpu_index, void const *input, void *output,
                                          uint32_t base_log, uint32_t level_count) {
   set_device(gpu_index);

@@ -26,6 +26,9 @@ void launch_pbs_fft_block(hipStream_t st, const PbsArgs &a, const FftTables &tb,
 void launch_keyswitch(hipStream_t st, uint64_t *lwe_out, const uint64_t *out_idx, const uint64_t *lwe_in,
                       const uint64_t *in_idx, const uint64_t *ksk, uint32_t n_in, uint32_t n_out,
                       uint32_t base_log, uint32_t level, uint32_t num_samples);
+void launch_keyswitch_64_32(hipStream_t st, uint32_t *lwe_out, const uint64_t *out_idx, const uint64_t *lwe_in,
+                            const uint64_t *in_idx, const uint32_t *ksk, uint32_t n_in, uint32_t n_out,
+                            uint32_t base_log, uint32_t level, uint32_t num_samples);
 
 extern bool g_keyswitch_use_mfma;
 extern bool g_ntt_kernel_serial;

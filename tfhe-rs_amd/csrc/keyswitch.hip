@@ -147,6 +147,68 @@ __global__ void __launch_bounds__(KS_TPB) keyswitch_small_base_kernel(uint64_t *
   }
 }
 
+// u64 input, u32 key and output ("KS32", cc/algorithms/lwe_keyswitch.rs:331-447; replaces
+// cuda_keyswitch_lwe_ciphertext_vector_64_32_async / cuda_keyswitch_gemm_64_32_async,
+// backends/tfhe-cuda-backend/cuda/include/keyswitch/keyswitch.h:23-47).  Same tiling as keyswitch_kernel;
+// the arithmetic is mod 2^32 (one full-rate v_mul_lo_u32 and a subtraction per term), the body is the
+// input body rounded to 32 bits.
+__global__ void __launch_bounds__(KS_TPB) keyswitch_64_32_kernel(uint32_t *lwe_out, const uint64_t *out_idx,
+                                                                 const uint64_t *lwe_in, const uint64_t *in_idx,
+                                                                 const uint32_t *ksk, uint32_t n_in, uint32_t n_out,
+                                                                 uint32_t base_log, uint32_t level,
+                                                                 uint32_t num_samples) {
+  HX_DYN_SMEM(smem);
+  uint32_t *dig = (uint32_t *)smem;  // [KS_IC][level][KS_TB], digits mod 2^32
+  const int tid = threadIdx.x;
+  const uint32_t col = blockIdx.x * KS_TPB + tid;
+  const uint32_t s0 = blockIdx.y * KS_TB;
+  const uint32_t ns = (num_samples - s0 < (uint32_t)KS_TB) ? num_samples - s0 : KS_TB;
+  const bool active = col <= n_out;
+
+  uint32_t accv[KS_TB];
+  HX_UNROLL
+  for (int s = 0; s < KS_TB; ++s) accv[s] = 0;
+
+  for (uint32_t i0 = 0; i0 < n_in; i0 += KS_IC) {
+    const uint32_t ic = (n_in - i0 < (uint32_t)KS_IC) ? n_in - i0 : KS_IC;
+    for (uint32_t w = tid; w < (uint32_t)(KS_IC * KS_TB); w += KS_TPB) {
+      const uint32_t ii = w / KS_TB, s = w - ii * KS_TB;
+      uint64_t st = 0;
+      const bool valid = ii < ic && s < ns;
+      if (valid) {
+        const uint64_t x = lwe_in[(size_t)in_idx[s0 + s] * (n_in + 1) + i0 + ii];
+        st = decomp_init_state(x, base_log, level);
+      }
+      for (uint32_t lv = 0; lv < level; ++lv) {
+        const int64_t d = valid ? decompose_one_level(base_log, st) : 0;
+        dig[(ii * level + lv) * KS_TB + s] = (uint32_t)(uint64_t)d;
+      }
+    }
+    __syncthreads();
+    if (active) {
+      for (uint32_t ii = 0; ii < ic; ++ii)
+        for (uint32_t lv = 0; lv < level; ++lv) {
+          const uint32_t w = ksk[((size_t)(i0 + ii) * level + lv) * (n_out + 1) + col];
+          const uint32_t *d = dig + (ii * level + lv) * KS_TB;
+          HX_UNROLL
+          for (int s = 0; s < KS_TB; ++s) accv[s] -= w * d[s];
+        }
+    }
+    __syncthreads();
+  }
+  if (active) {
+    for (uint32_t s = 0; s < ns; ++s) {
+      uint32_t v = accv[s];
+      if (col == n_out) {
+        const uint64_t b = lwe_in[(size_t)in_idx[s0 + s] * (n_in + 1) + n_in];
+        // closest representable on 32 bits, one level (decomposer.rs:25-50), shifted down to the output width
+        v += (uint32_t)(((b >> 31) + 1) >> 1);
+      }
+      lwe_out[(size_t)out_idx[s0 + s] * (n_out + 1) + col] = v;
+    }
+  }
+}
+
 // ------------------------------------------------------------------ keyswitch on the int8 matrix cores
 // The keyswitch is a GEMM: out[s][col] = -sum_k digit[s][k] * KSK[k][col], k = (mask element, level).  With
 // shifted digits d' = d + B/2 in [0, B] (an i8) and the key split in its 8 byte planes, re-centred to
@@ -357,6 +419,19 @@ void launch_keyswitch(hipStream_t st, uint64_t *lwe_out, const uint64_t *out_idx
     HX_LAUNCH((keyswitch_kernel<int64_t>), grid, dim3(KS_TPB), smem, st, lwe_out, out_idx, lwe_in, in_idx, ksk, n_in,
               n_out, base_log, level, num_samples);
   }
+}
+
+void launch_keyswitch_64_32(hipStream_t st, uint32_t *lwe_out, const uint64_t *out_idx, const uint64_t *lwe_in,
+                            const uint64_t *in_idx, const uint32_t *ksk, uint32_t n_in, uint32_t n_out,
+                            uint32_t base_log, uint32_t level, uint32_t num_samples) {
+  // lwe_keyswitch.rs:353-359: the decomposition must fit the OUTPUT width
+  HX_PANIC_IF_FALSE(base_log >= 1 && level >= 1 && level <= KS_MAXL && base_log * level <= 32,
+                    "keyswitch 64->32: unsupported decomposition (base_log=%u, level=%u)", base_log, level);
+  if (num_samples == 0) return;
+  const dim3 grid((n_out + 1 + KS_TPB - 1) / KS_TPB, (num_samples + KS_TB - 1) / KS_TB);
+  const size_t smem = sizeof(uint32_t) * KS_IC * level * KS_TB;
+  HX_LAUNCH(keyswitch_64_32_kernel, grid, dim3(KS_TPB), smem, st, lwe_out, out_idx, lwe_in, in_idx, ksk, n_in, n_out,
+            base_log, level, num_samples);
 }
 
 }  // namespace tfhe_hip

@@ -76,6 +76,9 @@ SIGNATURES = {
     "cuda_keyswitch_lwe_ciphertext_vector_64_64_async":
         (None, [_v, _u32, _v, _v, _v, _v, _v, _u32, _u32, _u32, _u32, _u32]),
     "cuda_keyswitch_gemm_64_64_async": (None, [_v, _u32, _v, _v, _v, _v, _v, _u32, _u32, _u32, _u32, _u32, _b]),
+    "cuda_keyswitch_lwe_ciphertext_vector_64_32_async":
+        (None, [_v, _u32, _v, _v, _v, _v, _v, _u32, _u32, _u32, _u32, _u32]),
+    "cuda_keyswitch_gemm_64_32_async": (None, [_v, _u32, _v, _v, _v, _v, _v, _u32, _u32, _u32, _u32, _u32, _b]),
     "cuda_closest_representable_64_async": (None, [_v, _u32, _v, _v, _u32, _u32]),
     # ciphertext helpers
     "cuda_convert_lwe_ciphertext_vector_to_gpu_64_async": (None, [_v, _u32, _v, _v, _u32, _u32]),
