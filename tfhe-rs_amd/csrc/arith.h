@@ -204,17 +204,41 @@ HX_HD uint64_t gl_add(uint64_t a, uint64_t b) {
   return a >= neg_b ? a - neg_b : a + b;
 }
 HX_HD uint64_t gl_sub(uint64_t a, uint64_t b) { return a >= b ? a - b : a + (GL_P - b); }
+// Carry-based forms for the transform loops.  "Lazy" values are any u64 congruent to the field element
+// (2^64 = EPS mod p lets a wrapped carry be folded back in); gl_canon brings one to [0, p).
+static constexpr uint64_t GL_EPS = 0xFFFFFFFFull;  // 2^64 mod p = 2^32 - 1
+HX_HD uint64_t gl_canon(uint64_t r) {  // r >= p  <=>  r + EPS wraps, and the wrapped sum is r - p
+  uint64_t t;
+  return __builtin_add_overflow(r, GL_EPS, &t) ? t : r;
+}
+// x lazy, c canonical -> lazy (c < p: the folded-in carry cannot wrap a second time)
+HX_HD uint64_t gl_add_lazy(uint64_t x, uint64_t c) {
+  uint64_t s;
+  const bool carry = __builtin_add_overflow(x, c, &s);
+  return s + (carry ? GL_EPS : 0);
+}
+HX_HD uint64_t gl_sub_lazy(uint64_t x, uint64_t c) {
+  uint64_t d;
+  const bool borrow = __builtin_sub_overflow(x, c, &d);
+  return d - (borrow ? GL_EPS : 0);
+}
+// a, b lazy -> canonical product.  Schoolbook 32x32 partial products chained through 64-bit
+// multiply-adds (one v_mad_u64_u32 each), then  lo + hl 2^64 + hh 2^96 = lo + hl EPS - hh  (mod p),
+// same value as tfhe-ntt/src/prime64/generic_solinas.rs:100-129.
 HX_HD uint64_t gl_mul(uint64_t a, uint64_t b) {
-  const uint64_t lo = a * b;
-  uint64_t hi = mulhi64(a, b);
-  const uint64_t mid = hi & 0xFFFFFFFFull;
-  hi >>= 32;
-  uint64_t low2 = lo - hi;
-  if (hi > lo) low2 += GL_P;
-  const uint64_t product = (mid << 32) - mid;
-  uint64_t result = low2 + product;
-  if (result < product || result >= GL_P) result -= GL_P;
-  return result;
+  const uint32_t a0 = (uint32_t)a, a1 = (uint32_t)(a >> 32), b0 = (uint32_t)b, b1 = (uint32_t)(b >> 32);
+  const uint64_t t0 = (uint64_t)a0 * b0;
+  const uint64_t t1 = (uint64_t)a0 * b1 + (t0 >> 32);
+  const uint64_t t2 = (uint64_t)a1 * b0 + (uint32_t)t1;
+  const uint64_t hi = (uint64_t)a1 * b1 + (t1 >> 32) + (t2 >> 32);
+  const uint64_t lo = (t2 << 32) | (uint32_t)t0;
+  const uint32_t hl = (uint32_t)hi, hh = (uint32_t)(hi >> 32);
+  uint64_t u, v;
+  const bool carry = __builtin_add_overflow((uint64_t)hl * GL_EPS, lo, &u);
+  const bool borrow = __builtin_sub_overflow(u, (uint64_t)hh, &v);
+  uint64_t r = v + (carry ? GL_EPS : 0);  // carry: u < 2^64 - 2^33, so this cannot wrap
+  r = r - (borrow ? GL_EPS : 0);          // borrow: v > 2^64 - 2^32, so this cannot wrap
+  return gl_canon(r);
 }
 // cc/commons/math/ntt/ntt64.rs:144-160, width 64:  (x*p + 2^63) >> 64
 HX_HD uint64_t gl_modswitch_from_pow2(uint64_t x) {

@@ -92,30 +92,53 @@ HX_DEV void lds_fft_inverse(cplx *buf, const double *__restrict__ inv, int tid) 
     __syncthreads();
   }
 }
-// Goldilocks negacyclic NTT, Cooley–Tukey / Gentleman–Sande (tfhe-ntt generic_solinas.rs:449-514)
+// Goldilocks negacyclic NTT, Cooley–Tukey / Gentleman–Sande (tfhe-ntt generic_solinas.rs:449-514).
+// Stage loops are unrolled (strides and table offsets become immediates).  Forward: values stay lazy
+// between stages (every addition has the canonical product as its second operand) and are made
+// canonical once at the end; inverse: sums are made canonical, differences go lazily into the product.
 template <int N, int TPB>
 HX_DEV void lds_ntt_forward(uint64_t *buf, const uint64_t *__restrict__ tw, int tid) {
-  for (int t = N / 2, m = 1; m < N; t >>= 1, m <<= 1) {
-    for (int b = tid; b < N / 2; b += TPB) {
-      const int g = b / t, j = b - g * t;
-      const int p0 = 2 * g * t + j, p1 = p0 + t;
-      const uint64_t zw = gl_mul(buf[p1], tw[m + g]);
-      const uint64_t a = buf[p0];
-      buf[p0] = gl_add(a, zw);
-      buf[p1] = gl_sub(a, zw);
+  constexpr int LOGN = ilog2_c(N), PER2 = (N / 2 + TPB - 1) / TPB;
+  HX_UNROLL
+  for (int s = 0; s < LOGN; ++s) {
+    HX_OPAQUE(tid);  // addresses are recomputed per stage instead of being kept (or spilled) across the caller's loop
+    const int t = N >> (s + 1), m = 1 << s, lt = LOGN - 1 - s;
+    HX_UNROLL
+    for (int q = 0; q < PER2; ++q) {
+      const int b = tid + q * TPB;
+      if (N / 2 % TPB == 0 || b < N / 2) {
+        const int g = b >> lt, j = b & (t - 1);
+        const int p0 = 2 * g * t + j, p1 = p0 + t;
+        const uint64_t zw = gl_mul(buf[p1], tw[m + g]);
+        const uint64_t a = buf[p0];
+        buf[p0] = gl_add_lazy(a, zw);
+        buf[p1] = gl_sub_lazy(a, zw);
+      }
+      if (q & 1) HX_SCHED_FENCE();  // two butterflies in flight: bounds the registers the unrolled body may take
     }
     __syncthreads();
   }
+  for (int j = tid; j < N; j += TPB) buf[j] = gl_canon(buf[j]);
+  __syncthreads();
 }
 template <int N, int TPB>
 HX_DEV void lds_ntt_inverse(uint64_t *buf, const uint64_t *__restrict__ itw, int tid) {
-  for (int t = 1, m = N / 2; m >= 1; t <<= 1, m >>= 1) {
-    for (int b = tid; b < N / 2; b += TPB) {
-      const int g = b / t, j = b - g * t;
-      const int p0 = 2 * g * t + j, p1 = p0 + t;
-      const uint64_t a = buf[p0], c = buf[p1];
-      buf[p0] = gl_add(a, c);
-      buf[p1] = gl_mul(gl_sub(a, c), itw[m + g]);
+  constexpr int LOGN = ilog2_c(N), PER2 = (N / 2 + TPB - 1) / TPB;
+  HX_UNROLL
+  for (int s = 0; s < LOGN; ++s) {
+    HX_OPAQUE(tid);
+    const int t = 1 << s, m = N >> (s + 1);
+    HX_UNROLL
+    for (int q = 0; q < PER2; ++q) {
+      const int b = tid + q * TPB;
+      if (N / 2 % TPB == 0 || b < N / 2) {
+        const int g = b >> s, j = b & (t - 1);
+        const int p0 = 2 * g * t + j, p1 = p0 + t;
+        const uint64_t a = buf[p0], c = buf[p1];
+        buf[p0] = gl_canon(gl_add_lazy(a, c));
+        buf[p1] = gl_mul(gl_sub_lazy(a, c), itw[m + g]);
+      }
+      if (q & 1) HX_SCHED_FENCE();
     }
     __syncthreads();
   }

@@ -278,7 +278,7 @@ __global__ void __launch_bounds__(GenericCfg<N>::TPB) pbs_ntt_generic_kernel(Pbs
         for (int c = 0; c < K1; ++c)
           for (int q = 0; q < PER; ++q) {
             const int pos = tid + q * TPB;
-            nacc[c][q] = gl_add(nacc[c][q], gl_mul(brow[(size_t)c * N + pos], nbuf[pos]));
+            nacc[c][q] = gl_add_lazy(nacc[c][q], gl_mul(brow[(size_t)c * N + pos], nbuf[pos]));
           }
         __syncthreads();
       }
@@ -360,7 +360,7 @@ __global__ void __launch_bounds__(K1 *GenericCfg<N>::TPB) pbs_ntt_par_kernel(Pbs
         const uint64_t *f = nbuf + (size_t)row * N;
         for (int q = 0; q < PER; ++q) {
           const int pos = lt + q * TPB;
-          nacc[q] = gl_add(nacc[q], gl_mul(brow[pos], f[pos]));
+          nacc[q] = gl_add_lazy(nacc[q], gl_mul(brow[pos], f[pos]));
         }
       }
       __syncthreads();

@@ -41,6 +41,18 @@ constexpr int REPS = 4096;
 #define I_LSHL64(i) "v_lshlrev_b64 %" #i ", 3, %" #i "\n"
 PROBE64(k_lshladd64, I_LSHLADD64, "memory")
 PROBE64(k_lshl64, I_LSHL64, "memory")
+__global__ void k_madu64(uint64_t *out, uint32_t b, uint32_t c) {
+  uint64_t a[8];
+  for (int i = 0; i < 8; ++i) a[i] = threadIdx.x + i;
+#define I_MADU64(i) "v_mad_u64_u32 %" #i ", vcc, %8, %9, %" #i "\n"
+  for (int r = 0; r < REPS; ++r)
+    asm volatile(R4(BODY8(I_MADU64))
+                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
+                 : "v"(b), "v"(c) : "vcc");
+  uint64_t s = 0;
+  for (int i = 0; i < 8; ++i) s += a[i];
+  if (s == 12345678u) out[0] = s;
+}
 
 #define I_BITOP3(i) "v_bitop3_b32 %" #i ", %" #i ", %8, %9 bitop3:0x96\n"
 #define I_MULLO(i) "v_mul_lo_u32 %" #i ", %" #i ", %8\n"
@@ -151,7 +163,7 @@ int main() {
 #define RUN64(K) rep(#K, time_ms([&] { hipLaunchKernelGGL(K, grid, block, 0, 0, dout, (uint64_t)3, (uint64_t)5); }))
 #define RUN32(K) rep(#K, time_ms([&] { hipLaunchKernelGGL(K, grid, block, 0, 0, dout, 3u, 5u); }))
 #define RUNF(K) rep(#K, time_ms([&] { hipLaunchKernelGGL(K, grid, block, 0, 0, dout, 1.0000001, 1e-9); }))
-    RUN64(k_lshladd64); RUN64(k_lshl64);
+    RUN64(k_lshladd64); RUN64(k_lshl64); RUN32(k_madu64);
     printf("(next two: 8 pairs per group of 32 slots -> divide by the pair count yourself: value*32/8... reported per 1/32 of a trip with 8 pairs + nops)\n");
     RUN32(k_subpair); RUN32(k_addpair_s);
     RUN32(k_bitop3); RUN32(k_mullo); RUN32(k_mulhi); RUN32(k_min); RUN32(k_min3); RUN32(k_ashr); RUN32(k_cnds);
