@@ -638,6 +638,18 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
   auto key_request = [&](cplx (&k0)[4], cplx (&k1)[4], const cplx *b0, const cplx *b1, int ch) {
     HX_UNROLL
     for (int j = 0; j < 4; ++j) {
+#if !defined(TFHE_HIPEMU)
+      if constexpr (MULTIBIT) {
+        // the parked keybundle is read back exactly once: a streaming load keeps it from displacing the
+        // shared key of the group in L2 (measured: 22.3 k -> 24.2 k PBS/s)
+        typedef double v2d __attribute__((ext_vector_type(2)));
+        const v2d x0 = __builtin_nontemporal_load((const v2d *)&b0[(ch * 4 + j) * 64]);
+        const v2d x1 = __builtin_nontemporal_load((const v2d *)&b1[(ch * 4 + j) * 64]);
+        k0[j] = cplx{x0.x, x0.y};
+        k1[j] = cplx{x1.x, x1.y};
+        continue;
+      }
+#endif
       k0[j] = b0[(ch * 4 + j) * 64];
       k1[j] = b1[(ch * 4 + j) * 64];
     }
