@@ -672,10 +672,14 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
     if (early < 2) key_request(kb0, kb1, b0, b1, 1);
     HX_SCHED_FENCE();
     flag_wait(f_ready_ot, epoch);
-    const cplx *q3 = obuf + base_m3(ctx);
+    const cplx *row0 = (w == 0 ? buf : obuf) + base_m3(ctx);
+    const cplx *row1 = (w == 0 ? obuf : buf) + base_m3(ctx);
     // the key pointers must not be known before the wait, or the later requests are hoisted above it
     HX_OPAQUE(b0);
     HX_OPAQUE(b1);
+    // Both rows are read from LDS — row 0 from the buffer of the wave that holds polynomial 0, row 1 from
+    // the other one — so the roles are a scalar pointer choice: no per-point test of w, no selects, and
+    // the registers of my own transform are free during the products.
     HX_UNROLL
     for (int ch = 0; ch < 4; ++ch) {
       cplx(&k0)[4] = (ch & 1) ? kb0 : ka0;
@@ -683,15 +687,9 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
       HX_UNROLL
       for (int j = 0; j < 4; ++j) {
         const int r = ch * 4 + j;
-        const cplx x = q3[r];  // partner's point at the same position
-        cplx t;
-        if (w == 0) {          // I hold row 0, the partner row 1
-          t = (idx == 0) ? cmul_first(d[r], k0[j]) : cmul_add(d[r], k0[j], dst[r]);
-          dst[r] = cmul_add(x, k1[j], t);
-        } else {
-          t = (idx == 0) ? cmul_first(x, k0[j]) : cmul_add(x, k0[j], dst[r]);
-          dst[r] = cmul_add(d[r], k1[j], t);
-        }
+        const cplx x0 = row0[r], x1 = row1[r];
+        const cplx t = (idx == 0) ? cmul_first(x0, k0[j]) : cmul_add(x0, k0[j], dst[r]);
+        dst[r] = cmul_add(x1, k1[j], t);
         // pin the product here: otherwise the FMAs are sunk below the flag wait that follows and
         // the key loads stay live across it
         HX_OPAQUE(dst[r].re);
