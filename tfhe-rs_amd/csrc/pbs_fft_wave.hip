@@ -59,11 +59,16 @@ constexpr int BUF_BYTES = BUF_SLOTS * 16;
 // compact LDS twiddle table (entries of 16 bytes), shared by the 8 waves
 constexpr int T_F1 = 0;      // forward d = 0..3, even groups: fwd[1], fwd[2], fwd[4], fwd[6], fwd[8..14 step 2]
 constexpr int T_F2 = 8;      // forward d = 4..7: 16 + 16 + 32 + 64
-constexpr int T_F3 = 136;    // forward d = 8, 9, even groups: 128 + 256
+constexpr int T_F3 = 136;    // forward d = 8, 9, even groups: 128 + 256, each stored [j][lane]
 constexpr int T_INV = 520;   // E[J] = inv[512 + J], J < 256; every inverse twiddle is E[j*512/half] or -i*E[.]
 constexpr int T_U = 776;     // untwist, j <= 512 (mirrored above): 513 entries
 constexpr int T_F6 = 1289;   // forward d = 6, all 64 groups: fwd[64 + x]
-constexpr int T_TOTAL = 1353;
+// contiguous copies of the strided E[] reads with the worst bank conflicts (one entry per distinct lane value)
+constexpr int T_E8 = 1353;   // E[4 x], x < 64    (inverse half = 128)
+constexpr int T_W7 = 1417;   // E[8 x], x < 32    (inverse half = 64)
+constexpr int T_E32 = 1449;  // E[16 x], x < 16   (inverse half = 32)
+constexpr int T_W16 = 1465;  // E[32 x], x < 8    (inverse half = 16)
+constexpr int T_TOTAL = 1473;
 constexpr int FLAGS_BYTES = 64;
 constexpr size_t SMEM_BYTES = (size_t)WAVES * BUF_BYTES + (size_t)T_TOTAL * 16 + FLAGS_BYTES;
 
@@ -203,11 +208,11 @@ HX_DEV void wave_forward(cplx (&d)[16], WaveCtx c) {
     const cplx e7 = T[T_F2 + 64 + lane];
     stage<2>(d, [&](int r) { return (r >> 3) ? times_i(e7) : e7; });
     HX_SCHED_FENCE();
-    const cplx e8[2] = {T[T_F3 + lane * 2], T[T_F3 + lane * 2 + 1]};
+    const cplx e8[2] = {T[T_F3 + lane], T[T_F3 + 64 + lane]};
     stage<1>(d, [&](int r) { return ((r >> 2) & 1) ? times_i(e8[r >> 3]) : e8[r >> 3]; });
     HX_SCHED_FENCE();
-    const cplx e9[4] = {T[T_F3 + 128 + lane * 4], T[T_F3 + 128 + lane * 4 + 1], T[T_F3 + 128 + lane * 4 + 2],
-                        T[T_F3 + 128 + lane * 4 + 3]};
+    const cplx e9[4] = {T[T_F3 + 128 + lane], T[T_F3 + 192 + lane], T[T_F3 + 256 + lane],
+                        T[T_F3 + 320 + lane]};
     stage_store<0>(d, [&](int r) { return ((r >> 1) & 1) ? times_i(e9[r >> 2]) : e9[r >> 2]; },
                    [&](int r) { p3[r] = d[r]; });
   }
@@ -260,14 +265,14 @@ HX_DEV void wave_forward(cplx (&d)[16], WaveCtx c) {
   // pass F3: stages 8, 9 over position bits 1, 0; the result also goes to my buffer (mapping M3) for
   // the partner wave
   {
-    const cplx e8[2] = {T[T_F3 + lane * 2], T[T_F3 + lane * 2 + 1]};
+    const cplx e8[2] = {T[T_F3 + lane], T[T_F3 + 64 + lane]};
     cplx *p3 = c.buf + base_m3(c);  // transpose M2 -> M3, load side
     load_pairs<1>([&](int r) { d[r] = p3[r]; });
     HX_WAVE_SYNC();
     stage<1>(d, [&](int r) { return ((r >> 2) & 1) ? times_i(e8[r >> 3]) : e8[r >> 3]; });
     HX_SCHED_FENCE();
-    const cplx e9[4] = {T[T_F3 + 128 + lane * 4], T[T_F3 + 128 + lane * 4 + 1], T[T_F3 + 128 + lane * 4 + 2],
-                        T[T_F3 + 128 + lane * 4 + 3]};
+    const cplx e9[4] = {T[T_F3 + 128 + lane], T[T_F3 + 192 + lane], T[T_F3 + 256 + lane],
+                        T[T_F3 + 320 + lane]};
     stage_store<0>(d, [&](int r) { return ((r >> 1) & 1) ? times_i(e9[r >> 2]) : e9[r >> 2]; },
                    [&](int r) { p3[r] = d[r]; });
   }
@@ -337,8 +342,8 @@ HX_DEV void wave_inverse_accumulate(cplx (&o)[16], uint64_t (&acc_re)[16], uint6
     int ln = c.lane;
     HX_OPAQUE(ln);
     const int l15 = ln & 15;
-    cplx w16 = T[T_INV + (l15 & 7) * 32];
-    const cplx e32 = T[T_INV + l15 * 16];
+    cplx w16 = T[T_W16 + (l15 & 7)];
+    const cplx e32 = T[T_E32 + l15];
     const cplx *px = c.buf + base_mx(c);  // transposition M3 -> MX, load side
     load_pairs<2>([&](int r) { o[r] = px[mx_off(r)]; });
     HX_WAVE_SYNC();
@@ -384,7 +389,7 @@ HX_DEV void wave_inverse_accumulate(cplx (&o)[16], uint64_t (&acc_re)[16], uint6
   {
     int lane = c.lane;
     HX_OPAQUE(lane);
-    cplx w7 = T[T_INV + (lane & 31) * 8];
+    cplx w7 = T[T_W7 + (lane & 31)];
 #if !WAVE_PERMLANE_PASS
     const cplx *p1 = c.buf + base_m1(c);  // transpose M2 -> M1, load side
     load_pairs<0>([&](int r) { o[r] = p1[68 * r]; });
@@ -392,7 +397,7 @@ HX_DEV void wave_inverse_accumulate(cplx (&o)[16], uint64_t (&acc_re)[16], uint6
 #endif
     if (lane & 32) w7 = times_mi(w7);
     stage<0>(o, [&](int) { return w7; });
-    const cplx e8 = T[T_INV + lane * 4];
+    const cplx e8 = T[T_E8 + lane];
     stage<1>(o, [&](int r) { return (r & 1) ? times_mi(e8) : e8; });
     HX_SCHED_FENCE();
     const cplx e9[2] = {T[T_INV + lane * 2], T[T_INV + (64 + lane) * 2]};
@@ -481,13 +486,24 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
         else v = ldg_c(tb.fwd, 128 + 2 * (x - 64));
       } else if (e < T_INV) {     // forward d = 8, 9, even groups only
         const int x = e - T_F3;
-        v = (x < 128) ? ldg_c(tb.fwd, 256 + 2 * x) : ldg_c(tb.fwd, 512 + 2 * (x - 128));
+        // stored [j][lane] so that a wave's read of one j is contiguous (the natural [lane][j] order is a
+        // 2-way / 4-way bank conflict)
+        if (x < 128) v = ldg_c(tb.fwd, 256 + 2 * ((x & 63) * 2 + (x >> 6)));
+        else v = ldg_c(tb.fwd, 512 + 2 * (((x - 128) & 63) * 4 + ((x - 128) >> 6)));
       } else if (e < T_U) {       // E[J] = inv[512 + J], J < 256
         v = ldg_c(tb.inv, 512 + (e - T_INV));
       } else if (e < T_F6) {
         v = ldg_c(tb.untw, e - T_U);
-      } else {
+      } else if (e < T_E8) {
         v = ldg_c(tb.fwd, 64 + (e - T_F6));
+      } else if (e < T_W7) {
+        v = ldg_c(tb.inv, 512 + 4 * (e - T_E8));
+      } else if (e < T_E32) {
+        v = ldg_c(tb.inv, 512 + 8 * (e - T_W7));
+      } else if (e < T_W16) {
+        v = ldg_c(tb.inv, 512 + 16 * (e - T_E32));
+      } else {
+        v = ldg_c(tb.inv, 512 + 32 * (e - T_W16));
       }
       Tw[e] = v;
     }
