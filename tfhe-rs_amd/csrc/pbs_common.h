@@ -47,16 +47,38 @@ HX_DEV int bsk_slot(int pos) {
 }
 
 // ---------------------------------------------------------------- LDS transforms (generic)
-// forward: DESIGN.md §4 merged-twist tree, in place over buf[0..n)
+// forward: DESIGN.md §4 merged-twist tree, in place over buf[0..n).  Two radix-2 stages per barrier: a
+// thread takes the 4 points {P, P + m/4, P + m/2, P + 3m/4} of a group through stage m and stage m/2 (the
+// same butterflies with the same twiddles as the stage-per-barrier form, hence the same bits); an odd
+// stage count ends with one radix-2 stage.
 template <int N, int TPB>
 HX_DEV void lds_fft_forward(cplx *buf, const double *__restrict__ fwd, int tid) {
   constexpr int n = N / 2;
-  for (int m = n, cnt = 1; m >= 2; m >>= 1, cnt <<= 1) {
-    const int half = m >> 1;
+  int m = n, cnt = 1;
+  for (; m >= 4; m >>= 2, cnt <<= 2) {
+    const int quarter = m >> 2;
+    for (int u = tid; u < n / 4; u += TPB) {
+      const int g = u / quarter, j = u - g * quarter;
+      const int p0 = g * m + j, p1 = p0 + quarter, p2 = p1 + quarter, p3 = p2 + quarter;
+      const cplx wa{fwd[2 * (cnt + g)], fwd[2 * (cnt + g) + 1]};
+      const cplx wb0{fwd[2 * (2 * cnt + 2 * g)], fwd[2 * (2 * cnt + 2 * g) + 1]};
+      const cplx wb1{fwd[2 * (2 * cnt + 2 * g + 1)], fwd[2 * (2 * cnt + 2 * g + 1) + 1]};
+      cplx x0 = buf[p0], x1 = buf[p1], x2 = buf[p2], x3 = buf[p3];
+      bfly(x0, x2, wa);
+      bfly(x1, x3, wa);
+      bfly(x0, x1, wb0);
+      bfly(x2, x3, wb1);
+      buf[p0] = x0;
+      buf[p1] = x1;
+      buf[p2] = x2;
+      buf[p3] = x3;
+    }
+    __syncthreads();
+  }
+  if (m == 2) {  // odd number of stages: the last one alone
     for (int b = tid; b < n / 2; b += TPB) {
-      const int g = b / half, j = b - g * half;
-      const int p0 = g * m + j, p1 = p0 + half;
-      const cplx s{fwd[2 * (cnt + g)], fwd[2 * (cnt + g) + 1]};
+      const int p0 = 2 * b, p1 = p0 + 1;
+      const cplx s{fwd[2 * (cnt + b)], fwd[2 * (cnt + b) + 1]};
       cplx x = buf[p0], y = buf[p1];
       bfly(x, y, s);
       buf[p0] = x;
@@ -65,29 +87,48 @@ HX_DEV void lds_fft_forward(cplx *buf, const double *__restrict__ fwd, int tid) 
     __syncthreads();
   }
 }
-// backward (unnormalised DIT over the tree order), stages m=2,4 plain, m>=8 fma butterfly
+// one radix-2 stage of the backward transform on (x, y) = (position j of its group, j + half):
+// stages half = 1, 2 have trivial twiddles (1, -i) and use plain additions
+HX_DEV void inv_bfly(cplx &x, cplx &y, int half, int j, const double *__restrict__ inv) {
+  if (half == 1 || (half == 2 && j == 0)) {
+    const cplx o1{x.re + y.re, x.im + y.im}, o2{x.re - y.re, x.im - y.im};
+    x = o1;
+    y = o2;
+  } else if (half == 2) {  // w = -i
+    const cplx o1{x.re + y.im, x.im - y.re}, o2{x.re - y.im, x.im + y.re};
+    x = o1;
+    y = o2;
+  } else {
+    bfly(x, y, cplx{inv[2 * (half + j)], inv[2 * (half + j) + 1]});
+  }
+}
+// backward (unnormalised DIT over the tree order), two stages (half, 2 half) per barrier
 template <int N, int TPB>
 HX_DEV void lds_fft_inverse(cplx *buf, const double *__restrict__ inv, int tid) {
   constexpr int n = N / 2;
-  for (int half = 1; half < n; half <<= 1) {
-    const int m = half << 1;
+  int half = 1;
+  for (; 4 * half <= n; half <<= 2) {
+    for (int u = tid; u < n / 4; u += TPB) {
+      const int q = u / half, j = u - q * half;
+      const int p0 = q * 4 * half + j, p1 = p0 + half, p2 = p1 + half, p3 = p2 + half;
+      cplx x0 = buf[p0], x1 = buf[p1], x2 = buf[p2], x3 = buf[p3];
+      inv_bfly(x0, x1, half, j, inv);
+      inv_bfly(x2, x3, half, j, inv);
+      inv_bfly(x0, x2, 2 * half, j, inv);
+      inv_bfly(x1, x3, 2 * half, j + half, inv);
+      buf[p0] = x0;
+      buf[p1] = x1;
+      buf[p2] = x2;
+      buf[p3] = x3;
+    }
+    __syncthreads();
+  }
+  if (2 * half <= n) {  // odd number of stages: the last one alone
     for (int b = tid; b < n / 2; b += TPB) {
-      const int q = b / half, j = b - q * half;
-      const int p0 = q * m + j, p1 = p0 + half;
-      cplx x = buf[p0], y = buf[p1];
-      if (half == 1 || (half == 2 && j == 0)) {
-        const cplx o1{x.re + y.re, x.im + y.im}, o2{x.re - y.re, x.im - y.im};
-        x = o1;
-        y = o2;
-      } else if (half == 2) {  // w = -i
-        const cplx o1{x.re + y.im, x.im - y.re}, o2{x.re - y.im, x.im + y.re};
-        x = o1;
-        y = o2;
-      } else {
-        bfly(x, y, cplx{inv[2 * (half + j)], inv[2 * (half + j) + 1]});
-      }
-      buf[p0] = x;
-      buf[p1] = y;
+      cplx x = buf[b], y = buf[b + half];
+      inv_bfly(x, y, half, b, inv);
+      buf[b] = x;
+      buf[b + half] = y;
     }
     __syncthreads();
   }

@@ -414,8 +414,8 @@ __global__ void __launch_bounds__(GenericCfg<N>::TPB) bsk_to_ntt_kernel(const ui
 // ------------------------------------------------------------------------- launchers
 template <int N, int K1>
 static void launch_fft(hipStream_t st, const PbsArgs &a, const FftTables &tb) {
-  // one group per polynomial pays off for k = 1 (32.3k vs 29.8k PBS/s at 2_2); with three groups (k = 2, N = 1024)
-  // the larger workgroup costs more occupancy than the shorter barrier chain returns (38k vs 46k): single group
+  // one group per polynomial pays off for k = 1 (43.5k PBS/s at 2_2); with three groups (k = 2, N = 1024) the
+  // larger workgroup costs more occupancy than the shorter barrier chain returns (45.9k vs 59.0k): single group
   if (g_ntt_kernel_serial || K1 != 2) {
     const size_t smem = (size_t)(K1 + 1) * N * 8;
     HX_CHECK(hipFuncSetAttribute((const void *)pbs_fft_generic_kernel<N, K1>,
