@@ -137,25 +137,57 @@ HX_DEV void lds_fft_inverse(cplx *buf, const double *__restrict__ inv, int tid) 
 // Stage loops are unrolled (strides and table offsets become immediates).  Forward: values stay lazy
 // between stages (every addition has the canonical product as its second operand) and are made
 // canonical once at the end; inverse: sums are made canonical, differences go lazily into the product.
+HX_DEV void ntt_ct(uint64_t &x, uint64_t &y, uint64_t w) {  // Cooley–Tukey butterfly, lazy in, lazy out
+  const uint64_t zw = gl_mul(y, w);
+  const uint64_t a = x;
+  x = gl_add_lazy(a, zw);
+  y = gl_sub_lazy(a, zw);
+}
+HX_DEV void ntt_gs(uint64_t &x, uint64_t &y, uint64_t w) {  // Gentleman–Sande butterfly, canonical in and out
+  const uint64_t a = x, c = y;
+  x = gl_canon(gl_add_lazy(a, c));
+  y = gl_mul(gl_sub_lazy(a, c), w);
+}
 template <int N, int TPB>
 HX_DEV void lds_ntt_forward(uint64_t *buf, const uint64_t *__restrict__ tw, int tid) {
-  constexpr int LOGN = ilog2_c(N), PER2 = (N / 2 + TPB - 1) / TPB;
+  constexpr int LOGN = ilog2_c(N), UNITS = (N / 4 + TPB - 1) / TPB, PER2 = (N / 2 + TPB - 1) / TPB;
   HX_UNROLL
-  for (int s = 0; s < LOGN; ++s) {
-    HX_OPAQUE(tid);  // addresses are recomputed per stage instead of being kept (or spilled) across the caller's loop
-    const int t = N >> (s + 1), m = 1 << s, lt = LOGN - 1 - s;
+  for (int s = 0; s + 1 < LOGN; s += 2) {  // stages s and s + 1 on the 4 points of one thread
+    HX_OPAQUE(tid);  // addresses are recomputed per pass instead of being kept (or spilled) across the caller's loop
+    const int t = N >> (s + 1), t2 = t >> 1, m = 1 << s, lt2 = LOGN - 2 - s;
+    HX_UNROLL
+    for (int q = 0; q < UNITS; ++q) {
+      const int u = tid + q * TPB;
+      if (N / 4 % TPB == 0 || u < N / 4) {
+        const int g = u >> lt2, j = u & (t2 - 1);
+        const int p0 = 2 * g * t + j, p1 = p0 + t2, p2 = p0 + t, p3 = p2 + t2;
+        uint64_t x0 = buf[p0], x1 = buf[p1], x2 = buf[p2], x3 = buf[p3];
+        const uint64_t wa = tw[m + g], wb0 = tw[2 * m + 2 * g], wb1 = tw[2 * m + 2 * g + 1];
+        ntt_ct(x0, x2, wa);
+        ntt_ct(x1, x3, wa);
+        ntt_ct(x0, x1, wb0);
+        ntt_ct(x2, x3, wb1);
+        buf[p0] = x0;
+        buf[p1] = x1;
+        buf[p2] = x2;
+        buf[p3] = x3;
+      }
+      HX_SCHED_FENCE();  // one unit in flight: bounds the registers the unrolled body may take
+    }
+    __syncthreads();
+  }
+  if (LOGN & 1) {  // last stage alone: t = 1, group g = pair index
+    HX_OPAQUE(tid);
     HX_UNROLL
     for (int q = 0; q < PER2; ++q) {
       const int b = tid + q * TPB;
       if (N / 2 % TPB == 0 || b < N / 2) {
-        const int g = b >> lt, j = b & (t - 1);
-        const int p0 = 2 * g * t + j, p1 = p0 + t;
-        const uint64_t zw = gl_mul(buf[p1], tw[m + g]);
-        const uint64_t a = buf[p0];
-        buf[p0] = gl_add_lazy(a, zw);
-        buf[p1] = gl_sub_lazy(a, zw);
+        uint64_t x = buf[2 * b], y = buf[2 * b + 1];
+        ntt_ct(x, y, tw[N / 2 + b]);
+        buf[2 * b] = x;
+        buf[2 * b + 1] = y;
       }
-      if (q & 1) HX_SCHED_FENCE();  // two butterflies in flight: bounds the registers the unrolled body may take
+      if (q & 1) HX_SCHED_FENCE();
     }
     __syncthreads();
   }
@@ -164,20 +196,43 @@ HX_DEV void lds_ntt_forward(uint64_t *buf, const uint64_t *__restrict__ tw, int 
 }
 template <int N, int TPB>
 HX_DEV void lds_ntt_inverse(uint64_t *buf, const uint64_t *__restrict__ itw, int tid) {
-  constexpr int LOGN = ilog2_c(N), PER2 = (N / 2 + TPB - 1) / TPB;
+  constexpr int LOGN = ilog2_c(N), UNITS = (N / 4 + TPB - 1) / TPB, PER2 = (N / 2 + TPB - 1) / TPB;
   HX_UNROLL
-  for (int s = 0; s < LOGN; ++s) {
+  for (int s = 0; s + 1 < LOGN; s += 2) {
     HX_OPAQUE(tid);
     const int t = 1 << s, m = N >> (s + 1);
+    HX_UNROLL
+    for (int q = 0; q < UNITS; ++q) {
+      const int u = tid + q * TPB;
+      if (N / 4 % TPB == 0 || u < N / 4) {
+        const int G = u >> s, j = u & (t - 1);
+        const int p0 = 4 * G * t + j, p1 = p0 + t, p2 = p1 + t, p3 = p2 + t;
+        uint64_t x0 = buf[p0], x1 = buf[p1], x2 = buf[p2], x3 = buf[p3];
+        const uint64_t wa0 = itw[m + 2 * G], wa1 = itw[m + 2 * G + 1], wb = itw[(m >> 1) + G];
+        ntt_gs(x0, x1, wa0);
+        ntt_gs(x2, x3, wa1);
+        ntt_gs(x0, x2, wb);
+        ntt_gs(x1, x3, wb);
+        buf[p0] = x0;
+        buf[p1] = x1;
+        buf[p2] = x2;
+        buf[p3] = x3;
+      }
+      HX_SCHED_FENCE();
+    }
+    __syncthreads();
+  }
+  if (LOGN & 1) {  // last stage alone: t = N / 2, one group, twiddle itw[1]
+    HX_OPAQUE(tid);
+    const uint64_t w = itw[1];
     HX_UNROLL
     for (int q = 0; q < PER2; ++q) {
       const int b = tid + q * TPB;
       if (N / 2 % TPB == 0 || b < N / 2) {
-        const int g = b >> s, j = b & (t - 1);
-        const int p0 = 2 * g * t + j, p1 = p0 + t;
-        const uint64_t a = buf[p0], c = buf[p1];
-        buf[p0] = gl_canon(gl_add_lazy(a, c));
-        buf[p1] = gl_mul(gl_sub_lazy(a, c), itw[m + g]);
+        uint64_t x = buf[b], y = buf[b + N / 2];
+        ntt_gs(x, y, w);
+        buf[b] = x;
+        buf[b + N / 2] = y;
       }
       if (q & 1) HX_SCHED_FENCE();
     }
