@@ -22,8 +22,8 @@ __global__ void __launch_bounds__(GenericCfg<N>::TPB)
   constexpr int n = N / 2, TPB = GenericCfg<N>::TPB, PER = n / TPB, LOG2N2 = ilog2_c(2 * N);
   HX_DYN_SMEM(smem);
   uint64_t *acc = (uint64_t *)smem;                  // K1*N torus words (src, then dst)
-  cplx *fbuf = (cplx *)(smem + (size_t)K1 * N * 8);  // n complex points / N u64 of keybundle build
-  uint64_t *kbuf = (uint64_t *)fbuf;
+  const FBuf fbuf{(cplx *)(smem + (size_t)K1 * N * 8)};  // n complex points (padded) / N u64 of keybundle build
+  uint64_t *kbuf = (uint64_t *)fbuf.p;
   const int tid = threadIdx.x;
   const uint32_t sample = blockIdx.x;
   const uint64_t *lwe = a.lwe_in + (size_t)a.in_idx[sample] * (a.n + 1);
@@ -125,7 +125,7 @@ __global__ void __launch_bounds__(GenericCfg<N>::TPB)
 
 template <int N, int K1>
 static void launch_mb(hipStream_t st, const MultiBitArgs &m, const FftTables &tb) {
-  const size_t smem = (size_t)(K1 + 1) * N * 8;
+  const size_t smem = (size_t)K1 * N * 8 + fbuf_bytes(N);
   HX_CHECK(hipFuncSetAttribute((const void *)pbs_multi_bit_kernel<N, K1>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)smem));
   HX_LAUNCH((pbs_multi_bit_kernel<N, K1>), dim3(m.pbs.num_samples), dim3(GenericCfg<N>::TPB), smem, st, m.pbs,

@@ -47,12 +47,21 @@ HX_DEV int bsk_slot(int pos) {
 }
 
 // ---------------------------------------------------------------- LDS transforms (generic)
+// Transform buffer of n = N/2 complex points with one spare 16-byte slot after every 16: the late
+// (forward) / early (inverse) passes touch points 4 or 16 apart, which unpadded is a 4-way bank conflict
+// on every access (39 % of the LDS time of the N = 1024 kernel before the padding).
+struct FBuf {
+  cplx *p;
+  HX_DEV cplx &operator[](int q) const { return p[q + (q >> 4)]; }
+};
+constexpr size_t fbuf_slots(int N) { return (size_t)(N / 2 + N / 32); }
+constexpr size_t fbuf_bytes(int N) { return fbuf_slots(N) * 16; }
 // forward: DESIGN.md §4 merged-twist tree, in place over buf[0..n).  Two radix-2 stages per barrier: a
 // thread takes the 4 points {P, P + m/4, P + m/2, P + 3m/4} of a group through stage m and stage m/2 (the
 // same butterflies with the same twiddles as the stage-per-barrier form, hence the same bits); an odd
 // stage count ends with one radix-2 stage.
 template <int N, int TPB>
-HX_DEV void lds_fft_forward(cplx *buf, const double *__restrict__ fwd, int tid) {
+HX_DEV void lds_fft_forward(FBuf buf, const double *__restrict__ fwd, int tid) {
   constexpr int n = N / 2;
   int m = n, cnt = 1;
   for (; m >= 4; m >>= 2, cnt <<= 2) {
@@ -104,7 +113,7 @@ HX_DEV void inv_bfly(cplx &x, cplx &y, int half, int j, const double *__restrict
 }
 // backward (unnormalised DIT over the tree order), two stages (half, 2 half) per barrier
 template <int N, int TPB>
-HX_DEV void lds_fft_inverse(cplx *buf, const double *__restrict__ inv, int tid) {
+HX_DEV void lds_fft_inverse(FBuf buf, const double *__restrict__ inv, int tid) {
   constexpr int n = N / 2;
   int half = 1;
   for (; 4 * half <= n; half <<= 2) {

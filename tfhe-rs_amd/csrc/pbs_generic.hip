@@ -29,14 +29,14 @@ __global__ void __launch_bounds__(GenericCfg<N>::TPB) pbs_fft_generic_kernel(Pbs
   constexpr int n = N / 2, TPB = GenericCfg<N>::TPB, PER = n / TPB, LOG2N2 = ilog2_c(2 * N);
   HX_DYN_SMEM(smem);
   uint64_t *acc = (uint64_t *)smem;                  // K1*N torus words
-  cplx *fbuf = (cplx *)(smem + (size_t)K1 * N * 8);  // n complex points
+  const FBuf fbuf{(cplx *)(smem + (size_t)K1 * N * 8)};  // n complex points, padded
   const int tid = threadIdx.x;
   const uint32_t sample = blockIdx.x;
   const uint64_t *lwe = a.lwe_in + (size_t)a.in_idx[sample] * (a.n + 1);
   const uint64_t *lut = a.lut + (size_t)a.lut_idx[sample] * K1 * N;
   const cplx *bsk = (const cplx *)a.bsk;
 
-  const uint32_t b_hat = block_body_modulus_switch<TPB>(lwe, a.n, LOG2N2, a.ms_type, (uint64_t *)fbuf, tid);
+  const uint32_t b_hat = block_body_modulus_switch<TPB>(lwe, a.n, LOG2N2, a.ms_type, (uint64_t *)fbuf.p, tid);
   // acc <- LUT * X^{-b_hat}
   for (int p = 0; p < K1; ++p)
     for (uint32_t j = tid; j < (uint32_t)N; j += TPB) {
@@ -101,19 +101,19 @@ __global__ void __launch_bounds__(K1 *GenericCfg<N>::TPB) pbs_fft_par_kernel(Pbs
   constexpr int n = N / 2, TPB = GenericCfg<N>::TPB, TPBT = K1 * TPB, PER = n / TPB, LOG2N2 = ilog2_c(2 * N);
   HX_DYN_SMEM(smem);
   uint64_t *acc = (uint64_t *)smem;                  // K1*N torus words
-  cplx *fbuf = (cplx *)(smem + (size_t)K1 * N * 8);  // K1 transform buffers of n complex points
+  cplx *fbase = (cplx *)(smem + (size_t)K1 * N * 8);  // K1 padded transform buffers of n complex points
   const int tid = threadIdx.x;
   const int grp = tid / TPB, lt = tid - grp * TPB;   // my row (forward) / column (inverse), thread inside it
   const uint32_t sample = blockIdx.x;
   const uint64_t *lwe = a.lwe_in + (size_t)a.in_idx[sample] * (a.n + 1);
   const uint64_t *lut = a.lut + (size_t)a.lut_idx[sample] * K1 * N;
   const cplx *bsk = (const cplx *)a.bsk;
-  cplx *mybuf = fbuf + (size_t)grp * n;
+  const FBuf mybuf{fbase + (size_t)grp * fbuf_slots(N)};
 
   // body modulus switch; TPBT need not be a power of two (k = 2), so the reduction is a plain sum
   uint64_t corr = 0;
   if (a.ms_type == 1) {
-    uint64_t *scratch = (uint64_t *)fbuf;
+    uint64_t *scratch = (uint64_t *)fbase;
     uint64_t sh = 0;
     int64_t sd = 0;
     for (uint32_t i = tid; i < a.n; i += TPBT) {
@@ -158,7 +158,7 @@ __global__ void __launch_bounds__(K1 *GenericCfg<N>::TPB) pbs_fft_par_kernel(Pbs
       lds_fft_forward<N, TPB>(mybuf, tb.fwd, lt);
       for (int row = 0; row < K1; ++row) {  // column `grp` of the external product
         const cplx *brow = bsk + ((((size_t)i * a.level + idx) * K1 + row) * K1 + grp) * n;
-        const cplx *f = fbuf + (size_t)row * n;
+        const FBuf f{fbase + (size_t)row * fbuf_slots(N)};
         for (int q = 0; q < PER; ++q) {
           const int pos = lt + q * TPB;
           const cplx y = brow[bsk_slot<N, K1>(pos)];
@@ -386,7 +386,7 @@ __global__ void __launch_bounds__(GenericCfg<N>::TPB) bsk_to_fourier_kernel(cons
                                                                            bool wave_order) {
   constexpr int n = N / 2, TPB = GenericCfg<N>::TPB;
   HX_DYN_SMEM(smem);
-  cplx *fbuf = (cplx *)smem;
+  const FBuf fbuf{(cplx *)smem};
   const int tid = threadIdx.x;
   const uint64_t *p = src + (size_t)blockIdx.x * N;
   for (int j = tid; j < n; j += TPB)
@@ -417,13 +417,13 @@ static void launch_fft(hipStream_t st, const PbsArgs &a, const FftTables &tb) {
   // one group per polynomial pays off for k = 1 (43.5k PBS/s at 2_2); with three groups (k = 2, N = 1024) the
   // larger workgroup costs more occupancy than the shorter barrier chain returns (45.9k vs 59.0k): single group
   if (g_ntt_kernel_serial || K1 != 2) {
-    const size_t smem = (size_t)(K1 + 1) * N * 8;
+    const size_t smem = (size_t)K1 * N * 8 + fbuf_bytes(N);
     HX_CHECK(hipFuncSetAttribute((const void *)pbs_fft_generic_kernel<N, K1>,
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     HX_LAUNCH((pbs_fft_generic_kernel<N, K1>), dim3(a.num_samples), dim3(GenericCfg<N>::TPB), smem, st, a, tb);
     return;
   }
-  const size_t smem = (size_t)2 * K1 * N * 8;
+  const size_t smem = (size_t)K1 * N * 8 + (size_t)K1 * fbuf_bytes(N);
   HX_CHECK(hipFuncSetAttribute((const void *)pbs_fft_par_kernel<N, K1>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)smem));
   HX_LAUNCH((pbs_fft_par_kernel<N, K1>), dim3(a.num_samples), dim3(K1 * GenericCfg<N>::TPB), smem, st, a, tb);
@@ -476,7 +476,7 @@ void launch_pbs_ntt_generic(hipStream_t st, uint32_t N, uint32_t glwe_dim, const
 }
 
 template <int N> static void launch_conv_f(hipStream_t st, const uint64_t *src, void *dst, size_t polys, const FftTables &tb, bool wave_order) {
-  HX_LAUNCH((bsk_to_fourier_kernel<N>), dim3((unsigned)polys), dim3(GenericCfg<N>::TPB), (size_t)N * 8, st, src, (cplx *)dst, tb, wave_order);
+  HX_LAUNCH((bsk_to_fourier_kernel<N>), dim3((unsigned)polys), dim3(GenericCfg<N>::TPB), fbuf_bytes(N), st, src, (cplx *)dst, tb, wave_order);
 }
 template <int N> static void launch_conv_n(hipStream_t st, const uint64_t *src, void *dst, size_t polys, const NttTables &tb) {
   HX_LAUNCH((bsk_to_ntt_kernel<N>), dim3((unsigned)polys), dim3(GenericCfg<N>::TPB), (size_t)N * 8, st, src, (uint64_t *)dst, tb);

@@ -48,7 +48,7 @@ __global__ void __launch_bounds__(GenericCfg<N>::TPB) test_transform_kernel(uint
   HX_DYN_SMEM(smem);
   const int tid = threadIdx.x;
   if (op <= 2) {
-    cplx *fbuf = (cplx *)smem;
+    const FBuf fbuf{(cplx *)smem};
     if (op == 0) {
       const int64_t *d = (const int64_t *)in;
       for (int j = tid; j < n; j += TPB) fbuf[j] = cplx{i64_to_f64(d[j]), i64_to_f64(d[j + n])};
@@ -90,7 +90,7 @@ __global__ void __launch_bounds__(GenericCfg<N>::TPB) test_transform_kernel(uint
 
 template <int N>
 static void launch_tt(hipStream_t st, uint32_t op, const void *in, void *out, const FftTables &ft, const NttTables &nt) {
-  HX_LAUNCH((test_transform_kernel<N>), dim3(1), dim3(GenericCfg<N>::TPB), (size_t)N * 8, st, op, in, out, ft, nt);
+  HX_LAUNCH((test_transform_kernel<N>), dim3(1), dim3(GenericCfg<N>::TPB), fbuf_bytes(N), st, op, in, out, ft, nt);
 }
 
 void launch_test_transform(hipStream_t st, uint32_t op, uint32_t N, const void *in, void *out, uint32_t gpu_index) {

@@ -30,7 +30,7 @@ def rand_u64(n):
 
 
 def timed(fn, steps=3, warmup=1):
-    if "mb1" in sys.argv or "lat1" in sys.argv or "ntt1" in sys.argv:
+    if "mb1" in sys.argv or "lat1" in sys.argv or "ntt1" in sys.argv or "n1024x" in sys.argv:
         warmup = 0
     for _ in range(warmup):
         fn()
@@ -128,6 +128,8 @@ if __name__ == "__main__":
         pbs_case(C4, 4096, steps=2)
     if "lat1" in which:  # one launch of the latency kernel, no warm-up (PMC passes)
         pbs_case(C1, 256, kernel=3, steps=1)
+    if "n1024x" in which:  # one launch, no warm-up (PMC passes)
+        pbs_case(C1P, 1024, steps=1)
     if "ntt1" in which:  # one launch, no warm-up (PMC passes)
         pbs_case(C1, 1024, engine="ntt64", steps=1)
     if "mb1" in which:   # one launch, no warm-up (PMC passes)
