@@ -31,6 +31,30 @@
 #endif
 // 1: transforms as radix 16 -> (permlane swaps) -> radix 4 -> (one LDS transposition) -> radix 16;
 // 0: radix 16 -> LDS -> radix 16 -> LDS -> radix 4 (the first layout of this kernel).  Same bits.
+// Issue priority of a wave by phase of its CMUX iteration (s_setprio, 0..3).  The two waves that share a
+// SIMD belong to different LWEs; with equal priority they interleave instruction by instruction and tend
+// to reach their LDS round trips and pair waits together.  Raising the priority as the iteration advances
+// lets the wave that is further along run through (its partner wave is waiting for it), while the other
+// one fills the gaps: measured 102.6 k -> 117 k PBS/s; the order matters (digits < forward, inverse >= MAC),
+// see profiles/r01_setprio_variants.txt.
+#ifndef WAVE_PRIO_A
+#define WAVE_PRIO_A 0  // rotation + digits
+#define WAVE_PRIO_B 1  // forward transform
+#define WAVE_PRIO_C 2  // pair exchange + MAC
+#define WAVE_PRIO_D 3  // inverse transform, conversion, accumulation
+#endif
+#ifndef WAVE_PRIO_MB_A
+#define WAVE_PRIO_MB_K 0  // multi-bit: keybundle build (key streaming)
+#define WAVE_PRIO_MB_A 1
+#define WAVE_PRIO_MB_B 2
+#define WAVE_PRIO_MB_C 3
+#define WAVE_PRIO_MB_D 3
+#endif
+#if !defined(TFHE_HIPEMU)
+#define HX_PRIO(p) __builtin_amdgcn_s_setprio(p)
+#else
+#define HX_PRIO(p) do { } while (0)
+#endif
 #ifndef WAVE_PERMLANE_PASS
 #define WAVE_PERMLANE_PASS 1
 #endif
@@ -816,11 +840,16 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
         const cplx *b0, *b1;
         key_rows(0, idx, b0, b1);
         HX_SCHED_FENCE();
+        HX_PRIO(WAVE_PRIO_MB_A);
         make_digits(d, 0, idx);
+        HX_PRIO(WAVE_PRIO_MB_B);
         wave_forward(d, ctx);
+        HX_PRIO(WAVE_PRIO_MB_C);
         mac(o, d, ka0, ka1, kb0, kb1, b0, b1, idx, grp * level + idx + 1, std::false_type{});
       }
+      HX_PRIO(WAVE_PRIO_MB_D);
       wave_inverse_accumulate<false, true>(o, acc_re, acc_im, ctx);
+      HX_PRIO(WAVE_PRIO_MB_K);
     }
   } else {
     stage_acc();
@@ -841,10 +870,14 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
         if (WAVE_EARLY_CHUNKS >= 1) key_request(ka0, ka1, b0, b1, 0);
         if (WAVE_EARLY_CHUNKS >= 2) key_request(kb0, kb1, b0, b1, 1);
         HX_SCHED_FENCE();
+        HX_PRIO(WAVE_PRIO_A);
         make_digits(d, a_hat, 0);
+        HX_PRIO(WAVE_PRIO_B);
         wave_forward(d, ctx);
+        HX_PRIO(WAVE_PRIO_C);
         // in place: d becomes the Fourier-domain output of polynomial w, first inverse pass applied
         mac(d, d, ka0, ka1, kb0, kb1, b0, b1, 0, it, std::integral_constant<bool, WAVE_FUSE_PASS1 != 0>{});
+        HX_PRIO(WAVE_PRIO_D);
         wave_inverse_accumulate<WAVE_FUSE_PASS1 != 0, false, NEGACC>(d, acc_re, acc_im, ctx);
       } else {
         cplx o[16];
@@ -853,10 +886,14 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
           const cplx *b0, *b1;
           key_rows(i, idx, b0, b1);
           HX_SCHED_FENCE();
+          HX_PRIO(WAVE_PRIO_A);
           make_digits(d, a_hat, idx);
+          HX_PRIO(WAVE_PRIO_B);
           wave_forward(d, ctx);
+          HX_PRIO(WAVE_PRIO_C);
           mac(o, d, ka0, ka1, kb0, kb1, b0, b1, idx, (it - 1) * level + idx + 1, std::false_type{});
         }
+        HX_PRIO(WAVE_PRIO_D);
         wave_inverse_accumulate<false, false, NEGACC>(o, acc_re, acc_im, ctx);
       }
     }
