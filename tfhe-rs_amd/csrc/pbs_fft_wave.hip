@@ -39,8 +39,14 @@
 // see profiles/r01_setprio_variants.txt.
 #ifndef WAVE_PRIO_A
 #define WAVE_PRIO_A 0  // rotation + digits
+#endif
+#ifndef WAVE_PRIO_B
 #define WAVE_PRIO_B 1  // forward transform
+#endif
+#ifndef WAVE_PRIO_C
 #define WAVE_PRIO_C 2  // pair exchange + MAC
+#endif
+#ifndef WAVE_PRIO_D
 #define WAVE_PRIO_D 3  // inverse transform, conversion, accumulation
 #endif
 #ifndef WAVE_PRIO_MB_A
@@ -49,6 +55,21 @@
 #define WAVE_PRIO_MB_B 2
 #define WAVE_PRIO_MB_C 3
 #define WAVE_PRIO_MB_D 3
+#endif
+// optional finer steps inside the transforms (-1: keep the phase's level)
+#ifndef WAVE_PRIO_F3
+#define WAVE_PRIO_F3 -1
+#endif
+#ifndef WAVE_PRIO_I3
+#define WAVE_PRIO_I3 -1
+#endif
+#ifndef WAVE_PRIO_CONV
+#define WAVE_PRIO_CONV -1
+#endif
+#if !defined(TFHE_HIPEMU)
+#define HX_PRIO_OPT(p) do { if ((p) >= 0) __builtin_amdgcn_s_setprio((p) < 0 ? 0 : (p)); } while (0)
+#else
+#define HX_PRIO_OPT(p) do { } while (0)
 #endif
 #if !defined(TFHE_HIPEMU)
 #define HX_PRIO(p) __builtin_amdgcn_s_setprio(p)
@@ -223,6 +244,7 @@ HX_DEV void wave_forward(cplx (&d)[16], WaveCtx c) {
                    [&](int r) { px[mx_off(r)] = d[r]; });
   }
   HX_WAVE_SYNC();
+  HX_PRIO_OPT(WAVE_PRIO_F3);
   {  // stages 6..9 over position bits 3..0 (= r bits 3..0), group index = lane . (r bits)
     const cplx w6 = T[T_F6 + lane];
     cplx *p3 = c.buf + base_m3(c);  // transposition MX -> M3, load side
@@ -409,6 +431,7 @@ HX_DEV void wave_inverse_accumulate(cplx (&o)[16], uint64_t (&acc_re)[16], uint6
   }
   HX_WAVE_SYNC();
 #endif  // WAVE_PERMLANE_PASS (inverse, passes 1-2)
+  HX_PRIO_OPT(WAVE_PRIO_I3);
   // pass I3: stages half = 64..512 over position bits 6..9 (= r bits 0..3); j = (r bits).lane
   {
     int lane = c.lane;
@@ -431,6 +454,7 @@ HX_DEV void wave_inverse_accumulate(cplx (&o)[16], uint64_t (&acc_re)[16], uint6
     stage<3>(o, [&](int r) { return (r & 4) ? times_mi(e10[r & 3]) : e10[r & 3]; });
   }
   HX_SCHED_FENCE();
+  HX_PRIO_OPT(WAVE_PRIO_CONV);
   // untwist, back to the torus, accumulate (fft/mod.rs:311-330)
   int lane_u = c.lane;
   HX_OPAQUE(lane_u);
