@@ -44,7 +44,7 @@ void check_pow2_poly(uint32_t N) {
                     "polynomial_size %u not supported by the MI355X PBS (256..4096, power of two)", N);
 }
 
-constexpr uint32_t kLatencyKernelMaxBatch = 256;  // measured (tools/measure_all.py latency): 4.0 ms vs 7.1 ms up to 256 LWEs, slower beyond
+constexpr uint32_t kLatencyKernelMaxBatch = 256;  // measured (tools/measure_all.py latency): 3.7-3.9 ms vs 5.9 ms up to 256 LWEs, slower beyond
 
 PbsArgs make_args(void *lwe_array_out, void const *lwe_output_indexes, void const *lut_vector,
                   void const *lut_vector_indexes, void const *lwe_array_in, void const *lwe_input_indexes,
