@@ -82,6 +82,9 @@ ABORTS = {
         one = (C.c_void_p * 1)(v.ptr)
         lib.cuda_propagate_single_carry_64_inplace_async(s, C.byref(ct), None, None, mem, one, one, 0, 0)
         """, "created with allocate_gpu_memory=false"),
+    "symbol outside the hot path": ("""
+        lib.cdll.cuda_integer_div_rem_64_async()   # a link-compatibility stub (csrc/link_stubs.hip)
+        """, "cuda_integer_div_rem_64_async: not part of the MI355X PBS backend"),
     "radix layer on a multi-bit key": ("""
         s = ffi.CudaStreamsFFI((C.c_void_p * 1)(S), (C.c_uint32 * 1)(0), 1)
         mem = C.c_void_p()
