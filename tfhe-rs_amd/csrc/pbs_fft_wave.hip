@@ -76,6 +76,9 @@
 #else
 #define HX_PRIO(p) do { } while (0)
 #endif
+#ifndef WAVE_FLAG_SLEEP
+#define WAVE_FLAG_SLEEP 1  // s_sleep argument between two polls of a pair flag
+#endif
 #ifndef WAVE_PERMLANE_PASS
 #define WAVE_PERMLANE_PASS 1
 #endif
@@ -131,7 +134,7 @@ HX_DEV void flag_set(uint32_t *f, uint32_t v) {
   __hip_atomic_store(f, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 HX_DEV void flag_wait(uint32_t *f, uint32_t v) {
-  while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < v) __builtin_amdgcn_s_sleep(1);
+  while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < v) __builtin_amdgcn_s_sleep(WAVE_FLAG_SLEEP);
 }
 #endif
 
