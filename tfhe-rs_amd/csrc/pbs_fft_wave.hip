@@ -824,10 +824,9 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
             HX_UNROLL
             for (int r = 0; r < 16; ++r) x[r] = ps[(t0 + r * 64) & (N - 1)];
           };
-          uint64_t cur[16], nxt[16];  // (two halves ahead measured slower: register pressure)
-          half_request(cur, 0);
-          for (uint32_t hh = 0; hh < halves; ++hh) {
-            if (hh + 1 < halves) half_request(nxt, hh + 1);
+          // two buffers in alternation (halves is even), one request in flight while the other buffer is
+          // accumulated; two requests in flight measured far slower (the third buffer ends up in scratch)
+          auto half_consume = [&](uint64_t (&x)[16], uint32_t hh) {
             const uint32_t sidx = 1 + (hh >> 1);
             const uint32_t rr = deg[sidx] & (N - 1);
             const bool odd = (deg[sidx] & N) != 0;
@@ -835,17 +834,24 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
               HX_UNROLL
               for (int r = 0; r < 16; ++r) {
                 const uint32_t c1 = 1024 + r * 64 + ln;
-                v_im[r] += ((c1 < rr) != odd) ? (uint64_t)0 - cur[r] : cur[r];
+                v_im[r] += ((c1 < rr) != odd) ? (uint64_t)0 - x[r] : x[r];
               }
             } else {
               HX_UNROLL
               for (int r = 0; r < 16; ++r) {
                 const uint32_t c0 = r * 64 + ln;
-                v_re[r] += ((c0 < rr) != odd) ? (uint64_t)0 - cur[r] : cur[r];
+                v_re[r] += ((c0 < rr) != odd) ? (uint64_t)0 - x[r] : x[r];
               }
             }
-            HX_UNROLL
-            for (int r = 0; r < 16; ++r) cur[r] = nxt[r];
+          };
+          uint64_t ha[16], hb[16];
+          half_request(ha, 0);
+          for (uint32_t hh = 0; hh < halves; hh += 2) {
+            half_request(hb, hh + 1);
+            half_consume(ha, hh);
+            HX_SCHED_FENCE();
+            if (hh + 2 < halves) half_request(ha, hh + 2);
+            half_consume(hb, hh + 1);
             HX_SCHED_FENCE();
           }
           cplx d[16];
