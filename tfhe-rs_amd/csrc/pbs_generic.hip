@@ -23,6 +23,14 @@ HX_DEV uint64_t rot_sub(const uint64_t *poly, uint32_t j, uint32_t a_hat) {
   return (neg ? (uint64_t)0 - s : s) - poly[j];
 }
 
+// digit `idx` of x as an f64: one-level sets read it off the high dword, and every digit of a base below
+// 2^31 converts from 32 bits (one instruction instead of the 64-bit conversion sequence)
+HX_DEV double digit_f64(uint64_t x, uint32_t base_log, uint32_t level, uint32_t idx) {
+  if (level == 1 && base_log <= 30) return (double)decomp_digit_l1_hi((uint32_t)(x >> 32), base_log);
+  const int64_t d = decomp_digit(x, base_log, level, idx);
+  return base_log <= 31 ? (double)(int32_t)d : i64_to_f64(d);
+}
+
 // ------------------------------------------------------------------------- f64 engine
 template <int N, int K1>
 __global__ void __launch_bounds__(GenericCfg<N>::TPB) pbs_fft_generic_kernel(PbsArgs a, FftTables tb) {
@@ -57,6 +65,7 @@ __global__ void __launch_bounds__(GenericCfg<N>::TPB) pbs_fft_generic_kernel(Pbs
         // ct1 = acc*X^a_hat - acc, decomposed on the fly; fold N reals into n complex
         for (int q = 0; q < PER; ++q) {
           const uint32_t j = tid + q * TPB;
+          // (digit_f64 of the kernel below costs this one 50 registers and a workgroup per CU: measured slower)
           const int64_t d0 = decomp_digit(rot_sub<N>(acc + row * N, j, a_hat), a.base_log, a.level, idx);
           const int64_t d1 = decomp_digit(rot_sub<N>(acc + row * N, j + n, a_hat), a.base_log, a.level, idx);
           fbuf[j] = cplx{i64_to_f64(d0), i64_to_f64(d1)};
@@ -150,9 +159,8 @@ __global__ void __launch_bounds__(K1 *GenericCfg<N>::TPB) pbs_fft_par_kernel(Pbs
     for (uint32_t idx = 0; idx < a.level; ++idx) {
       for (int q = 0; q < PER; ++q) {  // digits of my row
         const uint32_t j = lt + q * TPB;
-        const int64_t d0 = decomp_digit(rot_sub<N>(acc + grp * N, j, a_hat), a.base_log, a.level, idx);
-        const int64_t d1 = decomp_digit(rot_sub<N>(acc + grp * N, j + n, a_hat), a.base_log, a.level, idx);
-        mybuf[j] = cplx{i64_to_f64(d0), i64_to_f64(d1)};
+        mybuf[j] = cplx{digit_f64(rot_sub<N>(acc + grp * N, j, a_hat), a.base_log, a.level, idx),
+                        digit_f64(rot_sub<N>(acc + grp * N, j + n, a_hat), a.base_log, a.level, idx)};
       }
       __syncthreads();
       lds_fft_forward<N, TPB>(mybuf, tb.fwd, lt);
