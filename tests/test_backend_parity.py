@@ -557,3 +557,50 @@ def test_keyswitch_64_32_bit_exact_and_decrypts(kind, gemm):
     for m, ct in zip(msgs, ref):
         phase = (int(ct[-1]) - int((ct[:-1].astype(np.uint64) * s_small).sum())) % (1 << 32)
         assert ((phase + (1 << (31 - bits))) >> (32 - bits)) % p.plaintext_modulus == m
+
+
+# ------------------------------------------------------------------ empty and boundary-size batches
+@pytest.mark.parametrize("kind", BACKENDS)
+def test_empty_batches_are_noops(kind):
+    """num_samples = 0 is legal on every entry point of the path (the reference's wrappers pass empty lists
+    through): nothing is launched, nothing is written."""
+    p = TOY_2048
+    c = ctx(kind, p, "fft64", with_ksk=True)
+    st, lib = c.streams, c.lib
+    S, G = st.ptr[0], st.gpu_indexes[0]
+    sentinel = np.full(3 * (p.big_n + 1), 0xABCDEF0123456789, dtype=np.uint64)
+    d_out = gpu.CudaVec.from_cpu_async(sentinel, st)
+    d_in = gpu.CudaVec.from_cpu_async(np.zeros(4 * (p.big_n + 1), dtype=np.uint64), st)
+    idx = gpu.CudaVec.from_cpu_async(np.arange(4, dtype=np.uint64), st)
+    lut = gpu.CudaVec.from_cpu_async(np.zeros((p.k + 1) * p.N, dtype=np.uint64), st)
+    buf = C.c_void_p()
+    lib.scratch_cuda_programmable_bootstrap_64_async(S, G, C.byref(buf), p.n, p.k, p.N, p.pbs_level, 0, True, p.ms_type)
+    lib.cuda_programmable_bootstrap_64_async(S, G, d_out.ptr, idx.ptr, lut.ptr, idx.ptr, d_in.ptr, idx.ptr,
+                                             c.bsk.d_vec.ptr, buf, p.n, p.k, p.N, p.pbs_base_log, p.pbs_level, 0, 1, 0)
+    lib.cleanup_cuda_programmable_bootstrap_64(S, G, C.byref(buf))
+    lib.cuda_keyswitch_lwe_ciphertext_vector_64_64_async(S, G, d_out.ptr, idx.ptr, d_in.ptr, idx.ptr, c.ksk.d_vec.ptr,
+                                                         p.big_n, p.n, p.ks_base_log, p.ks_level, 0)
+    lib.cuda_keyswitch_gemm_64_64_async(S, G, d_out.ptr, idx.ptr, d_in.ptr, idx.ptr, c.ksk.d_vec.ptr,
+                                        p.big_n, p.n, p.ks_base_log, p.ks_level, 0, True)
+    assert np.array_equal(d_out.copy_to_cpu(st), sentinel)
+
+
+@pytest.mark.gpu
+def test_batch_sizes_around_the_kernel_selection_thresholds():
+    """The automatic choice switches from the latency kernel to the throughput kernel above 256 LWEs, and the
+    throughput kernel packs 1..4 LWEs per workgroup by batch size: every size gives the generic kernel's bits."""
+    p = TOY_2048
+    c = ctx("hip", p, "fft64")
+    rng = np.random.default_rng(2024)
+    lut = orc.generate_lut(p.k, p.N, p.plaintext_modulus, p.delta, lambda x: (x + 3) % p.plaintext_modulus)
+    cts = rng.integers(0, 1 << 64, size=(1030, p.n + 1), dtype=np.uint64)
+    try:
+        c.lib.hip_backend_set_fft_kernel(1)
+        want = c.pbs(cts, lut)
+        c.lib.hip_backend_set_fft_kernel(0)
+        for B, kid in ((1, 7), (3, 7), (255, 7), (256, 7), (257, 2), (511, 2), (513, 2), (769, 2), (1030, 2)):
+            got = c.pbs(cts[:B], lut)
+            assert c.lib.hip_backend_last_pbs_kernel() == kid, (B, c.lib.hip_backend_last_pbs_kernel())
+            assert np.array_equal(got, want[:B]), B
+    finally:
+        c.lib.hip_backend_set_fft_kernel(0)
