@@ -59,6 +59,7 @@ TOY_K3 = Params("toy_k3_N512", 16, 3, 512, 18, 2, 4, 5, 40, 18, 8, ms_type=0)
 TOY_2048 = Params("toy_k1_N2048_l1", 12, 1, 2048, 23, 1, 4, 4, 45, 17, 16, ms_type=1)
 TOY_2048_L2 = Params("toy_k1_N2048_l2", 9, 1, 2048, 15, 2, 3, 6, 45, 17, 16, ms_type=0)
 TOY_1024_K2 = Params("toy_k2_N1024_l1", 10, 2, 1024, 23, 1, 3, 5, 46, 24, 8, ms_type=0)
+TOY_1024_K1_L2 = Params("toy_k1_N1024_l2", 11, 1, 1024, 15, 2, 3, 5, 46, 20, 8, ms_type=1)
 TOY_MB = Params("toy_multibit_g3", 18, 1, 256, 15, 2, 4, 5, 40, 20, 4, grouping=3)
 TOY_MB2 = Params("toy_multibit_g2", 16, 1, 512, 15, 2, 4, 5, 40, 20, 4, grouping=2)
 TOY_MB_2048 = Params("toy_multibit_g3_N2048", 9, 1, 2048, 15, 2, 3, 6, 45, 17, 16, grouping=3)   # throughput kernel

@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 
 from . import oracle as orc
-from .common import (TOY_K1, TOY_K1_L1, TOY_K2, TOY_K3, TOY_2048, TOY_2048_L2, TOY_1024_K2, make_keys,
+from .common import (TOY_K1, TOY_K1_L1, TOY_K2, TOY_K3, TOY_2048, TOY_2048_L2, TOY_1024_K2, TOY_1024_K1_L2, make_keys,
                      encrypt_small, encrypt_big, decrypt_big, decrypt_small)
 from .harness import Ctx, use_backend, oracle_pbs, test_arith as run_arith
 from tfhe_rs_amd import core_crypto_gpu as gpu
@@ -137,7 +137,7 @@ def test_transforms_match_oracle(kind, N):
 # ------------------------------------------------------------------ PBS, classic
 PBS_CASES = [(TOY_K1, "fft64"), (TOY_K1, "ntt64"), (TOY_K1_L1, "fft64"), (TOY_K2, "fft64"), (TOY_K2, "ntt64"),
              (TOY_K3, "fft64"), (TOY_K3, "ntt64"), (TOY_2048, "fft64"), (TOY_2048, "ntt64"),
-             (TOY_2048_L2, "fft64"), (TOY_1024_K2, "fft64"), (TOY_1024_K2, "ntt64"),
+             (TOY_2048_L2, "fft64"), (TOY_1024_K2, "fft64"), (TOY_1024_K2, "ntt64"), (TOY_1024_K1_L2, "fft64"),
              (TOY_K1, "exact64"), (TOY_K2, "exact64"), (TOY_K3, "exact64")]
 
 
@@ -604,3 +604,39 @@ def test_batch_sizes_around_the_kernel_selection_thresholds():
             assert np.array_equal(got, want[:B]), B
     finally:
         c.lib.hip_backend_set_fft_kernel(0)
+
+
+# ------------------------------------------------------------------ throughput kernel for N = 1024
+@pytest.mark.parametrize("kind", BACKENDS)
+@pytest.mark.parametrize("p", [TOY_1024_K2, TOY_1024_K1_L2], ids=lambda p: p.name)
+def test_n1024_wave_kernel_equals_generic_and_oracle(kind, p):
+    """pbs_fft_wave3.hip (one wave per polynomial, k+1 waves per LWE): k = 2 with one level (the N = 1024 set
+    of BASELINE.json), k = 1 with two levels; ragged batch against the LWEs-per-workgroup packing, many-LUT,
+    non-trivial indexes, boundary digits of the one-level rounding."""
+    c = ctx(kind, p, "fft64")
+    msgs = [m % p.plaintext_modulus for m in range(11)]
+    cts = encrypt_small(p, c.keys, msgs, seed=31)
+    f = lambda x: (3 * x + 2) % p.plaintext_modulus
+    lut = orc.generate_lut(p.k, p.N, p.plaintext_modulus, p.delta, f)
+    ref = oracle_pbs(p, c.keys, "fft64", cts, lut)
+    stride = p.N // (2 * p.plaintext_modulus)
+    rng = np.random.default_rng(5)
+    edge_lut = rng.integers(0, 1 << 39, size=(p.k + 1) * p.N, dtype=np.uint64)
+    edge_lut[1::2] += np.uint64(1 << 63)
+    edge_cts = rng.integers(0, 1 << 64, size=(3, p.n + 1), dtype=np.uint64)
+    outs = {}
+    try:
+        for which, kid in ((1, 1), (0, 9)):
+            c.lib.hip_backend_set_fft_kernel(which)
+            outs[which] = (c.pbs(cts, lut),
+                           c.pbs(cts, lut, in_indexes=[7, 2, 0, 9], out_indexes=[1, 3, 0, 2], out_count=8,
+                                 num_many_lut=2, lut_stride=stride),
+                           c.pbs(edge_cts, edge_lut))
+            assert c.lib.hip_backend_last_pbs_kernel() == kid
+    finally:
+        c.lib.hip_backend_set_fft_kernel(0)
+    assert np.array_equal(outs[1][0], ref)
+    for a_, b_ in zip(outs[0], outs[1]):
+        assert np.array_equal(a_, b_)
+    assert np.array_equal(outs[0][2], oracle_pbs(p, c.keys, "fft64", edge_cts, edge_lut))
+    assert [decrypt_big(p, c.keys, o) for o in outs[0][0]] == [f(m) for m in msgs]

@@ -253,8 +253,9 @@ void cuda_programmable_bootstrap_64_async(void *stream, uint32_t gpu_index, void
                               num_samples, num_many_lut, lut_stride, b->ms_type);
   const uint32_t choice = g_fft_kernel_choice.load();
   const bool wave_ok = pbs_fft_wave_supported(polynomial_size, glwe_dimension, level_count) && base_log <= 31;
+  const bool wave3_ok = pbs_fft_wave3_supported(polynomial_size, glwe_dimension, level_count);
   const bool block_ok = pbs_fft_block_supported(polynomial_size, glwe_dimension, level_count);
-  if (choice == 2) HX_PANIC_IF_FALSE(wave_ok, "throughput kernel requested for an unsupported parameter set");
+  if (choice == 2) HX_PANIC_IF_FALSE(wave_ok || wave3_ok, "throughput kernel requested for an unsupported parameter set");
   if (choice == 3 || choice == 4) HX_PANIC_IF_FALSE(block_ok, "latency kernel requested for an unsupported parameter set");
   // automatic choice: up to one LWE per CU the latency kernel finishes first; beyond, the throughput kernel
   if (choice == 3 || choice == 4 || (choice == 0 && block_ok && num_samples <= kLatencyKernelMaxBatch)) {
@@ -262,9 +263,12 @@ void cuda_programmable_bootstrap_64_async(void *stream, uint32_t gpu_index, void
     // measured slower (4.7 vs 4.2 ms), kept for comparison
     launch_pbs_fft_block(S(stream), a, b->fft, choice == 4 ? 0 : 1);
     g_last_pbs_kernel.store(choice == 4 ? 8 : 7);
-  } else if ((choice == 0 && wave_ok) || choice == 2) {
+  } else if (wave_ok && (choice == 0 || choice == 2)) {
     launch_pbs_fft_wave(S(stream), a, b->fft);
     g_last_pbs_kernel.store(2);
+  } else if (wave3_ok && (choice == 0 || choice == 2)) {  // N = 1024: one wave per polynomial, 512-point transforms
+    launch_pbs_fft_wave3(S(stream), glwe_dimension, a, b->fft);
+    g_last_pbs_kernel.store(9);
   } else {
     launch_pbs_fft_generic(S(stream), polynomial_size, glwe_dimension, a, b->fft);
     g_last_pbs_kernel.store(1);

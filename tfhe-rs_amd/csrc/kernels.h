@@ -14,6 +14,9 @@ void launch_bsk_to_ntt(hipStream_t st, uint32_t N, const uint64_t *src_dev, void
 // throughput kernel for N=2048, k=1 (any l) — pbs_fft_wave.hip
 bool pbs_fft_wave_supported(uint32_t N, uint32_t glwe_dim, uint32_t level);
 void launch_pbs_fft_wave(hipStream_t st, const PbsArgs &a, const FftTables &tb);
+// throughput kernel for N = 1024, k = 1 or 2 (one wave per polynomial, 512-point transforms)
+bool pbs_fft_wave3_supported(uint32_t N, uint32_t glwe_dim, uint32_t level);
+void launch_pbs_fft_wave3(hipStream_t st, uint32_t glwe_dim, const PbsArgs &a, const FftTables &tb);
 // multi-bit PBS on the same kernel (a.grouping, a.keybundle set; a.bsk = standard-domain multi-bit key)
 bool pbs_multi_bit_wave_supported(uint32_t N, uint32_t glwe_dim, uint32_t level, uint32_t base_log, uint32_t grouping);
 void launch_pbs_multi_bit_wave(hipStream_t st, const PbsArgs &a, const FftTables &tb);

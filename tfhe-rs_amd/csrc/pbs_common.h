@@ -43,6 +43,7 @@ template <int N> struct GenericCfg {
 template <int N, int K1>
 HX_DEV int bsk_slot(int pos) {
   if constexpr (N == 2048 && K1 == 2) return (pos & 15) * 64 + (pos >> 4);
+  if constexpr (N == 1024 && (K1 == 2 || K1 == 3)) return (pos & 7) * 64 + (pos >> 3);  // pbs_fft_wave3.hip, layout LC
   return pos;
 }
 

@@ -391,7 +391,7 @@ __global__ void __launch_bounds__(K1 *GenericCfg<N>::TPB) pbs_ntt_par_kernel(Pbs
 // (cc/algorithms/lwe_bootstrap_key_conversion.rs:20-150, 367-434)
 template <int N>
 __global__ void __launch_bounds__(GenericCfg<N>::TPB) bsk_to_fourier_kernel(const uint64_t *src, cplx *dst, FftTables tb,
-                                                                           bool wave_order) {
+                                                                           int slot_order) {
   constexpr int n = N / 2, TPB = GenericCfg<N>::TPB;
   HX_DYN_SMEM(smem);
   const FBuf fbuf{(cplx *)smem};
@@ -402,7 +402,9 @@ __global__ void __launch_bounds__(GenericCfg<N>::TPB) bsk_to_fourier_kernel(cons
   __syncthreads();
   lds_fft_forward<N, TPB>(fbuf, tb.fwd, tid);
   cplx *o = dst + (size_t)blockIdx.x * n;
-  for (int j = tid; j < n; j += TPB) o[wave_order ? bsk_slot<2048, 2>(j) : j] = fbuf[j];
+  // slot_order: 0 tree order, 1 the N = 2048 throughput kernel's, 2 the N = 1024 one's (bsk_slot)
+  for (int j = tid; j < n; j += TPB)
+    o[slot_order == 1 ? bsk_slot<2048, 2>(j) : slot_order == 2 ? bsk_slot<1024, 2>(j) : j] = fbuf[j];
 }
 
 template <int N>
@@ -483,8 +485,8 @@ void launch_pbs_ntt_generic(hipStream_t st, uint32_t N, uint32_t glwe_dim, const
   HX_DISPATCH_NK(launch_ntt, st, a, tb);
 }
 
-template <int N> static void launch_conv_f(hipStream_t st, const uint64_t *src, void *dst, size_t polys, const FftTables &tb, bool wave_order) {
-  HX_LAUNCH((bsk_to_fourier_kernel<N>), dim3((unsigned)polys), dim3(GenericCfg<N>::TPB), fbuf_bytes(N), st, src, (cplx *)dst, tb, wave_order);
+template <int N> static void launch_conv_f(hipStream_t st, const uint64_t *src, void *dst, size_t polys, const FftTables &tb, int slot_order) {
+  HX_LAUNCH((bsk_to_fourier_kernel<N>), dim3((unsigned)polys), dim3(GenericCfg<N>::TPB), fbuf_bytes(N), st, src, (cplx *)dst, tb, slot_order);
 }
 template <int N> static void launch_conv_n(hipStream_t st, const uint64_t *src, void *dst, size_t polys, const NttTables &tb) {
   HX_LAUNCH((bsk_to_ntt_kernel<N>), dim3((unsigned)polys), dim3(GenericCfg<N>::TPB), (size_t)N * 8, st, src, (uint64_t *)dst, tb);
@@ -499,8 +501,9 @@ template <int N> static void launch_conv_n(hipStream_t st, const uint64_t *src, 
     default: HX_PANIC("unsupported polynomial_size=%u", N);                 \
   }
 void launch_bsk_to_fourier(hipStream_t st, uint32_t N, uint32_t glwe_dim, const uint64_t *src_dev, void *dst, size_t polys, const FftTables &tb) {
-  const bool wave_order = (N == 2048 && glwe_dim == 1);  // must agree with bsk_slot<N, K1>
-  HX_DISPATCH_N(launch_conv_f, st, src_dev, dst, polys, tb, wave_order);
+  // must agree with bsk_slot<N, K1>
+  const int slot_order = (N == 2048 && glwe_dim == 1) ? 1 : (N == 1024 && (glwe_dim == 1 || glwe_dim == 2)) ? 2 : 0;
+  HX_DISPATCH_N(launch_conv_f, st, src_dev, dst, polys, tb, slot_order);
 }
 void launch_bsk_to_ntt(hipStream_t st, uint32_t N, const uint64_t *src_dev, void *dst, size_t polys, const NttTables &tb) {
   HX_DISPATCH_N(launch_conv_n, st, src_dev, dst, polys, tb);
