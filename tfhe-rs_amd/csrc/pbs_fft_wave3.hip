@@ -30,7 +30,7 @@ namespace wave3k {
 
 constexpr int N = 1024, n = 512, LOG2N2 = 11;
 constexpr int BUF_SLOTS = 576, BUF_BYTES = BUF_SLOTS * 16;
-constexpr int MAX_WAVES = 8;  // 2 waves per SIMD with up to 256 VGPRs: at 3 per SIMD (168 VGPRs) the k = 2 kernel spills its accumulator (57 k vs 114 k PBS/s)
+constexpr int MAX_WAVES = 12;  // 3 waves per SIMD (up to 168 VGPRs; the kernels take 130-150).  Measured at k = 2: 6 waves 118.6 k, 9: 105.7 k, 12: 140.0 k, 15 (128 VGPRs): 108.6 k PBS/s
 // forward twiddles by pass
 constexpr int T_FA = 0;     // stages 0..2: fwd[1..7]
 constexpr int T_FB3 = 7;    // stage 3: fwd[8 + hi3]
@@ -94,10 +94,13 @@ HX_DEV void forward(cplx (&d)[8], Ctx c) {
   {  // stages 0..2: position bits 8, 7, 6 = register bits 2, 1, 0; group = the bits above
     const cplx w0 = T[T_FA + 0];
     stage8<2>(d, [&](int) { return w0; });
+    HX_SCHED_FENCE();  // twiddle loads stay next to their stage (hoisted together they cost 80 registers)
     const cplx w1[2] = {T[T_FA + 1], T[T_FA + 2]};
     stage8<1>(d, [&](int r) { return w1[r >> 2]; });
+    HX_SCHED_FENCE();
     const cplx w2[4] = {T[T_FA + 3], T[T_FA + 4], T[T_FA + 5], T[T_FA + 6]};
     stage8<0>(d, [&](int r) { return w2[r >> 1]; });
+    HX_SCHED_FENCE();
   }
   {
     cplx *pa = c.buf + lane;  // LA slots of P1
@@ -112,10 +115,13 @@ HX_DEV void forward(cplx (&d)[8], Ctx c) {
     HX_WAVE_SYNC();
     const cplx w3 = T[T_FB3 + hi3];
     stage8<2>(d, [&](int) { return w3; });
+    HX_SCHED_FENCE();
     const cplx w4[2] = {T[T_FB4 + hi3], T[T_FB4 + 8 + hi3]};
     stage8<1>(d, [&](int r) { return w4[r >> 2]; });
+    HX_SCHED_FENCE();
     const cplx w5[4] = {T[T_FB5 + hi3], T[T_FB5 + 8 + hi3], T[T_FB5 + 16 + hi3], T[T_FB5 + 24 + hi3]};
     stage8<0>(d, [&](int r) { return w5[r >> 1]; });
+    HX_SCHED_FENCE();
     cplx *pb2 = c.buf + hi3 * 72 + lo3;  // LB slots of P2
     HX_UNROLL
     for (int r = 0; r < 8; ++r) pb2[9 * r] = d[r];
@@ -128,10 +134,13 @@ HX_DEV void forward(cplx (&d)[8], Ctx c) {
     HX_WAVE_SYNC();
     const cplx w6 = T[T_FC6 + lane];
     stage8<2>(d, [&](int) { return w6; });
+    HX_SCHED_FENCE();
     const cplx w7[2] = {T[T_FC7 + lane], T[T_FC7 + 64 + lane]};
     stage8<1>(d, [&](int r) { return w7[r >> 2]; });
+    HX_SCHED_FENCE();
     const cplx w8[4] = {T[T_FC8 + lane], T[T_FC8 + 64 + lane], T[T_FC8 + 128 + lane], T[T_FC8 + 192 + lane]};
     stage8<0>(d, [&](int r) { return w8[r >> 1]; });
+    HX_SCHED_FENCE();
     HX_UNROLL
     for (int r = 0; r < 8; ++r) pc[r] = d[r];  // published for the other waves of the LWE
   }
@@ -152,8 +161,10 @@ HX_DEV void inverse_accumulate(cplx (&o)[8], uint64_t (&acc_re)[8], uint64_t (&a
     bfly_mi(o[1], o[3]);
     bfly_plain(o[4], o[6]);
     bfly_mi(o[5], o[7]);
+    HX_SCHED_FENCE();
     const cplx w4[4] = {T[T_INV + 4], T[T_INV + 5], T[T_INV + 6], T[T_INV + 7]};
     stage8<2>(o, [&](int r) { return w4[r & 3]; });
+    HX_SCHED_FENCE();
     cplx *pc = c.buf + lane * 9;  // LC slots of P2
     HX_UNROLL
     for (int r = 0; r < 8; ++r) pc[r] = o[r];
@@ -166,10 +177,13 @@ HX_DEV void inverse_accumulate(cplx (&o)[8], uint64_t (&acc_re)[8], uint64_t (&a
     HX_WAVE_SYNC();
     const cplx w8 = T[T_INV + 8 + lo3];
     stage8<0>(o, [&](int) { return w8; });
+    HX_SCHED_FENCE();
     const cplx w16[2] = {T[T_INV + 16 + lo3], T[T_INV + 24 + lo3]};
     stage8<1>(o, [&](int r) { return w16[r & 1]; });
+    HX_SCHED_FENCE();
     const cplx w32[4] = {T[T_INV + 32 + lo3], T[T_INV + 40 + lo3], T[T_INV + 48 + lo3], T[T_INV + 56 + lo3]};
     stage8<2>(o, [&](int r) { return w32[r & 3]; });
+    HX_SCHED_FENCE();
     cplx *pb = c.buf + hi3 * 72 + lo3;  // LB slots of P1
     HX_UNROLL
     for (int r = 0; r < 8; ++r) pb[8 * r] = o[r];
@@ -182,10 +196,13 @@ HX_DEV void inverse_accumulate(cplx (&o)[8], uint64_t (&acc_re)[8], uint64_t (&a
     HX_WAVE_SYNC();
     const cplx w64 = T[T_INV + 64 + lane];
     stage8<0>(o, [&](int) { return w64; });
+    HX_SCHED_FENCE();
     const cplx w128[2] = {T[T_INV + 128 + lane], T[T_INV + 192 + lane]};
     stage8<1>(o, [&](int r) { return w128[r & 1]; });
+    HX_SCHED_FENCE();
     const cplx w256[4] = {T[T_INV + 256 + lane], T[T_INV + 320 + lane], T[T_INV + 384 + lane], T[T_INV + 448 + lane]};
     stage8<2>(o, [&](int r) { return w256[r & 3]; });
+    HX_SCHED_FENCE();
   }
   // untwist, back to the torus, accumulate (fft/mod.rs:311-330); the buffer is free: stage the new accumulator
   const TorusConsts kt = torus_consts();
@@ -200,6 +217,7 @@ HX_DEV void inverse_accumulate(cplx (&o)[8], uint64_t (&acc_re)[8], uint64_t (&a
     from_torus_add(acc_im[r], ti, kt);
     stg[r * 64] = acc_re[r];
     stg[512 + r * 64] = acc_im[r];
+    if (r & 1) HX_SCHED_FENCE();
   }
   HX_WAVE_SYNC();
 }
@@ -383,6 +401,10 @@ __global__ void __launch_bounds__(MAX_WAVES * 64) pbs_fft_wave3_kernel(PbsArgs a
         for (int r = 0; r < 8; ++r) {
           const cplx x = f[r];
           o[r] = (idx == 0 && row == 0) ? cmul_first(x, k[r]) : cmul_add(x, k[r], o[r]);
+          // pin the product here: otherwise the FMAs are sunk below the next row's flag wait and all the
+          // key and transform values stay live across it (the accumulator then spills)
+          HX_OPAQUE(o[r].re);
+          HX_OPAQUE(o[r].im);
         }
         HX_SCHED_FENCE();
       }
