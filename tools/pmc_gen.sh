@@ -17,7 +17,7 @@ for db in glob.glob("$R/gpurun_out/pmc_gen_$k/**/*.db", recursive=True):
     cur = sqlite3.connect(db).cursor()
     try:
         for name, cn, v, n in cur.execute("select kernel_name, counter_name, sum(value), count(distinct dispatch_id) from counters_collection group by kernel_name, counter_name"):
-            if "pbs" in name:
+            if "pbs" in name or "wave3" in name:
                 print(f"$k {name[:48]} {cn}: {v:.4g} over {n} dispatch(es)")
     except Exception as e:
         print("err", e)
