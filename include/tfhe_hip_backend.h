@@ -312,8 +312,9 @@ uint64_t hip_integer_mult_pbs_count(int8_t *mem_ptr);
 uint64_t hip_integer_propagate_pbs_count(uint32_t num_blocks);
 
 /* Select which f64 kernel serves cuda_programmable_bootstrap_64_async (all give identical bits):
- * 0 = automatic (N=2048,k=1: latency kernel up to 256 LWEs, throughput kernel beyond; generic otherwise),
- * 1 = generic LDS kernel, 2 = throughput (wave) kernel, 3 = latency (block) kernel, 4 = its dual-stream
+ * 0 = automatic (N=2048,k=1: latency kernel up to 256 LWEs, throughput kernel beyond; N=1024,k<=2: its
+ *     throughput kernel; generic otherwise),
+ * 1 = generic LDS kernel, 2 = throughput (wave) kernel of the parameter set, 3 = latency (block) kernel, 4 = its dual-stream
  * variant; 2..4 abort on unsupported parameter sets.  For the multi-bit entry point 2 selects the
  * multi-bit mode of the throughput kernel, 1 the generic multi-bit kernel. */
 void hip_backend_set_fft_kernel(uint32_t which);
@@ -325,7 +326,7 @@ void hip_backend_set_keyswitch_kernel(uint32_t which);
  * kernels. Same bits. */
 void hip_backend_set_ntt_kernel(uint32_t which);
 /* last launched PBS kernel, for tests: 1 generic f64, 2 wave f64, 3 generic ntt, 4 generic multi-bit,
- * 5 exact, 6 wave multi-bit, 7 block (latency), 8 block dual-stream */
+ * 5 exact, 6 wave multi-bit, 7 block (latency), 8 block dual-stream, 9 wave f64 for N = 1024 */
 uint32_t hip_backend_last_pbs_kernel(void);
 const char *hip_backend_version(void);
 
