@@ -640,3 +640,27 @@ def test_n1024_wave_kernel_equals_generic_and_oracle(kind, p):
         assert np.array_equal(a_, b_)
     assert np.array_equal(outs[0][2], oracle_pbs(p, c.keys, "fft64", edge_cts, edge_lut))
     assert [decrypt_big(p, c.keys, o) for o in outs[0][0]] == [f(m) for m in msgs]
+
+
+@pytest.mark.gpu
+def test_full_size_n1024_k2_bit_exact():
+    """The N = 1024, k = 2 production set (n = 885): throughput kernel, generic kernel and oracle on the same
+    seeded inputs (ragged against the 4 LWEs of a workgroup), decrypt == f(m)."""
+    from .common import C1P
+    p = C1P
+    keys = make_keys(p, with_ksk=False)
+    msgs = [m % p.plaintext_modulus for m in range(19)]
+    cts = encrypt_small(p, keys, msgs, seed=77)
+    f = lambda x: (x + 5) % p.plaintext_modulus
+    lut = orc.generate_lut(p.k, p.N, p.plaintext_modulus, p.delta, f)
+    c = Ctx("hip", p, keys, "fft64")
+    ref = oracle_pbs(p, keys, "fft64", cts, lut)
+    try:
+        for which, kid in ((0, 9), (1, 1)):
+            c.lib.hip_backend_set_fft_kernel(which)
+            out = c.pbs(cts, lut)
+            assert c.lib.hip_backend_last_pbs_kernel() == kid
+            assert np.array_equal(out, ref), f"f64 kernel {which} differs from the oracle at full size"
+    finally:
+        c.lib.hip_backend_set_fft_kernel(0)
+    assert [decrypt_big(p, keys, o) for o in out] == [f(m) for m in msgs]
