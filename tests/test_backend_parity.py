@@ -664,3 +664,24 @@ def test_full_size_n1024_k2_bit_exact():
     finally:
         c.lib.hip_backend_set_fft_kernel(0)
     assert [decrypt_big(p, keys, o) for o in out] == [f(m) for m in msgs]
+
+
+@pytest.mark.gpu
+def test_n1024_wave_kernel_partially_filled_workgroups():
+    """1..4 LWEs per workgroup by batch size, last workgroup partially filled: every size gives the generic
+    kernel's bits."""
+    p = TOY_1024_K2
+    c = ctx("hip", p, "fft64")
+    rng = np.random.default_rng(99)
+    lut = orc.generate_lut(p.k, p.N, p.plaintext_modulus, p.delta, lambda x: (x + 1) % p.plaintext_modulus)
+    cts = rng.integers(0, 1 << 64, size=(1030, p.n + 1), dtype=np.uint64)
+    try:
+        c.lib.hip_backend_set_fft_kernel(1)
+        want = c.pbs(cts, lut)
+        c.lib.hip_backend_set_fft_kernel(0)
+        for B in (1, 2, 255, 257, 513, 770, 1030):
+            got = c.pbs(cts[:B], lut)
+            assert c.lib.hip_backend_last_pbs_kernel() == 9
+            assert np.array_equal(got, want[:B]), B
+    finally:
+        c.lib.hip_backend_set_fft_kernel(0)
