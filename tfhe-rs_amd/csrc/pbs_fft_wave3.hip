@@ -58,7 +58,11 @@ HX_DEV void flag_set(uint32_t *f, uint32_t v) { __hip_atomic_store(f, v, __ATOMI
 HX_DEV void flag_wait(uint32_t *f, uint32_t v) {
   while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < v) __builtin_amdgcn_s_sleep(1);
 }
+#ifndef W3_PRIO_OFF
 #define W3_PRIO(p) __builtin_amdgcn_s_setprio(p)
+#else
+#define W3_PRIO(p) do { } while (0)
+#endif
 #endif
 
 // one radix-2 stage over register-index bit BIT of 8 points; tw(r) is the twiddle of the butterfly (r, r | 1<<BIT)
