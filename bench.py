@@ -200,6 +200,42 @@ def main():
                                                                                               str(latency_kernel)),
                            "note": "one PBS, batch 1, same key; not part of `value` (the reference publishes "
                                    "4.21 ms on an H100, BASELINE.md)"}
+    if world == 1 and args.kernel == 0:
+        # the "N=1024" wording of BASELINE.json: the production set with polynomial size 1024 (k = 2, n = 885) on the
+        # same GPU, uniform-random key and inputs like the reference's own benches; reported next to `value`, never in it
+        from tests.common import C1P
+        q = C1P
+        r2 = np.random.default_rng(7)
+        bsk2 = gpu.CudaLweBootstrapKey.from_lwe_bootstrap_key(
+            r2.integers(0, 1 << 64, size=q.n * (q.k + 1) ** 2 * q.pbs_level * q.N, dtype=np.uint64), q.n, q.k, q.N,
+            q.pbs_base_log, q.pbs_level, streams)
+        d_in2 = gpu.CudaLweCiphertextList.from_lwe_ciphertext_list(
+            r2.integers(0, 1 << 64, size=(B, q.n + 1), dtype=np.uint64), streams)
+        d_out2 = gpu.CudaLweCiphertextList.new(q.k * q.N, B, streams)
+        d_lut2 = gpu.CudaGlweCiphertextList.from_glwe_ciphertext_list(
+            r2.integers(0, 1 << 64, size=(q.k + 1) * q.N, dtype=np.uint64), q.k, q.N, streams)
+        buf2 = C.c_void_p()
+        lib.scratch_cuda_programmable_bootstrap_64_async(s, g, C.byref(buf2), q.n, q.k, q.N, q.pbs_level, B, True, 0)
+
+        def step2():
+            lib.cuda_programmable_bootstrap_64_async(s, g, d_out2.d_vec.ptr, idx.ptr, d_lut2.d_vec.ptr, lidx.ptr,
+                                                     d_in2.d_vec.ptr, idx.ptr, bsk2.d_vec.ptr, buf2, q.n, q.k, q.N,
+                                                     q.pbs_base_log, q.pbs_level, B, 1, 0)
+        step2()
+        lib.cuda_synchronize_device(g)
+        e0, e1 = lib.hip_event_create(), lib.hip_event_create()
+        lib.hip_event_record(e0, s)
+        for _ in range(3):
+            step2()
+        lib.hip_event_record(e1, s)
+        lib.cuda_synchronize_device(g)
+        ms2 = lib.hip_event_elapsed_ms(e0, e1) / 3
+        lib.cleanup_cuda_programmable_bootstrap_64(s, g, C.byref(buf2))
+        bytes2 = q.n * (q.k + 1) ** 2 * q.pbs_level * q.N * 8 + (q.n + 1) * 8 + (q.k + 1) * q.N * 8 + (q.k * q.N + 1) * 8
+        result.setdefault("extra", {})["n1024_datapoint"] = {
+            "params": q.name + " (n=885, k=2, N=1024, l=1)", "batch": B, "ms_per_launch": ms2,
+            "pbs_per_s": B / ms2 * 1e3, "roofline_frac_streaming_model": B / ms2 * 1e3 * bytes2 / (HBM_PEAK_GBPS * 1e9),
+            "pbs_kernel_id": int(lib.hip_backend_last_pbs_kernel())}
     if world == 1 and not args.no_cpu_baseline:
         # CPU leg: the oracle's f64 path on the host cores actually available to this process
         # (affinity mask and cgroup quota, not the machine's nominal thread count), on a sample
