@@ -318,8 +318,8 @@ uint64_t hip_integer_propagate_pbs_count(uint32_t num_blocks);
  * variant; 2..4 abort on unsupported parameter sets.  For the multi-bit entry point 2 selects the
  * multi-bit mode of the throughput kernel, 1 the generic multi-bit kernel. */
 void hip_backend_set_fft_kernel(uint32_t which);
-/* keyswitch kernel: 0 = automatic (int8 matrix-core GEMM for >= 64 LWEs when level is a power of two <= 16,
- * base_log <= 6 and n_in*level is a multiple of 32; scalar kernels otherwise), 1 = scalar kernels only.
+/* keyswitch kernel: 0 = automatic (int8 matrix-core GEMM for >= 64 LWEs when level <= 16 (padded to a power of
+ * two), base_log <= 6 and n_in*padded level is a multiple of 32; scalar kernels otherwise), 1 = scalar kernels only.
  * Identical bits either way. */
 void hip_backend_set_keyswitch_kernel(uint32_t which);
 /* generic kernels (f64 and NTT engines): 0 = one thread group per GLWE polynomial (default), 1 = single-group

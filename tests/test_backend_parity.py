@@ -240,6 +240,29 @@ def test_keyswitch_matrix_core_path_equals_scalar_kernels_and_oracle(kind):
 
 
 @pytest.mark.parametrize("kind", BACKENDS)
+@pytest.mark.parametrize("p", [TOY_1024_K2, TOY_2048_L2], ids=lambda p: p.name)
+def test_keyswitch_matrix_core_path_with_padded_levels(kind, p):
+    """Level counts that are not a power of two (5 levels of base 2^3 from k N = 2048; 6 of 2^3) run on the
+    matrix cores with the K dimension padded to 8 rows per mask word (zero key rows, zero digits): same bits
+    as the scalar kernels and the oracle."""
+    c = ctx(kind, p, "fft64", with_ksk=True)
+    msgs = [m % p.plaintext_modulus for m in range(67)]
+    cts = encrypt_big(p, c.keys, msgs, seed=18)
+    lib = use_backend(kind)
+    try:
+        lib.hip_backend_set_keyswitch_kernel(0)
+        out = c.keyswitch(cts)
+        lib.hip_backend_set_keyswitch_kernel(1)
+        scalar = c.keyswitch(cts)
+    finally:
+        lib.hip_backend_set_keyswitch_kernel(0)
+    ref = orc.keyswitch_batch(cts, c.keys.ksk, p.k * p.N, p.n, p.ks_base_log, p.ks_level)
+    assert np.array_equal(scalar, ref)
+    assert np.array_equal(out, ref)
+    assert [decrypt_small(p, c.keys, o) for o in out] == msgs
+
+
+@pytest.mark.parametrize("kind", BACKENDS)
 def test_ks_then_pbs_pipeline(kind):
     # the shortint atomic pattern: keyswitch -> PBS (shortint/atomic_pattern/standard.rs:162-199)
     p = TOY_K1

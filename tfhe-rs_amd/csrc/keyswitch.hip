@@ -224,14 +224,18 @@ __global__ void __launch_bounds__(KS_TPB) keyswitch_64_32_kernel(uint32_t *lwe_o
 //     ARE the digits of consecutive mask words) and issues 8 MFMAs.
 constexpr int KSM_CT = 32;  // columns per tile
 
+// level_pad >= level: the K dimension is laid out with level_pad rows per mask word (a power of two, so that a
+// lane's 16 consecutive k cover whole mask words); the rows level..level_pad-1 are zero key rows
 __global__ void __launch_bounds__(256) ksk_planes_kernel(int8_t *planes, uint64_t *colsum, const uint64_t *ksk,
-                                                         uint32_t K, uint32_t ncols, uint32_t col_tiles) {
+                                                         uint32_t K, uint32_t ncols, uint32_t col_tiles,
+                                                         uint32_t level, uint32_t level_pad) {
   // one thread per (k block, column): 16 key words down the column
   const uint32_t col = blockIdx.x * 256 + threadIdx.x, kb = blockIdx.y;
   if (col >= col_tiles * KSM_CT) return;
   uint64_t wv[16], sum = 0;
   for (int j = 0; j < 16; ++j) {
-    wv[j] = col < ncols ? ksk[((size_t)kb * 16 + j) * ncols + col] : 0;
+    const uint32_t kp = kb * 16 + j, word = kp / level_pad, lv = kp - word * level_pad;
+    wv[j] = (col < ncols && lv < level) ? ksk[((size_t)word * level + lv) * ncols + col] : 0;
     sum += wv[j];
   }
   if (col < ncols && sum) atomicAdd((unsigned long long *)&colsum[col], (unsigned long long)sum);
@@ -251,11 +255,13 @@ __global__ void __launch_bounds__(256) ksk_planes_kernel(int8_t *planes, uint64_
   }
 }
 
-template <int LEVEL>
+// PADDED: `level` < LEVEL real levels per mask word, the rest zero digits against zero key rows
+template <int LEVEL, bool PADDED>
 __global__ void __launch_bounds__(256) ks_mfma_kernel(uint64_t *lwe_out, const uint64_t *out_idx, const uint64_t *lwe_in,
                                                       const uint64_t *in_idx, const int8_t *planes,
                                                       const uint64_t *colsum, uint32_t n_in, uint32_t n_out,
-                                                      uint32_t base_log, uint32_t num_samples, uint32_t col_tiles) {
+                                                      uint32_t base_log, uint32_t num_samples, uint32_t col_tiles,
+                                                      uint32_t level) {  // level <= LEVEL (the padded count)
   __shared__ int32_t sa[4][2][32];  // per wave: sum of the shifted digits of every row, per k half
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int row = lane & 31, h = lane >> 5;
@@ -303,10 +309,12 @@ __global__ void __launch_bounds__(256) ks_mfma_kernel(uint64_t *lwe_out, const u
       }
       HX_UNROLL
       for (int q = 0; q < WORDS; ++q) {
-        uint64_t state = decomp_init_state(xc[q], base_log, LEVEL);
+        uint64_t state = decomp_init_state(xc[q], base_log, PADDED ? level : (uint32_t)LEVEL);
         HX_UNROLL
         for (int lv = 0; lv < LEVEL; ++lv) {
-          const int32_t d = (int32_t)decompose_one_level(base_log, state) + (int32_t)half_b;
+          // padded levels: digit 0 against a zero key row (its two shift corrections cancel)
+          const int32_t d = ((!PADDED || (uint32_t)lv < level) ? (int32_t)decompose_one_level(base_log, state) : 0) +
+                            (int32_t)half_b;
           bytes[q * LEVEL + lv] = (uint32_t)d;
           my_sa += d;
         }
@@ -352,11 +360,12 @@ static std::mutex g_ksm_mutex;
 static bool keyswitch_mfma(hipStream_t st, uint64_t *lwe_out, const uint64_t *out_idx, const uint64_t *lwe_in,
                            const uint64_t *in_idx, const uint64_t *ksk, uint32_t n_in, uint32_t n_out,
                            uint32_t base_log, uint32_t level, uint32_t num_samples) {
-  const uint32_t K = n_in * level;
+  uint32_t level_pad = 1;  // levels per mask word in the K dimension: the next power of two
+  while (level_pad < level) level_pad <<= 1;
+  const uint32_t K = n_in * level_pad;
   uint32_t log_k = 0;
   while (((uint64_t)1 << log_k) < K) ++log_k;
-  const bool level_ok = level == 1 || level == 2 || level == 4 || level == 8 || level == 16;
-  if (!level_ok || K % 32 != 0 || base_log > 6 || base_log + 7 + log_k > 31 || num_samples < 64) return false;
+  if (level_pad > 16 || K % 32 != 0 || base_log > 6 || base_log + 7 + log_k > 31 || num_samples < 64) return false;
   const uint32_t ncols = n_out + 1, col_tiles = (ncols + KSM_CT - 1) / KSM_CT;
   const size_t plane_bytes = (size_t)(K / 16) * col_tiles * 8 * KSM_CT * 16;
   const size_t need = plane_bytes + (size_t)col_tiles * KSM_CT * sizeof(uint64_t);
@@ -378,12 +387,18 @@ static bool keyswitch_mfma(hipStream_t st, uint64_t *lwe_out, const uint64_t *ou
   uint64_t *colsum = (uint64_t *)((char *)ws + plane_bytes);
   HX_CHECK(hipMemsetAsync(colsum, 0, (size_t)col_tiles * KSM_CT * sizeof(uint64_t), st));
   HX_LAUNCH(ksk_planes_kernel, dim3((col_tiles * KSM_CT + 255) / 256, K / 16), dim3(256), 0, st, planes, colsum, ksk, K,
-            ncols, col_tiles);
+            ncols, col_tiles, level, level_pad);
   const dim3 grid(col_tiles, (num_samples + 127) / 128);
 #define KSM_LAUNCH(L)                                                                                              \
-  HX_LAUNCH((ks_mfma_kernel<L>), grid, dim3(256), 0, st, lwe_out, out_idx, lwe_in, in_idx, planes, colsum, n_in, \
-            n_out, base_log, num_samples, col_tiles)
-  switch (level) {
+  do {                                                                                                               \
+    if (level == L)                                                                                                  \
+      HX_LAUNCH((ks_mfma_kernel<L, false>), grid, dim3(256), 0, st, lwe_out, out_idx, lwe_in, in_idx, planes, colsum, \
+                n_in, n_out, base_log, num_samples, col_tiles, level);                                               \
+    else                                                                                                             \
+      HX_LAUNCH((ks_mfma_kernel<L, true>), grid, dim3(256), 0, st, lwe_out, out_idx, lwe_in, in_idx, planes, colsum,  \
+                n_in, n_out, base_log, num_samples, col_tiles, level);                                               \
+  } while (0)
+  switch (level_pad) {
     case 1: KSM_LAUNCH(1); break;
     case 2: KSM_LAUNCH(2); break;
     case 4: KSM_LAUNCH(4); break;

@@ -115,6 +115,8 @@ if __name__ == "__main__":
     which = sys.argv[1:] or ["ks", "wave", "generic", "ntt", "mb", "n1024", "sweep"]
     if "ks" in which:
         ks_ms = ks_case(C1, 4096)
+    if "ks1024" in which:
+        ks_case(C1P, 4096)
     if "wave" in which:
         w_ms = pbs_case(C1, 4096, kernel=2, steps=5)
         if "ks" in which:
