@@ -64,6 +64,34 @@ __device__ __forceinline__ uint32_t hx_select_by_lane_mask(uint64_t mask, uint32
 }
 #endif
 
+// ---- loads through a buffer resource: wave-uniform base in scalar registers + a 32-bit per-lane byte offset.
+// A per-lane index into a uniform array costs two vector instructions this way; as a 64-bit pointer the
+// compiler builds every address with a shift-add and a carry pair.
+#if defined(TFHE_HIPEMU)
+struct HxBuffer {
+  const char *base;
+};
+static inline HxBuffer hx_make_buffer(const void *base, uint32_t) { return HxBuffer{(const char *)base}; }
+static inline uint64_t hx_buffer_load_u64(HxBuffer b, uint32_t byte_offset) {
+  uint64_t v;
+  __builtin_memcpy(&v, b.base + byte_offset, 8);
+  return v;
+}
+#else
+struct HxBuffer {
+  __amdgpu_buffer_rsrc_t rsrc;
+};
+__device__ __forceinline__ HxBuffer hx_make_buffer(const void *base, uint32_t bytes) {
+  // word 3 = 0x00020000: raw (untyped) buffer on gfx90a/gfx94x/gfx950; stride 0, range check against `bytes`
+  return HxBuffer{__builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)bytes, 0x00020000)};
+}
+__device__ __forceinline__ uint64_t hx_buffer_load_u64(HxBuffer b, uint32_t byte_offset) {
+  typedef unsigned int hx_u32x2 __attribute__((ext_vector_type(2)));
+  const hx_u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(b.rsrc, (int)byte_offset, 0, 0);
+  return ((uint64_t)v.y << 32) | v.x;
+}
+#endif
+
 // ---- cross-lane swaps of gfx950: v_permlane32_swap exchanges the upper 32 lanes of `a` with the lower 32 lanes
 // of `b`; v_permlane16_swap exchanges the odd 16-lane rows of `a` with the even rows of `b`.  Applied to the
 // dwords of two registers they transpose (register select) x (lane bit 5, resp. bit 4).

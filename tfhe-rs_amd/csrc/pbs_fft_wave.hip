@@ -819,10 +819,11 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
           const uint32_t halves = 2 * (per - 1);
           auto half_request = [&](uint64_t (&x)[16], uint32_t hh) {
             const uint32_t sidx = 1 + (hh >> 1);
-            const uint64_t *ps = gk + (size_t)sidx * ggsw_sz + poly * N;
-            const uint32_t t0 = (uint32_t)ln - (deg[sidx] & (N - 1)) + ((hh & 1) ? 1024u : 0u);
+            // one polynomial of subset sidx as a buffer: uniform base, 32-bit per-lane byte offsets
+            const HxBuffer ps = hx_make_buffer(gk + (size_t)sidx * ggsw_sz + poly * N, N * 8);
+            const uint32_t ub = ((uint32_t)ln - (deg[sidx] & (N - 1)) + ((hh & 1) ? 1024u : 0u)) * 8u;
             HX_UNROLL
-            for (int r = 0; r < 16; ++r) x[r] = ps[(t0 + r * 64) & (N - 1)];
+            for (int r = 0; r < 16; ++r) x[r] = hx_buffer_load_u64(ps, (ub + r * 512u) & 0x3ff8u);
           };
           // two buffers in alternation (halves is even), one request in flight while the other buffer is
           // accumulated; two requests in flight measured far slower (the third buffer ends up in scratch)
