@@ -10,14 +10,22 @@
 //     waves = 4 LWEs, one workgroup per CU (2 waves per SIMD, <= 256 VGPRs each).
 //   * the torus accumulator (2048 u64 per polynomial) lives in VGPRs for all n iterations
 //     (32 u64 per lane); the 1024-point complex transform holds 16 points per lane.
-//   * every transform is 3 register passes (radix 16, 16, 4) with two wave-private LDS
-//     transposes in between — lanes of one wave run in lock step, so those exchanges need no
-//     s_barrier.  XOR swizzles make every ds_read_b128/ds_write_b128 bank-conflict free.
+//   * every transform is 3 register passes (radix 16, 4, 16): the exchange between the first two moves lane
+//     bits (5,4) with v_permlane32_swap / v_permlane16_swap, the one between the last two is a wave-private
+//     LDS transposition — lanes of one wave run in lock step, so neither needs an s_barrier.  Padded slot
+//     layouts make every ds_read_b128/ds_write_b128 bank-conflict free.
 //   * the only cross-wave traffic is the exchange of the two forward transforms before the
-//     multiply-accumulate; the pair synchronises through two LDS flags (no workgroup barrier,
-//     so the four LWEs of a CU drift apart and overlap their LDS- and VALU-heavy phases).
-//   * twiddles whose index depends on the lane sit in a 25 KB LDS table shared by the 8 waves;
-//     wave-uniform ones come through the scalar cache.
+//     multiply-accumulate (both rows are read from LDS; the role of a wave is a scalar pointer choice);
+//     the pair synchronises through two LDS flags (no workgroup barrier, so the four LWEs of a CU drift
+//     apart and overlap their LDS- and VALU-heavy phases).
+//   * the issue priority of a wave rises with the phase of its iteration (s_setprio): the wave that is
+//     further along runs through while its SIMD mate fills the gaps.
+//   * integer side written against the measured issue costs (tools/microbench2.hip): the registers hold
+//     MINUS the accumulator so that the rotate-and-subtract is xor / one 64-bit add / xor, one-level digits
+//     are a two-instruction rounding with an exact per-lane fallback at the -B/2 boundary, the torus
+//     conversion keeps its constants in registers.
+//   * twiddles whose index depends on the lane sit in a 23 KB LDS table shared by the 8 waves (strided
+//     sets stored contiguously); wave-uniform ones are broadcast reads.
 //   * the bootstrap key is stored in the order this kernel consumes it (lane-contiguous
 //     16-byte elements), so each of the 32 key loads per wave-iteration is one fully
 //     coalesced 1 KiB request; all workgroups stream GGSW_i at about the same time, so the
