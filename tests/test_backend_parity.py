@@ -582,6 +582,37 @@ def test_keyswitch_64_32_bit_exact_and_decrypts(kind, gemm):
         assert ((phase + (1 << (31 - bits))) >> (32 - bits)) % p.plaintext_modulus == m
 
 
+@pytest.mark.parametrize("kind", BACKENDS)
+@pytest.mark.parametrize("p", [TOY_2048, TOY_1024_K2], ids=lambda p: p.name)
+def test_keyswitch_64_32_matrix_core_path(kind, p):
+    """From 64 samples up the 64->32 keyswitch runs on the matrix cores (4 byte planes of the u32 key; 4 levels,
+    and 5 padded to 8): same bits as the scalar kernel and the oracle, ragged last tile, permuted outputs."""
+    c = ctx(kind, p, "fft64")
+    st = c.streams
+    lib = use_backend(kind)
+    ksk32 = _ks32_key(p, c.keys, 7)
+    ns = 71
+    msgs = [m % p.plaintext_modulus for m in range(ns)]
+    cts = encrypt_big(p, c.keys, msgs, seed=43)
+    ref = np.stack([orc.keyswitch_64_32(ct, ksk32, p.big_n, p.n, p.ks_base_log, p.ks_level) for ct in cts])
+    d_ksk = gpu.CudaLweKeyswitchKey.from_lwe_keyswitch_key(ksk32, p.big_n, p.n, p.ks_base_log, p.ks_level, st)
+    d_in = gpu.CudaLweCiphertextList.from_lwe_ciphertext_list(cts, st)
+    order = np.random.default_rng(3).permutation(ns).astype(np.uint64)
+    idx_in = gpu.CudaVec.from_cpu_async(np.arange(ns, dtype=np.uint64), st)
+    idx_out = gpu.CudaVec.from_cpu_async(order, st)
+    got = {}
+    try:
+        for choice in (0, 1):
+            lib.hip_backend_set_keyswitch_kernel(choice)
+            d_out = gpu.CudaLweCiphertextList.new(p.n, ns, st, dtype=np.uint32)
+            gpu.cuda_keyswitch_lwe_ciphertext(d_ksk, d_in, d_out, idx_in, idx_out, False, st)
+            got[choice] = d_out.to_lwe_ciphertext_list(st)[order.astype(np.int64)]
+    finally:
+        lib.hip_backend_set_keyswitch_kernel(0)
+    assert np.array_equal(got[1], ref)
+    assert np.array_equal(got[0], ref)
+
+
 # ------------------------------------------------------------------ empty and boundary-size batches
 @pytest.mark.parametrize("kind", BACKENDS)
 def test_empty_batches_are_noops(kind):

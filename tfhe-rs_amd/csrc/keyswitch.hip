@@ -226,9 +226,12 @@ constexpr int KSM_CT = 32;  // columns per tile
 
 // level_pad >= level: the K dimension is laid out with level_pad rows per mask word (a power of two, so that a
 // lane's 16 consecutive k cover whole mask words); the rows level..level_pad-1 are zero key rows
-__global__ void __launch_bounds__(256) ksk_planes_kernel(int8_t *planes, uint64_t *colsum, const uint64_t *ksk,
+// KeyT = uint64_t: 8 byte planes; uint32_t (the 64->32 keyswitch): 4
+template <typename KeyT>
+__global__ void __launch_bounds__(256) ksk_planes_kernel(int8_t *planes, uint64_t *colsum, const KeyT *ksk,
                                                          uint32_t K, uint32_t ncols, uint32_t col_tiles,
                                                          uint32_t level, uint32_t level_pad) {
+  constexpr int PLANES = (int)sizeof(KeyT);
   // one thread per (k block, column): 16 key words down the column
   const uint32_t col = blockIdx.x * 256 + threadIdx.x, kb = blockIdx.y;
   if (col >= col_tiles * KSM_CT) return;
@@ -240,14 +243,14 @@ __global__ void __launch_bounds__(256) ksk_planes_kernel(int8_t *planes, uint64_
   }
   if (col < ncols && sum) atomicAdd((unsigned long long *)&colsum[col], (unsigned long long)sum);
   const uint32_t ct = col / KSM_CT, cl = col % KSM_CT;
-  for (int p = 0; p < 8; ++p) {
+  for (int p = 0; p < PLANES; ++p) {
     uint32_t pk[4];
     for (int q = 0; q < 4; ++q) {
       uint32_t v = 0;
       for (int j = 0; j < 4; ++j) v |= (uint32_t)(uint8_t)((int)((wv[q * 4 + j] >> (8 * p)) & 0xFF) - 128) << (8 * j);
       pk[q] = v;
     }
-    uint32_t *dst = (uint32_t *)(planes + ((((size_t)kb * col_tiles + ct) * 8 + p) * KSM_CT + cl) * 16);
+    uint32_t *dst = (uint32_t *)(planes + ((((size_t)kb * col_tiles + ct) * PLANES + p) * KSM_CT + cl) * 16);
     dst[0] = pk[0];
     dst[1] = pk[1];
     dst[2] = pk[2];
@@ -256,12 +259,14 @@ __global__ void __launch_bounds__(256) ksk_planes_kernel(int8_t *planes, uint64_
 }
 
 // PADDED: `level` < LEVEL real levels per mask word, the rest zero digits against zero key rows
-template <int LEVEL, bool PADDED>
-__global__ void __launch_bounds__(256) ks_mfma_kernel(uint64_t *lwe_out, const uint64_t *out_idx, const uint64_t *lwe_in,
+// OutT = uint32_t: the 64->32 keyswitch (4 planes, arithmetic mod 2^32, body rounded to 32 bits)
+template <int LEVEL, bool PADDED, typename OutT>
+__global__ void __launch_bounds__(256) ks_mfma_kernel(OutT *lwe_out, const uint64_t *out_idx, const uint64_t *lwe_in,
                                                       const uint64_t *in_idx, const int8_t *planes,
                                                       const uint64_t *colsum, uint32_t n_in, uint32_t n_out,
                                                       uint32_t base_log, uint32_t num_samples, uint32_t col_tiles,
                                                       uint32_t level) {  // level <= LEVEL (the padded count)
+  constexpr int PLANES = (int)sizeof(OutT);
   __shared__ int32_t sa[4][2][32];  // per wave: sum of the shifted digits of every row, per k half
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int row = lane & 31, h = lane >> 5;
@@ -273,8 +278,8 @@ __global__ void __launch_bounds__(256) ks_mfma_kernel(uint64_t *lwe_out, const u
   const uint64_t *x = lwe_in + (size_t)in_idx[s_ld] * (n_in + 1);
   const uint32_t half_b = 1u << (base_log - 1);
   constexpr int WORDS = 16 / LEVEL;                 // mask words per lane per step
-  hx_i32x16 acc[8];
-  for (int p = 0; p < 8; ++p)
+  hx_i32x16 acc[PLANES];
+  for (int p = 0; p < PLANES; ++p)
     for (int r = 0; r < 16; ++r) acc[p].v[r] = 0;
   int32_t my_sa = 0;
   const uint32_t steps = n_in * LEVEL / 32;
@@ -297,10 +302,10 @@ __global__ void __launch_bounds__(256) ks_mfma_kernel(uint64_t *lwe_out, const u
         for (int q = 0; q < WORDS; ++q) xn[q] = x[w1 + q];
       }
       // B operands of this step: one 16-byte load per plane
-      const int8_t *bp = planes + ((((size_t)(st * 2 + h) * col_tiles + ct) * 8) * KSM_CT + row) * 16;
-      hx_i8x16 bv[8];
+      const int8_t *bp = planes + ((((size_t)(st * 2 + h) * col_tiles + ct) * PLANES) * KSM_CT + row) * 16;
+      hx_i8x16 bv[PLANES];
       HX_UNROLL
-      for (int p = 0; p < 8; ++p) {
+      for (int p = 0; p < PLANES; ++p) {
         const int32_t *src = (const int32_t *)(bp + (size_t)p * KSM_CT * 16);
         bv[p].w[0] = src[0];
         bv[p].w[1] = src[1];
@@ -323,7 +328,7 @@ __global__ void __launch_bounds__(256) ks_mfma_kernel(uint64_t *lwe_out, const u
       for (int q = 0; q < 4; ++q)
         av.w[q] = (int32_t)(bytes[4 * q] | (bytes[4 * q + 1] << 8) | (bytes[4 * q + 2] << 16) | (bytes[4 * q + 3] << 24));
       HX_UNROLL
-      for (int p = 0; p < 8; ++p) acc[p] = hx_mfma_i32_32x32x32_i8(av, bv[p], acc[p]);
+      for (int p = 0; p < PLANES; ++p) acc[p] = hx_mfma_i32_32x32x32_i8(av, bv[p], acc[p]);
     }
   }
   sa[wave][h][row] = my_sa;
@@ -340,10 +345,14 @@ __global__ void __launch_bounds__(256) ks_mfma_kernel(uint64_t *lwe_out, const u
     const int64_t sum_a = (int64_t)sa[wave][0][orow] + sa[wave][1][orow];
     uint64_t v = 0;
     HX_UNROLL
-    for (int p = 0; p < 8; ++p) v += (uint64_t)((int64_t)acc[p].v[r] + 128 * sum_a) << (8 * p);
+    for (int p = 0; p < PLANES; ++p) v += (uint64_t)((int64_t)acc[p].v[r] + 128 * sum_a) << (8 * p);
     uint64_t o = corr - v;
-    if (col == n_out) o += lwe_in[(size_t)in_idx[so] * (n_in + 1) + n_in];
-    lwe_out[(size_t)out_idx[so] * (n_out + 1) + col] = o;
+    if (col == n_out) {
+      const uint64_t b = lwe_in[(size_t)in_idx[so] * (n_in + 1) + n_in];
+      // 32-bit output: the body rounded to the closest multiple of 2^32, as keyswitch_64_32_kernel does
+      o += sizeof(OutT) == 8 ? b : ((b >> 31) + 1) >> 1;
+    }
+    lwe_out[(size_t)out_idx[so] * (n_out + 1) + col] = (OutT)o;
   }
 }
 
@@ -357,8 +366,9 @@ struct KsmWorkspace {
 static std::unordered_map<hipStream_t, KsmWorkspace> g_ksm_ws;
 static std::mutex g_ksm_mutex;
 
-static bool keyswitch_mfma(hipStream_t st, uint64_t *lwe_out, const uint64_t *out_idx, const uint64_t *lwe_in,
-                           const uint64_t *in_idx, const uint64_t *ksk, uint32_t n_in, uint32_t n_out,
+template <typename OutT>
+static bool keyswitch_mfma(hipStream_t st, OutT *lwe_out, const uint64_t *out_idx, const uint64_t *lwe_in,
+                           const uint64_t *in_idx, const OutT *ksk, uint32_t n_in, uint32_t n_out,
                            uint32_t base_log, uint32_t level, uint32_t num_samples) {
   uint32_t level_pad = 1;  // levels per mask word in the K dimension: the next power of two
   while (level_pad < level) level_pad <<= 1;
@@ -367,7 +377,7 @@ static bool keyswitch_mfma(hipStream_t st, uint64_t *lwe_out, const uint64_t *ou
   while (((uint64_t)1 << log_k) < K) ++log_k;
   if (level_pad > 16 || K % 32 != 0 || base_log > 6 || base_log + 7 + log_k > 31 || num_samples < 64) return false;
   const uint32_t ncols = n_out + 1, col_tiles = (ncols + KSM_CT - 1) / KSM_CT;
-  const size_t plane_bytes = (size_t)(K / 16) * col_tiles * 8 * KSM_CT * 16;
+  const size_t plane_bytes = (size_t)(K / 16) * col_tiles * sizeof(OutT) * KSM_CT * 16;
   const size_t need = plane_bytes + (size_t)col_tiles * KSM_CT * sizeof(uint64_t);
   void *ws = nullptr;
   {
@@ -386,17 +396,17 @@ static bool keyswitch_mfma(hipStream_t st, uint64_t *lwe_out, const uint64_t *ou
   int8_t *planes = (int8_t *)ws;
   uint64_t *colsum = (uint64_t *)((char *)ws + plane_bytes);
   HX_CHECK(hipMemsetAsync(colsum, 0, (size_t)col_tiles * KSM_CT * sizeof(uint64_t), st));
-  HX_LAUNCH(ksk_planes_kernel, dim3((col_tiles * KSM_CT + 255) / 256, K / 16), dim3(256), 0, st, planes, colsum, ksk, K,
-            ncols, col_tiles, level, level_pad);
+  HX_LAUNCH((ksk_planes_kernel<OutT>), dim3((col_tiles * KSM_CT + 255) / 256, K / 16), dim3(256), 0, st, planes, colsum,
+            ksk, K, ncols, col_tiles, level, level_pad);
   const dim3 grid(col_tiles, (num_samples + 127) / 128);
 #define KSM_LAUNCH(L)                                                                                              \
   do {                                                                                                               \
     if (level == L)                                                                                                  \
-      HX_LAUNCH((ks_mfma_kernel<L, false>), grid, dim3(256), 0, st, lwe_out, out_idx, lwe_in, in_idx, planes, colsum, \
-                n_in, n_out, base_log, num_samples, col_tiles, level);                                               \
+      HX_LAUNCH((ks_mfma_kernel<L, false, OutT>), grid, dim3(256), 0, st, lwe_out, out_idx, lwe_in, in_idx, planes,   \
+                colsum, n_in, n_out, base_log, num_samples, col_tiles, level);                                       \
     else                                                                                                             \
-      HX_LAUNCH((ks_mfma_kernel<L, true>), grid, dim3(256), 0, st, lwe_out, out_idx, lwe_in, in_idx, planes, colsum,  \
-                n_in, n_out, base_log, num_samples, col_tiles, level);                                               \
+      HX_LAUNCH((ks_mfma_kernel<L, true, OutT>), grid, dim3(256), 0, st, lwe_out, out_idx, lwe_in, in_idx, planes,    \
+                colsum, n_in, n_out, base_log, num_samples, col_tiles, level);                                       \
   } while (0)
   switch (level_pad) {
     case 1: KSM_LAUNCH(1); break;
@@ -443,6 +453,9 @@ void launch_keyswitch_64_32(hipStream_t st, uint32_t *lwe_out, const uint64_t *o
   HX_PANIC_IF_FALSE(base_log >= 1 && level >= 1 && level <= KS_MAXL && base_log * level <= 32,
                     "keyswitch 64->32: unsupported decomposition (base_log=%u, level=%u)", base_log, level);
   if (num_samples == 0) return;
+  if (g_keyswitch_use_mfma &&
+      keyswitch_mfma(st, lwe_out, out_idx, lwe_in, in_idx, ksk, n_in, n_out, base_log, level, num_samples))
+    return;
   const dim3 grid((n_out + 1 + KS_TPB - 1) / KS_TPB, (num_samples + KS_TB - 1) / KS_TB);
   const size_t smem = sizeof(uint32_t) * KS_IC * level * KS_TB;
   HX_LAUNCH(keyswitch_64_32_kernel, grid, dim3(KS_TPB), smem, st, lwe_out, out_idx, lwe_in, in_idx, ksk, n_in, n_out,

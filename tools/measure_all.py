@@ -111,10 +111,28 @@ def ks_case(p, B, steps=5):
     return ms
 
 
+def ks32_case(p, B, steps=5):
+    """64->32 keyswitch (u32 key) on the dimensions of `p`, matrix-core path and scalar kernel."""
+    n_in, n_out = p.k * p.N, p.n
+    key = rng.integers(0, 1 << 32, size=n_in * p.ks_level * (n_out + 1), dtype=np.uint64).astype(np.uint32)
+    ksk = gpu.CudaLweKeyswitchKey.from_lwe_keyswitch_key(key, n_in, n_out, p.ks_base_log, p.ks_level, streams)
+    d_in = gpu.CudaLweCiphertextList.from_lwe_ciphertext_list(rand_u64(B * (n_in + 1)).reshape(B, -1), streams)
+    d_out = gpu.CudaLweCiphertextList.new(n_out, B, streams, dtype=np.uint32)
+    idx = gpu.CudaVec.from_cpu_async(np.arange(B, dtype=np.uint64), streams)
+    for choice, name in ((0, "matrix cores"), (1, "scalar")):
+        lib.hip_backend_set_keyswitch_kernel(choice)
+        ms = timed(lambda: gpu.cuda_keyswitch_lwe_ciphertext(ksk, d_in, d_out, idx, idx, True, streams), steps=steps)
+        emit(what="keyswitch 64->32", path=name, params=p.name, batch=B, ms=ms, ks_per_s=B / ms * 1e3)
+    lib.hip_backend_set_keyswitch_kernel(0)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["ks", "wave", "generic", "ntt", "mb", "n1024", "sweep"]
     if "ks" in which:
         ks_ms = ks_case(C1, 4096)
+    if "ks32" in which:
+        ks32_case(C1, 4096)
+        ks32_case(C1P, 4096)
     if "ks1024" in which:
         ks_case(C1P, 4096)
     if "wave" in which:
