@@ -201,8 +201,8 @@ __global__ void __launch_bounds__(TPB) pbs_fft_block_kernel(PbsArgs a, FftTables
     if (a_hat == 0) continue;  // uniform over the workgroup (bootstrap.rs:334)
     // with A = -acc in the registers and in `stage`, S = A[(c - rr) mod N]:  ct1[c] = ((A[c] ^ M) + S) ^ M,
     // M = all-ones where the source is not negated (no wrap, a_hat < N; both flipped together), else zero
-    const int32_t ub = ((int32_t)t - (int32_t)(a_hat & (N - 1))) * 8;
-    const uint32_t keep = (a_hat & N) ? 0u : ~0u;
+    // (bit 31 of the byte offset u, which the LDS address ignores, carries the a_hat < N flag: M is one shift)
+    const uint32_t ub = (uint32_t)(((int32_t)t - (int32_t)(a_hat & (N - 1))) * 8) + ((a_hat & N) ? 0u : 0x80000000u);
     cplx o[4];
     for (uint32_t idx = 0; idx < level; ++idx) {
       // key rows [i][idx][row][c = w] at the storage slots of my 4 positions (pos = 4t + r)
@@ -220,8 +220,8 @@ __global__ void __launch_bounds__(TPB) pbs_fft_block_kernel(PbsArgs a, FftTables
       uint64_t x0[4], x1[4];
       HX_UNROLL
       for (int r = 0; r < 4; ++r) {
-        const int32_t u0 = ub + r * 2048, u1 = u0 + 8192;
-        const uint32_t m0 = keep ^ (uint32_t)(u0 >> 31), m1 = keep ^ (uint32_t)(u1 >> 31);
+        const int32_t u0 = (int32_t)(ub + r * 2048u), u1 = (int32_t)(ub + r * 2048u + 8192u);
+        const uint32_t m0 = (uint32_t)(u0 >> 31), m1 = (uint32_t)(u1 >> 31);
         const uint64_t M0 = ((uint64_t)m0 << 32) | m0, M1 = ((uint64_t)m1 << 32) | m1;
         const uint64_t s0 = *(const uint64_t *)((const char *)stage + (u0 & 0x3ff8));
         const uint64_t s1 = *(const uint64_t *)((const char *)stage + (u1 & 0x3ff8));

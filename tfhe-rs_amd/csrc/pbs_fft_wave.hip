@@ -647,9 +647,9 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
     //     ((A[c] ^ M) + S) ^ M ,   M = all-ones (sign +) or zero (sign -)
     // since ~(~A + S) = A - S: one 64-bit addition and xors, no subtraction, negation, compare or select.
     // u = 8 (c - rr) gives the byte offset (mod 16 KiB) and, by its sign bit, the negacyclic wrap.
-    const int32_t ub = ((int32_t)lane - (int32_t)(a_hat & (N - 1))) * 8;
-    uint32_t keep = (a_hat & N) ? 0u : ~0u;  // sign + when the source did not wrap (and a_hat < N)
-    HX_OPAQUE(keep);                         // a vector register: scalar operands double the cost of the xors
+    // Bit 31 of u (unused by the offset) also carries the a_hat < N flag, so the mask is one shift of u.
+    const int32_t ub =
+        (int32_t)((uint32_t)(((int32_t)lane - (int32_t)(a_hat & (N - 1))) * 8) + ((a_hat & N) ? 0u : 0x80000000u));
     int32_t lowest = 0;
     HX_UNROLL
     for (int r = 0; r < 16; ++r) {
@@ -658,8 +658,8 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
         x0 = acc_re[r];
         x1 = acc_im[r];
       } else {
-        const int32_t u0 = ub + r * 512, u1 = u0 + 8192;
-        const uint32_t m0 = keep ^ (uint32_t)(u0 >> 31), m1 = keep ^ (uint32_t)(u1 >> 31);
+        const int32_t u0 = (int32_t)((uint32_t)ub + r * 512u), u1 = (int32_t)((uint32_t)u0 + 8192u);
+        const uint32_t m0 = (uint32_t)(u0 >> 31), m1 = (uint32_t)(u1 >> 31);  // all-ones: sign +
         const uint64_t M0 = ((uint64_t)m0 << 32) | m0, M1 = ((uint64_t)m1 << 32) | m1;
         const uint64_t s0 = *(const uint64_t *)((const char *)buf64 + (u0 & 0x3ff8));
         const uint64_t s1 = *(const uint64_t *)((const char *)buf64 + (u1 & 0x3ff8));

@@ -325,14 +325,13 @@ __global__ void __launch_bounds__(MAX_WAVES * 64) pbs_fft_wave3_kernel(PbsArgs a
     constexpr bool EXACT = decltype(exact_tag)::value;
     int ln = ctx0.lane;
     HX_OPAQUE(ln);
-    const int32_t ub = ((int32_t)ln - (int32_t)(a_hat & (N - 1))) * 8;
-    uint32_t keep = (a_hat & N) ? 0u : ~0u;
-    HX_OPAQUE(keep);
+    // (bit 31 of the byte offset u, which the LDS address ignores, carries the a_hat < N flag: M is one shift)
+    const uint32_t ub = (uint32_t)(((int32_t)ln - (int32_t)(a_hat & (N - 1))) * 8) + ((a_hat & N) ? 0u : 0x80000000u);
     int32_t lowest = 0;
     HX_UNROLL
     for (int r = 0; r < 8; ++r) {
-      const int32_t u0 = ub + r * 512, u1 = u0 + 4096;
-      const uint32_t m0 = keep ^ (uint32_t)(u0 >> 31), m1 = keep ^ (uint32_t)(u1 >> 31);
+      const int32_t u0 = (int32_t)(ub + r * 512u), u1 = (int32_t)(ub + r * 512u + 4096u);
+      const uint32_t m0 = (uint32_t)(u0 >> 31), m1 = (uint32_t)(u1 >> 31);
       const uint64_t M0 = ((uint64_t)m0 << 32) | m0, M1 = ((uint64_t)m1 << 32) | m1;
       const uint64_t s0 = *(const uint64_t *)((const char *)buf64 + (u0 & 0x1ff8));
       const uint64_t s1 = *(const uint64_t *)((const char *)buf64 + (u1 & 0x1ff8));
