@@ -178,6 +178,23 @@ struct alignas(16) cplx {
   double re, im;
 };
 
+// 16-byte load through a pointer KNOWN to be device memory.  A pointer that went through HX_OPAQUE has lost
+// its address space: the compiler would emit FLAT loads, which also count on the LDS counter (lgkmcnt) and
+// return out of order with the LDS reads, so every LDS wait behind them becomes a wait for the key.
+// STREAM: read-once data (nontemporal).
+template <bool STREAM = false>
+HX_DEV cplx load_global_cplx(const cplx *p) {
+#if defined(TFHE_HIPEMU) || defined(HX_KEY_FLAT_LOADS)  // (the second: A/B knob of tools/build_variants.py)
+  return *p;
+#else
+  typedef double v2d __attribute__((ext_vector_type(2)));
+  typedef const v2d __attribute__((address_space(1))) *gptr;
+  const gptr g = (gptr)(const void *)p;
+  const v2d x = STREAM ? __builtin_nontemporal_load(g) : *g;
+  return cplx{x.x, x.y};
+#endif
+}
+
 // DESIGN.md §4 butterfly: (a, b) -> (a + s*b, 2a - (a + s*b))
 HX_DEV void bfly(cplx &a, cplx &b, const cplx s) {
   const double o1r = fma(-b.im, s.im, fma(b.re, s.re, a.re));

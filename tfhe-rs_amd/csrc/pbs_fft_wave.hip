@@ -651,6 +651,11 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
     const int32_t ub =
         (int32_t)((uint32_t)(((int32_t)lane - (int32_t)(a_hat & (N - 1))) * 8) + ((a_hat & N) ? 0u : 0x80000000u));
     int32_t lowest = 0;
+    uint32_t vzero = 0;
+#ifndef WAVE_STAGED_SGPR_BASE
+    HX_LAUNDER(vzero);  // the staged copy's base in a vector register: a scalar operand doubles the cost of the add
+#endif
+    const char *staged = (const char *)buf64 + vzero;
     HX_UNROLL
     for (int r = 0; r < 16; ++r) {
       uint64_t x0, x1;
@@ -661,8 +666,8 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
         const int32_t u0 = (int32_t)((uint32_t)ub + r * 512u), u1 = (int32_t)((uint32_t)u0 + 8192u);
         const uint32_t m0 = (uint32_t)(u0 >> 31), m1 = (uint32_t)(u1 >> 31);  // all-ones: sign +
         const uint64_t M0 = ((uint64_t)m0 << 32) | m0, M1 = ((uint64_t)m1 << 32) | m1;
-        const uint64_t s0 = *(const uint64_t *)((const char *)buf64 + (u0 & 0x3ff8));
-        const uint64_t s1 = *(const uint64_t *)((const char *)buf64 + (u1 & 0x3ff8));
+        const uint64_t s0 = *(const uint64_t *)(staged + (u0 & 0x3ff8));
+        const uint64_t s1 = *(const uint64_t *)(staged + (u1 & 0x3ff8));
         x0 = ((acc_re[r] ^ M0) + s0) ^ M0;
         x1 = ((acc_im[r] ^ M1) + s1) ^ M1;
       }
@@ -713,20 +718,10 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
   auto key_request = [&](cplx (&k0)[4], cplx (&k1)[4], const cplx *b0, const cplx *b1, int ch) {
     HX_UNROLL
     for (int j = 0; j < 4; ++j) {
-#if !defined(TFHE_HIPEMU)
-      if constexpr (MULTIBIT) {
-        // the parked keybundle is read back exactly once: a streaming load keeps it from displacing the
-        // shared key of the group in L2 (measured: 22.3 k -> 24.2 k PBS/s)
-        typedef double v2d __attribute__((ext_vector_type(2)));
-        const v2d x0 = __builtin_nontemporal_load((const v2d *)&b0[(ch * 4 + j) * 64]);
-        const v2d x1 = __builtin_nontemporal_load((const v2d *)&b1[(ch * 4 + j) * 64]);
-        k0[j] = cplx{x0.x, x0.y};
-        k1[j] = cplx{x1.x, x1.y};
-        continue;
-      }
-#endif
-      k0[j] = b0[(ch * 4 + j) * 64];
-      k1[j] = b1[(ch * 4 + j) * 64];
+      // MULTIBIT: the parked keybundle is read back exactly once — a streaming load keeps it from displacing
+      // the shared key of the group in L2 (measured: 22.3 k -> 24.2 k PBS/s)
+      k0[j] = load_global_cplx<MULTIBIT>(&b0[(ch * 4 + j) * 64]);
+      k1[j] = load_global_cplx<MULTIBIT>(&b1[(ch * 4 + j) * 64]);
     }
   };
 

@@ -328,13 +328,18 @@ __global__ void __launch_bounds__(MAX_WAVES * 64) pbs_fft_wave3_kernel(PbsArgs a
     // (bit 31 of the byte offset u, which the LDS address ignores, carries the a_hat < N flag: M is one shift)
     const uint32_t ub = (uint32_t)(((int32_t)ln - (int32_t)(a_hat & (N - 1))) * 8) + ((a_hat & N) ? 0u : 0x80000000u);
     int32_t lowest = 0;
+    uint32_t vzero = 0;
+#ifndef WAVE_STAGED_SGPR_BASE
+    HX_LAUNDER(vzero);  // base of the staged copy in a vector register (a scalar operand doubles the add's cost)
+#endif
+    const char *staged = (const char *)buf64 + vzero;
     HX_UNROLL
     for (int r = 0; r < 8; ++r) {
       const int32_t u0 = (int32_t)(ub + r * 512u), u1 = (int32_t)(ub + r * 512u + 4096u);
       const uint32_t m0 = (uint32_t)(u0 >> 31), m1 = (uint32_t)(u1 >> 31);
       const uint64_t M0 = ((uint64_t)m0 << 32) | m0, M1 = ((uint64_t)m1 << 32) | m1;
-      const uint64_t s0 = *(const uint64_t *)((const char *)buf64 + (u0 & 0x1ff8));
-      const uint64_t s1 = *(const uint64_t *)((const char *)buf64 + (u1 & 0x1ff8));
+      const uint64_t s0 = *(const uint64_t *)(staged + (u0 & 0x1ff8));
+      const uint64_t s1 = *(const uint64_t *)(staged + (u1 & 0x1ff8));
       const uint64_t x0 = ((acc_re[r] ^ M0) + s0) ^ M0, x1 = ((acc_im[r] ^ M1) + s1) ^ M1;
       if constexpr (L1) {
         if constexpr (EXACT) {
@@ -397,7 +402,7 @@ __global__ void __launch_bounds__(MAX_WAVES * 64) pbs_fft_wave3_kernel(PbsArgs a
         // above it and live (or spill) across the spin loop
         HX_OPAQUE(kcol);
         HX_UNROLL
-        for (int r = 0; r < 8; ++r) k[r] = kcol[(size_t)row * K1 * n + r * 64];
+        for (int r = 0; r < 8; ++r) k[r] = load_global_cplx(&kcol[(size_t)row * K1 * n + r * 64]);
         if (row != w) flag_wait(ready + row, epoch);
         const cplx *f = (const cplx *)(smem + (size_t)(slot * K1 + row) * BUF_BYTES) + ln * 9;
         HX_UNROLL
