@@ -45,6 +45,9 @@
 // lets the wave that is further along run through (its partner wave is waiting for it), while the other
 // one fills the gaps: measured 102.6 k -> 117 k PBS/s; the order matters (digits < forward, inverse >= MAC),
 // see profiles/r01_setprio_variants.txt.
+#ifndef WAVE_MAC_PREFETCH
+#define WAVE_MAC_PREFETCH 0  // measured: 0 -> 117.9 k, 2 -> 117.4 k, 4 -> 117.4 k, 8 -> 117.2 k PBS/s (the partner wave already covers the LDS latency)
+#endif
 #ifndef WAVE_PRIO_A
 #define WAVE_PRIO_A 0  // rotation + digits
 #endif
@@ -750,6 +753,15 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
     // Both rows are read from LDS — row 0 from the buffer of the wave that holds polynomial 0, row 1 from
     // the other one — so the roles are a scalar pointer choice: no per-point test of w, no selects, and
     // the registers of my own transform are free during the products.
+    // the LDS reads run WAVE_MAC_PREFETCH points ahead of the products that consume them (issued just in
+    // time, each pair exposed a full LDS latency to this wave)
+    constexpr int PF = WAVE_MAC_PREFETCH;
+    cplx xn0[PF > 0 ? PF : 1], xn1[PF > 0 ? PF : 1];
+    HX_UNROLL
+    for (int q = 0; q < PF; ++q) {
+      xn0[q] = row0[q];
+      xn1[q] = row1[q];
+    }
     HX_UNROLL
     for (int ch = 0; ch < 4; ++ch) {
       cplx(&k0)[4] = (ch & 1) ? kb0 : ka0;
@@ -757,7 +769,18 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
       HX_UNROLL
       for (int j = 0; j < 4; ++j) {
         const int r = ch * 4 + j;
-        const cplx x0 = row0[r], x1 = row1[r];
+        cplx x0, x1;
+        if constexpr (PF > 0) {
+          x0 = xn0[r % PF];
+          x1 = xn1[r % PF];
+          if (r + PF < 16) {
+            xn0[r % PF] = row0[r + PF];
+            xn1[r % PF] = row1[r + PF];
+          }
+        } else {
+          x0 = row0[r];
+          x1 = row1[r];
+        }
         const cplx t = (idx == 0) ? cmul_first(x0, k0[j]) : cmul_add(x0, k0[j], dst[r]);
         dst[r] = cmul_add(x1, k1[j], t);
         // pin the product here: otherwise the FMAs are sunk below the flag wait that follows and
