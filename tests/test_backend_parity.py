@@ -8,6 +8,8 @@ bit-exact against the oracle's fixed-order restatement and decry
 """
 import ctypes as C
 
+import dataclasses
+
 import numpy as np
 import pytest
 
@@ -218,10 +220,12 @@ def test_keyswitch_bit_exact(kind, p, gemm):
 
 
 @pytest.mark.parametrize("kind", BACKENDS)
-def test_keyswitch_matrix_core_path_equals_scalar_kernels_and_oracle(kind):
+@pytest.mark.parametrize("ks", [(4, 4), (4, 8), (5, 7)], ids=lambda ks: "ks_%dx%d" % ks)
+def test_keyswitch_matrix_core_path_equals_scalar_kernels_and_oracle(kind, ks):
     """>= 64 LWEs, 4 levels of base 2^4 on N = 2048: the int8-MFMA GEMM path (byte planes of the key, shifted
-    digits) against the scalar kernels and the oracle, bit for bit; ragged batch (70 = 2 tiles + 6 rows)."""
-    p = TOY_2048
+    digits) against the scalar kernels and the oracle, bit for bit; ragged batch (70 = 2 tiles + 6 rows).
+    4 x 4 decomposes on 32-bit registers (base_log * level <= 30), 4 x 8 and 5 x 7 (padded to 8) on 64-bit ones."""
+    p = dataclasses.replace(TOY_2048, name="toy_k1_N2048_ks%dx%d" % ks, ks_base_log=ks[0], ks_level=ks[1])
     c = ctx(kind, p, "fft64", with_ksk=True)
     msgs = [m % p.plaintext_modulus for m in range(70)]
     cts = encrypt_big(p, c.keys, msgs, seed=8)

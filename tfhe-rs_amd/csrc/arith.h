@@ -61,6 +61,25 @@ HX_DEV int64_t decompose_one_level(uint32_t base_log, uint64_t &state) {
   state += carry;
   return (int64_t)(res - (carry << base_log));
 }
+// The same two functions on 32-bit registers, for base_log * level <= 30: the initial state then reads bits of
+// the HIGH dword of x only and fits an int32 (|state| <= 2^(rep-1)), and every later state is smaller.
+// Half the vector instructions of the 64-bit forms (no carries across dwords); checked against them by the
+// keyswitch parity tests (the matrix-core keyswitch uses these).
+HX_DEV int32_t decomp_init_state32(uint32_t x_hi, uint32_t base_log, uint32_t level) {
+  const uint32_t rep = base_log * level;
+  uint32_t res = x_hi >> (32 - rep - 1);
+  const uint32_t rounding_bit = res & 1;
+  res = ((res + 1) >> 1) & (0xFFFFFFFFu >> (32 - rep));
+  const uint32_t need_balance = (((res - 1) | (rounding_bit << (rep - 1))) & res) >> (rep - 1);
+  return (int32_t)(res - (need_balance << rep));
+}
+HX_DEV int32_t decompose_one_level32(uint32_t base_log, int32_t &state) {
+  const uint32_t res = (uint32_t)state & ((1u << base_log) - 1);
+  state >>= base_log;
+  const uint32_t carry = (((res - 1) | (uint32_t)state) & res) >> (base_log - 1);
+  state += (int32_t)carry;
+  return (int32_t)(res - (carry << base_log));
+}
 // digit of level-matrix index `idx` (idx 0 <-> level l): run the iterator idx+1 times
 HX_DEV int64_t decomp_digit(uint64_t x, uint32_t base_log, uint32_t level, uint32_t idx) {
   uint64_t st = decomp_init_state(x, base_log, level);

@@ -283,6 +283,7 @@ __global__ void __launch_bounds__(256) ks_mfma_kernel(OutT *lwe_out, const uint6
     for (int r = 0; r < 16; ++r) acc[p].v[r] = 0;
   int32_t my_sa = 0;
   const uint32_t steps = n_in * LEVEL / 32;
+  const bool narrow = base_log * level <= 30;
   if (live) {
     // mask words of step st+1 are requested before step st is decomposed (n_in + 1 words per LWE: the last
     // request of the last step reads at most the body, in range)
@@ -314,14 +315,26 @@ __global__ void __launch_bounds__(256) ks_mfma_kernel(OutT *lwe_out, const uint6
       }
       HX_UNROLL
       for (int q = 0; q < WORDS; ++q) {
-        uint64_t state = decomp_init_state(xc[q], base_log, PADDED ? level : (uint32_t)LEVEL);
-        HX_UNROLL
-        for (int lv = 0; lv < LEVEL; ++lv) {
-          // padded levels: digit 0 against a zero key row (its two shift corrections cancel)
-          const int32_t d = ((!PADDED || (uint32_t)lv < level) ? (int32_t)decompose_one_level(base_log, state) : 0) +
-                            (int32_t)half_b;
-          bytes[q * LEVEL + lv] = (uint32_t)d;
-          my_sa += d;
+        const uint32_t real = PADDED ? level : (uint32_t)LEVEL;
+        if (narrow) {  // wave-uniform: the decomposition on 32-bit registers (arith.h)
+          int32_t state = decomp_init_state32((uint32_t)(xc[q] >> 32), base_log, real);
+          HX_UNROLL
+          for (int lv = 0; lv < LEVEL; ++lv) {
+            // padded levels: digit 0 against a zero key row (its two shift corrections cancel)
+            const int32_t d = ((!PADDED || (uint32_t)lv < level) ? decompose_one_level32(base_log, state) : 0) +
+                              (int32_t)half_b;
+            bytes[q * LEVEL + lv] = (uint32_t)d;
+            my_sa += d;
+          }
+        } else {
+          uint64_t state = decomp_init_state(xc[q], base_log, real);
+          HX_UNROLL
+          for (int lv = 0; lv < LEVEL; ++lv) {
+            const int32_t d = ((!PADDED || (uint32_t)lv < level) ? (int32_t)decompose_one_level(base_log, state) : 0) +
+                              (int32_t)half_b;
+            bytes[q * LEVEL + lv] = (uint32_t)d;
+            my_sa += d;
+          }
         }
       }
       HX_UNROLL
