@@ -65,7 +65,10 @@ void cuda_drop(void *ptr, uint32_t gpu_index);
 
 /* ------------------------------------------------------------------ classic PBS
  * backends/tfhe-cuda-backend/cuda/include/pbs/programmable_bootstrap.h:52-55,62-66,83-90,99-100
- * called from tfhe/src/core_crypto/gpu/ffi.rs:21-92 */
+ * called from tfhe/src/core_crypto/gpu/ffi.rs:21-92
+ * polynomial_size: a power of two in 256..16384 (the reference's range); glwe_dimension 1..3 up to 2048,
+ * 1 from 4096 up.  The scratch query returns 0 device bytes up to 4096 (the accumulator stays in LDS) and
+ * num_samples * (k+1) * N * 8 beyond. */
 void cuda_convert_lwe_programmable_bootstrap_key_64_async(
     void *stream, uint32_t gpu_index, void *dest, void const *src,
     uint32_t input_lwe_dim, uint32_t glwe_dim, uint32_t level_count,

@@ -49,6 +49,7 @@ class Params:
 
 C1 = Params("PARAM_MESSAGE_2_CARRY_2", 918, 1, 2048, 23, 1, 4, 4, 45, 17, 16, ms_type=1)
 C1P = Params("PARAM_MESSAGE_1_CARRY_2_N1024", 885, 2, 1024, 23, 1, 3, 5, 46, 24, 8, ms_type=0)
+C33 = Params("PARAM_MESSAGE_3_CARRY_3_N8192", 1006, 1, 8192, 15, 2, 3, 7, 45, 17, 64, ms_type=0)   # timing only
 C4 = Params("PARAM_MULTI_BIT_GROUP_3_MESSAGE_2_CARRY_2", 918, 1, 2048, 15, 2, 3, 6, 45, 17, 16,
             grouping=3)
 
@@ -60,6 +61,8 @@ TOY_2048 = Params("toy_k1_N2048_l1", 12, 1, 2048, 23, 1, 4, 4, 45, 17, 16, ms_ty
 TOY_2048_L2 = Params("toy_k1_N2048_l2", 9, 1, 2048, 15, 2, 3, 6, 45, 17, 16, ms_type=0)
 TOY_1024_K2 = Params("toy_k2_N1024_l1", 10, 2, 1024, 23, 1, 3, 5, 46, 24, 8, ms_type=0)
 TOY_1024_K1_L2 = Params("toy_k1_N1024_l2", 11, 1, 1024, 15, 2, 3, 5, 46, 20, 8, ms_type=1)
+TOY_8192 = Params("toy_k1_N8192_l1", 5, 1, 8192, 23, 1, 4, 5, 45, 17, 16, ms_type=1)    # accumulator in device memory
+TOY_16384 = Params("toy_k1_N16384_l2", 4, 1, 16384, 15, 2, 4, 5, 45, 17, 16, ms_type=0)
 TOY_MB = Params("toy_multibit_g3", 18, 1, 256, 15, 2, 4, 5, 40, 20, 4, grouping=3)
 TOY_MB2 = Params("toy_multibit_g2", 16, 1, 512, 15, 2, 4, 5, 40, 20, 4, grouping=2)
 TOY_MB_2048 = Params("toy_multibit_g3_N2048", 9, 1, 2048, 15, 2, 3, 6, 45, 17, 16, grouping=3)   # throughput kernel

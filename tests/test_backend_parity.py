@@ -14,7 +14,8 @@ import numpy as np
 import pytest
 
 from . import oracle as orc
-from .common import (TOY_K1, TOY_K1_L1, TOY_K2, TOY_K3, TOY_2048, TOY_2048_L2, TOY_1024_K2, TOY_1024_K1_L2, make_keys,
+from .common import (TOY_K1, TOY_K1_L1, TOY_K2, TOY_K3, TOY_2048, TOY_2048_L2, TOY_1024_K2, TOY_1024_K1_L2, TOY_8192,
+                     TOY_16384, make_keys,
                      encrypt_small, encrypt_big, decrypt_big, decrypt_small)
 from .harness import Ctx, use_backend, oracle_pbs, test_arith as run_arith
 from tfhe_rs_amd import core_crypto_gpu as gpu
@@ -140,7 +141,7 @@ def test_transforms_match_oracle(kind, N):
 PBS_CASES = [(TOY_K1, "fft64"), (TOY_K1, "ntt64"), (TOY_K1_L1, "fft64"), (TOY_K2, "fft64"), (TOY_K2, "ntt64"),
              (TOY_K3, "fft64"), (TOY_K3, "ntt64"), (TOY_2048, "fft64"), (TOY_2048, "ntt64"),
              (TOY_2048_L2, "fft64"), (TOY_1024_K2, "fft64"), (TOY_1024_K2, "ntt64"), (TOY_1024_K1_L2, "fft64"),
-             (TOY_K1, "exact64"), (TOY_K2, "exact64"), (TOY_K3, "exact64")]
+             (TOY_K1, "exact64"), (TOY_K2, "exact64"), (TOY_K3, "exact64"), (TOY_8192, "fft64"), (TOY_16384, "fft64")]
 
 
 @pytest.mark.parametrize("kind", BACKENDS)

@@ -20,7 +20,8 @@ constexpr uint32_t kMbMagic = 0x4d425031;    // "MBP1"
 
 // Host-side descriptor behind the opaque `int8_t *buffer` of the scratch/cleanup triple
 // (the reference's pbs_buffer<Torus, CLASSICAL>, cuda/include/pbs/pbs_utilities.h:100-260).
-// The whole CMUX loop runs on-chip, so the classic PBS needs no global scratch at all.
+// The whole CMUX loop runs on-chip, so the classic PBS needs no global scratch — except for the rings of
+// 8192 and 16384 coefficients, whose accumulator is a per-sample device buffer (acc_scratch).
 struct PbsBuffer {
   uint32_t magic;
   uint32_t lwe_dimension, glwe_dimension, polynomial_size, level_count, max_samples;
@@ -28,6 +29,7 @@ struct PbsBuffer {
   bool gpu_memory_allocated;
   FftTables fft;
   NttTables ntt;
+  uint64_t *acc_scratch = nullptr;
 };
 struct MultiBitBuffer {
   uint32_t magic;
@@ -39,9 +41,11 @@ struct MultiBitBuffer {
   uint64_t *acc;
 };
 
-void check_pow2_poly(uint32_t N) {
-  HX_PANIC_IF_FALSE(N >= 256 && N <= 4096 && (N & (N - 1)) == 0,
-                    "polynomial_size %u not supported by the MI355X PBS (256..4096, power of two)", N);
+// max_n: 16384 for the classic f64 PBS (programmable_bootstrap_classic.cuh supports rings up to 2^14), 4096 for
+// the NTT / exact engines and the multi-bit PBS
+void check_pow2_poly(uint32_t N, uint32_t max_n = 4096) {
+  HX_PANIC_IF_FALSE(N >= 256 && N <= max_n && (N & (N - 1)) == 0,
+                    "polynomial_size %u not supported by the MI355X PBS (256..%u, power of two)", N, max_n);
 }
 
 constexpr uint32_t kLatencyKernelMaxBatch = 256;  // measured (tools/measure_all.py latency): 3.7-3.9 ms vs 5.9 ms up to 256 LWEs, slower beyond
@@ -163,7 +167,7 @@ static void convert_bsk_common(bool ntt, void *stream, uint32_t gpu_index, void 
                                uint32_t input_lwe_dim, uint32_t glwe_dim, uint32_t level_count,
                                uint32_t polynomial_size) {
   set_device(gpu_index);
-  check_pow2_poly(polynomial_size);
+  check_pow2_poly(polynomial_size, ntt ? 4096 : 16384);
   HX_PANIC_IF_FALSE(dest != nullptr && src != nullptr, "bootstrap key conversion: null pointer");
   const size_t polys = (size_t)input_lwe_dim * level_count * (glwe_dim + 1) * (glwe_dim + 1);
   const size_t bytes = polys * polynomial_size * sizeof(uint64_t);
@@ -202,8 +206,10 @@ uint64_t scratch_cuda_programmable_bootstrap_64_async(void *stream, uint32_t gpu
                                                       uint32_t input_lwe_ciphertext_count, bool allocate_gpu_memory,
                                                       enum PBS_MS_REDUCTION_T noise_reduction_type) {
   set_device(gpu_index);
-  check_pow2_poly(polynomial_size);
+  check_pow2_poly(polynomial_size, 16384);
   HX_PANIC_IF_FALSE(glwe_dimension >= 1 && glwe_dimension <= 3, "glwe_dimension %u not supported", glwe_dimension);
+  HX_PANIC_IF_FALSE(polynomial_size <= 4096 || glwe_dimension == 1,
+                    "polynomial_size %u is supported with glwe_dimension 1 only", polynomial_size);
   auto *b = new PbsBuffer();
   b->magic = kPbsMagic;
   b->lwe_dimension = lwe_dimension;
@@ -216,10 +222,16 @@ uint64_t scratch_cuda_programmable_bootstrap_64_async(void *stream, uint32_t gpu
   if (allocate_gpu_memory) {
     // constant tables are built here (not in the launch) so the launch stays capture-safe
     b->fft = get_fft_tables(gpu_index, S(stream), polynomial_size);
-    b->ntt = get_ntt_tables(gpu_index, S(stream), polynomial_size);
+    if (polynomial_size <= 4096) b->ntt = get_ntt_tables(gpu_index, S(stream), polynomial_size);
   }
+  // bytes of device scratch: none up to N = 4096 (the accumulator never leaves the chip), one accumulator per
+  // sample beyond
+  const uint64_t bytes = polynomial_size <= 4096 ? 0
+                                                 : (uint64_t)input_lwe_ciphertext_count * (glwe_dimension + 1) *
+                                                       polynomial_size * sizeof(uint64_t);
+  if (allocate_gpu_memory && bytes) HX_CHECK(hipMalloc((void **)&b->acc_scratch, bytes));
   *buffer = reinterpret_cast<int8_t *>(b);
-  return 0;  // bytes of device scratch: the accumulator never leaves the chip
+  return bytes;
 }
 
 static PbsBuffer *checked_buffer(int8_t *buffer, uint32_t lwe_dimension, uint32_t glwe_dimension,
@@ -248,9 +260,10 @@ void cuda_programmable_bootstrap_64_async(void *stream, uint32_t gpu_index, void
                     base_log, level_count);
   HX_PANIC_IF_FALSE(num_many_lut >= 1, "num_many_lut must be >= 1");
   if (num_samples == 0) return;
-  const PbsArgs a = make_args(lwe_array_out, lwe_output_indexes, lut_vector, lut_vector_indexes, lwe_array_in,
-                              lwe_input_indexes, bootstrapping_key, lwe_dimension, base_log, level_count,
-                              num_samples, num_many_lut, lut_stride, b->ms_type);
+  PbsArgs a = make_args(lwe_array_out, lwe_output_indexes, lut_vector, lut_vector_indexes, lwe_array_in,
+                        lwe_input_indexes, bootstrapping_key, lwe_dimension, base_log, level_count, num_samples,
+                        num_many_lut, lut_stride, b->ms_type);
+  a.acc_scratch = b->acc_scratch;
   const uint32_t choice = g_fft_kernel_choice.load();
   const bool wave_ok = pbs_fft_wave_supported(polynomial_size, glwe_dimension, level_count) && base_log <= 31;
   const bool wave3_ok = pbs_fft_wave3_supported(polynomial_size, glwe_dimension, level_count);
@@ -328,6 +341,7 @@ void cleanup_cuda_programmable_bootstrap_64(void *stream, uint32_t gpu_index, in
   auto *b = reinterpret_cast<PbsBuffer *>(*pbs_buffer);
   HX_PANIC_IF_FALSE(b != nullptr && b->magic == kPbsMagic, "cleanup of a foreign PBS buffer");
   HX_CHECK(hipStreamSynchronize(S(stream)));  // cleanup_* synchronises (pbs_utilities.h:261-271)
+  if (b->acc_scratch) HX_CHECK(hipFree(b->acc_scratch));
   b->magic = 0;
   delete b;
   *pbs_buffer = nullptr;

@@ -29,11 +29,14 @@ struct PbsArgs {
   // multi-bit PBS only (0 / null otherwise): grouping factor, per-sample Fourier keybundle scratch
   uint32_t grouping = 0;
   void *keybundle = nullptr;
+  // N >= 8192 only: (k+1) N torus words per sample — the accumulator of those rings does not fit in LDS next
+  // to the transform buffer and lives in device memory (L2-resident between the iterations of a workgroup)
+  uint64_t *acc_scratch = nullptr;
 };
 
 constexpr int ilog2_c(int x) { return x <= 1 ? 0 : 1 + ilog2_c(x / 2); }
 template <int N> struct GenericCfg {
-  static constexpr int TPB = (N / 4 < 256) ? N / 4 : 256;
+  static constexpr int TPB = N > 8192 ? 1024 : N > 4096 ? 512 : (N / 4 < 256) ? N / 4 : 256;
 };
 
 // Storage slot of transform position `pos` inside one Fourier-domain key polynomial.  The

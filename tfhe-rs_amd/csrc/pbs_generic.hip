@@ -32,14 +32,17 @@ HX_DEV double digit_f64(uint64_t x, uint32_t base_log, uint32_t level, uint32_t 
 }
 
 // ------------------------------------------------------------------------- f64 engine
-template <int N, int K1>
+// ACC_GLOBAL (N = 8192, 16384: programmable_bootstrap_classic.cuh supports rings up to 2^14): the accumulator
+// is kept in a per-sample device buffer instead of LDS; a workgroup runs on one CU, so its own writes are
+// visible to its later reads through that CU's L1 after the workgroup barrier.
+template <int N, int K1, bool ACC_GLOBAL = false>
 __global__ void __launch_bounds__(GenericCfg<N>::TPB) pbs_fft_generic_kernel(PbsArgs a, FftTables tb) {
   constexpr int n = N / 2, TPB = GenericCfg<N>::TPB, PER = n / TPB, LOG2N2 = ilog2_c(2 * N);
   HX_DYN_SMEM(smem);
-  uint64_t *acc = (uint64_t *)smem;                  // K1*N torus words
-  const FBuf fbuf{(cplx *)(smem + (size_t)K1 * N * 8)};  // n complex points, padded
   const int tid = threadIdx.x;
   const uint32_t sample = blockIdx.x;
+  uint64_t *acc = ACC_GLOBAL ? a.acc_scratch + (size_t)sample * K1 * N : (uint64_t *)smem;  // K1*N torus words
+  const FBuf fbuf{(cplx *)(smem + (ACC_GLOBAL ? 0 : (size_t)K1 * N * 8))};                  // n complex points, padded
   const uint64_t *lwe = a.lwe_in + (size_t)a.in_idx[sample] * (a.n + 1);
   const uint64_t *lut = a.lut + (size_t)a.lut_idx[sample] * K1 * N;
   const cplx *bsk = (const cplx *)a.bsk;
@@ -422,6 +425,14 @@ __global__ void __launch_bounds__(GenericCfg<N>::TPB) bsk_to_ntt_kernel(const ui
 }
 
 // ------------------------------------------------------------------------- launchers
+template <int N>
+static void launch_fft_big(hipStream_t st, const PbsArgs &a, const FftTables &tb) {  // N >= 8192, k = 1
+  HX_PANIC_IF_FALSE(a.acc_scratch != nullptr, "PBS scratch of a polynomial_size >= 8192 set has no accumulator buffer");
+  const size_t smem = fbuf_bytes(N);
+  HX_CHECK(hipFuncSetAttribute((const void *)pbs_fft_generic_kernel<N, 2, true>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  HX_LAUNCH((pbs_fft_generic_kernel<N, 2, true>), dim3(a.num_samples), dim3(GenericCfg<N>::TPB), smem, st, a, tb);
+}
 template <int N, int K1>
 static void launch_fft(hipStream_t st, const PbsArgs &a, const FftTables &tb) {
   // one group per polynomial pays off for k = 1 (43.5k PBS/s at 2_2); with three groups (k = 2, N = 1024) the
@@ -469,6 +480,12 @@ static void launch_ntt(hipStream_t st, const PbsArgs &a, const NttTables &tb) {
   } while (0)
 
 void launch_pbs_fft_generic(hipStream_t st, uint32_t N, uint32_t glwe_dim, const PbsArgs &a, const FftTables &tb) {
+  if (N > 4096) {  // f64 engine only, k = 1 (the reference's 3_3 / 4_4 sets)
+    HX_PANIC_IF_FALSE(glwe_dim == 1 && (N == 8192 || N == 16384),
+                      "unsupported (polynomial_size=%u, glwe_dimension=%u) for the MI355X PBS", N, glwe_dim);
+    if (N == 8192) launch_fft_big<8192>(st, a, tb); else launch_fft_big<16384>(st, a, tb);
+    return;
+  }
   HX_DISPATCH_NK(launch_fft, st, a, tb);
 }
 template <int N, int K1>
@@ -486,6 +503,9 @@ void launch_pbs_ntt_generic(hipStream_t st, uint32_t N, uint32_t glwe_dim, const
 }
 
 template <int N> static void launch_conv_f(hipStream_t st, const uint64_t *src, void *dst, size_t polys, const FftTables &tb, int slot_order) {
+  if (fbuf_bytes(N) > 48 * 1024)
+    HX_CHECK(hipFuncSetAttribute((const void *)bsk_to_fourier_kernel<N>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)fbuf_bytes(N)));
   HX_LAUNCH((bsk_to_fourier_kernel<N>), dim3((unsigned)polys), dim3(GenericCfg<N>::TPB), fbuf_bytes(N), st, src, (cplx *)dst, tb, slot_order);
 }
 template <int N> static void launch_conv_n(hipStream_t st, const uint64_t *src, void *dst, size_t polys, const NttTables &tb) {
@@ -503,6 +523,8 @@ template <int N> static void launch_conv_n(hipStream_t st, const uint64_t *src, 
 void launch_bsk_to_fourier(hipStream_t st, uint32_t N, uint32_t glwe_dim, const uint64_t *src_dev, void *dst, size_t polys, const FftTables &tb) {
   // must agree with bsk_slot<N, K1>
   const int slot_order = (N == 2048 && glwe_dim == 1) ? 1 : (N == 1024 && (glwe_dim == 1 || glwe_dim == 2)) ? 2 : 0;
+  if (N == 8192) return launch_conv_f<8192>(st, src_dev, dst, polys, tb, slot_order);
+  if (N == 16384) return launch_conv_f<16384>(st, src_dev, dst, polys, tb, slot_order);
   HX_DISPATCH_N(launch_conv_f, st, src_dev, dst, polys, tb, slot_order);
 }
 void launch_bsk_to_ntt(hipStream_t st, uint32_t N, const uint64_t *src_dev, void *dst, size_t polys, const NttTables &tb) {
