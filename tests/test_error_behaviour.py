@@ -40,6 +40,14 @@ ABORTS = {
         buf = C.c_void_p()
         lib.scratch_cuda_programmable_bootstrap_64_async(S, G, C.byref(buf), 10, 1, 1000, 1, 4, True, 0)
         """, "polynomial_size 1000 not supported"),
+    "polynomial size beyond the reference's GPU range": ("""
+        buf = C.c_void_p()
+        lib.scratch_cuda_programmable_bootstrap_64_async(S, G, C.byref(buf), 10, 1, 32768, 1, 4, True, 0)
+        """, "polynomial_size 32768 not supported"),
+    "large ring with glwe_dimension above 1": ("""
+        buf = C.c_void_p()
+        lib.scratch_cuda_programmable_bootstrap_64_async(S, G, C.byref(buf), 10, 2, 8192, 1, 4, True, 0)
+        """, "supported with glwe_dimension 1 only"),
     "launch does not match its scratch": ("""
         buf = C.c_void_p()
         lib.scratch_cuda_programmable_bootstrap_64_async(S, G, C.byref(buf), 10, 1, 256, 1, 4, True, 0)
