@@ -53,6 +53,9 @@ C33 = Params("PARAM_MESSAGE_3_CARRY_3_N8192", 1006, 1, 8192, 15, 2, 3, 7, 45, 17
 C4 = Params("PARAM_MULTI_BIT_GROUP_3_MESSAGE_2_CARRY_2", 918, 1, 2048, 15, 2, 3, 6, 45, 17, 16,
             grouping=3)
 
+# the reference's GPU default (v1_1/multi_bit/tuniform/p_fail_2_minus_128/ks_pbs_gpu.rs:205-228); timing only
+C4G4 = Params("PARAM_GPU_MULTI_BIT_GROUP_4_MESSAGE_2_CARRY_2", 920, 1, 2048, 22, 1, 3, 5, 45, 17, 16, grouping=4)
+
 TOY_K1 = Params("toy_k1_N256", 24, 1, 256, 15, 2, 4, 5, 40, 20, 4, ms_type=1)
 TOY_K1_L1 = Params("toy_k1_N512_l1", 32, 1, 512, 23, 1, 4, 5, 40, 12, 4, ms_type=0)
 TOY_K2 = Params("toy_k2_N256", 20, 2, 256, 12, 3, 3, 6, 40, 20, 4, ms_type=1)

@@ -17,7 +17,7 @@ import numpy as np  # noqa: E402
 import tfhe_rs_amd  # noqa: E402,F401
 from tfhe_rs_amd import core_crypto_gpu as gpu  # noqa: E402
 from tfhe_rs_amd import ffi  # noqa: E402
-from tests.common import C1, C1P, C33, C4  # noqa: E402
+from tests.common import C1, C1P, C33, C4, C4G4  # noqa: E402
 
 lib = ffi.default_library()
 streams = gpu.CudaStreams.new_single_gpu(0)
@@ -133,6 +133,9 @@ if __name__ == "__main__":
     if "ks32" in which:
         ks32_case(C1, 4096)
         ks32_case(C1P, 4096)
+    if "mb4" in which:  # the reference's GPU default set (grouping factor 4, one level)
+        pbs_case(C4G4, 4096, steps=2)
+        pbs_case(C4G4, 1, steps=3)
     if "n8192" in which:  # the 3_3 set: generic kernel with the accumulator in device memory
         ks_case(C33, 1024)
         pbs_case(C33, 1024, steps=2)
