@@ -319,8 +319,11 @@ uint64_t hip_integer_propagate_pbs_count(uint32_t num_blocks);
  *     throughput kernel; generic otherwise),
  * 1 = generic LDS kernel, 2 = throughput (wave) kernel of the parameter set, 3 = latency (block) kernel, 4 = its dual-stream
  * variant; 2..4 abort on unsupported parameter sets.  For the multi-bit entry point 2 selects the
- * multi-bit mode of the throughput kernel, 1 the generic multi-bit kernel. */
+ * multi-bit mode of the throughput kernel, 1 the generic multi-bit kernel, 5 the two-launch latency path (all
+ * keybundles first, one workgroup per polynomial; then the products) that 0 takes up to 64 LWEs. */
 void hip_backend_set_fft_kernel(uint32_t which);
+/* test hook: cap of the groups the multi-bit latency path processes per pass (0 = what the scratch holds) */
+void hip_backend_set_multibit_latency_groups(uint32_t groups);
 /* keyswitch kernel: 0 = automatic (int8 matrix-core GEMM for >= 64 LWEs when level <= 16 (padded to a power of
  * two), base_log <= 6 and n_in*padded level is a multiple of 32; scalar kernels otherwise), 1 = scalar kernels only.
  * Identical bits either way. */
@@ -329,7 +332,8 @@ void hip_backend_set_keyswitch_kernel(uint32_t which);
  * kernels. Same bits. */
 void hip_backend_set_ntt_kernel(uint32_t which);
 /* last launched PBS kernel, for tests: 1 generic f64, 2 wave f64, 3 generic ntt, 4 generic multi-bit,
- * 5 exact, 6 wave multi-bit, 7 block (latency), 8 block dual-stream, 9 wave f64 for N = 1024 */
+ * 5 exact, 6 wave multi-bit, 7 block (latency), 8 block dual-stream, 9 wave f64 for N = 1024,
+ * 10 multi-bit latency path */
 uint32_t hip_backend_last_pbs_kernel(void);
 const char *hip_backend_version(void);
 

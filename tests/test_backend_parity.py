@@ -484,6 +484,39 @@ def test_multi_bit_throughput_kernel_equals_generic_and_oracle(kind, which):
     assert [decrypt_big(p, c.keys, o) for o in out] == [f(m) for m in msgs]
 
 
+@pytest.mark.parametrize("kind", BACKENDS)
+@pytest.mark.parametrize("which", ["g3", "g2", "g3_N2048"])
+def test_multi_bit_latency_path_equals_oracle(kind, which):
+    """Small batches: all keybundles first (one workgroup per group and polynomial), then the external products
+    (kernel id 10); in one pass and in passes of 2 groups with the accumulator crossing passes in device memory.
+    Same bits as the oracle and as the one-launch kernels."""
+    from .common import TOY_MB, TOY_MB2, TOY_MB_2048
+    p = {"g3": TOY_MB, "g2": TOY_MB2, "g3_N2048": TOY_MB_2048}[which]
+    c = ctx(kind, p, "fft64")
+    lib = use_backend(kind)
+    msgs = [m % p.plaintext_modulus for m in range(5)]
+    cts = encrypt_small(p, c.keys, msgs, seed=23)
+    f = lambda x: (3 * x + 2) % p.plaintext_modulus
+    lut = orc.generate_lut(p.k, p.N, p.plaintext_modulus, p.delta, f)
+    ref = oracle_pbs(p, c.keys, "fft64", cts, lut)
+    try:
+        lib.hip_backend_set_fft_kernel(5)
+        one_pass = c.pbs(cts, lut)
+        assert lib.hip_backend_last_pbs_kernel() == 10
+        lib.hip_backend_set_multibit_latency_groups(2)
+        chunked = c.pbs(cts, lut)
+        lib.hip_backend_set_fft_kernel(1)
+        generic = c.pbs(cts, lut)
+        assert lib.hip_backend_last_pbs_kernel() == 4
+    finally:
+        lib.hip_backend_set_fft_kernel(0)
+        lib.hip_backend_set_multibit_latency_groups(0)
+    assert np.array_equal(one_pass, ref)
+    assert np.array_equal(chunked, ref)
+    assert np.array_equal(generic, ref)
+    assert [decrypt_big(p, c.keys, o) for o in one_pass] == [f(m) for m in msgs]
+
+
 @pytest.mark.gpu
 def test_multi_bit_full_size_group3():
     """PARAM_MULTI_BIT_GROUP_3_MESSAGE_2_CARRY_2 (n=918, N=2048, l=2, base_log=15, g=3)."""

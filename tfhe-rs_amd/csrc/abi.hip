@@ -39,6 +39,9 @@ struct MultiBitBuffer {
   uint32_t chunk;
   cplx *keybundle;
   uint64_t *acc;
+  // latency path (small batches): keybundles of lat_groups groups for lat_samples ciphertexts
+  cplx *kb_lat = nullptr;
+  uint32_t lat_samples = 0, lat_groups = 0;
 };
 
 // max_n: 16384 for the classic f64 PBS (programmable_bootstrap_classic.cuh supports rings up to 2^14), 4096 for
@@ -48,6 +51,8 @@ void check_pow2_poly(uint32_t N, uint32_t max_n = 4096) {
                     "polynomial_size %u not supported by the MI355X PBS (256..%u, power of two)", N, max_n);
 }
 
+constexpr uint32_t kMultiBitLatencyMaxBatch = 64;  // multi-bit PBS: two-launch latency path up to this many LWEs
+std::atomic<uint32_t> g_multibit_latency_groups{0};  // test hook: cap of the groups per pass (0 = what the scratch holds)
 constexpr uint32_t kLatencyKernelMaxBatch = 256;  // measured (tools/measure_all.py latency): 3.7-3.9 ms vs 5.9 ms up to 256 LWEs, slower beyond
 
 PbsArgs make_args(void *lwe_array_out, void const *lwe_output_indexes, void const *lut_vector,
@@ -388,13 +393,21 @@ uint64_t scratch_cuda_multi_bit_programmable_bootstrap_64_async(void *stream, ui
   const size_t acc_per_sample = 2 * k1 * polynomial_size * sizeof(uint64_t);
   b->chunk = input_lwe_ciphertext_count ? input_lwe_ciphertext_count : 1;
   const uint64_t bytes = (uint64_t)b->chunk * (kb_per_sample + acc_per_sample);
+  // latency path: up to 64 ciphertexts, as many groups per pass as 2 GiB hold (the scratch is sized without
+  // knowing n or the grouping factor, like the reference's lwe_chunk_size)
+  b->lat_samples = b->chunk < kMultiBitLatencyMaxBatch ? b->chunk : kMultiBitLatencyMaxBatch;
+  const size_t per_group = (size_t)b->lat_samples * kb_per_sample;
+  size_t lat_groups = ((size_t)2 << 30) / per_group;
+  b->lat_groups = (uint32_t)(lat_groups < 1 ? 1 : lat_groups > 1024 ? 1024 : lat_groups);
+  const uint64_t lat_bytes = (uint64_t)b->lat_groups * per_group;
   if (allocate_gpu_memory) {
     b->fft = get_fft_tables(gpu_index, S(stream), polynomial_size);
     HX_CHECK(hipMalloc((void **)&b->keybundle, (size_t)b->chunk * kb_per_sample));
     HX_CHECK(hipMalloc((void **)&b->acc, (size_t)b->chunk * acc_per_sample));
+    HX_CHECK(hipMalloc((void **)&b->kb_lat, lat_bytes));
   }
   *pbs_buffer = reinterpret_cast<int8_t *>(b);
-  return bytes;
+  return bytes + lat_bytes;
 }
 
 void cuda_multi_bit_programmable_bootstrap_64_async(void *stream, uint32_t gpu_index, void *lwe_array_out,
@@ -426,7 +439,15 @@ void cuda_multi_bit_programmable_bootstrap_64_async(void *stream, uint32_t gpu_i
   const bool wave_ok = pbs_multi_bit_wave_supported(polynomial_size, glwe_dimension, level_count, base_log,
                                                     grouping_factor);
   if (choice == 2) HX_PANIC_IF_FALSE(wave_ok, "throughput kernel requested for an unsupported parameter set");
-  if ((choice == 0 && wave_ok) || choice == 2) {
+  if (choice == 5) HX_PANIC_IF_FALSE(num_samples <= b->lat_samples, "multi-bit latency path: %u samples exceed %u",
+                                     num_samples, b->lat_samples);
+  if (choice == 5 || (choice == 0 && num_samples <= b->lat_samples)) {
+    // few ciphertexts: every (group, keybundle polynomial) gets its own workgroup, then the products run alone
+    uint32_t gc = g_multibit_latency_groups.load();
+    gc = (gc == 0 || gc > b->lat_groups) ? b->lat_groups : gc;
+    launch_pbs_multi_bit_latency(S(stream), polynomial_size, glwe_dimension, m, b->fft, b->kb_lat, gc, b->acc);
+    g_last_pbs_kernel.store(10);
+  } else if ((choice == 0 && wave_ok) || choice == 2) {
     m.pbs.grouping = grouping_factor;
     m.pbs.keybundle = b->keybundle;
     launch_pbs_multi_bit_wave(S(stream), m.pbs, b->fft);
@@ -444,6 +465,7 @@ void cleanup_cuda_multi_bit_programmable_bootstrap_64(void *stream, uint32_t gpu
   HX_CHECK(hipStreamSynchronize(S(stream)));
   if (b->keybundle) HX_CHECK(hipFree(b->keybundle));
   if (b->acc) HX_CHECK(hipFree(b->acc));
+  if (b->kb_lat) HX_CHECK(hipFree(b->kb_lat));
   b->magic = 0;
   delete b;
   *pbs_buffer = nullptr;
@@ -544,6 +566,7 @@ void cuda_centered_modulus_switch_64_async(void *stream, uint32_t gpu_index, voi
 void hip_backend_set_fft_kernel(uint32_t which) { g_fft_kernel_choice.store(which); }
 void hip_backend_set_keyswitch_kernel(uint32_t which) { g_keyswitch_use_mfma = (which != 1); }
 void hip_backend_set_ntt_kernel(uint32_t which) { g_ntt_kernel_serial = (which == 1); }
+void hip_backend_set_multibit_latency_groups(uint32_t groups) { g_multibit_latency_groups.store(groups); }
 uint32_t hip_backend_last_pbs_kernel(void) { return g_last_pbs_kernel.load(); }
 const char *hip_backend_version(void) {
 #if defined(TFHE_HIPEMU)

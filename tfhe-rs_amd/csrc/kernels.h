@@ -53,6 +53,9 @@ struct MultiBitArgs {
 };
 void launch_pbs_multi_bit(hipStream_t st, uint32_t N, uint32_t glwe_dim, const MultiBitArgs &a, const FftTables &tb,
                           uint64_t *acc_scratch);
+// small batches: all keybundles of `group_chunk` groups first (one workgroup per polynomial), then the products
+void launch_pbs_multi_bit_latency(hipStream_t st, uint32_t N, uint32_t glwe_dim, const MultiBitArgs &a,
+                                  const FftTables &tb, cplx *kb_lat, uint32_t group_chunk, uint64_t *acc_g);
 
 // unit-test kernels (device functions exposed for parity tests) — testhooks.hip
 void launch_test_arith(hipStream_t st, uint32_t op, const uint64_t *in, uint64_t *out, uint32_t count, uint32_t p0, uint32_t p1);

@@ -123,6 +123,149 @@ __global__ void __launch_bounds__(GenericCfg<N>::TPB)
   block_sample_extract<N, K1, TPB>(a, acc, sample, 0, false, tid);
 }
 
+// ------------------------------------------------------------------------- latency path (small batches)
+// The keybundles depend on the LWE mask only, not on the accumulator, so they are all built up front by as many
+// workgroups as there are (group, keybundle polynomial) pairs — the whole chip works for ONE ciphertext, which is
+// what the reference's multi-block launch achieves (programmable_bootstrap_multibit.cuh:40-330) — and only the
+// n/g external products remain sequential.  Same integer combine, same transforms, same product order as
+// pbs_multi_bit_kernel: identical bits.  Groups are processed in chunks of at most `gcount` (the scratch is
+// sized without knowing n, like the reference's lwe_chunk_size), the accumulator crossing chunks in `acc_g`.
+template <int N, int K1>
+__global__ void __launch_bounds__(GenericCfg<N>::TPB)
+    mb_keybundle_kernel(PbsArgs a, uint32_t grouping, cplx *kb_lat, FftTables tb, uint32_t g0, uint32_t gcount) {
+  constexpr int n = N / 2, TPB = GenericCfg<N>::TPB, PER = n / TPB, LOG2N2 = ilog2_c(2 * N);
+  HX_DYN_SMEM(smem);
+  const FBuf fbuf{(cplx *)smem};
+  uint64_t *kbuf = (uint64_t *)fbuf.p;
+  const int tid = threadIdx.x;
+  const uint32_t sample = blockIdx.y;
+  const size_t kb_polys = (size_t)a.level * K1 * K1;
+  const uint32_t gl = blockIdx.x / (uint32_t)kb_polys, poly = blockIdx.x % (uint32_t)kb_polys, grp = g0 + gl;
+  const uint64_t *lwe = a.lwe_in + (size_t)a.in_idx[sample] * (a.n + 1);
+  const uint32_t per = 1u << grouping;
+  const size_t ggsw_sz = kb_polys * N;
+  const uint64_t *gk = (const uint64_t *)a.bsk + (size_t)grp * per * ggsw_sz;
+  uint32_t deg[16];
+  for (uint32_t s = 1; s < per; ++s) {
+    uint64_t sum = 0;
+    for (uint32_t m = 0; m < grouping; ++m)
+      if ((s >> (grouping - 1 - m)) & 1) sum += lwe[(size_t)grp * grouping + m];
+    deg[s] = (uint32_t)modulus_switch(sum, LOG2N2);
+  }
+  for (uint32_t j = tid; j < (uint32_t)N; j += TPB) {
+    uint64_t v = gk[poly * N + j];
+    for (uint32_t s = 1; s < per; ++s) {
+      bool neg;
+      const uint32_t src = monomial_mul_src(j, deg[s], N, neg);
+      const uint64_t x = gk[(size_t)s * ggsw_sz + poly * N + src];
+      v += neg ? (uint64_t)0 - x : x;
+    }
+    kbuf[j] = v;
+  }
+  __syncthreads();
+  cplx z[PER];
+  for (int q = 0; q < PER; ++q) {
+    const int j = tid + q * TPB;
+    z[q] = cplx{i64_to_f64((int64_t)kbuf[j]) * 5.421010862427522e-20, i64_to_f64((int64_t)kbuf[j + n]) * 5.421010862427522e-20};
+  }
+  __syncthreads();
+  for (int q = 0; q < PER; ++q) fbuf[tid + q * TPB] = z[q];
+  __syncthreads();
+  lds_fft_forward<N, TPB>(fbuf, tb.fwd, tid);
+  cplx *kb = kb_lat + (((size_t)sample * gcount + gl) * kb_polys + poly) * n;
+  for (int q = 0; q < PER; ++q) kb[tid + q * TPB] = fbuf[tid + q * TPB];
+}
+
+template <int N, int K1>
+__global__ void __launch_bounds__(GenericCfg<N>::TPB)
+    mb_accumulate_kernel(PbsArgs a, const cplx *kb_lat, FftTables tb, uint64_t *acc_g, uint32_t gcount, uint32_t gpass,
+                         int first, int last) {
+  constexpr int n = N / 2, TPB = GenericCfg<N>::TPB, PER = n / TPB, LOG2N2 = ilog2_c(2 * N);
+  HX_DYN_SMEM(smem);
+  uint64_t *acc = (uint64_t *)smem;
+  const FBuf fbuf{(cplx *)(smem + (size_t)K1 * N * 8)};
+  const int tid = threadIdx.x;
+  const uint32_t sample = blockIdx.x;
+  const uint64_t *lwe = a.lwe_in + (size_t)a.in_idx[sample] * (a.n + 1);
+  const uint64_t *lut = a.lut + (size_t)a.lut_idx[sample] * K1 * N;
+  const size_t kb_polys = (size_t)a.level * K1 * K1;
+  uint64_t *mine = acc_g + (size_t)sample * K1 * N;
+  if (first) {
+    const uint32_t b_hat = (uint32_t)modulus_switch(lwe[a.n], LOG2N2);
+    for (int p = 0; p < K1; ++p)
+      for (uint32_t j = tid; j < (uint32_t)N; j += TPB) {
+        bool neg;
+        const uint32_t src = monomial_div_src(j, b_hat, N, neg);
+        const uint64_t v = lut[p * N + src];
+        acc[p * N + j] = neg ? (uint64_t)0 - v : v;
+      }
+  } else {
+    for (uint32_t j = tid; j < (uint32_t)(K1 * N); j += TPB) acc[j] = mine[j];
+  }
+  __syncthreads();
+  for (uint32_t gl = 0; gl < gpass; ++gl) {
+    const cplx *kb = kb_lat + (((size_t)sample * gcount + gl) * kb_polys) * n;
+    cplx facc[K1][PER];
+    bool firstp = true;
+    for (uint32_t idx = 0; idx < a.level; ++idx) {
+      for (int row = 0; row < K1; ++row) {
+        for (int q = 0; q < PER; ++q) {
+          const uint32_t j = tid + q * TPB;
+          const int64_t d0 = decomp_digit(acc[row * N + j], a.base_log, a.level, idx);
+          const int64_t d1 = decomp_digit(acc[row * N + j + n], a.base_log, a.level, idx);
+          fbuf[j] = cplx{i64_to_f64(d0), i64_to_f64(d1)};
+        }
+        __syncthreads();
+        lds_fft_forward<N, TPB>(fbuf, tb.fwd, tid);
+        const cplx *brow = kb + (((size_t)idx * K1 + row) * K1) * n;
+        for (int c = 0; c < K1; ++c)
+          for (int q = 0; q < PER; ++q) {
+            const int pos = tid + q * TPB;
+            const cplx y = brow[(size_t)c * n + pos];
+            facc[c][q] = firstp ? cmul_first(fbuf[pos], y) : cmul_add(fbuf[pos], y, facc[c][q]);
+          }
+        firstp = false;
+        __syncthreads();
+      }
+    }
+    for (int c = 0; c < K1; ++c) {
+      for (int q = 0; q < PER; ++q) fbuf[tid + q * TPB] = facc[c][q];
+      __syncthreads();
+      lds_fft_inverse<N, TPB>(fbuf, tb.inv, tid);
+      for (int q = 0; q < PER; ++q) {
+        const int j = tid + q * TPB;
+        const cplx y = fbuf[j];
+        const double ur = tb.untw[2 * j], ui = tb.untw[2 * j + 1];
+        acc[c * N + j] = from_torus(fma(-y.im, ui, y.re * ur));
+        acc[c * N + j + n] = from_torus(fma(y.im, ur, y.re * ui));
+      }
+      __syncthreads();
+    }
+  }
+  if (last) {
+    block_sample_extract<N, K1, TPB>(a, acc, sample, 0, false, tid);
+  } else {
+    for (uint32_t j = tid; j < (uint32_t)(K1 * N); j += TPB) mine[j] = acc[j];
+  }
+}
+
+template <int N, int K1>
+static void launch_mb_latency(hipStream_t st, const MultiBitArgs &m, const FftTables &tb, cplx *kb_lat,
+                              uint32_t group_chunk, uint64_t *acc_g) {
+  const PbsArgs &a = m.pbs;
+  const uint32_t groups = a.n / m.grouping_factor, kb_polys = a.level * K1 * K1;
+  const size_t smem_b = (size_t)K1 * N * 8 + fbuf_bytes(N);
+  HX_CHECK(hipFuncSetAttribute((const void *)mb_accumulate_kernel<N, K1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)smem_b));
+  for (uint32_t g0 = 0; g0 < groups; g0 += group_chunk) {
+    const uint32_t gpass = groups - g0 < group_chunk ? groups - g0 : group_chunk;
+    HX_LAUNCH((mb_keybundle_kernel<N, K1>), dim3(gpass * kb_polys, a.num_samples), dim3(GenericCfg<N>::TPB),
+              fbuf_bytes(N), st, a, m.grouping_factor, kb_lat, tb, g0, group_chunk);
+    HX_LAUNCH((mb_accumulate_kernel<N, K1>), dim3(a.num_samples), dim3(GenericCfg<N>::TPB), smem_b, st, a,
+              (const cplx *)kb_lat, tb, acc_g, group_chunk, gpass, (int)(g0 == 0), (int)(g0 + gpass == groups));
+  }
+}
+
 template <int N, int K1>
 static void launch_mb(hipStream_t st, const MultiBitArgs &m, const FftTables &tb) {
   const size_t smem = (size_t)K1 * N * 8 + fbuf_bytes(N);
@@ -143,6 +286,21 @@ void launch_pbs_multi_bit(hipStream_t st, uint32_t N, uint32_t glwe_dim, const M
     case 1024: if (k1 == 2) launch_mb<1024, 2>(st, m, tb); else if (k1 == 3) launch_mb<1024, 3>(st, m, tb); else ok = false; break;
     case 2048: if (k1 == 2) launch_mb<2048, 2>(st, m, tb); else ok = false; break;
     case 4096: if (k1 == 2) launch_mb<4096, 2>(st, m, tb); else ok = false; break;
+    default: ok = false;
+  }
+  if (!ok) HX_PANIC("unsupported (polynomial_size=%u, glwe_dimension=%u) for the multi-bit PBS", N, glwe_dim);
+}
+
+void launch_pbs_multi_bit_latency(hipStream_t st, uint32_t N, uint32_t glwe_dim, const MultiBitArgs &m,
+                                  const FftTables &tb, cplx *kb_lat, uint32_t group_chunk, uint64_t *acc_g) {
+  const uint32_t k1 = glwe_dim + 1;
+  bool ok = true;
+  switch (N) {
+    case 256: if (k1 == 2) launch_mb_latency<256, 2>(st, m, tb, kb_lat, group_chunk, acc_g); else if (k1 == 3) launch_mb_latency<256, 3>(st, m, tb, kb_lat, group_chunk, acc_g); else ok = false; break;
+    case 512: if (k1 == 2) launch_mb_latency<512, 2>(st, m, tb, kb_lat, group_chunk, acc_g); else if (k1 == 3) launch_mb_latency<512, 3>(st, m, tb, kb_lat, group_chunk, acc_g); else ok = false; break;
+    case 1024: if (k1 == 2) launch_mb_latency<1024, 2>(st, m, tb, kb_lat, group_chunk, acc_g); else if (k1 == 3) launch_mb_latency<1024, 3>(st, m, tb, kb_lat, group_chunk, acc_g); else ok = false; break;
+    case 2048: if (k1 == 2) launch_mb_latency<2048, 2>(st, m, tb, kb_lat, group_chunk, acc_g); else ok = false; break;
+    case 4096: if (k1 == 2) launch_mb_latency<4096, 2>(st, m, tb, kb_lat, group_chunk, acc_g); else ok = false; break;
     default: ok = false;
   }
   if (!ok) HX_PANIC("unsupported (polynomial_size=%u, glwe_dimension=%u) for the multi-bit PBS", N, glwe_dim);

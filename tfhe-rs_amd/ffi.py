@@ -106,6 +106,7 @@ SIGNATURES = {
     "hip_test_fft_tables_host": (None, [_u32, _v, _v, _v]),
     "hip_backend_set_keyswitch_kernel": (None, [_u32]),
     "hip_backend_set_ntt_kernel": (None, [_u32]),
+    "hip_backend_set_multibit_latency_groups": (None, [_u32]),
     # radix integers
     "scratch_cuda_apply_univariate_lut_64_async": (_u64, [_S, _i8pp, _v, _BK, _KK, _u32, _u32, _u32, _u64, _b, _u32]),
     "cuda_apply_univariate_lut_64_async": (None, [_S, _R, _R, _v, _i8pp, _i8pp]),
