@@ -51,7 +51,7 @@ void check_pow2_poly(uint32_t N, uint32_t max_n = 4096) {
                     "polynomial_size %u not supported by the MI355X PBS (256..%u, power of two)", N, max_n);
 }
 
-constexpr uint32_t kMultiBitLatencyMaxBatch = 64;  // multi-bit PBS: two-launch latency path up to this many LWEs
+constexpr uint32_t kMultiBitLatencyMaxBatch = 128;  // multi-bit PBS: two-launch latency path up to this many LWEs
 std::atomic<uint32_t> g_multibit_latency_groups{0};  // test hook: cap of the groups per pass (0 = what the scratch holds)
 constexpr uint32_t kLatencyKernelMaxBatch = 256;  // measured (tools/measure_all.py latency): 3.7-3.9 ms vs 5.9 ms up to 256 LWEs, slower beyond
 
