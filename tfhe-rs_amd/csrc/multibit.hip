@@ -249,20 +249,101 @@ __global__ void __launch_bounds__(GenericCfg<N>::TPB)
   }
 }
 
+// The same products with one thread group per GLWE polynomial (as pbs_fft_par_kernel): the k+1 forward transforms
+// of a level and the k+1 inverse transforms run side by side, half the barrier-separated stages for k = 1.
+// Per output point the products are accumulated in the same order (level, then row): identical bits.
+template <int N, int K1>
+__global__ void __launch_bounds__(K1 *GenericCfg<N>::TPB)
+    mb_accumulate_par_kernel(PbsArgs a, const cplx *kb_lat, FftTables tb, uint64_t *acc_g, uint32_t gcount,
+                             uint32_t gpass, int first, int last) {
+  constexpr int n = N / 2, TPB = GenericCfg<N>::TPB, TPBT = K1 * TPB, PER = n / TPB, LOG2N2 = ilog2_c(2 * N);
+  HX_DYN_SMEM(smem);
+  uint64_t *acc = (uint64_t *)smem;
+  cplx *fbase = (cplx *)(smem + (size_t)K1 * N * 8);
+  const int tid = threadIdx.x;
+  const int grp = tid / TPB, lt = tid - grp * TPB;  // my row (forward) / column (inverse), thread inside it
+  const uint32_t sample = blockIdx.x;
+  const uint64_t *lwe = a.lwe_in + (size_t)a.in_idx[sample] * (a.n + 1);
+  const uint64_t *lut = a.lut + (size_t)a.lut_idx[sample] * K1 * N;
+  const size_t kb_polys = (size_t)a.level * K1 * K1;
+  uint64_t *mine = acc_g + (size_t)sample * K1 * N;
+  const FBuf mybuf{fbase + (size_t)grp * fbuf_slots(N)};
+  if (first) {
+    const uint32_t b_hat = (uint32_t)modulus_switch(lwe[a.n], LOG2N2);
+    for (uint32_t j = lt; j < (uint32_t)N; j += TPB) {
+      bool neg;
+      const uint32_t src = monomial_div_src(j, b_hat, N, neg);
+      const uint64_t v = lut[grp * N + src];
+      acc[grp * N + j] = neg ? (uint64_t)0 - v : v;
+    }
+  } else {
+    for (uint32_t j = tid; j < (uint32_t)(K1 * N); j += TPBT) acc[j] = mine[j];
+  }
+  __syncthreads();
+  for (uint32_t gl = 0; gl < gpass; ++gl) {
+    const cplx *kb = kb_lat + (((size_t)sample * gcount + gl) * kb_polys) * n;
+    cplx facc[PER];
+    for (uint32_t idx = 0; idx < a.level; ++idx) {
+      for (int q = 0; q < PER; ++q) {  // digits of my row of the accumulator itself
+        const uint32_t j = lt + q * TPB;
+        const int64_t d0 = decomp_digit(acc[grp * N + j], a.base_log, a.level, idx);
+        const int64_t d1 = decomp_digit(acc[grp * N + j + n], a.base_log, a.level, idx);
+        mybuf[j] = cplx{i64_to_f64(d0), i64_to_f64(d1)};
+      }
+      __syncthreads();
+      lds_fft_forward<N, TPB>(mybuf, tb.fwd, lt);
+      for (int row = 0; row < K1; ++row) {  // column `grp` of the external product
+        const cplx *brow = kb + (((size_t)idx * K1 + row) * K1 + grp) * n;
+        const FBuf f{fbase + (size_t)row * fbuf_slots(N)};
+        for (int q = 0; q < PER; ++q) {
+          const int pos = lt + q * TPB;
+          const cplx y = brow[pos];
+          facc[q] = (idx == 0 && row == 0) ? cmul_first(f[pos], y) : cmul_add(f[pos], y, facc[q]);
+        }
+      }
+      __syncthreads();
+    }
+    for (int q = 0; q < PER; ++q) mybuf[lt + q * TPB] = facc[q];
+    __syncthreads();
+    lds_fft_inverse<N, TPB>(mybuf, tb.inv, lt);
+    for (int q = 0; q < PER; ++q) {
+      const int j = lt + q * TPB;
+      const cplx y = mybuf[j];
+      const double ur = tb.untw[2 * j], ui = tb.untw[2 * j + 1];
+      acc[grp * N + j] = from_torus(fma(-y.im, ui, y.re * ur));
+      acc[grp * N + j + n] = from_torus(fma(y.im, ur, y.re * ui));
+    }
+    __syncthreads();
+  }
+  if (last) {
+    block_sample_extract<N, K1, TPBT>(a, acc, sample, 0, false, tid);
+  } else {
+    for (uint32_t j = tid; j < (uint32_t)(K1 * N); j += TPBT) mine[j] = acc[j];
+  }
+}
+
 template <int N, int K1>
 static void launch_mb_latency(hipStream_t st, const MultiBitArgs &m, const FftTables &tb, cplx *kb_lat,
                               uint32_t group_chunk, uint64_t *acc_g) {
   const PbsArgs &a = m.pbs;
   const uint32_t groups = a.n / m.grouping_factor, kb_polys = a.level * K1 * K1;
   const size_t smem_b = (size_t)K1 * N * 8 + fbuf_bytes(N);
+  const size_t smem_p = (size_t)K1 * N * 8 + (size_t)K1 * fbuf_bytes(N);
   HX_CHECK(hipFuncSetAttribute((const void *)mb_accumulate_kernel<N, K1>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)smem_b));
+  if (K1 == 2)
+    HX_CHECK(hipFuncSetAttribute((const void *)mb_accumulate_par_kernel<N, K1>,
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_p));
   for (uint32_t g0 = 0; g0 < groups; g0 += group_chunk) {
     const uint32_t gpass = groups - g0 < group_chunk ? groups - g0 : group_chunk;
     HX_LAUNCH((mb_keybundle_kernel<N, K1>), dim3(gpass * kb_polys, a.num_samples), dim3(GenericCfg<N>::TPB),
               fbuf_bytes(N), st, a, m.grouping_factor, kb_lat, tb, g0, group_chunk);
-    HX_LAUNCH((mb_accumulate_kernel<N, K1>), dim3(a.num_samples), dim3(GenericCfg<N>::TPB), smem_b, st, a,
-              (const cplx *)kb_lat, tb, acc_g, group_chunk, gpass, (int)(g0 == 0), (int)(g0 + gpass == groups));
+    if (K1 == 2 && !g_ntt_kernel_serial)  // same rule as the classic generic kernels (hip_backend_set_ntt_kernel)
+      HX_LAUNCH((mb_accumulate_par_kernel<N, K1>), dim3(a.num_samples), dim3(K1 * GenericCfg<N>::TPB), smem_p, st, a,
+                (const cplx *)kb_lat, tb, acc_g, group_chunk, gpass, (int)(g0 == 0), (int)(g0 + gpass == groups));
+    else
+      HX_LAUNCH((mb_accumulate_kernel<N, K1>), dim3(a.num_samples), dim3(GenericCfg<N>::TPB), smem_b, st, a,
+                (const cplx *)kb_lat, tb, acc_g, group_chunk, gpass, (int)(g0 == 0), (int)(g0 + gpass == groups));
   }
 }
 
