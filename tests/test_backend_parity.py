@@ -523,17 +523,29 @@ def test_multi_bit_latency_path_equals_oracle(kind, which):
 
 
 @pytest.mark.gpu
-def test_multi_bit_full_size_group3():
-    """PARAM_MULTI_BIT_GROUP_3_MESSAGE_2_CARRY_2 (n=918, N=2048, l=2, base_log=15, g=3)."""
-    from .common import C4
-    p = C4
+@pytest.mark.parametrize("which", ["g3_l2", "g4_l1"])
+def test_multi_bit_full_size(which):
+    """PARAM_MULTI_BIT_GROUP_3_MESSAGE_2_CARRY_2 (n=918, N=2048, l=2, base_log=15, g=3) and the reference's GPU
+    default PARAM_GPU_MULTI_BIT_GROUP_4_MESSAGE_2_CARRY_2 (n=920, l=1, base_log=22, g=4): the latency path (what
+    a batch of 12 takes) and the throughput kernel give the oracle's bits, and every output decrypts."""
+    from .common import C4, C4G4
+    p = C4 if which == "g3_l2" else C4G4
     keys = make_keys(p, with_ksk=False)
     msgs = [m % 16 for m in range(12)]
     cts = encrypt_small(p, keys, msgs, seed=51)
     f = lambda x: (x * x) % 16
     lut = orc.generate_lut(p.k, p.N, p.plaintext_modulus, p.delta, f)
     c = Ctx("hip", p, keys, "fft64")
+    lib = use_backend("hip")
     out = c.pbs(cts, lut)
+    assert lib.hip_backend_last_pbs_kernel() == 10
+    try:
+        lib.hip_backend_set_fft_kernel(2)
+        wave = c.pbs(cts, lut)
+        assert lib.hip_backend_last_pbs_kernel() == 6
+    finally:
+        lib.hip_backend_set_fft_kernel(0)
+    assert np.array_equal(out, wave)
     assert [decrypt_big(p, keys, o) for o in out] == [f(m) for m in msgs]
     ref = oracle_pbs(p, keys, "fft64", cts[:3], lut)
     assert np.array_equal(out[:3], ref)
