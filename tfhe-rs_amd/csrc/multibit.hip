@@ -12,6 +12,8 @@
 //
 // One workgroup per LWE runs all groups in one launch: keybundle polynomial -> LDS -> forward
 // transform -> per-sample global scratch (stays in L2), then the external product reads it back.
+#include <atomic>
+
 #include "kernels.h"
 
 namespace tfhe_hip {
@@ -329,16 +331,26 @@ static void launch_mb_latency(hipStream_t st, const MultiBitArgs &m, const FftTa
   const uint32_t groups = a.n / m.grouping_factor, kb_polys = a.level * K1 * K1;
   const size_t smem_b = (size_t)K1 * N * 8 + fbuf_bytes(N);
   const size_t smem_p = (size_t)K1 * N * 8 + (size_t)K1 * fbuf_bytes(N);
-  HX_CHECK(hipFuncSetAttribute((const void *)mb_accumulate_kernel<N, K1>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)smem_b));
-  if (K1 == 2)
-    HX_CHECK(hipFuncSetAttribute((const void *)mb_accumulate_par_kernel<N, K1>,
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_p));
+  const bool par = K1 == 2 && !g_ntt_kernel_serial;  // same rule as the classic generic kernels (hip_backend_set_ntt_kernel)
+  // once per device and kernel: the call costs host time on a path that exists for latency
+  static std::atomic<uint64_t> done_par{0}, done_ser{0};
+  int dev = 0;
+  HX_CHECK(hipGetDevice(&dev));
+  std::atomic<uint64_t> &done = par ? done_par : done_ser;
+  if (!((done.load() >> (dev & 63)) & 1)) {
+    if (par)
+      HX_CHECK(hipFuncSetAttribute((const void *)mb_accumulate_par_kernel<N, K1>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_p));
+    else
+      HX_CHECK(hipFuncSetAttribute((const void *)mb_accumulate_kernel<N, K1>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_b));
+    done.fetch_or((uint64_t)1 << (dev & 63));
+  }
   for (uint32_t g0 = 0; g0 < groups; g0 += group_chunk) {
     const uint32_t gpass = groups - g0 < group_chunk ? groups - g0 : group_chunk;
     HX_LAUNCH((mb_keybundle_kernel<N, K1>), dim3(gpass * kb_polys, a.num_samples), dim3(GenericCfg<N>::TPB),
               fbuf_bytes(N), st, a, m.grouping_factor, kb_lat, tb, g0, group_chunk);
-    if (K1 == 2 && !g_ntt_kernel_serial)  // same rule as the classic generic kernels (hip_backend_set_ntt_kernel)
+    if (par)
       HX_LAUNCH((mb_accumulate_par_kernel<N, K1>), dim3(a.num_samples), dim3(K1 * GenericCfg<N>::TPB), smem_p, st, a,
                 (const cplx *)kb_lat, tb, acc_g, group_chunk, gpass, (int)(g0 == 0), (int)(g0 + gpass == groups));
     else
