@@ -344,7 +344,7 @@ float hip_event_elapsed_ms(void *start, void *stop); /* synchronises `stop` */
 void hip_event_destroy(void *event);
 
 /* test hooks: run single device functions / transforms so that tests can compare them with
- * the oracle (ops documented in tfhe-rs_amd/csrc/testhooks.hip) */
+ * the oracle (ops documented in tfhe_rs_amd/csrc/testhooks.hip) */
 void hip_test_arith_async(void *stream, uint32_t gpu_index, uint32_t op, void const *in,
                           void *out, uint32_t count, uint32_t p0, uint32_t p1);
 void hip_test_transform_async(void *stream, uint32_t gpu_index, uint32_t op,

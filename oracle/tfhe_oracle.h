@@ -3,7 +3,7 @@
  *
  * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product: only
  * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this
- * library, and only as the checker.  The product (tfhe-rs_amd/) never links,
+ * library, and only as the checker.  The product (tfhe_rs_amd/) never links,
  * imports or falls back to it.
  *
  * Every function cites the reference file:line it restates (paths relative to

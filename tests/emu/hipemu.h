@@ -1,6 +1,6 @@
 // hipemu.h — minimal host-side emulation of the HIP kernel language, TEST INFRASTRUCTURE ONLY.
 //
-// Purpose: compile the product's kernel sources (tfhe-rs_amd/csrc/*.hip) with g++ and run
+// Purpose: compile the product's kernel sources (tfhe_rs_amd/csrc/*.hip) with g++ and run
 // them on the CPU so that `pytest -m "not gpu"` can check the kernels' LOGIC bit-for-bit
 // against the oracle in a container without a GPU.  It is never linked into, loaded by, or
 // used as a fallback for the product library (libtfhe_hip_backend.so aborts without a GPU).

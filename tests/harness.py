@@ -1,6 +1,6 @@
 """Test harness: selects which build of the backend the parity tests drive.
 
-  "hip" — the product library tfhe-rs_amd/lib/libtfhe_hip_backend.so on a real MI355X
+  "hip" — the product library tfhe_rs_amd/lib/libtfhe_hip_backend.so on a real MI355X
           (tests marked `gpu`)
   "emu" — the SAME kernel sources compiled for the host by tests/emu (no GPU needed); this
           checks kernel logic only and is test infrastructure, never a product path.

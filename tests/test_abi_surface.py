@@ -9,7 +9,7 @@ import pytest
 
 ROOT = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), os.pardir))
 HEADER = os.path.join(ROOT, "include", "tfhe_hip_backend.h")
-LIB = os.path.join(ROOT, "tfhe-rs_amd", "lib", "libtfhe_hip_backend.so")
+LIB = os.path.join(ROOT, "tfhe_rs_amd", "lib", "libtfhe_hip_backend.so")
 
 
 def declared_symbols():
@@ -53,7 +53,7 @@ def test_ctypes_binding_matches_header():
 def test_product_package_does_not_touch_the_oracle():
     """No file of the product package imports, includes, links or opens anything of oracle/ or
     tests/ (comments may mention the word)."""
-    pkg = os.path.join(ROOT, "tfhe-rs_amd")
+    pkg = os.path.join(ROOT, "tfhe_rs_amd")
     bad = re.compile(r"tfhe_oracle|libtfhe_oracle|orc_[a-z]|oracle/|from tests|import tests|tests\.oracle|"
                      r"#include\s*[\"<][^\">]*oracle|_emu\.so")
     for dirpath, dirs, files in os.walk(pkg):

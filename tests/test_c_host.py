@@ -14,7 +14,7 @@ from .harness import EMU_LIB, build_emu, oracle_pbs
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-PRODUCT_LIB = os.path.join(ROOT, "tfhe-rs_amd", "lib", "libtfhe_hip_backend.so")
+PRODUCT_LIB = os.path.join(ROOT, "tfhe_rs_amd", "lib", "libtfhe_hip_backend.so")
 
 
 def build_smoke(tmp_path):

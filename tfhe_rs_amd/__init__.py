@@ -1,8 +1,11 @@
-"""Import shim: the package directory is `tfhe-rs_amd/` (named after the reference repo);
-Python cannot import a hyphenated name, so `import tfhe_rs_amd` loads it from there."""
-import os as _os
+"""tfhe_rs_amd — MI355X-native TFHE programmable-bootstrapping backend (host-side package).
 
-_real = _os.path.normpath(_os.path.join(_os.path.dirname(_os.path.abspath(__file__)), _os.pardir, "tfhe-rs_amd"))
-__path__ = [_real]
-with open(_os.path.join(_real, "__init__.py")) as _f:
-    exec(compile(_f.read(), _os.path.join(_real, "__init__.py"), "exec"))
+The product is libtfhe_hip_backend.so (tfhe_rs_amd/csrc, C ABI in include/tfhe_hip_backend.h);
+this package is the thin host side: `ffi` (raw binding) and `core_crypto_gpu` (mirror of
+tfhe::core_crypto::gpu), `integer_gpu` (mirror of the wired part of tfhe::integer::gpu).
+"""
+from . import ffi  # noqa: F401
+from . import core_crypto_gpu  # noqa: F401
+from . import multi_gpu  # noqa: F401
+
+__all__ = ["ffi", "core_crypto_gpu", "multi_gpu"]

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Config 5 of BASELINE.json on ONE GPU: FheUint64 (32 blocks of PARAM_MESSAGE_2_CARRY_2) add and mul
-over a batch of ciphertexts, through the radix layer of the backend (tfhe-rs_amd/integer_gpu.py).
+over a batch of ciphertexts, through the radix layer of the backend (tfhe_rs_amd/integer_gpu.py).
 Prints one JSON line per operation: ops/s, PBS per operation, the equivalent KS-PBS/s, and checks
 every result against clear arithmetic (decryption by the oracle, outside the timed region).
 

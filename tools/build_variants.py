@@ -8,7 +8,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "tfhe-rs_amd", "csrc")
+SRC = os.path.join(ROOT, "tfhe_rs_amd", "csrc")
 OUT = os.path.join(ROOT, "variants")
 os.makedirs(OUT, exist_ok=True)
 subprocess.check_call(["make", "-C", SRC], stdout=subprocess.DEVNULL)
