@@ -268,6 +268,34 @@ def test_keyswitch_matrix_core_path_with_padded_levels(kind, p):
 
 
 @pytest.mark.parametrize("kind", BACKENDS)
+def test_keyswitch_key_layout_cache_follows_the_key_memory(kind):
+    """The matrix-core path lays the key out once per key pointer and keeps that layout (no per-call re-layout, no
+    allocation in the steady state).  The cache must follow the device memory: a key rewritten in place
+    (cuda_memcpy_async_to_gpu) or dropped and replaced by another key at a recycled address has to give the NEW
+    key's results — repeated calls with an unchanged key give the same bits every time."""
+    p = TOY_2048
+    c = ctx(kind, p, "fft64", with_ksk=True)
+    msgs = [m % p.plaintext_modulus for m in range(70)]
+    cts = encrypt_big(p, c.keys, msgs, seed=28)
+    ref_a = orc.keyswitch_batch(cts, c.keys.ksk, p.k * p.N, p.n, p.ks_base_log, p.ks_level)
+    assert np.array_equal(c.keyswitch(cts), ref_a)
+    assert np.array_equal(c.keyswitch(cts), ref_a)          # served from the cached layout
+    # a different key for the same secret keys, written over the first one in place
+    ksk_b = orc.gen_ksk(991, c.keys.glwe_sk, c.keys.lwe_sk, p.ks_base_log, p.ks_level, p.lwe_noise)
+    assert not np.array_equal(ksk_b, c.keys.ksk)
+    ref_b = orc.keyswitch_batch(cts, ksk_b, p.k * p.N, p.n, p.ks_base_log, p.ks_level)
+    c.ksk.d_vec.copy_from_cpu_async(ksk_b, c.streams)
+    out_b = c.keyswitch(cts)
+    assert np.array_equal(out_b, ref_b) and not np.array_equal(out_b, ref_a)
+    # drop the key, upload key A again (the allocator may hand the same address back), same question
+    c.ksk.d_vec.drop()
+    c.ksk = gpu.CudaLweKeyswitchKey.from_lwe_keyswitch_key(c.keys.ksk, p.k * p.N, p.n, p.ks_base_log, p.ks_level,
+                                                           c.streams)
+    assert np.array_equal(c.keyswitch(cts), ref_a)
+    assert [decrypt_small(p, c.keys, o) for o in c.keyswitch(cts)] == msgs
+
+
+@pytest.mark.parametrize("kind", BACKENDS)
 def test_ks_then_pbs_pipeline(kind):
     # the shortint atomic pattern: keyswitch -> PBS (shortint/atomic_pattern/standard.rs:162-199)
     p = TOY_K1

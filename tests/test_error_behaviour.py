@@ -93,6 +93,20 @@ ABORTS = {
     "symbol outside the hot path": ("""
         lib.cdll.cuda_integer_div_rem_64_async()   # a link-compatibility stub (csrc/link_stubs.hip)
         """, "cuda_integer_div_rem_64_async: not part of the MI355X PBS backend"),
+    "carry propagation with message_modulus 2 (MESSAGE_1_CARRY_3-class sets)": ("""
+        s = ffi.CudaStreamsFFI((C.c_void_p * 1)(S), (C.c_uint32 * 1)(0), 1)
+        mem = C.c_void_p()
+        lib.scratch_cuda_propagate_single_carry_64_inplace_async(
+            s, C.byref(mem), ffi.CudaLweBootstrapKeyParamsFFI(12, 1, 2048, 23, 1, 2048, 1, 0),
+            ffi.CudaLweKeyswitchKeyParamsFFI(2048, 12, 4, 4), 8, 2, 8, 0, True, 0)
+        """, "message_modulus 2 < 3 is not supported"),
+    "signed-overflow flag of the carry propagation": ("""
+        s = ffi.CudaStreamsFFI((C.c_void_p * 1)(S), (C.c_uint32 * 1)(0), 1)
+        mem = C.c_void_p()
+        lib.scratch_cuda_propagate_single_carry_64_inplace_async(
+            s, C.byref(mem), ffi.CudaLweBootstrapKeyParamsFFI(12, 1, 2048, 23, 1, 2048, 1, 0),
+            ffi.CudaLweKeyswitchKeyParamsFFI(2048, 12, 4, 4), 8, 4, 4, 1, True, 0)
+        """, "signed-overflow flag is not wired"),
     "radix layer on a multi-bit key": ("""
         s = ffi.CudaStreamsFFI((C.c_void_p * 1)(S), (C.c_uint32 * 1)(0), 1)
         mem = C.c_void_p()

@@ -80,9 +80,15 @@ def test_add_and_carry_propagation(kind):
     rows = decrypt_blocks(p, keys, tmp.to_blocks(st))
     assert all(d < MSG for r in rows for d in r)
     assert recompose(rows) == [(x + y) % (1 << bits) for x, y in zip(a, b)]
-    # fused entry point
-    sks.add_assign(ca, cb, st)
-    assert recompose(decrypt_blocks(p, keys, ca.to_blocks(st))) == [(x + y) % (1 << bits) for x, y in zip(a, b)]
+    # fused entry point, with an input carry per integer and the output carry requested (OutputFlag::Carry):
+    # a + b + c_in = result + 2^bits * c_out
+    cin_vals = [i & 1 for i in range(len(a))]
+    cin = igpu.CudaUnsignedRadixCiphertext.from_blocks(
+        encrypt_big(p, keys, cin_vals, seed=23).reshape(len(a), 1, -1), st)
+    cout = sks.add_assign(ca, cb, st, carry_in=cin, want_carry_out=True)
+    full = [x + y + c for x, y, c in zip(a, b, cin_vals)]
+    assert recompose(decrypt_blocks(p, keys, ca.to_blocks(st))) == [f % (1 << bits) for f in full]
+    assert [r[0] for r in decrypt_blocks(p, keys, cout.to_blocks(st))] == [f >> bits for f in full]
 
 
 @pytest.mark.parametrize("kind", BACKENDS)

@@ -40,8 +40,11 @@ struct MultiBitBuffer {
   cplx *keybundle;
   uint64_t *acc;
   // latency path (small batches): keybundles of lat_groups groups for lat_samples ciphertexts
+  // (allocated by the first call that takes that path: integer operations hold several scratches at once and
+  // most never see a small batch)
   cplx *kb_lat = nullptr;
   uint32_t lat_samples = 0, lat_groups = 0;
+  uint64_t lat_bytes = 0;
 };
 
 // max_n: 16384 for the classic f64 PBS (programmable_bootstrap_classic.cuh supports rings up to 2^14), 4096 for
@@ -124,17 +127,20 @@ void cuda_memcpy_async_to_gpu(void *dest, const void *src, uint64_t size, void *
   if (size == 0) return;
   set_device(gpu_index);
   HX_PANIC_IF_FALSE(dest != nullptr && src != nullptr, "memcpy to gpu: null pointer");
+  ksm_invalidate_range((int)gpu_index, dest, size);  // a keyswitch key may be rewritten in place
   HX_CHECK(hipMemcpyAsync(dest, src, size, hipMemcpyHostToDevice, S(stream)));
 }
 void cuda_memcpy_async_gpu_to_gpu(void *dest, void const *src, uint64_t size, void *stream, uint32_t gpu_index) {
   if (size == 0) return;
   set_device(gpu_index);
   HX_PANIC_IF_FALSE(dest != nullptr && src != nullptr, "memcpy gpu to gpu: null pointer");
+  ksm_invalidate_range((int)gpu_index, dest, size);
   HX_CHECK(hipMemcpyAsync(dest, src, size, hipMemcpyDeviceToDevice, S(stream)));
 }
 void cuda_memcpy_gpu_to_gpu(void *dest, void const *src, uint64_t size, uint32_t gpu_index) {
   if (size == 0) return;
   set_device(gpu_index);
+  ksm_invalidate_range((int)gpu_index, dest, size);
   HX_CHECK(hipMemcpy(dest, src, size, hipMemcpyDeviceToDevice));
 }
 void cuda_memcpy_async_to_cpu(void *dest, const void *src, uint64_t size, void *stream, uint32_t gpu_index) {
@@ -146,6 +152,7 @@ void cuda_memcpy_async_to_cpu(void *dest, const void *src, uint64_t size, void *
 void cuda_memset_async(void *dest, uint64_t val, uint64_t size, void *stream, uint32_t gpu_index) {
   if (size == 0) return;
   set_device(gpu_index);
+  ksm_invalidate_range((int)gpu_index, dest, size);
   HX_CHECK(hipMemsetAsync(dest, (int)val, size, S(stream)));
 }
 int cuda_get_number_of_gpus(void) {
@@ -164,6 +171,13 @@ void cuda_synchronize_device(uint32_t gpu_index) {
 }
 void cuda_drop(void *ptr, uint32_t gpu_index) {
   set_device(gpu_index);
+  if (ptr != nullptr && ksm_cache_entries() != 0) {
+    // a keyswitch key inside this allocation takes its cached matrix-core layout with it
+    void *base = ptr;
+    size_t bytes = 1;
+    if (hipMemGetAddressRange(&base, &bytes, ptr) != hipSuccess) base = ptr, bytes = 1;
+    ksm_invalidate_range((int)gpu_index, base, bytes);
+  }
   HX_CHECK(hipFree(ptr));
 }
 
@@ -393,8 +407,8 @@ uint64_t scratch_cuda_multi_bit_programmable_bootstrap_64_async(void *stream, ui
   const size_t acc_per_sample = 2 * k1 * polynomial_size * sizeof(uint64_t);
   b->chunk = input_lwe_ciphertext_count ? input_lwe_ciphertext_count : 1;
   const uint64_t bytes = (uint64_t)b->chunk * (kb_per_sample + acc_per_sample);
-  // latency path: up to 64 ciphertexts, as many groups per pass as 2 GiB hold (the scratch is sized without
-  // knowing n or the grouping factor, like the reference's lwe_chunk_size)
+  // latency path: up to kMultiBitLatencyMaxBatch ciphertexts, as many groups per pass as 2 GiB hold (the scratch
+  // is sized without knowing n or the grouping factor, like the reference's lwe_chunk_size)
   b->lat_samples = b->chunk < kMultiBitLatencyMaxBatch ? b->chunk : kMultiBitLatencyMaxBatch;
   const size_t per_group = (size_t)b->lat_samples * kb_per_sample;
   size_t lat_groups = ((size_t)2 << 30) / per_group;
@@ -404,10 +418,10 @@ uint64_t scratch_cuda_multi_bit_programmable_bootstrap_64_async(void *stream, ui
     b->fft = get_fft_tables(gpu_index, S(stream), polynomial_size);
     HX_CHECK(hipMalloc((void **)&b->keybundle, (size_t)b->chunk * kb_per_sample));
     HX_CHECK(hipMalloc((void **)&b->acc, (size_t)b->chunk * acc_per_sample));
-    HX_CHECK(hipMalloc((void **)&b->kb_lat, lat_bytes));
   }
+  b->lat_bytes = lat_bytes;
   *pbs_buffer = reinterpret_cast<int8_t *>(b);
-  return bytes + lat_bytes;
+  return bytes + lat_bytes;  // upper bound: the latency buffer exists only once a small batch has been run
 }
 
 void cuda_multi_bit_programmable_bootstrap_64_async(void *stream, uint32_t gpu_index, void *lwe_array_out,
@@ -445,6 +459,7 @@ void cuda_multi_bit_programmable_bootstrap_64_async(void *stream, uint32_t gpu_i
     // few ciphertexts: every (group, keybundle polynomial) gets its own workgroup, then the products run alone
     uint32_t gc = g_multibit_latency_groups.load();
     gc = (gc == 0 || gc > b->lat_groups) ? b->lat_groups : gc;
+    if (b->kb_lat == nullptr) HX_CHECK(hipMalloc((void **)&b->kb_lat, b->lat_bytes));  // first small batch only
     launch_pbs_multi_bit_latency(S(stream), polynomial_size, glwe_dimension, m, b->fft, b->kb_lat, gc, b->acc);
     g_last_pbs_kernel.store(10);
   } else if ((choice == 0 && wave_ok) || choice == 2) {

@@ -20,8 +20,14 @@
 #define HX_BLOCK_SYNC_LDS() __syncthreads()
 #else
 #include <hip/hip_runtime.h>
-#define HX_LAUNCH(kern, grid, block, smem, stream, ...) \
-  hipLaunchKernelGGL(kern, grid, block, smem, stream, __VA_ARGS__)
+// a launch that the runtime rejects (dynamic LDS over the limit, bad grid, missing code object) aborts like every
+// other misuse of the boundary (the reference: check_cuda_error(cudaGetLastError()) after each launch);
+// hipGetLastError is legal during stream capture
+#define HX_LAUNCH(kern, grid, block, smem, stream, ...)                 \
+  do {                                                                  \
+    hipLaunchKernelGGL(kern, grid, block, smem, stream, __VA_ARGS__);   \
+    HX_CHECK_LAUNCH(#kern);                                             \
+  } while (0)
 #define HX_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) char name[]
 // Lanes of one wave exchanging data through LDS need no s_barrier (they execute in lock
 // step); they do need the compiler not to reorder the LDS accesses across this point.
@@ -184,6 +190,15 @@ __device__ __forceinline__ hx_i32x16 hx_mfma_i32_32x32x32_i8(const hx_i8x16 a, c
   do {                                                              \
     if (!(cond)) HX_PANIC(format "\n\n %s\n", ##__VA_ARGS__, #cond); \
   } while (0)
+#define HX_CHECK_LAUNCH(name)                                                                    \
+  do {                                                                                           \
+    hipError_t hx_le_ = hipGetLastError();                                                       \
+    if (hx_le_ != hipSuccess) {                                                                  \
+      std::fprintf(stderr, "HIP launch error: %s (%s) %s %d\n", hipGetErrorString(hx_le_), name, \
+                   __FILE__, __LINE__);                                                          \
+      std::abort();                                                                              \
+    }                                                                                            \
+  } while (0)
 #define HX_CHECK(ans)                                                                     \
   do {                                                                                    \
     hipError_t hx_code_ = (ans);                                                          \
@@ -193,3 +208,17 @@ __device__ __forceinline__ hx_i32x16 hx_mfma_i32_32x32x32_i8(const hx_i8x16 a, c
       std::abort();                                                                       \
     }                                                                                     \
   } while (0)
+
+// Dynamic-LDS limit of a kernel, raised once per (kernel, device) instead of on every launch: the attribute call
+// takes the runtime's device lock and showed up as host time between back-to-back launches.
+#include <atomic>
+template <auto Kernel>
+static inline void hx_set_dynamic_smem_once(size_t bytes) {
+  static std::atomic<uint64_t> done{0};
+  int dev = 0;
+  HX_CHECK(hipGetDevice(&dev));
+  const uint64_t bit = (uint64_t)1 << (dev & 63);
+  if (done.load(std::memory_order_acquire) & bit) return;
+  HX_CHECK(hipFuncSetAttribute((const void *)Kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  done.fetch_or(bit, std::memory_order_release);
+}

@@ -214,7 +214,8 @@ enum : uint64_t {
   LUT_IS_GEN = 7,      // state -> state == generated
   LUT_BIT = 8,         // + q (q = 1..3): S -> bit q of S
   LUT_MSG = 12,        // x -> x % msg
-  LUT_PROP_COUNT = 13
+  LUT_CARRY = 13,      // x -> x / msg (output carry of an integer's last block, FLAG_CARRY)
+  LUT_PROP_COUNT = 14
 };
 
 struct PropagateMem {
@@ -234,7 +235,7 @@ struct PropagateMem {
     uint64_t *a = nullptr, *b = nullptr, *o = nullptr, *lut = nullptr;
     uint32_t count = 0;
   };
-  Idx rA, csrU, rC1, rC2, rD, csrS, rE, addC, addS, rF;
+  Idx rA, csrU, rC1, rC2, rD, csrS, rE, addC, addS, rF, rIO;
   std::vector<Idx> scan;
 
   static uint32_t ngroups(uint32_t L) { return (L + G - 1) / G; }
@@ -359,6 +360,16 @@ struct PropagateMem {
     reset();
     for (uint32_t t = 0; t < TT; ++t) l.push_back(LUT_MSG);
     rF = make(st, {}, {}, {}, l);
+    // optional input carry (added to block 0 of every integer) and output carry (x / msg of the last block
+    // once its incoming carry has been added)
+    reset();
+    for (uint32_t c = 0; c < cts; ++c) {
+      a.push_back(T(c, 0));
+      b.push_back(T(c, L - 1));
+      l.push_back(LUT_CARRY);
+    }
+    rIO = make(st, a, b, {}, l);
+    rIO.count = cts;
     cached_cts = cts;
   }
 
@@ -367,6 +378,9 @@ struct PropagateMem {
     max_cts = cts;
     HX_PANIC_IF_FALSE(p.msg * p.carry >= 16 && p.carry >= p.msg,
                       "carry propagation needs at least 4 bits per block (message_modulus * carry_modulus >= 16)");
+    // the scan packs two states as prev * msg + cur with cur in {0, 1, 2}: unambiguous only for msg >= 3
+    // (MESSAGE_1_CARRY_3-class sets, msg = 2, would decode silently wrong)
+    HX_PANIC_IF_FALSE(p.msg >= 3, "carry propagation: message_modulus %u < 3 is not supported", p.msg);
     const uint64_t m = p.msg;
     std::vector<std::function<uint64_t(uint64_t)>> fs(LUT_PROP_COUNT, [](uint64_t) -> uint64_t { return 0; });
     for (uint64_t q = 0; q + 1 < G; ++q)
@@ -381,6 +395,7 @@ struct PropagateMem {
     fs[LUT_IS_GEN] = [](uint64_t x) -> uint64_t { return x == 1 ? 1 : 0; };
     for (uint64_t q = 1; q < G; ++q) fs[LUT_BIT + q] = [q](uint64_t x) -> uint64_t { return (x >> q) & 1; };
     fs[LUT_MSG] = [m](uint64_t x) -> uint64_t { return x % m; };
+    fs[LUT_CARRY] = [m](uint64_t x) -> uint64_t { return x / m; };
     std::vector<std::vector<uint64_t>> luts;
     for (auto &f : fs) {
       luts.emplace_back((size_t)(p.k + 1) * p.N);
@@ -401,13 +416,17 @@ struct PropagateMem {
     HX_LAUNCH(lwe_group_sum_kernel, dim3(groups), dim3(256), 0, st, out, pool, csr.a, csr.b, w, groups);
   }
 
-  // in place on v (cts integers of `blocks` blocks)
-  void run(hipStream_t st, uint64_t *v, uint32_t cts, const void *ksk, const void *bsk) {
+  // in place on v (cts integers of `blocks` blocks).  carry_in (one block per integer, value 0/1) is added to
+  // block 0 first — a first block of value <= 2 msg - 1 still emits at most one carry and receives none;
+  // carry_out (one block per integer) receives the carry leaving the last block.  Either may be null.
+  void run(hipStream_t st, uint64_t *v, uint32_t cts, const void *ksk, const void *bsk,
+           const uint64_t *carry_in = nullptr, uint64_t *carry_out = nullptr) {
     HX_PANIC_IF_FALSE(cts >= 1 && cts <= max_cts, "carry propagation: %u integers exceed the scratch capacity %u", cts,
                       max_cts);
     if (cached_cts != cts) build_indexes(st, cts);
     const Params &p = drv.p;
     const uint32_t w = p.big_n + 1, T = cts * blocks;
+    if (carry_in) axpy(st, v, rIO.a, v, rIO.a, 1, carry_in, nullptr, w, cts);
     // A: shifted / plain state of every block
     drv.round(st, d_pool, rA.o, v, rA.a, rA.lut, rA.count, ksk, bsk);
     if (csrU.count) {
@@ -428,6 +447,7 @@ struct PropagateMem {
     // F: add the carries, extract the messages
     axpy(st, v, addC.o, v, addC.o, 1, d_pool, addC.a, w, addC.count);
     axpy(st, v, addS.o, v, addS.o, 1, d_s, addS.o, w, addS.count);
+    if (carry_out) drv.round(st, carry_out, nullptr, v, rIO.b, rIO.lut, cts, ksk, bsk);
     drv.round(st, v, nullptr, v, nullptr, rF.lut, T, ksk, bsk);
   }
 
@@ -744,7 +764,8 @@ uint64_t scratch_cuda_propagate_single_carry_64_inplace_async(CudaStreamsFFI str
                                                               uint32_t carry_modulus, uint32_t requested_flag,
                                                               bool allocate_gpu_memory,
                                                               enum PBS_MS_REDUCTION_T noise_reduction_type) {
-  HX_PANIC_IF_FALSE(requested_flag == 0, "propagate_single_carry: overflow / carry flags are not wired");
+  HX_PANIC_IF_FALSE(requested_flag == 0 /* FLAG_NONE */ || requested_flag == 2 /* FLAG_CARRY */,
+                    "propagate_single_carry: the signed-overflow flag is not wired (requested_flag=%u)", requested_flag);
   const Params p = make_params(bsk_params, ksk_params, message_modulus, carry_modulus, (uint32_t)noise_reduction_type);
   t_dry = !allocate_gpu_memory;
   t_bytes = 0;
@@ -769,14 +790,34 @@ void cuda_propagate_single_carry_64_inplace_async(CudaStreamsFFI streams, CudaRa
                                                   const CudaRadixCiphertextFFI *carry_in, int8_t *mem_ptr,
                                                   void *const *bsks, void *const *ksks, uint32_t requested_flag,
                                                   uint32_t uses_carry) {
-  (void)carry_out;
   auto *m = reinterpret_cast<PropagateMem *>(mem_ptr);
   HX_PANIC_IF_FALSE(m && m->magic == PropagateMem::kMagic, "propagate_single_carry: foreign scratch pointer");
   HX_PANIC_IF_FALSE(!m->size_only, "propagate_single_carry: scratch was created with allocate_gpu_memory=false");
-  HX_PANIC_IF_FALSE(requested_flag == 0 && uses_carry == 0 && carry_in == nullptr,
-                    "propagate_single_carry: input carry / flags are not wired");
+  HX_PANIC_IF_FALSE(requested_flag == 0 || requested_flag == 2,
+                    "propagate_single_carry: the signed-overflow flag is not wired (requested_flag=%u)", requested_flag);
   const uint32_t cts = batch_of(lwe_array, m->blocks, "propagate_single_carry");
-  m->run(S0(streams), (uint64_t *)lwe_array->ptr, cts, ksks[0], bsks[0]);
+  // the reference's Rust caller always hands over carry_in / carry_out structs (integer/gpu/ffi.rs:2213-2237);
+  // they are read / written only when uses_carry / requested_flag say so
+  const uint64_t *cin = nullptr;
+  uint64_t *cout = nullptr;
+  if (uses_carry != 0) {
+    HX_PANIC_IF_FALSE(carry_in && carry_in->ptr && carry_in->num_radix_blocks >= cts &&
+                          carry_in->lwe_dimension == lwe_array->lwe_dimension,
+                      "propagate_single_carry: uses_carry needs one input carry block per integer");
+    cin = (const uint64_t *)carry_in->ptr;
+  }
+  if (requested_flag == 2) {
+    HX_PANIC_IF_FALSE(carry_out && carry_out->ptr && carry_out->num_radix_blocks >= cts &&
+                          carry_out->lwe_dimension == lwe_array->lwe_dimension,
+                      "propagate_single_carry: FLAG_CARRY needs one output carry block per integer");
+    cout = (uint64_t *)carry_out->ptr;
+  }
+  m->run(S0(streams), (uint64_t *)lwe_array->ptr, cts, ksks[0], bsks[0], cin, cout);
+  if (cout)
+    for (uint32_t i = 0; i < cts; ++i) {
+      if (carry_out->degrees) carry_out->degrees[i] = 1;
+      if (carry_out->noise_levels) carry_out->noise_levels[i] = 1;
+    }
   for (uint32_t i = 0; i < lwe_array->num_radix_blocks; ++i) {
     if (lwe_array->degrees) lwe_array->degrees[i] = m->drv.p.msg - 1;
     if (lwe_array->noise_levels) lwe_array->noise_levels[i] = 1;

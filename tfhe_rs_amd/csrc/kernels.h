@@ -33,6 +33,9 @@ void launch_keyswitch_64_32(hipStream_t st, uint32_t *lwe_out, const uint64_t *o
                             const uint64_t *in_idx, const uint32_t *ksk, uint32_t n_in, uint32_t n_out,
                             uint32_t base_log, uint32_t level, uint32_t num_samples);
 
+// cache of the matrix-core key layout (keyswitch.hip): drop what overlaps device memory about to be freed / written
+void ksm_invalidate_range(int device, const void *p, size_t bytes);
+size_t ksm_cache_entries();
 extern bool g_keyswitch_use_mfma;
 extern bool g_ntt_kernel_serial;
 

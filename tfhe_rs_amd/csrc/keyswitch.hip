@@ -12,7 +12,7 @@
 // elements are staged in LDS and broadcast-read.
 #include "kernels.h"
 #include <mutex>
-#include <unordered_map>
+#include <vector>
 
 namespace tfhe_hip {
 
@@ -369,15 +369,56 @@ __global__ void __launch_bounds__(256) ks_mfma_kernel(OutT *lwe_out, const uint6
   }
 }
 
-// workspace of the matrix-core path (byte planes + column sums): one per stream, grown on demand, so that host
-// threads driving different streams never share it (the boundary allows concurrent calls on different streams,
-// SURVEY §8b).  Entries live until process exit.
-struct KsmWorkspace {
-  void *ptr = nullptr;
-  size_t bytes = 0;
+// Byte planes + column sums of a keyswitch key, built ONCE per key and kept until the key's device memory is
+// released or overwritten.  The C ABI hands the key over as a plain device array at every call, so the cache is
+// keyed by (device, key pointer, shape); every entry point of the boundary that frees or writes device memory
+// (cuda_drop, cuda_memcpy_*_to_gpu / gpu_to_gpu, cuda_memset_async) calls ksm_invalidate_range first, so a
+// recycled address can never serve stale planes.  A steady-state keyswitch call therefore allocates nothing and
+// launches one kernel (graph-capture safe); only the first call with a new key allocates and lays the key out.
+struct KsmEntry {
+  int device;
+  const void *ksk;
+  size_t ksk_bytes;
+  uint32_t n_in, n_out, level, level_pad, key_size;
+  void *planes;      // [K/16][col tile][plane][col][16 B], then the column sums
+  size_t plane_bytes;
+  hipEvent_t ready;  // recorded behind the layout kernel: streams other than the building one wait for it
+  uint64_t last_use;
 };
-static std::unordered_map<hipStream_t, KsmWorkspace> g_ksm_ws;
+static std::vector<KsmEntry> g_ksm_cache;
 static std::mutex g_ksm_mutex;
+static uint64_t g_ksm_tick = 0;
+constexpr size_t kKsmMaxEntries = 32;
+
+static void ksm_release(KsmEntry &e) {
+  int cur = 0;
+  HX_CHECK(hipGetDevice(&cur));
+  HX_CHECK(hipSetDevice(e.device));
+  HX_CHECK(hipFree(e.planes));  // synchronises the device: no kernel still reads the planes
+  HX_CHECK(hipEventDestroy(e.ready));
+  HX_CHECK(hipSetDevice(cur));
+}
+
+// device memory [p, p + bytes) of `device` is about to be freed or written
+void ksm_invalidate_range(int device, const void *p, size_t bytes) {
+  if (p == nullptr) return;
+  std::lock_guard<std::mutex> lock(g_ksm_mutex);
+  const char *lo = (const char *)p, *hi = lo + (bytes ? bytes : 1);
+  for (size_t i = 0; i < g_ksm_cache.size();) {
+    KsmEntry &e = g_ksm_cache[i];
+    const char *klo = (const char *)e.ksk, *khi = klo + e.ksk_bytes;
+    if (e.device == device && klo < hi && lo < khi) {
+      ksm_release(e);
+      g_ksm_cache.erase(g_ksm_cache.begin() + i);
+    } else {
+      ++i;
+    }
+  }
+}
+size_t ksm_cache_entries() {
+  std::lock_guard<std::mutex> lock(g_ksm_mutex);
+  return g_ksm_cache.size();
+}
 
 template <typename OutT>
 static bool keyswitch_mfma(hipStream_t st, OutT *lwe_out, const uint64_t *out_idx, const uint64_t *lwe_in,
@@ -392,25 +433,49 @@ static bool keyswitch_mfma(hipStream_t st, OutT *lwe_out, const uint64_t *out_id
   const uint32_t ncols = n_out + 1, col_tiles = (ncols + KSM_CT - 1) / KSM_CT;
   const size_t plane_bytes = (size_t)(K / 16) * col_tiles * sizeof(OutT) * KSM_CT * 16;
   const size_t need = plane_bytes + (size_t)col_tiles * KSM_CT * sizeof(uint64_t);
-  void *ws = nullptr;
+  int device = 0;
+  HX_CHECK(hipGetDevice(&device));
+  int8_t *planes = nullptr;
+  uint64_t *colsum = nullptr;
   {
     std::lock_guard<std::mutex> lock(g_ksm_mutex);
-    KsmWorkspace &w = g_ksm_ws[st];
-    if (w.bytes < need) {
-      if (w.ptr) {
-        HX_CHECK(hipStreamSynchronize(st));  // the previous call on this stream may still read the old planes
-        HX_CHECK(hipFree(w.ptr));
+    KsmEntry *hit = nullptr;
+    for (KsmEntry &e : g_ksm_cache)
+      if (e.device == device && e.ksk == (const void *)ksk && e.n_in == n_in && e.n_out == n_out && e.level == level &&
+          e.key_size == sizeof(OutT)) {
+        hit = &e;
+        break;
       }
-      HX_CHECK(hipMalloc(&w.ptr, need));
-      w.bytes = need;
+    if (hit == nullptr) {
+      if (g_ksm_cache.size() >= kKsmMaxEntries) {  // least recently used key goes
+        size_t lru = 0;
+        for (size_t i = 1; i < g_ksm_cache.size(); ++i)
+          if (g_ksm_cache[i].last_use < g_ksm_cache[lru].last_use) lru = i;
+        ksm_release(g_ksm_cache[lru]);
+        g_ksm_cache.erase(g_ksm_cache.begin() + lru);
+      }
+      KsmEntry e{};
+      e.device = device;
+      e.ksk = ksk;
+      e.ksk_bytes = (size_t)n_in * level * ncols * sizeof(OutT);
+      e.n_in = n_in, e.n_out = n_out, e.level = level, e.level_pad = level_pad, e.key_size = sizeof(OutT);
+      e.plane_bytes = plane_bytes;
+      HX_CHECK(hipMalloc(&e.planes, need));
+      HX_CHECK(hipEventCreate(&e.ready));
+      uint64_t *cs = (uint64_t *)((char *)e.planes + plane_bytes);
+      HX_CHECK(hipMemsetAsync(cs, 0, (size_t)col_tiles * KSM_CT * sizeof(uint64_t), st));
+      HX_LAUNCH((ksk_planes_kernel<OutT>), dim3((col_tiles * KSM_CT + 255) / 256, K / 16), dim3(256), 0, st,
+                (int8_t *)e.planes, cs, ksk, K, ncols, col_tiles, level, level_pad);
+      HX_CHECK(hipEventRecord(e.ready, st));
+      g_ksm_cache.push_back(e);
+      hit = &g_ksm_cache.back();
+    } else {
+      HX_CHECK(hipStreamWaitEvent(st, hit->ready, 0));  // no-op once the layout kernel has completed
     }
-    ws = w.ptr;
+    hit->last_use = ++g_ksm_tick;
+    planes = (int8_t *)hit->planes;
+    colsum = (uint64_t *)((char *)hit->planes + hit->plane_bytes);
   }
-  int8_t *planes = (int8_t *)ws;
-  uint64_t *colsum = (uint64_t *)((char *)ws + plane_bytes);
-  HX_CHECK(hipMemsetAsync(colsum, 0, (size_t)col_tiles * KSM_CT * sizeof(uint64_t), st));
-  HX_LAUNCH((ksk_planes_kernel<OutT>), dim3((col_tiles * KSM_CT + 255) / 256, K / 16), dim3(256), 0, st, planes, colsum,
-            ksk, K, ncols, col_tiles, level, level_pad);
   const dim3 grid(col_tiles, (num_samples + 127) / 128);
 #define KSM_LAUNCH(L)                                                                                              \
   do {                                                                                                               \
@@ -435,12 +500,15 @@ static bool keyswitch_mfma(hipStream_t st, OutT *lwe_out, const uint64_t *out_id
 void launch_keyswitch(hipStream_t st, uint64_t *lwe_out, const uint64_t *out_idx, const uint64_t *lwe_in,
                       const uint64_t *in_idx, const uint64_t *ksk, uint32_t n_in, uint32_t n_out,
                       uint32_t base_log, uint32_t level, uint32_t num_samples) {
-  HX_PANIC_IF_FALSE(base_log >= 1 && level >= 1 && level <= KS_MAXL && base_log * level < 64,
+  HX_PANIC_IF_FALSE(base_log >= 1 && level >= 1 && base_log * level < 64,
                     "keyswitch: unsupported decomposition (base_log=%u, level=%u)", base_log, level);
   if (num_samples == 0) return;
   if (g_keyswitch_use_mfma &&
       keyswitch_mfma(st, lwe_out, out_idx, lwe_in, in_idx, ksk, n_in, n_out, base_log, level, num_samples))
     return;
+  // the scalar kernels stage at most KS_MAXL levels per mask element (the matrix-core path above takes up to 16)
+  HX_PANIC_IF_FALSE(level <= KS_MAXL, "keyswitch: level_count %u > %d is only supported from 64 LWEs up (base_log <= 6)",
+                    level, KS_MAXL);
   const dim3 grid((n_out + 1 + KS_TPB - 1) / KS_TPB, (num_samples + KS_TB - 1) / KS_TB);
   uint32_t log_terms = 0;
   while (((uint64_t)1 << log_terms) < (uint64_t)n_in * level) ++log_terms;
@@ -463,12 +531,14 @@ void launch_keyswitch_64_32(hipStream_t st, uint32_t *lwe_out, const uint64_t *o
                             const uint64_t *in_idx, const uint32_t *ksk, uint32_t n_in, uint32_t n_out,
                             uint32_t base_log, uint32_t level, uint32_t num_samples) {
   // lwe_keyswitch.rs:353-359: the decomposition must fit the OUTPUT width
-  HX_PANIC_IF_FALSE(base_log >= 1 && level >= 1 && level <= KS_MAXL && base_log * level <= 32,
+  HX_PANIC_IF_FALSE(base_log >= 1 && level >= 1 && base_log * level <= 32,
                     "keyswitch 64->32: unsupported decomposition (base_log=%u, level=%u)", base_log, level);
   if (num_samples == 0) return;
   if (g_keyswitch_use_mfma &&
       keyswitch_mfma(st, lwe_out, out_idx, lwe_in, in_idx, ksk, n_in, n_out, base_log, level, num_samples))
     return;
+  HX_PANIC_IF_FALSE(level <= KS_MAXL, "keyswitch 64->32: level_count %u > %d is only supported from 64 LWEs up",
+                    level, KS_MAXL);
   const dim3 grid((n_out + 1 + KS_TPB - 1) / KS_TPB, (num_samples + KS_TB - 1) / KS_TB);
   const size_t smem = sizeof(uint32_t) * KS_IC * level * KS_TB;
   HX_LAUNCH(keyswitch_64_32_kernel, grid, dim3(KS_TPB), smem, st, lwe_out, out_idx, lwe_in, in_idx, ksk, n_in, n_out,

@@ -332,20 +332,10 @@ static void launch_mb_latency(hipStream_t st, const MultiBitArgs &m, const FftTa
   const size_t smem_b = (size_t)K1 * N * 8 + fbuf_bytes(N);
   const size_t smem_p = (size_t)K1 * N * 8 + (size_t)K1 * fbuf_bytes(N);
   const bool par = K1 == 2 && !g_ntt_kernel_serial;  // same rule as the classic generic kernels (hip_backend_set_ntt_kernel)
-  // once per device and kernel: the call costs host time on a path that exists for latency
-  static std::atomic<uint64_t> done_par{0}, done_ser{0};
-  int dev = 0;
-  HX_CHECK(hipGetDevice(&dev));
-  std::atomic<uint64_t> &done = par ? done_par : done_ser;
-  if (!((done.load() >> (dev & 63)) & 1)) {
-    if (par)
-      HX_CHECK(hipFuncSetAttribute((const void *)mb_accumulate_par_kernel<N, K1>,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_p));
-    else
-      HX_CHECK(hipFuncSetAttribute((const void *)mb_accumulate_kernel<N, K1>,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_b));
-    done.fetch_or((uint64_t)1 << (dev & 63));
-  }
+  if (par)
+    hx_set_dynamic_smem_once<mb_accumulate_par_kernel<N, K1>>(smem_p);
+  else
+    hx_set_dynamic_smem_once<mb_accumulate_kernel<N, K1>>(smem_b);
   for (uint32_t g0 = 0; g0 < groups; g0 += group_chunk) {
     const uint32_t gpass = groups - g0 < group_chunk ? groups - g0 : group_chunk;
     HX_LAUNCH((mb_keybundle_kernel<N, K1>), dim3(gpass * kb_polys, a.num_samples), dim3(GenericCfg<N>::TPB),
@@ -362,8 +352,7 @@ static void launch_mb_latency(hipStream_t st, const MultiBitArgs &m, const FftTa
 template <int N, int K1>
 static void launch_mb(hipStream_t st, const MultiBitArgs &m, const FftTables &tb) {
   const size_t smem = (size_t)K1 * N * 8 + fbuf_bytes(N);
-  HX_CHECK(hipFuncSetAttribute((const void *)pbs_multi_bit_kernel<N, K1>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)smem));
+  hx_set_dynamic_smem_once<pbs_multi_bit_kernel<N, K1>>(smem);
   HX_LAUNCH((pbs_multi_bit_kernel<N, K1>), dim3(m.pbs.num_samples), dim3(GenericCfg<N>::TPB), smem, st, m.pbs,
             m.grouping_factor, m.keybundle, tb);
 }

@@ -560,16 +560,14 @@ bool pbs_fft_block_supported(uint32_t N, uint32_t glwe_dim, uint32_t level) {
 template <int L, int B>
 static void launch_block_t(hipStream_t st, const PbsArgs &a, const FftTables &tb) {
   using namespace blockk;
-  HX_CHECK(hipFuncSetAttribute((const void *)pbs_fft_block_kernel<L, B>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)SMEM_BYTES));
+  hx_set_dynamic_smem_once<pbs_fft_block_kernel<L, B>>(SMEM_BYTES);
   HX_LAUNCH((pbs_fft_block_kernel<L, B>), dim3(a.num_samples), dim3(TPB), SMEM_BYTES, st, a, tb);
 }
 
 template <int L, int B>
 static void launch_block2_t(hipStream_t st, const PbsArgs &a, const FftTables &tb) {
   using namespace blockk;
-  HX_CHECK(hipFuncSetAttribute((const void *)pbs_fft_block2_kernel<L, B>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)SMEM2_BYTES));
+  hx_set_dynamic_smem_once<pbs_fft_block2_kernel<L, B>>(SMEM2_BYTES);
   HX_LAUNCH((pbs_fft_block2_kernel<L, B>), dim3(a.num_samples), dim3(TPB2), SMEM2_BYTES, st, a, tb);
 }
 

@@ -999,8 +999,7 @@ bool pbs_fft_wave_supported(uint32_t N, uint32_t glwe_dim, uint32_t level) {
 template <int L, int B>
 static void launch_wave_t(hipStream_t st, const PbsArgs &a, const FftTables &tb) {
   using namespace wavek;
-  HX_CHECK(hipFuncSetAttribute((const void *)pbs_fft_wave_kernel<L, B>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)SMEM_BYTES));
+  hx_set_dynamic_smem_once<pbs_fft_wave_kernel<L, B>>(SMEM_BYTES);
   const unsigned per_block = lwes_per_block(a.num_samples);
   const unsigned blocks = (a.num_samples + per_block - 1) / per_block;
   HX_LAUNCH((pbs_fft_wave_kernel<L, B>), dim3(blocks), dim3(128 * per_block), SMEM_BYTES, st, a, tb);
@@ -1013,8 +1012,7 @@ bool pbs_multi_bit_wave_supported(uint32_t N, uint32_t glwe_dim, uint32_t level,
 template <int L, int B>
 static void launch_wave_mb_t(hipStream_t st, const PbsArgs &a, const FftTables &tb) {
   using namespace wavek;
-  HX_CHECK(hipFuncSetAttribute((const void *)pbs_fft_wave_kernel<L, B, true>,
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM_BYTES));
+  hx_set_dynamic_smem_once<pbs_fft_wave_kernel<L, B, true>>(SMEM_BYTES);
   const unsigned per_block = lwes_per_block(a.num_samples);
   const unsigned blocks = (a.num_samples + per_block - 1) / per_block;
   HX_LAUNCH((pbs_fft_wave_kernel<L, B, true>), dim3(blocks), dim3(128 * per_block), SMEM_BYTES, st, a, tb);

@@ -467,12 +467,10 @@ static void launch_wave3_t(hipStream_t st, const PbsArgs &a, const FftTables &tb
   const size_t smem = smem_bytes((int)(per_block * K1));
   const bool l1 = a.level == 1 && a.base_log >= 1 && a.base_log <= 30;
   if (l1) {
-    HX_CHECK(hipFuncSetAttribute((const void *)pbs_fft_wave3_kernel<K1, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 (int)smem_bytes(MAX_WAVES)));
+    hx_set_dynamic_smem_once<pbs_fft_wave3_kernel<K1, true>>(smem_bytes(MAX_WAVES));
     HX_LAUNCH((pbs_fft_wave3_kernel<K1, true>), dim3(blocks), dim3(64 * per_block * K1), smem, st, a, tb, per_block);
   } else {
-    HX_CHECK(hipFuncSetAttribute((const void *)pbs_fft_wave3_kernel<K1, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 (int)smem_bytes(MAX_WAVES)));
+    hx_set_dynamic_smem_once<pbs_fft_wave3_kernel<K1, false>>(smem_bytes(MAX_WAVES));
     HX_LAUNCH((pbs_fft_wave3_kernel<K1, false>), dim3(blocks), dim3(64 * per_block * K1), smem, st, a, tb, per_block);
   }
 }

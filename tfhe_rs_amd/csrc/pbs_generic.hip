@@ -429,8 +429,7 @@ template <int N>
 static void launch_fft_big(hipStream_t st, const PbsArgs &a, const FftTables &tb) {  // N >= 8192, k = 1
   HX_PANIC_IF_FALSE(a.acc_scratch != nullptr, "PBS scratch of a polynomial_size >= 8192 set has no accumulator buffer");
   const size_t smem = fbuf_bytes(N);
-  HX_CHECK(hipFuncSetAttribute((const void *)pbs_fft_generic_kernel<N, 2, true>,
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  hx_set_dynamic_smem_once<pbs_fft_generic_kernel<N, 2, true>>(smem);
   HX_LAUNCH((pbs_fft_generic_kernel<N, 2, true>), dim3(a.num_samples), dim3(GenericCfg<N>::TPB), smem, st, a, tb);
 }
 template <int N, int K1>
@@ -439,28 +438,24 @@ static void launch_fft(hipStream_t st, const PbsArgs &a, const FftTables &tb) {
   // larger workgroup costs more occupancy than the shorter barrier chain returns (45.9k vs 59.0k): single group
   if (g_ntt_kernel_serial || K1 != 2) {
     const size_t smem = (size_t)K1 * N * 8 + fbuf_bytes(N);
-    HX_CHECK(hipFuncSetAttribute((const void *)pbs_fft_generic_kernel<N, K1>,
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    hx_set_dynamic_smem_once<pbs_fft_generic_kernel<N, K1>>(smem);
     HX_LAUNCH((pbs_fft_generic_kernel<N, K1>), dim3(a.num_samples), dim3(GenericCfg<N>::TPB), smem, st, a, tb);
     return;
   }
   const size_t smem = (size_t)K1 * N * 8 + (size_t)K1 * fbuf_bytes(N);
-  HX_CHECK(hipFuncSetAttribute((const void *)pbs_fft_par_kernel<N, K1>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)smem));
+  hx_set_dynamic_smem_once<pbs_fft_par_kernel<N, K1>>(smem);
   HX_LAUNCH((pbs_fft_par_kernel<N, K1>), dim3(a.num_samples), dim3(K1 * GenericCfg<N>::TPB), smem, st, a, tb);
 }
 template <int N, int K1>
 static void launch_ntt(hipStream_t st, const PbsArgs &a, const NttTables &tb) {
   if (g_ntt_kernel_serial || K1 != 2) {  // same rule as the f64 engine above
     const size_t smem = (size_t)(K1 + 1) * N * 8;
-    HX_CHECK(hipFuncSetAttribute((const void *)pbs_ntt_generic_kernel<N, K1>,
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    hx_set_dynamic_smem_once<pbs_ntt_generic_kernel<N, K1>>(smem);
     HX_LAUNCH((pbs_ntt_generic_kernel<N, K1>), dim3(a.num_samples), dim3(GenericCfg<N>::TPB), smem, st, a, tb);
     return;
   }
   const size_t smem = (size_t)2 * K1 * N * 8;
-  HX_CHECK(hipFuncSetAttribute((const void *)pbs_ntt_par_kernel<N, K1>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)smem));
+  hx_set_dynamic_smem_once<pbs_ntt_par_kernel<N, K1>>(smem);
   HX_LAUNCH((pbs_ntt_par_kernel<N, K1>), dim3(a.num_samples), dim3(K1 * GenericCfg<N>::TPB), smem, st, a, tb);
 }
 
@@ -491,8 +486,7 @@ void launch_pbs_fft_generic(hipStream_t st, uint32_t N, uint32_t glwe_dim, const
 template <int N, int K1>
 static void launch_exact(hipStream_t st, const PbsArgs &a) {
   const size_t smem = (size_t)(K1 + 1) * N * 8;
-  HX_CHECK(hipFuncSetAttribute((const void *)pbs_exact_generic_kernel<N, K1>,
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  hx_set_dynamic_smem_once<pbs_exact_generic_kernel<N, K1>>(smem);
   HX_LAUNCH((pbs_exact_generic_kernel<N, K1>), dim3(a.num_samples), dim3(GenericCfg<N>::TPB), smem, st, a);
 }
 void launch_pbs_exact_generic(hipStream_t st, uint32_t N, uint32_t glwe_dim, const PbsArgs &a) {
@@ -504,8 +498,7 @@ void launch_pbs_ntt_generic(hipStream_t st, uint32_t N, uint32_t glwe_dim, const
 
 template <int N> static void launch_conv_f(hipStream_t st, const uint64_t *src, void *dst, size_t polys, const FftTables &tb, int slot_order) {
   if (fbuf_bytes(N) > 48 * 1024)
-    HX_CHECK(hipFuncSetAttribute((const void *)bsk_to_fourier_kernel<N>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 (int)fbuf_bytes(N)));
+    hx_set_dynamic_smem_once<bsk_to_fourier_kernel<N>>(fbuf_bytes(N));
   HX_LAUNCH((bsk_to_fourier_kernel<N>), dim3((unsigned)polys), dim3(GenericCfg<N>::TPB), fbuf_bytes(N), st, src, (cplx *)dst, tb, slot_order);
 }
 template <int N> static void launch_conv_n(hipStream_t st, const uint64_t *src, void *dst, size_t polys, const NttTables &tb) {

@@ -18,7 +18,8 @@ from . import ffi
 from .core_crypto_gpu import CudaLweBootstrapKey, CudaLweKeyswitchKey, CudaVec, _lib
 
 U64 = np.uint64
-PBS_TYPE_CLASSICAL = 1
+PBS_TYPE_MULTI_BIT, PBS_TYPE_CLASSICAL = 0, 1          # pbs/pbs_enums.h:4
+OUTPUT_FLAG_NONE, OUTPUT_FLAG_OVERFLOW, OUTPUT_FLAG_CARRY = 0, 1, 2   # integer/integer.h:39
 
 
 class CudaServerKey:
@@ -79,29 +80,51 @@ class CudaServerKey:
         _lib().cuda_add_lwe_ciphertext_vector_inplace_64(streams.ptr[0], streams.gpu_indexes[0], C.byref(lhs._ffi()),
                                                          C.byref(rhs._ffi()))
 
-    def propagate_single_carry_assign(self, ct, streams):
+    def _carry_blocks(self, ct, carry, streams):
+        """The reference's wrappers ALWAYS hand carry_in / carry_out radix structs to the backend, whether
+        or not uses_carry / requested_flag select them (integer/gpu/ffi.rs:2194-2237): one block per
+        integer, zero (trivial) unless the caller supplies one."""
+        if carry is not None:
+            assert carry.total_blocks == ct.num_integers and carry.lwe_dimension == ct.lwe_dimension
+            return carry
+        return CudaUnsignedRadixCiphertext(CudaVec(ct.num_integers * (ct.lwe_dimension + 1), streams),
+                                           ct.num_integers, 1, ct.lwe_dimension)
+
+    def propagate_single_carry_assign(self, ct, streams, carry_in=None, want_carry_out=False):
+        """integer/gpu/mod.rs propagate_single_carry_assign: carry_in (one block per integer, 0/1) enters
+        block 0 when given; with want_carry_out (OutputFlag::Carry) the carry leaving the last block is
+        returned as a one-block-per-integer ciphertext."""
         s, keep = self._streams(streams)
         ksks, bsks = self._key_ptrs()
         mem = C.c_void_p()
+        flag = OUTPUT_FLAG_CARRY if want_carry_out else OUTPUT_FLAG_NONE
+        cin, cout = self._carry_blocks(ct, carry_in, streams), self._carry_blocks(ct, None, streams)
         _lib().hip_integer_scratch_batch(ct.num_integers)
         _lib().scratch_cuda_propagate_single_carry_64_inplace_async(
             s, C.byref(mem), self._bsk_params(), self._ksk_params(), ct.num_blocks, self.message_modulus,
-            self.carry_modulus, 0, True, self._noise_reduction())
-        _lib().cuda_propagate_single_carry_64_inplace_async(s, C.byref(ct._ffi()), None, None, mem, bsks, ksks, 0, 0)
+            self.carry_modulus, flag, True, self._noise_reduction())
+        _lib().cuda_propagate_single_carry_64_inplace_async(s, C.byref(ct._ffi()), C.byref(cout._ffi()),
+                                                            C.byref(cin._ffi()), mem, bsks, ksks, flag,
+                                                            1 if carry_in is not None else 0)
         _lib().cleanup_cuda_propagate_single_carry_64_inplace(s, C.byref(mem))
+        return cout if want_carry_out else None
 
-    def add_assign(self, lhs, rhs, streams):
-        """lhs += rhs on clean (carry-free) operands: block additions, then one carry propagation."""
+    def add_assign(self, lhs, rhs, streams, carry_in=None, want_carry_out=False):
+        """lhs += rhs (+ carry_in) on clean (carry-free) operands: block additions, then one carry propagation."""
         s, keep = self._streams(streams)
         ksks, bsks = self._key_ptrs()
         mem = C.c_void_p()
+        flag = OUTPUT_FLAG_CARRY if want_carry_out else OUTPUT_FLAG_NONE
+        cin, cout = self._carry_blocks(lhs, carry_in, streams), self._carry_blocks(lhs, None, streams)
         _lib().hip_integer_scratch_batch(lhs.num_integers)
         _lib().scratch_cuda_add_and_propagate_single_carry_64_inplace_async(
             s, C.byref(mem), self._bsk_params(), self._ksk_params(), lhs.num_blocks, self.message_modulus,
-            self.carry_modulus, 0, True, self._noise_reduction())
-        _lib().cuda_add_and_propagate_single_carry_64_inplace_async(s, C.byref(lhs._ffi()), C.byref(rhs._ffi()), None,
-                                                                    None, mem, bsks, ksks, 0, 0)
+            self.carry_modulus, flag, True, self._noise_reduction())
+        _lib().cuda_add_and_propagate_single_carry_64_inplace_async(s, C.byref(lhs._ffi()), C.byref(rhs._ffi()),
+                                                                    C.byref(cout._ffi()), C.byref(cin._ffi()), mem,
+                                                                    bsks, ksks, flag, 1 if carry_in is not None else 0)
         _lib().cleanup_cuda_add_and_propagate_single_carry_64_inplace(s, C.byref(mem))
+        return cout if want_carry_out else None
 
     def mul_assign(self, lhs, rhs, streams, return_pbs_count=False):
         """lhs *= rhs (mod 2^bits) on clean operands: schoolbook block products, column sums, propagation."""
