@@ -25,21 +25,40 @@ BATCH = 4096
 # algorithmic bytes per PBS, streaming model with no inter-LWE key reuse:
 # BSK n*(k+1)^2*l*N*8 + LWE_in (n+1)*8 + LUT (k+1)*N*8 + LWE_out (kN+1)*8
 ALGO_BYTES_PER_PBS = 918 * 4 * 1 * 2048 * 8 + 919 * 8 + 2 * 2048 * 8 + 2049 * 8  # = 60,218,560
-HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
+# algorithmic f64 flop per PBS = n x 270,336 (2 forward + 2 inverse 1024-point transforms at
+# 5 (N/2) log2(N/2), the (k+1)^2 l (N/2) 8-flop MAC and the twists, per external product)
+ALGO_FLOP_PER_PBS = 918 * 270336  # = 2.48e8
+HBM_PEAK_GBPS = 8000.0    # MI355X_MICROARCH.md: HBM3E 8 TB/s
+FP64_PEAK_TFLOPS = 78.6   # MI355X_MICROARCH.md / datasheet: FP64 vector = half of the 157.3 TF FP32 vector rate
 
 
-def pmc_traffic_bytes(kernel_id):
-    """HBM bytes per launch of the dominant kernel, from the PMC passes committed with this kernel build
-    (tools/pmc.sh -> profiles/pmc_latest.json; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for
-    16-byte coalesced reads on gfx950).  None when no measurement of this kernel is on file."""
+def bytes_per_pbs(p):
+    """streaming-model bytes of one PBS of parameter set p (multi-bit: the standard-domain key, 2^g GGSW per group)"""
+    k1 = p.k + 1
+    key = p.n * k1 * k1 * p.pbs_level * p.N * 8
+    if p.grouping:
+        key = (p.n // p.grouping) * (1 << p.grouping) * k1 * k1 * p.pbs_level * p.N * 8
+    return key + (p.n + 1) * 8 + k1 * p.N * 8 + (p.k * p.N + 1) * 8
+
+
+def pmc_record(target):
+    """Counter record of one throughput kernel ("fft", "ntt", "mb_g3"), measured by tools/pmc_record.py on the SAME
+    kernel sources this tree holds (profiles/pmc_latest.json carries the build id of what it profiled; a record
+    of another build is refused).  Returns (hbm_bytes_per_launch or None, provenance string)."""
+    from tools.build_id import source_build_id
+    path = os.path.join(ROOT, "profiles", "pmc_latest.json")
     try:
-        import json
-        m = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_latest.json")))
-        if m.get("pbs_kernel_id") != kernel_id:
-            return None
-        return 2 * m["FETCH_SIZE_KB"] * 1024 + m["WRITE_SIZE_KB"] * 1024
-    except Exception:
-        return None
+        m = json.load(open(path))
+    except Exception as e:
+        return None, f"no PMC record ({e.__class__.__name__})"
+    mine = source_build_id()
+    if m.get("build_id") != mine:
+        return None, f"PMC record is of build {m.get('build_id')}, this tree is {mine}: refused as stale"
+    k = m.get("kernels", {}).get(target)
+    if not k or "hbm_bytes_per_launch" not in k:
+        return None, f"PMC record of build {mine} has no '{target}' entry"
+    return k["hbm_bytes_per_launch"], (f"profiles/pmc_latest.json, build {mine}, kernel {k.get('kernel')}: "
+                                       f"2 x FETCH_SIZE + WRITE_SIZE per launch, L2 hit rate {k.get('l2_hit_rate', 0):.3f}")
 
 
 def main():
@@ -50,6 +69,7 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH, help="LWEs per GPU per step (default: the metric's 4096)")
     ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 generic LDS kernel, 2 throughput kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the config-3/4 and N=1024 datapoints under `extra`")
     ap.add_argument("--no-verify", action="store_true", help="skip the decrypt check (timing-ablation builds only)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="PBS count of the CPU baseline sample (0 = auto)")
     args = ap.parse_args()
@@ -175,6 +195,26 @@ def main():
     value = total_pbs / elapsed
     avg_kernel_s = (sum(kernel_ms) / len(kernel_ms)) * 1e-3
     achieved = ALGO_BYTES_PER_PBS * B / avg_kernel_s / 1e9
+    tflops = ALGO_FLOP_PER_PBS * B / avg_kernel_s / 1e12
+    traffic, traffic_src = pmc_record("fft")
+    # What bounds the kernel: the 60 MB key is shared by all workgroups through L2 / Infinity Cache (measured
+    # HBM traffic is ~1 % of the streaming model's bytes), so the binding roof is the FP64 vector pipe.  The
+    # streaming-model HBM fraction that SURVEY §8(d) / north_star name is kept under its own name next to it.
+    roofline = {"bound": "fp64_valu", "achieved": tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": tflops / FP64_PEAK_TFLOPS, "frac_fp64": tflops / FP64_PEAK_TFLOPS,
+                "algorithmic_flop_per_launch": ALGO_FLOP_PER_PBS * B,
+                "hbm_streaming_model": {"achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                        "frac": achieved / HBM_PEAK_GBPS,
+                                        "algorithmic_bytes_per_launch": ALGO_BYTES_PER_PBS * B,
+                                        "note": "key re-read per LWE (no inter-LWE reuse): a model, not a bound — "
+                                                "compare `traffic`"},
+                "frac_hbm_streaming_model": achieved / HBM_PEAK_GBPS,
+                "traffic": traffic, "traffic_source": traffic_src,
+                "hbm_measured_frac": (traffic / avg_kernel_s / 1e9 / HBM_PEAK_GBPS) if traffic else None,
+                "kernel_ms_avg": avg_kernel_s * 1e3,
+                "note": "achieved = algorithmic f64 flop (SURVEY §8d, 2.48e8 per PBS) / HIP-event launch time; "
+                        "peak = FP64 vector 78.6 TFLOP/s; traffic = HBM bytes per launch from PMC passes of this "
+                        "exact kernel build (null when the committed record is of another build)"}
     result = {
         "metric": "PBS/sec (shortint PARAM_MESSAGE_2_CARRY_2, classic PBS, f64 FFT external product)",
         "value": value, "unit": "PBS/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -185,14 +225,7 @@ def main():
                    "batch_per_gpu": B, "lwe_dimension": p.n, "glwe_dimension": p.k, "polynomial_size": p.N,
                    "pbs_kernel": {1: "generic_lds", 2: "wave_throughput"}.get(kernel_id, str(kernel_id)),
                    "parallelism": f"batch-sharded x{world}, key replicas, no collective"},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc_traffic_bytes(kernel_id),
-                     "algorithmic_bytes_per_launch": ALGO_BYTES_PER_PBS * B,
-                     "kernel_ms_avg": avg_kernel_s * 1e3,
-                     "note": "achieved = streaming model (key re-read per LWE, SURVEY §8d); traffic = HBM bytes per "
-                             "launch from the committed PMC passes of this kernel (profiles/pmc_latest.json: "
-                             "2 x FETCH_SIZE + WRITE_SIZE, tools/pmc.sh), not re-measured in this run; "
-                             "fp64 ceiling see DESIGN.md"},
+        "roofline": roofline,
     }
     if latency_ms is not None:
         result["extra"] = {"single_pbs_latency_ms": latency_ms,
@@ -200,7 +233,7 @@ def main():
                                                                                               str(latency_kernel)),
                            "note": "one PBS, batch 1, same key; not part of `value` (the reference publishes "
                                    "4.21 ms on an H100, BASELINE.md)"}
-    if world == 1 and args.kernel == 0:
+    if world == 1 and args.kernel == 0 and not args.no_extra:
         # the "N=1024" wording of BASELINE.json: the production set with polynomial size 1024 (k = 2, n = 885) on the
         # same GPU, uniform-random key and inputs like the reference's own benches; reported next to `value`, never in it
         from tests.common import C1P
@@ -234,8 +267,90 @@ def main():
         bytes2 = q.n * (q.k + 1) ** 2 * q.pbs_level * q.N * 8 + (q.n + 1) * 8 + (q.k + 1) * q.N * 8 + (q.k * q.N + 1) * 8
         result.setdefault("extra", {})["n1024_datapoint"] = {
             "params": q.name + " (n=885, k=2, N=1024, l=1)", "batch": B, "ms_per_launch": ms2,
-            "pbs_per_s": B / ms2 * 1e3, "roofline_frac_streaming_model": B / ms2 * 1e3 * bytes2 / (HBM_PEAK_GBPS * 1e9),
+            "pbs_per_s": B / ms2 * 1e3, "frac_hbm_streaming_model": B / ms2 * 1e3 * bytes2 / (HBM_PEAK_GBPS * 1e9),
+            "frac_fp64": B / ms2 * 1e3 * 1.8e8 / (FP64_PEAK_TFLOPS * 1e12),
             "pbs_kernel_id": int(lib.hip_backend_last_pbs_kernel())}
+    if world == 1 and args.kernel == 0 and not args.no_extra:
+        # BASELINE.json configs 3 and 4 next to the headline (never part of `value`): batch 4096 on this GPU, HIP-event
+        # time over 3 launches, and the GPU's output words compared with the CPU oracle on the first 64 LWEs.
+        from concurrent.futures import ThreadPoolExecutor
+        from tests.common import C4
+        PAR = 64
+
+        def datapoint(q, run_gpu, steps=3):
+            run_gpu()
+            lib.cuda_synchronize_device(g)
+            e0, e1 = lib.hip_event_create(), lib.hip_event_create()
+            lib.hip_event_record(e0, s)
+            for _ in range(steps):
+                run_gpu()
+            lib.hip_event_record(e1, s)
+            lib.cuda_synchronize_device(g)
+            ms = lib.hip_event_elapsed_ms(e0, e1) / steps
+            rate = B / ms * 1e3
+            return {"params": q.name, "batch": B, "ms_per_launch": ms, "pbs_per_s": rate,
+                    "frac_hbm_streaming_model": rate * bytes_per_pbs(q) / (HBM_PEAK_GBPS * 1e9),
+                    "pbs_kernel_id": int(lib.hip_backend_last_pbs_kernel())}
+
+        # ---- config 3: 64-bit prime NTT engine (tfhe-ntt semantics), same key, same ciphertexts as the headline
+        bsk_n = gpu.CudaLweBootstrapKey.from_lwe_bootstrap_key(keys.bsk, p.n, p.k, p.N, p.pbs_base_log, p.pbs_level,
+                                                               streams, ms_noise_reduction=True, engine="ntt64")
+        d_out3 = gpu.CudaLweCiphertextList.new(p.k * p.N, B, streams)
+        buf3 = C.c_void_p()
+        lib.scratch_cuda_programmable_bootstrap_64_async(s, g, C.byref(buf3), p.n, p.k, p.N, p.pbs_level, B, True, 1)
+        dp = datapoint(p, lambda: lib.hip_programmable_bootstrap_ntt64_async(
+            s, g, d_out3.d_vec.ptr, idx.ptr, d_lut.d_vec.ptr, lidx.ptr, d_in.d_vec.ptr, idx.ptr, bsk_n.d_vec.ptr, buf3,
+            p.n, p.k, p.N, p.pbs_base_log, p.pbs_level, B, 1, 0), steps=2)
+        out3 = d_out3.to_lwe_ciphertext_list(streams)
+        lib.cleanup_cuda_programmable_bootstrap_64(s, g, C.byref(buf3))
+        t0 = time.perf_counter()
+        ref3 = orc.pbs_batch(orc.ENGINE_NTT, cts[:PAR], lut, orc.convert_bsk_ntt(keys.bsk, p.n, p.k, p.N, p.pbs_level),
+                             p.n, p.k, p.N, p.pbs_base_log, p.pbs_level, 1)
+        traffic3, src3 = pmc_record("ntt")
+        dp.update({"engine": "Goldilocks NTT (p = 2^64 - 2^32 + 1), exact integer arithmetic", "bound": "int64 VALU",
+                   "mulmod_per_s": dp["pbs_per_s"] * 5.2e7, "hbm_traffic_bytes_per_launch": traffic3,
+                   "traffic_source": src3, "gpu_matches_cpu_bits": bool(np.array_equal(ref3, out3[:PAR])),
+                   "parity_sample": f"first {PAR} LWEs, all 2049 words, vs the C oracle's NTT engine "
+                                    f"({time.perf_counter() - t0:.1f} s CPU)",
+                   "decrypts": all(decrypt_big(p, keys, out3[i]) == f(msgs[i]) for i in range(PAR))})
+        result.setdefault("extra", {})["ntt"] = dp
+        del bsk_n, d_out3
+
+        # ---- config 4: multi-bit PBS, grouping factor 3 (uniform-random key and inputs like the reference's benches:
+        # bit parity with the oracle does not need a valid key, and a real 320 MB key takes minutes to encrypt)
+        q = C4
+        r4 = np.random.default_rng(11)
+        bsk4_h = r4.integers(0, 1 << 64, size=(q.n // q.grouping) * (1 << q.grouping) * q.pbs_level * 4 * q.N,
+                             dtype=np.uint64)
+        cts4 = r4.integers(0, 1 << 64, size=(B, q.n + 1), dtype=np.uint64)
+        lut4 = r4.integers(0, 1 << 64, size=2 * q.N, dtype=np.uint64)
+        bsk4 = gpu.CudaLweMultiBitBootstrapKey.from_lwe_multi_bit_bootstrap_key(bsk4_h, q.n, q.k, q.N, q.pbs_base_log,
+                                                                                q.pbs_level, q.grouping, streams)
+        d_in4 = gpu.CudaLweCiphertextList.from_lwe_ciphertext_list(cts4, streams)
+        d_out4 = gpu.CudaLweCiphertextList.new(q.k * q.N, B, streams)
+        d_lut4 = gpu.CudaGlweCiphertextList.from_glwe_ciphertext_list(lut4, q.k, q.N, streams)
+        buf4 = C.c_void_p()
+        lib.scratch_cuda_multi_bit_programmable_bootstrap_64_async(s, g, C.byref(buf4), q.k, q.N, q.pbs_level, B, True)
+        dp = datapoint(q, lambda: lib.cuda_multi_bit_programmable_bootstrap_64_async(
+            s, g, d_out4.d_vec.ptr, idx.ptr, d_lut4.d_vec.ptr, lidx.ptr, d_in4.d_vec.ptr, idx.ptr, bsk4.d_vec.ptr, buf4,
+            q.n, q.k, q.N, q.grouping, q.pbs_base_log, q.pbs_level, B, 1, 0), steps=2)
+        out4 = d_out4.to_lwe_ciphertext_list(streams)
+        lib.cleanup_cuda_multi_bit_programmable_bootstrap_64(s, g, C.byref(buf4))
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(max(1, len(os.sched_getaffinity(0)))) as ex:   # the oracle call releases the GIL
+            ref4 = np.concatenate(list(ex.map(lambda i: orc.pbs_multi_bit(
+                orc.ENGINE_FFT, cts4[i:i + 1], lut4, bsk4_h, q.n, q.k, q.N, q.pbs_base_log, q.pbs_level, q.grouping),
+                range(PAR))))
+        traffic4, src4 = pmc_record("mb_g3")
+        flop4 = 3.7e8   # ~1.22 MFLOP per group x 306 groups
+        dp.update({"engine": "f64 FFT, multi-bit grouping factor 3 (keybundle built per LWE and group on the GPU)",
+                   "frac_fp64": dp["pbs_per_s"] * flop4 / (FP64_PEAK_TFLOPS * 1e12),
+                   "hbm_traffic_bytes_per_launch": traffic4, "traffic_source": src4,
+                   "gpu_matches_cpu_bits": bool(np.array_equal(ref4, out4[:PAR])),
+                   "parity_sample": f"first {PAR} LWEs, all 2049 words, vs the C oracle's multi-bit f64 path "
+                                    f"({time.perf_counter() - t0:.1f} s CPU); uniform-random key and inputs"})
+        result["extra"]["multibit_g3"] = dp
+        del bsk4, d_in4, d_out4
     if world == 1 and not args.no_cpu_baseline:
         # CPU leg: the oracle's f64 path on the host cores actually available to this process
         # (affinity mask and cgroup quota, not the machine's nominal thread count), on a sample

@@ -129,3 +129,54 @@ def torus_distance(a, b):
     """max |a-b| on the 2^64 torus, element-wise wrapped to signed."""
     d = (np.asarray(a, dtype=np.uint64) - np.asarray(b, dtype=np.uint64)).astype(np.int64)
     return np.abs(d.astype(np.float64)).max() if d.size else 0.0
+
+
+# ---------------------------------------------------------------- centered-mean modulus switch, pure Python
+def centered_ms_reference(lwe, log_mod):
+    """Exact-integer restatement of tfhe/src/core_crypto/algorithms/modulus_switch.rs:57-103 (+ the plain switch of
+    fft_impl/common.rs:10-23 for the mask), independent of the C oracle: returns the switched ciphertext."""
+    M = (1 << 64) - 1
+
+    def ms(x):
+        return ((x + (1 << (63 - log_mod))) & M) >> (64 - log_mod)
+
+    def trunc_half(v):   # Rust's signed `/ 2`: toward zero
+        return -((-v) // 2) if v < 0 else v // 2
+
+    H, D = 0, 0
+    for a in lwe[:-1]:
+        a = int(a)
+        e = ((ms(a) << (64 - log_mod)) - a) & M
+        e = e - (1 << 64) if e >= (1 << 63) else e
+        h = trunc_half(e)
+        H = (H + h) & M
+        D += 2 * h - e
+    corr = (H - trunc_half(D) - (1 << (63 - log_mod))) & M
+    return np.array([ms(int(a)) for a in lwe[:-1]] + [ms((int(lwe[-1]) + corr) & M)], dtype=np.uint64), corr
+
+
+def centered_ms_edge_vectors(n, log_mod, seed=5):
+    """Mask patterns on the rounding boundaries of the switch (s = 64 - log_mod): exact ties r 2^s + 2^(s-1) (round
+    up, even error), tie +- 1 (odd errors of both signs: every halving truncates, and with n odd the sum of the
+    doubled halving errors is odd, so ITS halving truncates too — toward zero for either sign), exact multiples
+    (zero error), all-ones / all-zero words, and a mix; bodies on and next to a boundary."""
+    rng = np.random.default_rng(seed)
+    s = 64 - log_mod
+    M = (1 << 64) - 1
+    r = [int(v) for v in rng.integers(0, 1 << log_mod, size=n)]
+    tie = [((x << s) + (1 << (s - 1))) & M for x in r]
+    pats = {
+        "ties": tie,
+        "tie_minus_1": [(t - 1) & M for t in tie],
+        "tie_plus_1": [(t + 1) & M for t in tie],
+        "multiples": [(x << s) & M for x in r],
+        "all_ones": [M] * n,
+        "zeros": [0] * n,
+        "mixed": [[tie[i], (tie[i] - 1) & M, (tie[i] + 1) & M, (r[i] << s) & M, M][i % 5] for i in range(n)],
+    }
+    bodies = [0, (1 << (s - 1)) - 1, 1 << (s - 1), (1 << 63) + (1 << (s - 1)), M]
+    out = {}
+    for name, mask in pats.items():
+        for j, b in enumerate(bodies):
+            out[f"{name}/body{j}"] = np.array(mask + [b], dtype=np.uint64)
+    return out

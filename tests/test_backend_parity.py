@@ -344,6 +344,36 @@ def test_modulus_switch_and_sample_extract_helpers(kind):
     assert int(d_y.copy_to_cpu(st)[0]) == 1341128704 << 32
 
 
+@pytest.mark.parametrize("kind", BACKENDS)
+def test_centered_modulus_switch_on_rounding_boundaries(kind):
+    """The centered-mean switch (what PARAM_MESSAGE_2_CARRY_2 uses) on masks that sit on its rounding boundaries —
+    exact ties, tie +- 1 with n odd (the halving of the summed halving errors truncates toward zero from either
+    side), saturated words: the helper kernel against the exact-integer restatement of modulus_switch.rs:57-103,
+    and whole PBS launches (every f64 kernel reduces the correction in its own way) against the oracle."""
+    from .common import centered_ms_edge_vectors, centered_ms_reference
+    use_backend(kind)
+    st = gpu.CudaStreams.new_single_gpu(0)
+    for n, log_mod in ((31, 12), (10, 11)):
+        for name, lwe in centered_ms_edge_vectors(n, log_mod).items():
+            d_in = gpu.CudaVec.from_cpu_async(lwe, st)
+            d_out = gpu.CudaVec(n + 1, st)
+            gpu.cuda_modulus_switch_ciphertext(d_out, d_in, n, log_mod, True, st)
+            assert np.array_equal(d_out.copy_to_cpu(st), centered_ms_reference(lwe, log_mod)[0]), (n, log_mod, name)
+    # through the PBS kernels: odd n, N = 2048 (log_modulus 12), centered switch
+    p = dataclasses.replace(TOY_2048, name="toy_k1_N2048_n11", n=11)
+    c = ctx(kind, p, "fft64")
+    vecs = centered_ms_edge_vectors(p.n, p.log2N2)
+    cts = np.stack([vecs[k] for k in sorted(vecs)])
+    lut = orc.generate_lut(p.k, p.N, p.plaintext_modulus, p.delta, lambda x: (x + 3) % p.plaintext_modulus)
+    ref = oracle_pbs(p, c.keys, "fft64", cts, lut)
+    try:
+        for which in (1, 2, 3):
+            c.lib.hip_backend_set_fft_kernel(which)
+            assert np.array_equal(c.pbs(cts, lut), ref), f"kernel {which}"
+    finally:
+        c.lib.hip_backend_set_fft_kernel(0)
+
+
 # ------------------------------------------------------------------ throughput (wave) kernel
 @pytest.mark.parametrize("kind", BACKENDS)
 @pytest.mark.parametrize("p", [TOY_2048, TOY_2048_L2], ids=lambda p: p.name)
@@ -577,6 +607,66 @@ def test_multi_bit_full_size(which):
     assert [decrypt_big(p, keys, o) for o in out] == [f(m) for m in msgs]
     ref = oracle_pbs(p, keys, "fft64", cts[:3], lut)
     assert np.array_equal(out[:3], ref)
+
+
+@pytest.mark.gpu
+def test_full_size_ntt_engine_wide_batch_bit_exact():
+    """Config 3 at production size (n=918, N=2048): 259 LWEs (ragged against every tile size of the launch)
+    through the NTT engine, every output word against the oracle; all of them decrypt."""
+    from .common import C1
+    p = C1
+    keys = make_keys(p, with_ksk=False)
+    B = 259
+    msgs = [(5 * m + 1) % 16 for m in range(B)]
+    cts = encrypt_small(p, keys, msgs, seed=61)
+    f = lambda x: (x * x + 1) % 16
+    lut = orc.generate_lut(p.k, p.N, p.plaintext_modulus, p.delta, f)
+    out = Ctx("hip", p, keys, "ntt64").pbs(cts, lut)
+    assert np.array_equal(out, oracle_pbs(p, keys, "ntt64", cts, lut))
+    assert [decrypt_big(p, keys, o) for o in out] == [f(m) for m in msgs]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", ["g3_l2", "g4_l1"])
+def test_multi_bit_full_size_wide_batch_indexes_and_many_lut(which):
+    """Config 4 (g = 3) and the reference's GPU default (g = 4) at production size through the throughput kernel:
+    259 launches' worth of blocks reading a PERMUTED subset of 300 inputs, writing permuted outputs, choosing
+    between two LUTs per block — every output word against the oracle (the reference's GPU multi-bit tests:
+    tfhe/src/core_crypto/gpu/algorithms/test/lwe_multi_bit_programmable_bootstrapping.rs) — and a many-LUT call
+    (two functions per PBS) whose second outputs decrypt to the second function."""
+    from .common import C4, C4G4
+    p = C4 if which == "g3_l2" else C4G4
+    keys = make_keys(p, with_ksk=False)
+    n_in, B = 300, 259
+    msgs = [(3 * m + 2) % 16 for m in range(n_in)]
+    cts = encrypt_small(p, keys, msgs, seed=71)
+    f0 = lambda x: (x * x) % 16
+    f1 = lambda x: (15 - x) % 16
+    luts = np.stack([orc.generate_lut(p.k, p.N, p.plaintext_modulus, p.delta, f) for f in (f0, f1)])
+    rng = np.random.default_rng(3)
+    in_idx = rng.permutation(n_in)[:B]
+    out_idx = rng.permutation(B)
+    lut_idx = rng.integers(0, 2, size=B)
+    c = Ctx("hip", p, keys, "fft64")
+    lib = use_backend("hip")
+    out = c.pbs(cts, luts, lut_indexes=lut_idx, in_indexes=in_idx, out_indexes=out_idx, out_count=B)
+    assert lib.hip_backend_last_pbs_kernel() == 6
+    for t, lut in enumerate(luts):
+        sel = np.nonzero(lut_idx == t)[0]
+        ref = oracle_pbs(p, keys, "fft64", cts[in_idx[sel]], lut)
+        assert np.array_equal(out[out_idx[sel]], ref), f"LUT {t}: GPU differs from the oracle"
+    assert [decrypt_big(p, keys, out[out_idx[i]]) for i in range(B)] == \
+        [(f1 if lut_idx[i] else f0)(msgs[in_idx[i]]) for i in range(B)]
+    # many-LUT (shortint generate_many_lookup_table layout): 3-bit inputs, function t occupies boxes 8t..8t+7 of
+    # the LUT and is read by extracting coefficient t * stride, stride = 8 boxes
+    small = [m % 8 for m in range(140)]
+    cts8 = encrypt_small(p, keys, small, seed=72)
+    g0, g1 = (lambda x: (x + 1) % 8), (lambda x: (7 - x) % 8)
+    packed = orc.generate_lut(p.k, p.N, p.plaintext_modulus, p.delta, lambda x: g0(x) if x < 8 else g1(x - 8))
+    stride = 8 * (p.N // 16)
+    out2 = c.pbs(cts8, packed, num_many_lut=2, lut_stride=stride)
+    assert [decrypt_big(p, keys, o) for o in out2[:140]] == [g0(m) for m in small]
+    assert [decrypt_big(p, keys, o) for o in out2[140:]] == [g1(m) for m in small]
 
 
 @pytest.mark.gpu

@@ -134,26 +134,27 @@ def test_modswitch_prime_pow2_formulas():
 
 
 def test_modulus_switch_and_centered_correction_formula():
+    from .common import centered_ms_reference
     rng = np.random.default_rng(13)
     for log_mod in (9, 10, 11, 12, 13):
         lwe = rng.integers(0, 1 << 64, size=65, dtype=np.uint64)
-        # independent python restatement of modulus_switch.rs:57-103
-        def ms(x):
-            return ((x + (1 << (63 - log_mod))) & M64) >> (64 - log_mod)
-        H, D = 0, 0
-        for a in lwe[:-1]:
-            a = int(a)
-            e = ((ms(a) << (64 - log_mod)) - a) & M64
-            e = e - (1 << 64) if e >= (1 << 63) else e
-            h = int(e / 2)  # trunc toward zero
-            H = (H + h) & M64
-            D += 2 * h - e
-        corr = (H - int(D / 2) - (1 << (63 - log_mod))) & M64
+        ref, corr = centered_ms_reference(lwe, log_mod)   # exact-integer restatement of modulus_switch.rs:57-103
         assert orc.centered_ms_body_correction(lwe, log_mod) == corr
         out = orc.lwe_modulus_switch(lwe, log_mod, 1)
-        assert int(out[-1]) == ms((int(lwe[-1]) + corr) & M64)
-        assert all(int(o) == ms(int(a)) for o, a in zip(out[:-1], lwe[:-1]))
+        assert np.array_equal(out, ref)
         assert out.max() < (1 << log_mod)
+
+
+def test_centered_modulus_switch_on_rounding_boundaries():
+    """Ties, tie +- 1 (odd errors of either sign), exact multiples, saturated words; n odd and even so that the
+    halving of the summed halving errors truncates toward zero from both sides (modulus_switch.rs:78-96)."""
+    from .common import centered_ms_edge_vectors, centered_ms_reference
+    for log_mod in (11, 12):
+        for n in (9, 10, 31):
+            for name, lwe in centered_ms_edge_vectors(n, log_mod).items():
+                ref, corr = centered_ms_reference(lwe, log_mod)
+                assert orc.centered_ms_body_correction(lwe, log_mod) == corr, (log_mod, n, name)
+                assert np.array_equal(orc.lwe_modulus_switch(lwe, log_mod, 1), ref), (log_mod, n, name)
 
 
 def test_sample_extract_formula():

@@ -275,7 +275,8 @@ def cuda_programmable_bootstrap_lwe_ciphertext(input, output, accumulator, lut_i
 
 
 def cuda_multi_bit_programmable_bootstrap_lwe_ciphertext(input, output, accumulator, lut_indexes, output_indexes,
-                                                         input_indexes, multi_bit_bsk, streams):
+                                                         input_indexes, multi_bit_bsk, streams, num_many_lut=1,
+                                                         lut_stride=0):
     """gpu/algorithms/lwe_multi_bit_programmable_bootstrapping.rs:10-145 + gpu/ffi.rs:208-309"""
     bsk = multi_bit_bsk
     assert input.lwe_dimension == bsk.input_lwe_dimension, "Mismatched input LweDimension"
@@ -283,6 +284,7 @@ def cuda_multi_bit_programmable_bootstrap_lwe_ciphertext(input, output, accumula
     assert accumulator.glwe_dimension == bsk.glwe_dimension, "Mismatched GlweSize"
     assert accumulator.polynomial_size == bsk.polynomial_size, "Mismatched PolynomialSize"
     num_samples = input.lwe_ciphertext_count
+    assert output.lwe_ciphertext_count >= num_samples * num_many_lut
     lib = _lib()
     buf = C.c_void_p()
     s, g = streams.ptr[0], streams.gpu_indexes[0]
@@ -291,7 +293,7 @@ def cuda_multi_bit_programmable_bootstrap_lwe_ciphertext(input, output, accumula
     lib.cuda_multi_bit_programmable_bootstrap_64_async(
         s, g, output.d_vec.ptr, output_indexes.ptr, accumulator.d_vec.ptr, lut_indexes.ptr, input.d_vec.ptr,
         input_indexes.ptr, bsk.d_vec.ptr, buf, bsk.input_lwe_dimension, bsk.glwe_dimension, bsk.polynomial_size,
-        bsk.grouping_factor, bsk.decomp_base_log, bsk.decomp_level_count, num_samples, 1, 0)
+        bsk.grouping_factor, bsk.decomp_base_log, bsk.decomp_level_count, num_samples, num_many_lut, lut_stride)
     lib.cleanup_cuda_multi_bit_programmable_bootstrap_64(s, g, C.byref(buf))
 
 

@@ -30,8 +30,8 @@ def rand_u64(n):
 
 
 def timed(fn, steps=3, warmup=1):
-    if "mb1" in sys.argv or "lat1" in sys.argv or "ntt1" in sys.argv or "n1024x" in sys.argv:
-        warmup = 0
+    if any(a in sys.argv for a in ("mb1", "lat1", "ntt1", "n1024x", "wave1", "ntt4096", "n1024x4096", "ks1")):
+        warmup = 0   # exactly one launch: the PMC passes of tools/pmc_record.py
     for _ in range(warmup):
         fn()
     lib.cuda_synchronize_device(G)
@@ -152,6 +152,14 @@ if __name__ == "__main__":
         pbs_case(C1, 4096, engine="ntt64", steps=2)
     if "mb" in which:
         pbs_case(C4, 4096, steps=2)
+    if "wave1" in which:   # one launch each, no warm-up (PMC passes, tools/pmc_record.py)
+        pbs_case(C1, 4096, kernel=2, steps=1)
+    if "ntt4096" in which:
+        pbs_case(C1, 4096, engine="ntt64", steps=1)
+    if "n1024x4096" in which:
+        pbs_case(C1P, 4096, steps=1)
+    if "ks1" in which:
+        ks_case(C1, 4096, steps=1)
     if "lat1" in which:  # one launch of the latency kernel, no warm-up (PMC passes)
         pbs_case(C1, 256, kernel=3, steps=1)
     if "n1024x" in which:  # one launch, no warm-up (PMC passes)
