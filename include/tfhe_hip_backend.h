@@ -350,6 +350,7 @@ void hip_test_arith_async(void *stream, uint32_t gpu_index, uint32_t op, void co
 void hip_test_transform_async(void *stream, uint32_t gpu_index, uint32_t op,
                               uint32_t polynomial_size, void const *in, void *out);
 void hip_test_fft_tables_host(uint32_t polynomial_size, double *fwd, double *inv, double *untwist);
+void hip_test_monomial_table_host(uint32_t polynomial_size, double *mono /* 4 * polynomial_size doubles */);
 
 #ifdef __cplusplus
 }

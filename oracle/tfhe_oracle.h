@@ -131,17 +131,25 @@ void orc_pbs_fft(uint64_t *lwe_out, const uint64_t *lwe_in, const uint64_t *lut,
                  uint32_t base_log, uint32_t level, uint32_t ms_type);
 
 /* ---- multi-bit PBS, deterministic semantics
- *      (lwe_multi_bit_programmable_bootstrapping.rs:647-880), keybundle built in
- *      the integer domain then one forward transform per polynomial ---- */
+ *      (lwe_multi_bit_programmable_bootstrapping.rs:647-880).  exact engine: keybundle combined in the
+ *      integer domain (standard-domain key); f64 engine: combined in the Fourier domain like the CPU
+ *      reference (:116-156), key converted once by orc_convert_multi_bit_bsk_fft ---- */
 void orc_multi_bit_modulus_switch(const uint64_t *lwe, uint32_t n, uint32_t log_modulus,
                                   uint32_t grouping_factor, uint64_t *degrees /* (n/g)*(2^g) */,
                                   uint64_t *body_hat);
 void orc_pbs_multi_bit_exact(uint64_t *lwe_out, const uint64_t *lwe_in, const uint64_t *lut,
                              const uint64_t *bsk_std, uint32_t n, uint32_t k, uint32_t N,
                              uint32_t base_log, uint32_t level, uint32_t grouping_factor);
+void orc_monomial_table(uint32_t N, double *z /* 2N complex: e^{i pi j / N} */);
+void orc_monomial_fourier(uint32_t N, uint64_t degree, const double *z, double *m /* N/2 complex */);
+void orc_convert_multi_bit_bsk_fft(double *bsk_f, const uint64_t *bsk_std, uint32_t n, uint32_t k, uint32_t N,
+                                   uint32_t level, uint32_t grouping_factor);
 void orc_pbs_multi_bit_fft(uint64_t *lwe_out, const uint64_t *lwe_in, const uint64_t *lut,
-                           const uint64_t *bsk_std, uint32_t n, uint32_t k, uint32_t N,
+                           const double *bsk_f, uint32_t n, uint32_t k, uint32_t N,
                            uint32_t base_log, uint32_t level, uint32_t grouping_factor);
+void orc_pbs_multi_bit_fft_batch(uint64_t *lwe_out, const uint64_t *lwe_in, const uint64_t *lut,
+                                 const double *bsk_f, uint32_t n, uint32_t k, uint32_t N, uint32_t base_log,
+                                 uint32_t level, uint32_t grouping_factor, uint32_t count, uint32_t threads);
 
 /* ---- batches (OpenMP over independent LWEs, like the reference's rayon bench,
  *      tfhe-benchmark/benches/core_crypto/pbs_bench.rs:176-196) ---- */

@@ -4,16 +4,27 @@
  * Follows cc/algorithms/lwe_multi_bit_programmable_bootstrapping.rs (deterministic
  * variant, :647-880) and cc/algorithms/lwe_multi_bit_bootstrap_key_generation.rs.
  *
- * The CPU reference combines the group's GGSWs in the FOURIER domain
- * (prepare_multi_bit_ggsw_mem_optimized :116-156); the reference's GPU backend
- * combines them in the STANDARD (u64) domain with exact monomial products and
- * transforms afterwards (backends/tfhe-cuda-backend/cuda/src/pbs/
- * programmable_bootstrap_multibit.cuh:40-330).  We restate the latter (it is the
- * interface we replace, and it is exact up to the final transform); SURVEY D7
- * explains why raw bits cannot be compared with the CPU Fourier-combine anyway.
+ * f64 engine: like the CPU reference, the group's 2^g GGSWs are kept in the FOURIER domain and
+ * combined there (prepare_multi_bit_ggsw_mem_optimized :116-156):
+ *     GGSW_comb = GGSW_0 + sum_{s >= 1} GGSW_s (.) FFT(X^{deg_s})
+ * where the transform of a monomial is a vector of roots of unity (fft/mod.rs:411-446
+ * incomplete_monomial_forward_as_integer + tfhe-fft unordered.rs fwd_monomial).  In this repository's
+ * fixed transform order (position p holds the evaluation at zeta^(1 + 4 bitrev(p)),
+ * zeta = e^{i pi/N}) the monomial factor at position p is, bit for bit,
+ *     M_d[p] = cmul( Z[((1 + 4 bitrev_{L-4}(p >> 4)) d) mod 2N] , Z[(N/8) ((bitrev_4(p & 15) d) mod 16)] )
+ * with Z[j] = e^{i pi j / N} (2N entries, octant-symmetric, evaluated in long double and rounded once),
+ * L = log2(N/2), cmul(x, y) = (fma(-x.im, y.im, x.re y.re), fma(x.im, y.re, x.re y.im)); the split into a
+ * per-16-positions base and a 16th root of unity is what lets a GPU wave derive its 16 factors per lane
+ * from one table entry.  The combine accumulates subsets in increasing s:
+ *     KB[p] <- K_0[p];  KB[p] <- (fma(-k.im, m.im, fma(k.re, m.re, KB.re)), fma(k.im, m.re, fma(k.re, m.im, KB.im)))
+ * exact engine: the reference's GPU backend combines in the STANDARD (u64) domain with exact monomial
+ * products (backends/tfhe-cuda-backend/cuda/src/pbs/programmable_bootstrap_multibit.cuh:40-330); that
+ * form is kept for the exact-integer verification engine, where it is error free.
  */
 #include "tfhe_oracle.h"
 #include "tfhe_oracle_internal.h"
+#include <math.h>
+#include <omp.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -81,7 +92,7 @@ static void build_keybundle(uint64_t *kb, const uint64_t *group, const uint64_t 
   }
 }
 
-static void multi_bit_core(int use_fft, uint64_t *lwe_out, const uint64_t *lwe_in,
+static void multi_bit_core(uint64_t *lwe_out, const uint64_t *lwe_in,
                            const uint64_t *lut, const uint64_t *bsk_std, uint32_t n, uint32_t k,
                            uint32_t N, uint32_t base_log, uint32_t level, uint32_t g) {
   size_t gl = (size_t)(k + 1) * N;
@@ -95,12 +106,6 @@ static void multi_bit_core(int use_fft, uint64_t *lwe_out, const uint64_t *lwe_i
   uint64_t *ct0 = buf, *ct1 = buf + gl, *states = buf + 2 * gl, *kb = buf + 3 * gl,
            *tmp = kb + ggsw_sz;
   int64_t *digits = (int64_t *)malloc(sizeof(int64_t) * gl);
-  double *kb_f = NULL, *fbuf = NULL, *outbuf = NULL;
-  if (use_fft) {
-    kb_f = (double *)malloc(sizeof(double) * ggsw_sz);
-    fbuf = (double *)malloc(sizeof(double) * (N + gl));
-    outbuf = fbuf + N;
-  }
   /* acc <- LUT * X^{-b_hat}  (:700-720 of the reference's blind rotate) */
   for (uint32_t p = 0; p <= k; ++p) orc_monomial_div(ct0 + (size_t)p * N, lut + (size_t)p * N, N, body_hat);
 
@@ -108,27 +113,113 @@ static void multi_bit_core(int use_fft, uint64_t *lwe_out, const uint64_t *lwe_i
   for (uint32_t grp = 0; grp < groups; ++grp) {
     build_keybundle(kb, bsk_std + (size_t)grp * per * ggsw_sz, deg + (size_t)grp * per, k, N, level, g, tmp);
     memset(dst, 0, sizeof(uint64_t) * gl);
-    if (use_fft) {
-      for (size_t p = 0; p < ggsw_sz / N; ++p) orc_fft_forward_torus(kb_f + p * N, kb + p * N, N);
-      orc_ext_product_fft(dst, src, kb_f, k, N, base_log, level, states, digits, fbuf, outbuf);
-    } else {
-      orc_ext_product_exact(dst, src, kb, k, N, base_log, level, digits, states);
-    }
+    orc_ext_product_exact(dst, src, kb, k, N, base_log, level, digits, states);
     uint64_t *t = src; src = dst; dst = t;
   }
   orc_sample_extract(lwe_out, src, k, N, 0);
   free(deg); free(buf); free(digits);
-  if (use_fft) { free(kb_f); free(fbuf); }
 }
 
 void orc_pbs_multi_bit_exact(uint64_t *lwe_out, const uint64_t *lwe_in, const uint64_t *lut,
                              const uint64_t *bsk_std, uint32_t n, uint32_t k, uint32_t N,
                              uint32_t base_log, uint32_t level, uint32_t g) {
-  multi_bit_core(0, lwe_out, lwe_in, lut, bsk_std, n, k, N, base_log, level, g);
+  multi_bit_core(lwe_out, lwe_in, lut, bsk_std, n, k, N, base_log, level, g);
 }
 
+/* Z[j] = e^{i pi j / N}, j < 2N: octant [0, N/4] evaluated, the rest by exact symmetries */
+void orc_monomial_table(uint32_t N, double *z) {
+  const long double PI = 3.14159265358979323846264338327950288L;
+  for (uint32_t j = 0; j <= N / 4; ++j) {
+    long double ang = PI * (long double)j / (long double)N;
+    z[2 * j] = (double)cosl(ang);
+    z[2 * j + 1] = (double)sinl(ang);
+  }
+  z[0] = 1.0; z[1] = 0.0;
+  for (uint32_t j = N / 4 + 1; j <= N / 2; ++j) { z[2 * j] = z[2 * (N / 2 - j) + 1]; z[2 * j + 1] = z[2 * (N / 2 - j)]; }
+  for (uint32_t j = N / 2 + 1; j <= N; ++j) { z[2 * j] = -z[2 * (j - N / 2) + 1]; z[2 * j + 1] = z[2 * (j - N / 2)]; }
+  for (uint32_t j = N + 1; j < 2 * N; ++j) { z[2 * j] = -z[2 * (j - N)]; z[2 * j + 1] = -z[2 * (j - N) + 1]; }
+}
+
+static uint32_t bitrev_u32(uint32_t x, uint32_t bits) {
+  uint32_t r = 0;
+  for (uint32_t i = 0; i < bits; ++i) { r = (r << 1) | (x & 1); x >>= 1; }
+  return r;
+}
+
+/* M_d[p] for p < N/2 (re, im interleaved) */
+void orc_monomial_fourier(uint32_t N, uint64_t degree, const double *z, double *m) {
+  uint32_t n = N / 2, L = orc_log2_u32(n);
+  for (uint32_t p = 0; p < n; ++p) {
+    uint32_t jb = (uint32_t)(((uint64_t)(1 + 4 * bitrev_u32(p >> 4, L - 4)) * degree) % (2 * N));
+    uint32_t jw = (N / 8) * (uint32_t)((bitrev_u32(p & 15, 4) * degree) % 16);
+    double xr = z[2 * jb], xi = z[2 * jb + 1], yr = z[2 * jw], yi = z[2 * jw + 1];
+    m[2 * p] = fma(-xi, yi, xr * yr);
+    m[2 * p + 1] = fma(xi, yr, xr * yi);
+  }
+}
+
+/* standard-domain multi-bit key -> Fourier domain, same nesting [group][subset][level][row][col], each
+ * polynomial N/2 complex in transform-position order (cc/algorithms/lwe_multi_bit_bootstrap_key_conversion.rs) */
+void orc_convert_multi_bit_bsk_fft(double *bsk_f, const uint64_t *bsk_std, uint32_t n, uint32_t k, uint32_t N,
+                                   uint32_t level, uint32_t g) {
+  size_t polys = (size_t)(n / g) * ((size_t)1 << g) * level * (k + 1) * (k + 1);
+  orc_fft_forward_torus(bsk_f, bsk_std, N); /* builds the plan outside the parallel region */
+#pragma omp parallel for schedule(static)
+  for (size_t p = 0; p < polys; ++p) orc_fft_forward_torus(bsk_f + p * N, bsk_std + p * N, N);
+}
+
+/* lwe_multi_bit_programmable_bootstrapping.rs:116-156 + :647-880, f64 engine; bsk_f from
+ * orc_convert_multi_bit_bsk_fft */
 void orc_pbs_multi_bit_fft(uint64_t *lwe_out, const uint64_t *lwe_in, const uint64_t *lut,
-                           const uint64_t *bsk_std, uint32_t n, uint32_t k, uint32_t N,
+                           const double *bsk_f, uint32_t n, uint32_t k, uint32_t N,
                            uint32_t base_log, uint32_t level, uint32_t g) {
-  multi_bit_core(1, lwe_out, lwe_in, lut, bsk_std, n, k, N, base_log, level, g);
+  size_t gl = (size_t)(k + 1) * N;
+  size_t ggsw_sz = (size_t)level * (k + 1) * gl; /* doubles per Fourier GGSW = u64 per standard GGSW */
+  uint32_t groups = n / g, per = 1u << g, nn = N / 2;
+  uint64_t *deg = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)groups * per);
+  uint64_t body_hat;
+  orc_multi_bit_modulus_switch(lwe_in, n, orc_log2_u32(2 * N), g, deg, &body_hat);
+  uint64_t *buf = (uint64_t *)malloc(sizeof(uint64_t) * gl * 3);
+  uint64_t *ct0 = buf, *ct1 = buf + gl, *states = buf + 2 * gl;
+  int64_t *digits = (int64_t *)malloc(sizeof(int64_t) * gl);
+  double *kb_f = (double *)malloc(sizeof(double) * ggsw_sz);
+  double *fbuf = (double *)malloc(sizeof(double) * (N + gl));
+  double *outbuf = fbuf + N;
+  double *z = (double *)malloc(sizeof(double) * 4 * N);
+  double *mono = (double *)malloc(sizeof(double) * N);
+  orc_monomial_table(N, z);
+  for (uint32_t p = 0; p <= k; ++p) orc_monomial_div(ct0 + (size_t)p * N, lut + (size_t)p * N, N, body_hat);
+  uint64_t *src = ct0, *dst = ct1;
+  for (uint32_t grp = 0; grp < groups; ++grp) {
+    const double *group = bsk_f + (size_t)grp * per * ggsw_sz;
+    memcpy(kb_f, group, sizeof(double) * ggsw_sz);
+    for (uint32_t s = 1; s < per; ++s) {
+      const double *ks = group + (size_t)s * ggsw_sz;
+      orc_monomial_fourier(N, deg[(size_t)grp * per + s], z, mono);
+      for (size_t poly = 0; poly < ggsw_sz / N; ++poly)
+        for (uint32_t p = 0; p < nn; ++p) {
+          double kr = ks[poly * N + 2 * p], ki = ks[poly * N + 2 * p + 1];
+          double mr = mono[2 * p], mi = mono[2 * p + 1];
+          double *o = kb_f + poly * N + 2 * p;
+          o[0] = fma(-ki, mi, fma(kr, mr, o[0]));
+          o[1] = fma(ki, mr, fma(kr, mi, o[1]));
+        }
+    }
+    memset(dst, 0, sizeof(uint64_t) * gl);
+    orc_ext_product_fft(dst, src, kb_f, k, N, base_log, level, states, digits, fbuf, outbuf);
+    uint64_t *t = src; src = dst; dst = t;
+  }
+  orc_sample_extract(lwe_out, src, k, N, 0);
+  free(deg); free(buf); free(digits); free(kb_f); free(fbuf); free(z); free(mono);
+}
+
+void orc_pbs_multi_bit_fft_batch(uint64_t *lwe_out, const uint64_t *lwe_in, const uint64_t *lut,
+                                 const double *bsk_f, uint32_t n, uint32_t k, uint32_t N, uint32_t base_log,
+                                 uint32_t level, uint32_t g, uint32_t count, uint32_t threads) {
+  size_t out_sz = (size_t)k * N + 1;
+  (void)threads;
+#pragma omp parallel for schedule(dynamic) num_threads(threads ? (int)threads : omp_get_max_threads())
+  for (uint32_t i = 0; i < count; ++i)
+    orc_pbs_multi_bit_fft(lwe_out + (size_t)i * out_sz, lwe_in + (size_t)i * (n + 1), lut, bsk_f, n, k, N,
+                          base_log, level, g);
 }

@@ -66,6 +66,11 @@ static inline uint64_t __umul64hi(uint64_t a, uint64_t b) {
   return (uint64_t)(((unsigned __int128)a * b) >> 64);
 }
 static inline uint32_t __umulhi(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
+static inline uint32_t __brev(uint32_t x) {
+  uint32_t r = 0;
+  for (int i = 0; i < 32; ++i) r |= ((x >> i) & 1u) << (31 - i);
+  return r;
+}
 
 // kernel launch: HX_LAUNCH(kernel, grid, block, smem_bytes, stream, args...)
 #define HX_LAUNCH(kern, grid, block, smem, stream, ...) \

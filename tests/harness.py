@@ -106,15 +106,9 @@ def oracle_bsk(p, keys, engine):
 
 def oracle_pbs(p, keys, engine, cts, lut):
     if p.grouping:
-        e = orc.ENGINE_FFT if engine == "fft64" else orc.ENGINE_EXACT
-        cts = np.ascontiguousarray(cts, dtype=np.uint64).reshape(-1, p.n + 1)
-        if len(cts) < 8:
-            return orc.pbs_multi_bit(e, cts, lut, keys.bsk, p.n, p.k, p.N, p.pbs_base_log, p.pbs_level, p.grouping)
-        from concurrent.futures import ThreadPoolExecutor   # one LWE per call; the C call releases the GIL
-        with ThreadPoolExecutor(max(1, len(os.sched_getaffinity(0)))) as ex:
-            return np.concatenate(list(ex.map(lambda i: orc.pbs_multi_bit(
-                e, cts[i:i + 1], lut, keys.bsk, p.n, p.k, p.N, p.pbs_base_log, p.pbs_level, p.grouping),
-                range(len(cts)))))
+        # f64 engine: Fourier-domain key (converted once per key, cached), OpenMP over the LWEs inside the C call
+        return orc.pbs_multi_bit(orc.ENGINE_FFT if engine == "fft64" else orc.ENGINE_EXACT, cts, lut, keys.bsk,
+                                 p.n, p.k, p.N, p.pbs_base_log, p.pbs_level, p.grouping)
     bsk, e = oracle_bsk(p, keys, engine)
     return orc.pbs_batch(e, cts, lut, bsk, p.n, p.k, p.N, p.pbs_base_log, p.pbs_level, p.ms_type)
 

@@ -232,15 +232,50 @@ def pbs_batch(engine, lwe_in, lut, bsk, n, k, N, base_log, level, ms_type, threa
     return out
 
 
-def pbs_multi_bit(engine, lwe_in, lut, bsk_std, n, k, N, base_log, level, g):
+def convert_multi_bit_bsk_fft(bsk_std, n, k, N, level, g):
+    """standard-domain multi-bit key -> Fourier domain (what the f64 multi-bit engine consumes)"""
+    bsk_std = _u64(bsk_std)
+    out = np.zeros(bsk_std.size, dtype=np.float64)
+    lib().orc_convert_multi_bit_bsk_fft(_p(out), _p(bsk_std), u32(n), u32(k), u32(N), u32(level), u32(g))
+    return out
+
+
+_mb_fft_cache = {}
+
+
+def pbs_multi_bit(engine, lwe_in, lut, bsk_std, n, k, N, base_log, level, g, threads=0):
+    """engine EXACT: integer-domain keybundle from the standard key; FFT: Fourier-domain combine — the key is
+    converted once per key array (cached by identity) and the batch runs under OpenMP."""
     lwe_in = _u64(lwe_in).reshape(-1, n + 1)
     lut = _u64(lut)
     out = np.zeros((lwe_in.shape[0], k * N + 1), dtype=np.uint64)
-    fn = lib().orc_pbs_multi_bit_fft if engine == ENGINE_FFT else lib().orc_pbs_multi_bit_exact
+    if engine == ENGINE_FFT:
+        key = (id(bsk_std), n, k, N, level, g)
+        if key not in _mb_fft_cache:
+            _mb_fft_cache.clear()   # one converted key at a time (320 MB at production size)
+            _mb_fft_cache[key] = (bsk_std, convert_multi_bit_bsk_fft(bsk_std, n, k, N, level, g))
+        bsk_f = _mb_fft_cache[key][1]
+        lib().orc_pbs_multi_bit_fft_batch(_p(out), _p(lwe_in), _p(lut), _p(bsk_f), u32(n), u32(k), u32(N),
+                                          u32(base_log), u32(level), u32(g), u32(lwe_in.shape[0]), u32(threads))
+        return out
+    bsk_std = _u64(bsk_std)
     for i in range(lwe_in.shape[0]):
-        fn(_p(out[i]), _p(lwe_in[i]), _p(lut), _p(bsk_std), u32(n), u32(k), u32(N), u32(base_log),
-           u32(level), u32(g))
+        lib().orc_pbs_multi_bit_exact(_p(out[i]), _p(lwe_in[i]), _p(lut), _p(bsk_std), u32(n), u32(k), u32(N),
+                                      u32(base_log), u32(level), u32(g))
     return out
+
+
+def monomial_table(N):
+    z = np.zeros(4 * N, dtype=np.float64)
+    lib().orc_monomial_table(u32(N), _p(z))
+    return z
+
+
+def monomial_fourier(N, degree, z=None):
+    z = monomial_table(N) if z is None else z
+    m = np.zeros(N, dtype=np.float64)
+    lib().orc_monomial_fourier(u32(N), C.c_uint64(int(degree)), _p(z), _p(m))
+    return m
 
 
 def multi_bit_modulus_switch(lwe, log_modulus, g):

@@ -113,6 +113,9 @@ def test_transforms_match_oracle(kind, N):
                                  untw.ctypes.data_as(C.c_void_p))
     for a, b in zip((fwd, inv, untw), orc.fft_tables(N)):
         assert np.array_equal(a.view(np.uint64), b.view(np.uint64))
+    mono = np.zeros(4 * N)   # e^{i pi j / N}: the multi-bit monomial factors are read from it
+    lib.hip_test_monomial_table_host(N, mono.ctypes.data_as(C.c_void_p))
+    assert np.array_equal(mono.view(np.uint64), orc.monomial_table(N).view(np.uint64))
 
     def run(op, host_in, out_dtype):
         d_in = gpu.CudaVec.from_cpu_async(host_in, st)

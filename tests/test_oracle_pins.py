@@ -157,6 +157,46 @@ def test_centered_modulus_switch_on_rounding_boundaries():
                 assert np.array_equal(orc.lwe_modulus_switch(lwe, log_mod, 1), ref), (log_mod, n, name)
 
 
+def test_multi_bit_monomial_factors_are_the_transform_of_the_monomial():
+    """Fourier-domain keybundle (lwe_multi_bit_programmable_bootstrapping.rs:116-156, fft/mod.rs:411-446): the
+    factor the oracle and the kernels multiply a key polynomial by at transform position p must be the value of
+    X^d there — checked against the oracle's own forward transform of the monomial (d >= N: X^d = -X^(d-N)) and
+    against e^{i pi (1 + 4 bitrev p) d / N} evaluated directly."""
+    for N in (256, 1024, 2048):
+        n, L = N // 2, (N // 2).bit_length() - 1
+        z = orc.monomial_table(N)
+        ang = np.pi * np.arange(2 * N) / N
+        assert np.abs(z[0::2] - np.cos(ang)).max() < 2e-15 and np.abs(z[1::2] - np.sin(ang)).max() < 2e-15
+        assert (z[0], z[1], z[N], z[N + 1], z[2 * N], z[2 * N + 1]) == (1.0, 0.0, 0.0, 1.0, -1.0, 0.0)
+        br = np.array([int(format(p, "0%db" % L)[::-1], 2) for p in range(n)])
+        for d in (0, 1, 5, N - 1, N, N + 3, 2 * N - 1, 777):
+            digits = np.zeros(N, dtype=np.int64)
+            digits[d % N] = 1 if d < N else -1
+            m = orc.monomial_fourier(N, d, z)
+            assert np.abs(np.asarray(orc.fft_forward_int(digits)).reshape(-1) - m).max() < 1e-12
+            e = np.pi * (((1 + 4 * br) * d) % (2 * N)) / N
+            assert np.abs(m[0::2] - np.cos(e)).max() < 1e-15 and np.abs(m[1::2] - np.sin(e)).max() < 1e-15
+
+
+def test_multi_bit_fourier_combine_agrees_with_the_integer_combine():
+    """The f64 multi-bit engine (keybundle combined in the Fourier domain) and the exact engine (integer monomial
+    products) decrypt to the same message with phases a few 2^40 apart at most (toy set, no key noise budget
+    issue): pins the combine order / degrees / key layout of the new path against the exact one."""
+    from .common import TOY_MB, make_keys, encrypt_small, decrypt_big
+    p = TOY_MB
+    keys = make_keys(p)
+    msgs = [0, 1, 2, 3]
+    cts = encrypt_small(p, keys, msgs, seed=4)
+    f = lambda x: (x + 1) % p.plaintext_modulus
+    lut = orc.generate_lut(p.k, p.N, p.plaintext_modulus, p.delta, f)
+    a = orc.pbs_multi_bit(orc.ENGINE_FFT, cts, lut, keys.bsk, p.n, p.k, p.N, p.pbs_base_log, p.pbs_level, p.grouping)
+    b = orc.pbs_multi_bit(orc.ENGINE_EXACT, cts, lut, keys.bsk, p.n, p.k, p.N, p.pbs_base_log, p.pbs_level, p.grouping)
+    for x, y, m in zip(a, b, msgs):
+        assert decrypt_big(p, keys, x) == decrypt_big(p, keys, y) == f(m)
+        d = (int(orc.lwe_decrypt(x, keys.glwe_sk)) - int(orc.lwe_decrypt(y, keys.glwe_sk))) & M64
+        assert min(d, (1 << 64) - d) < (1 << 50)
+
+
 def test_sample_extract_formula():
     rng = np.random.default_rng(17)
     k, N = 2, 64

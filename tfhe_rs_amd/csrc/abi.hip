@@ -37,8 +37,7 @@ struct MultiBitBuffer {
   bool gpu_memory_allocated;
   FftTables fft;
   uint32_t chunk;
-  cplx *keybundle;
-  uint64_t *acc;
+  uint64_t *acc;   // latency path: the accumulators crossing passes
   // latency path (small batches): keybundles of lat_groups groups for lat_samples ciphertexts
   // (allocated by the first call that takes that path: integer operations hold several scratches at once and
   // most never see a small batch)
@@ -376,14 +375,26 @@ void cuda_convert_lwe_multi_bit_programmable_bootstrap_key_64_async(void *stream
                                                                     uint32_t glwe_dim, uint32_t level_count,
                                                                     uint32_t polynomial_size,
                                                                     uint32_t grouping_factor) {
-  // The multi-bit key stays in the standard (u64) domain on the device, like the reference
-  // backend (cuda/src/pbs/bootstrapping_key.cu:78-93); the layout is the host layout.
+  // The CPU reference keeps the multi-bit key in the Fourier domain (FourierLweMultiBitBootstrapKey,
+  // cc/algorithms/lwe_multi_bit_bootstrap_key_conversion.rs); its GPU backend uploads the standard-domain key
+  // unchanged (cuda/src/pbs/bootstrapping_key.cu:78-93).  Here the key is transformed once at conversion time —
+  // same byte size (N u64 -> N/2 complex per polynomial), same nesting [group][subset][level][row][col] — so that
+  // the keybundle of every group is a pointwise combine (multibit.hip).
   set_device(gpu_index);
+  check_pow2_poly(polynomial_size);
+  HX_PANIC_IF_FALSE(dest != nullptr && src != nullptr, "multi-bit bootstrap key conversion: null pointer");
   HX_PANIC_IF_FALSE(grouping_factor >= 1 && input_lwe_dim % grouping_factor == 0,
                     "input_lwe_dim %u not a multiple of grouping_factor %u", input_lwe_dim, grouping_factor);
-  const size_t elems = (size_t)(input_lwe_dim / grouping_factor) * ((size_t)1 << grouping_factor) * level_count *
-                       (glwe_dim + 1) * (glwe_dim + 1) * polynomial_size;
-  HX_CHECK(hipMemcpyAsync(dest, src, elems * sizeof(uint64_t), hipMemcpyHostToDevice, S(stream)));
+  const size_t polys = (size_t)(input_lwe_dim / grouping_factor) * ((size_t)1 << grouping_factor) * level_count *
+                       (glwe_dim + 1) * (glwe_dim + 1);
+  const size_t bytes = polys * polynomial_size * sizeof(uint64_t);
+  void *tmp = nullptr;
+  HX_CHECK(hipMalloc(&tmp, bytes));
+  HX_CHECK(hipMemcpyAsync(tmp, src, bytes, hipMemcpyHostToDevice, S(stream)));
+  const FftTables tb = get_fft_tables(gpu_index, S(stream), polynomial_size);
+  launch_bsk_to_fourier(S(stream), polynomial_size, glwe_dim, (const uint64_t *)tmp, dest, polys, tb);
+  HX_CHECK(hipStreamSynchronize(S(stream)));  // the staging buffer must outlive the kernel
+  HX_CHECK(hipFree(tmp));
 }
 
 uint64_t scratch_cuda_multi_bit_programmable_bootstrap_64_async(void *stream, uint32_t gpu_index,
@@ -400,13 +411,13 @@ uint64_t scratch_cuda_multi_bit_programmable_bootstrap_64_async(void *stream, ui
   b->level_count = level_count;
   b->max_samples = input_lwe_ciphertext_count;
   b->gpu_memory_allocated = allocate_gpu_memory;
-  b->keybundle = nullptr;
   b->acc = nullptr;
   const size_t k1 = glwe_dimension + 1;
   const size_t kb_per_sample = (size_t)level_count * k1 * k1 * (polynomial_size / 2) * sizeof(cplx);
   const size_t acc_per_sample = 2 * k1 * polynomial_size * sizeof(uint64_t);
   b->chunk = input_lwe_ciphertext_count ? input_lwe_ciphertext_count : 1;
-  const uint64_t bytes = (uint64_t)b->chunk * (kb_per_sample + acc_per_sample);
+  // the throughput kernels build every keybundle element in registers: no per-sample keybundle scratch
+  const uint64_t bytes = (uint64_t)b->chunk * acc_per_sample;
   // latency path: up to kMultiBitLatencyMaxBatch ciphertexts, as many groups per pass as 2 GiB hold (the scratch
   // is sized without knowing n or the grouping factor, like the reference's lwe_chunk_size)
   b->lat_samples = b->chunk < kMultiBitLatencyMaxBatch ? b->chunk : kMultiBitLatencyMaxBatch;
@@ -416,7 +427,6 @@ uint64_t scratch_cuda_multi_bit_programmable_bootstrap_64_async(void *stream, ui
   const uint64_t lat_bytes = (uint64_t)b->lat_groups * per_group;
   if (allocate_gpu_memory) {
     b->fft = get_fft_tables(gpu_index, S(stream), polynomial_size);
-    HX_CHECK(hipMalloc((void **)&b->keybundle, (size_t)b->chunk * kb_per_sample));
     HX_CHECK(hipMalloc((void **)&b->acc, (size_t)b->chunk * acc_per_sample));
   }
   b->lat_bytes = lat_bytes;
@@ -447,8 +457,6 @@ void cuda_multi_bit_programmable_bootstrap_64_async(void *stream, uint32_t gpu_i
                     lwe_input_indexes, bootstrapping_key, lwe_dimension, base_log, level_count, num_samples,
                     num_many_lut, lut_stride, 0);
   m.grouping_factor = grouping_factor;
-  m.keybundle = b->keybundle;
-  m.chunk = b->chunk;
   const uint32_t choice = g_fft_kernel_choice.load();
   const bool wave_ok = pbs_multi_bit_wave_supported(polynomial_size, glwe_dimension, level_count, base_log,
                                                     grouping_factor);
@@ -464,7 +472,6 @@ void cuda_multi_bit_programmable_bootstrap_64_async(void *stream, uint32_t gpu_i
     g_last_pbs_kernel.store(10);
   } else if ((choice == 0 && wave_ok) || choice == 2) {
     m.pbs.grouping = grouping_factor;
-    m.pbs.keybundle = b->keybundle;
     launch_pbs_multi_bit_wave(S(stream), m.pbs, b->fft);
     g_last_pbs_kernel.store(6);
   } else {
@@ -478,7 +485,6 @@ void cleanup_cuda_multi_bit_programmable_bootstrap_64(void *stream, uint32_t gpu
   auto *b = reinterpret_cast<MultiBitBuffer *>(*pbs_buffer);
   HX_PANIC_IF_FALSE(b != nullptr && b->magic == kMbMagic, "cleanup of a foreign multi-bit PBS buffer");
   HX_CHECK(hipStreamSynchronize(S(stream)));
-  if (b->keybundle) HX_CHECK(hipFree(b->keybundle));
   if (b->acc) HX_CHECK(hipFree(b->acc));
   if (b->kb_lat) HX_CHECK(hipFree(b->kb_lat));
   b->magic = 0;
@@ -619,6 +625,9 @@ void hip_test_transform_async(void *stream, uint32_t gpu_index, uint32_t op, uin
 }
 void hip_test_fft_tables_host(uint32_t polynomial_size, double *fwd, double *inv, double *untwist) {
   fill_fft_tables_host(polynomial_size, fwd, inv, untwist);
+}
+void hip_test_monomial_table_host(uint32_t polynomial_size, double *mono) {
+  fill_monomial_table_host(polynomial_size, mono);
 }
 
 }  // extern "C"

@@ -83,6 +83,14 @@ static inline uint64_t hx_buffer_load_u64(HxBuffer b, uint32_t byte_offset) {
   __builtin_memcpy(&v, b.base + byte_offset, 8);
   return v;
 }
+struct hx_f64x2 {
+  double x, y;
+};
+static inline hx_f64x2 hx_buffer_load_f64x2(HxBuffer b, uint32_t lane_byte_offset, uint32_t uniform_byte_offset) {
+  hx_f64x2 v;
+  __builtin_memcpy(&v, b.base + lane_byte_offset + uniform_byte_offset, 16);
+  return v;
+}
 #else
 struct HxBuffer {
   __amdgpu_buffer_rsrc_t rsrc;
@@ -95,6 +103,19 @@ __device__ __forceinline__ uint64_t hx_buffer_load_u64(HxBuffer b, uint32_t byte
   typedef unsigned int hx_u32x2 __attribute__((ext_vector_type(2)));
   const hx_u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(b.rsrc, (int)byte_offset, 0, 0);
   return ((uint64_t)v.y << 32) | v.x;
+}
+// 16 bytes per lane at (per-lane byte offset in ONE vector register) + (wave-uniform byte offset in a scalar
+// register): the address of every load of an unrolled sweep costs at most one scalar add and no vector registers
+struct hx_f64x2 {
+  double x, y;
+};
+__device__ __forceinline__ hx_f64x2 hx_buffer_load_f64x2(HxBuffer b, uint32_t lane_byte_offset,
+                                                         uint32_t uniform_byte_offset) {
+  typedef unsigned int hx_u32x4 __attribute__((ext_vector_type(4)));
+  const hx_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(b.rsrc, (int)lane_byte_offset, (int)uniform_byte_offset, 0);
+  hx_f64x2 r;
+  __builtin_memcpy(&r, &v, 16);
+  return r;
 }
 #endif
 

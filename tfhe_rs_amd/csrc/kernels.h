@@ -17,7 +17,7 @@ void launch_pbs_fft_wave(hipStream_t st, const PbsArgs &a, const FftTables &tb);
 // throughput kernel for N = 1024, k = 1 or 2 (one wave per polynomial, 512-point transforms)
 bool pbs_fft_wave3_supported(uint32_t N, uint32_t glwe_dim, uint32_t level);
 void launch_pbs_fft_wave3(hipStream_t st, uint32_t glwe_dim, const PbsArgs &a, const FftTables &tb);
-// multi-bit PBS on the same kernel (a.grouping, a.keybundle set; a.bsk = standard-domain multi-bit key)
+// multi-bit PBS on the same kernel (a.grouping set; a.bsk = Fourier-domain multi-bit key)
 bool pbs_multi_bit_wave_supported(uint32_t N, uint32_t glwe_dim, uint32_t level, uint32_t base_log, uint32_t grouping);
 void launch_pbs_multi_bit_wave(hipStream_t st, const PbsArgs &a, const FftTables &tb);
 
@@ -49,10 +49,8 @@ void launch_closest_representable(hipStream_t st, const uint64_t *in, uint64_t *
 
 // multi-bit — multibit.hip
 struct MultiBitArgs {
-  PbsArgs pbs;             // bsk = standard-domain multi-bit key on the device
+  PbsArgs pbs;             // bsk = Fourier-domain multi-bit key on the device ([group][subset][level][row][col][slot])
   uint32_t grouping_factor;
-  cplx *keybundle;         // scratch: num_samples * level*(k+1)^2 * n complex per group step
-  uint32_t chunk;          // samples processed per pass
 };
 void launch_pbs_multi_bit(hipStream_t st, uint32_t N, uint32_t glwe_dim, const MultiBitArgs &a, const FftTables &tb,
                           uint64_t *acc_scratch);

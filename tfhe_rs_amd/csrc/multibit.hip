@@ -4,37 +4,47 @@
 // the 2^g - 1 subset sums), :647-880 (deterministic blind rotation: acc <- LUT*X^-b, then per
 // group dst = 0 + src (x) GGSW_comb), key layout of
 // cc/algorithms/lwe_multi_bit_bootstrap_key_generation.rs:21-78.
-// Like the reference's GPU backend (cuda/src/pbs/programmable_bootstrap_multibit.cuh:40-330,
-// bootstrapping_key.cu:78-93) the key stays in the STANDARD u64 domain on the device and the
-// per-LWE "keybundle"  GGSW_comb = GGSW_0 + sum_s GGSW_s * X^{deg_s}  is built with exact
-// integer monomial products and transformed afterwards, so the only inexact step is the f64
-// transform itself (fixed order) and results are bit-exact against the oracle.
+// Like the CPU reference (:116-156) — and unlike the reference's GPU backend, which keeps the key in the standard
+// domain and combines with integer monomial products before transforming — the key lives in the FOURIER domain on
+// the device (converted once by cuda_convert_lwe_multi_bit_programmable_bootstrap_key_64_async) and the per-LWE
+// keybundle  GGSW_comb = GGSW_0 + sum_s GGSW_s (.) FFT(X^{deg_s})  is a pointwise combine with the monomial
+// factors of pbs_common.h: no rotations, no keybundle transforms, nothing parked in device memory by the
+// throughput kernels.  Operation order fixed (pbs_common.h), so results are bit-exact against the oracle.
 //
-// One workgroup per LWE runs all groups in one launch: keybundle polynomial -> LDS -> forward
-// transform -> per-sample global scratch (stays in L2), then the external product reads it back.
+// pbs_multi_bit_kernel: one workgroup per LWE runs all groups in one launch, building every keybundle element in
+// registers right where the multiply-accumulate consumes it.
 #include <atomic>
 
 #include "kernels.h"
 
 namespace tfhe_hip {
 
+// keybundle element of polynomial `poly` (index inside one GGSW) at storage slot `slot` / position `pos`
+template <int N>
+HX_DEV cplx keybundle_point(const cplx *__restrict__ gk, size_t ggsw_c, size_t poly, uint32_t slot, uint32_t pos,
+                            uint32_t per, const uint32_t *deg, const double *__restrict__ mono) {
+  constexpr int n = N / 2;
+  cplx kb = gk[poly * n + slot];  // subset 0: not rotated
+  for (uint32_t s = 1; s < per; ++s)
+    kb = cmul_add(gk[(size_t)s * ggsw_c + poly * n + slot], monomial_factor<N>(mono, pos, deg[s]), kb);
+  return kb;
+}
+
 template <int N, int K1>
 __global__ void __launch_bounds__(GenericCfg<N>::TPB)
-    pbs_multi_bit_kernel(PbsArgs a, uint32_t grouping, cplx *keybundle, FftTables tb) {
+    pbs_multi_bit_kernel(PbsArgs a, uint32_t grouping, FftTables tb) {
   constexpr int n = N / 2, TPB = GenericCfg<N>::TPB, PER = n / TPB, LOG2N2 = ilog2_c(2 * N);
   HX_DYN_SMEM(smem);
   uint64_t *acc = (uint64_t *)smem;                  // K1*N torus words (src, then dst)
-  const FBuf fbuf{(cplx *)(smem + (size_t)K1 * N * 8)};  // n complex points (padded) / N u64 of keybundle build
-  uint64_t *kbuf = (uint64_t *)fbuf.p;
+  const FBuf fbuf{(cplx *)(smem + (size_t)K1 * N * 8)};  // n complex points (padded)
   const int tid = threadIdx.x;
   const uint32_t sample = blockIdx.x;
   const uint64_t *lwe = a.lwe_in + (size_t)a.in_idx[sample] * (a.n + 1);
   const uint64_t *lut = a.lut + (size_t)a.lut_idx[sample] * K1 * N;
-  const uint64_t *bsk = (const uint64_t *)a.bsk;
+  const cplx *bsk = (const cplx *)a.bsk;  // Fourier domain: [group][subset][level][row][col][slot]
   const uint32_t per = 1u << grouping, groups = a.n / grouping;
   const size_t kb_polys = (size_t)a.level * K1 * K1;
-  const size_t ggsw_sz = kb_polys * N;
-  cplx *kb = keybundle + (size_t)sample * kb_polys * n;
+  const size_t ggsw_c = kb_polys * n;  // complex elements per GGSW
 
   // standard modulus switch of the body (multi-bit sets use no centered correction, :98-103)
   const uint32_t b_hat = (uint32_t)modulus_switch(lwe[a.n], LOG2N2);
@@ -48,43 +58,10 @@ __global__ void __launch_bounds__(GenericCfg<N>::TPB)
   __syncthreads();
 
   for (uint32_t grp = 0; grp < groups; ++grp) {
-    const uint64_t *gk = bsk + (size_t)grp * per * ggsw_sz;
-    // ---- keybundle: integer combine, then forward transform (as torus), polynomial by polynomial
-    for (size_t poly = 0; poly < kb_polys; ++poly) {
-      for (uint32_t j = tid; j < (uint32_t)N; j += TPB) {
-        uint64_t v = gk[poly * N + j];  // subset index 0: not rotated
-        for (uint32_t s = 1; s < per; ++s) {
-          uint64_t sum = 0;
-          for (uint32_t m = 0; m < grouping; ++m)
-            if ((s >> (grouping - 1 - m)) & 1) sum += lwe[(size_t)grp * grouping + m];
-          const uint32_t deg = (uint32_t)modulus_switch(sum, LOG2N2);
-          bool neg;
-          const uint32_t src = monomial_mul_src(j, deg, N, neg);
-          const uint64_t x = gk[(size_t)s * ggsw_sz + poly * N + src];
-          v += neg ? (uint64_t)0 - x : x;
-        }
-        kbuf[j] = v;
-      }
-      __syncthreads();
-      // fold + scale to the torus (fft/mod.rs:201-222), in place: kbuf[j], kbuf[j+n] -> fbuf[j]
-      cplx z[PER];
-      for (int q = 0; q < PER; ++q) {
-        const int j = tid + q * TPB;
-        z[q] = cplx{i64_to_f64((int64_t)kbuf[j]) * 5.421010862427522e-20,
-                    i64_to_f64((int64_t)kbuf[j + n]) * 5.421010862427522e-20};
-      }
-      __syncthreads();
-      for (int q = 0; q < PER; ++q) fbuf[tid + q * TPB] = z[q];
-      __syncthreads();
-      lds_fft_forward<N, TPB>(fbuf, tb.fwd, tid);
-      for (int q = 0; q < PER; ++q) kb[poly * n + tid + q * TPB] = fbuf[tid + q * TPB];
-      __syncthreads();
-    }
-    // my own global writes are read back by other threads of this workgroup only
-    __threadfence_block();
-    __syncthreads();
-
-    // ---- dst = 0 + src (x) keybundle   (ggsw.rs:483-602 with a zeroed output)
+    const cplx *gk = bsk + (size_t)grp * per * ggsw_c;
+    uint32_t deg[16];
+    multi_bit_degrees(lwe + (size_t)grp * grouping, grouping, LOG2N2, deg);
+    // ---- dst = 0 + src (x) keybundle   (ggsw.rs:483-602 with a zeroed output), keybundle built point by point
     cplx facc[K1][PER];
     bool first = true;
     for (uint32_t idx = 0; idx < a.level; ++idx) {
@@ -97,11 +74,11 @@ __global__ void __launch_bounds__(GenericCfg<N>::TPB)
         }
         __syncthreads();
         lds_fft_forward<N, TPB>(fbuf, tb.fwd, tid);
-        const cplx *brow = kb + (((size_t)idx * K1 + row) * K1) * n;
         for (int c = 0; c < K1; ++c)
           for (int q = 0; q < PER; ++q) {
             const int pos = tid + q * TPB;
-            const cplx y = brow[(size_t)c * n + pos];
+            const cplx y = keybundle_point<N>(gk, ggsw_c, ((size_t)idx * K1 + row) * K1 + c, bsk_slot<N, K1>(pos), pos,
+                                              per, deg, tb.mono);
             facc[c][q] = first ? cmul_first(fbuf[pos], y) : cmul_add(fbuf[pos], y, facc[c][q]);
           }
         first = false;
@@ -135,47 +112,21 @@ __global__ void __launch_bounds__(GenericCfg<N>::TPB)
 template <int N, int K1>
 __global__ void __launch_bounds__(GenericCfg<N>::TPB)
     mb_keybundle_kernel(PbsArgs a, uint32_t grouping, cplx *kb_lat, FftTables tb, uint32_t g0, uint32_t gcount) {
-  constexpr int n = N / 2, TPB = GenericCfg<N>::TPB, PER = n / TPB, LOG2N2 = ilog2_c(2 * N);
-  HX_DYN_SMEM(smem);
-  const FBuf fbuf{(cplx *)smem};
-  uint64_t *kbuf = (uint64_t *)fbuf.p;
+  constexpr int n = N / 2, TPB = GenericCfg<N>::TPB, LOG2N2 = ilog2_c(2 * N);
   const int tid = threadIdx.x;
   const uint32_t sample = blockIdx.y;
   const size_t kb_polys = (size_t)a.level * K1 * K1;
   const uint32_t gl = blockIdx.x / (uint32_t)kb_polys, poly = blockIdx.x % (uint32_t)kb_polys, grp = g0 + gl;
   const uint64_t *lwe = a.lwe_in + (size_t)a.in_idx[sample] * (a.n + 1);
   const uint32_t per = 1u << grouping;
-  const size_t ggsw_sz = kb_polys * N;
-  const uint64_t *gk = (const uint64_t *)a.bsk + (size_t)grp * per * ggsw_sz;
+  const size_t ggsw_c = kb_polys * n;
+  const cplx *gk = (const cplx *)a.bsk + (size_t)grp * per * ggsw_c;
   uint32_t deg[16];
-  for (uint32_t s = 1; s < per; ++s) {
-    uint64_t sum = 0;
-    for (uint32_t m = 0; m < grouping; ++m)
-      if ((s >> (grouping - 1 - m)) & 1) sum += lwe[(size_t)grp * grouping + m];
-    deg[s] = (uint32_t)modulus_switch(sum, LOG2N2);
-  }
-  for (uint32_t j = tid; j < (uint32_t)N; j += TPB) {
-    uint64_t v = gk[poly * N + j];
-    for (uint32_t s = 1; s < per; ++s) {
-      bool neg;
-      const uint32_t src = monomial_mul_src(j, deg[s], N, neg);
-      const uint64_t x = gk[(size_t)s * ggsw_sz + poly * N + src];
-      v += neg ? (uint64_t)0 - x : x;
-    }
-    kbuf[j] = v;
-  }
-  __syncthreads();
-  cplx z[PER];
-  for (int q = 0; q < PER; ++q) {
-    const int j = tid + q * TPB;
-    z[q] = cplx{i64_to_f64((int64_t)kbuf[j]) * 5.421010862427522e-20, i64_to_f64((int64_t)kbuf[j + n]) * 5.421010862427522e-20};
-  }
-  __syncthreads();
-  for (int q = 0; q < PER; ++q) fbuf[tid + q * TPB] = z[q];
-  __syncthreads();
-  lds_fft_forward<N, TPB>(fbuf, tb.fwd, tid);
+  multi_bit_degrees(lwe + (size_t)grp * grouping, grouping, LOG2N2, deg);
+  // pointwise combine; parked in transform-POSITION order (what the accumulate kernels index)
   cplx *kb = kb_lat + (((size_t)sample * gcount + gl) * kb_polys + poly) * n;
-  for (int q = 0; q < PER; ++q) kb[tid + q * TPB] = fbuf[tid + q * TPB];
+  for (uint32_t pos = tid; pos < (uint32_t)n; pos += TPB)
+    kb[pos] = keybundle_point<N>(gk, ggsw_c, poly, bsk_slot<N, K1>(pos), pos, per, deg, tb.mono);
 }
 
 template <int N, int K1>
@@ -338,8 +289,8 @@ static void launch_mb_latency(hipStream_t st, const MultiBitArgs &m, const FftTa
     hx_set_dynamic_smem_once<mb_accumulate_kernel<N, K1>>(smem_b);
   for (uint32_t g0 = 0; g0 < groups; g0 += group_chunk) {
     const uint32_t gpass = groups - g0 < group_chunk ? groups - g0 : group_chunk;
-    HX_LAUNCH((mb_keybundle_kernel<N, K1>), dim3(gpass * kb_polys, a.num_samples), dim3(GenericCfg<N>::TPB),
-              fbuf_bytes(N), st, a, m.grouping_factor, kb_lat, tb, g0, group_chunk);
+    HX_LAUNCH((mb_keybundle_kernel<N, K1>), dim3(gpass * kb_polys, a.num_samples), dim3(GenericCfg<N>::TPB), 0, st, a,
+              m.grouping_factor, kb_lat, tb, g0, group_chunk);
     if (par)
       HX_LAUNCH((mb_accumulate_par_kernel<N, K1>), dim3(a.num_samples), dim3(K1 * GenericCfg<N>::TPB), smem_p, st, a,
                 (const cplx *)kb_lat, tb, acc_g, group_chunk, gpass, (int)(g0 == 0), (int)(g0 + gpass == groups));
@@ -354,7 +305,7 @@ static void launch_mb(hipStream_t st, const MultiBitArgs &m, const FftTables &tb
   const size_t smem = (size_t)K1 * N * 8 + fbuf_bytes(N);
   hx_set_dynamic_smem_once<pbs_multi_bit_kernel<N, K1>>(smem);
   HX_LAUNCH((pbs_multi_bit_kernel<N, K1>), dim3(m.pbs.num_samples), dim3(GenericCfg<N>::TPB), smem, st, m.pbs,
-            m.grouping_factor, m.keybundle, tb);
+            m.grouping_factor, tb);
 }
 
 void launch_pbs_multi_bit(hipStream_t st, uint32_t N, uint32_t glwe_dim, const MultiBitArgs &m, const FftTables &tb,

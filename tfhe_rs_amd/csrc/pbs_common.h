@@ -26,9 +26,8 @@ struct PbsArgs {
   uint32_t num_many_lut;
   uint32_t lut_stride;
   uint32_t ms_type;    // PBS_MS_REDUCTION_T: 0 none, 1 centered
-  // multi-bit PBS only (0 / null otherwise): grouping factor, per-sample Fourier keybundle scratch
+  // multi-bit PBS only (0 otherwise): grouping factor; bsk is then the Fourier-domain multi-bit key
   uint32_t grouping = 0;
-  void *keybundle = nullptr;
   // N >= 8192 only: (k+1) N torus words per sample — the accumulator of those rings does not fit in LDS next
   // to the transform buffer and lives in device memory (L2-resident between the iterations of a workgroup)
   uint64_t *acc_scratch = nullptr;
@@ -48,6 +47,43 @@ HX_DEV int bsk_slot(int pos) {
   if constexpr (N == 2048 && K1 == 2) return (pos & 15) * 64 + (pos >> 4);
   if constexpr (N == 1024 && (K1 == 2 || K1 == 3)) return (pos & 7) * 64 + (pos >> 3);  // pbs_fft_wave3.hip, layout LC
   return pos;
+}
+
+// ---------------------------------------------------------------- multi-bit: Fourier-domain keybundle
+// The CPU reference keeps the multi-bit key in the Fourier domain and combines the 2^g GGSWs of a group there
+// (cc/algorithms/lwe_multi_bit_programmable_bootstrapping.rs:116-156):
+//     GGSW_comb = GGSW_0 + sum_{s >= 1} GGSW_s (.) FFT(X^{deg_s})
+// In the transform order of DESIGN.md §4 (position p <-> zeta^(1 + 4 bitrev p)) the monomial's value at
+// position p is the product of one table entry per 16 positions and a 16th root of unity — which is how a lane
+// that owns 16 consecutive positions gets its 16 factors from one gathered table entry.  Spec (bit-exact
+// across the oracle and every kernel): M_d[p] = cmul_first(mono[jb], mono[jw]),
+//     jb = ((1 + 4 bitrev_{L-4}(p >> 4)) d) mod 2N,  jw = (N/8) ((bitrev_4(p & 15) d) mod 16),  L = log2(N/2);
+// KB <- K_0, then KB <- cmul_add(K_s, M_{deg_s}, KB) for s = 1 .. 2^g - 1 in this order.
+template <int N>
+HX_DEV uint32_t monomial_base_index(uint32_t hi /* p >> 4 */, uint32_t deg) {
+  constexpr int L4 = ilog2_c(N / 2) - 4;
+  const uint32_t br = L4 ? (__brev(hi) >> (32 - (L4 ? L4 : 1))) : 0u;
+  return ((1u + 4u * br) * deg) & (2u * N - 1u);
+}
+template <int N>
+HX_DEV uint32_t monomial_root_index(uint32_t lo /* p & 15 */, uint32_t deg) {
+  return (uint32_t)(N / 8) * (((__brev(lo) >> 28) * deg) & 15u);
+}
+template <int N>
+HX_DEV cplx monomial_factor(const double *__restrict__ mono, uint32_t pos, uint32_t deg) {
+  const uint32_t jb = monomial_base_index<N>(pos >> 4, deg), jw = monomial_root_index<N>(pos & 15u, deg);
+  return cmul_first(cplx{mono[2 * jb], mono[2 * jb + 1]}, cplx{mono[2 * jw], mono[2 * jw + 1]});
+}
+// subset degrees of one group (:30-65): subset s selects mask element m when bit (g-1-m) of s is set; the
+// sum wraps BEFORE the modulus switch
+HX_DEV void multi_bit_degrees(const uint64_t *__restrict__ group_mask, uint32_t g, uint32_t log2_2n, uint32_t *deg) {
+  const uint32_t per = 1u << g;
+  for (uint32_t s = 1; s < per; ++s) {
+    uint64_t sum = 0;
+    for (uint32_t m = 0; m < g; ++m)
+      if ((s >> (g - 1 - m)) & 1) sum += group_mask[m];
+    deg[s] = (uint32_t)modulus_switch(sum, log2_2n);
+  }
 }
 
 // ---------------------------------------------------------------- LDS transforms (generic)

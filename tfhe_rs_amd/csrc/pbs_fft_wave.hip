@@ -93,6 +93,12 @@
 #ifndef WAVE_PERMLANE_PASS
 #define WAVE_PERMLANE_PASS 1
 #endif
+#ifndef WAVE_MB_PTS
+#define WAVE_MB_PTS 2   // multi-bit: points per lane and row of one keybundle step (16 / PTS chunks per level)
+#endif
+#ifndef WAVE_MB_SETS
+#define WAVE_MB_SETS 4  // multi-bit: register sets in rotation (SETS - 1 key requests in flight)
+#endif
 #ifndef WAVE_FUSE_PASS1
 #define WAVE_FUSE_PASS1 1    // first inverse pass interleaved with the MAC chunks
 #endif
@@ -127,7 +133,8 @@ constexpr int T_E8 = 1353;   // E[4 x], x < 64    (inverse half = 128)
 constexpr int T_W7 = 1417;   // E[8 x], x < 32    (inverse half = 64)
 constexpr int T_E32 = 1449;  // E[16 x], x < 16   (inverse half = 32)
 constexpr int T_W16 = 1465;  // E[32 x], x < 8    (inverse half = 16)
-constexpr int T_TOTAL = 1473;
+constexpr int T_W16X = 1473; // 16th roots of unity e^{2 pi i t / 16} = mono[t N/8] (multi-bit monomial factors)
+constexpr int T_TOTAL = 1489;
 constexpr int FLAGS_BYTES = 64;
 constexpr size_t SMEM_BYTES = (size_t)WAVES * BUF_BYTES + (size_t)T_TOTAL * 16 + FLAGS_BYTES;
 
@@ -503,14 +510,13 @@ HX_DEV void wave_inverse_accumulate(cplx (&o)[16], uint64_t (&acc_re)[16], uint6
   HX_WAVE_SYNC();
 }
 
-// MULTIBIT: multi-bit PBS on the same machinery (cc/algorithms/lwe_multi_bit_programmable_bootstrapping.rs
-// :647-880, integer keybundle as multibit.hip): per group of g mask elements each wave builds the 2*level
-// keybundle polynomials of its column with exact integer monomial products, transforms them and parks
-// them in the per-sample scratch (a.keybundle, classic key layout of ONE GGSW), then runs the external
-// product  acc <- acc (x) keybundle  with the classic digit / MAC / inverse code (no rotation, result
-// overwrites the accumulator).
-template <int LEVEL_CT, int BASE_LOG_CT, bool MULTIBIT = false>
+// GROUPING > 0: multi-bit PBS on the same machinery (cc/algorithms/lwe_multi_bit_programmable_bootstrapping.rs
+// :116-156, :647-880): per group of g mask elements the external product  acc <- acc (x) GGSW_comb  with the
+// keybundle combined in the Fourier domain on the fly (see the MULTIBIT block below); no rotation, the result
+// overwrites the accumulator.
+template <int LEVEL_CT, int BASE_LOG_CT, int GROUPING = 0>
 __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables tb) {
+  constexpr bool MULTIBIT = GROUPING > 0;
   HX_DYN_SMEM(smem);
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -564,8 +570,10 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
         v = ldg_c(tb.inv, 512 + 8 * (e - T_W7));
       } else if (e < T_W16) {
         v = ldg_c(tb.inv, 512 + 16 * (e - T_E32));
-      } else {
+      } else if (e < T_W16X) {
         v = ldg_c(tb.inv, 512 + 32 * (e - T_W16));
+      } else {
+        v = ldg_c(tb.mono, (N / 8) * (e - T_W16X));
       }
       Tw[e] = v;
     }
@@ -578,7 +586,7 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
   if (sample >= a.num_samples) return;  // whole pair leaves together; no later block barrier
   const uint64_t *lwe = a.lwe_in + (size_t)a.in_idx[sample] * (a.n + 1);
   const uint64_t *lut = a.lut + (size_t)a.lut_idx[sample] * 2 * N + (size_t)w * N;
-  const cplx *bsk = MULTIBIT ? (const cplx *)a.keybundle + (size_t)sample * level * 4 * n : (const cplx *)a.bsk;
+  const cplx *bsk = (const cplx *)a.bsk;
   const WaveCtx ctx0{buf, obuf, T, lane, lane >> 2, lane & 3, w};
   const WaveCtx &ctx = ctx0;
 
@@ -721,10 +729,8 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
   auto key_request = [&](cplx (&k0)[4], cplx (&k1)[4], const cplx *b0, const cplx *b1, int ch) {
     HX_UNROLL
     for (int j = 0; j < 4; ++j) {
-      // MULTIBIT: the parked keybundle is read back exactly once — a streaming load keeps it from displacing
-      // the shared key of the group in L2 (measured: 22.3 k -> 24.2 k PBS/s)
-      k0[j] = load_global_cplx<MULTIBIT>(&b0[(ch * 4 + j) * 64]);
-      k1[j] = load_global_cplx<MULTIBIT>(&b1[(ch * 4 + j) * 64]);
+      k0[j] = load_global_cplx<false>(&b0[(ch * 4 + j) * 64]);
+      k1[j] = load_global_cplx<false>(&b1[(ch * 4 + j) * 64]);
     }
   };
 
@@ -806,106 +812,154 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
   };
 
   if constexpr (MULTIBIT) {
-    const uint32_t g = a.grouping, per = 1u << g, groups = a.n / g;
-    const uint64_t *key = (const uint64_t *)a.bsk;  // standard domain: [group][subset][level][row][col][N]
-    const size_t ggsw_sz = (size_t)level * 4 * N;
-    cplx *kbs = (cplx *)a.keybundle + (size_t)sample * level * 4 * n;
+    // Multi-bit PBS (cc/algorithms/lwe_multi_bit_programmable_bootstrapping.rs:116-156, :647-880): per group of g
+    // mask elements  acc <- acc (x) GGSW_comb,  GGSW_comb = GGSW_0 + sum_s GGSW_s (.) FFT(X^{deg_s})  combined
+    // in the Fourier domain (pbs_common.h).  The keybundle never exists in memory: each chunk of 4 points per
+    // lane and row is accumulated in registers out of the 2^g key polynomials (coalesced 1 KiB wave loads, two
+    // subsets in flight) and consumed by the multiply-accumulate at once.  A lane owns positions lane*16 + r, so
+    // its monomial factors are  base_s(lane) * w16[(bitrev4(r) deg_s) mod 16]  with ONE gathered table entry per
+    // subset and group; the 16th roots sit in the LDS table (wave-uniform index: broadcast reads).
+    constexpr uint32_t g = GROUPING, per = 1u << g;
+    const uint32_t groups = a.n / g;
+    const cplx *key = (const cplx *)a.bsk;  // Fourier domain: [group][subset][level][row][col][slot]
+    const size_t ggsw_c = (size_t)level * 4 * n;
+    const HxBuffer mono = hx_make_buffer(tb.mono, 2u * N * 16u);
+    const uint32_t a_lane = 1u + 4u * (__brev((uint32_t)lane) >> 26);  // 1 + 4 bitrev6(lane)
+    const uint32_t ggsw_bytes = (uint32_t)(ggsw_c * sizeof(cplx));
+    auto ldc = [](HxBuffer b, uint32_t voff, uint32_t soff) {
+      const hx_f64x2 v = hx_buffer_load_f64x2(b, voff, soff);
+      return cplx{v.x, v.y};
+    };
     for (uint32_t grp = 0; grp < groups; ++grp) {
       // monomial degrees of the 2^g - 1 non-empty subsets (:30-65): subset s selects mask element m of
       // the group when bit (g-1-m) of s is set
-      uint32_t deg[16];
+      uint32_t deg[per];
+      cplx base[per];
       {
-        uint64_t m[4] = {0, 0, 0, 0};
+        uint64_t m[g];
+        HX_UNROLL
         for (uint32_t q = 0; q < g; ++q) m[q] = lwe[(size_t)grp * g + q];
+        HX_UNROLL
         for (uint32_t sidx = 1; sidx < per; ++sidx) {
           uint64_t sum = 0;
+          HX_UNROLL
           for (uint32_t q = 0; q < g; ++q)
             if ((sidx >> (g - 1 - q)) & 1) sum += m[q];
-          deg[sidx] = (uint32_t)modulus_switch(sum, LOG2N2);
+          deg[sidx] = HX_UNIFORM((uint32_t)modulus_switch(sum, LOG2N2));
+          base[sidx] = ldc(mono, ((a_lane * deg[sidx]) & (2u * N - 1u)) * 16u, 0u);
+        }
+        deg[0] = 0;
+        base[0] = cplx{1.0, 0.0};
+      }
+      // the group's 2^g GGSWs as one buffer: uniform base in scalar registers, lane offset in one vector register
+      const HxBuffer gk = hx_make_buffer(key + (size_t)grp * per * ggsw_c, per * ggsw_bytes);
+      cplx o[16];
+      // The accumulator is dead once its digits exist (the product OVERWRITES it): with several levels on
+      // a decomposition of at most 30 bits only the 32-bit decomposer states stay live across the levels (32
+      // registers instead of the 64 of the accumulator), cc/commons/math/decomposition/iter.rs:122-151
+      constexpr bool STATE32 = LEVEL_CT >= 2 && BASE_LOG_CT != 0 && LEVEL_CT * BASE_LOG_CT <= 30;
+      HX_UNROLL
+      for (int r = 0; r < 16; ++r) o[r] = cplx{-0.0, -0.0};
+      int32_t st_re[STATE32 ? 16 : 1], st_im[STATE32 ? 16 : 1];
+      if constexpr (STATE32) {
+        HX_UNROLL
+        for (int r = 0; r < 16; ++r) {
+          st_re[r] = decomp_init_state32((uint32_t)(acc_re[r] >> 32), BASE_LOG_CT, LEVEL_CT);
+          st_im[r] = decomp_init_state32((uint32_t)(acc_im[r] >> 32), BASE_LOG_CT, LEVEL_CT);
         }
       }
-      const uint64_t *gk = key + (size_t)grp * per * ggsw_sz;
-      // ---- keybundle polynomials [idx][row][col = w]: integer combine, to the torus, transform, park
-      for (uint32_t idx = 0; idx < level; ++idx)
-        for (uint32_t row = 0; row < 2; ++row) {
-          const size_t poly = ((size_t)idx * 2 + row) * 2 + w;
-          int ln = ctx.lane;
-          HX_OPAQUE(ln);
-          uint64_t v_re[16], v_im[16];
-          {
-            const uint64_t *p0 = gk + poly * N + ln;  // subset 0 is not rotated
-            HX_UNROLL
-            for (int r = 0; r < 16; ++r) {
-              v_re[r] = p0[r * 64];
-              v_im[r] = p0[1024 + r * 64];
-            }
-          }
-          // the 2*(2^g - 1) rotated half polynomials (low / high coefficients of each subset) are streamed
-          // with one half in flight while the previous one is accumulated
-          const uint32_t halves = 2 * (per - 1);
-          auto half_request = [&](uint64_t (&x)[16], uint32_t hh) {
-            const uint32_t sidx = 1 + (hh >> 1);
-            // one polynomial of subset sidx as a buffer: uniform base, 32-bit per-lane byte offsets
-            const HxBuffer ps = hx_make_buffer(gk + (size_t)sidx * ggsw_sz + poly * N, N * 8);
-            const uint32_t ub = ((uint32_t)ln - (deg[sidx] & (N - 1)) + ((hh & 1) ? 1024u : 0u)) * 8u;
-            HX_UNROLL
-            for (int r = 0; r < 16; ++r) x[r] = hx_buffer_load_u64(ps, (ub + r * 512u) & 0x3ff8u);
-          };
-          // two buffers in alternation (halves is even), one request in flight while the other buffer is
-          // accumulated; two requests in flight measured far slower (the third buffer ends up in scratch)
-          auto half_consume = [&](uint64_t (&x)[16], uint32_t hh) {
-            const uint32_t sidx = 1 + (hh >> 1);
-            const uint32_t rr = deg[sidx] & (N - 1);
-            const bool odd = (deg[sidx] & N) != 0;
-            if (hh & 1) {
-              HX_UNROLL
-              for (int r = 0; r < 16; ++r) {
-                const uint32_t c1 = 1024 + r * 64 + ln;
-                v_im[r] += ((c1 < rr) != odd) ? (uint64_t)0 - x[r] : x[r];
-              }
-            } else {
-              HX_UNROLL
-              for (int r = 0; r < 16; ++r) {
-                const uint32_t c0 = r * 64 + ln;
-                v_re[r] += ((c0 < rr) != odd) ? (uint64_t)0 - x[r] : x[r];
-              }
-            }
-          };
-          uint64_t ha[16], hb[16];
-          half_request(ha, 0);
-          for (uint32_t hh = 0; hh < halves; hh += 2) {
-            half_request(hb, hh + 1);
-            half_consume(ha, hh);
-            HX_SCHED_FENCE();
-            if (hh + 2 < halves) half_request(ha, hh + 2);
-            half_consume(hb, hh + 1);
-            HX_SCHED_FENCE();
-          }
-          cplx d[16];
-          HX_UNROLL
-          for (int r = 0; r < 16; ++r)  // fold + scale to the torus (fft/mod.rs:201-222)
-            d[r] = cplx{i64_to_f64((int64_t)v_re[r]) * 5.421010862427522e-20,
-                        i64_to_f64((int64_t)v_im[r]) * 5.421010862427522e-20};
-          wave_forward(d, ctx);
-          cplx *dst = kbs + poly * n + ln;  // storage slot r*64 + lane = the classic key order (bsk_slot)
-          HX_UNROLL
-          for (int r = 0; r < 16; ++r) dst[r * 64] = d[r];
-        }
-      __threadfence_block();  // my parked polynomials are read back below by this wave only
-      HX_WAVE_SYNC();
-      // ---- acc <- acc (x) keybundle
-      cplx o[16];
       for (uint32_t idx = 0; idx < level; ++idx) {
-        cplx d[16], ka0[4], ka1[4], kb0[4], kb1[4];
-        const cplx *b0, *b1;
-        key_rows(0, idx, b0, b1);
-        HX_SCHED_FENCE();
+        cplx d[16];
         HX_PRIO(WAVE_PRIO_MB_A);
-        make_digits(d, 0, idx);
+        if constexpr (STATE32) {
+          HX_UNROLL
+          for (int r = 0; r < 16; ++r)
+            d[r] = cplx{(double)decompose_one_level32(BASE_LOG_CT, st_re[r]),
+                        (double)decompose_one_level32(BASE_LOG_CT, st_im[r])};
+          HX_WAVE_SYNC();
+        } else {
+          make_digits(d, 0, idx);
+        }
         HX_PRIO(WAVE_PRIO_MB_B);
         wave_forward(d, ctx);
         HX_PRIO(WAVE_PRIO_MB_C);
-        mac(o, d, ka0, ka1, kb0, kb1, b0, b1, idx, grp * level + idx + 1, std::false_type{});
+        {  // publish my transform, fetch the partner's, build the keybundle chunks and multiply-accumulate
+          const uint32_t epoch = grp * level + idx + 1;
+          WaveCtx cx = ctx0;
+          HX_OPAQUE(cx.lane);
+          const int ln = cx.lane;
+          if (ln == 0) flag_set(f_ready_me, epoch);
+          // rows 0, 1 of level idx, column w, subset s: byte s*ggsw_bytes + (((idx*2 + row)*2 + w)*n + slot)*16
+          const uint32_t lane_off = (uint32_t)ln * 16u;
+          const uint32_t row0_off = (((idx * 2 + 0) * 2 + (uint32_t)w) * n) * 16u;
+          const uint32_t row1_off = (((idx * 2 + 1) * 2 + (uint32_t)w) * n) * 16u;
+          // A step consumes one subset of one chunk of PTS points per lane (both rows).  SETS register sets
+          // rotate: the set a step frees takes the request of the step SETS ahead, so SETS - 1 requests
+          // (2 PTS coalesced 1 KiB wave loads each) are in flight while one set is accumulated.
+          constexpr int PTS = WAVE_MB_PTS, SETS = WAVE_MB_SETS, CHUNKS = 16 / PTS, STEPS = CHUNKS * (int)per;
+          cplx x0[SETS][PTS], x1[SETS][PTS];
+          auto request = [&](int set, int t) {
+            const uint32_t sidx = (uint32_t)(t % (int)per);
+            const int ch = t / (int)per;
+            HX_UNROLL
+            for (int j = 0; j < PTS; ++j) {
+              x0[set][j] = ldc(gk, lane_off, sidx * ggsw_bytes + row0_off + (uint32_t)(ch * PTS + j) * 1024u);
+              x1[set][j] = ldc(gk, lane_off, sidx * ggsw_bytes + row1_off + (uint32_t)(ch * PTS + j) * 1024u);
+            }
+          };
+          HX_UNROLL
+          for (int t = 0; t < SETS && t < STEPS; ++t) request(t, t);
+          HX_SCHED_FENCE();
+          flag_wait(f_ready_ot, epoch);
+          const cplx *row0 = (w == 0 ? buf : obuf) + base_m3(cx);
+          const cplx *row1 = (w == 0 ? obuf : buf) + base_m3(cx);
+          cplx kb0[PTS], kb1[PTS];
+          HX_UNROLL
+          for (int t = 0; t < STEPS; ++t) {
+            const int ch = t / (int)per, set = t % SETS;
+            const uint32_t sidx = (uint32_t)(t % (int)per);
+            if (sidx == 0) {  // subset 0 is not rotated: it initialises the chunk's accumulators
+              HX_UNROLL
+              for (int j = 0; j < PTS; ++j) {
+                kb0[j] = x0[set][j];
+                kb1[j] = x1[set][j];
+              }
+            } else {
+              HX_UNROLL
+              for (int j = 0; j < PTS; ++j) {
+                constexpr uint32_t br4[16] = {0, 8, 4, 12, 2, 10, 6, 14, 1, 9, 5, 13, 3, 11, 7, 15};
+                const cplx wr = T[T_W16X + ((br4[ch * PTS + j] * deg[sidx]) & 15u)];
+                const cplx mf = cmul_first(base[sidx], wr);
+                kb0[j] = cmul_add(x0[set][j], mf, kb0[j]);
+                kb1[j] = cmul_add(x1[set][j], mf, kb1[j]);
+                // pin the accumulation to this step: left alone, instruction selection sinks three of the four
+                // products to the end of the chunk and every loaded set stays live until then
+                HX_OPAQUE(kb0[j].re);
+                HX_OPAQUE(kb0[j].im);
+                HX_OPAQUE(kb1[j].re);
+                HX_OPAQUE(kb1[j].im);
+              }
+            }
+            HX_SCHED_FENCE();
+            if (t + SETS < STEPS) request(set, t + SETS);
+            if (sidx == per - 1) {  // chunk complete: multiply-accumulate with the two digit transforms
+              HX_UNROLL
+              for (int j = 0; j < PTS; ++j) {
+                const int r = ch * PTS + j;
+                const cplx x0r = row0[r], x1r = row1[r];
+                // o starts at -0.0: fma(a, b, -0.0) is the rounded product a b with its sign of zero, so the first
+                // term needs no cmul_first (no branch on idx in the unrolled steps) and the bits are the same
+                o[r] = cmul_add(x1r, kb1[j], cmul_add(x0r, kb0[j], o[r]));
+                HX_OPAQUE(o[r].re);
+                HX_OPAQUE(o[r].im);
+              }
+            }
+            HX_SCHED_FENCE();
+          }
+          HX_WAVE_SYNC();
+          if (ln == 0) flag_set(r_done_me, epoch);
+          flag_wait(r_done_ot, epoch);  // the partner must be done with my buffer before I reuse it
+        }
       }
       HX_PRIO(WAVE_PRIO_MB_D);
       wave_inverse_accumulate<false, true>(o, acc_re, acc_im, ctx);
@@ -1009,20 +1063,23 @@ bool pbs_multi_bit_wave_supported(uint32_t N, uint32_t glwe_dim, uint32_t level,
   return N == 2048 && glwe_dim == 1 && level >= 1 && level <= 4 && base_log <= 31 && grouping >= 1 && grouping <= 4;
 }
 
-template <int L, int B>
+template <int L, int B, int G>
 static void launch_wave_mb_t(hipStream_t st, const PbsArgs &a, const FftTables &tb) {
   using namespace wavek;
-  hx_set_dynamic_smem_once<pbs_fft_wave_kernel<L, B, true>>(SMEM_BYTES);
+  hx_set_dynamic_smem_once<pbs_fft_wave_kernel<L, B, G>>(SMEM_BYTES);
   const unsigned per_block = lwes_per_block(a.num_samples);
   const unsigned blocks = (a.num_samples + per_block - 1) / per_block;
-  HX_LAUNCH((pbs_fft_wave_kernel<L, B, true>), dim3(blocks), dim3(128 * per_block), SMEM_BYTES, st, a, tb);
+  HX_LAUNCH((pbs_fft_wave_kernel<L, B, G>), dim3(blocks), dim3(128 * per_block), SMEM_BYTES, st, a, tb);
 }
 
-// a.grouping and a.keybundle set; a.bsk = standard-domain multi-bit key
+// a.grouping set; a.bsk = Fourier-domain multi-bit key
 void launch_pbs_multi_bit_wave(hipStream_t st, const PbsArgs &a, const FftTables &tb) {
-  if (a.level == 2 && a.base_log == 15) launch_wave_mb_t<2, 15>(st, a, tb);  // PARAM_MULTI_BIT_GROUP_3_MESSAGE_2_CARRY_2
-  else if (a.level == 1 && a.base_log == 22) launch_wave_mb_t<1, 22>(st, a, tb);  // the GPU group-4 sets
-  else launch_wave_mb_t<0, 0>(st, a, tb);
+  if (a.grouping == 3 && a.level == 2 && a.base_log == 15) launch_wave_mb_t<2, 15, 3>(st, a, tb);  // PARAM_MULTI_BIT_GROUP_3_MESSAGE_2_CARRY_2
+  else if (a.grouping == 4 && a.level == 1 && a.base_log == 22) launch_wave_mb_t<1, 22, 4>(st, a, tb);  // the GPU group-4 sets
+  else if (a.grouping == 1) launch_wave_mb_t<0, 0, 1>(st, a, tb);
+  else if (a.grouping == 2) launch_wave_mb_t<0, 0, 2>(st, a, tb);
+  else if (a.grouping == 3) launch_wave_mb_t<0, 0, 3>(st, a, tb);
+  else launch_wave_mb_t<0, 0, 4>(st, a, tb);
 }
 
 void launch_pbs_fft_wave(hipStream_t st, const PbsArgs &a, const FftTables &tb) {

@@ -9,10 +9,13 @@ namespace tfhe_hip {
 //   inv[half+j]    = exp(-2*pi*i*j / (2*half))                   half = 1,2,..,n/2 ; j < half
 //   untw[j]        = conj(exp(i*pi*j/N)) / n
 // each entry (re, im) as two doubles; index 0 of fwd/inv unused.
+//   mono[j]        = exp(i*pi*j/N), j < 2N (octant-symmetric): the transform of a monomial X^d at position p is
+//                    mono[((1+4*bitrev_{L-4}(p>>4))*d) mod 2N] * mono[(N/8)*((bitrev_4(p&15)*d) mod 16)]  (multi-bit PBS)
 struct FftTables {
   const double *fwd;
   const double *inv;
   const double *untw;
+  const double *mono;
 };
 
 // Goldilocks tables: tw[m+g] = psi^bitrev(m+g), itw likewise for psi^-1; n_inv = N^-1 mod p
@@ -29,6 +32,7 @@ NttTables get_ntt_tables(uint32_t gpu_index, hipStream_t stream, uint32_t N);
 // host-side generators (also exported through the test ABI so the tables can be compared
 // with the oracle's independently computed ones)
 void fill_fft_tables_host(uint32_t N, double *fwd, double *inv, double *untw);
+void fill_monomial_table_host(uint32_t N, double *mono /* 4N doubles */);
 void fill_ntt_tables_host(uint32_t N, uint64_t *tw, uint64_t *itw, uint64_t *n_inv);
 
 }  // namespace tfhe_hip

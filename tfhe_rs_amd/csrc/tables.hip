@@ -75,6 +75,31 @@ void fill_fft_tables_host(uint32_t N, double *fwd, double *inv, double *untw) {
   }
 }
 
+// e^{i pi j / N} for j < 2N: the first octant evaluated (long double, rounded once), the rest by exact symmetries,
+// so that the quarter turns are exact and the table is closed under conjugation and multiplication by i
+void fill_monomial_table_host(uint32_t N, double *z) {
+  const long double PI = 3.14159265358979323846264338327950288L;
+  for (uint32_t j = 0; j <= N / 4; ++j) {
+    const long double ang = PI * (long double)j / (long double)N;
+    z[2 * j] = (double)cosl(ang);
+    z[2 * j + 1] = (double)sinl(ang);
+  }
+  z[0] = 1.0;
+  z[1] = 0.0;
+  for (uint32_t j = N / 4 + 1; j <= N / 2; ++j) {  // reflection about pi/4
+    z[2 * j] = z[2 * (N / 2 - j) + 1];
+    z[2 * j + 1] = z[2 * (N / 2 - j)];
+  }
+  for (uint32_t j = N / 2 + 1; j <= N; ++j) {  // times i
+    z[2 * j] = -z[2 * (j - N / 2) + 1];
+    z[2 * j + 1] = z[2 * (j - N / 2)];
+  }
+  for (uint32_t j = N + 1; j < 2 * N; ++j) {  // times -1
+    z[2 * j] = -z[2 * (j - N)];
+    z[2 * j + 1] = -z[2 * (j - N) + 1];
+  }
+}
+
 static uint64_t gl_pow_host(uint64_t a, uint64_t e) {
   uint64_t r = 1;
   while (e) {
@@ -111,7 +136,7 @@ void fill_ntt_tables_host(uint32_t N, uint64_t *tw, uint64_t *itw, uint64_t *n_i
 
 namespace {
 struct FftEntry {
-  double *fwd, *inv, *untw;
+  double *fwd, *inv, *untw, *mono;
 };
 struct NttEntry {
   uint64_t *tw, *itw;
@@ -127,13 +152,16 @@ FftTables get_fft_tables(uint32_t gpu_index, hipStream_t stream, uint32_t N) {
   auto key = std::make_pair(gpu_index, N);
   auto it = g_fft.find(key);
   if (it == g_fft.end()) {
-    std::vector<double> fwd(N), inv(N), untw(N);
+    std::vector<double> fwd(N), inv(N), untw(N), mono(4 * (size_t)N);
     fill_fft_tables_host(N, fwd.data(), inv.data(), untw.data());
+    fill_monomial_table_host(N, mono.data());
     FftEntry e;
     HX_CHECK(hipSetDevice((int)gpu_index));
     HX_CHECK(hipMalloc((void **)&e.fwd, sizeof(double) * N));
     HX_CHECK(hipMalloc((void **)&e.inv, sizeof(double) * N));
     HX_CHECK(hipMalloc((void **)&e.untw, sizeof(double) * N));
+    HX_CHECK(hipMalloc((void **)&e.mono, sizeof(double) * 4 * N));
+    HX_CHECK(hipMemcpy(e.mono, mono.data(), sizeof(double) * 4 * N, hipMemcpyHostToDevice));
     // synchronous copies from pageable host memory: complete before we return
     HX_CHECK(hipMemcpy(e.fwd, fwd.data(), sizeof(double) * N, hipMemcpyHostToDevice));
     HX_CHECK(hipMemcpy(e.inv, inv.data(), sizeof(double) * N, hipMemcpyHostToDevice));
@@ -141,7 +169,7 @@ FftTables get_fft_tables(uint32_t gpu_index, hipStream_t stream, uint32_t N) {
     (void)stream;
     it = g_fft.emplace(key, e).first;
   }
-  return FftTables{it->second.fwd, it->second.inv, it->second.untw};
+  return FftTables{it->second.fwd, it->second.inv, it->second.untw, it->second.mono};
 }
 
 NttTables get_ntt_tables(uint32_t gpu_index, hipStream_t stream, uint32_t N) {

@@ -104,6 +104,7 @@ SIGNATURES = {
     "hip_test_arith_async": (None, [_v, _u32, _u32, _v, _v, _u32, _u32, _u32]),
     "hip_test_transform_async": (None, [_v, _u32, _u32, _u32, _v, _v]),
     "hip_test_fft_tables_host": (None, [_u32, _v, _v, _v]),
+    "hip_test_monomial_table_host": (None, [_u32, _v]),
     "hip_backend_set_keyswitch_kernel": (None, [_u32]),
     "hip_backend_set_ntt_kernel": (None, [_u32]),
     "hip_backend_set_multibit_latency_groups": (None, [_u32]),
