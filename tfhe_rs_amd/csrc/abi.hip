@@ -38,6 +38,7 @@ struct MultiBitBuffer {
   FftTables fft;
   uint32_t chunk;
   uint64_t *acc;   // latency path: the accumulators crossing passes
+  uint32_t *pace = nullptr;  // throughput kernel: per-XCD progress counters (PbsArgs::pace)
   // latency path (small batches): keybundles of lat_groups groups for lat_samples ciphertexts
   // (allocated by the first call that takes that path: integer operations hold several scratches at once and
   // most never see a small batch)
@@ -428,6 +429,7 @@ uint64_t scratch_cuda_multi_bit_programmable_bootstrap_64_async(void *stream, ui
   if (allocate_gpu_memory) {
     b->fft = get_fft_tables(gpu_index, S(stream), polynomial_size);
     HX_CHECK(hipMalloc((void **)&b->acc, (size_t)b->chunk * acc_per_sample));
+    HX_CHECK(hipMalloc((void **)&b->pace, 8 * 32 * sizeof(uint32_t)));
   }
   b->lat_bytes = lat_bytes;
   *pbs_buffer = reinterpret_cast<int8_t *>(b);
@@ -472,6 +474,7 @@ void cuda_multi_bit_programmable_bootstrap_64_async(void *stream, uint32_t gpu_i
     g_last_pbs_kernel.store(10);
   } else if ((choice == 0 && wave_ok) || choice == 2) {
     m.pbs.grouping = grouping_factor;
+    m.pbs.pace = b->pace;
     launch_pbs_multi_bit_wave(S(stream), m.pbs, b->fft);
     g_last_pbs_kernel.store(6);
   } else {
@@ -487,6 +490,7 @@ void cleanup_cuda_multi_bit_programmable_bootstrap_64(void *stream, uint32_t gpu
   HX_CHECK(hipStreamSynchronize(S(stream)));
   if (b->acc) HX_CHECK(hipFree(b->acc));
   if (b->kb_lat) HX_CHECK(hipFree(b->kb_lat));
+  if (b->pace) HX_CHECK(hipFree(b->pace));
   b->magic = 0;
   delete b;
   *pbs_buffer = nullptr;

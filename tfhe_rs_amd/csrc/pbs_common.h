@@ -31,6 +31,10 @@ struct PbsArgs {
   // N >= 8192 only: (k+1) N torus words per sample — the accumulator of those rings does not fit in LDS next
   // to the transform buffer and lives in device memory (L2-resident between the iterations of a workgroup)
   uint64_t *acc_scratch = nullptr;
+  // multi-bit throughput kernel only: 8 progress counters (one per XCD, 128 bytes apart), zeroed by the launch —
+  // the workgroups of an XCD stay within a few groups of each other so that a group's key is fetched from HBM
+  // once per XCD instead of once per workgroup
+  uint32_t *pace = nullptr;
 };
 
 constexpr int ilog2_c(int x) { return x <= 1 ? 0 : 1 + ilog2_c(x / 2); }

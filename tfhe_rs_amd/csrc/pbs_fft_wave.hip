@@ -96,6 +96,15 @@
 #ifndef WAVE_MB_PTS
 #define WAVE_MB_PTS 2   // multi-bit: points per lane and row of one keybundle step (16 / PTS chunks per level)
 #endif
+#ifndef WAVE_MB_PACE
+#define WAVE_MB_PACE 1  // multi-bit: groups a wave pair may run ahead of the slowest pair of its XCD, plus 1 (0: no pacing)
+#endif
+#ifndef WAVE_MB_STAGGER
+#define WAVE_MB_STAGGER 0  // multi-bit: the LWEs 2, 3 of a workgroup (the SIMD mates of LWEs 0, 1) start this many s_sleep(127) late
+#endif
+#ifndef WAVE_MB_PACE_SPINS
+#define WAVE_MB_PACE_SPINS 4096  // polls (with s_sleep) before a wave gives up pacing for the rest of the launch
+#endif
 #ifndef WAVE_MB_SETS
 #define WAVE_MB_SETS 4  // multi-bit: register sets in rotation (SETS - 1 key requests in flight)
 #endif
@@ -825,11 +834,34 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
     const size_t ggsw_c = (size_t)level * 4 * n;
     const HxBuffer mono = hx_make_buffer(tb.mono, 2u * N * 16u);
     const uint32_t a_lane = 1u + 4u * (__brev((uint32_t)lane) >> 26);  // 1 + 4 bitrev6(lane)
+#if WAVE_MB_PACE && !defined(TFHE_HIPEMU)
+    // Pacing.  Workgroup b runs on XCD b % 8 (round-robin dispatch; used for speed only, never for correctness),
+    // 32 workgroups of an XCD are resident at a time, in index order.  Every wave pair adds 1 to its XCD's counter
+    // when it finishes a group; a pair of the XCD's r-th batch may start group g once the counter shows that all
+    // pairs of the earlier batches are done and all pairs of its own batch have finished group g - WAVE_MB_PACE.
+    // A wave that polls WAVE_MB_PACE_SPINS times in vain (peers not resident: fewer CUs than expected) stops
+    // pacing, so the scheme cannot deadlock.
+    uint32_t *pace_ctr = a.pace + (blockIdx.x & 7u) * 32u;
+    uint32_t pace_before = 0, pace_mine = 0;  // pairs of earlier batches of my XCD; pairs of my batch
+    bool pacing = a.pace != nullptr;
+    {
+      const uint32_t ppb = blockDim.x >> 7, xcd = blockIdx.x & 7u, my_batch = (blockIdx.x >> 3) / 32u;
+      for (uint32_t j = 0; j < (my_batch + 1) * 32u; ++j) {
+        const uint64_t first = (uint64_t)(xcd + 8u * j) * ppb;
+        const uint32_t cnt = first >= a.num_samples ? 0u : (a.num_samples - first < ppb ? (uint32_t)(a.num_samples - first) : ppb);
+        if (j < my_batch * 32u) pace_before += cnt; else pace_mine += cnt;
+      }
+    }
+#endif
     const uint32_t ggsw_bytes = (uint32_t)(ggsw_c * sizeof(cplx));
     auto ldc = [](HxBuffer b, uint32_t voff, uint32_t soff) {
       const hx_f64x2 v = hx_buffer_load_f64x2(b, voff, soff);
       return cplx{v.x, v.y};
     };
+#if WAVE_MB_STAGGER && !defined(TFHE_HIPEMU)
+    if (pair >= 2)
+      for (int q = 0; q < WAVE_MB_STAGGER; ++q) __builtin_amdgcn_s_sleep(127);
+#endif
     for (uint32_t grp = 0; grp < groups; ++grp) {
       // monomial degrees of the 2^g - 1 non-empty subsets (:30-65): subset s selects mask element m of
       // the group when bit (g-1-m) of s is set
@@ -852,6 +884,19 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
         base[0] = cplx{1.0, 0.0};
       }
       // the group's 2^g GGSWs as one buffer: uniform base in scalar registers, lane offset in one vector register
+#if WAVE_MB_PACE && !defined(TFHE_HIPEMU)
+      if (pacing && grp >= (uint32_t)WAVE_MB_PACE) {
+        const uint32_t need = pace_before * groups + pace_mine * (grp + 1u - (uint32_t)WAVE_MB_PACE);
+        uint32_t spins = 0;
+        while (__hip_atomic_load(pace_ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+          __builtin_amdgcn_s_sleep(8);
+          if (++spins > (uint32_t)WAVE_MB_PACE_SPINS) {
+            pacing = false;
+            break;
+          }
+        }
+      }
+#endif
       const HxBuffer gk = hx_make_buffer(key + (size_t)grp * per * ggsw_c, per * ggsw_bytes);
       cplx o[16];
       // The accumulator is dead once its digits exist (the product OVERWRITES it): with several levels on
@@ -915,44 +960,46 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
           const cplx *row1 = (w == 0 ? obuf : buf) + base_m3(cx);
           cplx kb0[PTS], kb1[PTS];
           HX_UNROLL
-          for (int t = 0; t < STEPS; ++t) {
-            const int ch = t / (int)per, set = t % SETS;
-            const uint32_t sidx = (uint32_t)(t % (int)per);
-            if (sidx == 0) {  // subset 0 is not rotated: it initialises the chunk's accumulators
-              HX_UNROLL
-              for (int j = 0; j < PTS; ++j) {
-                kb0[j] = x0[set][j];
-                kb1[j] = x1[set][j];
+          for (int ch = 0; ch < CHUNKS; ++ch) {
+            HX_UNROLL
+            for (int si = 0; si < (int)per; ++si) {
+              const int t = ch * (int)per + si, set = t % SETS;
+              const uint32_t sidx = (uint32_t)si;
+              if (si == 0) {  // subset 0 is not rotated: it initialises the chunk's accumulators
+                HX_UNROLL
+                for (int j = 0; j < PTS; ++j) {
+                  kb0[j] = x0[set][j];
+                  kb1[j] = x1[set][j];
+                }
+              } else {
+                HX_UNROLL
+                for (int j = 0; j < PTS; ++j) {
+                  constexpr uint32_t br4[16] = {0, 8, 4, 12, 2, 10, 6, 14, 1, 9, 5, 13, 3, 11, 7, 15};
+                  const cplx wr = T[T_W16X + ((br4[ch * PTS + j] * deg[sidx]) & 15u)];
+                  const cplx mf = cmul_first(base[sidx], wr);
+                  kb0[j] = cmul_add(x0[set][j], mf, kb0[j]);
+                  kb1[j] = cmul_add(x1[set][j], mf, kb1[j]);
+                  // pin the accumulation to this step: left alone, instruction selection sinks three of the four
+                  // products to the end of the chunk and every loaded set stays live until then
+                  HX_OPAQUE(kb0[j].re);
+                  HX_OPAQUE(kb0[j].im);
+                  HX_OPAQUE(kb1[j].re);
+                  HX_OPAQUE(kb1[j].im);
+                }
               }
-            } else {
-              HX_UNROLL
-              for (int j = 0; j < PTS; ++j) {
-                constexpr uint32_t br4[16] = {0, 8, 4, 12, 2, 10, 6, 14, 1, 9, 5, 13, 3, 11, 7, 15};
-                const cplx wr = T[T_W16X + ((br4[ch * PTS + j] * deg[sidx]) & 15u)];
-                const cplx mf = cmul_first(base[sidx], wr);
-                kb0[j] = cmul_add(x0[set][j], mf, kb0[j]);
-                kb1[j] = cmul_add(x1[set][j], mf, kb1[j]);
-                // pin the accumulation to this step: left alone, instruction selection sinks three of the four
-                // products to the end of the chunk and every loaded set stays live until then
-                HX_OPAQUE(kb0[j].re);
-                HX_OPAQUE(kb0[j].im);
-                HX_OPAQUE(kb1[j].re);
-                HX_OPAQUE(kb1[j].im);
-              }
+              HX_SCHED_FENCE();
+              if (t + SETS < STEPS) request(set, t + SETS);
+              HX_SCHED_FENCE();
             }
-            HX_SCHED_FENCE();
-            if (t + SETS < STEPS) request(set, t + SETS);
-            if (sidx == per - 1) {  // chunk complete: multiply-accumulate with the two digit transforms
-              HX_UNROLL
-              for (int j = 0; j < PTS; ++j) {
-                const int r = ch * PTS + j;
-                const cplx x0r = row0[r], x1r = row1[r];
-                // o starts at -0.0: fma(a, b, -0.0) is the rounded product a b with its sign of zero, so the first
-                // term needs no cmul_first (no branch on idx in the unrolled steps) and the bits are the same
-                o[r] = cmul_add(x1r, kb1[j], cmul_add(x0r, kb0[j], o[r]));
-                HX_OPAQUE(o[r].re);
-                HX_OPAQUE(o[r].im);
-              }
+            // chunk complete: multiply-accumulate with the two digit transforms.  o starts at -0.0: fma(a, b, -0.0)
+            // is the rounded product a b with its sign of zero, so the first level needs no separate form
+            HX_UNROLL
+            for (int j = 0; j < PTS; ++j) {
+              const int r = ch * PTS + j;
+              const cplx x0r = row0[r], x1r = row1[r];
+              o[r] = cmul_add(x1r, kb1[j], cmul_add(x0r, kb0[j], o[r]));
+              HX_OPAQUE(o[r].re);
+              HX_OPAQUE(o[r].im);
             }
             HX_SCHED_FENCE();
           }
@@ -964,6 +1011,10 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
       HX_PRIO(WAVE_PRIO_MB_D);
       wave_inverse_accumulate<false, true>(o, acc_re, acc_im, ctx);
       HX_PRIO(WAVE_PRIO_MB_K);
+#if WAVE_MB_PACE && !defined(TFHE_HIPEMU)
+      if (a.pace != nullptr && w == 0 && lane == 0)
+        __hip_atomic_fetch_add(pace_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
     }
   } else {
     stage_acc();
@@ -1067,6 +1118,7 @@ template <int L, int B, int G>
 static void launch_wave_mb_t(hipStream_t st, const PbsArgs &a, const FftTables &tb) {
   using namespace wavek;
   hx_set_dynamic_smem_once<pbs_fft_wave_kernel<L, B, G>>(SMEM_BYTES);
+  if (a.pace) HX_CHECK(hipMemsetAsync(a.pace, 0, 8 * 32 * sizeof(uint32_t), st));
   const unsigned per_block = lwes_per_block(a.num_samples);
   const unsigned blocks = (a.num_samples + per_block - 1) / per_block;
   HX_LAUNCH((pbs_fft_wave_kernel<L, B, G>), dim3(blocks), dim3(128 * per_block), SMEM_BYTES, st, a, tb);
