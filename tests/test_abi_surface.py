@@ -70,3 +70,62 @@ def test_missing_library_fails_loudly(tmp_path):
     from tfhe_rs_amd import ffi
     with pytest.raises(ImportError):
         ffi.Library(str(tmp_path / "nope.so"))
+
+
+# ------------------------------------------------------------------ prototypes, types and order
+def _protos():
+    import sys
+    sys.path.insert(0, ROOT)
+    from tools.c_prototypes import parse_prototypes
+    return parse_prototypes(open(HEADER).read())
+
+
+def _golden():
+    import json
+    return json.load(open(os.path.join(ROOT, "tests", "golden", "reference_prototypes.json")))["prototypes"]
+
+
+def test_every_reference_named_prototype_equals_the_reference_header():
+    """Return type, every parameter type and their order, for EVERY function the header declares under a
+    reference name (50 of them), against the prototypes of the reference's own headers (snapshot:
+    tests/golden/reference_prototypes.json, made by tests/golden/make_prototypes.py from
+    backends/tfhe-cuda-backend/cuda/include/**/*.h and tfhe-cuda-common/cuda/include/device.h)."""
+    ours, ref = _protos(), _golden()
+    in_scope = sorted(n for n in ours if not n.startswith("hip_"))
+    assert in_scope == sorted(ref), "the snapshot does not cover the header: re-run tests/golden/make_prototypes.py"
+    assert len(in_scope) >= 50
+    for name in in_scope:
+        ret, params = ours[name]
+        assert ret == ref[name]["ret"], f"{name}: return type {ret} != {ref[name]['ret']} ({ref[name]['header']})"
+        assert params == ref[name]["params"], f"{name}: parameters differ from {ref[name]['header']}"
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/backends"), reason="reference tree absent")
+def test_prototype_snapshot_is_what_the_reference_tree_says():
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import make_prototypes
+    assert make_prototypes.build() == _golden()
+
+
+def test_rust_crate_bindings_are_generated_from_the_header_and_equal_the_reference_bindings():
+    """backends/tfhe-hip-backend/src/{bindings,cuda_bind}.rs are the generator's output for the current header,
+    and every declaration under a reference name is, token for token, the declaration bindgen produced for the
+    reference (backends/tfhe-cuda-backend/src/bindings.rs, tfhe-cuda-common/src/cuda_bind.rs; snapshot)."""
+    import sys
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from tools import gen_rust_bindings as g
+    from make_prototypes import rust_declarations
+    crate = os.path.join(ROOT, "backends", "tfhe-hip-backend", "src")
+    ours = {}
+    for which, fname in (("backend", "bindings.rs"), ("runtime", "cuda_bind.rs")):
+        text = open(os.path.join(crate, fname)).read()
+        assert text == g.generate(which), f"{fname} is stale: run tools/gen_rust_bindings.py"
+        ours.update(rust_declarations(text))
+    ref = _golden()
+    assert sorted(n for n in ours if not n.startswith("hip_")) == sorted(ref)
+    for name, entry in ref.items():
+        assert ours[name] == entry["rust"], f"{name}:\n  ours {ours[name]}\n  ref  {entry['rust']}"
+    for f in ("Cargo.toml", "build.rs", "src/lib.rs", "src/ffi.rs", "src/ffi_types.rs"):
+        assert os.path.exists(os.path.join(ROOT, "backends", "tfhe-hip-backend", f))
