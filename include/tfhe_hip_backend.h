@@ -311,6 +311,9 @@ void cleanup_cuda_integer_mult_inplace_64(CudaStreamsFFI streams, int8_t **mem_p
 /* extensions: integers per launch the NEXT scratch_* call is sized for (default 1), and the number
  * of PBS one multiplication issues per integer (for throughput accounting) */
 void hip_integer_scratch_batch(uint32_t num_integers);
+/* blocks per GPU from which a KS -> PBS round of the radix layer spreads over one more GPU of its CudaStreamsFFI
+ * (default 512); the stream set may also name the same GPU several times (one stream each) */
+void hip_integer_set_multi_gpu_threshold(uint32_t blocks_per_gpu);
 uint64_t hip_integer_mult_pbs_count(int8_t *mem_ptr);
 uint64_t hip_integer_propagate_pbs_count(uint32_t num_blocks);
 

@@ -107,13 +107,13 @@ ABORTS = {
             s, C.byref(mem), ffi.CudaLweBootstrapKeyParamsFFI(12, 1, 2048, 23, 1, 2048, 1, 0),
             ffi.CudaLweKeyswitchKeyParamsFFI(2048, 12, 4, 4), 8, 4, 4, 1, True, 0)
         """, "signed-overflow flag is not wired"),
-    "radix layer on a multi-bit key": ("""
+    "radix layer on a multi-bit key whose grouping factor does not divide n": ("""
         s = ffi.CudaStreamsFFI((C.c_void_p * 1)(S), (C.c_uint32 * 1)(0), 1)
         mem = C.c_void_p()
         lib.scratch_cuda_propagate_single_carry_64_inplace_async(
             s, C.byref(mem), ffi.CudaLweBootstrapKeyParamsFFI(10, 1, 256, 4, 1, 256, 0, 3),
             ffi.CudaLweKeyswitchKeyParamsFFI(256, 10, 4, 4), 4, 4, 4, 0, True, 0)
-        """, "only the classic PBS is wired"),
+        """, "grouping factor in 1..4 dividing the LWE dimension"),
 }
 
 

@@ -16,16 +16,20 @@ BACKENDS = [pytest.param("emu", id="emu"), pytest.param("hip", id="hip", marks=p
 MSG = 4  # message_modulus = carry_modulus = 4
 
 
-def setup(kind):
+def setup(kind, p=None, gpu_indexes=(0,)):
     from tfhe_rs_amd import core_crypto_gpu as gpu
     from tfhe_rs_amd import integer_gpu as igpu
     use_backend(kind)
-    p = TOY_2048 if kind == "emu" else C1
+    p = p or (TOY_2048 if kind == "emu" else C1)
     keys = make_keys(p)
-    st = gpu.CudaStreams.new_single_gpu(0)
+    st = gpu.CudaStreams(gpu_indexes)
     ksk = gpu.CudaLweKeyswitchKey.from_lwe_keyswitch_key(keys.ksk, p.big_n, p.n, p.ks_base_log, p.ks_level, st)
-    bsk = gpu.CudaLweBootstrapKey.from_lwe_bootstrap_key(keys.bsk, p.n, p.k, p.N, p.pbs_base_log, p.pbs_level, st,
-                                                         ms_noise_reduction=bool(p.ms_type))
+    if p.grouping:
+        bsk = gpu.CudaLweMultiBitBootstrapKey.from_lwe_multi_bit_bootstrap_key(
+            keys.bsk, p.n, p.k, p.N, p.pbs_base_log, p.pbs_level, p.grouping, st)
+    else:
+        bsk = gpu.CudaLweBootstrapKey.from_lwe_bootstrap_key(keys.bsk, p.n, p.k, p.N, p.pbs_base_log, p.pbs_level, st,
+                                                             ms_noise_reduction=bool(p.ms_type))
     return p, keys, st, igpu.CudaServerKey(ksk, bsk, MSG, MSG), igpu
 
 
@@ -107,3 +111,54 @@ def test_mul(kind):
     assert all(d < MSG for r in rows for d in r)
     assert recompose(rows) == [(x * y) & mask for x, y in zip(a, b)]
     assert pbs > L * L
+
+
+@pytest.mark.parametrize("kind", BACKENDS)
+def test_radix_ops_on_a_multi_bit_key(kind):
+    """pbs_type = MULTI_BIT through the radix FFI (the reference's GPU defaults are multi-bit sets,
+    cuda/src/pbs/programmable_bootstrap.cuh:348-535): add with carries and mul on a multi-bit server key."""
+    from .common import C4, TOY_MB_2048
+    p, keys, st, sks, igpu = setup(kind, TOY_MB_2048 if kind == "emu" else C4)
+    L = 6 if kind == "emu" else 16
+    bits, mask = 2 * L, (1 << (2 * L)) - 1
+    a, b = [0x9E3779B9 & mask, mask, 0x12345678 & mask], [0x7F4A7C15 & mask, 1, 0x0FEDCBA9 & mask]
+    ca = igpu.CudaUnsignedRadixCiphertext.from_blocks(encrypt_radix(p, keys, a, L, 41), st)
+    cb = igpu.CudaUnsignedRadixCiphertext.from_blocks(encrypt_radix(p, keys, b, L, 42), st)
+    cm = ca.duplicate(st)
+    sks.add_assign(ca, cb, st)
+    assert recompose(decrypt_blocks(p, keys, ca.to_blocks(st))) == [(x + y) & mask for x, y in zip(a, b)]
+    sks.mul_assign(cm, cb, st)
+    assert recompose(decrypt_blocks(p, keys, cm.to_blocks(st))) == [(x * y) & mask for x, y in zip(a, b)]
+
+
+@pytest.mark.parametrize("kind", BACKENDS)
+def test_radix_rounds_sharded_over_the_streams_of_the_set(kind):
+    """In-library multi-GPU (helper_multi_gpu.cuh:170-294): every KS -> PBS round of add / mul is split over the
+    streams of the CudaStreamsFFI by the reference's get_num_inputs_on_gpu rule, with per-stream key replicas and
+    scratch, peer copies and events.  Three streams on GPU 0 (the reference's debug-fake-multi-gpu idea: the box
+    has one GPU) and a threshold of 3 blocks per GPU so that even the small rounds are sharded raggedly; results
+    must equal the single-stream run bit for bit and decrypt to the clear results."""
+    p, keys, st1, sks1, igpu = setup(kind)
+    _, _, st3, sks3, _ = setup(kind, gpu_indexes=(0, 0, 0))
+    lib = use_backend(kind)
+    L = 7 if kind == "emu" else 32
+    mask = (1 << (2 * L)) - 1
+    rng = np.random.default_rng(77)
+    a = [int(x) & mask for x in rng.integers(0, 1 << 62, size=3)] + [mask]
+    b = [int(x) & mask for x in rng.integers(0, 1 << 62, size=3)] + [1]
+    blocks_a, blocks_b = encrypt_radix(p, keys, a, L, 51), encrypt_radix(p, keys, b, L, 52)
+    outs = {}
+    for name, st, sks, thr in (("one", st1, sks1, 512), ("three", st3, sks3, 3)):
+        lib.hip_integer_set_multi_gpu_threshold(thr)
+        try:
+            ca = igpu.CudaUnsignedRadixCiphertext.from_blocks(blocks_a, st)
+            cb = igpu.CudaUnsignedRadixCiphertext.from_blocks(blocks_b, st)
+            cm = ca.duplicate(st)
+            sks.add_assign(ca, cb, st)
+            sks.mul_assign(cm, cb, st)
+            outs[name] = (ca.to_blocks(st), cm.to_blocks(st))
+        finally:
+            lib.hip_integer_set_multi_gpu_threshold(512)
+    assert np.array_equal(outs["one"][0], outs["three"][0]) and np.array_equal(outs["one"][1], outs["three"][1])
+    assert recompose(decrypt_blocks(p, keys, outs["three"][0])) == [(x + y) & mask for x, y in zip(a, b)]
+    assert recompose(decrypt_blocks(p, keys, outs["three"][1])) == [(x * y) & mask for x, y in zip(a, b)]

@@ -66,12 +66,16 @@ static void axpy(hipStream_t st, uint64_t *out, const uint64_t *out_idx, const u
 // ------------------------------------------------------------------ host helpers
 struct Params {
   uint32_t big_n, small_n, k, N, pbs_base_log, pbs_level, ks_base_log, ks_level, msg, carry, ms_type;
+  uint32_t grouping;  // 0: classic PBS; g >= 1: multi-bit PBS with that grouping factor (pbs_type = MULTI_BIT)
 };
 
 static Params make_params(CudaLweBootstrapKeyParamsFFI b, CudaLweKeyswitchKeyParamsFFI k, uint32_t msg, uint32_t carry,
                           uint32_t ms_type) {
-  HX_PANIC_IF_FALSE(b.pbs_type == 1 /* CLASSICAL */, "radix layer: only the classic PBS is wired (pbs_type=%u)",
-                    b.pbs_type);
+  HX_PANIC_IF_FALSE(b.pbs_type == CLASSICAL || b.pbs_type == MULTI_BIT, "radix layer: unknown pbs_type %u", b.pbs_type);
+  HX_PANIC_IF_FALSE(b.pbs_type == CLASSICAL || (b.grouping_factor >= 1 && b.grouping_factor <= 4 &&
+                                                b.input_lwe_dimension % b.grouping_factor == 0),
+                    "radix layer: multi-bit PBS needs a grouping factor in 1..4 dividing the LWE dimension (got %u)",
+                    b.grouping_factor);
   HX_PANIC_IF_FALSE(b.glwe_dimension * b.polynomial_size == k.input_lwe_dimension &&
                         k.output_lwe_dimension == b.input_lwe_dimension,
                     "radix layer: keyswitch and bootstrap key dimensions do not chain");
@@ -79,7 +83,7 @@ static Params make_params(CudaLweBootstrapKeyParamsFFI b, CudaLweKeyswitchKeyPar
                     "radix layer: unsupported message/carry moduli (%u, %u)", msg, carry);
   return Params{k.input_lwe_dimension, b.input_lwe_dimension, b.glwe_dimension, b.polynomial_size, b.base_log,
                 b.level_count,         k.base_log,            k.level_count,    msg,               carry,
-                ms_type};
+                ms_type,               b.pbs_type == MULTI_BIT ? b.grouping_factor : 0u};
 }
 
 // cuda/src/integer/integer.cuh:1266-1305 (generate_lookup_table_with_encoding, same in/out encoding)
@@ -119,56 +123,186 @@ static T *dev_upload(hipStream_t st, const std::vector<T> &h) {
   return d;
 }
 
-// The KS -> PBS round driver (integer.cuh:869-990 for one GPU): `count` blocks gathered from `in`
-// through in_idx are keyswitched, bootstrapped with LUT lut_idx[s] and scattered to out[out_idx[s]].
+// The KS -> PBS round driver (integer.cuh:869-990): `count` blocks gathered from `in` through in_idx are
+// keyswitched, bootstrapped with LUT lut_idx[s] and scattered to out[out_idx[s]].
+//
+// Multi-GPU (helper_multi_gpu.cuh:170-294, helper_multi_gpu.cu:39-101): the ciphertexts live on the first GPU of
+// the stream set; a round over enough blocks is split into contiguous shards by the reference's rule
+// (get_num_inputs_on_gpu), GPU 0 works on its shard in place, every other active GPU i receives its shard
+// (gathered on GPU 0, one peer copy on stream i), runs the same two launches with ITS key replicas
+// (ksks[i], bsks[i]) and scratch, and sends the results back for a scatter on GPU 0.  Events order the streams;
+// no host synchronisation, no collective.  The same code runs with several streams on ONE device (the
+// reference's debug-fake-multi-gpu idea), which is how the 1-GPU test box exercises it.
+static uint32_t g_multi_gpu_min_blocks = 512;  // blocks per GPU below which a round stays on fewer GPUs
+
+static uint32_t num_inputs_on_gpu(uint32_t total, uint32_t gpu, uint32_t gpus) {  // helper_multi_gpu.cu:71-101
+  if (gpus > total) return gpu < total ? 1u : 0u;
+  const uint32_t large = (total + gpus - 1) / gpus, small = total / gpus, cutoff = total % gpus;
+  return (cutoff != 0 && gpu < cutoff) ? large : small;
+}
+
 struct LutDriver {
   static constexpr uint32_t kMagic = 0x52445231;  // "RDR1"
   uint32_t magic = kMagic;
   Params p{};
-  uint32_t gpu = 0, cap = 0, num_luts = 0;
-  uint64_t *d_ks = nullptr, *d_luts = nullptr, *d_trivial = nullptr;  // d_trivial = 0, 1, ..., cap - 1
-  int8_t *pbs_buf = nullptr;
+  uint32_t cap = 0, num_luts = 0;
+  struct PerGpu {
+    uint32_t gpu = 0;
+    uint64_t *d_ks = nullptr, *d_luts = nullptr, *d_trivial = nullptr;  // d_trivial = 0, 1, ..., cap - 1
+    int8_t *pbs_buf = nullptr;
+    // GPUs other than the first: shard buffers on this GPU and their twins on the first GPU
+    uint64_t *d_in = nullptr, *d_out = nullptr, *d_lut_idx = nullptr;   // on this GPU
+    uint64_t *d0_in = nullptr, *d0_out = nullptr;                       // on the first GPU
+    hipEvent_t staged = nullptr, done = nullptr, copied = nullptr;
+  };
+  std::vector<PerGpu> gpus;
 
-  void init(hipStream_t st, uint32_t gpu_index, const Params &params, uint32_t capacity,
+  void scratch_pbs(hipStream_t st, PerGpu &g) {
+    if (p.grouping)
+      scratch_cuda_multi_bit_programmable_bootstrap_64_async(st, g.gpu, &g.pbs_buf, p.k, p.N, p.pbs_level, cap, !t_dry);
+    else
+      scratch_cuda_programmable_bootstrap_64_async(st, g.gpu, &g.pbs_buf, p.small_n, p.k, p.N, p.pbs_level, cap,
+                                                   !t_dry, (enum PBS_MS_REDUCTION_T)p.ms_type);
+  }
+
+  void init(const CudaStreamsFFI &s, const Params &params, uint32_t capacity,
             const std::vector<std::vector<uint64_t>> &luts) {
+    HX_PANIC_IF_FALSE(s.gpu_count >= 1 && s.streams != nullptr, "radix layer: empty stream set");
     p = params;
-    gpu = gpu_index;
     cap = capacity;
     num_luts = (uint32_t)luts.size();
-    const size_t lw = (size_t)(p.k + 1) * p.N;
-    radix_alloc((void **)&d_ks, (size_t)cap * (p.small_n + 1) * sizeof(uint64_t));
-    radix_alloc((void **)&d_luts, std::max<size_t>(1, num_luts) * lw * sizeof(uint64_t));
-    for (uint32_t i = 0; i < num_luts && !t_dry; ++i)
-      HX_CHECK(hipMemcpyAsync(d_luts + i * lw, luts[i].data(), lw * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+    const size_t lw = (size_t)(p.k + 1) * p.N, w = (size_t)p.big_n + 1;
     std::vector<uint64_t> triv(cap);
     for (uint32_t i = 0; i < cap; ++i) triv[i] = i;
-    d_trivial = dev_upload(st, triv);
-    HX_CHECK(hipStreamSynchronize(st));
-    scratch_cuda_programmable_bootstrap_64_async(st, gpu, &pbs_buf, p.small_n, p.k, p.N, p.pbs_level, cap, !t_dry,
-                                                 (enum PBS_MS_REDUCTION_T)p.ms_type);
+    gpus.resize(s.gpu_count);
+    for (uint32_t i = 0; i < s.gpu_count; ++i) {
+      PerGpu &g = gpus[i];
+      g.gpu = s.gpu_indexes ? s.gpu_indexes[i] : 0;
+      const hipStream_t st = (hipStream_t)s.streams[i];
+      HX_CHECK(hipSetDevice((int)g.gpu));
+      radix_alloc((void **)&g.d_ks, (size_t)cap * (p.small_n + 1) * sizeof(uint64_t));
+      radix_alloc((void **)&g.d_luts, std::max<size_t>(1, num_luts) * lw * sizeof(uint64_t));
+      for (uint32_t t = 0; t < num_luts && !t_dry; ++t)
+        HX_CHECK(hipMemcpyAsync(g.d_luts + t * lw, luts[t].data(), lw * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+      g.d_trivial = dev_upload(st, triv);
+      if (i > 0) {
+        radix_alloc((void **)&g.d_in, (size_t)cap * w * sizeof(uint64_t));
+        radix_alloc((void **)&g.d_out, (size_t)cap * w * sizeof(uint64_t));
+        radix_alloc((void **)&g.d_lut_idx, (size_t)cap * sizeof(uint64_t));
+        HX_CHECK(hipSetDevice((int)gpus[0].gpu));
+        radix_alloc((void **)&g.d0_in, (size_t)cap * w * sizeof(uint64_t));
+        radix_alloc((void **)&g.d0_out, (size_t)cap * w * sizeof(uint64_t));
+        HX_CHECK(hipSetDevice((int)g.gpu));
+        if (!t_dry) {
+          HX_CHECK(hipEventCreateWithFlags(&g.staged, hipEventDisableTiming));
+          HX_CHECK(hipEventCreateWithFlags(&g.done, hipEventDisableTiming));
+          HX_CHECK(hipEventCreateWithFlags(&g.copied, hipEventDisableTiming));
+        }
+      }
+      HX_CHECK(hipStreamSynchronize(st));  // the LUT sources may be temporaries
+      scratch_pbs(st, g);
+    }
+    HX_CHECK(hipSetDevice((int)gpus[0].gpu));
   }
+
+  void ks_pbs(hipStream_t st, const PerGpu &g, uint64_t *out, const uint64_t *out_idx, const uint64_t *in,
+              const uint64_t *in_idx, const uint64_t *lut_idx, uint32_t c, const void *ksk, const void *bsk) const {
+    cuda_keyswitch_lwe_ciphertext_vector_64_64_async(st, g.gpu, g.d_ks, g.d_trivial, in, in_idx, ksk, p.big_n, p.small_n,
+                                                     p.ks_base_log, p.ks_level, c);
+    if (p.grouping)
+      cuda_multi_bit_programmable_bootstrap_64_async(st, g.gpu, out, out_idx, g.d_luts, lut_idx, g.d_ks, g.d_trivial, bsk,
+                                                     g.pbs_buf, p.small_n, p.k, p.N, p.grouping, p.pbs_base_log,
+                                                     p.pbs_level, c, 1, 0);
+    else
+      cuda_programmable_bootstrap_64_async(st, g.gpu, out, out_idx, g.d_luts, lut_idx, g.d_ks, g.d_trivial, bsk, g.pbs_buf,
+                                           p.small_n, p.k, p.N, p.pbs_base_log, p.pbs_level, c, 1, 0);
+  }
+
   // one round, split into launches of at most `cap` blocks; a null in_idx / out_idx means "block s"
-  void round(hipStream_t st, uint64_t *out, const uint64_t *out_idx, const uint64_t *in, const uint64_t *in_idx,
-             const uint64_t *lut_idx, uint32_t count, const void *ksk, const void *bsk) const {
+  void round(const CudaStreamsFFI &s, uint64_t *out, const uint64_t *out_idx, const uint64_t *in, const uint64_t *in_idx,
+             const uint64_t *lut_idx, uint32_t count, void *const *ksks, void *const *bsks) const {
     const size_t w = (size_t)p.big_n + 1;
+    const uint32_t avail = std::min<uint32_t>(s.gpu_count, (uint32_t)gpus.size());
+    const hipStream_t st0 = (hipStream_t)s.streams[0];
     for (uint32_t off = 0; off < count; off += cap) {
       const uint32_t c = std::min(cap, count - off);
-      cuda_keyswitch_lwe_ciphertext_vector_64_64_async(st, gpu, d_ks, d_trivial, in_idx ? in : in + off * w,
-                                                       in_idx ? in_idx + off : d_trivial, ksk, p.big_n, p.small_n,
-                                                       p.ks_base_log, p.ks_level, c);
-      cuda_programmable_bootstrap_64_async(st, gpu, out_idx ? out : out + off * w,
-                                           out_idx ? out_idx + off : d_trivial, d_luts, lut_idx + off, d_ks,
-                                           d_trivial, bsk, pbs_buf, p.small_n, p.k, p.N, p.pbs_base_log, p.pbs_level,
-                                           c, 1, 0);
+      // helper_multi_gpu.cu:39-48 (get_active_gpu_count): as many GPUs as the round can keep busy
+      const uint32_t active = std::max(1u, std::min(avail, (c + g_multi_gpu_min_blocks - 1) / g_multi_gpu_min_blocks));
+      const uint64_t *ii = in_idx ? in_idx + off : nullptr, *oi = out_idx ? out_idx + off : nullptr;
+      const uint64_t *in0 = in_idx ? in : in + off * w;
+      uint64_t *out0 = out_idx ? out : out + off * w;
+      uint32_t first = num_inputs_on_gpu(c, 0, active);
+      // shards of the other GPUs: gather on the first GPU, ship, compute, ship back (all asynchronous)
+      uint32_t begin = first;
+      for (uint32_t i = 1; i < active; ++i) {
+        const PerGpu &g = gpus[i];
+        const hipStream_t sti = (hipStream_t)s.streams[i];
+        const uint32_t ci = num_inputs_on_gpu(c, i, active);
+        if (ci == 0) continue;
+        HX_CHECK(hipSetDevice((int)gpus[0].gpu));
+        if (ii)
+          axpy(st0, g.d0_in, nullptr, in0, ii + begin, 1, nullptr, nullptr, (uint32_t)w, ci);
+        else  // trivial input indexing: the shard starts at block `begin`
+          HX_CHECK(hipMemcpyAsync(g.d0_in, in0 + (size_t)begin * w, (size_t)ci * w * sizeof(uint64_t),
+                                  hipMemcpyDeviceToDevice, st0));
+        HX_CHECK(hipEventRecord(g.staged, st0));
+        HX_CHECK(hipSetDevice((int)g.gpu));
+        HX_CHECK(hipStreamWaitEvent(sti, g.staged, 0));
+        HX_CHECK(hipMemcpyPeerAsync(g.d_in, (int)g.gpu, g.d0_in, (int)gpus[0].gpu, (size_t)ci * w * sizeof(uint64_t), sti));
+        HX_CHECK(hipMemcpyPeerAsync(g.d_lut_idx, (int)g.gpu, lut_idx + off + begin, (int)gpus[0].gpu,
+                                    (size_t)ci * sizeof(uint64_t), sti));
+        ks_pbs(sti, g, g.d_out, g.d_trivial, g.d_in, g.d_trivial, g.d_lut_idx, ci, ksks[i], bsks[i]);
+        HX_CHECK(hipMemcpyPeerAsync(g.d0_out, (int)gpus[0].gpu, g.d_out, (int)g.gpu, (size_t)ci * w * sizeof(uint64_t), sti));
+        HX_CHECK(hipEventRecord(g.done, sti));
+        begin += ci;
+      }
+      // the first GPU's own shard, in place
+      HX_CHECK(hipSetDevice((int)gpus[0].gpu));
+      ks_pbs(st0, gpus[0], out0, oi ? oi : gpus[0].d_trivial, in0, ii ? ii : gpus[0].d_trivial, lut_idx + off, first,
+             ksks[0], bsks[0]);
+      // results of the other GPUs: scatter on the first GPU
+      begin = first;
+      for (uint32_t i = 1; i < active; ++i) {
+        const PerGpu &g = gpus[i];
+        const uint32_t ci = num_inputs_on_gpu(c, i, active);
+        if (ci == 0) continue;
+        HX_CHECK(hipStreamWaitEvent(st0, g.done, 0));
+        if (oi)
+          axpy(st0, out0, oi + begin, g.d0_out, nullptr, 1, nullptr, nullptr, (uint32_t)w, ci);
+        else
+          HX_CHECK(hipMemcpyAsync(out0 + (size_t)begin * w, g.d0_out, (size_t)ci * w * sizeof(uint64_t),
+                                  hipMemcpyDeviceToDevice, st0));
+        // the next use of this GPU's staging buffers must wait for the scatter
+        HX_CHECK(hipEventRecord(g.copied, st0));
+        HX_CHECK(hipSetDevice((int)g.gpu));
+        HX_CHECK(hipStreamWaitEvent((hipStream_t)s.streams[i], g.copied, 0));
+        HX_CHECK(hipSetDevice((int)gpus[0].gpu));
+        begin += ci;
+      }
     }
   }
-  void release(hipStream_t st) {
-    HX_CHECK(hipStreamSynchronize(st));
-    if (pbs_buf) cleanup_cuda_programmable_bootstrap_64(st, gpu, &pbs_buf);
-    if (d_ks) HX_CHECK(hipFree(d_ks));
-    if (d_luts) HX_CHECK(hipFree(d_luts));
-    if (d_trivial) HX_CHECK(hipFree(d_trivial));
-    d_ks = d_luts = d_trivial = nullptr;
+
+  void release(const CudaStreamsFFI &s) {
+    for (uint32_t i = 0; i < (uint32_t)gpus.size(); ++i) {
+      PerGpu &g = gpus[i];
+      const hipStream_t st = (hipStream_t)s.streams[i < s.gpu_count ? i : 0];
+      HX_CHECK(hipSetDevice((int)g.gpu));
+      HX_CHECK(hipStreamSynchronize(st));
+      if (g.pbs_buf) {
+        if (p.grouping)
+          cleanup_cuda_multi_bit_programmable_bootstrap_64(st, g.gpu, &g.pbs_buf);
+        else
+          cleanup_cuda_programmable_bootstrap_64(st, g.gpu, &g.pbs_buf);
+      }
+      for (uint64_t *d : {g.d_ks, g.d_luts, g.d_trivial, g.d_in, g.d_out, g.d_lut_idx})
+        if (d) HX_CHECK(hipFree(d));
+      for (hipEvent_t e : {g.staged, g.done, g.copied})
+        if (e) HX_CHECK(hipEventDestroy(e));
+      HX_CHECK(hipSetDevice((int)gpus[0].gpu));
+      for (uint64_t *d : {g.d0_in, g.d0_out})
+        if (d) HX_CHECK(hipFree(d));
+    }
+    gpus.clear();
     magic = 0;
   }
 };
@@ -373,7 +507,7 @@ struct PropagateMem {
     cached_cts = cts;
   }
 
-  void init(hipStream_t st, uint32_t gpu, const Params &p, uint32_t num_blocks, uint32_t cts) {
+  void init(const CudaStreamsFFI &ss, const Params &p, uint32_t num_blocks, uint32_t cts) {
     blocks = num_blocks;
     max_cts = cts;
     HX_PANIC_IF_FALSE(p.msg * p.carry >= 16 && p.carry >= p.msg,
@@ -402,7 +536,7 @@ struct PropagateMem {
       generate_lut(p, luts.back().data(), f);
     }
     const uint32_t T = cts * num_blocks, NG = ngroups(num_blocks);
-    drv.init(st, gpu, p, std::min<uint32_t>(T, 1u << 16), luts);
+    drv.init(ss, p, std::min<uint32_t>(T, 1u << 16), luts);
     const size_t w = p.big_n + 1;
     radix_alloc((void **)&d_pool, ((size_t)T + (size_t)cts * NG) * w * sizeof(uint64_t));
     radix_alloc((void **)&d_s, (size_t)T * w * sizeof(uint64_t));
@@ -419,8 +553,9 @@ struct PropagateMem {
   // in place on v (cts integers of `blocks` blocks).  carry_in (one block per integer, value 0/1) is added to
   // block 0 first — a first block of value <= 2 msg - 1 still emits at most one carry and receives none;
   // carry_out (one block per integer) receives the carry leaving the last block.  Either may be null.
-  void run(hipStream_t st, uint64_t *v, uint32_t cts, const void *ksk, const void *bsk,
+  void run(const CudaStreamsFFI &ss, uint64_t *v, uint32_t cts, void *const *ksks, void *const *bsks,
            const uint64_t *carry_in = nullptr, uint64_t *carry_out = nullptr) {
+    const hipStream_t st = S0(ss);  // linear operations and index uploads: first GPU only, like the reference
     HX_PANIC_IF_FALSE(cts >= 1 && cts <= max_cts, "carry propagation: %u integers exceed the scratch capacity %u", cts,
                       max_cts);
     if (cached_cts != cts) build_indexes(st, cts);
@@ -428,31 +563,31 @@ struct PropagateMem {
     const uint32_t w = p.big_n + 1, T = cts * blocks;
     if (carry_in) axpy(st, v, rIO.a, v, rIO.a, 1, carry_in, nullptr, w, cts);
     // A: shifted / plain state of every block
-    drv.round(st, d_pool, rA.o, v, rA.a, rA.lut, rA.count, ksk, bsk);
+    drv.round(ss, d_pool, rA.o, v, rA.a, rA.lut, rA.count, ksks, bsks);
     if (csrU.count) {
       // group states: U (dense) -> first G-1 blocks -> whole group -> prefix scan -> carry into each group
       group_sum(st, d_u, d_pool, csrU, csrU.count, w);
-      drv.round(st, d_gs, rC1.o, d_u, nullptr, rC1.lut, rC1.count, ksk, bsk);
+      drv.round(ss, d_gs, rC1.o, d_u, nullptr, rC1.lut, rC1.count, ksks, bsks);
       axpy(st, d_p, nullptr, d_gs, rC2.a, p.msg, d_pool, rC2.b, w, rC2.count);
-      drv.round(st, d_gs, rC2.o, d_p, nullptr, rC2.lut, rC2.count, ksk, bsk);
+      drv.round(ss, d_gs, rC2.o, d_p, nullptr, rC2.lut, rC2.count, ksks, bsks);
       for (const Idx &r : scan) {
         axpy(st, d_p, nullptr, d_gs, r.a, p.msg, d_gs, r.b, w, r.count);
-        drv.round(st, d_gs, r.o, d_p, nullptr, r.lut, r.count, ksk, bsk);
+        drv.round(ss, d_gs, r.o, d_p, nullptr, r.lut, r.count, ksks, bsks);
       }
-      drv.round(st, d_pool, rD.o, d_gs, rD.a, rD.lut, rD.count, ksk, bsk);
+      drv.round(ss, d_pool, rD.o, d_gs, rD.a, rD.lut, rD.count, ksks, bsks);
     }
     // E: inner carries (dense partial sums in P, bit q of each -> S[t])
     group_sum(st, d_p, d_pool, csrS, csrS.count, w);
-    drv.round(st, d_s, csrS.o, d_p, nullptr, csrS.lut, csrS.count, ksk, bsk);
+    drv.round(ss, d_s, csrS.o, d_p, nullptr, csrS.lut, csrS.count, ksks, bsks);
     // F: add the carries, extract the messages
     axpy(st, v, addC.o, v, addC.o, 1, d_pool, addC.a, w, addC.count);
     axpy(st, v, addS.o, v, addS.o, 1, d_s, addS.o, w, addS.count);
-    if (carry_out) drv.round(st, carry_out, nullptr, v, rIO.b, rIO.lut, cts, ksk, bsk);
-    drv.round(st, v, nullptr, v, nullptr, rF.lut, T, ksk, bsk);
+    if (carry_out) drv.round(ss, carry_out, nullptr, v, rIO.b, rIO.lut, cts, ksks, bsks);
+    drv.round(ss, v, nullptr, v, nullptr, rF.lut, T, ksks, bsks);
   }
 
-  void release(hipStream_t st) {
-    drv.release(st);
+  void release(const CudaStreamsFFI &ss) {
+    drv.release(ss);
     for (auto *d : dev_arrays) HX_CHECK(hipFree(d));
     dev_arrays.clear();
     for (uint64_t *d : {d_pool, d_s, d_p, d_u, d_gs})
@@ -539,7 +674,7 @@ struct MulMem {
     slots = (uint32_t)next;
   }
 
-  void init(hipStream_t st, uint32_t gpu, const Params &p, uint32_t num_blocks, uint32_t cts) {
+  void init(const CudaStreamsFFI &ss, const Params &p, uint32_t num_blocks, uint32_t cts) {
     blocks = num_blocks;
     max_cts = cts;
     const uint64_t m = p.msg;
@@ -561,18 +696,20 @@ struct MulMem {
     const size_t w = p.big_n + 1;
     const size_t per_ct = (size_t)slots * w * sizeof(uint64_t);
     sub = (uint32_t)std::max<size_t>(1, std::min<size_t>(cts, ((size_t)12 << 30) / per_ct));
-    drv.init(st, gpu, p, 1u << 16, luts);
+    drv.init(ss, p, 1u << 16, luts);
     radix_alloc((void **)&d_pool, (size_t)sub * per_ct);
     const size_t n_prod = prod_slot.size();
     size_t max_groups = 0;
     for (auto &s : steps) max_groups = std::max(max_groups, s.msg_slot.size());
     radix_alloc((void **)&d_pack, (size_t)sub * n_prod * w * sizeof(uint64_t));
     radix_alloc((void **)&d_sum, std::max<size_t>(1, (size_t)sub * max_groups) * w * sizeof(uint64_t));
-    prop.init(st, gpu, p, num_blocks, sub);
+    prop.init(ss, p, num_blocks, sub);
   }
 
   // lhs <- lhs * rhs for `cts` integers
-  void run(hipStream_t st, uint64_t *lhs, const uint64_t *rhs, uint32_t cts, const void *ksk, const void *bsk) {
+  void run(const CudaStreamsFFI &ss, uint64_t *lhs, const uint64_t *rhs, uint32_t cts, void *const *ksks,
+           void *const *bsks) {
+    const hipStream_t st = S0(ss);
     HX_PANIC_IF_FALSE(cts >= 1 && cts <= max_cts, "multiplication: %u integers exceed the scratch capacity %u", cts,
                       max_cts);
     const Params &p = drv.p;
@@ -599,7 +736,7 @@ struct MulMem {
           }
         uint64_t *da = up(a), *db = up(b), *dout = up(o), *dl = up(l);
         axpy(st, d_pack, nullptr, l0, da, p.msg, r0, db, w, (uint32_t)(nb * n_prod));
-        drv.round(st, d_pool, dout, d_pack, nullptr, dl, (uint32_t)(nb * n_prod), ksk, bsk);
+        drv.round(ss, d_pool, dout, d_pack, nullptr, dl, (uint32_t)(nb * n_prod), ksks, bsks);
       }
       for (const Step &s : steps) {  // column sums
         const size_t G = s.msg_slot.size();
@@ -624,7 +761,7 @@ struct MulMem {
         uint64_t *doff = up(off), *dmem = up(mem);
         HX_LAUNCH(lwe_group_sum_kernel, dim3((unsigned)(nb * G)), dim3(256), 0, st, d_sum, d_pool, doff, dmem, w,
                   (uint32_t)(nb * G));
-        drv.round(st, d_pool, up(out), d_sum, up(in), up(lut), (uint32_t)in.size(), ksk, bsk);
+        drv.round(ss, d_pool, up(out), d_sum, up(in), up(lut), (uint32_t)in.size(), ksks, bsks);
       }
       {  // at most two terms per column: add them into lhs, then propagate the carries
         std::vector<uint64_t> a, b, o, a1, o1;
@@ -642,16 +779,16 @@ struct MulMem {
           }
         axpy(st, l0, up(o), d_pool, up(a), 1, d_pool, up(b), w, (uint32_t)a.size());
         axpy(st, l0, up(o1), d_pool, up(a1), 1, nullptr, nullptr, w, (uint32_t)a1.size());
-        prop.run(st, l0, nb, ksk, bsk);
+        prop.run(ss, l0, nb, ksks, bsks);
       }
       HX_CHECK(hipStreamSynchronize(st));
       for (auto *d : tmp) HX_CHECK(hipFree(d));
     }
   }
 
-  void release(hipStream_t st) {
-    drv.release(st);
-    prop.release(st);
+  void release(const CudaStreamsFFI &ss) {
+    drv.release(ss);
+    prop.release(ss);
     if (d_pool) HX_CHECK(hipFree(d_pool));
     if (d_pack) HX_CHECK(hipFree(d_pack));
     if (d_sum) HX_CHECK(hipFree(d_sum));
@@ -690,7 +827,7 @@ uint64_t scratch_cuda_apply_univariate_lut_64_async(CudaStreamsFFI streams, int8
   const size_t lw = (size_t)(p.k + 1) * p.N;
   std::vector<std::vector<uint64_t>> luts(1);
   luts[0].assign((const uint64_t *)input_lut, (const uint64_t *)input_lut + lw);
-  m->drv.init(S0(streams), G0(streams), p, std::max<uint32_t>(1, input_lwe_ciphertext_count), luts);
+  m->drv.init(streams, p, std::max<uint32_t>(1, input_lwe_ciphertext_count), luts);
   m->degree = lut_degree;
   radix_alloc((void **)&m->d_lut_idx, std::max<uint32_t>(1, input_lwe_ciphertext_count) * sizeof(uint64_t));
   if (!t_dry)
@@ -715,8 +852,8 @@ void cuda_apply_univariate_lut_64_async(CudaStreamsFFI streams, CudaRadixCiphert
   HX_PANIC_IF_FALSE(n <= m->drv.cap && n <= output_radix_lwe->num_radix_blocks,
                     "num radix blocks on which lut is applied should be smaller or equal to the number of lut radix "
                     "blocks");
-  m->drv.round(S0(streams), (uint64_t *)output_radix_lwe->ptr, nullptr, (const uint64_t *)input_radix_lwe->ptr,
-               nullptr, m->d_lut_idx, n, ksks[0], bsks[0]);
+  m->drv.round(streams, (uint64_t *)output_radix_lwe->ptr, nullptr, (const uint64_t *)input_radix_lwe->ptr, nullptr,
+               m->d_lut_idx, n, ksks, bsks);
   if (output_radix_lwe->degrees)
     for (uint32_t i = 0; i < n; ++i) output_radix_lwe->degrees[i] = m->degree;
   if (output_radix_lwe->noise_levels)
@@ -726,7 +863,7 @@ void cuda_apply_univariate_lut_64_async(CudaStreamsFFI streams, CudaRadixCiphert
 void cleanup_cuda_apply_univariate_lut_64(CudaStreamsFFI streams, int8_t **mem_ptr_void) {
   auto *m = reinterpret_cast<ApplyLutMem *>(*mem_ptr_void);
   HX_PANIC_IF_FALSE(m && m->magic == ApplyLutMem::kMagic, "cleanup apply_univariate_lut: foreign scratch pointer");
-  m->drv.release(S0(streams));
+  m->drv.release(streams);
   if (m->d_lut_idx) HX_CHECK(hipFree(m->d_lut_idx));
   m->magic = 0;
   delete m;
@@ -756,6 +893,11 @@ void cuda_add_lwe_ciphertext_vector_inplace_64(void *stream, uint32_t gpu_index,
 // of integers up to the capacity given through hip_integer_scratch_batch (default 1).
 static uint32_t g_scratch_batch = 1;
 void hip_integer_scratch_batch(uint32_t num_integers) { g_scratch_batch = num_integers ? num_integers : 1; }
+// blocks per GPU from which a KS -> PBS round spreads over one more GPU of the stream set (default 512; the
+// reference's THRESHOLD_MULTI_GPU_* constants, helper_multi_gpu.cu:12-48); tests lower it
+void hip_integer_set_multi_gpu_threshold(uint32_t blocks_per_gpu) {
+  radix::g_multi_gpu_min_blocks = blocks_per_gpu ? blocks_per_gpu : 1;
+}
 
 uint64_t scratch_cuda_propagate_single_carry_64_inplace_async(CudaStreamsFFI streams, int8_t **mem_ptr,
                                                               CudaLweBootstrapKeyParamsFFI bsk_params,
@@ -770,7 +912,7 @@ uint64_t scratch_cuda_propagate_single_carry_64_inplace_async(CudaStreamsFFI str
   t_dry = !allocate_gpu_memory;
   t_bytes = 0;
   auto *m = new PropagateMem();
-  m->init(S0(streams), G0(streams), p, num_blocks, g_scratch_batch);
+  m->init(streams, p, num_blocks, g_scratch_batch);
   m->size_only = t_dry;
   t_dry = false;
   *mem_ptr = reinterpret_cast<int8_t *>(m);
@@ -812,7 +954,7 @@ void cuda_propagate_single_carry_64_inplace_async(CudaStreamsFFI streams, CudaRa
                       "propagate_single_carry: FLAG_CARRY needs one output carry block per integer");
     cout = (uint64_t *)carry_out->ptr;
   }
-  m->run(S0(streams), (uint64_t *)lwe_array->ptr, cts, ksks[0], bsks[0], cin, cout);
+  m->run(streams, (uint64_t *)lwe_array->ptr, cts, ksks, bsks, cin, cout);
   if (cout)
     for (uint32_t i = 0; i < cts; ++i) {
       if (carry_out->degrees) carry_out->degrees[i] = 1;
@@ -838,7 +980,7 @@ void cuda_add_and_propagate_single_carry_64_inplace_async(CudaStreamsFFI streams
 void cleanup_cuda_propagate_single_carry_64_inplace(CudaStreamsFFI streams, int8_t **mem_ptr_void) {
   auto *m = reinterpret_cast<PropagateMem *>(*mem_ptr_void);
   HX_PANIC_IF_FALSE(m && m->magic == PropagateMem::kMagic, "cleanup propagate_single_carry: foreign scratch pointer");
-  m->release(S0(streams));
+  m->release(streams);
   delete m;
   *mem_ptr_void = nullptr;
 }
@@ -859,7 +1001,7 @@ uint64_t scratch_cuda_integer_mult_inplace_64_async(CudaStreamsFFI streams, int8
   t_dry = !allocate_gpu_memory;
   t_bytes = 0;
   auto *m = new MulMem();
-  m->init(S0(streams), G0(streams), p, num_blocks, g_scratch_batch);
+  m->init(streams, p, num_blocks, g_scratch_batch);
   m->size_only = t_dry;
   t_dry = false;
   *mem_ptr = reinterpret_cast<int8_t *>(m);
@@ -878,7 +1020,7 @@ void cuda_integer_mult_inplace_64_async(CudaStreamsFFI streams, CudaRadixCiphert
   const uint32_t cts = batch_of(radix_lwe_inout, m->blocks, "integer_mult");
   HX_PANIC_IF_FALSE(radix_lwe_right && radix_lwe_right->num_radix_blocks == radix_lwe_inout->num_radix_blocks,
                     "integer_mult: operands must have the same shape");
-  m->run(S0(streams), (uint64_t *)radix_lwe_inout->ptr, (const uint64_t *)radix_lwe_right->ptr, cts, ksks[0], bsks[0]);
+  m->run(streams, (uint64_t *)radix_lwe_inout->ptr, (const uint64_t *)radix_lwe_right->ptr, cts, ksks, bsks);
   for (uint32_t i = 0; i < radix_lwe_inout->num_radix_blocks; ++i) {
     if (radix_lwe_inout->degrees) radix_lwe_inout->degrees[i] = m->drv.p.msg - 1;
     if (radix_lwe_inout->noise_levels) radix_lwe_inout->noise_levels[i] = 1;
@@ -888,7 +1030,7 @@ void cuda_integer_mult_inplace_64_async(CudaStreamsFFI streams, CudaRadixCiphert
 void cleanup_cuda_integer_mult_inplace_64(CudaStreamsFFI streams, int8_t **mem_ptr_void) {
   auto *m = reinterpret_cast<MulMem *>(*mem_ptr_void);
   HX_PANIC_IF_FALSE(m && m->magic == MulMem::kMagic, "cleanup integer_mult: foreign scratch pointer");
-  m->release(S0(streams));
+  m->release(streams);
   delete m;
   *mem_ptr_void = nullptr;
 }

@@ -34,18 +34,24 @@ class CudaServerKey:
     # ---- FFI views
     def _bsk_params(self):
         b = self.bootstrapping_key
+        g = getattr(b, "grouping_factor", 0)   # a CudaLweMultiBitBootstrapKey selects the multi-bit PBS
         return ffi.CudaLweBootstrapKeyParamsFFI(b.input_lwe_dimension, b.glwe_dimension, b.polynomial_size,
                                                 b.decomp_base_log, b.decomp_level_count, b.output_lwe_dimension,
-                                                PBS_TYPE_CLASSICAL, 0)
+                                                PBS_TYPE_MULTI_BIT if g else PBS_TYPE_CLASSICAL, g)
 
     def _ksk_params(self):
         k = self.key_switching_key
         return ffi.CudaLweKeyswitchKeyParamsFFI(k.input_key_lwe_dimension, k.output_key_lwe_dimension,
                                                 k.decomp_base_log, k.decomp_level_count)
 
-    def _key_ptrs(self):
-        ksks = (C.c_void_p * 1)(self.key_switching_key.d_vec.ptr)
-        bsks = (C.c_void_p * 1)(self.bootstrapping_key.d_vec.ptr)
+    def _key_ptrs(self, streams=None):
+        """One key replica per stream of the set (gpu/ffi.rs passes `ksks` / `bsks` arrays of per-GPU pointers:
+        integer/gpu/mod.rs); the keys must have been converted with a stream set at least as large."""
+        n = len(streams) if streams is not None else 1
+        kv, bv = self.key_switching_key.d_vecs, self.bootstrapping_key.d_vecs
+        assert len(kv) >= n and len(bv) >= n, "server key has fewer GPU replicas than the stream set has streams"
+        ksks = (C.c_void_p * n)(*[v.ptr for v in kv[:n]])
+        bsks = (C.c_void_p * n)(*[v.ptr for v in bv[:n]])
         return ksks, bsks
 
     @staticmethod
@@ -55,13 +61,13 @@ class CudaServerKey:
         return ffi.CudaStreamsFFI(ptrs, idx, len(streams)), (ptrs, idx)
 
     def _noise_reduction(self):
-        return 1 if self.bootstrapping_key.ms_noise_reduction else 0
+        return 1 if getattr(self.bootstrapping_key, "ms_noise_reduction", False) else 0
 
     # ---- operations
     def apply_lookup_table(self, ct, lut, streams, degree=None):
         """Every block of every integer goes through KS -> PBS with `lut` (a (k+1)*N accumulator)."""
         s, keep = self._streams(streams)
-        ksks, bsks = self._key_ptrs()
+        ksks, bsks = self._key_ptrs(streams)
         lut = np.ascontiguousarray(lut, dtype=U64)
         mem = C.c_void_p()
         n = ct.total_blocks
@@ -95,7 +101,7 @@ class CudaServerKey:
         block 0 when given; with want_carry_out (OutputFlag::Carry) the carry leaving the last block is
         returned as a one-block-per-integer ciphertext."""
         s, keep = self._streams(streams)
-        ksks, bsks = self._key_ptrs()
+        ksks, bsks = self._key_ptrs(streams)
         mem = C.c_void_p()
         flag = OUTPUT_FLAG_CARRY if want_carry_out else OUTPUT_FLAG_NONE
         cin, cout = self._carry_blocks(ct, carry_in, streams), self._carry_blocks(ct, None, streams)
@@ -112,7 +118,7 @@ class CudaServerKey:
     def add_assign(self, lhs, rhs, streams, carry_in=None, want_carry_out=False):
         """lhs += rhs (+ carry_in) on clean (carry-free) operands: block additions, then one carry propagation."""
         s, keep = self._streams(streams)
-        ksks, bsks = self._key_ptrs()
+        ksks, bsks = self._key_ptrs(streams)
         mem = C.c_void_p()
         flag = OUTPUT_FLAG_CARRY if want_carry_out else OUTPUT_FLAG_NONE
         cin, cout = self._carry_blocks(lhs, carry_in, streams), self._carry_blocks(lhs, None, streams)
@@ -129,7 +135,7 @@ class CudaServerKey:
     def mul_assign(self, lhs, rhs, streams, return_pbs_count=False):
         """lhs *= rhs (mod 2^bits) on clean operands: schoolbook block products, column sums, propagation."""
         s, keep = self._streams(streams)
-        ksks, bsks = self._key_ptrs()
+        ksks, bsks = self._key_ptrs(streams)
         mem = C.c_void_p()
         _lib().hip_integer_scratch_batch(lhs.num_integers)
         _lib().scratch_cuda_integer_mult_inplace_64_async(
