@@ -91,6 +91,18 @@ void cuda_programmable_bootstrap_64_async(
 
 void cleanup_cuda_programmable_bootstrap_64(void *stream, uint32_t gpu_index, int8_t **pbs_buffer);
 
+/* extension: the shortint atomic pattern KS -> PBS (tfhe/src/shortint/atomic_pattern/standard.rs:162-199) in ONE
+ * call on a scratch made by scratch_cuda_programmable_bootstrap_64_async: lwe_array_in holds ciphertexts under the
+ * BIG key (dimension glwe_dimension * polynomial_size), ksk the big -> small keyswitch key; the keyswitched list
+ * lives in the scratch.  Two launches on `stream`, no allocation, no host synchronisation. */
+void hip_keyswitch_programmable_bootstrap_64_async(
+    void *stream, uint32_t gpu_index, void *lwe_array_out, void const *lwe_output_indexes,
+    void const *lut_vector, void const *lut_vector_indexes, void const *lwe_array_in,
+    void const *lwe_input_indexes, void const *ksk, void const *bootstrapping_key, int8_t *buffer,
+    uint32_t lwe_dimension, uint32_t glwe_dimension, uint32_t polynomial_size, uint32_t ks_base_log,
+    uint32_t ks_level, uint32_t base_log, uint32_t level_count, uint32_t num_samples,
+    uint32_t num_many_lut, uint32_t lut_stride);
+
 /* ------------------------------------------------------------------ multi-bit PBS
  * backends/tfhe-cuda-backend/cuda/include/pbs/programmable_bootstrap_multibit.h:9-40
  * called from tfhe/src/core_crypto/gpu/ffi.rs:208-309,789-835 */

@@ -312,6 +312,17 @@ def test_ks_then_pbs_pipeline(kind):
     ref_small = orc.keyswitch_batch(cts, c.keys.ksk, p.k * p.N, p.n, p.ks_base_log, p.ks_level)
     assert np.array_equal(out, oracle_pbs(p, c.keys, "fft64", ref_small, lut))
     assert [decrypt_big(p, c.keys, o) for o in out] == [f(m) for m in msgs]
+    # the same pipeline as one call of the backend, reading a permuted subset of the big-key list
+    st = c.streams
+    sel = [7, 0, 3, 5, 2]
+    d_big = gpu.CudaLweCiphertextList.from_lwe_ciphertext_list(cts, st)
+    view = gpu.CudaLweCiphertextList(d_big.d_vec, len(sel), p.k * p.N)
+    d_out = gpu.CudaLweCiphertextList.new(p.k * p.N, len(sel), st)
+    d_lut = gpu.CudaGlweCiphertextList.from_glwe_ciphertext_list(lut, p.k, p.N, st)
+    mk = lambda a: gpu.CudaVec.from_cpu_async(np.asarray(a, dtype=np.uint64), st)
+    gpu.cuda_keyswitch_programmable_bootstrap_lwe_ciphertext(view, d_out, d_lut, mk(np.zeros(len(sel))),
+                                                             mk(np.arange(len(sel))), mk(sel), c.ksk, c.bsk, st)
+    assert np.array_equal(d_out.to_lwe_ciphertext_list(st), out[sel])
 
 
 @pytest.mark.parametrize("kind", BACKENDS)
@@ -474,6 +485,49 @@ def test_full_size_param_message_2_carry_2_bit_exact():
     outn = cn.pbs(cts[:8], lut)
     assert np.array_equal(outn, oracle_pbs(p, keys, "ntt64", cts[:8], lut))
     assert [decrypt_big(p, keys, o) for o in outn] == [f(m) for m in msgs[:8]]
+
+
+def reference_fft_noise_variance(n, k, N, base_log, level, mantissa=53.0, log2_q=64.0):
+    """FFT term of pbs_variance_132_bits_security_gaussian_fft_mul_impl
+    (tfhe/src/core_crypto/commons/noise_formulas/lwe_programmable_bootstrap.rs:46-58), in torus^2."""
+    import math
+    loss = max(0.0, log2_q - mantissa)
+    return n * 0.00705 * 2.0 ** (2 * loss + 2 * base_log - 2 * log2_q) * level ** 1.01827 * k ** 1.22003 * \
+        N ** 2.22003 * (k + 1) ** 1.01827
+
+
+@pytest.mark.gpu
+def test_f64_engine_noise_matches_the_reference_fft_noise_model():
+    """the f64 engine differs from exact arithmetic only by floating-point error, whose
+    variance the reference models (noise_formulas/lwe_programmable_bootstrap.rs:46-58, the `fft_mul` term).
+    PARAM_MESSAGE_2_CARRY_2 at full size: the same 192 ciphertexts through the f64 throughput kernel and through the
+    exact-integer engine (which reproduces the reference's Karatsuba golden vectors), 8 coefficients extracted per
+    PBS (many-LUT); the empirical std of the phase difference must not exceed 2x the model's std (2^48 in u64
+    units), and a std far BELOW the model would mean the comparison is broken."""
+    from .common import C1
+    p = C1
+    keys = make_keys(p, with_ksk=False)
+    B, M = 192, 8
+    msgs = [m % 16 for m in range(B)]
+    cts = encrypt_small(p, keys, msgs, seed=81)
+    lut = orc.generate_lut(p.k, p.N, p.plaintext_modulus, p.delta, lambda x: (7 * x + 3) % 16)
+    stride = p.N // (2 * M)
+    outs = {}
+    for engine in ("fft64", "exact64"):
+        c = Ctx("hip", p, keys, engine)
+        outs[engine] = c.pbs(cts, lut, num_many_lut=M, lut_stride=stride)
+    sk = keys.glwe_sk
+    diff = np.array([(int(orc.lwe_decrypt(a, sk)) - int(orc.lwe_decrypt(b, sk))) & M64
+                     for a, b in zip(outs["fft64"], outs["exact64"])], dtype=object)
+    d = np.array([int(x) - (1 << 64) if x >= (1 << 63) else int(x) for x in diff], dtype=np.float64)
+    std_model = float(np.sqrt(reference_fft_noise_variance(p.n, p.k, p.N, p.pbs_base_log, p.pbs_level))) * 2.0 ** 64
+    std_meas = float(d.std())
+    print(f"f64 engine phase error: std 2^{np.log2(std_meas):.2f}, reference model 2^{np.log2(std_model):.2f}, "
+          f"max 2^{np.log2(np.abs(d).max()):.2f} over {d.size} samples")
+    assert abs(d.mean()) < 0.2 * std_meas + 2.0 ** 44          # unbiased
+    assert std_meas <= 2.0 * std_model
+    assert std_meas >= std_model / 16.0
+    assert np.abs(d).max() < 2.0 ** 52
 
 
 @pytest.mark.gpu

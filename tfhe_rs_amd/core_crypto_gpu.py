@@ -274,6 +274,32 @@ def cuda_programmable_bootstrap_lwe_ciphertext(input, output, accumulator, lut_i
     lib.cleanup_cuda_programmable_bootstrap_64(s, g, C.byref(buf))
 
 
+def cuda_keyswitch_programmable_bootstrap_lwe_ciphertext(input, output, accumulator, lut_indexes, output_indexes,
+                                                         input_indexes, ksk, bsk, streams, num_many_lut=1,
+                                                         lut_stride=0):
+    """The shortint atomic pattern (shortint/atomic_pattern/standard.rs:162-199: keyswitch then bootstrap) as ONE
+    call of the backend (extension hip_keyswitch_programmable_bootstrap_64_async): `input` holds ciphertexts under
+    the big key, the keyswitched list lives in the PBS scratch."""
+    assert ksk.input_key_lwe_dimension == input.lwe_dimension, "Mismatched input LweDimension"
+    assert ksk.output_key_lwe_dimension == bsk.input_lwe_dimension, "keyswitch and bootstrap keys do not chain"
+    assert output.lwe_dimension == bsk.output_lwe_dimension, "Mismatched output LweDimension"
+    assert bsk.engine == "fft64" and ksk.scalar_bits == 64
+    num_samples = input.lwe_ciphertext_count
+    assert output.lwe_ciphertext_count >= num_samples * num_many_lut
+    lib = _lib()
+    buf = C.c_void_p()
+    s, g = streams.ptr[0], streams.gpu_indexes[0]
+    lib.scratch_cuda_programmable_bootstrap_64_async(
+        s, g, C.byref(buf), bsk.input_lwe_dimension, bsk.glwe_dimension, bsk.polynomial_size,
+        bsk.decomp_level_count, num_samples, True, 1 if bsk.ms_noise_reduction else 0)
+    lib.hip_keyswitch_programmable_bootstrap_64_async(
+        s, g, output.d_vec.ptr, output_indexes.ptr, accumulator.d_vec.ptr, lut_indexes.ptr, input.d_vec.ptr,
+        input_indexes.ptr, ksk.d_vec.ptr, bsk.d_vec.ptr, buf, bsk.input_lwe_dimension, bsk.glwe_dimension,
+        bsk.polynomial_size, ksk.decomp_base_log, ksk.decomp_level_count, bsk.decomp_base_log,
+        bsk.decomp_level_count, num_samples, num_many_lut, lut_stride)
+    lib.cleanup_cuda_programmable_bootstrap_64(s, g, C.byref(buf))
+
+
 def cuda_multi_bit_programmable_bootstrap_lwe_ciphertext(input, output, accumulator, lut_indexes, output_indexes,
                                                          input_indexes, multi_bit_bsk, streams, num_many_lut=1,
                                                          lut_stride=0):

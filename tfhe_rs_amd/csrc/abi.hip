@@ -5,6 +5,7 @@
 
 #include <atomic>
 #include <cstring>
+#include <vector>
 
 using namespace tfhe_hip;
 
@@ -30,6 +31,8 @@ struct PbsBuffer {
   FftTables fft;
   NttTables ntt;
   uint64_t *acc_scratch = nullptr;
+  uint64_t *ks_out = nullptr;  // hip_keyswitch_programmable_bootstrap_64_async: the keyswitched LWEs (small key)
+  uint64_t *trivial = nullptr; // 0, 1, ..., max_samples - 1 (indexes of that list)
 };
 struct MultiBitBuffer {
   uint32_t magic;
@@ -249,8 +252,18 @@ uint64_t scratch_cuda_programmable_bootstrap_64_async(void *stream, uint32_t gpu
                                                  : (uint64_t)input_lwe_ciphertext_count * (glwe_dimension + 1) *
                                                        polynomial_size * sizeof(uint64_t);
   if (allocate_gpu_memory && bytes) HX_CHECK(hipMalloc((void **)&b->acc_scratch, bytes));
+  // room for the keyswitch output of the one-call KS -> PBS entry point (the atomic pattern of the shortint layer)
+  const uint64_t ks_bytes = (uint64_t)input_lwe_ciphertext_count * (lwe_dimension + 1) * sizeof(uint64_t);
+  const uint64_t idx_bytes = (uint64_t)input_lwe_ciphertext_count * sizeof(uint64_t);
+  if (allocate_gpu_memory && ks_bytes) {
+    HX_CHECK(hipMalloc((void **)&b->ks_out, ks_bytes));
+    HX_CHECK(hipMalloc((void **)&b->trivial, idx_bytes));
+    std::vector<uint64_t> triv(input_lwe_ciphertext_count);
+    for (uint32_t i = 0; i < input_lwe_ciphertext_count; ++i) triv[i] = i;
+    HX_CHECK(hipMemcpy(b->trivial, triv.data(), idx_bytes, hipMemcpyHostToDevice));
+  }
   *buffer = reinterpret_cast<int8_t *>(b);
-  return bytes;
+  return bytes + ks_bytes + idx_bytes;
 }
 
 static PbsBuffer *checked_buffer(int8_t *buffer, uint32_t lwe_dimension, uint32_t glwe_dimension,
@@ -307,6 +320,33 @@ void cuda_programmable_bootstrap_64_async(void *stream, uint32_t gpu_index, void
   }
 }
 
+// The shortint atomic pattern (tfhe/src/shortint/atomic_pattern/standard.rs:162-199; GPU: integer.cuh:869-990) in
+// one call: keyswitch big -> small key into the scratch, then the PBS on the result — two launches on `stream`,
+// nothing allocated, no host synchronisation, the key layout of the matrix-core keyswitch served from its cache.
+// lwe_array_in holds ciphertexts under the BIG key (dimension k*N); the PBS reads the keyswitched list trivially.
+void hip_keyswitch_programmable_bootstrap_64_async(void *stream, uint32_t gpu_index, void *lwe_array_out,
+                                                   void const *lwe_output_indexes, void const *lut_vector,
+                                                   void const *lut_vector_indexes, void const *lwe_array_in,
+                                                   void const *lwe_input_indexes, void const *ksk,
+                                                   void const *bootstrapping_key, int8_t *buffer,
+                                                   uint32_t lwe_dimension, uint32_t glwe_dimension,
+                                                   uint32_t polynomial_size, uint32_t ks_base_log, uint32_t ks_level,
+                                                   uint32_t base_log, uint32_t level_count, uint32_t num_samples,
+                                                   uint32_t num_many_lut, uint32_t lut_stride) {
+  set_device(gpu_index);
+  PbsBuffer *b = checked_buffer(buffer, lwe_dimension, glwe_dimension, polynomial_size, level_count, num_samples);
+  HX_PANIC_IF_FALSE(b->ks_out != nullptr || num_samples == 0, "PBS buffer has no keyswitch scratch");
+  if (num_samples == 0) return;
+  // the keyswitch writes block s at position s of the scratch list; the PBS reads that list trivially
+  launch_keyswitch(S(stream), b->ks_out, b->trivial, (const uint64_t *)lwe_array_in,
+                   (const uint64_t *)lwe_input_indexes, (const uint64_t *)ksk, glwe_dimension * polynomial_size,
+                   lwe_dimension, ks_base_log, ks_level, num_samples);
+  cuda_programmable_bootstrap_64_async(stream, gpu_index, lwe_array_out, lwe_output_indexes, lut_vector,
+                                       lut_vector_indexes, b->ks_out, b->trivial, bootstrapping_key,
+                                       buffer, lwe_dimension, glwe_dimension, polynomial_size, base_log, level_count,
+                                       num_samples, num_many_lut, lut_stride);
+}
+
 void hip_programmable_bootstrap_ntt64_async(void *stream, uint32_t gpu_index, void *lwe_array_out,
                                             void const *lwe_output_indexes, void const *lut_vector,
                                             void const *lut_vector_indexes, void const *lwe_array_in,
@@ -361,6 +401,8 @@ void cleanup_cuda_programmable_bootstrap_64(void *stream, uint32_t gpu_index, in
   HX_PANIC_IF_FALSE(b != nullptr && b->magic == kPbsMagic, "cleanup of a foreign PBS buffer");
   HX_CHECK(hipStreamSynchronize(S(stream)));  // cleanup_* synchronises (pbs_utilities.h:261-271)
   if (b->acc_scratch) HX_CHECK(hipFree(b->acc_scratch));
+  if (b->ks_out) HX_CHECK(hipFree(b->ks_out));
+  if (b->trivial) HX_CHECK(hipFree(b->trivial));
   b->magic = 0;
   delete b;
   *pbs_buffer = nullptr;

@@ -64,6 +64,9 @@ SIGNATURES = {
     "cuda_programmable_bootstrap_64_async":
         (None, [_v, _u32, _v, _v, _v, _v, _v, _v, _v, _v, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _u32]),
     "cleanup_cuda_programmable_bootstrap_64": (None, [_v, _u32, _i8pp]),
+    "hip_keyswitch_programmable_bootstrap_64_async":
+        (None, [_v, _u32, _v, _v, _v, _v, _v, _v, _v, _v, _v, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _u32,
+                _u32]),
     # multi-bit PBS
     "has_support_to_cuda_programmable_bootstrap_cg_multi_bit": (_b, [_u32, _u32, _u32, _u32, _u32]),
     "cuda_convert_lwe_multi_bit_programmable_bootstrap_key_64_async":
