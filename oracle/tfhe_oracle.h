@@ -151,6 +151,13 @@ void orc_pbs_multi_bit_fft_batch(uint64_t *lwe_out, const uint64_t *lwe_in, cons
                                  const double *bsk_f, uint32_t n, uint32_t k, uint32_t N, uint32_t base_log,
                                  uint32_t level, uint32_t grouping_factor, uint32_t count, uint32_t threads);
 
+/* ---- the reference's own f64 transform in its golden-vector configuration (tfhe-fft radix-4 DIF plan,
+ *      x86 conversion paths): tfhe_oracle_dif4.c ---- */
+void orc_dif4_fft(double *buf /* N/2 complex, in place */, uint32_t N, int fwd);
+void orc_dif4_convert_bsk(double *bsk_f, const uint64_t *bsk_std, uint32_t n, uint32_t k, uint32_t N, uint32_t level);
+void orc_dif4_blind_rotate(uint64_t *acc, const uint64_t *lut, const uint64_t *msed, const double *bsk_f, uint32_t n,
+                           uint32_t k, uint32_t N, uint32_t base_log, uint32_t level);
+
 /* ---- batches (OpenMP over independent LWEs, like the reference's rayon bench,
  *      tfhe-benchmark/benches/core_crypto/pbs_bench.rs:176-196) ---- */
 /* engine: 0 = exact, 1 = ntt_bnf, 2 = fft ; bsk in the engine's own format */

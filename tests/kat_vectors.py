@@ -299,11 +299,18 @@ def generate_vectors(P):
     out["lwe_ms"] = ser_lwe_ciphertext(msed << np.uint64(64 - log_mod), native=False, modulus=1 << log_mod)
 
     p = 1 << P["msg_bits"]
+    # the f64 vectors: the reference's own transform in the configuration the vectors were made with
+    # (tfhe-fft radix-4 DIF plan forced by `experimental-force_fft_algo_dif4`, x86 conversion paths),
+    # restated in oracle/tfhe_oracle_dif4.c
+    bsk_f = orc.dif4_convert_bsk(bsk, n, k, N, P["pbs_level"])                              # ORACLE
     for name, f in (("id", lambda x: x), ("spec", lambda x: (2 * x) % p)):
         lut = orc.generate_lut(k, N, p, 1 << log_delta, f)                                  # ORACLE
         acc = orc.blind_rotate_exact(lut, msed, bsk, n, k, N, P["pbs_base_log"], P["pbs_level"])  # ORACLE
         out[f"glwe_after_{name}_br_karatsuba"] = ser_glwe_ciphertext(acc, N)
         out[f"lwe_after_{name}_pbs_karatsuba"] = ser_lwe_ciphertext(orc.sample_extract(acc, k, N, 0))  # ORACLE
+        acc_f = orc.dif4_blind_rotate(lut, msed, bsk_f, n, k, N, P["pbs_base_log"], P["pbs_level"])  # ORACLE
+        out[f"glwe_after_{name}_br"] = ser_glwe_ciphertext(acc_f, N)
+        out[f"lwe_after_{name}_pbs"] = ser_lwe_ciphertext(orc.sample_extract(acc_f, k, N, 0))      # ORACLE
     return out, dict(glwe_sk=glwe_sk, small_sk=small_sk, lwe_a=lwe_a, ksk=ksk, bsk=bsk, lwe_ks=lwe_ks, msed=msed)
 
 

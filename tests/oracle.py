@@ -340,6 +340,28 @@ def blind_rotate_exact(lut, msed, bsk_std, n, k, N, base_log, level):
     return acc
 
 
+def dif4_convert_bsk(bsk_std, n, k, N, level):
+    """the reference's own key conversion in its golden-vector configuration (tfhe_oracle_dif4.c)"""
+    bsk_std = _u64(bsk_std)
+    out = np.zeros(bsk_std.size, dtype=np.float64)
+    lib().orc_dif4_convert_bsk(_p(out), _p(bsk_std), u32(n), u32(k), u32(N), u32(level))
+    return out
+
+
+def dif4_blind_rotate(lut, msed, bsk_f, n, k, N, base_log, level):
+    lut, msed = _u64(lut), _u64(msed)
+    acc = np.zeros((k + 1) * N, dtype=np.uint64)
+    lib().orc_dif4_blind_rotate(_p(acc), _p(lut), _p(msed), _p(bsk_f), u32(n), u32(k), u32(N), u32(base_log),
+                                u32(level))
+    return acc
+
+
+def dif4_fft(buf, N, fwd=True):
+    buf = np.ascontiguousarray(buf, dtype=np.float64).copy()
+    lib().orc_dif4_fft(_p(buf), u32(N), C.c_int(1 if fwd else 0))
+    return buf
+
+
 def csprng_bytes(seed, offset, n):
     """Bytes [offset, offset+n) of tfhe-csprng's AES-CTR byte table for Seed(seed)."""
     key = np.frombuffer(int(seed).to_bytes(16, "little"), dtype=np.uint8).copy()

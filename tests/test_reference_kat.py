@@ -1,8 +1,10 @@
-"""Pins the oracle's integer path to bytes produced by the reference itself: regenerates the
-reference's golden test vectors (apps/test-vectors; BOTH parameter sets: toy n=10/N=256 without
-noise, and valid_params_128 n=833/N=2048/PBS 23x1/KS 3x5 with Gaussian noise: KS -> MS -> blind
-rotation with exact products -> sample extract, identity and 2x LUTs) and compares SHA-256 digests
-with apps/test-vectors/checksums.sha256 (transcribed into tests/golden/reference_kats.json).
+"""Pins the oracle to bytes produced by the reference itself: regenerates ALL 36 of the reference's golden
+test vectors (apps/test-vectors; BOTH parameter sets: toy n=10/N=256 without noise, and valid_params_128
+n=833/N=2048/PBS 23x1/KS 3x5 with Gaussian noise: KS -> MS -> blind rotation -> sample extract, identity and
+2x LUTs; the blind rotation once with exact integer products (`*_karatsuba`) and once with the reference's f64
+transform in the configuration the vectors were made with — tfhe-fft's radix-4 DIF plan, x86 conversion
+paths, oracle/tfhe_oracle_dif4.c) and compares SHA-256 digests with apps/test-vectors/checksums.sha256
+(transcribed into tests/golden/reference_kats.json).
 The key material comes from a restatement of tfhe-csprng (tests/kat_vectors.py); everything after
 it — keyswitch, modulus switch, blind rotation, sample extraction — is the oracle under test."""
 import json
@@ -21,6 +23,9 @@ PARAMS = {"toy": kv.TOY, "valid": kv.VALID}
 INTEGER_FILES = ["large_lwe_secret_key", "small_lwe_secret_key", "lwe_a", "lwe_b", "lwe_sum", "lwe_prod", "ksk",
                  "lwe_ks", "bsk", "lwe_ms", "glwe_after_id_br_karatsuba", "lwe_after_id_pbs_karatsuba",
                  "glwe_after_spec_br_karatsuba", "lwe_after_spec_pbs_karatsuba"]
+# the f64 vectors: twist factors, conversions, roundings, multiply-accumulate forms and blind-rotation order of the
+# reference's f64 engine, pinned to its bytes
+F64_FILES = ["glwe_after_id_br", "lwe_after_id_pbs", "glwe_after_spec_br", "lwe_after_spec_pbs"]
 
 
 _CACHE = {}
@@ -48,8 +53,13 @@ def test_c_and_python_csprng_agree():
     assert orc.csprng_bytes(kv.RAND_SEED, 37, 50).tobytes() == py[37:87]
 
 
+def test_every_reference_digest_is_covered():
+    for which in ("toy", "valid"):
+        assert sorted(INTEGER_FILES + F64_FILES) == sorted(SUMS[which]), "a golden vector is not regenerated"
+
+
 @pytest.mark.parametrize("which", ["toy", "valid"])
-@pytest.mark.parametrize("name", INTEGER_FILES)
+@pytest.mark.parametrize("name", INTEGER_FILES + F64_FILES)
 def test_regenerated_vector_matches_reference_sha256(which, name):
     out, _ = _vectors(which)
     assert kv.sha256_hex(out[name]) == SUMS[which][name], f"{which}/{name}.cbor differs from the reference's"
@@ -57,9 +67,9 @@ def test_regenerated_vector_matches_reference_sha256(which, name):
 
 @pytest.mark.parametrize("which", ["toy", "valid"])
 def test_f64_path_agrees_in_phase_with_the_pinned_exact_path(which):
-    """The reference's FFT vectors (glwe_after_*_br.cbor) depend on its runtime-planned FFT order and
-    cannot be reproduced bit-for-bit; our fixed-order f64 path must decrypt to the same
-    message and sit within 2^50 of the pinned exact result in phase."""
+    """The fixed-order f64 path the GPU implements differs from the reference's dif4 plan only in
+    the order of the butterflies: it must decrypt to the same message and sit within 2^50 in phase of the pinned
+    exact result AND of the pinned dif4 result (whose bytes equal the reference's, test above)."""
     _, m = _vectors(which)
     P = PARAMS[which]
     n, k, N = P["n"], P["k"], P["N"]
@@ -74,6 +84,11 @@ def test_f64_path_agrees_in_phase_with_the_pinned_exact_path(which):
         pf = int(orc.lwe_decrypt(out_f, m["glwe_sk"]))
         pe = int(orc.lwe_decrypt(out_e, m["glwe_sk"]))
         d = (pf - pe) % (1 << 64)
+        assert min(d, (1 << 64) - d) < (1 << 50)
+        acc_r = orc.dif4_blind_rotate(lut, m["msed"], orc.dif4_convert_bsk(m["bsk"], n, k, N, P["pbs_level"]), n, k, N,
+                                      P["pbs_base_log"], P["pbs_level"])
+        pr = int(orc.lwe_decrypt(orc.sample_extract(acc_r, k, N, 0), m["glwe_sk"]))
+        d = (pf - pr) % (1 << 64)
         assert min(d, (1 << 64) - d) < (1 << 50)
         assert ((pe + (1 << 58)) >> 59) % 32 == f(kv.MSG_A)
 
