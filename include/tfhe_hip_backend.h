@@ -230,6 +230,23 @@ void hip_programmable_bootstrap_exact64_async(
     uint32_t polynomial_size, uint32_t base_log, uint32_t level_count,
     uint32_t num_samples, uint32_t num_many_lut, uint32_t lut_stride);
 
+/* Reference-order f64 engine: the blind rotation with tfhe-fft's radix-4 DIF Stockham plan and the reference's x86
+ * conversion / multiply-accumulate forms, operation for operation (csrc/pbs_ref64.hip).  A verification engine:
+ * it reproduces the reference's f64 golden vectors (apps/test-vectors, lwe_after_{id,spec}_pbs.cbor, made with
+ * `experimental-force_fft_algo_dif4`) bit for bit on the MI355X.  glwe_dimension 1, polynomial_size <= 2048. */
+void hip_convert_lwe_programmable_bootstrap_key_ref64_async(
+    void *stream, uint32_t gpu_index, void *dest, void const *src,
+    uint32_t input_lwe_dim, uint32_t glwe_dim, uint32_t level_count,
+    uint32_t polynomial_size);
+void hip_programmable_bootstrap_ref64_async(
+    void *stream, uint32_t gpu_index, void *lwe_array_out,
+    void const *lwe_output_indexes, void const *lut_vector,
+    void const *lut_vector_indexes, void const *lwe_array_in,
+    void const *lwe_input_indexes, void const *bootstrapping_key,
+    int8_t *buffer, uint32_t lwe_dimension, uint32_t glwe_dimension,
+    uint32_t polynomial_size, uint32_t base_log, uint32_t level_count,
+    uint32_t num_samples, uint32_t num_many_lut, uint32_t lut_stride);
+
 /* ------------------------------------------------------------------ radix integers ("next" row N1)
  * backends/tfhe-cuda-backend/cuda/include/integer/integer.h:52-65,100-113 (FFI structs),
  * :127-148 (apply_univariate_lut), :173-187 (integer_mult_inplace), :383-413 (propagate_single_carry,
@@ -348,7 +365,7 @@ void hip_backend_set_keyswitch_kernel(uint32_t which);
 void hip_backend_set_ntt_kernel(uint32_t which);
 /* last launched PBS kernel, for tests: 1 generic f64, 2 wave f64, 3 generic ntt, 4 generic multi-bit,
  * 5 exact, 6 wave multi-bit, 7 block (latency), 8 block dual-stream, 9 wave f64 for N = 1024,
- * 10 multi-bit latency path */
+ * 10 multi-bit latency path, 11 reference-order f64 engine */
 uint32_t hip_backend_last_pbs_kernel(void);
 const char *hip_backend_version(void);
 

@@ -143,6 +143,14 @@ def test_backend_reproduces_reference_golden_vectors(kind, which):
         assert lib.hip_backend_last_pbs_kernel() == 5
         out = d_out.to_lwe_ciphertext_list(st)[0]
         assert kv.sha256_hex(kv.ser_lwe_ciphertext(out)) == SUMS[f"lwe_after_{name}_pbs_karatsuba"]
+        # the reference's f64 vector: same pipeline with the reference-order f64 engine (tfhe-fft's dif4 plan and
+        # the x86 conversion forms, operation for operation on the GPU) ==> lwe_after_*_pbs.cbor
+        b_ref = gpu.CudaLweBootstrapKey.from_lwe_bootstrap_key(m["bsk"], n, k, N, P["pbs_base_log"], P["pbs_level"],
+                                                               st, engine="ref64")
+        d_or = gpu.CudaLweCiphertextList.new(k * N, 1, st)
+        gpu.cuda_programmable_bootstrap_lwe_ciphertext(d_ks, d_or, d_lut, idx, idx, idx, b_ref, st)
+        assert lib.hip_backend_last_pbs_kernel() == 11
+        assert kv.sha256_hex(kv.ser_lwe_ciphertext(d_or.to_lwe_ciphertext_list(st)[0])) == SUMS[f"lwe_after_{name}_pbs"]
         # and the production engines land on the same message, within 2^50 in phase
         for engine in ("fft64", "ntt64"):
             b2 = gpu.CudaLweBootstrapKey.from_lwe_bootstrap_key(m["bsk"], n, k, N, P["pbs_base_log"],

@@ -154,7 +154,8 @@ class CudaGlweCiphertextList:
 class CudaLweBootstrapKey:
     """Bootstrap key converted once per GPU of `streams` (lwe_bootstrap_key.rs:57-104,
     gpu/ffi.rs:744-787).  engine 'fft64' is the reference GPU path; 'ntt64' the Goldilocks
-    extension, 'exact64' the O(N^2) exact-convolution verification engine."""
+    extension, 'exact64' the O(N^2) exact-convolution verification engine, 'ref64' the reference-order f64
+    verification engine (tfhe-fft's dif4 plan: reproduces the reference's f64 golden vectors)."""
 
     def __init__(self):
         self.d_vec = None
@@ -180,7 +181,8 @@ class CudaLweBootstrapKey:
             d = CudaVec(elems, streams, i, np.float64)
             conv = {"fft64": _lib().cuda_convert_lwe_programmable_bootstrap_key_64_async,
                     "ntt64": _lib().hip_convert_lwe_programmable_bootstrap_key_ntt64_async,
-                    "exact64": _lib().hip_convert_lwe_programmable_bootstrap_key_exact64_async}[engine]
+                    "exact64": _lib().hip_convert_lwe_programmable_bootstrap_key_exact64_async,
+                    "ref64": _lib().hip_convert_lwe_programmable_bootstrap_key_ref64_async}[engine]
             conv(streams.ptr[i], streams.gpu_indexes[i], d.ptr, h_bsk.ctypes.data_as(C.c_void_p),
                  self.input_lwe_dimension, glwe_dimension, decomp_level_count, polynomial_size)
             self.d_vecs.append(d)
@@ -267,7 +269,8 @@ def cuda_programmable_bootstrap_lwe_ciphertext(input, output, accumulator, lut_i
         bsk.decomp_level_count, num_samples, True, 1 if bsk.ms_noise_reduction else 0)
     launch = {"fft64": lib.cuda_programmable_bootstrap_64_async,
               "ntt64": lib.hip_programmable_bootstrap_ntt64_async,
-              "exact64": lib.hip_programmable_bootstrap_exact64_async}[bsk.engine]
+              "exact64": lib.hip_programmable_bootstrap_exact64_async,
+              "ref64": lib.hip_programmable_bootstrap_ref64_async}[bsk.engine]
     launch(s, g, output.d_vec.ptr, output_indexes.ptr, accumulator.d_vec.ptr, lut_indexes.ptr,
            input.d_vec.ptr, input_indexes.ptr, bsk.d_vec.ptr, buf, bsk.input_lwe_dimension, bsk.glwe_dimension,
            bsk.polynomial_size, bsk.decomp_base_log, bsk.decomp_level_count, num_samples, num_many_lut, lut_stride)

@@ -11,6 +11,10 @@ void launch_pbs_exact_generic(hipStream_t st, uint32_t N, uint32_t glwe_dim, con
 void launch_bsk_to_fourier(hipStream_t st, uint32_t N, uint32_t glwe_dim, const uint64_t *src_dev, void *dst, size_t polys, const FftTables &tb);
 void launch_bsk_to_ntt(hipStream_t st, uint32_t N, const uint64_t *src_dev, void *dst, size_t polys, const NttTables &tb);
 
+// reference-order f64 verification engine (tfhe-fft radix-4 DIF plan, x86 conversion forms) — pbs_ref64.hip
+void launch_pbs_ref64(hipStream_t st, uint32_t N, uint32_t glwe_dim, const PbsArgs &a, const RefTables &tb);
+void launch_bsk_to_ref64(hipStream_t st, uint32_t N, const uint64_t *src_dev, void *dst, size_t polys, const RefTables &tb);
+
 // throughput kernel for N=2048, k=1 (any l) — pbs_fft_wave.hip
 bool pbs_fft_wave_supported(uint32_t N, uint32_t glwe_dim, uint32_t level);
 void launch_pbs_fft_wave(hipStream_t st, const PbsArgs &a, const FftTables &tb);

@@ -18,6 +18,15 @@ struct FftTables {
   const double *mono;
 };
 
+// Tables of the reference-order f64 engine (pbs_ref64.hip): what tfhe-fft / tfhe build for a radix-4 DIF plan of
+// n = N/2 points — twist[i] = (cos, sin)(i*pi/(2n)) from the host libm like Twisties::new (fft/mod.rs:63-74);
+// w = [w_init | w] of init_wt(4, n) with tfhe-fft's sincospi64 (fft_simd.rs:239-321), w_inv its conjugate
+struct RefTables {
+  const double *twist;
+  const double *w;
+  const double *w_inv;
+};
+
 // Goldilocks tables: tw[m+g] = psi^bitrev(m+g), itw likewise for psi^-1; n_inv = N^-1 mod p
 struct NttTables {
   const uint64_t *tw;
@@ -28,6 +37,7 @@ struct NttTables {
 // Lazily built, cached per (device, N); `stream` orders the upload before first use.
 FftTables get_fft_tables(uint32_t gpu_index, hipStream_t stream, uint32_t N);
 NttTables get_ntt_tables(uint32_t gpu_index, hipStream_t stream, uint32_t N);
+RefTables get_ref_tables(uint32_t gpu_index, hipStream_t stream, uint32_t N);
 
 // host-side generators (also exported through the test ABI so the tables can be compared
 // with the oracle's independently computed ones)

@@ -100,6 +100,67 @@ void fill_monomial_table_host(uint32_t N, double *z) {
   }
 }
 
+// tfhe-fft/src/fft_simd.rs:239-295 (sincospi64, after https://stackoverflow.com/a/42792940): every operation as
+// there, fused where it says mul_add
+static void ref_sincospi64(double a, double *s_out, double *c_out) {
+  const double az = a * 0.0;
+  a = std::fabs(a) < 9007199254740992.0 ? a : az;
+  double r = std::round(a + a);
+  const int64_t i = (int64_t)r;
+  const double t = std::fma(-0.5, r, a);
+  double s = t * t;
+  r = -1.0369917389758117e-4;
+  r = std::fma(r, s, 1.9294935641298806e-3);
+  r = std::fma(r, s, -2.5806887942825395e-2);
+  r = std::fma(r, s, 2.3533063028328211e-1);
+  r = std::fma(r, s, -1.3352627688538006e+0);
+  r = std::fma(r, s, 4.0587121264167623e+0);
+  r = std::fma(r, s, -4.9348022005446790e+0);
+  double c = std::fma(r, s, 1.0000000000000000e+0);
+  r = 4.6151442520157035e-4;
+  r = std::fma(r, s, -7.3700183130883555e-3);
+  r = std::fma(r, s, 8.2145868949323936e-2);
+  r = std::fma(r, s, -5.9926452893214921e-1);
+  r = std::fma(r, s, 2.5501640398732688e+0);
+  r = std::fma(r, s, -5.1677127800499516e+0);
+  s = s * t;
+  r *= s;
+  s = std::fma(t, 3.14159265358979323846264338327950288, r);
+  if (i & 2) {
+    s = 0.0 - s;
+    c = 0.0 - c;
+  }
+  if (i & 1) {
+    const double tt = 0.0 - s;
+    s = c;
+    c = tt;
+  }
+  if (a == std::floor(a)) s = az;
+  *s_out = s;
+  *c_out = c;
+}
+void fill_ref_tables_host(uint32_t N, double *twist, double *w, double *w_inv) {
+  const uint32_t n = N / 2, nr = n / 4;
+  const double unit = 3.14159265358979323846264338327950288 / (2.0 * (double)n);  // fft/mod.rs:68
+  for (uint32_t i = 0; i < n; ++i) {
+    twist[2 * i] = std::cos((double)i * unit);
+    twist[2 * i + 1] = std::sin((double)i * unit);
+  }
+  for (uint32_t i = 0; i < 4 * n; ++i) w[i] = w_inv[i] = std::nan("");
+  const double theta = -2.0 / (double)n;
+  for (uint32_t q = 0; q < nr; ++q)
+    for (uint32_t k = 1; k < 4; ++k) {
+      double s, c;
+      ref_sincospi64(theta * (double)(k * q), &s, &c);
+      for (const uint32_t at : {q + k * nr, n + 4 * q + k}) {
+        w[2 * at] = c;
+        w[2 * at + 1] = s;
+        w_inv[2 * at] = c;
+        w_inv[2 * at + 1] = -s;
+      }
+    }
+}
+
 static uint64_t gl_pow_host(uint64_t a, uint64_t e) {
   uint64_t r = 1;
   while (e) {
@@ -142,10 +203,36 @@ struct NttEntry {
   uint64_t *tw, *itw;
   uint64_t n_inv;
 };
+struct RefEntry {
+  double *twist, *w, *w_inv;
+};
 std::mutex g_mu;
 std::map<std::pair<uint32_t, uint32_t>, FftEntry> g_fft;
 std::map<std::pair<uint32_t, uint32_t>, NttEntry> g_ntt;
+std::map<std::pair<uint32_t, uint32_t>, RefEntry> g_ref;
 }  // namespace
+
+RefTables get_ref_tables(uint32_t gpu_index, hipStream_t stream, uint32_t N) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  auto key = std::make_pair(gpu_index, N);
+  auto it = g_ref.find(key);
+  if (it == g_ref.end()) {
+    const size_t n = N / 2;
+    std::vector<double> twist(2 * n), w(4 * n), w_inv(4 * n);
+    fill_ref_tables_host(N, twist.data(), w.data(), w_inv.data());
+    RefEntry e;
+    HX_CHECK(hipSetDevice((int)gpu_index));
+    HX_CHECK(hipMalloc((void **)&e.twist, sizeof(double) * 2 * n));
+    HX_CHECK(hipMalloc((void **)&e.w, sizeof(double) * 4 * n));
+    HX_CHECK(hipMalloc((void **)&e.w_inv, sizeof(double) * 4 * n));
+    HX_CHECK(hipMemcpy(e.twist, twist.data(), sizeof(double) * 2 * n, hipMemcpyHostToDevice));
+    HX_CHECK(hipMemcpy(e.w, w.data(), sizeof(double) * 4 * n, hipMemcpyHostToDevice));
+    HX_CHECK(hipMemcpy(e.w_inv, w_inv.data(), sizeof(double) * 4 * n, hipMemcpyHostToDevice));
+    (void)stream;
+    it = g_ref.emplace(key, e).first;
+  }
+  return RefTables{it->second.twist, it->second.w, it->second.w_inv};
+}
 
 FftTables get_fft_tables(uint32_t gpu_index, hipStream_t stream, uint32_t N) {
   std::lock_guard<std::mutex> lk(g_mu);

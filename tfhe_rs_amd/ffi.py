@@ -95,6 +95,9 @@ SIGNATURES = {
     "hip_programmable_bootstrap_ntt64_async":
         (None, [_v, _u32, _v, _v, _v, _v, _v, _v, _v, _v, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _u32]),
     "hip_convert_lwe_programmable_bootstrap_key_exact64_async": (None, [_v, _u32, _v, _v, _u32, _u32, _u32, _u32]),
+    "hip_convert_lwe_programmable_bootstrap_key_ref64_async": (None, [_v, _u32, _v, _v, _u32, _u32, _u32, _u32]),
+    "hip_programmable_bootstrap_ref64_async":
+        (None, [_v, _u32, _v, _v, _v, _v, _v, _v, _v, _v, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _u32]),
     "hip_programmable_bootstrap_exact64_async":
         (None, [_v, _u32, _v, _v, _v, _v, _v, _v, _v, _v, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _u32]),
     "hip_backend_set_fft_kernel": (None, [_u32]),
