@@ -102,6 +102,10 @@
 #ifndef WAVE_MB_STAGGER
 #define WAVE_MB_STAGGER 0  // multi-bit: the LWEs 2, 3 of a workgroup (the SIMD mates of LWEs 0, 1) start this many s_sleep(127) late
 #endif
+#ifndef WAVE_MB_ANTIPHASE
+#define WAVE_MB_ANTIPHASE 0  // multi-bit: LWEs 2, 3 of a workgroup (SIMD mates of LWEs 0, 1) meet the XCD barrier before
+                             // their first multiply-accumulate of a group instead of at its start
+#endif
 #ifndef WAVE_MB_PACE_SPINS
 #define WAVE_MB_PACE_SPINS 4096  // polls (with s_sleep) before a wave gives up pacing for the rest of the launch
 #endif
@@ -885,17 +889,25 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
       }
       // the group's 2^g GGSWs as one buffer: uniform base in scalar registers, lane offset in one vector register
 #if WAVE_MB_PACE && !defined(TFHE_HIPEMU)
-      if (pacing && grp >= (uint32_t)WAVE_MB_PACE) {
-        const uint32_t need = pace_before * groups + pace_mine * (grp + 1u - (uint32_t)WAVE_MB_PACE);
-        uint32_t spins = 0;
-        while (__hip_atomic_load(pace_ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
-          __builtin_amdgcn_s_sleep(8);
-          if (++spins > (uint32_t)WAVE_MB_PACE_SPINS) {
-            pacing = false;
-            break;
+      auto pace_wait = [&]() {
+        if (pacing && grp >= (uint32_t)WAVE_MB_PACE) {
+          const uint32_t need = pace_before * groups + pace_mine * (grp + 1u - (uint32_t)WAVE_MB_PACE);
+          uint32_t spins = 0;
+          while (__hip_atomic_load(pace_ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+            __builtin_amdgcn_s_sleep(8);
+            if (++spins > (uint32_t)WAVE_MB_PACE_SPINS) {
+              pacing = false;
+              break;
+            }
           }
         }
-      }
+      };
+      auto pace_arrive = [&]() {
+        if (a.pace != nullptr && w == 0 && lane == 0)
+          __hip_atomic_fetch_add(pace_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      };
+      const bool late_class = WAVE_MB_ANTIPHASE && pair >= 2;
+      if (!late_class) pace_wait();
 #endif
       const HxBuffer gk = hx_make_buffer(key + (size_t)grp * per * ggsw_c, per * ggsw_bytes);
       cplx o[16];
@@ -927,6 +939,12 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
         }
         HX_PRIO(WAVE_PRIO_MB_B);
         wave_forward(d, ctx);
+#if WAVE_MB_PACE && !defined(TFHE_HIPEMU)
+        if (late_class && idx == 0) {  // arrival number grp of this pair (number groups follows the last group)
+          if (grp > 0) pace_arrive();
+          pace_wait();
+        }
+#endif
         HX_PRIO(WAVE_PRIO_MB_C);
         {  // publish my transform, fetch the partner's, build the keybundle chunks and multiply-accumulate
           const uint32_t epoch = grp * level + idx + 1;
@@ -1012,8 +1030,7 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
       wave_inverse_accumulate<false, true>(o, acc_re, acc_im, ctx);
       HX_PRIO(WAVE_PRIO_MB_K);
 #if WAVE_MB_PACE && !defined(TFHE_HIPEMU)
-      if (a.pace != nullptr && w == 0 && lane == 0)
-        __hip_atomic_fetch_add(pace_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (!late_class || grp + 1 == groups) pace_arrive();
 #endif
     }
   } else {

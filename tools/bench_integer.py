@@ -25,15 +25,25 @@ def main():
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--blocks", type=int, default=32)
     ap.add_argument("--ops", default="add,mul")
+    ap.add_argument("--params", default="classic", choices=["classic", "multibit_g3", "multibit_g4"],
+                    help="classic = PARAM_MESSAGE_2_CARRY_2; multibit_g4 = the reference's GPU default set "
+                         "(PARAM_GPU_MULTI_BIT_GROUP_4_MESSAGE_2_CARRY_2), the one its published numbers use")
+    ap.add_argument("--streams", type=int, default=1, help="streams of the set (all on GPU 0 on a 1-GPU box)")
     args = ap.parse_args()
     from tfhe_rs_amd import core_crypto_gpu as gpu
     from tfhe_rs_amd import integer_gpu as igpu
-    p = C1
+    from tests.common import C4, C4G4
+    p = {"classic": C1, "multibit_g3": C4, "multibit_g4": C4G4}[args.params]
     keys = make_keys(p)
-    st = gpu.CudaStreams.new_single_gpu(0)
+    n_gpus = gpu.get_number_of_gpus()
+    st = gpu.CudaStreams([i % n_gpus for i in range(args.streams)])
     ksk = gpu.CudaLweKeyswitchKey.from_lwe_keyswitch_key(keys.ksk, p.big_n, p.n, p.ks_base_log, p.ks_level, st)
-    bsk = gpu.CudaLweBootstrapKey.from_lwe_bootstrap_key(keys.bsk, p.n, p.k, p.N, p.pbs_base_log, p.pbs_level, st,
-                                                         ms_noise_reduction=True)
+    if p.grouping:
+        bsk = gpu.CudaLweMultiBitBootstrapKey.from_lwe_multi_bit_bootstrap_key(
+            keys.bsk, p.n, p.k, p.N, p.pbs_base_log, p.pbs_level, p.grouping, st)
+    else:
+        bsk = gpu.CudaLweBootstrapKey.from_lwe_bootstrap_key(keys.bsk, p.n, p.k, p.N, p.pbs_base_log, p.pbs_level, st,
+                                                             ms_noise_reduction=True)
     sks = igpu.CudaServerKey(ksk, bsk, 4, 4)
     B, L = args.batch, args.blocks
     mask = (1 << (2 * L)) - 1
@@ -71,7 +81,8 @@ def main():
                if sum(decrypt_big(p, keys, rows[i, j]) << (2 * j) for j in range(L)) != want[i]]
         assert not bad, f"{op}: wrong results at {bad}"
         print(json.dumps({"op": f"FheUint{2 * L} {op}", "batch": B, "seconds": dt, "ops_per_s": B / dt,
-                          "pbs_per_op": pbs, "ks_pbs_per_s": B * pbs / dt, "n_gpus": 1,
+                          "pbs_per_op": pbs, "ks_pbs_per_s": B * pbs / dt, "n_gpus": len(set(st.gpu_indexes)),
+                          "streams": len(st),
                           "params": p.name, "includes": "scratch allocation, index uploads, all rounds"}))
 
 
