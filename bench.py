@@ -315,39 +315,52 @@ def main():
         result.setdefault("extra", {})["ntt"] = dp
         del bsk_n, d_out3
 
-        # ---- config 4: multi-bit PBS, grouping factor 3 (uniform-random key and inputs like the reference's benches:
-        # bit parity with the oracle does not need a valid key, and a real 320 MB key takes minutes to encrypt)
-        q = C4
-        r4 = np.random.default_rng(11)
-        bsk4_h = r4.integers(0, 1 << 64, size=(q.n // q.grouping) * (1 << q.grouping) * q.pbs_level * 4 * q.N,
-                             dtype=np.uint64)
-        cts4 = r4.integers(0, 1 << 64, size=(B, q.n + 1), dtype=np.uint64)
-        lut4 = r4.integers(0, 1 << 64, size=2 * q.N, dtype=np.uint64)
-        bsk4 = gpu.CudaLweMultiBitBootstrapKey.from_lwe_multi_bit_bootstrap_key(bsk4_h, q.n, q.k, q.N, q.pbs_base_log,
-                                                                                q.pbs_level, q.grouping, streams)
-        d_in4 = gpu.CudaLweCiphertextList.from_lwe_ciphertext_list(cts4, streams)
-        d_out4 = gpu.CudaLweCiphertextList.new(q.k * q.N, B, streams)
-        d_lut4 = gpu.CudaGlweCiphertextList.from_glwe_ciphertext_list(lut4, q.k, q.N, streams)
-        buf4 = C.c_void_p()
-        lib.scratch_cuda_multi_bit_programmable_bootstrap_64_async(s, g, C.byref(buf4), q.k, q.N, q.pbs_level, B, True)
-        dp = datapoint(q, lambda: lib.cuda_multi_bit_programmable_bootstrap_64_async(
-            s, g, d_out4.d_vec.ptr, idx.ptr, d_lut4.d_vec.ptr, lidx.ptr, d_in4.d_vec.ptr, idx.ptr, bsk4.d_vec.ptr, buf4,
-            q.n, q.k, q.N, q.grouping, q.pbs_base_log, q.pbs_level, B, 1, 0), steps=2)
-        out4 = d_out4.to_lwe_ciphertext_list(streams)
-        lib.cleanup_cuda_multi_bit_programmable_bootstrap_64(s, g, C.byref(buf4))
-        t0 = time.perf_counter()
-        ref4 = orc.pbs_multi_bit(orc.ENGINE_FFT, cts4[:PAR], lut4, bsk4_h, q.n, q.k, q.N, q.pbs_base_log, q.pbs_level,
-                                 q.grouping)   # key conversion + OpenMP over the LWEs inside the C oracle
-        traffic4, src4 = pmc_record("mb_g3")
-        flop4 = 3.7e8   # ~1.22 MFLOP per group x 306 groups
-        dp.update({"engine": "f64 FFT, multi-bit grouping factor 3 (Fourier-domain key; keybundle combined in registers per LWE and group)",
-                   "frac_fp64": dp["pbs_per_s"] * flop4 / (FP64_PEAK_TFLOPS * 1e12),
-                   "hbm_traffic_bytes_per_launch": traffic4, "traffic_source": src4,
-                   "gpu_matches_cpu_bits": bool(np.array_equal(ref4, out4[:PAR])),
-                   "parity_sample": f"first {PAR} LWEs, all 2049 words, vs the C oracle's multi-bit f64 path "
-                                    f"({time.perf_counter() - t0:.1f} s CPU); uniform-random key and inputs"})
-        result["extra"]["multibit_g3"] = dp
-        del bsk4, d_in4, d_out4
+        # ---- config 4: multi-bit PBS, grouping factor 3; and the reference's GPU default multi-bit set (g = 4).
+        # Uniform-random key and inputs like the reference's benches: bit parity with the oracle does not need a
+        # valid key, and a real 320 MB key takes minutes to encrypt.
+        from tests.common import C4G4
+        def multibit_flop(q):
+            """f64 flop per multi-bit PBS with the keybundle combined in the Fourier domain: per group l (k+1) forward and
+            (k+1) inverse transforms at 5 n log2 n, (2^g - 1) l (k+1)^2 n complex multiply-adds for the combine and
+            l (k+1)^2 n for the products at 8 flop each; n / g groups.  (SURVEY §8(d) quotes 3.7e8 for g = 3 with the
+            keybundle built in the integer domain and transformed: that formulation is no longer what runs.)"""
+            nn, k1 = q.N // 2, q.k + 1
+            tr = 5 * nn * (nn.bit_length() - 1)
+            per_group = (q.pbs_level * k1 + k1) * tr + ((1 << q.grouping) - 1 + 1) * q.pbs_level * k1 * k1 * nn * 8
+            return per_group * (q.n // q.grouping)
+
+        for tag, q in (("multibit_g3", C4), ("multibit_g4", C4G4)):
+            flop = multibit_flop(q)
+            r4 = np.random.default_rng(11)
+            bsk4_h = r4.integers(0, 1 << 64, size=(q.n // q.grouping) * (1 << q.grouping) * q.pbs_level * 4 * q.N,
+                                 dtype=np.uint64)
+            cts4 = r4.integers(0, 1 << 64, size=(B, q.n + 1), dtype=np.uint64)
+            lut4 = r4.integers(0, 1 << 64, size=2 * q.N, dtype=np.uint64)
+            bsk4 = gpu.CudaLweMultiBitBootstrapKey.from_lwe_multi_bit_bootstrap_key(
+                bsk4_h, q.n, q.k, q.N, q.pbs_base_log, q.pbs_level, q.grouping, streams)
+            d_in4 = gpu.CudaLweCiphertextList.from_lwe_ciphertext_list(cts4, streams)
+            d_out4 = gpu.CudaLweCiphertextList.new(q.k * q.N, B, streams)
+            d_lut4 = gpu.CudaGlweCiphertextList.from_glwe_ciphertext_list(lut4, q.k, q.N, streams)
+            buf4 = C.c_void_p()
+            lib.scratch_cuda_multi_bit_programmable_bootstrap_64_async(s, g, C.byref(buf4), q.k, q.N, q.pbs_level, B, True)
+            dp = datapoint(q, lambda: lib.cuda_multi_bit_programmable_bootstrap_64_async(
+                s, g, d_out4.d_vec.ptr, idx.ptr, d_lut4.d_vec.ptr, lidx.ptr, d_in4.d_vec.ptr, idx.ptr, bsk4.d_vec.ptr,
+                buf4, q.n, q.k, q.N, q.grouping, q.pbs_base_log, q.pbs_level, B, 1, 0), steps=2)
+            out4 = d_out4.to_lwe_ciphertext_list(streams)
+            lib.cleanup_cuda_multi_bit_programmable_bootstrap_64(s, g, C.byref(buf4))
+            t0 = time.perf_counter()
+            ref4 = orc.pbs_multi_bit(orc.ENGINE_FFT, cts4[:PAR], lut4, bsk4_h, q.n, q.k, q.N, q.pbs_base_log,
+                                     q.pbs_level, q.grouping)   # key conversion + OpenMP over the LWEs in the C oracle
+            traffic4, src4 = pmc_record("mb_g3") if tag == "multibit_g3" else (None, "not profiled")
+            dp.update({"engine": f"f64 FFT, multi-bit grouping factor {q.grouping} (Fourier-domain key; keybundle "
+                                 "combined in registers per LWE and group)",
+                       "frac_fp64": dp["pbs_per_s"] * flop / (FP64_PEAK_TFLOPS * 1e12), "f64_flop_per_pbs": flop,
+                       "hbm_traffic_bytes_per_launch": traffic4, "traffic_source": src4,
+                       "gpu_matches_cpu_bits": bool(np.array_equal(ref4, out4[:PAR])),
+                       "parity_sample": f"first {PAR} LWEs, all 2049 words, vs the C oracle's multi-bit f64 path "
+                                        f"({time.perf_counter() - t0:.1f} s CPU); uniform-random key and inputs"})
+            result["extra"][tag] = dp
+            del bsk4, d_in4, d_out4
     if world == 1 and not args.no_cpu_baseline:
         # CPU leg: the oracle's f64 path on the host cores actually available to this process
         # (affinity mask and cgroup quota, not the machine's nominal thread count), on a sample

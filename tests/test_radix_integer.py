@@ -141,11 +141,11 @@ def test_radix_rounds_sharded_over_the_streams_of_the_set(kind):
     p, keys, st1, sks1, igpu = setup(kind)
     _, _, st3, sks3, _ = setup(kind, gpu_indexes=(0, 0, 0))
     lib = use_backend(kind)
-    L = 7 if kind == "emu" else 32
+    L = 5 if kind == "emu" else 32
     mask = (1 << (2 * L)) - 1
     rng = np.random.default_rng(77)
-    a = [int(x) & mask for x in rng.integers(0, 1 << 62, size=3)] + [mask]
-    b = [int(x) & mask for x in rng.integers(0, 1 << 62, size=3)] + [1]
+    a = [int(x) & mask for x in rng.integers(0, 1 << 62, size=2 if kind == "emu" else 3)] + [mask]
+    b = [int(x) & mask for x in rng.integers(0, 1 << 62, size=2 if kind == "emu" else 3)] + [1]
     blocks_a, blocks_b = encrypt_radix(p, keys, a, L, 51), encrypt_radix(p, keys, b, L, 52)
     outs = {}
     for name, st, sks, thr in (("one", st1, sks1, 512), ("three", st3, sks3, 3)):

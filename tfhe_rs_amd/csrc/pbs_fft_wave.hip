@@ -99,13 +99,6 @@
 #ifndef WAVE_MB_PACE
 #define WAVE_MB_PACE 1  // multi-bit: groups a wave pair may run ahead of the slowest pair of its XCD, plus 1 (0: no pacing)
 #endif
-#ifndef WAVE_MB_STAGGER
-#define WAVE_MB_STAGGER 0  // multi-bit: the LWEs 2, 3 of a workgroup (the SIMD mates of LWEs 0, 1) start this many s_sleep(127) late
-#endif
-#ifndef WAVE_MB_ANTIPHASE
-#define WAVE_MB_ANTIPHASE 0  // multi-bit: LWEs 2, 3 of a workgroup (SIMD mates of LWEs 0, 1) meet the XCD barrier before
-                             // their first multiply-accumulate of a group instead of at its start
-#endif
 #ifndef WAVE_MB_PACE_SPINS
 #define WAVE_MB_PACE_SPINS 4096  // polls (with s_sleep) before a wave gives up pacing for the rest of the launch
 #endif
@@ -862,10 +855,6 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
       const hx_f64x2 v = hx_buffer_load_f64x2(b, voff, soff);
       return cplx{v.x, v.y};
     };
-#if WAVE_MB_STAGGER && !defined(TFHE_HIPEMU)
-    if (pair >= 2)
-      for (int q = 0; q < WAVE_MB_STAGGER; ++q) __builtin_amdgcn_s_sleep(127);
-#endif
     for (uint32_t grp = 0; grp < groups; ++grp) {
       // monomial degrees of the 2^g - 1 non-empty subsets (:30-65): subset s selects mask element m of
       // the group when bit (g-1-m) of s is set
@@ -906,8 +895,7 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
         if (a.pace != nullptr && w == 0 && lane == 0)
           __hip_atomic_fetch_add(pace_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       };
-      const bool late_class = WAVE_MB_ANTIPHASE && pair >= 2;
-      if (!late_class) pace_wait();
+      pace_wait();
 #endif
       const HxBuffer gk = hx_make_buffer(key + (size_t)grp * per * ggsw_c, per * ggsw_bytes);
       cplx o[16];
@@ -939,12 +927,6 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
         }
         HX_PRIO(WAVE_PRIO_MB_B);
         wave_forward(d, ctx);
-#if WAVE_MB_PACE && !defined(TFHE_HIPEMU)
-        if (late_class && idx == 0) {  // arrival number grp of this pair (number groups follows the last group)
-          if (grp > 0) pace_arrive();
-          pace_wait();
-        }
-#endif
         HX_PRIO(WAVE_PRIO_MB_C);
         {  // publish my transform, fetch the partner's, build the keybundle chunks and multiply-accumulate
           const uint32_t epoch = grp * level + idx + 1;
@@ -1030,7 +1012,7 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
       wave_inverse_accumulate<false, true>(o, acc_re, acc_im, ctx);
       HX_PRIO(WAVE_PRIO_MB_K);
 #if WAVE_MB_PACE && !defined(TFHE_HIPEMU)
-      if (!late_class || grp + 1 == groups) pace_arrive();
+      pace_arrive();
 #endif
     }
   } else {
