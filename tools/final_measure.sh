@@ -1,10 +1,18 @@
-set -x
-cd $GRAFT_REPO_ROOT
-python bench.py --steps 10 --warmup 2 > gpurun_out/bench_final.json 2> gpurun_out/bench_final.err
-tail -1 gpurun_out/bench_final.json | cut -c1-400
-python tools/measure_all.py > gpurun_out/measure_all_final.jsonl 2>&1
-cat gpurun_out/measure_all_final.jsonl
+# Round-end measurement on the GPU box:  bash tools/final_measure.sh <tag>
+# everything lands under gpurun_out/ (copy what is to be judged into profiles/)
+tag=${1:-final}
+R=${GRAFT_REPO_ROOT:-/root/repo}
+cd $R
+python -m pytest tests -m gpu -x -q 2>&1 | tail -4 > gpurun_out/${tag}_gputest.log; cat gpurun_out/${tag}_gputest.log
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
+python bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err; tail -2 gpurun_out/${tag}_bench.err; cut -c1-300 gpurun_out/${tag}_bench.json
+# the multi-rank code path of bench.py at N = 1 (torch.distributed over RCCL, one rank)
+TFHE_BENCH_FORCE_DIST=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29571 RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 python bench.py --steps 3 --no-cpu-baseline --no-extra > gpurun_out/${tag}_bench_dist1.json 2> gpurun_out/${tag}_bench_dist1.err; cut -c1-200 gpurun_out/${tag}_bench_dist1.json; tail -2 gpurun_out/${tag}_bench_dist1.err
+# rocprofv3 kernel-trace statistics of the bench command itself
 cd /tmp && export TMPDIR=/tmp
-rm -rf $GRAFT_REPO_ROOT/gpurun_out/rocprof_final
-rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/rocprof_final -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/rocprof_final.log 2>&1
-cd $GRAFT_REPO_ROOT && python tools/rocprof_summary.py gpurun_out/rocprof_final gpurun_out/rocprof_final_summary.txt | head -20
+rm -rf $R/gpurun_out/${tag}_rocprof
+rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${tag}_rocprof -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline > $R/gpurun_out/${tag}_rocprof.log 2>&1
+cd $R && python tools/rocprof_summary.py gpurun_out/${tag}_rocprof gpurun_out/${tag}_rocprof_stats.txt | head -14
+# counters stamped with the build
+python tools/pmc_record.py fft ntt mb_g3 --tag ${tag} > gpurun_out/${tag}_pmc.log 2>&1; tail -1 gpurun_out/${tag}_pmc.log
+python tools/measure_all.py ks wave n1024 mb mb4 ntt sweep > gpurun_out/${tag}_measure_all.jsonl 2>&1; cat gpurun_out/${tag}_measure_all.jsonl | cut -c1-260
