@@ -624,6 +624,10 @@ def test_multi_bit_latency_path_equals_oracle(kind, which):
         lib.hip_backend_set_ntt_kernel(1)      # products in the single-group kernel instead of one group per row
         single_group = c.pbs(cts, lut)
         lib.hip_backend_set_ntt_kernel(0)
+        lib.hip_backend_set_multibit_latency_groups(0)
+        lib.hip_backend_set_fft_kernel(6)      # N = 2048: products on the generic kernels, not the latency kernel
+        generic_products = c.pbs(cts, lut)
+        assert lib.hip_backend_last_pbs_kernel() == 10
         lib.hip_backend_set_fft_kernel(1)
         generic = c.pbs(cts, lut)
         assert lib.hip_backend_last_pbs_kernel() == 4
@@ -634,6 +638,7 @@ def test_multi_bit_latency_path_equals_oracle(kind, which):
     assert np.array_equal(one_pass, ref)
     assert np.array_equal(chunked, ref)
     assert np.array_equal(single_group, ref)
+    assert np.array_equal(generic_products, ref)
     assert np.array_equal(generic, ref)
     assert [decrypt_big(p, c.keys, o) for o in one_pass] == [f(m) for m in msgs]
 

@@ -542,9 +542,11 @@ void cuda_multi_bit_programmable_bootstrap_64_async(void *stream, uint32_t gpu_i
   const bool wave_ok = pbs_multi_bit_wave_supported(polynomial_size, glwe_dimension, level_count, base_log,
                                                     grouping_factor);
   if (choice == 2) HX_PANIC_IF_FALSE(wave_ok, "throughput kernel requested for an unsupported parameter set");
-  if (choice == 5) HX_PANIC_IF_FALSE(num_samples <= b->lat_samples, "multi-bit latency path: %u samples exceed %u",
-                                     num_samples, b->lat_samples);
-  if (choice == 5 || (choice == 0 && num_samples <= b->lat_samples)) {
+  if (choice == 5 || choice == 6)
+    HX_PANIC_IF_FALSE(num_samples <= b->lat_samples, "multi-bit latency path: %u samples exceed %u", num_samples,
+                      b->lat_samples);
+  if (choice == 5 || choice == 6 || (choice == 0 && num_samples <= b->lat_samples)) {
+    g_multibit_latency_block = choice != 6;  // 6: the products on the generic kernels (comparison)
     // few ciphertexts: every (group, keybundle polynomial) gets its own workgroup, then the products run alone
     uint32_t gc = g_multibit_latency_groups.load();
     gc = (gc == 0 || gc > b->lat_groups) ? b->lat_groups : gc;

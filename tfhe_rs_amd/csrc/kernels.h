@@ -28,6 +28,9 @@ void launch_pbs_multi_bit_wave(hipStream_t st, const PbsArgs &a, const FftTables
 // latency kernel for N=2048, k=1: one workgroup per LWE — pbs_fft_block.hip
 bool pbs_fft_block_supported(uint32_t N, uint32_t glwe_dim, uint32_t level);
 void launch_pbs_fft_block(hipStream_t st, const PbsArgs &a, const FftTables &tb, int variant);
+// the same kernel running the products of the multi-bit latency path from parked keybundles (multibit.hip)
+void launch_mb_accumulate_block(hipStream_t st, const PbsArgs &a, const FftTables &tb, const cplx *kb_lat, uint64_t *acc_g,
+                                uint32_t gcount, uint32_t gpass, int first, int last);
 
 // keyswitch — keyswitch.hip
 void launch_keyswitch(hipStream_t st, uint64_t *lwe_out, const uint64_t *out_idx, const uint64_t *lwe_in,
@@ -42,6 +45,7 @@ void ksm_invalidate_range(int device, const void *p, size_t bytes);
 size_t ksm_cache_entries();
 extern bool g_keyswitch_use_mfma;
 extern bool g_ntt_kernel_serial;
+extern bool g_multibit_latency_block;
 
 // small helpers — ciphertext.hip
 void launch_modulus_switch(hipStream_t st, uint64_t *out, const uint64_t *in, uint32_t size, uint32_t log_modulus);

@@ -18,6 +18,7 @@
 #include "kernels.h"
 
 namespace tfhe_hip {
+bool g_multibit_latency_block = true;  // hip_backend_set_fft_kernel(6): generic accumulate kernels instead (comparison)
 
 // keybundle element of polynomial `poly` (index inside one GGSW) at storage slot `slot` / position `pos`
 template <int N>
@@ -291,7 +292,11 @@ static void launch_mb_latency(hipStream_t st, const MultiBitArgs &m, const FftTa
     const uint32_t gpass = groups - g0 < group_chunk ? groups - g0 : group_chunk;
     HX_LAUNCH((mb_keybundle_kernel<N, K1>), dim3(gpass * kb_polys, a.num_samples), dim3(GenericCfg<N>::TPB), 0, st, a,
               m.grouping_factor, kb_lat, tb, g0, group_chunk);
-    if (par)
+    if (N == 2048 && K1 == 2 && a.level <= 8 && !g_ntt_kernel_serial && g_multibit_latency_block)
+      // the latency kernel's structure (registers + wave-local exchanges, 4 barriers per product)
+      launch_mb_accumulate_block(st, a, tb, (const cplx *)kb_lat, acc_g, group_chunk, gpass, (int)(g0 == 0),
+                                 (int)(g0 + gpass == groups));
+    else if (par)
       HX_LAUNCH((mb_accumulate_par_kernel<N, K1>), dim3(a.num_samples), dim3(K1 * GenericCfg<N>::TPB), smem_p, st, a,
                 (const cplx *)kb_lat, tb, acc_g, group_chunk, gpass, (int)(g0 == 0), (int)(g0 + gpass == groups));
     else

@@ -109,8 +109,19 @@ HX_DEV void swap_lane54(cplx (&d)[4]) {
   for (int r = 0; r < 4; ++r) __builtin_memcpy(&d[r], w[r], 16);
 }
 
-template <int LEVEL_CT, int BASE_LOG_CT>
-__global__ void __launch_bounds__(TPB) pbs_fft_block_kernel(PbsArgs a, FftTables tb) {
+// MB (multi-bit latency path, multibit.hip): the "key" of group gl is the keybundle parked by mb_keybundle_kernel
+// in transform-position order, the product takes the accumulator itself (no rotation) and OVERWRITES it
+// (cc/algorithms/lwe_multi_bit_programmable_bootstrapping.rs:647-880); groups come in passes of at most `gcount`,
+// the accumulator crossing passes in `acc_g`.
+struct MbLatArgs {
+  const cplx *kb = nullptr;   // [sample][gcount][level][row][col][n]
+  uint64_t *acc_g = nullptr;  // [sample][2][N]
+  uint32_t gcount = 0, gpass = 0;
+  int first = 1, last = 1;
+};
+
+template <int LEVEL_CT, int BASE_LOG_CT, bool MB = false>
+__global__ void __launch_bounds__(TPB) pbs_fft_block_kernel(PbsArgs a, FftTables tb, MbLatArgs mb) {
   HX_DYN_SMEM(smem);
   const int tid = threadIdx.x;
   const int w = tid >> 8;   // polynomial of the GLWE this thread works on
@@ -174,31 +185,47 @@ __global__ void __launch_bounds__(TPB) pbs_fft_block_kernel(PbsArgs a, FftTables
 
   // ---- accumulator registers: coefficients (r*256 + t) and (1024 + r*256 + t), held NEGATED (as the
   // throughput kernel does): the rotate-and-subtract is then xor / one 64-bit add / xor
+  constexpr bool NEGACC = !MB;  // the multi-bit product needs no rotation: the accumulator keeps its sign
   uint64_t acc_re[4], acc_im[4];
-  HX_UNROLL
-  for (int r = 0; r < 4; ++r) {
-    bool neg;
-    uint32_t src = monomial_div_src(r * 256 + t, b_hat, N, neg);
-    uint64_t v = lut[src];
-    acc_re[r] = neg ? v : (uint64_t)0 - v;
-    src = monomial_div_src(1024 + r * 256 + t, b_hat, N, neg);
-    v = lut[src];
-    acc_im[r] = neg ? v : (uint64_t)0 - v;
+  if (MB && !mb.first) {  // a later pass over the groups: the accumulator of the previous pass
+    const uint64_t *mine = mb.acc_g + (size_t)sample * 2 * N + (size_t)w * N;
+    HX_UNROLL
+    for (int r = 0; r < 4; ++r) {
+      acc_re[r] = mine[r * 256 + t];
+      acc_im[r] = mine[1024 + r * 256 + t];
+    }
+  } else {
+    HX_UNROLL
+    for (int r = 0; r < 4; ++r) {
+      bool neg;
+      uint32_t src = monomial_div_src(r * 256 + t, b_hat, N, neg);
+      uint64_t v = lut[src];
+      acc_re[r] = (neg != NEGACC) ? (uint64_t)0 - v : v;
+      src = monomial_div_src(1024 + r * 256 + t, b_hat, N, neg);
+      v = lut[src];
+      acc_im[r] = (neg != NEGACC) ? (uint64_t)0 - v : v;
+    }
   }
   const TorusConsts kt = torus_consts();
-  HX_UNROLL
-  for (int r = 0; r < 4; ++r) {
-    stage[r * 256 + t] = acc_re[r];
-    stage[1024 + r * 256 + t] = acc_im[r];
+  if constexpr (!MB) {
+    HX_UNROLL
+    for (int r = 0; r < 4; ++r) {
+      stage[r * 256 + t] = acc_re[r];
+      stage[1024 + r * 256 + t] = acc_im[r];
+    }
   }
   __syncthreads();
 
   uint64_t mask_next = lwe[0];
-  for (uint32_t i = 0; i < a.n; ++i) {
-    const uint64_t mask_cur = mask_next;  // requested one iteration ago (lwe has n + 1 words)
-    mask_next = lwe[i + 1];
-    const uint32_t a_hat = (uint32_t)modulus_switch(mask_cur, LOG2N2);
-    if (a_hat == 0) continue;  // uniform over the workgroup (bootstrap.rs:334)
+  const uint32_t trips = MB ? mb.gpass : a.n;
+  for (uint32_t i = 0; i < trips; ++i) {
+    uint32_t a_hat = 1;
+    if constexpr (!MB) {
+      const uint64_t mask_cur = mask_next;  // requested one iteration ago (lwe has n + 1 words)
+      mask_next = lwe[i + 1];
+      a_hat = (uint32_t)modulus_switch(mask_cur, LOG2N2);
+      if (a_hat == 0) continue;  // uniform over the workgroup (bootstrap.rs:334)
+    }
     // with A = -acc in the registers and in `stage`, S = A[(c - rr) mod N]:  ct1[c] = ((A[c] ^ M) + S) ^ M,
     // M = all-ones where the source is not negated (no wrap, a_hat < N; both flipped together), else zero
     // (bit 31 of the byte offset u, which the LDS address ignores, carries the a_hat < N flag: M is one shift)
@@ -206,12 +233,13 @@ __global__ void __launch_bounds__(TPB) pbs_fft_block_kernel(PbsArgs a, FftTables
     cplx o[4];
     for (uint32_t idx = 0; idx < level; ++idx) {
       // key rows [i][idx][row][c = w] at the storage slots of my 4 positions (pos = 4t + r)
-      const cplx *b0 = bsk + ((((size_t)i * level + idx) * 2 + 0) * 2 + w) * n;
-      const cplx *b1 = bsk + ((((size_t)i * level + idx) * 2 + 1) * 2 + w) * n;
+      const cplx *kbase = MB ? mb.kb + ((size_t)sample * mb.gcount + i) * level * 4 * n : bsk + (size_t)i * level * 4 * n;
+      const cplx *b0 = kbase + (((size_t)idx * 2 + 0) * 2 + w) * n;
+      const cplx *b1 = kbase + (((size_t)idx * 2 + 1) * 2 + w) * n;
       cplx k0[4], k1[4];
       HX_UNROLL
       for (int r = 0; r < 4; ++r) {
-        const int slot = bsk_slot<N, 2>(4 * t + r);
+        const int slot = MB ? 4 * t + r : bsk_slot<N, 2>(4 * t + r);  // parked keybundles are in position order
         k0[r] = b0[slot];
         k1[r] = b1[slot];
       }
@@ -220,13 +248,18 @@ __global__ void __launch_bounds__(TPB) pbs_fft_block_kernel(PbsArgs a, FftTables
       uint64_t x0[4], x1[4];
       HX_UNROLL
       for (int r = 0; r < 4; ++r) {
-        const int32_t u0 = (int32_t)(ub + r * 2048u), u1 = (int32_t)(ub + r * 2048u + 8192u);
-        const uint32_t m0 = (uint32_t)(u0 >> 31), m1 = (uint32_t)(u1 >> 31);
-        const uint64_t M0 = ((uint64_t)m0 << 32) | m0, M1 = ((uint64_t)m1 << 32) | m1;
-        const uint64_t s0 = *(const uint64_t *)((const char *)stage + (u0 & 0x3ff8));
-        const uint64_t s1 = *(const uint64_t *)((const char *)stage + (u1 & 0x3ff8));
-        x0[r] = ((acc_re[r] ^ M0) + s0) ^ M0;
-        x1[r] = ((acc_im[r] ^ M1) + s1) ^ M1;
+        if constexpr (MB) {  // the external product of the accumulator itself
+          x0[r] = acc_re[r];
+          x1[r] = acc_im[r];
+        } else {
+          const int32_t u0 = (int32_t)(ub + r * 2048u), u1 = (int32_t)(ub + r * 2048u + 8192u);
+          const uint32_t m0 = (uint32_t)(u0 >> 31), m1 = (uint32_t)(u1 >> 31);
+          const uint64_t M0 = ((uint64_t)m0 << 32) | m0, M1 = ((uint64_t)m1 << 32) | m1;
+          const uint64_t s0 = *(const uint64_t *)((const char *)stage + (u0 & 0x3ff8));
+          const uint64_t s1 = *(const uint64_t *)((const char *)stage + (u1 & 0x3ff8));
+          x0[r] = ((acc_re[r] ^ M0) + s0) ^ M0;
+          x1[r] = ((acc_im[r] ^ M1) + s1) ^ M1;
+        }
       }
       if constexpr (LEVEL_CT == 1 && BASE_LOG_CT != 0 && BASE_LOG_CT <= 30) {
         // two-instruction rounding; it can differ from the decomposer only where it yields -B/2, and a
@@ -305,21 +338,39 @@ __global__ void __launch_bounds__(TPB) pbs_fft_block_kernel(PbsArgs a, FftTables
       inv_pass(o, iw[Q][0], iw[Q][1], iw[Q][2]);
     }
     // ---- untwist, back to the torus, accumulate, restage (fft/mod.rs:311-330); map pos = 256 r + t
+    if constexpr (MB) {
+      HX_UNROLL
+      for (int r = 0; r < 4; ++r) {  // dst = 0 + src (x) keybundle: the result replaces the accumulator
+        acc_re[r] = from_torus(fma(-o[r].im, un[r].im, o[r].re * un[r].re));
+        acc_im[r] = from_torus(fma(o[r].im, un[r].re, o[r].re * un[r].im));
+      }
+      HX_BLOCK_SYNC_LDS();  // xmy / work are rewritten by the next group's forward passes
+    } else {
+      HX_UNROLL
+      for (int r = 0; r < 4; ++r) {
+        // minus the untwisted value: from_torus is odd, the sign rides on the multiplication
+        const double tr = fma(o[r].im, un[r].im, -o[r].re * un[r].re);
+        const double ti = fma(-o[r].im, un[r].re, -o[r].re * un[r].im);
+        from_torus_add(acc_re[r], tr, kt);
+        from_torus_add(acc_im[r], ti, kt);
+      }
+      // the rotated reads of this iteration are many barriers behind: restage for the next one
+      HX_UNROLL
+      for (int r = 0; r < 4; ++r) {
+        stage[r * 256 + t] = acc_re[r];
+        stage[1024 + r * 256 + t] = acc_im[r];
+      }
+      HX_BLOCK_SYNC_LDS();
+    }
+  }
+  if (MB && !mb.last) {  // more groups to come in another pass
+    uint64_t *mine = mb.acc_g + (size_t)sample * 2 * N + (size_t)w * N;
     HX_UNROLL
     for (int r = 0; r < 4; ++r) {
-      // minus the untwisted value: from_torus is odd, the sign rides on the multiplication
-      const double tr = fma(o[r].im, un[r].im, -o[r].re * un[r].re);
-      const double ti = fma(-o[r].im, un[r].re, -o[r].re * un[r].im);
-      from_torus_add(acc_re[r], tr, kt);
-      from_torus_add(acc_im[r], ti, kt);
+      mine[r * 256 + t] = acc_re[r];
+      mine[1024 + r * 256 + t] = acc_im[r];
     }
-    // the rotated reads of this iteration are many barriers behind: restage for the next one
-    HX_UNROLL
-    for (int r = 0; r < 4; ++r) {
-      stage[r * 256 + t] = acc_re[r];
-      stage[1024 + r * 256 + t] = acc_im[r];
-    }
-    HX_BLOCK_SYNC_LDS();
+    return;
   }
 
   // ---- sample extraction (cc/algorithms/glwe_sample_extraction.rs:119-146); many-LUT outputs
@@ -331,15 +382,15 @@ __global__ void __launch_bounds__(TPB) pbs_fft_block_kernel(PbsArgs a, FftTables
       HX_UNROLL
       for (int r = 0; r < 4; ++r) {
         uint32_t c = r * 256 + t;
-        out[c <= nth ? nth - c : N + nth - c] = c <= nth ? (uint64_t)0 - acc_re[r] : acc_re[r];
+        out[c <= nth ? nth - c : N + nth - c] = ((c <= nth) != NEGACC) ? acc_re[r] : (uint64_t)0 - acc_re[r];
         c += 1024;
-        out[c <= nth ? nth - c : N + nth - c] = c <= nth ? (uint64_t)0 - acc_im[r] : acc_im[r];
+        out[c <= nth ? nth - c : N + nth - c] = ((c <= nth) != NEGACC) ? acc_im[r] : (uint64_t)0 - acc_im[r];
       }
     } else {
       HX_UNROLL
       for (int r = 0; r < 4; ++r) {
-        if ((uint32_t)(r * 256 + t) == nth) out[N] = (uint64_t)0 - acc_re[r];
-        if ((uint32_t)(1024 + r * 256 + t) == nth) out[N] = (uint64_t)0 - acc_im[r];
+        if ((uint32_t)(r * 256 + t) == nth) out[N] = NEGACC ? (uint64_t)0 - acc_re[r] : acc_re[r];
+        if ((uint32_t)(1024 + r * 256 + t) == nth) out[N] = NEGACC ? (uint64_t)0 - acc_im[r] : acc_im[r];
       }
     }
   }
@@ -561,7 +612,28 @@ template <int L, int B>
 static void launch_block_t(hipStream_t st, const PbsArgs &a, const FftTables &tb) {
   using namespace blockk;
   hx_set_dynamic_smem_once<pbs_fft_block_kernel<L, B>>(SMEM_BYTES);
-  HX_LAUNCH((pbs_fft_block_kernel<L, B>), dim3(a.num_samples), dim3(TPB), SMEM_BYTES, st, a, tb);
+  HX_LAUNCH((pbs_fft_block_kernel<L, B>), dim3(a.num_samples), dim3(TPB), SMEM_BYTES, st, a, tb, MbLatArgs{});
+}
+
+template <int L, int B>
+static void launch_block_mb_t(hipStream_t st, const PbsArgs &a, const FftTables &tb, const blockk::MbLatArgs &mb) {
+  using namespace blockk;
+  hx_set_dynamic_smem_once<pbs_fft_block_kernel<L, B, true>>(SMEM_BYTES);
+  HX_LAUNCH((pbs_fft_block_kernel<L, B, true>), dim3(a.num_samples), dim3(TPB), SMEM_BYTES, st, a, tb, mb);
+}
+// products of the multi-bit latency path (multibit.hip) on the latency kernel: N = 2048, k = 1
+void launch_mb_accumulate_block(hipStream_t st, const PbsArgs &a, const FftTables &tb, const cplx *kb_lat,
+                                uint64_t *acc_g, uint32_t gcount, uint32_t gpass, int first, int last) {
+  blockk::MbLatArgs mb;
+  mb.kb = kb_lat;
+  mb.acc_g = acc_g;
+  mb.gcount = gcount;
+  mb.gpass = gpass;
+  mb.first = first;
+  mb.last = last;
+  if (a.level == 1 && a.base_log == 22) launch_block_mb_t<1, 22>(st, a, tb, mb);       // the GPU group-4 sets
+  else if (a.level == 2 && a.base_log == 15) launch_block_mb_t<2, 15>(st, a, tb, mb);  // group-3 set
+  else launch_block_mb_t<0, 0>(st, a, tb, mb);
 }
 
 template <int L, int B>

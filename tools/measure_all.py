@@ -91,7 +91,7 @@ def pbs_case(p, B, engine="fft64", kernel=0, steps=3):
     else:
         lib.cleanup_cuda_programmable_bootstrap_64(S, G, C.byref(buf))
     lib.hip_backend_set_fft_kernel(0)
-    emit(what="pbs", params=p.name, engine=engine if not p.grouping else "multi_bit_fft64", kernel_id=kid, batch=B,
+    emit(what="pbs", params=p.name, engine=engine if not p.grouping else "multi_bit_fft64", kernel_id=kid, requested=kernel, batch=B,
          ms=ms, pbs_per_s=B / ms * 1e3)
     return ms
 
@@ -136,6 +136,11 @@ if __name__ == "__main__":
     if "mb4" in which:  # the reference's GPU default set (grouping factor 4, one level)
         pbs_case(C4G4, 4096, steps=2)
         pbs_case(C4G4, 1, steps=3)
+    if "mblat" in which:  # multi-bit latency path: products on the latency kernel (5) or the generic kernels (6)
+        for p in (C4G4, C4):
+            for kern in (5, 6):
+                for B in (1, 16, 128):
+                    pbs_case(p, B, kernel=kern, steps=5)
     if "n8192" in which:  # the 3_3 set: generic kernel with the accumulator in device memory
         ks_case(C33, 1024)
         pbs_case(C33, 1024, steps=2)
