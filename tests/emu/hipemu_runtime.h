@@ -43,6 +43,7 @@ static inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t
 static inline hipError_t hipEventDestroy(hipEvent_t e) { free(e); return hipSuccess; }
 static inline hipError_t hipGetLastError() { return hipSuccess; }
 static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
+static inline hipError_t hipEventQuery(hipEvent_t) { return hipSuccess; }
 static inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { *e = malloc(sizeof(double)); return hipSuccess; }
 #define hipEventDisableTiming 0
 static inline hipError_t hipMemcpyPeerAsync(void *d, int, const void *s, int, size_t n, hipStream_t) { memcpy(d, s, n); return hipSuccess; }

@@ -42,12 +42,10 @@ struct MultiBitBuffer {
   uint32_t chunk;
   uint64_t *acc;   // latency path: the accumulators crossing passes
   uint32_t *pace = nullptr;  // throughput kernel: per-XCD progress counters (PbsArgs::pace)
-  // latency path (small batches): keybundles of lat_groups groups for lat_samples ciphertexts
-  // (allocated by the first call that takes that path: integer operations hold several scratches at once and
-  // most never see a small batch)
+  // latency path (small batches): the keybundles of a pass, lat_bytes / (batch * kb_per_sample) groups at a time
   cplx *kb_lat = nullptr;
-  uint32_t lat_samples = 0, lat_groups = 0;
-  uint64_t lat_bytes = 0;
+  uint32_t lat_samples = 0;
+  uint64_t lat_bytes = 0, kb_per_sample = 0;
 };
 
 // max_n: 16384 for the classic f64 PBS (programmable_bootstrap_classic.cuh supports rings up to 2^14), 4096 for
@@ -57,6 +55,7 @@ void check_pow2_poly(uint32_t N, uint32_t max_n = 4096) {
                     "polynomial_size %u not supported by the MI355X PBS (256..%u, power of two)", N, max_n);
 }
 
+constexpr uint64_t kMultiBitLatencyBytes = 256ull << 20;  // keybundle scratch of the multi-bit latency path
 constexpr uint32_t kMultiBitLatencyMaxBatch = 128;  // multi-bit PBS: two-launch latency path up to this many LWEs
 std::atomic<uint32_t> g_multibit_latency_groups{0};  // test hook: cap of the groups per pass (0 = what the scratch holds)
 constexpr uint32_t kLatencyKernelMaxBatch = 256;  // measured (tools/measure_all.py latency): 3.7-3.9 ms vs 5.9 ms up to 256 LWEs, slower beyond
@@ -498,21 +497,24 @@ uint64_t scratch_cuda_multi_bit_programmable_bootstrap_64_async(void *stream, ui
   b->chunk = input_lwe_ciphertext_count ? input_lwe_ciphertext_count : 1;
   // the throughput kernels build every keybundle element in registers: no per-sample keybundle scratch
   const uint64_t bytes = (uint64_t)b->chunk * acc_per_sample;
-  // latency path: up to kMultiBitLatencyMaxBatch ciphertexts, as many groups per pass as 2 GiB hold (the scratch
-  // is sized without knowing n or the grouping factor, like the reference's lwe_chunk_size)
+  // latency path: up to kMultiBitLatencyMaxBatch ciphertexts; the keybundles of as many groups per pass as
+  // kMultiBitLatencyBytes hold (the scratch is sized without knowing n or the grouping factor, like the
+  // reference's lwe_chunk_size); allocated here, never inside the launch
   b->lat_samples = b->chunk < kMultiBitLatencyMaxBatch ? b->chunk : kMultiBitLatencyMaxBatch;
-  const size_t per_group = (size_t)b->lat_samples * kb_per_sample;
-  size_t lat_groups = ((size_t)2 << 30) / per_group;
-  b->lat_groups = (uint32_t)(lat_groups < 1 ? 1 : lat_groups > 1024 ? 1024 : lat_groups);
-  const uint64_t lat_bytes = (uint64_t)b->lat_groups * per_group;
+  b->kb_per_sample = kb_per_sample;
+  uint64_t slots = kMultiBitLatencyBytes / kb_per_sample;  // (ciphertext, group) keybundles held at once
+  const uint64_t most = (uint64_t)b->lat_samples * 1024;  // never more than 1024 groups per pass
+  slots = slots < b->lat_samples ? b->lat_samples : slots > most ? most : slots;  // at least one group each
+  const uint64_t lat_bytes = slots * kb_per_sample;
   if (allocate_gpu_memory) {
     b->fft = get_fft_tables(gpu_index, S(stream), polynomial_size);
     HX_CHECK(hipMalloc((void **)&b->acc, (size_t)b->chunk * acc_per_sample));
     HX_CHECK(hipMalloc((void **)&b->pace, 8 * 32 * sizeof(uint32_t)));
+    HX_CHECK(hipMalloc((void **)&b->kb_lat, lat_bytes));
   }
   b->lat_bytes = lat_bytes;
   *pbs_buffer = reinterpret_cast<int8_t *>(b);
-  return bytes + lat_bytes;  // upper bound: the latency buffer exists only once a small batch has been run
+  return bytes + lat_bytes;
 }
 
 void cuda_multi_bit_programmable_bootstrap_64_async(void *stream, uint32_t gpu_index, void *lwe_array_out,
@@ -548,9 +550,10 @@ void cuda_multi_bit_programmable_bootstrap_64_async(void *stream, uint32_t gpu_i
   if (choice == 5 || choice == 6 || (choice == 0 && num_samples <= b->lat_samples)) {
     g_multibit_latency_block = choice != 6;  // 6: the products on the generic kernels (comparison)
     // few ciphertexts: every (group, keybundle polynomial) gets its own workgroup, then the products run alone
+    const uint64_t fit = b->lat_bytes / ((uint64_t)num_samples * b->kb_per_sample);  // groups per pass for this batch
+    const uint32_t fit_groups = (uint32_t)(fit > 1024 ? 1024 : fit);
     uint32_t gc = g_multibit_latency_groups.load();
-    gc = (gc == 0 || gc > b->lat_groups) ? b->lat_groups : gc;
-    if (b->kb_lat == nullptr) HX_CHECK(hipMalloc((void **)&b->kb_lat, b->lat_bytes));  // first small batch only
+    gc = (gc == 0 || gc > fit_groups) ? fit_groups : gc;
     launch_pbs_multi_bit_latency(S(stream), polynomial_size, glwe_dimension, m, b->fft, b->kb_lat, gc, b->acc);
     g_last_pbs_kernel.store(10);
   } else if ((choice == 0 && wave_ok) || choice == 2) {

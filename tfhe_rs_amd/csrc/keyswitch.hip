@@ -383,6 +383,8 @@ struct KsmEntry {
   void *planes;      // [K/16][col tile][plane][col][16 B], then the column sums
   size_t plane_bytes;
   hipEvent_t ready;  // recorded behind the layout kernel: streams other than the building one wait for it
+  hipStream_t builder;  // the stream the layout kernel ran on (its later work is ordered behind it anyway)
+  bool done;            // the layout kernel is known to have completed: no more waits
   uint64_t last_use;
 };
 static std::vector<KsmEntry> g_ksm_cache;
@@ -467,10 +469,15 @@ static bool keyswitch_mfma(hipStream_t st, OutT *lwe_out, const uint64_t *out_id
       HX_LAUNCH((ksk_planes_kernel<OutT>), dim3((col_tiles * KSM_CT + 255) / 256, K / 16), dim3(256), 0, st,
                 (int8_t *)e.planes, cs, ksk, K, ncols, col_tiles, level, level_pad);
       HX_CHECK(hipEventRecord(e.ready, st));
+      e.builder = st;
+      e.done = false;
       g_ksm_cache.push_back(e);
       hit = &g_ksm_cache.back();
-    } else {
-      HX_CHECK(hipStreamWaitEvent(st, hit->ready, 0));  // no-op once the layout kernel has completed
+    } else if (!hit->done && st != hit->builder) {
+      // another stream: behind the layout kernel unless it is known to be over (a query, so that a launch under
+      // stream capture does not pick up an event from outside the capture once the key is warm)
+      if (hipEventQuery(hit->ready) == hipSuccess) hit->done = true;
+      else HX_CHECK(hipStreamWaitEvent(st, hit->ready, 0));
     }
     hit->last_use = ++g_ksm_tick;
     planes = (int8_t *)hit->planes;
