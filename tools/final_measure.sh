@@ -15,4 +15,4 @@ rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${tag}_rocprof -- python $R/be
 cd $R && python tools/rocprof_summary.py gpurun_out/${tag}_rocprof gpurun_out/${tag}_rocprof_stats.txt | head -14
 # counters stamped with the build
 python tools/pmc_record.py fft ntt mb_g3 --tag ${tag} > gpurun_out/${tag}_pmc.log 2>&1; tail -1 gpurun_out/${tag}_pmc.log
-python tools/measure_all.py ks wave n1024 mb mb4 ntt sweep > gpurun_out/${tag}_measure_all.jsonl 2>&1; cat gpurun_out/${tag}_measure_all.jsonl | cut -c1-260
+python tools/measure_all.py ks wave n1024 mb mb4 mblat ntt sweep > gpurun_out/${tag}_measure_all.jsonl 2>&1; cat gpurun_out/${tag}_measure_all.jsonl | cut -c1-260
