@@ -5,6 +5,9 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
 python -m pytest tests -m gpu -x -q 2>&1 | tail -4 > gpurun_out/${tag}_gputest.log; cat gpurun_out/${tag}_gputest.log
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
+python tools/pmc_record.py fft ntt mb_g3 --tag ${tag} > gpurun_out/${tag}_pmc.log 2>&1; tail -1 gpurun_out/${tag}_pmc.log
+# bench.py ties `traffic` to the build through this record: publish it before the bench line is taken
+cp gpurun_out/pmc_${tag}.json profiles/pmc_latest.json
 python bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err; tail -2 gpurun_out/${tag}_bench.err; cut -c1-300 gpurun_out/${tag}_bench.json
 # the multi-rank code path of bench.py at N = 1 (torch.distributed over RCCL, one rank)
 TFHE_BENCH_FORCE_DIST=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29571 RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 python bench.py --steps 3 --no-cpu-baseline --no-extra > gpurun_out/${tag}_bench_dist1.json 2> gpurun_out/${tag}_bench_dist1.err; cut -c1-200 gpurun_out/${tag}_bench_dist1.json; tail -2 gpurun_out/${tag}_bench_dist1.err
@@ -13,6 +16,4 @@ cd /tmp && export TMPDIR=/tmp
 rm -rf $R/gpurun_out/${tag}_rocprof
 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${tag}_rocprof -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline > $R/gpurun_out/${tag}_rocprof.log 2>&1
 cd $R && python tools/rocprof_summary.py gpurun_out/${tag}_rocprof gpurun_out/${tag}_rocprof_stats.txt | head -14
-# counters stamped with the build
-python tools/pmc_record.py fft ntt mb_g3 --tag ${tag} > gpurun_out/${tag}_pmc.log 2>&1; tail -1 gpurun_out/${tag}_pmc.log
 python tools/measure_all.py ks wave n1024 mb mb4 mblat ntt sweep > gpurun_out/${tag}_measure_all.jsonl 2>&1; cat gpurun_out/${tag}_measure_all.jsonl | cut -c1-260
