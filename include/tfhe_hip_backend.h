@@ -105,7 +105,10 @@ void hip_keyswitch_programmable_bootstrap_64_async(
 
 /* ------------------------------------------------------------------ multi-bit PBS
  * backends/tfhe-cuda-backend/cuda/include/pbs/programmable_bootstrap_multibit.h:9-40
- * called from tfhe/src/core_crypto/gpu/ffi.rs:208-309,789-835 */
+ * called from tfhe/src/core_crypto/gpu/ffi.rs:208-309,789-835
+ * polynomial_size: a power of two in 256..16384, glwe_dimension as for the classic PBS (1..3 up to 1024, 1..2 at
+ * 2048, 1 beyond); grouping_factor 1..4.
+ * The scratch holds everything a launch needs (nothing is allocated by the launch itself). */
 bool has_support_to_cuda_programmable_bootstrap_cg_multi_bit(
     uint32_t glwe_dimension, uint32_t polynomial_size, uint32_t level_count,
     uint32_t num_samples, uint32_t max_shared_memory);

@@ -69,6 +69,8 @@ TOY_16384 = Params("toy_k1_N16384_l2", 4, 1, 16384, 15, 2, 4, 5, 45, 17, 16, ms_
 TOY_MB = Params("toy_multibit_g3", 18, 1, 256, 15, 2, 4, 5, 40, 20, 4, grouping=3)
 TOY_MB2 = Params("toy_multibit_g2", 16, 1, 512, 15, 2, 4, 5, 40, 20, 4, grouping=2)
 TOY_MB_2048 = Params("toy_multibit_g3_N2048", 9, 1, 2048, 15, 2, 3, 6, 45, 17, 16, grouping=3)   # throughput kernel
+TOY_MB_K3 = Params("toy_multibit_g3_k3_N512", 12, 3, 512, 18, 2, 4, 5, 40, 18, 8, grouping=3)
+TOY_MB_8192 = Params("toy_multibit_g2_N8192", 4, 1, 8192, 15, 2, 4, 5, 45, 17, 16, grouping=2)   # accumulator in device memory
 TOY_MB4_2048 = Params("toy_multibit_g4_N2048_l1", 8, 1, 2048, 22, 1, 3, 6, 45, 17, 16, grouping=4)
 
 

@@ -553,12 +553,15 @@ def test_full_batch_properties():
 
 # ------------------------------------------------------------------ multi-bit PBS
 @pytest.mark.parametrize("kind", BACKENDS)
-@pytest.mark.parametrize("p", [pytest.param(None, id="g3"), pytest.param(1, id="g2")])
+@pytest.mark.parametrize("p", [pytest.param(None, id="g3"), pytest.param(1, id="g2"), pytest.param(2, id="g2_N8192"),
+                               pytest.param(3, id="g3_k3_N512")])
 def test_multi_bit_pbs_bit_exact_and_decrypts(kind, p):
-    from .common import TOY_MB, TOY_MB2
-    p = TOY_MB2 if p else TOY_MB
+    """Generic multi-bit kernel (and, up to 128 LWEs, the latency path) against the oracle; N = 8192: the variant
+    with the accumulator in device memory (rings of 2^13 and 2^14, programmable_bootstrap_multibit.cuh)."""
+    from .common import TOY_MB, TOY_MB2, TOY_MB_8192, TOY_MB_K3
+    p = {None: TOY_MB, 1: TOY_MB2, 2: TOY_MB_8192, 3: TOY_MB_K3}[p]
     c = ctx(kind, p, "fft64")
-    msgs = [m % p.plaintext_modulus for m in range(p.plaintext_modulus + 2)]
+    msgs = [m % p.plaintext_modulus for m in range(6 if p.N > 4096 else p.plaintext_modulus + 2)]
     cts = encrypt_small(p, c.keys, msgs, seed=13)
     f = lambda x: (3 * x + 1) % p.plaintext_modulus
     lut = orc.generate_lut(p.k, p.N, p.plaintext_modulus, p.delta, f)
@@ -601,13 +604,13 @@ def test_multi_bit_throughput_kernel_equals_generic_and_oracle(kind, which):
 
 
 @pytest.mark.parametrize("kind", BACKENDS)
-@pytest.mark.parametrize("which", ["g3", "g2", "g3_N2048"])
+@pytest.mark.parametrize("which", ["g3", "g2", "g3_N2048", "g3_k3_N512"])
 def test_multi_bit_latency_path_equals_oracle(kind, which):
     """Small batches: all keybundles first (one workgroup per group and polynomial), then the external products
     (kernel id 10); in one pass and in passes of 2 groups with the accumulator crossing passes in device memory.
     Same bits as the oracle and as the one-launch kernels."""
-    from .common import TOY_MB, TOY_MB2, TOY_MB_2048
-    p = {"g3": TOY_MB, "g2": TOY_MB2, "g3_N2048": TOY_MB_2048}[which]
+    from .common import TOY_MB, TOY_MB2, TOY_MB_2048, TOY_MB_K3
+    p = {"g3": TOY_MB, "g2": TOY_MB2, "g3_N2048": TOY_MB_2048, "g3_k3_N512": TOY_MB_K3}[which]
     c = ctx(kind, p, "fft64")
     lib = use_backend(kind)
     msgs = [m % p.plaintext_modulus for m in range(5)]

@@ -48,8 +48,8 @@ struct MultiBitBuffer {
   uint64_t lat_bytes = 0, kb_per_sample = 0;
 };
 
-// max_n: 16384 for the classic f64 PBS (programmable_bootstrap_classic.cuh supports rings up to 2^14), 4096 for
-// the NTT / exact engines and the multi-bit PBS
+// max_n: 16384 for the classic and the multi-bit f64 PBS with k = 1 (the reference's kernels support rings up to
+// 2^14), 4096 for the NTT / exact engines
 void check_pow2_poly(uint32_t N, uint32_t max_n = 4096) {
   HX_PANIC_IF_FALSE(N >= 256 && N <= max_n && (N & (N - 1)) == 0,
                     "polynomial_size %u not supported by the MI355X PBS (256..%u, power of two)", N, max_n);
@@ -460,7 +460,7 @@ void cuda_convert_lwe_multi_bit_programmable_bootstrap_key_64_async(void *stream
   // same byte size (N u64 -> N/2 complex per polynomial), same nesting [group][subset][level][row][col] — so that
   // the keybundle of every group is a pointwise combine (multibit.hip).
   set_device(gpu_index);
-  check_pow2_poly(polynomial_size);
+  check_pow2_poly(polynomial_size, glwe_dim == 1 ? 16384 : glwe_dim == 2 ? 2048 : 1024);
   HX_PANIC_IF_FALSE(dest != nullptr && src != nullptr, "multi-bit bootstrap key conversion: null pointer");
   HX_PANIC_IF_FALSE(grouping_factor >= 1 && input_lwe_dim % grouping_factor == 0,
                     "input_lwe_dim %u not a multiple of grouping_factor %u", input_lwe_dim, grouping_factor);
@@ -482,7 +482,7 @@ uint64_t scratch_cuda_multi_bit_programmable_bootstrap_64_async(void *stream, ui
                                                                 uint32_t input_lwe_ciphertext_count,
                                                                 bool allocate_gpu_memory) {
   set_device(gpu_index);
-  check_pow2_poly(polynomial_size);
+  check_pow2_poly(polynomial_size, glwe_dimension == 1 ? 16384 : glwe_dimension == 2 ? 2048 : 1024);
   auto *b = new MultiBitBuffer();
   b->magic = kMbMagic;
   b->glwe_dimension = glwe_dimension;
@@ -501,16 +501,17 @@ uint64_t scratch_cuda_multi_bit_programmable_bootstrap_64_async(void *stream, ui
   // kMultiBitLatencyBytes hold (the scratch is sized without knowing n or the grouping factor, like the
   // reference's lwe_chunk_size); allocated here, never inside the launch
   b->lat_samples = b->chunk < kMultiBitLatencyMaxBatch ? b->chunk : kMultiBitLatencyMaxBatch;
+  if (polynomial_size > 4096) b->lat_samples = 0;  // rings of 2^13, 2^14: the one-launch kernel only
   b->kb_per_sample = kb_per_sample;
   uint64_t slots = kMultiBitLatencyBytes / kb_per_sample;  // (ciphertext, group) keybundles held at once
   const uint64_t most = (uint64_t)b->lat_samples * 1024;  // never more than 1024 groups per pass
   slots = slots < b->lat_samples ? b->lat_samples : slots > most ? most : slots;  // at least one group each
-  const uint64_t lat_bytes = slots * kb_per_sample;
+  const uint64_t lat_bytes = b->lat_samples ? slots * kb_per_sample : 0;
   if (allocate_gpu_memory) {
     b->fft = get_fft_tables(gpu_index, S(stream), polynomial_size);
     HX_CHECK(hipMalloc((void **)&b->acc, (size_t)b->chunk * acc_per_sample));
     HX_CHECK(hipMalloc((void **)&b->pace, 8 * 32 * sizeof(uint32_t)));
-    HX_CHECK(hipMalloc((void **)&b->kb_lat, lat_bytes));
+    if (lat_bytes) HX_CHECK(hipMalloc((void **)&b->kb_lat, lat_bytes));
   }
   b->lat_bytes = lat_bytes;
   *pbs_buffer = reinterpret_cast<int8_t *>(b);

@@ -31,15 +31,17 @@ HX_DEV cplx keybundle_point(const cplx *__restrict__ gk, size_t ggsw_c, size_t p
   return kb;
 }
 
-template <int N, int K1>
+// ACC_GLOBAL (N = 8192, 16384, as in pbs_fft_generic_kernel): the accumulator lives in the per-sample device
+// buffer of the scratch; the workgroup runs on one CU, so its writes are visible to its reads after the barrier.
+template <int N, int K1, bool ACC_GLOBAL = false>
 __global__ void __launch_bounds__(GenericCfg<N>::TPB)
     pbs_multi_bit_kernel(PbsArgs a, uint32_t grouping, FftTables tb) {
   constexpr int n = N / 2, TPB = GenericCfg<N>::TPB, PER = n / TPB, LOG2N2 = ilog2_c(2 * N);
   HX_DYN_SMEM(smem);
-  uint64_t *acc = (uint64_t *)smem;                  // K1*N torus words (src, then dst)
-  const FBuf fbuf{(cplx *)(smem + (size_t)K1 * N * 8)};  // n complex points (padded)
   const int tid = threadIdx.x;
   const uint32_t sample = blockIdx.x;
+  uint64_t *acc = ACC_GLOBAL ? a.acc_scratch + (size_t)sample * K1 * N : (uint64_t *)smem;  // K1*N torus words (src, then dst)
+  const FBuf fbuf{(cplx *)(smem + (ACC_GLOBAL ? 0 : (size_t)K1 * N * 8))};                  // n complex points (padded)
   const uint64_t *lwe = a.lwe_in + (size_t)a.in_idx[sample] * (a.n + 1);
   const uint64_t *lut = a.lut + (size_t)a.lut_idx[sample] * K1 * N;
   const cplx *bsk = (const cplx *)a.bsk;  // Fourier domain: [group][subset][level][row][col][slot]
@@ -312,17 +314,28 @@ static void launch_mb(hipStream_t st, const MultiBitArgs &m, const FftTables &tb
   HX_LAUNCH((pbs_multi_bit_kernel<N, K1>), dim3(m.pbs.num_samples), dim3(GenericCfg<N>::TPB), smem, st, m.pbs,
             m.grouping_factor, tb);
 }
+template <int N>
+static void launch_mb_big(hipStream_t st, const MultiBitArgs &m, const FftTables &tb) {  // N >= 8192, k = 1
+  HX_PANIC_IF_FALSE(m.pbs.acc_scratch != nullptr, "multi-bit PBS scratch of a polynomial_size >= 8192 set has no accumulator buffer");
+  const size_t smem = fbuf_bytes(N);
+  hx_set_dynamic_smem_once<pbs_multi_bit_kernel<N, 2, true>>(smem);
+  HX_LAUNCH((pbs_multi_bit_kernel<N, 2, true>), dim3(m.pbs.num_samples), dim3(GenericCfg<N>::TPB), smem, st, m.pbs,
+            m.grouping_factor, tb);
+}
 
-void launch_pbs_multi_bit(hipStream_t st, uint32_t N, uint32_t glwe_dim, const MultiBitArgs &m, const FftTables &tb,
+void launch_pbs_multi_bit(hipStream_t st, uint32_t N, uint32_t glwe_dim, const MultiBitArgs &m0, const FftTables &tb,
                           uint64_t *acc_scratch) {
-  (void)acc_scratch;
+  MultiBitArgs m = m0;
+  m.pbs.acc_scratch = acc_scratch;
   const uint32_t k1 = glwe_dim + 1;
   bool ok = true;
   switch (N) {
-    case 256: if (k1 == 2) launch_mb<256, 2>(st, m, tb); else if (k1 == 3) launch_mb<256, 3>(st, m, tb); else ok = false; break;
-    case 512: if (k1 == 2) launch_mb<512, 2>(st, m, tb); else if (k1 == 3) launch_mb<512, 3>(st, m, tb); else ok = false; break;
-    case 1024: if (k1 == 2) launch_mb<1024, 2>(st, m, tb); else if (k1 == 3) launch_mb<1024, 3>(st, m, tb); else ok = false; break;
-    case 2048: if (k1 == 2) launch_mb<2048, 2>(st, m, tb); else ok = false; break;
+    case 8192: if (k1 == 2) launch_mb_big<8192>(st, m, tb); else ok = false; break;
+    case 16384: if (k1 == 2) launch_mb_big<16384>(st, m, tb); else ok = false; break;
+    case 256: if (k1 == 2) launch_mb<256, 2>(st, m, tb); else if (k1 == 3) launch_mb<256, 3>(st, m, tb); else if (k1 == 4) launch_mb<256, 4>(st, m, tb); else ok = false; break;
+    case 512: if (k1 == 2) launch_mb<512, 2>(st, m, tb); else if (k1 == 3) launch_mb<512, 3>(st, m, tb); else if (k1 == 4) launch_mb<512, 4>(st, m, tb); else ok = false; break;
+    case 1024: if (k1 == 2) launch_mb<1024, 2>(st, m, tb); else if (k1 == 3) launch_mb<1024, 3>(st, m, tb); else if (k1 == 4) launch_mb<1024, 4>(st, m, tb); else ok = false; break;
+    case 2048: if (k1 == 2) launch_mb<2048, 2>(st, m, tb); else if (k1 == 3) launch_mb<2048, 3>(st, m, tb); else ok = false; break;
     case 4096: if (k1 == 2) launch_mb<4096, 2>(st, m, tb); else ok = false; break;
     default: ok = false;
   }
@@ -334,10 +347,10 @@ void launch_pbs_multi_bit_latency(hipStream_t st, uint32_t N, uint32_t glwe_dim,
   const uint32_t k1 = glwe_dim + 1;
   bool ok = true;
   switch (N) {
-    case 256: if (k1 == 2) launch_mb_latency<256, 2>(st, m, tb, kb_lat, group_chunk, acc_g); else if (k1 == 3) launch_mb_latency<256, 3>(st, m, tb, kb_lat, group_chunk, acc_g); else ok = false; break;
-    case 512: if (k1 == 2) launch_mb_latency<512, 2>(st, m, tb, kb_lat, group_chunk, acc_g); else if (k1 == 3) launch_mb_latency<512, 3>(st, m, tb, kb_lat, group_chunk, acc_g); else ok = false; break;
-    case 1024: if (k1 == 2) launch_mb_latency<1024, 2>(st, m, tb, kb_lat, group_chunk, acc_g); else if (k1 == 3) launch_mb_latency<1024, 3>(st, m, tb, kb_lat, group_chunk, acc_g); else ok = false; break;
-    case 2048: if (k1 == 2) launch_mb_latency<2048, 2>(st, m, tb, kb_lat, group_chunk, acc_g); else ok = false; break;
+    case 256: if (k1 == 2) launch_mb_latency<256, 2>(st, m, tb, kb_lat, group_chunk, acc_g); else if (k1 == 3) launch_mb_latency<256, 3>(st, m, tb, kb_lat, group_chunk, acc_g); else if (k1 == 4) launch_mb_latency<256, 4>(st, m, tb, kb_lat, group_chunk, acc_g); else ok = false; break;
+    case 512: if (k1 == 2) launch_mb_latency<512, 2>(st, m, tb, kb_lat, group_chunk, acc_g); else if (k1 == 3) launch_mb_latency<512, 3>(st, m, tb, kb_lat, group_chunk, acc_g); else if (k1 == 4) launch_mb_latency<512, 4>(st, m, tb, kb_lat, group_chunk, acc_g); else ok = false; break;
+    case 1024: if (k1 == 2) launch_mb_latency<1024, 2>(st, m, tb, kb_lat, group_chunk, acc_g); else if (k1 == 3) launch_mb_latency<1024, 3>(st, m, tb, kb_lat, group_chunk, acc_g); else if (k1 == 4) launch_mb_latency<1024, 4>(st, m, tb, kb_lat, group_chunk, acc_g); else ok = false; break;
+    case 2048: if (k1 == 2) launch_mb_latency<2048, 2>(st, m, tb, kb_lat, group_chunk, acc_g); else if (k1 == 3) launch_mb_latency<2048, 3>(st, m, tb, kb_lat, group_chunk, acc_g); else ok = false; break;
     case 4096: if (k1 == 2) launch_mb_latency<4096, 2>(st, m, tb, kb_lat, group_chunk, acc_g); else ok = false; break;
     default: ok = false;
   }
