@@ -8,7 +8,10 @@ One "step" = one batched PBS launch (modulus switch + 918 CMUXes + sample extrac
 rank owns its own 4096-LWE shard and a replica of the key; no data-path collective (weak
 scaling); the barrier/max-over-ranks timing uses torch.distributed (RCCL).
 
-Prints ONE JSON line (contract in the task statement) with `roofline` and `cpu_baseline`.
+Prints ONE JSON line (contract in the task statement) with `roofline` and `cpu_baseline`.  At N = 1 the line
+also carries `extra`: the single-PBS latency, the N=1024/k=2 datapoint, BASELINE.json's configs 3 (NTT engine) and
+4 (multi-bit g = 3, plus the reference's GPU default g = 4), each at batch 4096 with its oracle-parity bit, and
+config 5 on one GPU (FheUint64 add / mul through the radix layer, results decrypted) — none of them part of `value`.
 """
 import argparse
 import ctypes as C
@@ -361,6 +364,48 @@ def main():
                                         f"({time.perf_counter() - t0:.1f} s CPU); uniform-random key and inputs"})
             result["extra"][tag] = dp
             del bsk4, d_in4, d_out4
+        # ---- config 5 on ONE GPU: FheUint64 (32 blocks of the 2_2 set) add and mul through the radix layer of the
+        # backend (keyswitch -> PBS rounds, `tfhe_rs_amd/integer_gpu.py` over the reference's integer FFI names);
+        # same key as the headline, 32 distinct operand pairs tiled over the batch (timing is data independent),
+        # every distinct result decrypted and compared with clear arithmetic outside the timed region.
+        from tfhe_rs_amd import integer_gpu as igpu
+        ksk_h = orc.gen_ksk(0x74666865 + 2, keys.glwe_sk, keys.lwe_sk, p.ks_base_log, p.ks_level, p.lwe_noise)
+        ksk = gpu.CudaLweKeyswitchKey.from_lwe_keyswitch_key(ksk_h, p.k * p.N, p.n, p.ks_base_log, p.ks_level, streams)
+        sks = igpu.CudaServerKey(ksk, bsk, 4, 4)
+        LB, DISTINCT = 32, 32
+        mask64 = (1 << (2 * LB)) - 1
+        r5 = np.random.default_rng(5)
+        va = [int.from_bytes(r5.bytes(8), "little") for _ in range(DISTINCT)]
+        vb = [int.from_bytes(r5.bytes(8), "little") for _ in range(DISTINCT)]
+        er = orc.Rng(55)
+        enc = lambda vals: np.stack([np.stack([orc.lwe_encrypt(er, keys.glwe_sk, (((v >> (2 * j)) & 3) * p.delta) % (1 << 64),
+                                                               p.glwe_noise) for j in range(LB)]) for v in vals])
+        ha, hb = enc(va), enc(vb)
+        fhe = {}
+        for op, nb in (("add", 1024), ("mul", 128)):
+            reps = nb // DISTINCT
+            ca = igpu.CudaUnsignedRadixCiphertext.from_blocks(np.tile(ha, (reps, 1, 1)), streams)
+            cb = igpu.CudaUnsignedRadixCiphertext.from_blocks(np.tile(hb, (reps, 1, 1)), streams)
+            streams.synchronize()
+            t0 = time.perf_counter()
+            if op == "add":
+                sks.add_assign(ca, cb, streams)
+                pbs_count = int(lib.hip_integer_propagate_pbs_count(LB))
+            else:
+                pbs_count = int(sks.mul_assign(ca, cb, streams, return_pbs_count=True))
+            streams.synchronize()
+            dt = time.perf_counter() - t0
+            rows = ca.to_blocks(streams)
+            want = [((x + y) if op == "add" else (x * y)) & mask64 for x, y in zip(va, vb)]
+            got = [sum(decrypt_big(p, keys, rows[i, j]) << (2 * j) for j in range(LB)) for i in range(DISTINCT)]
+            fhe[op] = {"batch": nb, "seconds": dt, "ops_per_s": nb / dt, "pbs_per_op": pbs_count,
+                       "ks_pbs_per_s": nb * pbs_count / dt, "results_decrypt_to_clear_arithmetic": got == want}
+            del ca, cb
+        fhe["note"] = ("one GPU, classic 2_2 set, wall clock including scratch allocation, index uploads and every round; "
+                       "the reference publishes 510 add/s and 53.2 mul/s on 8xH100 with multi-bit parameters (BASELINE.md); "
+                       "multi-bit sets and several streams: tools/bench_integer.py, profiles/r02_bench_integer_fheuint64.jsonl")
+        result["extra"]["fheuint64"] = fhe
+        del sks, ksk
     if world == 1 and not args.no_cpu_baseline:
         # CPU leg: the oracle's f64 path on the host cores actually available to this process
         # (affinity mask and cgroup quota, not the machine's nominal thread count), on a sample
