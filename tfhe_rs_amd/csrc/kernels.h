@@ -46,6 +46,7 @@ size_t ksm_cache_entries();
 extern bool g_keyswitch_use_mfma;
 extern bool g_ntt_kernel_serial;
 extern bool g_multibit_latency_block;
+extern bool g_multibit_share;
 
 // small helpers — ciphertext.hip
 void launch_modulus_switch(hipStream_t st, uint64_t *out, const uint64_t *in, uint32_t size, uint32_t log_modulus);

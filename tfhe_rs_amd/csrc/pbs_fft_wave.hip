@@ -110,6 +110,7 @@
 #endif
 
 namespace tfhe_hip {
+bool g_multibit_share = true;  // hip_backend_set_fft_kernel(7) on the multi-bit entry point: pairs only (comparison)
 namespace wavek {
 
 constexpr int N = 2048, n = 1024, LOG2N2 = 12;
@@ -520,9 +521,19 @@ HX_DEV void wave_inverse_accumulate(cplx (&o)[16], uint64_t (&acc_re)[16], uint6
 // :116-156, :647-880): per group of g mask elements the external product  acc <- acc (x) GGSW_comb  with the
 // keybundle combined in the Fourier domain on the fly (see the MULTIBIT block below); no rotation, the result
 // overwrites the accumulator.
-template <int LEVEL_CT, int BASE_LOG_CT, int GROUPING = 0>
+//
+// SHARE (multi-bit only, an even number of LWEs per workgroup): the key of a group is what a CU's vector-L1
+// delivers slowest (1 MB per LWE and group through 64 B/clk), so the two LWEs of a QUAD of waves share every key
+// load: after the forward transforms the quad's four waves re-partition the multiply-accumulate by (output
+// column, half of the 16 points a lane owns) instead of by (LWE, output column) — a wave combines the keybundle
+// of its column at its 8 points for BOTH LWEs out of one load of each key element (their monomial factors
+// differ, the key does not), reads the four digit transforms from the quad's buffers, and hands the half it
+// computed for the other LWE back through LDS before the inverse transforms.  Same products in the same order
+// per output point: identical bits.  Workgroup barriers replace the pair flags.
+template <int LEVEL_CT, int BASE_LOG_CT, int GROUPING = 0, bool SHARE = false>
 __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables tb) {
   constexpr bool MULTIBIT = GROUPING > 0;
+  static_assert(!SHARE || MULTIBIT, "SHARE is a mode of the multi-bit loop");
   HX_DYN_SMEM(smem);
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -588,8 +599,15 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
   __syncthreads();
 
   // the launch picks 1..4 LWEs per workgroup (blockDim.x = 128 per LWE): small batches spread over the CUs
-  const uint32_t sample = blockIdx.x * (blockDim.x >> 7) + pair;
-  if (sample >= a.num_samples) return;  // whole pair leaves together; no later block barrier
+  uint32_t sample = blockIdx.x * (blockDim.x >> 7) + pair;
+  const bool valid = sample < a.num_samples;
+  if constexpr (SHARE) {
+    // every wave of the workgroup works for its quad and meets the block barriers: the pairs past the end of a
+    // ragged last workgroup redo the last ciphertext and write nothing
+    if (!valid) sample = a.num_samples - 1;
+  } else {
+    if (!valid) return;  // whole pair leaves together; no later block barrier
+  }
   const uint64_t *lwe = a.lwe_in + (size_t)a.in_idx[sample] * (a.n + 1);
   const uint64_t *lut = a.lut + (size_t)a.lut_idx[sample] * 2 * N + (size_t)w * N;
   const cplx *bsk = (const cplx *)a.bsk;
@@ -850,6 +868,15 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
       }
     }
 #endif
+    // SHARE: the quad = waves 4q .. 4q+3 = (LWE 2q, column 0), (2q, 1), (2q+1, 0), (2q+1, 1)
+    const int quad_lwe = pair & 1;  // which LWE of its quad this wave owns = which half of a lane's 16 points it works on
+    const uint64_t *lwe_q0 = lwe, *lwe_q1 = lwe;
+    if constexpr (SHARE) {
+      const uint32_t s0 = blockIdx.x * (blockDim.x >> 7) + (uint32_t)(pair & ~1);
+      const uint32_t last = a.num_samples - 1;
+      lwe_q0 = a.lwe_in + (size_t)a.in_idx[s0 < last ? s0 : last] * (a.n + 1);
+      lwe_q1 = a.lwe_in + (size_t)a.in_idx[s0 + 1 < last ? s0 + 1 : last] * (a.n + 1);
+    }
     const uint32_t ggsw_bytes = (uint32_t)(ggsw_c * sizeof(cplx));
     auto ldc = [](HxBuffer b, uint32_t voff, uint32_t soff) {
       const hx_f64x2 v = hx_buffer_load_f64x2(b, voff, soff);
@@ -858,23 +885,31 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
     for (uint32_t grp = 0; grp < groups; ++grp) {
       // monomial degrees of the 2^g - 1 non-empty subsets (:30-65): subset s selects mask element m of
       // the group when bit (g-1-m) of s is set
-      uint32_t deg[per];
-      cplx base[per];
-      {
+      auto degrees = [&](const uint64_t *lw, uint32_t (&dg)[per], cplx (&bs)[per]) {
         uint64_t m[g];
         HX_UNROLL
-        for (uint32_t q = 0; q < g; ++q) m[q] = lwe[(size_t)grp * g + q];
+        for (uint32_t q = 0; q < g; ++q) m[q] = lw[(size_t)grp * g + q];
         HX_UNROLL
         for (uint32_t sidx = 1; sidx < per; ++sidx) {
           uint64_t sum = 0;
           HX_UNROLL
           for (uint32_t q = 0; q < g; ++q)
             if ((sidx >> (g - 1 - q)) & 1) sum += m[q];
-          deg[sidx] = HX_UNIFORM((uint32_t)modulus_switch(sum, LOG2N2));
-          base[sidx] = ldc(mono, ((a_lane * deg[sidx]) & (2u * N - 1u)) * 16u, 0u);
+          dg[sidx] = HX_UNIFORM((uint32_t)modulus_switch(sum, LOG2N2));
+          bs[sidx] = ldc(mono, ((a_lane * dg[sidx]) & (2u * N - 1u)) * 16u, 0u);
         }
-        deg[0] = 0;
-        base[0] = cplx{1.0, 0.0};
+        dg[0] = 0;
+        bs[0] = cplx{1.0, 0.0};
+      };
+      uint32_t deg[per];
+      cplx base[per];
+      uint32_t deg_b[SHARE ? per : 1];  // SHARE: deg / base belong to the quad's first LWE, these to its second
+      cplx base_b[SHARE ? per : 1];
+      if constexpr (SHARE) {
+        degrees(lwe_q0, deg, base);
+        degrees(lwe_q1, deg_b, base_b);
+      } else {
+        degrees(lwe, deg, base);
       }
       // the group's 2^g GGSWs as one buffer: uniform base in scalar registers, lane offset in one vector register
 #if WAVE_MB_PACE && !defined(TFHE_HIPEMU)
@@ -892,13 +927,18 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
         }
       };
       auto pace_arrive = [&]() {
-        if (a.pace != nullptr && w == 0 && lane == 0)
+        if (a.pace != nullptr && valid && w == 0 && lane == 0)
           __hip_atomic_fetch_add(pace_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       };
       pace_wait();
 #endif
       const HxBuffer gk = hx_make_buffer(key + (size_t)grp * per * ggsw_c, per * ggsw_bytes);
       cplx o[16];
+      cplx oq_a[SHARE ? 8 : 1], oq_b[SHARE ? 8 : 1];  // SHARE: my column at my 8 points, first / second LWE of the quad
+      if constexpr (SHARE) {
+        HX_UNROLL
+        for (int j = 0; j < 8; ++j) oq_a[j] = oq_b[j] = cplx{-0.0, -0.0};
+      }
       // The accumulator is dead once its digits exist (the product OVERWRITES it): with several levels on
       // a decomposition of at most 30 bits only the 32-bit decomposer states stay live across the levels (32
       // registers instead of the 64 of the accumulator), cc/commons/math/decomposition/iter.rs:122-151
@@ -928,6 +968,76 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
         HX_PRIO(WAVE_PRIO_MB_B);
         wave_forward(d, ctx);
         HX_PRIO(WAVE_PRIO_MB_C);
+        if constexpr (SHARE) {
+          // ---- all four transforms of the quad are in its buffers (mapping M3: slot lane*17 + r)
+          HX_BLOCK_SYNC_LDS();
+          WaveCtx cx = ctx0;
+          HX_OPAQUE(cx.lane);
+          const int ln = cx.lane;
+          const uint32_t lane_off = (uint32_t)ln * 16u;
+          const uint32_t r0 = 8u * (uint32_t)quad_lwe;  // my points: r0 .. r0 + 7 of every lane, column w, both LWEs
+          const uint32_t row0_off = (((idx * 2 + 0) * 2 + (uint32_t)w) * n) * 16u + r0 * 1024u;
+          const uint32_t row1_off = (((idx * 2 + 1) * 2 + (uint32_t)w) * n) * 16u + r0 * 1024u;
+          const cplx *qbuf = (const cplx *)(smem + (size_t)(wave & ~3) * BUF_BYTES);
+          const int fslot = base_m3(cx) + (int)r0;
+          const cplx *fa0 = qbuf + fslot, *fa1 = (const cplx *)((const char *)qbuf + BUF_BYTES) + fslot;
+          const cplx *fb0 = (const cplx *)((const char *)qbuf + 2 * BUF_BYTES) + fslot;
+          const cplx *fb1 = (const cplx *)((const char *)qbuf + 3 * BUF_BYTES) + fslot;
+          constexpr int SETS = WAVE_MB_SETS, RW = 8, STEPS = RW * (int)per;
+          cplx x0[SETS], x1[SETS];
+          auto request = [&](int set, int t) {
+            const uint32_t sidx = (uint32_t)(t % (int)per);
+            const int j = t / (int)per;
+            x0[set] = ldc(gk, lane_off, sidx * ggsw_bytes + row0_off + (uint32_t)j * 1024u);
+            x1[set] = ldc(gk, lane_off, sidx * ggsw_bytes + row1_off + (uint32_t)j * 1024u);
+          };
+          HX_UNROLL
+          for (int t = 0; t < SETS && t < STEPS; ++t) request(t, t);
+          HX_SCHED_FENCE();
+          cplx ka0, ka1, kb0, kb1;
+          HX_UNROLL
+          for (int j = 0; j < RW; ++j) {
+            HX_UNROLL
+            for (int si = 0; si < (int)per; ++si) {
+              const int t = j * (int)per + si, set = t % SETS;
+              if (si == 0) {  // subset 0 is not rotated: it initialises the accumulators of both LWEs
+                ka0 = x0[set];
+                ka1 = x1[set];
+                kb0 = x0[set];
+                kb1 = x1[set];
+              } else {
+                constexpr uint32_t br4[8] = {0, 8, 4, 12, 2, 10, 6, 14};  // bitrev4(8 h + j) = bitrev4(j) + h
+                const uint32_t br = br4[j] + (uint32_t)quad_lwe;
+                const cplx mfa = cmul_first(base[si], T[T_W16X + ((br * deg[si]) & 15u)]);
+                const cplx mfb = cmul_first(base_b[si], T[T_W16X + ((br * deg_b[si]) & 15u)]);
+                ka0 = cmul_add(x0[set], mfa, ka0);
+                ka1 = cmul_add(x1[set], mfa, ka1);
+                kb0 = cmul_add(x0[set], mfb, kb0);
+                kb1 = cmul_add(x1[set], mfb, kb1);
+                HX_OPAQUE(ka0.re);
+                HX_OPAQUE(ka0.im);
+                HX_OPAQUE(ka1.re);
+                HX_OPAQUE(ka1.im);
+                HX_OPAQUE(kb0.re);
+                HX_OPAQUE(kb0.im);
+                HX_OPAQUE(kb1.re);
+                HX_OPAQUE(kb1.im);
+              }
+              HX_SCHED_FENCE();
+              if (t + SETS < STEPS) request(set, t + SETS);
+              HX_SCHED_FENCE();
+            }
+            const cplx xa0 = fa0[j], xa1 = fa1[j], xb0 = fb0[j], xb1 = fb1[j];
+            oq_a[j] = cmul_add(xa1, ka1, cmul_add(xa0, ka0, oq_a[j]));
+            oq_b[j] = cmul_add(xb1, kb1, cmul_add(xb0, kb0, oq_b[j]));
+            HX_OPAQUE(oq_a[j].re);
+            HX_OPAQUE(oq_a[j].im);
+            HX_OPAQUE(oq_b[j].re);
+            HX_OPAQUE(oq_b[j].im);
+            HX_SCHED_FENCE();
+          }
+          HX_BLOCK_SYNC_LDS();  // every wave is done with the transforms of this level
+        } else
         {  // publish my transform, fetch the partner's, build the keybundle chunks and multiply-accumulate
           const uint32_t epoch = grp * level + idx + 1;
           WaveCtx cx = ctx0;
@@ -946,6 +1056,9 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
           auto request = [&](int set, int t) {
             const uint32_t sidx = (uint32_t)(t % (int)per);
             const int ch = t / (int)per;
+#ifdef WAVE_MB_EXPERIMENT_SKIP_LOADS  // timing experiment only (wrong results): 1 of N key requests is issued
+            if (t % WAVE_MB_EXPERIMENT_SKIP_LOADS != 0) return;
+#endif
             HX_UNROLL
             for (int j = 0; j < PTS; ++j) {
               x0[set][j] = ldc(gk, lane_off, sidx * ggsw_bytes + row0_off + (uint32_t)(ch * PTS + j) * 1024u);
@@ -1008,6 +1121,34 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
           flag_wait(r_done_ot, epoch);  // the partner must be done with my buffer before I reuse it
         }
       }
+      if constexpr (SHARE) {
+        // the half I computed for the quad's other LWE goes to the wave that owns that polynomial (same column),
+        // its half for my LWE comes back the same way (the buffers are free: barrier above)
+        cplx *pbuf = (cplx *)(smem + (size_t)(wave ^ 2) * BUF_BYTES) + base_m3(ctx0) + 8 * quad_lwe;
+        const cplx *mine = buf + base_m3(ctx0) + 8 * (quad_lwe ^ 1);
+        if (quad_lwe == 0) {
+          HX_UNROLL
+          for (int j = 0; j < 8; ++j) pbuf[j] = oq_b[j];
+        } else {
+          HX_UNROLL
+          for (int j = 0; j < 8; ++j) pbuf[j] = oq_a[j];
+        }
+        HX_BLOCK_SYNC_LDS();
+        if (quad_lwe == 0) {
+          HX_UNROLL
+          for (int j = 0; j < 8; ++j) {
+            o[j] = oq_a[j];
+            o[8 + j] = mine[j];
+          }
+        } else {
+          HX_UNROLL
+          for (int j = 0; j < 8; ++j) {
+            o[j] = mine[j];
+            o[8 + j] = oq_b[j];
+          }
+        }
+        HX_WAVE_SYNC();
+      }
       HX_PRIO(WAVE_PRIO_MB_D);
       wave_inverse_accumulate<false, true>(o, acc_re, acc_im, ctx);
       HX_PRIO(WAVE_PRIO_MB_K);
@@ -1064,6 +1205,7 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
   }
 
   // ---- sample extraction (cc/algorithms/glwe_sample_extraction.rs:119-146); many-LUT outputs
+  if (!valid) return;  // SHARE: a pair past the end of the batch
   const size_t out_sz = (size_t)N + 1;
   for (uint32_t t = 0; t < a.num_many_lut; ++t) {
     const uint32_t nth = t * a.lut_stride;
@@ -1116,11 +1258,17 @@ bool pbs_multi_bit_wave_supported(uint32_t N, uint32_t glwe_dim, uint32_t level,
 template <int L, int B, int G>
 static void launch_wave_mb_t(hipStream_t st, const PbsArgs &a, const FftTables &tb) {
   using namespace wavek;
-  hx_set_dynamic_smem_once<pbs_fft_wave_kernel<L, B, G>>(SMEM_BYTES);
   if (a.pace) HX_CHECK(hipMemsetAsync(a.pace, 0, 8 * 32 * sizeof(uint32_t), st));
   const unsigned per_block = lwes_per_block(a.num_samples);
   const unsigned blocks = (a.num_samples + per_block - 1) / per_block;
-  HX_LAUNCH((pbs_fft_wave_kernel<L, B, G>), dim3(blocks), dim3(128 * per_block), SMEM_BYTES, st, a, tb);
+  // an even number of LWEs per workgroup: quads of waves share the key loads of their two LWEs (SHARE)
+  if (per_block % 2 == 0 && g_multibit_share) {
+    hx_set_dynamic_smem_once<pbs_fft_wave_kernel<L, B, G, true>>(SMEM_BYTES);
+    HX_LAUNCH((pbs_fft_wave_kernel<L, B, G, true>), dim3(blocks), dim3(128 * per_block), SMEM_BYTES, st, a, tb);
+  } else {
+    hx_set_dynamic_smem_once<pbs_fft_wave_kernel<L, B, G>>(SMEM_BYTES);
+    HX_LAUNCH((pbs_fft_wave_kernel<L, B, G>), dim3(blocks), dim3(128 * per_block), SMEM_BYTES, st, a, tb);
+  }
 }
 
 // a.grouping set; a.bsk = Fourier-domain multi-bit key
