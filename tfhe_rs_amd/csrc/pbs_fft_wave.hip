@@ -102,6 +102,9 @@
 #ifndef WAVE_MB_PACE_SPINS
 #define WAVE_MB_PACE_SPINS 4096  // polls (with s_sleep) before a wave gives up pacing for the rest of the launch
 #endif
+#ifndef WAVE_MB_TURNS
+#define WAVE_MB_TURNS 0  // SHARE: the two quads of a workgroup take the multiply-accumulate in turns (measured slower: 60 vs 54 ms)
+#endif
 #ifndef WAVE_MB_SETS
 #define WAVE_MB_SETS 4  // multi-bit: register sets in rotation (SETS - 1 key requests in flight)
 #endif
@@ -856,14 +859,18 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
     // pairs of the earlier batches are done and all pairs of its own batch have finished group g - WAVE_MB_PACE.
     // A wave that polls WAVE_MB_PACE_SPINS times in vain (peers not resident: fewer CUs than expected) stops
     // pacing, so the scheme cannot deadlock.
-    uint32_t *pace_ctr = a.pace + (blockIdx.x & 7u) * 32u;
+    // SHARE: the two quads of a workgroup run half a group apart (see mac_turn below), so each quad index paces
+    // with its likes: its own counter (another cache line), its own pair counts
+    const uint32_t pclass = SHARE ? (uint32_t)(pair >> 1) : 0u;
+    uint32_t *pace_ctr = a.pace + (blockIdx.x & 7u) * 32u + pclass * 16u;
     uint32_t pace_before = 0, pace_mine = 0;  // pairs of earlier batches of my XCD; pairs of my batch
     bool pacing = a.pace != nullptr;
     {
       const uint32_t ppb = blockDim.x >> 7, xcd = blockIdx.x & 7u, my_batch = (blockIdx.x >> 3) / 32u;
       for (uint32_t j = 0; j < (my_batch + 1) * 32u; ++j) {
         const uint64_t first = (uint64_t)(xcd + 8u * j) * ppb;
-        const uint32_t cnt = first >= a.num_samples ? 0u : (a.num_samples - first < ppb ? (uint32_t)(a.num_samples - first) : ppb);
+        uint32_t cnt = first >= a.num_samples ? 0u : (a.num_samples - first < ppb ? (uint32_t)(a.num_samples - first) : ppb);
+        if constexpr (SHARE) cnt = pclass == 0 ? (cnt < 2u ? cnt : 2u) : (cnt > 2u ? cnt - 2u : 0u);  // pairs 0, 1 / 2, 3
         if (j < my_batch * 32u) pace_before += cnt; else pace_mine += cnt;
       }
     }
@@ -877,6 +884,27 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
       lwe_q0 = a.lwe_in + (size_t)a.in_idx[s0 < last ? s0 : last] * (a.n + 1);
       lwe_q1 = a.lwe_in + (size_t)a.in_idx[s0 + 1 < last ? s0 + 1 : last] * (a.n + 1);
     }
+    // SHARE synchronisation, all in the LDS flag words: word v = progress of wave v (quad_sync: each of the four
+    // waves of a quad posts its count and waits for the other three), word 8 = mac_turn.  The multiply-accumulate
+    // is what loads the key, the transforms are what computes: the two quads of a workgroup (one wave of each per
+    // SIMD) take the multiply-accumulate IN TURNS, so one quad's key loads run under the other's transforms.
+    uint32_t q_epoch = 0;
+    auto quad_sync = [&]() {
+      ++q_epoch;
+      HX_WAVE_SYNC();
+      if (lane == 0) flag_set(flags + wave, q_epoch);
+      const int q0 = wave & ~3;
+      HX_UNROLL
+      for (int v = 0; v < 4; ++v)
+        if (q0 + v != wave) flag_wait(flags + q0 + v, q_epoch);
+    };
+    const bool two_quads = WAVE_MB_TURNS && SHARE && blockDim.x == 512;
+    auto mac_enter = [&](uint32_t m) {  // m-th multiply-accumulate of the launch (group, level)
+      if (two_quads) flag_wait(flags + 8, 2u * m + (uint32_t)(pair >> 1));
+    };
+    auto mac_leave = [&](uint32_t m) {  // after the quad_sync that ends it
+      if (two_quads && (wave & 3) == 0 && lane == 0) flag_set(flags + 8, 2u * m + (uint32_t)(pair >> 1) + 1u);
+    };
     const uint32_t ggsw_bytes = (uint32_t)(ggsw_c * sizeof(cplx));
     auto ldc = [](HxBuffer b, uint32_t voff, uint32_t soff) {
       const hx_f64x2 v = hx_buffer_load_f64x2(b, voff, soff);
@@ -958,9 +986,14 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
         HX_PRIO(WAVE_PRIO_MB_A);
         if constexpr (STATE32) {
           HX_UNROLL
-          for (int r = 0; r < 16; ++r)
+          for (int r = 0; r < 16; ++r) {
             d[r] = cplx{(double)decompose_one_level32(BASE_LOG_CT, st_re[r]),
                         (double)decompose_one_level32(BASE_LOG_CT, st_im[r])};
+            // the new state now: left alone, `state += carry` is sunk to the end of the level and both operands of
+            // every one of the 32 additions stay live (or are spilled) across the whole multiply-accumulate
+            HX_OPAQUE(st_re[r]);
+            HX_OPAQUE(st_im[r]);
+          }
           HX_WAVE_SYNC();
         } else {
           make_digits(d, 0, idx);
@@ -970,7 +1003,8 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
         HX_PRIO(WAVE_PRIO_MB_C);
         if constexpr (SHARE) {
           // ---- all four transforms of the quad are in its buffers (mapping M3: slot lane*17 + r)
-          HX_BLOCK_SYNC_LDS();
+          quad_sync();
+          mac_enter(grp * level + idx);
           WaveCtx cx = ctx0;
           HX_OPAQUE(cx.lane);
           const int ln = cx.lane;
@@ -1036,7 +1070,8 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
             HX_OPAQUE(oq_b[j].im);
             HX_SCHED_FENCE();
           }
-          HX_BLOCK_SYNC_LDS();  // every wave is done with the transforms of this level
+          quad_sync();  // every wave of the quad is done with the transforms of this level
+          mac_leave(grp * level + idx);
         } else
         {  // publish my transform, fetch the partner's, build the keybundle chunks and multiply-accumulate
           const uint32_t epoch = grp * level + idx + 1;
@@ -1133,7 +1168,7 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
           HX_UNROLL
           for (int j = 0; j < 8; ++j) pbuf[j] = oq_a[j];
         }
-        HX_BLOCK_SYNC_LDS();
+        quad_sync();
         if (quad_lwe == 0) {
           HX_UNROLL
           for (int j = 0; j < 8; ++j) {
