@@ -105,6 +105,9 @@
 #ifndef WAVE_MB_TURNS
 #define WAVE_MB_TURNS 0  // SHARE: the two quads of a workgroup take the multiply-accumulate in turns (measured slower: 60 vs 54 ms)
 #endif
+#ifndef WAVE_MB_SHARE_SETS
+#define WAVE_MB_SHARE_SETS 3  // SHARE: register sets in rotation (a request = the 2 rows of one point and subset)
+#endif
 #ifndef WAVE_MB_SETS
 #define WAVE_MB_SETS 4  // multi-bit: register sets in rotation (SETS - 1 key requests in flight)
 #endif
@@ -1002,9 +1005,6 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
         wave_forward(d, ctx);
         HX_PRIO(WAVE_PRIO_MB_C);
         if constexpr (SHARE) {
-          // ---- all four transforms of the quad are in its buffers (mapping M3: slot lane*17 + r)
-          quad_sync();
-          mac_enter(grp * level + idx);
           WaveCtx cx = ctx0;
           HX_OPAQUE(cx.lane);
           const int ln = cx.lane;
@@ -1017,7 +1017,7 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
           const cplx *fa0 = qbuf + fslot, *fa1 = (const cplx *)((const char *)qbuf + BUF_BYTES) + fslot;
           const cplx *fb0 = (const cplx *)((const char *)qbuf + 2 * BUF_BYTES) + fslot;
           const cplx *fb1 = (const cplx *)((const char *)qbuf + 3 * BUF_BYTES) + fslot;
-          constexpr int SETS = WAVE_MB_SETS, RW = 8, STEPS = RW * (int)per;
+          constexpr int SETS = WAVE_MB_SHARE_SETS, RW = 8, STEPS = RW * (int)per;
           cplx x0[SETS], x1[SETS];
           auto request = [&](int set, int t) {
             const uint32_t sidx = (uint32_t)(t % (int)per);
@@ -1027,6 +1027,11 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
           };
           HX_UNROLL
           for (int t = 0; t < SETS && t < STEPS; ++t) request(t, t);
+          HX_SCHED_FENCE();
+          // ---- all four transforms of the quad are in its buffers (mapping M3: slot lane*17 + r); the first key
+          // requests are already on their way
+          quad_sync();
+          mac_enter(grp * level + idx);
           HX_SCHED_FENCE();
           cplx ka0, ka1, kb0, kb1;
           HX_UNROLL

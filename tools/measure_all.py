@@ -30,7 +30,7 @@ def rand_u64(n):
 
 
 def timed(fn, steps=3, warmup=1):
-    if any(a in sys.argv for a in ("mb1", "lat1", "ntt1", "n1024x", "wave1", "ntt4096", "n1024x4096", "ks1")):
+    if any(a in sys.argv for a in ("mb1", "mb4one", "lat1", "ntt1", "n1024x", "wave1", "ntt4096", "n1024x4096", "ks1")):
         warmup = 0   # exactly one launch: the PMC passes of tools/pmc_record.py
     for _ in range(warmup):
         fn()
@@ -173,6 +173,8 @@ if __name__ == "__main__":
         pbs_case(C1, 1024, engine="ntt64", steps=1)
     if "mb1" in which:   # one launch, no warm-up (PMC passes)
         pbs_case(C4, 4096, steps=1)
+    if "mb4one" in which:   # one launch, no warm-up (PMC passes)
+        pbs_case(C4G4, 4096, steps=1)
     if "n1024" in which:
         pbs_case(C1P, 4096, steps=3)
     if "latency" in which:

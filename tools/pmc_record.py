@@ -32,6 +32,7 @@ TARGETS = {
     "fft": ("wave1", "pbs_fft_wave_kernel"),
     "ntt": ("ntt4096", "pbs_ntt"),
     "mb_g3": ("mb1", "pbs_"),
+    "mb_g4": ("mb4one", "pbs_"),
     "n1024": ("n1024x4096", "pbs_fft_wave3"),
     "ks": ("ks1", "ks_mfma"),
 }
