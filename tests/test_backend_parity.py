@@ -604,6 +604,37 @@ def test_multi_bit_throughput_kernel_equals_generic_and_oracle(kind, which):
 
 
 @pytest.mark.parametrize("kind", BACKENDS)
+@pytest.mark.parametrize("which,B", [("g3_l2", 259), ("g4_l1", 259), ("g3_l2", 771), ("g4_l1", 771)])
+def test_multi_bit_throughput_kernel_shared_key_loads(kind, which, B):
+    """With an even number of LWEs per workgroup (2 from 257 LWEs, 4 from 769) the quads of waves of the
+    throughput kernel share the key loads of their two LWEs (SHARE mode of pbs_fft_wave_kernel): a wave works on
+    one output column at 8 of a lane's 16 points for BOTH LWEs and hands half of its results over through LDS.
+    259 and 771 LWEs leave a ragged last workgroup (1 of 2, 3 of 4 LWEs present: the missing pairs redo the last
+    ciphertext and write nothing).  Same bits as the pair-per-LWE form (kernel choice 7) and as the oracle."""
+    from .common import TOY_MB_2048, TOY_MB4_2048
+    p = TOY_MB_2048 if which == "g3_l2" else TOY_MB4_2048
+    c = ctx(kind, p, "fft64")
+    lib = use_backend(kind)
+    msgs = [(5 * m + 2) % 16 for m in range(B)]
+    cts = encrypt_small(p, c.keys, msgs, seed=29)
+    f = lambda x: (x * x + 3) % 16
+    lut = orc.generate_lut(p.k, p.N, p.plaintext_modulus, p.delta, f)
+    try:
+        lib.hip_backend_set_fft_kernel(2)
+        shared = c.pbs(cts, lut)
+        assert lib.hip_backend_last_pbs_kernel() == 6
+        lib.hip_backend_set_fft_kernel(7)
+        pairs = c.pbs(cts, lut)
+        assert lib.hip_backend_last_pbs_kernel() == 6
+    finally:
+        lib.hip_backend_set_fft_kernel(0)
+    ref = oracle_pbs(p, c.keys, "fft64", cts, lut)
+    assert np.array_equal(shared, ref)
+    assert np.array_equal(pairs, ref)
+    assert [decrypt_big(p, c.keys, o) for o in shared[-8:]] == [f(m) for m in msgs[-8:]]
+
+
+@pytest.mark.parametrize("kind", BACKENDS)
 @pytest.mark.parametrize("which", ["g3", "g2", "g3_N2048", "g3_k3_N512"])
 def test_multi_bit_latency_path_equals_oracle(kind, which):
     """Small batches: all keybundles first (one workgroup per group and polynomial), then the external products
