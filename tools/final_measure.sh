@@ -14,6 +14,10 @@ TFHE_BENCH_FORCE_DIST=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29571 RANK=0 LOCAL_RAN
 # rocprofv3 kernel-trace statistics of the bench command itself
 cd /tmp && export TMPDIR=/tmp
 rm -rf $R/gpurun_out/${tag}_rocprof
-rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${tag}_rocprof -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline > $R/gpurun_out/${tag}_rocprof.log 2>&1
+# headline only (--no-extra): the average duration of the headline kernel must be that of bench.py's timed launches,
+# and the radix datapoint under `extra` launches the same kernel at other batch sizes
+rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${tag}_rocprof -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extra > $R/gpurun_out/${tag}_rocprof.log 2>&1
+rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${tag}_rocprof_extra -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline > $R/gpurun_out/${tag}_rocprof_extra.log 2>&1
 cd $R && python tools/rocprof_summary.py gpurun_out/${tag}_rocprof gpurun_out/${tag}_rocprof_stats.txt | head -14
+cd $R && python tools/rocprof_summary.py gpurun_out/${tag}_rocprof_extra gpurun_out/${tag}_rocprof_extra_stats.txt | head -3
 python tools/measure_all.py ks wave n1024 mb mb4 mblat ntt sweep > gpurun_out/${tag}_measure_all.jsonl 2>&1; cat gpurun_out/${tag}_measure_all.jsonl | cut -c1-260
