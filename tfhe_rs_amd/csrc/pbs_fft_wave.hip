@@ -757,9 +757,6 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
     b1 = bsk + ((((size_t)i * level + idx) * 2 + 1) * 2 + w) * n + lane;
   };
   auto key_request = [&](cplx (&k0)[4], cplx (&k1)[4], const cplx *b0, const cplx *b1, int ch) {
-#ifdef WAVE_EXPERIMENT_SKIP_KEY  // timing experiment only (wrong results): chunks >= this value are not loaded
-    if (ch >= WAVE_EXPERIMENT_SKIP_KEY) return;
-#endif
     HX_UNROLL
     for (int j = 0; j < 4; ++j) {
       k0[j] = load_global_cplx<false>(&b0[(ch * 4 + j) * 64]);
