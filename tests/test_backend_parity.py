@@ -634,6 +634,27 @@ def test_multi_bit_throughput_kernel_shared_key_loads(kind, which, B):
     assert [decrypt_big(p, c.keys, o) for o in shared[-8:]] == [f(m) for m in msgs[-8:]]
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", ["g3_l2", "g4_l1"])
+def test_multi_bit_shared_key_loads_full_launch_ragged(which):
+    """4099 LWEs (1025 workgroups of 4, the last one with 3 present; more than one wave of workgroups per XCD, so
+    the per-quad pacing counters run through several batches): every output word against the oracle, and the same
+    call twice gives the same bytes."""
+    from .common import TOY_MB_2048, TOY_MB4_2048
+    p = TOY_MB_2048 if which == "g3_l2" else TOY_MB4_2048
+    c = ctx("hip", p, "fft64")
+    B = 4099
+    msgs = [(7 * m + 1) % 16 for m in range(B)]
+    cts = encrypt_small(p, c.keys, msgs, seed=37)
+    f = lambda x: (3 * x + 5) % 16
+    lut = orc.generate_lut(p.k, p.N, p.plaintext_modulus, p.delta, f)
+    out = c.pbs(cts, lut)
+    assert use_backend("hip").hip_backend_last_pbs_kernel() == 6
+    assert np.array_equal(out, c.pbs(cts, lut))
+    assert np.array_equal(out, oracle_pbs(p, c.keys, "fft64", cts, lut))
+    assert [decrypt_big(p, c.keys, o) for o in out[-16:]] == [f(m) for m in msgs[-16:]]
+
+
 @pytest.mark.parametrize("kind", BACKENDS)
 @pytest.mark.parametrize("which", ["g3", "g2", "g3_N2048", "g3_k3_N512"])
 def test_multi_bit_latency_path_equals_oracle(kind, which):
