@@ -300,7 +300,9 @@ def main():
         d_out3 = gpu.CudaLweCiphertextList.new(p.k * p.N, B, streams)
         buf3 = C.c_void_p()
         lib.scratch_cuda_programmable_bootstrap_64_async(s, g, C.byref(buf3), p.n, p.k, p.N, p.pbs_level, B, True, 1)
-        dp = datapoint(p, lambda: lib.hip_programmable_bootstrap_ntt64_async(
+        ntt_launch = (lib.hip_programmable_bootstrap_ntt64_crt_async if bsk_n.engine_impl == "ntt64_crt"
+                      else lib.hip_programmable_bootstrap_ntt64_async)
+        dp = datapoint(p, lambda: ntt_launch(
             s, g, d_out3.d_vec.ptr, idx.ptr, d_lut.d_vec.ptr, lidx.ptr, d_in.d_vec.ptr, idx.ptr, bsk_n.d_vec.ptr, buf3,
             p.n, p.k, p.N, p.pbs_base_log, p.pbs_level, B, 1, 0), steps=2)
         out3 = d_out3.to_lwe_ciphertext_list(streams)

@@ -217,6 +217,27 @@ void hip_programmable_bootstrap_ntt64_async(
     uint32_t polynomial_size, uint32_t base_log, uint32_t level_count,
     uint32_t num_samples, uint32_t num_many_lut, uint32_t lut_stride);
 
+/* The same engine computed on the FP64 pipes (pbs_ntt_crt.hip): the products are taken modulo two primes below
+ * 2^49.5 with exact 6-instruction FP64 modular multiplications and recombined; identical outputs to
+ * hip_programmable_bootstrap_ntt64_async, about twice as fast on the MI355X.  Accepts the parameter sets for which
+ * hip_programmable_bootstrap_ntt64_crt_supported() holds (ceil(log2((k+1) l N)) + base_log <= 35: the exact integer
+ * product must stay below p1 p2 / 2).  The key buffer takes TWICE the bytes of the standard key: n*(k+1)^2*l*N*16. */
+bool hip_programmable_bootstrap_ntt64_crt_supported(
+    uint32_t glwe_dimension, uint32_t polynomial_size, uint32_t level_count,
+    uint32_t base_log);
+void hip_convert_lwe_programmable_bootstrap_key_ntt64_crt_async(
+    void *stream, uint32_t gpu_index, void *dest, void const *src,
+    uint32_t input_lwe_dim, uint32_t glwe_dim, uint32_t level_count,
+    uint32_t polynomial_size);
+void hip_programmable_bootstrap_ntt64_crt_async(
+    void *stream, uint32_t gpu_index, void *lwe_array_out,
+    void const *lwe_output_indexes, void const *lut_vector,
+    void const *lut_vector_indexes, void const *lwe_array_in,
+    void const *lwe_input_indexes, void const *bootstrapping_key,
+    int8_t *buffer, uint32_t lwe_dimension, uint32_t glwe_dimension,
+    uint32_t polynomial_size, uint32_t base_log, uint32_t level_count,
+    uint32_t num_samples, uint32_t num_many_lut, uint32_t lut_stride);
+
 /* Exact-integer engine (negacyclic convolution mod 2^64 on the standard-domain key,
  * cc/algorithms/lwe_programmable_bootstrapping/karatsuba_pbs.rs:71-116,199-413).  O(N^2): a
  * verification engine; it reproduces the reference's golden *_karatsuba vectors bit for bit. */
@@ -370,7 +391,7 @@ void hip_backend_set_keyswitch_kernel(uint32_t which);
 void hip_backend_set_ntt_kernel(uint32_t which);
 /* last launched PBS kernel, for tests: 1 generic f64, 2 wave f64, 3 generic ntt, 4 generic multi-bit,
  * 5 exact, 6 wave multi-bit, 7 block (latency), 8 block dual-stream, 9 wave f64 for N = 1024,
- * 10 multi-bit latency path, 11 reference-order f64 engine */
+ * 10 multi-bit latency path, 11 reference-order f64 engine, 12 NTT engine in its two-prime FP64 form */
 uint32_t hip_backend_last_pbs_kernel(void);
 const char *hip_backend_version(void);
 

@@ -154,8 +154,11 @@ class CudaGlweCiphertextList:
 class CudaLweBootstrapKey:
     """Bootstrap key converted once per GPU of `streams` (lwe_bootstrap_key.rs:57-104,
     gpu/ffi.rs:744-787).  engine 'fft64' is the reference GPU path; 'ntt64' the Goldilocks
-    extension, 'exact64' the O(N^2) exact-convolution verification engine, 'ref64' the reference-order f64
-    verification engine (tfhe-fft's dif4 plan: reproduces the reference's f64 golden vectors)."""
+    extension (integer arithmetic modulo 2^64 - 2^32 + 1), 'ntt64_crt' the same function computed on the FP64 pipes
+    modulo two 50-bit primes (a key of twice the bytes; identical outputs, measured 8 % slower on the MI355X: kept as a
+    second, independent implementation of the exact engine); 'exact64' the O(N^2)
+    exact-convolution verification engine, 'ref64' the reference-order f64 verification engine (tfhe-fft's dif4
+    plan: reproduces the reference's f64 golden vectors)."""
 
     def __init__(self):
         self.d_vec = None
@@ -171,16 +174,23 @@ class CudaLweBootstrapKey:
         self.decomp_base_log = int(decomp_base_log)
         self.decomp_level_count = int(decomp_level_count)
         self.ms_noise_reduction = bool(ms_noise_reduction)
-        self.engine = engine
+        self.engine = "ntt64" if engine == "ntt64_crt" else engine
+        self.engine_impl = "ntt64_int" if engine == "ntt64" else engine
+        if engine == "ntt64_crt":
+            assert _lib().hip_programmable_bootstrap_ntt64_crt_supported(
+                glwe_dimension, polynomial_size, decomp_level_count, decomp_base_log), \
+                "parameter set outside the two-prime form of the NTT engine"
+        engine = self.engine_impl
         h_bsk = np.ascontiguousarray(h_bsk, dtype=U64)
         elems = (self.input_lwe_dimension * (glwe_dimension + 1) ** 2 * decomp_level_count * polynomial_size)
         assert h_bsk.size == elems, "bootstrap key container has the wrong size"
-        # n*(k+1)^2*l*N f64 per GPU — same byte size for both engines
+        # n*(k+1)^2*l*N f64 per GPU — the byte size of the standard key; two residues per value for 'ntt64_crt'
         self.d_vecs = []
         for i in range(len(streams)):
-            d = CudaVec(elems, streams, i, np.float64)
+            d = CudaVec(elems * (2 if engine == "ntt64_crt" else 1), streams, i, np.float64)
             conv = {"fft64": _lib().cuda_convert_lwe_programmable_bootstrap_key_64_async,
-                    "ntt64": _lib().hip_convert_lwe_programmable_bootstrap_key_ntt64_async,
+                    "ntt64_int": _lib().hip_convert_lwe_programmable_bootstrap_key_ntt64_async,
+                    "ntt64_crt": _lib().hip_convert_lwe_programmable_bootstrap_key_ntt64_crt_async,
                     "exact64": _lib().hip_convert_lwe_programmable_bootstrap_key_exact64_async,
                     "ref64": _lib().hip_convert_lwe_programmable_bootstrap_key_ref64_async}[engine]
             conv(streams.ptr[i], streams.gpu_indexes[i], d.ptr, h_bsk.ctypes.data_as(C.c_void_p),
@@ -268,9 +278,10 @@ def cuda_programmable_bootstrap_lwe_ciphertext(input, output, accumulator, lut_i
         s, g, C.byref(buf), bsk.input_lwe_dimension, bsk.glwe_dimension, bsk.polynomial_size,
         bsk.decomp_level_count, num_samples, True, 1 if bsk.ms_noise_reduction else 0)
     launch = {"fft64": lib.cuda_programmable_bootstrap_64_async,
-              "ntt64": lib.hip_programmable_bootstrap_ntt64_async,
+              "ntt64_int": lib.hip_programmable_bootstrap_ntt64_async,
+              "ntt64_crt": lib.hip_programmable_bootstrap_ntt64_crt_async,
               "exact64": lib.hip_programmable_bootstrap_exact64_async,
-              "ref64": lib.hip_programmable_bootstrap_ref64_async}[bsk.engine]
+              "ref64": lib.hip_programmable_bootstrap_ref64_async}[bsk.engine_impl]
     launch(s, g, output.d_vec.ptr, output_indexes.ptr, accumulator.d_vec.ptr, lut_indexes.ptr,
            input.d_vec.ptr, input_indexes.ptr, bsk.d_vec.ptr, buf, bsk.input_lwe_dimension, bsk.glwe_dimension,
            bsk.polynomial_size, bsk.decomp_base_log, bsk.decomp_level_count, num_samples, num_many_lut, lut_stride)
