@@ -382,7 +382,7 @@ uint64_t hip_integer_propagate_pbs_count(uint32_t num_blocks);
 void hip_backend_set_fft_kernel(uint32_t which);
 /* test hook: cap of the groups the multi-bit latency path processes per pass (0 = what the scratch holds) */
 void hip_backend_set_multibit_latency_groups(uint32_t groups);
-/* keyswitch kernel: 0 = automatic (int8 matrix-core GEMM for >= 64 LWEs when level <= 16 (padded to a power of
+/* keyswitch kernel: 0 = automatic (int8 matrix-core GEMM, any batch size, when level <= 16 (padded to a power of
  * two), base_log <= 6 and n_in*padded level is a multiple of 32; scalar kernels otherwise), 1 = scalar kernels only.
  * Identical bits either way. */
 void hip_backend_set_keyswitch_kernel(uint32_t which);
