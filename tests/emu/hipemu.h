@@ -25,7 +25,7 @@
 #define __forceinline__ inline __attribute__((always_inline))
 #define __launch_bounds__(...)
 #define __restrict__ __restrict
-#define __shared__ static
+#define __shared__ static thread_local  // one block at a time per host thread: per-block storage
 
 struct dim3 {
   unsigned x, y, z;

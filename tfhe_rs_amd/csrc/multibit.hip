@@ -112,24 +112,51 @@ __global__ void __launch_bounds__(GenericCfg<N>::TPB)
 // n/g external products remain sequential.  Same integer combine, same transforms, same product order as
 // pbs_multi_bit_kernel: identical bits.  Groups are processed in chunks of at most `gcount` (the scratch is
 // sized without knowing n, like the reference's lwe_chunk_size), the accumulator crossing chunks in `acc_g`.
+// One workgroup per (group, keybundle polynomial, tile of MB_KB_TILE ciphertexts): every key element is loaded once
+// and combined for the whole tile (the monomial factors differ per ciphertext, the key does not) — with one
+// ciphertext per workgroup 32 ciphertexts re-read the 241 MB key 32 times from L2 (2.5 ms for a round of 32 blocks
+// of the radix layer).  Same combine order per ciphertext: identical bits.
+constexpr int MB_KB_TILE = 8;
 template <int N, int K1>
 __global__ void __launch_bounds__(GenericCfg<N>::TPB)
     mb_keybundle_kernel(PbsArgs a, uint32_t grouping, cplx *kb_lat, FftTables tb, uint32_t g0, uint32_t gcount) {
-  constexpr int n = N / 2, TPB = GenericCfg<N>::TPB, LOG2N2 = ilog2_c(2 * N);
+  constexpr int n = N / 2, TPB = GenericCfg<N>::TPB, LOG2N2 = ilog2_c(2 * N), S = MB_KB_TILE;
+  HX_DYN_SMEM(smem);
+  uint32_t (*sdeg)[16] = (uint32_t (*)[16])smem;  // [S][16]
   const int tid = threadIdx.x;
-  const uint32_t sample = blockIdx.y;
+  const uint32_t s0 = blockIdx.y * S;
+  const uint32_t count = a.num_samples - s0 < (uint32_t)S ? a.num_samples - s0 : (uint32_t)S;
   const size_t kb_polys = (size_t)a.level * K1 * K1;
   const uint32_t gl = blockIdx.x / (uint32_t)kb_polys, poly = blockIdx.x % (uint32_t)kb_polys, grp = g0 + gl;
-  const uint64_t *lwe = a.lwe_in + (size_t)a.in_idx[sample] * (a.n + 1);
   const uint32_t per = 1u << grouping;
   const size_t ggsw_c = kb_polys * n;
   const cplx *gk = (const cplx *)a.bsk + (size_t)grp * per * ggsw_c;
-  uint32_t deg[16];
-  multi_bit_degrees(lwe + (size_t)grp * grouping, grouping, LOG2N2, deg);
+  if (tid < S) {  // the subset degrees of ciphertext s0 + tid
+    uint32_t deg[16];
+    for (int q = 0; q < 16; ++q) deg[q] = 0;
+    if ((uint32_t)tid < count) {
+      const uint64_t *lwe = a.lwe_in + (size_t)a.in_idx[s0 + tid] * (a.n + 1);
+      multi_bit_degrees(lwe + (size_t)grp * grouping, grouping, LOG2N2, deg);
+    }
+    for (int q = 0; q < 16; ++q) sdeg[tid][q] = deg[q];
+  }
+  __syncthreads();
   // pointwise combine; parked in transform-POSITION order (what the accumulate kernels index)
-  cplx *kb = kb_lat + (((size_t)sample * gcount + gl) * kb_polys + poly) * n;
-  for (uint32_t pos = tid; pos < (uint32_t)n; pos += TPB)
-    kb[pos] = keybundle_point<N>(gk, ggsw_c, poly, bsk_slot<N, K1>(pos), pos, per, deg, tb.mono);
+  for (uint32_t pos = tid; pos < (uint32_t)n; pos += TPB) {
+    const uint32_t slot = bsk_slot<N, K1>(pos);
+    cplx kb[S];
+    const cplx k0 = gk[poly * n + slot];  // subset 0: not rotated
+    HX_UNROLL
+    for (int j = 0; j < S; ++j) kb[j] = k0;
+    for (uint32_t sb = 1; sb < per; ++sb) {
+      const cplx ks = gk[(size_t)sb * ggsw_c + poly * n + slot];
+      HX_UNROLL
+      for (int j = 0; j < S; ++j) kb[j] = cmul_add(ks, monomial_factor<N>(tb.mono, pos, sdeg[j][sb]), kb[j]);
+    }
+    HX_UNROLL
+    for (int j = 0; j < S; ++j)
+      if ((uint32_t)j < count) kb_lat[(((size_t)(s0 + j) * gcount + gl) * kb_polys + poly) * n + pos] = kb[j];
+  }
 }
 
 template <int N, int K1>
@@ -292,8 +319,9 @@ static void launch_mb_latency(hipStream_t st, const MultiBitArgs &m, const FftTa
     hx_set_dynamic_smem_once<mb_accumulate_kernel<N, K1>>(smem_b);
   for (uint32_t g0 = 0; g0 < groups; g0 += group_chunk) {
     const uint32_t gpass = groups - g0 < group_chunk ? groups - g0 : group_chunk;
-    HX_LAUNCH((mb_keybundle_kernel<N, K1>), dim3(gpass * kb_polys, a.num_samples), dim3(GenericCfg<N>::TPB), 0, st, a,
-              m.grouping_factor, kb_lat, tb, g0, group_chunk);
+    HX_LAUNCH((mb_keybundle_kernel<N, K1>), dim3(gpass * kb_polys, (a.num_samples + MB_KB_TILE - 1) / MB_KB_TILE),
+              dim3(GenericCfg<N>::TPB), MB_KB_TILE * 16 * sizeof(uint32_t), st, a, m.grouping_factor, kb_lat, tb, g0,
+              group_chunk);
     if (N == 2048 && K1 == 2 && a.level <= 8 && !g_ntt_kernel_serial && g_multibit_latency_block)
       // the latency kernel's structure (registers + wave-local exchanges, 4 barriers per product)
       launch_mb_accumulate_block(st, a, tb, (const cplx *)kb_lat, acc_g, group_chunk, gpass, (int)(g0 == 0),
