@@ -680,6 +680,7 @@ def test_multi_bit_latency_path_equals_oracle(kind, which):
         lib.hip_backend_set_fft_kernel(5)
         one_pass = c.pbs(cts, lut)
         assert lib.hip_backend_last_pbs_kernel() == 10
+        pair = c.pbs(cts[:2], lut)             # below 4 ciphertexts: one keybundle workgroup per ciphertext
         lib.hip_backend_set_multibit_latency_groups(2)
         chunked = c.pbs(cts, lut)
         lib.hip_backend_set_ntt_kernel(1)      # products in the single-group kernel instead of one group per row
@@ -697,6 +698,7 @@ def test_multi_bit_latency_path_equals_oracle(kind, which):
         lib.hip_backend_set_ntt_kernel(0)
         lib.hip_backend_set_multibit_latency_groups(0)
     assert np.array_equal(one_pass, ref)
+    assert np.array_equal(pair, ref[:2])
     assert np.array_equal(chunked, ref)
     assert np.array_equal(single_group, ref)
     assert np.array_equal(generic_products, ref)

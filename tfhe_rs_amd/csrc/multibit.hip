@@ -116,11 +116,11 @@ __global__ void __launch_bounds__(GenericCfg<N>::TPB)
 // and combined for the whole tile (the monomial factors differ per ciphertext, the key does not) — with one
 // ciphertext per workgroup 32 ciphertexts re-read the 241 MB key 32 times from L2 (2.5 ms for a round of 32 blocks
 // of the radix layer).  Same combine order per ciphertext: identical bits.
-constexpr int MB_KB_TILE = 8;
-template <int N, int K1>
+constexpr int MB_KB_TILE = 8;  // from 4 ciphertexts up; below, one ciphertext per workgroup (S = 1)
+template <int N, int K1, int S>
 __global__ void __launch_bounds__(GenericCfg<N>::TPB)
     mb_keybundle_kernel(PbsArgs a, uint32_t grouping, cplx *kb_lat, FftTables tb, uint32_t g0, uint32_t gcount) {
-  constexpr int n = N / 2, TPB = GenericCfg<N>::TPB, LOG2N2 = ilog2_c(2 * N), S = MB_KB_TILE;
+  constexpr int n = N / 2, TPB = GenericCfg<N>::TPB, LOG2N2 = ilog2_c(2 * N);
   HX_DYN_SMEM(smem);
   uint32_t (*sdeg)[16] = (uint32_t (*)[16])smem;  // [S][16]
   const int tid = threadIdx.x;
@@ -319,9 +319,13 @@ static void launch_mb_latency(hipStream_t st, const MultiBitArgs &m, const FftTa
     hx_set_dynamic_smem_once<mb_accumulate_kernel<N, K1>>(smem_b);
   for (uint32_t g0 = 0; g0 < groups; g0 += group_chunk) {
     const uint32_t gpass = groups - g0 < group_chunk ? groups - g0 : group_chunk;
-    HX_LAUNCH((mb_keybundle_kernel<N, K1>), dim3(gpass * kb_polys, (a.num_samples + MB_KB_TILE - 1) / MB_KB_TILE),
-              dim3(GenericCfg<N>::TPB), MB_KB_TILE * 16 * sizeof(uint32_t), st, a, m.grouping_factor, kb_lat, tb, g0,
-              group_chunk);
+    if (a.num_samples < 4)
+      HX_LAUNCH((mb_keybundle_kernel<N, K1, 1>), dim3(gpass * kb_polys, a.num_samples), dim3(GenericCfg<N>::TPB),
+                16 * sizeof(uint32_t), st, a, m.grouping_factor, kb_lat, tb, g0, group_chunk);
+    else
+      HX_LAUNCH((mb_keybundle_kernel<N, K1, MB_KB_TILE>), dim3(gpass * kb_polys, (a.num_samples + MB_KB_TILE - 1) / MB_KB_TILE),
+                dim3(GenericCfg<N>::TPB), MB_KB_TILE * 16 * sizeof(uint32_t), st, a, m.grouping_factor, kb_lat, tb, g0,
+                group_chunk);
     if (N == 2048 && K1 == 2 && a.level <= 8 && !g_ntt_kernel_serial && g_multibit_latency_block)
       // the latency kernel's structure (registers + wave-local exchanges, 4 barriers per product)
       launch_mb_accumulate_block(st, a, tb, (const cplx *)kb_lat, acc_g, group_chunk, gpass, (int)(g0 == 0),
