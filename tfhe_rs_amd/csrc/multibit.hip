@@ -141,11 +141,9 @@ __global__ void __launch_bounds__(GenericCfg<N>::TPB)
     for (int q = 0; q < 16; ++q) sdeg[tid][q] = deg[q];
   }
   __syncthreads();
-  // pointwise combine; parked in the key's own storage order (bsk_slot), so that the loads of the key and the stores
-  // of the keybundles are both contiguous across the workgroup (in position order the loads of the N = 2048 layout
-  // were 16 bytes at a stride of 1 KB: 1 TB/s; the whole 241 MB key is read once per tile of ciphertexts)
-  for (uint32_t slot = tid; slot < (uint32_t)n; slot += TPB) {
-    const uint32_t pos = (uint32_t)bsk_pos<N, K1>((int)slot);
+  // pointwise combine; parked in transform-POSITION order (what the accumulate kernels index)
+  for (uint32_t pos = tid; pos < (uint32_t)n; pos += TPB) {
+    const uint32_t slot = bsk_slot<N, K1>(pos);
     cplx kb[S];
     const cplx k0 = gk[poly * n + slot];  // subset 0: not rotated
     HX_UNROLL
@@ -157,7 +155,7 @@ __global__ void __launch_bounds__(GenericCfg<N>::TPB)
     }
     HX_UNROLL
     for (int j = 0; j < S; ++j)
-      if ((uint32_t)j < count) kb_lat[(((size_t)(s0 + j) * gcount + gl) * kb_polys + poly) * n + slot] = kb[j];
+      if ((uint32_t)j < count) kb_lat[(((size_t)(s0 + j) * gcount + gl) * kb_polys + poly) * n + pos] = kb[j];
   }
 }
 
@@ -206,7 +204,7 @@ __global__ void __launch_bounds__(GenericCfg<N>::TPB)
         for (int c = 0; c < K1; ++c)
           for (int q = 0; q < PER; ++q) {
             const int pos = tid + q * TPB;
-            const cplx y = brow[(size_t)c * n + bsk_slot<N, K1>(pos)];
+            const cplx y = brow[(size_t)c * n + pos];
             facc[c][q] = firstp ? cmul_first(fbuf[pos], y) : cmul_add(fbuf[pos], y, facc[c][q]);
           }
         firstp = false;
@@ -282,7 +280,7 @@ __global__ void __launch_bounds__(K1 *GenericCfg<N>::TPB)
         const FBuf f{fbase + (size_t)row * fbuf_slots(N)};
         for (int q = 0; q < PER; ++q) {
           const int pos = lt + q * TPB;
-          const cplx y = brow[bsk_slot<N, K1>(pos)];
+          const cplx y = brow[pos];
           facc[q] = (idx == 0 && row == 0) ? cmul_first(f[pos], y) : cmul_add(f[pos], y, facc[q]);
         }
       }

@@ -52,13 +52,6 @@ HX_DEV int bsk_slot(int pos) {
   if constexpr (N == 1024 && (K1 == 2 || K1 == 3)) return (pos & 7) * 64 + (pos >> 3);  // pbs_fft_wave3.hip, layout LC
   return pos;
 }
-// inverse: the transform position stored at `slot`
-template <int N, int K1>
-HX_DEV int bsk_pos(int slot) {
-  if constexpr (N == 2048 && K1 == 2) return (slot & 63) * 16 + (slot >> 6);
-  if constexpr (N == 1024 && (K1 == 2 || K1 == 3)) return (slot & 63) * 8 + (slot >> 6);
-  return slot;
-}
 
 // ---------------------------------------------------------------- multi-bit: Fourier-domain keybundle
 // The CPU reference keeps the multi-bit key in the Fourier domain and combines the 2^g GGSWs of a group there

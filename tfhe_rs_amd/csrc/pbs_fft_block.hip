@@ -110,11 +110,11 @@ HX_DEV void swap_lane54(cplx (&d)[4]) {
 }
 
 // MB (multi-bit latency path, multibit.hip): the "key" of group gl is the keybundle parked by mb_keybundle_kernel
-// in the key's storage order, the product takes the accumulator itself (no rotation) and OVERWRITES it
+// in transform-position order, the product takes the accumulator itself (no rotation) and OVERWRITES it
 // (cc/algorithms/lwe_multi_bit_programmable_bootstrapping.rs:647-880); groups come in passes of at most `gcount`,
 // the accumulator crossing passes in `acc_g`.
 struct MbLatArgs {
-  const cplx *kb = nullptr;   // [sample][gcount][level][row][col][n], each polynomial in the key's storage order
+  const cplx *kb = nullptr;   // [sample][gcount][level][row][col][n]
   uint64_t *acc_g = nullptr;  // [sample][2][N]
   uint32_t gcount = 0, gpass = 0;
   int first = 1, last = 1;
@@ -239,7 +239,7 @@ __global__ void __launch_bounds__(TPB) pbs_fft_block_kernel(PbsArgs a, FftTables
       cplx k0[4], k1[4];
       HX_UNROLL
       for (int r = 0; r < 4; ++r) {
-        const int slot = bsk_slot<N, 2>(4 * t + r);  // parked keybundles are stored like the key
+        const int slot = MB ? 4 * t + r : bsk_slot<N, 2>(4 * t + r);  // parked keybundles are in position order
         k0[r] = b0[slot];
         k1[r] = b1[slot];
       }
