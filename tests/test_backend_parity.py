@@ -254,6 +254,31 @@ def test_keyswitch_matrix_core_path_equals_scalar_kernels_and_oracle(kind, ks):
 
 
 @pytest.mark.parametrize("kind", BACKENDS)
+@pytest.mark.parametrize("p", [TOY_2048, TOY_2048_L2, TOY_1024_K2], ids=lambda p: p.name)
+def test_keyswitch_matrix_core_path_small_batches(kind, p):
+    """Every batch size takes the matrix-core kernel; up to 32 LWEs the four waves of a workgroup split the K
+    dimension and add their accumulators through LDS (the rounds of one radix operation are 7 to 32 blocks).  1, 7,
+    31, 32 LWEs (split) and 33 (not split) against the scalar kernels and the oracle; power-of-two and padded level
+    counts, 64- and (via test_keyswitch_64_32_*) 32-bit keys."""
+    c = ctx(kind, p, "fft64", with_ksk=True)
+    lib = use_backend(kind)
+    for count in (1, 7, 31, 32, 33):
+        msgs = [(3 * m + 1) % p.plaintext_modulus for m in range(count)]
+        cts = encrypt_big(p, c.keys, msgs, seed=40 + count)
+        try:
+            lib.hip_backend_set_keyswitch_kernel(0)
+            out = c.keyswitch(cts)
+            lib.hip_backend_set_keyswitch_kernel(1)
+            scalar = c.keyswitch(cts)
+        finally:
+            lib.hip_backend_set_keyswitch_kernel(0)
+        ref = orc.keyswitch_batch(cts, c.keys.ksk, p.k * p.N, p.n, p.ks_base_log, p.ks_level)
+        assert np.array_equal(scalar, ref), count
+        assert np.array_equal(out, ref), count
+        assert [decrypt_small(p, c.keys, o) for o in out] == msgs
+
+
+@pytest.mark.parametrize("kind", BACKENDS)
 @pytest.mark.parametrize("p", [TOY_1024_K2, TOY_2048_L2], ids=lambda p: p.name)
 def test_keyswitch_matrix_core_path_with_padded_levels(kind, p):
     """Level counts that are not a power of two (5 levels of base 2^3 from k N = 2048; 6 of 2^3) run on the

@@ -260,7 +260,11 @@ __global__ void __launch_bounds__(256) ksk_planes_kernel(int8_t *planes, uint64_
 
 // PADDED: `level` < LEVEL real levels per mask word, the rest zero digits against zero key rows
 // OutT = uint32_t: the 64->32 keyswitch (4 planes, arithmetic mod 2^32, body rounded to 32 bits)
-template <int LEVEL, bool PADDED, typename OutT>
+// KSPLIT = 4 (batches of at most 32 LWEs: one tile of samples per workgroup): the four waves of a workgroup take a
+// quarter of the K dimension each for the SAME tile and add their integer accumulators through LDS — the key is
+// streamed four times faster for the latency-bound rounds of the radix layer (7 to 32 blocks)
+#define PLANES_OF(T) ((int)sizeof(T))
+template <int LEVEL, bool PADDED, typename OutT, int KSPLIT = 1>
 __global__ void __launch_bounds__(256) ks_mfma_kernel(OutT *lwe_out, const uint64_t *out_idx, const uint64_t *lwe_in,
                                                       const uint64_t *in_idx, const int8_t *planes,
                                                       const uint64_t *colsum, uint32_t n_in, uint32_t n_out,
@@ -268,10 +272,11 @@ __global__ void __launch_bounds__(256) ks_mfma_kernel(OutT *lwe_out, const uint6
                                                       uint32_t level) {  // level <= LEVEL (the padded count)
   constexpr int PLANES = (int)sizeof(OutT);
   __shared__ int32_t sa[4][2][32];  // per wave: sum of the shifted digits of every row, per k half
+  __shared__ int32_t red[KSPLIT > 1 ? 2 : 1][KSPLIT > 1 ? PLANES_OF(OutT) : 1][KSPLIT > 1 ? 16 : 1][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int row = lane & 31, h = lane >> 5;
   const uint32_t ct = blockIdx.x;
-  const uint32_t stile = blockIdx.y * 4 + wave;
+  const uint32_t stile = KSPLIT > 1 ? blockIdx.y : blockIdx.y * 4 + wave;
   const uint32_t s = stile * 32 + row;
   const bool live = stile * 32 < num_samples;       // whole wave
   const uint32_t s_ld = s < num_samples ? s : 0;    // rows past the batch compute on sample 0 and store nothing
@@ -287,17 +292,20 @@ __global__ void __launch_bounds__(256) ks_mfma_kernel(OutT *lwe_out, const uint6
   if (live) {
     // mask words of step st+1 are requested before step st is decomposed (n_in + 1 words per LWE: the last
     // request of the last step reads at most the body, in range)
+    // my share of the steps (all of them unless the waves split K)
+    const uint32_t st_lo = KSPLIT > 1 ? (steps / KSPLIT) * (uint32_t)wave : 0u;
+    const uint32_t st_hi = KSPLIT > 1 ? st_lo + steps / KSPLIT : steps;
     uint64_t xn[WORDS];
     HX_UNROLL
-    for (int q = 0; q < WORDS; ++q) xn[q] = x[(h * 16) / LEVEL + q];
-    for (uint32_t st = 0; st < steps; ++st) {
+    for (int q = 0; q < WORDS; ++q) xn[q] = x[(st_lo * 32 + h * 16) / LEVEL + q];
+    for (uint32_t st = st_lo; st < st_hi; ++st) {
       // A operand: k = st*32 + h*16 + j  <->  mask word (k / LEVEL), level index (k % LEVEL), level l first
       hx_i8x16 av;
       uint32_t bytes[16];
       uint64_t xc[WORDS];
       HX_UNROLL
       for (int q = 0; q < WORDS; ++q) xc[q] = xn[q];
-      if (st + 1 < steps) {
+      if (st + 1 < st_hi) {
         const uint32_t w1 = ((st + 1) * 32 + h * 16) / LEVEL;
         HX_UNROLL
         for (int q = 0; q < WORDS; ++q) xn[q] = x[w1 + q];
@@ -345,7 +353,29 @@ __global__ void __launch_bounds__(256) ks_mfma_kernel(OutT *lwe_out, const uint6
     }
   }
   sa[wave][h][row] = my_sa;
-  __syncthreads();
+  if constexpr (KSPLIT > 1) {  // waves 2, 3 -> 0, 1; then wave 1 -> 0 (integer sums: exact in any order)
+    HX_UNROLL
+    for (int round = 0; round < 2; ++round) {
+      const int senders_from = round == 0 ? 2 : 1, senders_to = round == 0 ? 4 : 2;
+      if (wave >= senders_from && wave < senders_to) {
+        HX_UNROLL
+        for (int p = 0; p < PLANES; ++p)
+          HX_UNROLL
+          for (int r = 0; r < 16; ++r) red[wave - senders_from][p][r][lane] = acc[p].v[r];
+      }
+      __syncthreads();
+      if (wave < senders_to - senders_from) {  // round 0: waves 0, 1 take 2, 3; round 1: wave 0 takes 1
+        HX_UNROLL
+        for (int p = 0; p < PLANES; ++p)
+          HX_UNROLL
+          for (int r = 0; r < 16; ++r) acc[p].v[r] += red[wave][p][r][lane];
+      }
+      __syncthreads();
+    }
+    if (wave != 0) return;
+  } else {
+    __syncthreads();
+  }
   if (!live) return;
   const uint32_t col = ct * KSM_CT + (lane & 31);
   if (col > n_out) return;
@@ -355,7 +385,11 @@ __global__ void __launch_bounds__(256) ks_mfma_kernel(OutT *lwe_out, const uint6
     const int orow = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
     const uint32_t so = stile * 32 + orow;
     if (so >= num_samples) continue;
-    const int64_t sum_a = (int64_t)sa[wave][0][orow] + sa[wave][1][orow];
+    int64_t sum_a = (int64_t)sa[wave][0][orow] + sa[wave][1][orow];
+    if constexpr (KSPLIT > 1) {
+      HX_UNROLL
+      for (int ww = 1; ww < KSPLIT; ++ww) sum_a += (int64_t)sa[ww][0][orow] + sa[ww][1][orow];
+    }
     uint64_t v = 0;
     HX_UNROLL
     for (int p = 0; p < PLANES; ++p) v += (uint64_t)((int64_t)acc[p].v[r] + 128 * sum_a) << (8 * p);
@@ -485,10 +519,18 @@ static bool keyswitch_mfma(hipStream_t st, OutT *lwe_out, const uint64_t *out_id
     planes = (int8_t *)hit->planes;
     colsum = (uint64_t *)((char *)hit->planes + hit->plane_bytes);
   }
-  const dim3 grid(col_tiles, (num_samples + 127) / 128);
+  // up to 32 LWEs: one tile of samples, the four waves of a workgroup split K (needs steps = K / 32 divisible by 4)
+  const bool split = num_samples <= 32 && (K / 32) % 4 == 0;
+  const dim3 grid(col_tiles, split ? 1 : (num_samples + 127) / 128);
 #define KSM_LAUNCH(L)                                                                                              \
   do {                                                                                                               \
-    if (level == L)                                                                                                  \
+    if (split && level == L)                                                                                         \
+      HX_LAUNCH((ks_mfma_kernel<L, false, OutT, 4>), grid, dim3(256), 0, st, lwe_out, out_idx, lwe_in, in_idx,       \
+                planes, colsum, n_in, n_out, base_log, num_samples, col_tiles, level);                               \
+    else if (split)                                                                                                  \
+      HX_LAUNCH((ks_mfma_kernel<L, true, OutT, 4>), grid, dim3(256), 0, st, lwe_out, out_idx, lwe_in, in_idx,        \
+                planes, colsum, n_in, n_out, base_log, num_samples, col_tiles, level);                               \
+    else if (level == L)                                                                                             \
       HX_LAUNCH((ks_mfma_kernel<L, false, OutT>), grid, dim3(256), 0, st, lwe_out, out_idx, lwe_in, in_idx, planes,   \
                 colsum, n_in, n_out, base_log, num_samples, col_tiles, level);                                       \
     else                                                                                                             \
