@@ -1299,7 +1299,8 @@ template <int L, int B, int G>
 static void launch_wave_mb_t(hipStream_t st, const PbsArgs &a, const FftTables &tb) {
   using namespace wavek;
   if (a.pace) HX_CHECK(hipMemsetAsync(a.pace, 0, 8 * 32 * sizeof(uint32_t), st));
-  const unsigned per_block = lwes_per_block(a.num_samples);
+  unsigned per_block = lwes_per_block(a.num_samples);
+  if (per_block == 3 && g_multibit_share) per_block = 4;  // 513 .. 768 LWEs: fuller workgroups that can share (4-12 % faster)
   const unsigned blocks = (a.num_samples + per_block - 1) / per_block;
   // an even number of LWEs per workgroup: quads of waves share the key loads of their two LWEs (SHARE)
   if (per_block % 2 == 0 && g_multibit_share) {
