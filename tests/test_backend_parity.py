@@ -635,13 +635,13 @@ def test_multi_bit_throughput_kernel_equals_generic_and_oracle(kind, which):
 
 
 @pytest.mark.parametrize("kind", BACKENDS)
-@pytest.mark.parametrize("which,B", [("g3_l2", 259), ("g4_l1", 259), ("g3_l2", 771), ("g4_l1", 771)])
+@pytest.mark.parametrize("which,B", [("g3_l2", 259), ("g4_l1", 259), ("g4_l1", 515), ("g3_l2", 771), ("g4_l1", 771)])
 def test_multi_bit_throughput_kernel_shared_key_loads(kind, which, B):
     """With an even number of LWEs per workgroup (2 from 257 LWEs, 4 from 769) the quads of waves of the
     throughput kernel share the key loads of their two LWEs (SHARE mode of pbs_fft_wave_kernel): a wave works on
     one output column at 8 of a lane's 16 points for BOTH LWEs and hands half of its results over through LDS.
     259 and 771 LWEs leave a ragged last workgroup (1 of 2, 3 of 4 LWEs present: the missing pairs redo the last
-    ciphertext and write nothing).  Same bits as the pair-per-LWE form (kernel choice 7) and as the oracle."""
+    ciphertext and write nothing); 515 is in the range (513 .. 768) that would get 3 LWEs per workgroup and takes 4.  Same bits as the pair-per-LWE form (kernel choice 7) and as the oracle."""
     from .common import TOY_MB_2048, TOY_MB4_2048
     p = TOY_MB_2048 if which == "g3_l2" else TOY_MB4_2048
     c = ctx(kind, p, "fft64")
