@@ -194,3 +194,60 @@ def test_concurrent_host_threads_on_their_own_streams_share_the_keys():
     for j in jobs:
         j.close()
     assert not errors, errors
+
+
+@pytest.mark.parametrize("which", ["classic", "multi_bit_g4"])
+def test_a_whole_radix_addition_is_captured_and_replayed(which):
+    """`cuda_add_and_propagate_single_carry_64_inplace_async` between its scratch and cleanup calls only enqueues:
+    the block additions and the nine KS -> PBS rounds of a 16-block addition (index arrays, LUTs and every buffer
+    belong to the scratch) are captured into one HIP graph and replayed on fresh operands; each replay decrypts to
+    the sum."""
+    from tfhe_rs_amd import core_crypto_gpu as gpu
+    from tfhe_rs_amd import integer_gpu as igpu
+    lib = use_backend("hip")
+    p = TOY_2048 if which == "classic" else TOY_MB4_2048
+    keys = make_keys(p, with_ksk=True)
+    st = gpu.CudaStreams.new_single_gpu(0)
+    bsk, ksk = upload(gpu, p, keys, True)
+    sks = igpu.CudaServerKey(ksk, bsk, 4, 4)
+    L, mask = 16, (1 << 32) - 1
+    rng = np.random.default_rng(77)
+
+    def enc(vals, seed):
+        flat = encrypt_big(p, keys, [(int(v) >> (2 * j)) & 3 for v in vals for j in range(L)], seed=seed)
+        return flat.reshape(len(vals), L, -1)
+
+    def dec(rows):
+        return [sum(decrypt_big(p, keys, b) << (2 * j) for j, b in enumerate(row)) for row in rows]
+
+    a0 = [int(x) for x in rng.integers(0, 1 << 32, size=3)]
+    b0 = [int(x) for x in rng.integers(0, 1 << 32, size=3)]
+    ca = igpu.CudaUnsignedRadixCiphertext.from_blocks(enc(a0, 1), st)
+    cb = igpu.CudaUnsignedRadixCiphertext.from_blocks(enc(b0, 2), st)
+    cin, cout = sks._carry_blocks(ca, None, st), sks._carry_blocks(ca, None, st)
+    s, keep = sks._streams(st)
+    ksks, bsks = sks._key_ptrs(st)
+    mem = C.c_void_p()
+    lib.hip_integer_scratch_batch(3)
+    lib.scratch_cuda_add_and_propagate_single_carry_64_inplace_async(
+        s, C.byref(mem), sks._bsk_params(), sks._ksk_params(), L, 4, 4, 0, True, sks._noise_reduction())
+    st.synchronize()
+
+    def enqueue():
+        lib.cuda_add_and_propagate_single_carry_64_inplace_async(
+            s, C.byref(ca._ffi()), C.byref(cb._ffi()), C.byref(cout._ffi()), C.byref(cin._ffi()), mem, bsks, ksks, 0, 0)
+
+    hip = Hip()
+    try:
+        enqueue()   # warm: the keyswitch key's matrix-core layout is built by the first launch that sees the key
+        assert dec(ca.to_blocks(st)) == [(x + y) & mask for x, y in zip(a0, b0)]
+        graph, exe = hip.capture(st.ptr[0], enqueue)
+        for rep in range(2):
+            a1 = [int(x) for x in rng.integers(0, 1 << 32, size=3)]
+            ca.d_blocks.copy_from_cpu_async(np.ascontiguousarray(enc(a1, 10 + rep).reshape(-1)), st)
+            st.synchronize()
+            hip.launch(exe, st.ptr[0])
+            assert dec(ca.to_blocks(st)) == [(x + y) & mask for x, y in zip(a1, b0)]
+        hip.destroy(graph, exe)
+    finally:
+        lib.cleanup_cuda_add_and_propagate_single_carry_64_inplace(s, C.byref(mem))
