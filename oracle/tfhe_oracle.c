@@ -743,11 +743,59 @@ static inline void bfly(double *a, double *b, double sr, double si) {
   b[1] = fma(2.0, ai, -o1i);
 }
 
+/* Two butterflies at a time on AVX2 (two complex points per register): lane by lane the SAME operations as bfly()
+ * in the same order — inner fma(br, s?, a?), outer fma(-+bi, s?, inner), then fma(2, a, -o1) — so the results are
+ * the scalar ones bit for bit (tests/test_oracle_pins.py pins them to the reference's golden vectors). */
+#if defined(__AVX2__) && defined(__FMA__)
+#include <immintrin.h>
+/* a = [a0r a0i a1r a1i], b likewise; s_in = [s0r s0i s1r s1i] (inner multipliers), s_out = [-s0i s0r -s1i s1r] */
+static inline void bfly2(double *pa, double *pb, __m256d s_in, __m256d s_out) {
+  const __m256d a = _mm256_loadu_pd(pa), b = _mm256_loadu_pd(pb);
+  const __m256d brr = _mm256_movedup_pd(b);        /* [br br br' br'] */
+  const __m256d bii = _mm256_permute_pd(b, 0xF);   /* [bi bi bi' bi'] */
+  const __m256d inner = _mm256_fmadd_pd(brr, s_in, a);
+  const __m256d o1 = _mm256_fmadd_pd(bii, s_out, inner);
+  _mm256_storeu_pd(pa, o1);
+  _mm256_storeu_pd(pb, _mm256_fmsub_pd(_mm256_set1_pd(2.0), a, o1));
+}
+#define ORC_HAVE_AVX2 1
+#else
+#define ORC_HAVE_AVX2 0
+#endif
+
 static void fft_forward_inplace(double *v, uint32_t N) {
   const fft_plan *pl = fft_get_plan(N);
   uint32_t n = N / 2;
   for (uint32_t m = n, cnt = 1; m >= 2; m /= 2, cnt *= 2) {
     uint32_t half = m / 2;
+#if ORC_HAVE_AVX2
+    if (half >= 2) {  /* one twiddle per group, two consecutive j per step */
+      for (uint32_t g = 0; g < cnt; ++g) {
+        const double sr = pl->fwd[2 * (cnt + g)], si = pl->fwd[2 * (cnt + g) + 1];
+        const __m256d s_in = _mm256_setr_pd(sr, si, sr, si), s_out = _mm256_setr_pd(-si, sr, -si, sr);
+        double *base = v + 2 * (size_t)g * m;
+        for (uint32_t j = 0; j < half; j += 2) bfly2(base + 2 * j, base + 2 * (j + half), s_in, s_out);
+      }
+      continue;
+    }
+    if (cnt >= 2) {  /* half == 1: groups g, g+1 = points [a b a' b'] in memory, one twiddle each */
+      for (uint32_t g = 0; g < cnt; g += 2) {
+        double *base = v + 4 * (size_t)g;
+        const __m256d x = _mm256_loadu_pd(base), y = _mm256_loadu_pd(base + 4);  /* [a b], [a' b'] */
+        const __m256d a = _mm256_permute2f128_pd(x, y, 0x20), b = _mm256_permute2f128_pd(x, y, 0x31);
+        const double *t = pl->fwd + 2 * (cnt + g);  /* s_g, s_{g+1} */
+        const __m256d s_in = _mm256_loadu_pd(t);
+        const __m256d s_out = _mm256_xor_pd(_mm256_permute_pd(s_in, 0x5), _mm256_setr_pd(-0.0, 0.0, -0.0, 0.0));
+        const __m256d brr = _mm256_movedup_pd(b), bii = _mm256_permute_pd(b, 0xF);
+        const __m256d inner = _mm256_fmadd_pd(brr, s_in, a);
+        const __m256d o1 = _mm256_fmadd_pd(bii, s_out, inner);
+        const __m256d o2 = _mm256_fmsub_pd(_mm256_set1_pd(2.0), a, o1);
+        _mm256_storeu_pd(base, _mm256_permute2f128_pd(o1, o2, 0x20));
+        _mm256_storeu_pd(base + 4, _mm256_permute2f128_pd(o1, o2, 0x31));
+      }
+      continue;
+    }
+#endif
     for (uint32_t g = 0; g < cnt; ++g) {
       double sr = pl->fwd[2 * (cnt + g)], si = pl->fwd[2 * (cnt + g) + 1];
       double *base = v + 2 * (size_t)g * m;
@@ -761,6 +809,19 @@ static void fft_inverse_inplace(double *v, uint32_t N) {
   uint32_t n = N / 2;
   for (uint32_t half = 1; half < n; half *= 2) {
     uint32_t m = 2 * half;
+#if ORC_HAVE_AVX2
+    if (half >= 4) {  /* twiddle inv[half + j] per j: two consecutive j per step */
+      for (uint32_t q = 0; q < n / m; ++q) {
+        double *base = v + 2 * (size_t)q * m;
+        for (uint32_t j = 0; j < half; j += 2) {
+          const __m256d s_in = _mm256_loadu_pd(pl->inv + 2 * (half + j));
+          const __m256d s_out = _mm256_xor_pd(_mm256_permute_pd(s_in, 0x5), _mm256_setr_pd(-0.0, 0.0, -0.0, 0.0));
+          bfly2(base + 2 * j, base + 2 * (j + half), s_in, s_out);
+        }
+      }
+      continue;
+    }
+#endif
     for (uint32_t q = 0; q < n / m; ++q) {
       double *base = v + 2 * (size_t)q * m;
       for (uint32_t j = 0; j < half; ++j) {
