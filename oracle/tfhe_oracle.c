@@ -884,6 +884,24 @@ void orc_fft_backward_add(uint64_t *poly, double *fourier, uint32_t N) {
   const fft_plan *pl = fft_get_plan(N);
   uint32_t n = N / 2;
   fft_inverse_inplace(fourier, N);
+#if ORC_HAVE_AVX2
+  /* two points per step; untwist and orc_from_torus lane by lane as below (rint = round to nearest even) */
+  const __m256d sgn = _mm256_setr_pd(-0.0, 0.0, -0.0, 0.0), two64 = _mm256_set1_pd(18446744073709551616.0);
+  for (uint32_t j = 0; j < n; j += 2) {
+    const __m256d y = _mm256_loadu_pd(fourier + 2 * j), u = _mm256_loadu_pd(pl->untw + 2 * j);
+    const __m256d yrr = _mm256_movedup_pd(y), yii = _mm256_permute_pd(y, 0xF);
+    const __m256d us = _mm256_xor_pd(_mm256_permute_pd(u, 0x5), sgn);           /* [-ui ur] */
+    const __m256d t = _mm256_fmadd_pd(yii, us, _mm256_mul_pd(yrr, u));          /* [tr ti tr' ti'] */
+    __m256d f = _mm256_sub_pd(t, _mm256_round_pd(t, _MM_FROUND_TO_NEAREST_INT | _MM_FROUND_NO_EXC));
+    f = _mm256_round_pd(_mm256_mul_pd(f, two64), _MM_FROUND_TO_NEAREST_INT | _MM_FROUND_NO_EXC);
+    double w[4];
+    _mm256_storeu_pd(w, f);
+    poly[j] += (uint64_t)orc_f64_to_i64_sat(w[0]);
+    poly[j + n] += (uint64_t)orc_f64_to_i64_sat(w[1]);
+    poly[j + 1] += (uint64_t)orc_f64_to_i64_sat(w[2]);
+    poly[j + 1 + n] += (uint64_t)orc_f64_to_i64_sat(w[3]);
+  }
+#else
   for (uint32_t j = 0; j < n; ++j) {
     double yr = fourier[2 * j], yi = fourier[2 * j + 1];
     double ur = pl->untw[2 * j], ui = pl->untw[2 * j + 1];
@@ -892,6 +910,7 @@ void orc_fft_backward_add(uint64_t *poly, double *fourier, uint32_t N) {
     poly[j] += orc_from_torus(tr);
     poly[j + n] += orc_from_torus(ti);
   }
+#endif
 }
 
 /* cc/algorithms/lwe_bootstrap_key_conversion.rs:20-150 ; layout stays
@@ -921,6 +940,17 @@ void orc_ext_product_fft(uint64_t *acc, const uint64_t *ct1, const double *ggsw_
       for (uint32_t c = 0; c <= k; ++c) {
         double *o = outbuf + (size_t)c * N;
         const double *g = grow + (size_t)c * N;
+#if ORC_HAVE_AVX2
+        /* two points per step, lane by lane the scalar operations below in the same order */
+        const __m256d sgn = _mm256_setr_pd(-0.0, 0.0, -0.0, 0.0);
+        for (uint32_t j = 0; j < n; j += 2) {
+          const __m256d x = _mm256_loadu_pd(fbuf + 2 * j), y = _mm256_loadu_pd(g + 2 * j);
+          const __m256d xrr = _mm256_movedup_pd(x), xii = _mm256_permute_pd(x, 0xF);
+          const __m256d ys = _mm256_xor_pd(_mm256_permute_pd(y, 0x5), sgn);  /* [-yi yr] */
+          const __m256d inner = first ? _mm256_mul_pd(xrr, y) : _mm256_fmadd_pd(xrr, y, _mm256_loadu_pd(o + 2 * j));
+          _mm256_storeu_pd(o + 2 * j, _mm256_fmadd_pd(xii, ys, inner));
+        }
+#else
         for (uint32_t j = 0; j < n; ++j) {
           double xr = fbuf[2 * j], xi = fbuf[2 * j + 1], yr = g[2 * j], yi = g[2 * j + 1];
           if (first) {
@@ -931,6 +961,7 @@ void orc_ext_product_fft(uint64_t *acc, const uint64_t *ct1, const double *ggsw_
             o[2 * j + 1] = fma(xi, yr, fma(xr, yi, o[2 * j + 1]));
           }
         }
+#endif
       }
       first = 0;
     }
