@@ -435,7 +435,7 @@ def main():
         dt = time.perf_counter() - t0
         result["cpu_baseline"] = {
             "value": count / dt, "unit": "PBS/s", "cores": cores, "kind": "port",
-            "sample": f"{count} PBS of the same batch through the C oracle's f64 FFT path (scalar C restatement, "
+            "sample": f"{count} PBS of the same batch through the C oracle's f64 FFT path (C restatement with AVX2 butterflies, "
                       f"OpenMP over LWEs, {cores} threads, {dt:.1f} s); the reference's AVX-512 Rust publishes "
                       f"5.64 ms/PBS on one EPYC 9R45 core",
             "gpu_matches_cpu_bits": bool(np.array_equal(ref, out[:count])),
