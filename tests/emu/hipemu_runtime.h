@@ -13,10 +13,19 @@ enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDevi
 struct hipDeviceProp_t { int multiProcessorCount; size_t totalGlobalMem; size_t sharedMemPerBlock; char gcnArchName[64]; };
 
 static inline const char *hipGetErrorString(hipError_t) { return "hipemu error"; }
-static inline hipError_t hipSetDevice(int) { return hipSuccess; }
-static inline hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
-static inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
-static inline hipError_t hipStreamCreate(hipStream_t *s) { *s = malloc(8); return hipSuccess; }
+// Device model: HIPEMU_DEVICES (default 1) pretend devices sharing host memory.  The current device is per host
+// thread as in HIP; a stream and an event remember the device that was current when they were created, and
+// hipEventRecord rejects an event recorded on a stream of another device (hipErrorInvalidHandle on real HIP) —
+// that rule is what the multi-GPU radix tests of the CPU tier check.
+#define hipErrorInvalidDevice 101
+#define hipErrorInvalidHandle 400
+inline thread_local int hipemu_current_device = 0;
+static inline int hipemu_device_count() { const char *e = getenv("HIPEMU_DEVICES"); int n = e ? atoi(e) : 1; return n < 1 ? 1 : n; }
+static inline hipError_t hipSetDevice(int d) { if (d < 0 || d >= hipemu_device_count()) return hipErrorInvalidDevice; hipemu_current_device = d; return hipSuccess; }
+static inline hipError_t hipGetDevice(int *d) { *d = hipemu_current_device; return hipSuccess; }
+static inline hipError_t hipGetDeviceCount(int *n) { *n = hipemu_device_count(); return hipSuccess; }
+static inline int hipemu_stream_device(hipStream_t s) { return s ? *(int *)s : hipemu_current_device; }
+static inline hipError_t hipStreamCreate(hipStream_t *s) { *s = malloc(8); *(int *)*s = hipemu_current_device; return hipSuccess; }
 static inline hipError_t hipStreamDestroy(hipStream_t s) { free(s); return hipSuccess; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
@@ -34,8 +43,11 @@ static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int) {
   return hipSuccess;
 }
 #include <time.h>
-static inline hipError_t hipEventCreate(hipEvent_t *e) { *e = malloc(sizeof(double)); return hipSuccess; }
-static inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) {
+struct hipemu_event { double t; int device; };
+static inline hipError_t hipEventCreate(hipEvent_t *e) {
+  hipemu_event *ev = (hipemu_event *)malloc(sizeof(hipemu_event)); ev->t = 0; ev->device = hipemu_current_device; *e = ev; return hipSuccess; }
+static inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t s) {
+  if (((hipemu_event *)e)->device != hipemu_stream_device(s)) return hipErrorInvalidHandle;
   struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts);
   *(double *)e = ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; return hipSuccess; }
 static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
@@ -44,7 +56,7 @@ static inline hipError_t hipEventDestroy(hipEvent_t e) { free(e); return hipSucc
 static inline hipError_t hipGetLastError() { return hipSuccess; }
 static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 static inline hipError_t hipEventQuery(hipEvent_t) { return hipSuccess; }
-static inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { *e = malloc(sizeof(double)); return hipSuccess; }
+static inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { return hipEventCreate(e); }
 #define hipEventDisableTiming 0
 static inline hipError_t hipMemcpyPeerAsync(void *d, int, const void *s, int, size_t n, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
 static inline hipError_t hipMemGetAddressRange(void **base, size_t *size, void *p) { *base = p; *size = 1; return hipSuccess; }

@@ -162,3 +162,35 @@ def test_radix_rounds_sharded_over_the_streams_of_the_set(kind):
     assert np.array_equal(outs["one"][0], outs["three"][0]) and np.array_equal(outs["one"][1], outs["three"][1])
     assert recompose(decrypt_blocks(p, keys, outs["three"][0])) == [(x + y) & mask for x, y in zip(a, b)]
     assert recompose(decrypt_blocks(p, keys, outs["three"][1])) == [(x * y) & mask for x, y in zip(a, b)]
+
+
+def test_radix_rounds_on_distinct_devices_record_events_on_their_own_streams(monkeypatch):
+    """The same sharded rounds with the stream set naming three DIFFERENT devices.  The CPU tier's runtime stand-in
+    models devices (HIPEMU_DEVICES): a stream and an event belong to the device current at their creation and
+    hipEventRecord fails — as on real HIP, hipErrorInvalidHandle — for an event recorded on another device's stream;
+    HX_CHECK aborts on that.  (A round-2 build created `staged` / `copied` under the shard's GPU and recorded them on
+    the first GPU's stream: it only ever ran as several streams of one device.)"""
+    monkeypatch.setenv("HIPEMU_DEVICES", "3")
+    kind = "emu"
+    lib = use_backend(kind)
+    assert lib.cuda_get_number_of_gpus() == 3
+    p, keys, st1, sks1, igpu = setup(kind)
+    _, _, st3, sks3, _ = setup(kind, gpu_indexes=(0, 1, 2))
+    L, mask = 5, (1 << 10) - 1
+    a, b = [0x2A7, 0x155, mask], [0x1F3, 0x2AB, 1]
+    blocks_a, blocks_b = encrypt_radix(p, keys, a, L, 61), encrypt_radix(p, keys, b, L, 62)
+    outs = {}
+    for name, st, sks, thr in (("one", st1, sks1, 512), ("three", st3, sks3, 3)):
+        lib.hip_integer_set_multi_gpu_threshold(thr)
+        try:
+            ca = igpu.CudaUnsignedRadixCiphertext.from_blocks(blocks_a, st)
+            cb = igpu.CudaUnsignedRadixCiphertext.from_blocks(blocks_b, st)
+            cm = ca.duplicate(st)
+            sks.add_assign(ca, cb, st)
+            sks.mul_assign(cm, cb, st)
+            outs[name] = (ca.to_blocks(st), cm.to_blocks(st))
+        finally:
+            lib.hip_integer_set_multi_gpu_threshold(512)
+    assert np.array_equal(outs["one"][0], outs["three"][0]) and np.array_equal(outs["one"][1], outs["three"][1])
+    assert recompose(decrypt_blocks(p, keys, outs["three"][0])) == [(x + y) & mask for x, y in zip(a, b)]
+    assert recompose(decrypt_blocks(p, keys, outs["three"][1])) == [(x * y) & mask for x, y in zip(a, b)]

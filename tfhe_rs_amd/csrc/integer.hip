@@ -189,15 +189,17 @@ struct LutDriver {
         radix_alloc((void **)&g.d_in, (size_t)cap * w * sizeof(uint64_t));
         radix_alloc((void **)&g.d_out, (size_t)cap * w * sizeof(uint64_t));
         radix_alloc((void **)&g.d_lut_idx, (size_t)cap * sizeof(uint64_t));
+        // An event is recorded on a stream of ITS device only (hipEventRecord rejects a foreign stream): `staged` and
+        // `copied` are recorded on the first GPU's stream, `done` on this GPU's; waiting across devices is allowed.
         HX_CHECK(hipSetDevice((int)gpus[0].gpu));
         radix_alloc((void **)&g.d0_in, (size_t)cap * w * sizeof(uint64_t));
         radix_alloc((void **)&g.d0_out, (size_t)cap * w * sizeof(uint64_t));
-        HX_CHECK(hipSetDevice((int)g.gpu));
         if (!t_dry) {
           HX_CHECK(hipEventCreateWithFlags(&g.staged, hipEventDisableTiming));
-          HX_CHECK(hipEventCreateWithFlags(&g.done, hipEventDisableTiming));
           HX_CHECK(hipEventCreateWithFlags(&g.copied, hipEventDisableTiming));
         }
+        HX_CHECK(hipSetDevice((int)g.gpu));
+        if (!t_dry) HX_CHECK(hipEventCreateWithFlags(&g.done, hipEventDisableTiming));
       }
       HX_CHECK(hipStreamSynchronize(st));  // the LUT sources may be temporaries
       scratch_pbs(st, g);
