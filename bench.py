@@ -44,24 +44,283 @@ def bytes_per_pbs(p):
     return key + (p.n + 1) * 8 + k1 * p.N * 8 + (p.k * p.N + 1) * 8
 
 
+_PMC_NOW = {}   # counter record measured by THIS run (measure_traffic_now), else the committed one
+
+
+def measure_traffic_now(targets, budget_s=420):
+    """HBM traffic of one launch of each throughput kernel, measured DURING this bench run: tools/pmc_record.py runs
+    `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes, counters only) over one batch-4096 launch
+    per kernel in child processes.  Skipped — the committed, build-stamped record is used instead — when rocprofv3 is
+    absent or this process is itself being profiled (nested tool libraries)."""
+    import shutil
+    import subprocess
+    if not shutil.which("rocprofv3"):
+        return "rocprofv3 not on PATH"
+    if any(k in os.environ for k in ("ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB", "ROCPROFILER_REGISTER_FORCE_LOAD")):
+        return "this process runs under a profiler"
+    out = os.path.join(ROOT, "gpurun_out", "pmc_bench_run.json")
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    try:
+        os.remove(out)
+    except OSError:
+        pass
+    try:
+        subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_record.py"), *targets, "--hbm-only", "--tag",
+                        "benchrun", "--out", out, "--timeout", "150"], capture_output=True, text=True, timeout=budget_s)
+        _PMC_NOW.update(json.load(open(out)))
+        return None
+    except Exception as e:  # noqa: BLE001
+        return f"in-run PMC passes failed ({e.__class__.__name__})"
+
+
 def pmc_record(target):
-    """Counter record of one throughput kernel ("fft", "ntt", "mb_g3"), measured by tools/pmc_record.py on the SAME
-    kernel sources this tree holds (profiles/pmc_latest.json carries the build id of what it profiled; a record
-    of another build is refused).  Returns (hbm_bytes_per_launch or None, provenance string)."""
+    """HBM bytes per launch of one throughput kernel ("fft", "ntt", "mb_g3", "mb_g4") and where the figure comes from:
+    the PMC passes of this very run when they were taken (measure_traffic_now), else the committed record
+    profiles/pmc_latest.json — measured by tools/pmc_record.py and stamped with the build id of the kernel sources it
+    profiled; a record of another build is refused.  Returns (hbm_bytes_per_launch or None, provenance string)."""
     from tools.build_id import source_build_id
+    mine = source_build_id()
+    k = _PMC_NOW.get("kernels", {}).get(target)
+    if _PMC_NOW.get("build_id") == mine and k and "hbm_bytes_per_launch" in k:
+        pv = _PMC_NOW.get("provenance", {})
+        return k["hbm_bytes_per_launch"], (f"measured in this bench run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over "
+                                           f"one batch-4096 launch of {k.get('kernel')}, 2 x FETCH_SIZE + WRITE_SIZE; build "
+                                           f"{mine}, {pv.get('gpus')}, ROCm {pv.get('rocm')}, host {pv.get('host')}")
     path = os.path.join(ROOT, "profiles", "pmc_latest.json")
     try:
         m = json.load(open(path))
     except Exception as e:
         return None, f"no PMC record ({e.__class__.__name__})"
-    mine = source_build_id()
     if m.get("build_id") != mine:
         return None, f"PMC record is of build {m.get('build_id')}, this tree is {mine}: refused as stale"
     k = m.get("kernels", {}).get(target)
     if not k or "hbm_bytes_per_launch" not in k:
         return None, f"PMC record of build {mine} has no '{target}' entry"
-    return k["hbm_bytes_per_launch"], (f"profiles/pmc_latest.json, build {mine}, kernel {k.get('kernel')}: "
-                                       f"2 x FETCH_SIZE + WRITE_SIZE per launch, L2 hit rate {k.get('l2_hit_rate', 0):.3f}")
+    pv = m.get("provenance", {})
+    return k["hbm_bytes_per_launch"], (f"profiles/pmc_latest.json (committed record, not re-measured in this run"
+                                       f"{': ' + _PMC_NOW['skipped'] if 'skipped' in _PMC_NOW else ''}), build {mine}, kernel "
+                                       f"{k.get('kernel')}: 2 x FETCH_SIZE + WRITE_SIZE per launch, L2 hit rate "
+                                       f"{k.get('l2_hit_rate', 0):.3f}; taken on {pv.get('gpus')}, ROCm {pv.get('rocm')}, "
+                                       f"host {pv.get('host')}")
+
+
+class HeadlineShard:
+    """One GPU's part of the headline workload: a replica of the bootstrap key, this GPU's shard of the global batch
+    resident in HBM, its scratch, and the launches through the C ABI.  The reference's throughput bench has the same
+    shape — one host thread and one stream per GPU, key replicas, contiguous shards
+    (tfhe-benchmark/benches/core_crypto/pbs_bench.rs:1050-1160, cuda/src/utils/helper_multi_gpu.cuh:170-294)."""
+
+    def __init__(self, lib, p, keys, device, rank, world, B, kernel=0, f=lambda x: x):
+        import numpy as np
+        from tfhe_rs_amd import core_crypto_gpu as gpu
+        from tfhe_rs_amd.multi_gpu import shard_range
+        from tests import oracle as orc
+        from tests.common import encrypt_small
+        self.lib, self.p, self.keys, self.g, self.rank, self.B, self.f = lib, p, keys, int(device), rank, B, f
+        lib.hip_backend_set_fft_kernel(kernel)
+        self.streams = gpu.CudaStreams([self.g])
+        self.s = self.streams.ptr[0]
+        self.bsk = gpu.CudaLweBootstrapKey.from_lwe_bootstrap_key(keys.bsk, p.n, p.k, p.N, p.pbs_base_log, p.pbs_level,
+                                                                  self.streams, ms_noise_reduction=bool(p.ms_type),
+                                                                  engine="fft64")
+        lo, hi = shard_range(B * world, rank, world)          # this GPU's shard of the global batch (weak scaling)
+        assert hi - lo == B
+        self.msgs = [(lo + i) % p.plaintext_modulus for i in range(B)]
+        self.cts = encrypt_small(p, keys, self.msgs, seed=100 + rank)   # B distinct fresh encryptions
+        self.lut = orc.generate_lut(p.k, p.N, p.plaintext_modulus, p.delta, f)
+        self.d_in = gpu.CudaLweCiphertextList.from_lwe_ciphertext_list(self.cts, self.streams)
+        self.d_out = gpu.CudaLweCiphertextList.new(p.k * p.N, B, self.streams)
+        self.d_lut = gpu.CudaGlweCiphertextList.from_glwe_ciphertext_list(self.lut, p.k, p.N, self.streams)
+        self.idx = gpu.CudaVec.from_cpu_async(np.arange(B, dtype=np.uint64), self.streams)
+        self.lidx = gpu.CudaVec.from_cpu_async(np.zeros(B, dtype=np.uint64), self.streams)
+        self.buf = C.c_void_p()
+        lib.scratch_cuda_programmable_bootstrap_64_async(self.s, self.g, C.byref(self.buf), p.n, p.k, p.N, p.pbs_level, B,
+                                                         True, int(p.ms_type))
+
+    def step(self, out=None, count=None):
+        p = self.p
+        self.lib.cuda_programmable_bootstrap_64_async(
+            self.s, self.g, (out or self.d_out).d_vec.ptr, self.idx.ptr, self.d_lut.d_vec.ptr, self.lidx.ptr,
+            self.d_in.d_vec.ptr, self.idx.ptr, self.bsk.d_vec.ptr, self.buf, p.n, p.k, p.N, p.pbs_base_log, p.pbs_level,
+            count or self.B, 1, 0)
+
+    def sync(self):
+        self.lib.cuda_synchronize_stream(self.s, self.g)
+
+    def timed(self, steps):
+        """EXACTLY `steps` launches, each bracketed by HIP events on the stream it is launched on; returns the
+        per-launch milliseconds after draining the stream."""
+        lib = self.lib
+        ev = [(lib.hip_event_create(), lib.hip_event_create()) for _ in range(steps)]
+        for e0, e1 in ev:
+            lib.hip_event_record(e0, self.s)
+            self.step()
+            lib.hip_event_record(e1, self.s)
+        self.sync()
+        return [lib.hip_event_elapsed_ms(e0, e1) for e0, e1 in ev]
+
+    def outputs(self):
+        return self.d_out.to_lwe_ciphertext_list(self.streams)
+
+    def undecryptable_rows(self, sample=256):
+        import numpy as np
+        from tests.common import decrypt_big
+        out = self.outputs()
+        rng = np.random.default_rng(1234 + self.rank)
+        check = rng.choice(self.B, size=min(self.B, sample), replace=False)
+        return [int(i) for i in check if decrypt_big(self.p, self.keys, out[i]) != self.f(self.msgs[i])]
+
+    def close(self):
+        if self.buf:
+            self.lib.cleanup_cuda_programmable_bootstrap_64(self.s, self.g, C.byref(self.buf))
+            self.buf = None
+
+
+def run_in_process(lib, p, keys, devices, B, steps, warmup, kernel=0, verify=True):
+    """The headline on len(devices) GPUs from ONE process: one host thread, one stream, one key replica and one
+    B-LWE shard per GPU (the reference bench's shape, pbs_bench.rs:1050-1160); no exchange between GPUs.  All
+    threads meet before the timed region, time their own `steps` launches and drain their stream; the job's time is
+    latest finish - earliest start.  `devices` may name one GPU several times (the reference's
+    debug-fake-multi-gpu idea: several streams on one device) — the logic is the same, the rate is not.
+    Returns (elapsed_s, per_gpu list, shard 0 kept open for the rank-0 datapoints)."""
+    import threading
+    n = len(devices)
+    gate = threading.Barrier(n)
+    res, errs = [None] * n, []
+
+    def work(i):
+        try:
+            sh = HeadlineShard(lib, p, keys, devices[i], i, n, B, kernel)
+            for _ in range(warmup):
+                sh.step()
+            sh.sync()
+            gate.wait()
+            t0 = time.perf_counter()
+            kernel_ms = sh.timed(steps)
+            t1 = time.perf_counter()
+            gate.wait()
+            bad = sh.undecryptable_rows() if verify else []
+            res[i] = {"t0": t0, "t1": t1, "kernel_ms": kernel_ms, "bad": bad, "shard": sh, "device": int(devices[i]),
+                      "kernel_id": int(lib.hip_backend_last_pbs_kernel())}
+            if i:
+                sh.close()
+        except BaseException as e:  # noqa: BLE001 — a failed GPU must not leave the others parked at the barrier
+            errs.append(e)
+            gate.abort()
+
+    threads = [threading.Thread(target=work, args=(i,), name=f"gpu{devices[i]}-shard{i}") for i in range(n)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if errs:
+        raise errs[0]
+    elapsed = max(r["t1"] for r in res) - min(r["t0"] for r in res)
+    per_gpu = [{"shard": i, "device": r["device"], "lwes": B, "seconds": r["t1"] - r["t0"],
+                "pbs_per_s": B * steps / (r["t1"] - r["t0"]), "kernel_ms_avg": sum(r["kernel_ms"]) / len(r["kernel_ms"]),
+                "verified": not r["bad"]} for i, r in enumerate(res)]
+    for r in res:
+        assert not verify or not r["bad"], f"PBS outputs failed to decrypt at rows {r['bad'][:8]}"
+    return elapsed, per_gpu, res[0]["shard"], res[0]["kernel_ms"], res[0]["kernel_id"]
+
+
+def fheuint64_datapoint(lib, p, keys, devices, batches, in_library):
+    """BASELINE.json config 5: FheUint64 (32 blocks of the 2_2 set) add and mul through the radix layer of the backend
+    (keyswitch -> PBS rounds, `tfhe_rs_amd/integer_gpu.py` over the reference's integer FFI names), `batches[op]`
+    integers in total over `devices`; 32 distinct operand pairs tiled over the batch (timing is data independent),
+    every distinct result of every shard decrypted and compared with clear arithmetic outside the timed region.
+    in_library=False: the caller shards, one host thread + stream + key replicas per GPU, batch / N integers each,
+    nothing crosses GPUs.  in_library=True: ONE stream set naming all GPUs, the library shards every round."""
+    import threading
+    import numpy as np
+    from tfhe_rs_amd import core_crypto_gpu as gpu
+    from tfhe_rs_amd import integer_gpu as igpu
+    from tfhe_rs_amd.multi_gpu import get_num_inputs_on_gpu
+    from tests import oracle as orc
+    from tests.common import decrypt_big
+    ksk_h = orc.gen_ksk(0x74666865 + 2, keys.glwe_sk, keys.lwe_sk, p.ks_base_log, p.ks_level, p.lwe_noise)
+    LB, DISTINCT = 32, 32
+    mask64 = (1 << (2 * LB)) - 1
+    r5 = np.random.default_rng(5)
+    va = [int.from_bytes(r5.bytes(8), "little") for _ in range(DISTINCT)]
+    vb = [int.from_bytes(r5.bytes(8), "little") for _ in range(DISTINCT)]
+    er = orc.Rng(55)
+    enc = lambda vals: np.stack([np.stack([orc.lwe_encrypt(er, keys.glwe_sk, (((v >> (2 * j)) & 3) * p.delta) % (1 << 64),
+                                                           p.glwe_noise) for j in range(LB)]) for v in vals])
+    ha, hb = enc(va), enc(vb)
+    groups = [list(devices)] if in_library else [[d] for d in devices]
+    n = len(groups)
+    gate = threading.Barrier(n)
+    res, errs = {}, []
+
+    def work(i):
+        try:
+            streams = gpu.CudaStreams(groups[i])
+            bsk = gpu.CudaLweBootstrapKey.from_lwe_bootstrap_key(keys.bsk, p.n, p.k, p.N, p.pbs_base_log, p.pbs_level,
+                                                                 streams, ms_noise_reduction=bool(p.ms_type))
+            ksk = gpu.CudaLweKeyswitchKey.from_lwe_keyswitch_key(ksk_h, p.k * p.N, p.n, p.ks_base_log, p.ks_level, streams)
+            sks = igpu.CudaServerKey(ksk, bsk, 4, 4)
+            for op, total in batches.items():
+                nb = get_num_inputs_on_gpu(total, i, n)
+                tile = lambda h: np.tile(h, ((nb + DISTINCT - 1) // DISTINCT, 1, 1))[:nb]
+                ca = igpu.CudaUnsignedRadixCiphertext.from_blocks(tile(ha), streams)
+                cb = igpu.CudaUnsignedRadixCiphertext.from_blocks(tile(hb), streams)
+                streams.synchronize()
+                gate.wait()
+                t0 = time.perf_counter()
+                if op == "add":
+                    sks.add_assign(ca, cb, streams)
+                    pbs_count = int(lib.hip_integer_propagate_pbs_count(LB))
+                else:
+                    pbs_count = int(sks.mul_assign(ca, cb, streams, return_pbs_count=True))
+                streams.synchronize()
+                t1 = time.perf_counter()
+                gate.wait()
+                rows = ca.to_blocks(streams)
+                m = min(nb, DISTINCT)
+                want = [((x + y) if op == "add" else (x * y)) & mask64 for x, y in zip(va[:m], vb[:m])]
+                got = [sum(decrypt_big(p, keys, rows[r, j]) << (2 * j) for j in range(LB)) for r in range(m)]
+                res[(op, i)] = (t0, t1, nb, pbs_count, got == want)
+                del ca, cb
+        except BaseException as e:  # noqa: BLE001
+            errs.append(e)
+            gate.abort()
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(n)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if errs:
+        raise errs[0]
+    fhe = {}
+    for op, total in batches.items():
+        rs = [res[(op, i)] for i in range(n)]
+        dt = max(r[1] for r in rs) - min(r[0] for r in rs)
+        fhe[op] = {"batch": total, "seconds": dt, "ops_per_s": total / dt, "pbs_per_op": rs[0][3],
+                   "ks_pbs_per_s": total * rs[0][3] / dt, "per_shard_integers": [r[2] for r in rs],
+                   "results_decrypt_to_clear_arithmetic": all(r[4] for r in rs)}
+    fhe["gpus"] = [int(d) for d in devices]
+    fhe["sharding"] = ("in the library: one CudaStreamsFFI over all GPUs, every KS -> PBS round split by "
+                       "get_num_inputs_on_gpu with peer copies, ciphertexts on the first GPU" if in_library else
+                       "by the caller: batch / N integers per GPU, one host thread + stream + key replicas each, nothing "
+                       "crosses GPUs")
+    fhe["note"] = ("classic 2_2 set, wall clock including scratch allocation, index uploads and every round; the reference "
+                   "publishes 510 add/s and 53.2 mul/s on 8xH100 with multi-bit parameters (BASELINE.md); multi-bit sets: "
+                   "tools/bench_integer.py")
+    return fhe
+
+
+def pick_devices(lib, n):
+    """GPU of each of the n shards.  More shards than GPUs is an error unless TFHE_BENCH_FAKE_MULTI_GPU=1, which maps
+    shard i to GPU i mod (GPUs present): a logic check of the multi-GPU path on a smaller box, never a scaling number."""
+    have = int(lib.cuda_get_number_of_gpus())
+    if n <= have:
+        return list(range(n)), False
+    if os.environ.get("TFHE_BENCH_FAKE_MULTI_GPU") == "1":
+        return [i % have for i in range(n)], True
+    raise SystemExit(f"bench.py --gpus {n}: only {have} GPU(s) visible (TFHE_BENCH_FAKE_MULTI_GPU=1 runs the "
+                     f"{n} shards as streams of the GPUs present — logic check only)")
 
 
 def main():
@@ -72,16 +331,22 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH, help="LWEs per GPU per step (default: the metric's 4096)")
     ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 generic LDS kernel, 2 throughput kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra", action="store_true", help="skip the config-3/4 and N=1024 datapoints under `extra`")
+    ap.add_argument("--no-extra", action="store_true", help="skip the config-3/4/5 and N=1024 datapoints under `extra`")
+    ap.add_argument("--no-pmc", action="store_true", help="do not take rocprofv3 counter passes during the run "
+                    "(`traffic` then comes from the committed build-stamped record)")
     ap.add_argument("--no-verify", action="store_true", help="skip the decrypt check (timing-ablation builds only)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="PBS count of the CPU baseline sample (0 = auto)")
     args = ap.parse_args()
 
+    # Two ways to N GPUs.  (1) Launched by torch.distributed.run (WORLD_SIZE set): one process per GPU, barrier and
+    # max-over-ranks through torch.distributed (RCCL).  (2) Plain `python bench.py --gpus N`: this process drives
+    # the N GPUs itself, one host thread + stream + key replica per GPU (run_in_process) — the reference bench's shape.
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    launched = "WORLD_SIZE" in os.environ and world > 1
     dist = None
-    if world > 1 or os.environ.get("TFHE_BENCH_FORCE_DIST"):  # the env knob exercises this path at N = 1
+    if launched or os.environ.get("TFHE_BENCH_FORCE_DIST"):  # the env knob exercises this path at N = 1
         # import torch first so its HIP runtime is the process's single libamdhip64 instance
         import torch
         import torch.distributed as dist
@@ -93,77 +358,59 @@ def main():
     import tfhe_rs_amd  # noqa: F401
     from tfhe_rs_amd import core_crypto_gpu as gpu
     from tfhe_rs_amd import ffi
-    from tfhe_rs_amd.multi_gpu import shard_range
     from tests import oracle as orc          # checker + cpu_baseline leg only
-    from tests.common import C1, make_keys, encrypt_small, decrypt_big
+    from tests.common import C1, make_keys, decrypt_big
 
     lib = ffi.default_library()
     assert lib.cuda_is_available() == 1, "no GPU visible: the backend has no CPU fallback"
-    lib.hip_backend_set_fft_kernel(args.kernel)
     p = C1
     B = args.batch
-    gpu_index = local_rank
+    f = lambda x: x
 
     # ---- synthetic inputs: real keys (seeded), fresh encryptions of i mod 16, LUT f(x) = x
     keys = make_keys(p, with_ksk=False)
-    streams = gpu.CudaStreams([gpu_index])
-    bsk = gpu.CudaLweBootstrapKey.from_lwe_bootstrap_key(keys.bsk, p.n, p.k, p.N, p.pbs_base_log, p.pbs_level,
-                                                         streams, ms_noise_reduction=True, engine="fft64")
-    lo, hi = shard_range(B * world, rank, world)          # this rank's shard of the global batch
-    msgs = [(lo + i) % p.plaintext_modulus for i in range(B)]
-    cts = encrypt_small(p, keys, msgs, seed=100 + rank)   # B distinct fresh encryptions
-    rng = np.random.default_rng(1234 + rank)
-    f = lambda x: x
-    lut = orc.generate_lut(p.k, p.N, p.plaintext_modulus, p.delta, f)
-
-    d_in = gpu.CudaLweCiphertextList.from_lwe_ciphertext_list(cts, streams)
-    d_out = gpu.CudaLweCiphertextList.new(p.k * p.N, B, streams)
-    d_lut = gpu.CudaGlweCiphertextList.from_glwe_ciphertext_list(lut, p.k, p.N, streams)
-    idx = gpu.CudaVec.from_cpu_async(np.arange(B, dtype=np.uint64), streams)
-    lidx = gpu.CudaVec.from_cpu_async(np.zeros(B, dtype=np.uint64), streams)
-
-    s, g = streams.ptr[0], gpu_index
-    buf = C.c_void_p()
-    lib.scratch_cuda_programmable_bootstrap_64_async(s, g, C.byref(buf), p.n, p.k, p.N, p.pbs_level, B, True, 1)
-
-    def step():
-        lib.cuda_programmable_bootstrap_64_async(s, g, d_out.d_vec.ptr, idx.ptr, d_lut.d_vec.ptr, lidx.ptr,
-                                                 d_in.d_vec.ptr, idx.ptr, bsk.d_vec.ptr, buf, p.n, p.k, p.N,
-                                                 p.pbs_base_log, p.pbs_level, B, 1, 0)
-
-    def sync_all():
-        lib.cuda_synchronize_device(g)
+    fake = False
+    if launched or args.gpus <= 1:
+        sh = HeadlineShard(lib, p, keys, local_rank, rank, world, B, args.kernel, f)
+        for _ in range(args.warmup):
+            sh.step()
+        sh.sync()
         if dist is not None:
             import torch
             torch.cuda.synchronize()
             dist.barrier()
-
-    for _ in range(args.warmup):
-        step()
-    sync_all()
-    ev = [(lib.hip_event_create(), lib.hip_event_create()) for _ in range(args.steps)]
-    t0 = time.perf_counter()
-    for e0, e1 in ev:
-        lib.hip_event_record(e0, s)
-        step()
-        lib.hip_event_record(e1, s)
-    lib.cuda_synchronize_device(g)
-    if dist is not None:
-        import torch
-        torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    kernel_ms = [lib.hip_event_elapsed_ms(e0, e1) for e0, e1 in ev]
-    if dist is not None:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.barrier()
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    kernel_id = lib.hip_backend_last_pbs_kernel()
+        t0 = time.perf_counter()
+        kernel_ms = sh.timed(args.steps)
+        if dist is not None:
+            import torch
+            torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        if dist is not None:
+            import torch
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            dist.barrier()
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        kernel_id = lib.hip_backend_last_pbs_kernel()
+        bad = [] if args.no_verify else sh.undecryptable_rows()
+        assert not bad, f"PBS outputs failed to decrypt at rows {bad[:8]}"
+        per_gpu, n_gpus, devices = None, world, [local_rank]
+        mode = f"one process per GPU (torch.distributed, RCCL barrier) x{world}" if launched else "single GPU"
+    else:
+        devices, fake = pick_devices(lib, args.gpus)
+        elapsed, per_gpu, sh, kernel_ms, kernel_id = run_in_process(lib, p, keys, devices, B, args.steps, args.warmup,
+                                                                    args.kernel, not args.no_verify)
+        n_gpus = args.gpus
+        mode = (f"one process, {n_gpus} host threads, one stream + key replica + {B}-LWE shard per GPU"
+                + (" — FAKE multi-GPU: shards are streams of the GPUs present, logic check only" if fake else ""))
+    streams, s, g = sh.streams, sh.s, sh.g
+    bsk, d_in, d_lut, idx, lidx, buf, cts, lut, msgs = (sh.bsk, sh.d_in, sh.d_lut, sh.idx, sh.lidx, sh.buf, sh.cts,
+                                                        sh.lut, sh.msgs)
+    single = n_gpus == 1
 
     # ---- single-PBS latency (outside the timed region; the reference publishes this figure)
     latency_ms = None
-    if rank == 0 and args.kernel == 0:
+    if rank == 0 and args.kernel == 0 and not args.no_extra:
         d_o1 = gpu.CudaLweCiphertextList.new(p.k * p.N, 1, streams)
 
         def one():
@@ -182,23 +429,24 @@ def main():
         latency_kernel = lib.hip_backend_last_pbs_kernel()
         assert decrypt_big(p, keys, d_o1.to_lwe_ciphertext_list(streams)[0]) == f(msgs[0])
 
-    # ---- validity (outside the timed region): every output of this rank decrypts to f(m)
-    out = d_out.to_lwe_ciphertext_list(streams)
-    check = rng.choice(B, size=min(B, 256), replace=False)
-    bad = [int(i) for i in check if decrypt_big(p, keys, out[i]) != f(msgs[i])]
-    assert args.no_verify or not bad, f"PBS outputs failed to decrypt at rows {bad[:8]}"
-    lib.cleanup_cuda_programmable_bootstrap_64(s, g, C.byref(buf))
+    out = None if args.no_cpu_baseline or not single else sh.outputs()   # compared with the CPU leg's bits below
+    sh.close()
 
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
         return
 
-    total_pbs = B * world * args.steps
+    total_pbs = B * n_gpus * args.steps
     value = total_pbs / elapsed
     avg_kernel_s = (sum(kernel_ms) / len(kernel_ms)) * 1e-3
     achieved = ALGO_BYTES_PER_PBS * B / avg_kernel_s / 1e9
     tflops = ALGO_FLOP_PER_PBS * B / avg_kernel_s / 1e12
+    if single and not args.no_pmc and args.kernel == 0:
+        # after the timed region: one launch per kernel under `rocprofv3 --pmc`, in child processes
+        why = measure_traffic_now(["fft"] if args.no_extra else ["fft", "ntt", "mb_g3", "mb_g4"])
+        if why:
+            _PMC_NOW["skipped"] = why
     traffic, traffic_src = pmc_record("fft")
     # What bounds the kernel: the 60 MB key is shared by all workgroups through L2 / Infinity Cache (measured
     # HBM traffic is ~1 % of the streaming model's bytes), so the binding roof is the FP64 vector pipe.  The
@@ -220,23 +468,26 @@ def main():
                         "exact kernel build (null when the committed record is of another build)"}
     result = {
         "metric": "PBS/sec (shortint PARAM_MESSAGE_2_CARRY_2, classic PBS, f64 FFT external product)",
-        "value": value, "unit": "PBS/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "value": value, "unit": "PBS/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64 (u64 torus)", "data": "synthetic",
         "config": {"workload": "batch of 4096 independent PBS per GPU, PARAM_MESSAGE_2_CARRY_2 "
                                "(n=918,k=1,N=2048,l=1,base_log=23, centered-mean MS), f64 FFT, inputs resident in HBM",
                    "batch_per_gpu": B, "lwe_dimension": p.n, "glwe_dimension": p.k, "polynomial_size": p.N,
                    "pbs_kernel": {1: "generic_lds", 2: "wave_throughput"}.get(kernel_id, str(kernel_id)),
-                   "parallelism": f"batch-sharded x{world}, key replicas, no collective"},
+                   "parallelism": f"batch-sharded x{n_gpus}, key replicas, no collective", "launch": mode},
         "roofline": roofline,
     }
+    if per_gpu is not None:
+        result["per_gpu"] = per_gpu
+        result["fake_multi_gpu"] = fake
     if latency_ms is not None:
         result["extra"] = {"single_pbs_latency_ms": latency_ms,
                            "single_pbs_kernel": {7: "block_latency", 2: "wave_throughput"}.get(latency_kernel,
                                                                                               str(latency_kernel)),
                            "note": "one PBS, batch 1, same key; not part of `value` (the reference publishes "
                                    "4.21 ms on an H100, BASELINE.md)"}
-    if world == 1 and args.kernel == 0 and not args.no_extra:
+    if single and args.kernel == 0 and not args.no_extra:
         # the "N=1024" wording of BASELINE.json: the production set with polynomial size 1024 (k = 2, n = 885) on the
         # same GPU, uniform-random key and inputs like the reference's own benches; reported next to `value`, never in it
         from tests.common import C1P
@@ -273,7 +524,7 @@ def main():
             "pbs_per_s": B / ms2 * 1e3, "frac_hbm_streaming_model": B / ms2 * 1e3 * bytes2 / (HBM_PEAK_GBPS * 1e9),
             "frac_fp64": B / ms2 * 1e3 * 1.8e8 / (FP64_PEAK_TFLOPS * 1e12),
             "pbs_kernel_id": int(lib.hip_backend_last_pbs_kernel())}
-    if world == 1 and args.kernel == 0 and not args.no_extra:
+    if single and args.kernel == 0 and not args.no_extra:
         # BASELINE.json configs 3 and 4 next to the headline (never part of `value`): batch 4096 on this GPU, HIP-event
         # time over 3 launches, and the GPU's output words compared with the CPU oracle on the first 64 LWEs.
         from tests.common import C4
@@ -356,7 +607,7 @@ def main():
             t0 = time.perf_counter()
             ref4 = orc.pbs_multi_bit(orc.ENGINE_FFT, cts4[:PAR], lut4, bsk4_h, q.n, q.k, q.N, q.pbs_base_log,
                                      q.pbs_level, q.grouping)   # key conversion + OpenMP over the LWEs in the C oracle
-            traffic4, src4 = pmc_record("mb_g3") if tag == "multibit_g3" else (None, "not profiled")
+            traffic4, src4 = pmc_record("mb_g3" if tag == "multibit_g3" else "mb_g4")
             dp.update({"engine": f"f64 FFT, multi-bit grouping factor {q.grouping} (Fourier-domain key; keybundle "
                                  "combined in registers per LWE and group)",
                        "frac_fp64": dp["pbs_per_s"] * flop / (FP64_PEAK_TFLOPS * 1e12), "f64_flop_per_pbs": flop,
@@ -366,49 +617,18 @@ def main():
                                         f"({time.perf_counter() - t0:.1f} s CPU); uniform-random key and inputs"})
             result["extra"][tag] = dp
             del bsk4, d_in4, d_out4
-        # ---- config 5 on ONE GPU: FheUint64 (32 blocks of the 2_2 set) add and mul through the radix layer of the
-        # backend (keyswitch -> PBS rounds, `tfhe_rs_amd/integer_gpu.py` over the reference's integer FFI names);
-        # same key as the headline, 32 distinct operand pairs tiled over the batch (timing is data independent),
-        # every distinct result decrypted and compared with clear arithmetic outside the timed region.
-        from tfhe_rs_amd import integer_gpu as igpu
-        ksk_h = orc.gen_ksk(0x74666865 + 2, keys.glwe_sk, keys.lwe_sk, p.ks_base_log, p.ks_level, p.lwe_noise)
-        ksk = gpu.CudaLweKeyswitchKey.from_lwe_keyswitch_key(ksk_h, p.k * p.N, p.n, p.ks_base_log, p.ks_level, streams)
-        sks = igpu.CudaServerKey(ksk, bsk, 4, 4)
-        LB, DISTINCT = 32, 32
-        mask64 = (1 << (2 * LB)) - 1
-        r5 = np.random.default_rng(5)
-        va = [int.from_bytes(r5.bytes(8), "little") for _ in range(DISTINCT)]
-        vb = [int.from_bytes(r5.bytes(8), "little") for _ in range(DISTINCT)]
-        er = orc.Rng(55)
-        enc = lambda vals: np.stack([np.stack([orc.lwe_encrypt(er, keys.glwe_sk, (((v >> (2 * j)) & 3) * p.delta) % (1 << 64),
-                                                               p.glwe_noise) for j in range(LB)]) for v in vals])
-        ha, hb = enc(va), enc(vb)
-        fhe = {}
-        for op, nb in (("add", 1024), ("mul", 128)):
-            reps = nb // DISTINCT
-            ca = igpu.CudaUnsignedRadixCiphertext.from_blocks(np.tile(ha, (reps, 1, 1)), streams)
-            cb = igpu.CudaUnsignedRadixCiphertext.from_blocks(np.tile(hb, (reps, 1, 1)), streams)
-            streams.synchronize()
-            t0 = time.perf_counter()
-            if op == "add":
-                sks.add_assign(ca, cb, streams)
-                pbs_count = int(lib.hip_integer_propagate_pbs_count(LB))
-            else:
-                pbs_count = int(sks.mul_assign(ca, cb, streams, return_pbs_count=True))
-            streams.synchronize()
-            dt = time.perf_counter() - t0
-            rows = ca.to_blocks(streams)
-            want = [((x + y) if op == "add" else (x * y)) & mask64 for x, y in zip(va, vb)]
-            got = [sum(decrypt_big(p, keys, rows[i, j]) << (2 * j) for j in range(LB)) for i in range(DISTINCT)]
-            fhe[op] = {"batch": nb, "seconds": dt, "ops_per_s": nb / dt, "pbs_per_op": pbs_count,
-                       "ks_pbs_per_s": nb * pbs_count / dt, "results_decrypt_to_clear_arithmetic": got == want}
-            del ca, cb
-        fhe["note"] = ("one GPU, classic 2_2 set, wall clock including scratch allocation, index uploads and every round; "
-                       "the reference publishes 510 add/s and 53.2 mul/s on 8xH100 with multi-bit parameters (BASELINE.md); "
-                       "multi-bit sets and several streams: tools/bench_integer.py, profiles/r02_bench_integer_fheuint64.jsonl")
-        result["extra"]["fheuint64"] = fhe
-        del sks, ksk
-    if world == 1 and not args.no_cpu_baseline:
+        # ---- config 5 on ONE GPU: FheUint64 (32 blocks of the 2_2 set) add and mul through the radix layer
+        result["extra"]["fheuint64"] = fheuint64_datapoint(lib, p, keys, [g], {"add": 1024, "mul": 128}, in_library=False)
+    if not single and per_gpu is not None and args.kernel == 0 and not args.no_extra:
+        # ---- config 5 on the N GPUs: the batch of 1024 FheUint64 sharded (a) by the caller, 1024 / N integers per GPU,
+        # every round GPU-local, and (b) inside the library, one CudaStreamsFFI naming the N GPUs: the
+        # ciphertexts live on the first GPU and every KS -> PBS round is split over the GPUs with peer copies
+        # (helper_multi_gpu.cuh:170-294).
+        result.setdefault("extra", {})["fheuint64"] = fheuint64_datapoint(lib, p, keys, devices, {"add": 1024, "mul": 128},
+                                                                          in_library=False)
+        result["extra"]["fheuint64_in_library_sharding"] = fheuint64_datapoint(lib, p, keys, devices,
+                                                                               {"add": 1024, "mul": 128}, in_library=True)
+    if single and not args.no_cpu_baseline:
         # CPU leg: the oracle's f64 path on the host cores actually available to this process
         # (affinity mask and cgroup quota, not the machine's nominal thread count), on a sample
         # sized from a short calibration so the leg takes ~15 s.

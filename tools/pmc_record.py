@@ -38,17 +38,52 @@ TARGETS = {
 }
 
 
+HBM_PASSES = ["FETCH_SIZE", "WRITE_SIZE"]   # --hbm-only: what bench.py's `traffic` needs, two passes per kernel
+
+
+def provenance():
+    """Where and with what the counters were taken (written into the record)."""
+    info = {"host": os.uname().nodename}
+    try:
+        info["rocm"] = open("/opt/rocm/.info/version").read().strip()
+    except OSError:
+        pass
+    try:
+        r = subprocess.run(["rocminfo"], capture_output=True, text=True, timeout=60).stdout
+        names = [l.split(":", 1)[1].strip() for l in r.splitlines() if "Marketing Name" in l]
+        gfx = [l.split(":", 1)[1].strip() for l in r.splitlines() if l.strip().startswith("Name:") and "gfx" in l]
+        info["isa"] = sorted(set(gfx))
+        info["gpus"] = [n for n in names if "Instinct" in n or "MI3" in n] or [n for n in names if n][-1:] or info["isa"]
+    except Exception as e:  # noqa: BLE001
+        info["rocminfo"] = f"unavailable ({e.__class__.__name__})"
+    try:
+        info["rocprofv3"] = subprocess.run(["rocprofv3", "--version"], capture_output=True, text=True,
+                                           timeout=60).stdout.strip().splitlines()[0]
+    except Exception:  # noqa: BLE001
+        pass
+    return info
+
+
 def main():
-    args = [a for a in sys.argv[1:] if not a.startswith("--")]
-    tag = "run"
-    if "--tag" in sys.argv:
-        tag = sys.argv[sys.argv.index("--tag") + 1]
-        args = [a for a in args if a != tag]
-    targets = args or ["fft", "ntt", "mb_g3"]
+    global PASSES
+    argv = sys.argv[1:]
+    opts = {}
+    for name in ("--tag", "--out", "--timeout"):
+        if name in argv:
+            i = argv.index(name)
+            opts[name] = argv[i + 1]
+            del argv[i:i + 2]
+    if "--hbm-only" in argv:
+        argv.remove("--hbm-only")
+        PASSES = HBM_PASSES
+    tag = opts.get("--tag", "run")
+    per_pass_timeout = float(opts.get("--timeout", 600))
+    targets = [a for a in argv if not a.startswith("--")] or ["fft", "ntt", "mb_g3", "mb_g4"]
     out_dir = os.path.join(ROOT, "gpurun_out")
     os.makedirs(out_dir, exist_ok=True)
     env = dict(os.environ, TMPDIR="/tmp")
-    record = {"build_id": source_build_id(), "batch": 4096, "kernels": {},
+    record = {"build_id": source_build_id(), "batch": 4096, "kernels": {}, "provenance": provenance(),
+              "measured_unix_time": __import__("time").time(),
               "method": "rocprofv3 --pmc, one counter group per pass, one launch per pass; hbm_bytes_per_launch = "
                         "2*FETCH_SIZE + WRITE_SIZE (MI355X_MICROARCH.md, HBM section)"}
     for t in targets:
@@ -57,9 +92,13 @@ def main():
         for i, counters in enumerate(PASSES):
             d = os.path.join(out_dir, f"pmc_{tag}_{t}_{i}")
             subprocess.run(["rm", "-rf", d])
-            r = subprocess.run(["rocprofv3", "--pmc", *counters.split(), "-d", d, "--", sys.executable,
-                                os.path.join(ROOT, "tools", "measure_all.py"), sel], cwd="/tmp", env=env,
-                               capture_output=True, text=True)
+            try:
+                r = subprocess.run(["rocprofv3", "--pmc", *counters.split(), "-d", d, "--", sys.executable,
+                                    os.path.join(ROOT, "tools", "measure_all.py"), sel], cwd="/tmp", env=env,
+                                   capture_output=True, text=True, timeout=per_pass_timeout)
+            except (OSError, subprocess.TimeoutExpired) as e:
+                print(f"[{t} pass {i}] rocprofv3 did not run: {e}", file=sys.stderr)
+                continue
             if r.returncode != 0:
                 print(f"[{t} pass {i}] rocprofv3 failed:\n{r.stderr[-800:]}", file=sys.stderr)
                 continue
@@ -87,9 +126,10 @@ def main():
         sums["kernel"] = kname
         record["kernels"][t] = sums
         print(t, json.dumps(sums))
-    with open(os.path.join(out_dir, f"pmc_{tag}.json"), "w") as f:
+    out_path = opts.get("--out", os.path.join(out_dir, f"pmc_{tag}.json"))
+    with open(out_path, "w") as f:
         json.dump(record, f, indent=1)
-    print("wrote", os.path.join(out_dir, f"pmc_{tag}.json"), "- copy to profiles/pmc_latest.json to publish")
+    print("wrote", out_path, "- copy to profiles/pmc_latest.json to publish")
 
 
 if __name__ == "__main__":
