@@ -324,6 +324,19 @@ void cuda_apply_univariate_lut_64_async(
     CudaStreamsFFI streams, CudaRadixCiphertextFFI *output_radix_lwe,
     CudaRadixCiphertextFFI const *input_radix_lwe, int8_t *mem_ptr, void *const *ksks, void *const *bsks);
 void cleanup_cuda_apply_univariate_lut_64(CudaStreamsFFI streams, int8_t **mem_ptr_void);
+/* integer.h:135-160: `input_lut` is ONE accumulator that packs num_many_lut functions in sub-tables of lut_stride
+ * coefficients (tfhe/src/shortint/engine/mod.rs:169-254); one keyswitch and one PBS per block, the PBS extracts
+ * num_luts samples; function t of input block s is written to output block t * n + s. */
+uint64_t scratch_cuda_apply_many_univariate_lut_64_async(
+    CudaStreamsFFI streams, int8_t **mem_ptr, void const *input_lut,
+    CudaLweBootstrapKeyParamsFFI bsk_params, CudaLweKeyswitchKeyParamsFFI ksk_params,
+    uint32_t num_radix_blocks, uint32_t message_modulus, uint32_t carry_modulus, uint32_t num_many_lut,
+    uint64_t lut_degree, bool allocate_gpu_memory, enum PBS_MS_REDUCTION_T noise_reduction_type);
+void cuda_apply_many_univariate_lut_64_async(
+    CudaStreamsFFI streams, CudaRadixCiphertextFFI *output_radix_lwe,
+    CudaRadixCiphertextFFI const *input_radix_lwe, int8_t *mem_ptr, void *const *ksks, void *const *bsks,
+    uint32_t num_luts, uint32_t lut_stride);
+void cleanup_cuda_apply_many_univariate_lut_64(CudaStreamsFFI streams, int8_t **mem_ptr_void);
 
 void cuda_add_lwe_ciphertext_vector_inplace_64(
     void *stream, uint32_t gpu_index, CudaRadixCiphertextFFI *lwe_array_inout,

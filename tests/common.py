@@ -182,3 +182,24 @@ def centered_ms_edge_vectors(n, log_mod, seed=5):
         for j, b in enumerate(bodies):
             out[f"{name}/body{j}"] = np.array(mask + [b], dtype=np.uint64)
     return out
+
+
+def generate_many_lut(p: Params, functions):
+    """shortint's many-LUT accumulator (tfhe/src/shortint/engine/mod.rs:169-254 fill_many_lut_accumulator): the
+    plaintext space of p.plaintext_modulus values is shared by len(functions) functions; inputs must stay below
+    max_degree + 1 = plaintext_modulus // len(functions); function t occupies the boxes of sub-table t, of
+    sample_extraction_stride = (max_degree + 1) * box coefficients.  Returns (accumulator, max_degree, stride)."""
+    fn = len(functions)
+    sup = p.plaintext_modulus
+    assert 1 <= fn <= sup // 2, "Cannot generate many lut accumulator for that many functions"
+    box = p.N // sup
+    max_degree = sup // fn - 1
+    sub = (max_degree + 1) * box
+    body = np.zeros(p.N, dtype=np.uint64)
+    for t, f in enumerate(functions):
+        for m in range(max_degree + 1):
+            body[t * sub + m * box:t * sub + (m + 1) * box] = np.uint64((int(f(m)) * p.delta) % (1 << 64))
+    half = box // 2
+    body[:half] = (np.uint64(0) - body[:half])
+    body = np.roll(body, -half)
+    return np.concatenate([np.zeros(p.k * p.N, dtype=np.uint64), body]), max_degree, sub

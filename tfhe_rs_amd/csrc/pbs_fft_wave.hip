@@ -111,6 +111,9 @@
 #ifndef WAVE_MB_SETS
 #define WAVE_MB_SETS 4  // multi-bit: register sets in rotation (SETS - 1 key requests in flight)
 #endif
+#ifndef WAVE_MB_BASES
+#define WAVE_MB_BASES 2  // multi-bit monomial bases gathered 0: once per group, 1: per level ahead of the key requests, 2: per level behind the first ones
+#endif
 #ifndef WAVE_FUSE_PASS1
 #define WAVE_FUSE_PASS1 1    // first inverse pass interleaved with the MAC chunks
 #endif
@@ -916,7 +919,7 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
     for (uint32_t grp = 0; grp < groups; ++grp) {
       // monomial degrees of the 2^g - 1 non-empty subsets (:30-65): subset s selects mask element m of
       // the group when bit (g-1-m) of s is set
-      auto degrees = [&](const uint64_t *lw, uint32_t (&dg)[per], cplx (&bs)[per]) {
+      auto degrees = [&](const uint64_t *lw, uint32_t (&dg)[per]) {
         uint64_t m[g];
         HX_UNROLL
         for (uint32_t q = 0; q < g; ++q) m[q] = lw[(size_t)grp * g + q];
@@ -927,21 +930,33 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
           for (uint32_t q = 0; q < g; ++q)
             if ((sidx >> (g - 1 - q)) & 1) sum += m[q];
           dg[sidx] = HX_UNIFORM((uint32_t)modulus_switch(sum, LOG2N2));
-          bs[sidx] = ldc(mono, ((a_lane * dg[sidx]) & (2u * N - 1u)) * 16u, 0u);
         }
         dg[0] = 0;
+      };
+      // The gathered monomial bases (one table entry per lane and subset) are requested per LEVEL, right before
+      // the multiply-accumulate that uses them, not per group: held across the digit and forward-transform phases
+      // they cost 4 (2^g - 1) registers per LWE (56 at g = 3 in SHARE mode) exactly where the transform needs the
+      // file, and the two-level g = 3 kernel spilled 55 registers (5.4 GB of scratch writes per launch).  The
+      // 64 KB table is L1/L2 resident; the requests are issued ahead of the level's first key requests.
+      auto bases = [&](const uint32_t (&dg)[per], cplx (&bs)[per]) {
+        HX_UNROLL
+        for (uint32_t sidx = 1; sidx < per; ++sidx)
+          bs[sidx] = ldc(mono, ((a_lane * dg[sidx]) & (2u * N - 1u)) * 16u, 0u);
         bs[0] = cplx{1.0, 0.0};
       };
       uint32_t deg[per];
-      cplx base[per];
       uint32_t deg_b[SHARE ? per : 1];  // SHARE: deg / base belong to the quad's first LWE, these to its second
-      cplx base_b[SHARE ? per : 1];
       if constexpr (SHARE) {
-        degrees(lwe_q0, deg, base);
-        degrees(lwe_q1, deg_b, base_b);
+        degrees(lwe_q0, deg);
+        degrees(lwe_q1, deg_b);
       } else {
-        degrees(lwe, deg, base);
+        degrees(lwe, deg);
       }
+#if WAVE_MB_BASES == 0
+      cplx base[per], base_b[SHARE ? per : 1];
+      bases(deg, base);
+      if constexpr (SHARE) bases(deg_b, base_b);
+#endif
       // the group's 2^g GGSWs as one buffer: uniform base in scalar registers, lane offset in one vector register
 #if WAVE_MB_PACE && !defined(TFHE_HIPEMU)
       auto pace_wait = [&]() {
@@ -1018,6 +1033,13 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
           const cplx *fb0 = (const cplx *)((const char *)qbuf + 2 * BUF_BYTES) + fslot;
           const cplx *fb1 = (const cplx *)((const char *)qbuf + 3 * BUF_BYTES) + fslot;
           constexpr int SETS = WAVE_MB_SHARE_SETS, RW = 8, STEPS = RW * (int)per;
+#if WAVE_MB_BASES != 0
+          cplx base[per], base_b[per];
+#endif
+#if WAVE_MB_BASES == 1
+          bases(deg, base);
+          bases(deg_b, base_b);
+#endif
           cplx x0[SETS], x1[SETS];
           auto request = [&](int set, int t) {
             const uint32_t sidx = (uint32_t)(t % (int)per);
@@ -1028,6 +1050,12 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
           HX_UNROLL
           for (int t = 0; t < SETS && t < STEPS; ++t) request(t, t);
           HX_SCHED_FENCE();
+#if WAVE_MB_BASES == 2
+          // behind the first key requests (loads return in order and subset 0 needs no factor)
+          bases(deg, base);
+          bases(deg_b, base_b);
+          HX_SCHED_FENCE();
+#endif
           // ---- all four transforms of the quad are in its buffers (mapping M3: slot lane*17 + r); the first key
           // requests are already on their way
           quad_sync();
@@ -1092,6 +1120,12 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
           // rotate: the set a step frees takes the request of the step SETS ahead, so SETS - 1 requests
           // (2 PTS coalesced 1 KiB wave loads each) are in flight while one set is accumulated.
           constexpr int PTS = WAVE_MB_PTS, SETS = WAVE_MB_SETS, CHUNKS = 16 / PTS, STEPS = CHUNKS * (int)per;
+#if WAVE_MB_BASES != 0
+          cplx base[per];
+#endif
+#if WAVE_MB_BASES == 1
+          bases(deg, base);
+#endif
           cplx x0[SETS][PTS], x1[SETS][PTS];
           auto request = [&](int set, int t) {
             const uint32_t sidx = (uint32_t)(t % (int)per);
@@ -1108,6 +1142,10 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
           HX_UNROLL
           for (int t = 0; t < SETS && t < STEPS; ++t) request(t, t);
           HX_SCHED_FENCE();
+#if WAVE_MB_BASES == 2
+          bases(deg, base);  // behind the first key requests (loads return in order and subset 0 needs no factor)
+          HX_SCHED_FENCE();
+#endif
           flag_wait(f_ready_ot, epoch);
           const cplx *row0 = (w == 0 ? buf : obuf) + base_m3(cx);
           const cplx *row1 = (w == 0 ? obuf : buf) + base_m3(cx);

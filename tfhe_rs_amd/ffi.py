@@ -123,6 +123,10 @@ SIGNATURES = {
     "scratch_cuda_apply_univariate_lut_64_async": (_u64, [_S, _i8pp, _v, _BK, _KK, _u32, _u32, _u32, _u64, _b, _u32]),
     "cuda_apply_univariate_lut_64_async": (None, [_S, _R, _R, _v, _i8pp, _i8pp]),
     "cleanup_cuda_apply_univariate_lut_64": (None, [_S, _i8pp]),
+    "scratch_cuda_apply_many_univariate_lut_64_async": (_u64, [_S, _i8pp, _v, _BK, _KK, _u32, _u32, _u32, _u32, _u64, _b,
+                                                                _u32]),
+    "cuda_apply_many_univariate_lut_64_async": (None, [_S, _R, _R, _v, _i8pp, _i8pp, _u32, _u32]),
+    "cleanup_cuda_apply_many_univariate_lut_64": (None, [_S, _i8pp]),
     "cuda_add_lwe_ciphertext_vector_inplace_64": (None, [_v, _u32, _R, _R]),
     "scratch_cuda_propagate_single_carry_64_inplace_async":
         (_u64, [_S, _i8pp, _BK, _KK, _u32, _u32, _u32, _u32, _b, _u32]),

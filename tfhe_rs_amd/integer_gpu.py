@@ -80,6 +80,27 @@ class CudaServerKey:
         _lib().cleanup_cuda_apply_univariate_lut_64(s, C.byref(mem))
         return out
 
+    def apply_many_lookup_table(self, ct, many_lut, num_luts, lut_stride, streams, degree=None):
+        """integer/gpu/mod.rs cuda_backend_apply_many_univariate_lut: ONE keyswitch and ONE bootstrap per block evaluate the
+        `num_luts` functions packed in `many_lut` (shortint ManyLookupTable: sub-tables of `lut_stride` coefficients,
+        shortint/engine/mod.rs:169-254).  Returns a ciphertext of num_luts * blocks blocks: function t of block s of
+        the input at flat block t * total_blocks + s."""
+        s, keep = self._streams(streams)
+        ksks, bsks = self._key_ptrs(streams)
+        many_lut = np.ascontiguousarray(many_lut, dtype=U64)
+        mem = C.c_void_p()
+        n = ct.total_blocks
+        _lib().scratch_cuda_apply_many_univariate_lut_64_async(
+            s, C.byref(mem), many_lut.ctypes.data_as(C.c_void_p), self._bsk_params(), self._ksk_params(), n,
+            self.message_modulus, self.carry_modulus, num_luts, degree if degree is not None else self.message_modulus - 1,
+            True, self._noise_reduction())
+        out = CudaUnsignedRadixCiphertext(CudaVec(num_luts * n * (ct.lwe_dimension + 1), streams), num_luts * ct.num_integers,
+                                          ct.num_blocks, ct.lwe_dimension)
+        _lib().cuda_apply_many_univariate_lut_64_async(s, C.byref(out._ffi()), C.byref(ct._ffi()), mem, ksks, bsks,
+                                                       num_luts, lut_stride)
+        _lib().cleanup_cuda_apply_many_univariate_lut_64(s, C.byref(mem))
+        return out
+
     def unchecked_add_assign(self, lhs, rhs, streams):
         """Block-wise LWE addition, no carry handling (radix/add.rs unchecked_add_assign)."""
         assert lhs.total_blocks == rhs.total_blocks
