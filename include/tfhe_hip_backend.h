@@ -92,9 +92,16 @@ void cuda_programmable_bootstrap_64_async(
 void cleanup_cuda_programmable_bootstrap_64(void *stream, uint32_t gpu_index, int8_t **pbs_buffer);
 
 /* extension: the shortint atomic pattern KS -> PBS (tfhe/src/shortint/atomic_pattern/standard.rs:162-199) in ONE
- * call on a scratch made by scratch_cuda_programmable_bootstrap_64_async: lwe_array_in holds ciphertexts under the
- * BIG key (dimension glwe_dimension * polynomial_size), ksk the big -> small keyswitch key; the keyswitched list
- * lives in the scratch.  Two launches on `stream`, no allocation, no host synchronisation. */
+ * call on a scratch made by hip_scratch_keyswitch_programmable_bootstrap_64_async (the classic PBS scratch plus the
+ * keyswitched list and its indexes; same parameters and cleanup as scratch_cuda_programmable_bootstrap_64_async, whose
+ * own size the reference's callers track): lwe_array_in holds ciphertexts under the BIG key (dimension
+ * glwe_dimension * polynomial_size), ksk the big -> small keyswitch key.  Two launches on `stream`, no allocation,
+ * no host synchronisation. */
+uint64_t hip_scratch_keyswitch_programmable_bootstrap_64_async(
+    void *stream, uint32_t gpu_index, int8_t **buffer, uint32_t lwe_dimension,
+    uint32_t glwe_dimension, uint32_t polynomial_size, uint32_t level_count,
+    uint32_t input_lwe_ciphertext_count, bool allocate_gpu_memory,
+    enum PBS_MS_REDUCTION_T noise_reduction_type);
 void hip_keyswitch_programmable_bootstrap_64_async(
     void *stream, uint32_t gpu_index, void *lwe_array_out, void const *lwe_output_indexes,
     void const *lut_vector, void const *lut_vector_indexes, void const *lwe_array_in,

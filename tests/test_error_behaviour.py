@@ -146,3 +146,47 @@ def test_missing_library_fails_loudly_instead_of_falling_back():
     r = subprocess.run([sys.executable, "-c", PRELUDE], env=env, capture_output=True, text=True, timeout=120)
     assert r.returncode != 0
     assert "no CPU fallback" in r.stderr.lower() or "There is no CPU fallback" in r.stderr
+
+
+KEY_REWRITE = """
+n_in, n_out, bl, lv, B = 2048, 12, 4, 4, 5
+rng = np.random.default_rng(3)
+ksk = gpu.CudaLweKeyswitchKey.from_lwe_keyswitch_key(rng.integers(0, 1 << 64, size=n_in * lv * (n_out + 1), dtype=np.uint64),
+                                                     n_in, n_out, bl, lv, st)
+d_in = gpu.CudaLweCiphertextList.from_lwe_ciphertext_list(rng.integers(0, 1 << 64, size=(B, n_in + 1), dtype=np.uint64), st)
+d_out = gpu.CudaLweCiphertextList.new(n_out, B, st)
+idx = gpu.CudaVec.from_cpu_async(np.arange(B, dtype=np.uint64), st)
+gpu.cuda_keyswitch_lwe_ciphertext(ksk, d_in, d_out, idx, idx, True, st)      # builds the matrix-core layout
+st.synchronize()
+print("WARM", flush=True)
+%s                                                                            # the key changes BEHIND the library
+gpu.cuda_keyswitch_lwe_ciphertext(ksk, d_in, d_out, idx, idx, True, st)
+st.synchronize()
+print("SURVIVED", flush=True)
+"""
+
+
+def test_key_rewritten_behind_the_library_is_detected_not_served_stale():
+    """INTEGRATION.md, keyswitch-key contract: the cached matrix-core layout carries a fingerprint of the key; a key
+    rewritten in place without going through the library's entry points makes the next keyswitch trap instead of
+    returning results computed from stale planes.  (Host emulation: device memory is host memory, the rewrite is a
+    plain memset.)"""
+    r = run(KEY_REWRITE % "C.memset(ksk.d_vec.ptr, 0x5A, n_in * lv * (n_out + 1) * 8)")
+    assert "WARM" in r.stdout and "SURVIVED" not in r.stdout, (r.stdout, r.stderr[-300:])
+    assert r.returncode < 0, r.returncode          # killed by the trap
+    # the same rewrite THROUGH the library invalidates the layout and the keyswitch simply rebuilds it
+    r = run(KEY_REWRITE % "lib.cuda_memset_async(ksk.d_vec.ptr, 0x5A, n_in * lv * (n_out + 1) * 8, S, G)")
+    assert r.returncode == 0 and "SURVIVED" in r.stdout, r.stderr[-300:]
+
+
+@pytest.mark.gpu
+def test_key_rewritten_by_a_raw_hip_call_traps_on_the_gpu():
+    snippet = KEY_REWRITE % ("hip = C.CDLL('libamdhip64.so'); hip.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]; "
+                             "assert hip.hipMemset(ksk.d_vec.ptr, 0x5A, n_in * lv * (n_out + 1) * 8) == 0; "
+                             "assert hip.hipDeviceSynchronize() == 0")
+    env = dict(os.environ)
+    env.pop("TFHE_HIP_BACKEND_LIB", None)
+    r = subprocess.run([sys.executable, "-c", PRELUDE + textwrap.dedent(snippet)], env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert "WARM" in r.stdout and "SURVIVED" not in r.stdout, (r.stdout, r.stderr[-400:])
+    assert r.returncode != 0

@@ -69,8 +69,9 @@ class Job:
             lib.scratch_cuda_multi_bit_programmable_bootstrap_64_async(s, 0, C.byref(self.buf), p.k, p.N, p.pbs_level,
                                                                        B, True)
         else:
-            lib.scratch_cuda_programmable_bootstrap_64_async(s, 0, C.byref(self.buf), p.n, p.k, p.N, p.pbs_level, B,
-                                                             True, p.ms_type)
+            scratch = (lib.hip_scratch_keyswitch_programmable_bootstrap_64_async if ksk is not None
+                       else lib.scratch_cuda_programmable_bootstrap_64_async)
+            scratch(s, 0, C.byref(self.buf), p.n, p.k, p.N, p.pbs_level, B, True, p.ms_type)
         self.st.synchronize()
 
     def enqueue(self):

@@ -303,7 +303,7 @@ def cuda_keyswitch_programmable_bootstrap_lwe_ciphertext(input, output, accumula
     lib = _lib()
     buf = C.c_void_p()
     s, g = streams.ptr[0], streams.gpu_indexes[0]
-    lib.scratch_cuda_programmable_bootstrap_64_async(
+    lib.hip_scratch_keyswitch_programmable_bootstrap_64_async(
         s, g, C.byref(buf), bsk.input_lwe_dimension, bsk.glwe_dimension, bsk.polynomial_size,
         bsk.decomp_level_count, num_samples, True, 1 if bsk.ms_noise_reduction else 0)
     lib.hip_keyswitch_programmable_bootstrap_64_async(

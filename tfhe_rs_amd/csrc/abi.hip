@@ -255,17 +255,30 @@ uint64_t scratch_cuda_programmable_bootstrap_64_async(void *stream, uint32_t gpu
                                                  : (uint64_t)input_lwe_ciphertext_count * (glwe_dimension + 1) *
                                                        polynomial_size * sizeof(uint64_t);
   if (allocate_gpu_memory && bytes) HX_CHECK(hipMalloc((void **)&b->acc_scratch, bytes));
-  // room for the keyswitch output of the one-call KS -> PBS entry point (the atomic pattern of the shortint layer)
+  *buffer = reinterpret_cast<int8_t *>(b);
+  return bytes;
+}
+
+// Scratch of the one-call KS -> PBS entry point (hip_keyswitch_programmable_bootstrap_64_async): the classic PBS
+// scratch plus room for the keyswitched list and its trivial indexes (filled by a kernel on `stream`: nothing
+// blocks).  A caller that only bootstraps takes the plain scratch above and pays for neither.
+uint64_t hip_scratch_keyswitch_programmable_bootstrap_64_async(void *stream, uint32_t gpu_index, int8_t **buffer,
+                                                               uint32_t lwe_dimension, uint32_t glwe_dimension,
+                                                               uint32_t polynomial_size, uint32_t level_count,
+                                                               uint32_t input_lwe_ciphertext_count,
+                                                               bool allocate_gpu_memory,
+                                                               enum PBS_MS_REDUCTION_T noise_reduction_type) {
+  const uint64_t bytes = scratch_cuda_programmable_bootstrap_64_async(
+      stream, gpu_index, buffer, lwe_dimension, glwe_dimension, polynomial_size, level_count,
+      input_lwe_ciphertext_count, allocate_gpu_memory, noise_reduction_type);
+  auto *b = reinterpret_cast<PbsBuffer *>(*buffer);
   const uint64_t ks_bytes = (uint64_t)input_lwe_ciphertext_count * (lwe_dimension + 1) * sizeof(uint64_t);
   const uint64_t idx_bytes = (uint64_t)input_lwe_ciphertext_count * sizeof(uint64_t);
   if (allocate_gpu_memory && ks_bytes) {
     HX_CHECK(hipMalloc((void **)&b->ks_out, ks_bytes));
     HX_CHECK(hipMalloc((void **)&b->trivial, idx_bytes));
-    std::vector<uint64_t> triv(input_lwe_ciphertext_count);
-    for (uint32_t i = 0; i < input_lwe_ciphertext_count; ++i) triv[i] = i;
-    HX_CHECK(hipMemcpy(b->trivial, triv.data(), idx_bytes, hipMemcpyHostToDevice));
+    launch_iota_u64(S(stream), b->trivial, input_lwe_ciphertext_count);
   }
-  *buffer = reinterpret_cast<int8_t *>(b);
   return bytes + ks_bytes + idx_bytes;
 }
 
@@ -338,7 +351,8 @@ void hip_keyswitch_programmable_bootstrap_64_async(void *stream, uint32_t gpu_in
                                                    uint32_t num_many_lut, uint32_t lut_stride) {
   set_device(gpu_index);
   PbsBuffer *b = checked_buffer(buffer, lwe_dimension, glwe_dimension, polynomial_size, level_count, num_samples);
-  HX_PANIC_IF_FALSE(b->ks_out != nullptr || num_samples == 0, "PBS buffer has no keyswitch scratch");
+  HX_PANIC_IF_FALSE(b->ks_out != nullptr || num_samples == 0,
+                    "PBS buffer has no keyswitch scratch: create it with hip_scratch_keyswitch_programmable_bootstrap_64_async");
   if (num_samples == 0) return;
   // the keyswitch writes block s at position s of the scratch list; the PBS reads that list trivially
   launch_keyswitch(S(stream), b->ks_out, b->trivial, (const uint64_t *)lwe_array_in,
@@ -595,7 +609,7 @@ void cuda_multi_bit_programmable_bootstrap_64_async(void *stream, uint32_t gpu_i
     HX_PANIC_IF_FALSE(num_samples <= b->lat_samples, "multi-bit latency path: %u samples exceed %u", num_samples,
                       b->lat_samples);
   if (choice == 5 || choice == 6 || (choice == 0 && num_samples <= b->lat_samples)) {
-    g_multibit_latency_block = choice != 6;  // 6: the products on the generic kernels (comparison)
+    m.pbs.mb_generic_products = choice == 6;  // 6: the products on the generic kernels (comparison)
     // few ciphertexts: every (group, keybundle polynomial) gets its own workgroup, then the products run alone
     const uint64_t fit = b->lat_bytes / ((uint64_t)num_samples * b->kb_per_sample);  // groups per pass for this batch
     const uint32_t fit_groups = (uint32_t)(fit > 1024 ? 1024 : fit);
@@ -604,7 +618,7 @@ void cuda_multi_bit_programmable_bootstrap_64_async(void *stream, uint32_t gpu_i
     launch_pbs_multi_bit_latency(S(stream), polynomial_size, glwe_dimension, m, b->fft, b->kb_lat, gc, b->acc);
     g_last_pbs_kernel.store(10);
   } else if ((choice == 0 && wave_ok) || choice == 2 || (choice == 7 && wave_ok)) {
-    g_multibit_share = choice != 7;  // 7: every wave pair loads its own key (comparison)
+    m.pbs.mb_no_share = choice == 7;  // 7: every wave pair loads its own key (comparison)
     m.pbs.grouping = grouping_factor;
     m.pbs.pace = b->pace;
     launch_pbs_multi_bit_wave(S(stream), m.pbs, b->fft);
@@ -721,7 +735,7 @@ void cuda_centered_modulus_switch_64_async(void *stream, uint32_t gpu_index, voi
 
 // =========================================================================== extensions
 void hip_backend_set_fft_kernel(uint32_t which) { g_fft_kernel_choice.store(which); }
-void hip_backend_set_keyswitch_kernel(uint32_t which) { g_keyswitch_use_mfma = (which != 1); }
+void hip_backend_set_keyswitch_kernel(uint32_t which) { g_keyswitch_use_mfma.store(which != 1); }
 void hip_backend_set_ntt_kernel(uint32_t which) { g_ntt_kernel_serial = (which == 1); }
 void hip_backend_set_multibit_latency_groups(uint32_t groups) { g_multibit_latency_groups.store(groups); }
 uint32_t hip_backend_last_pbs_kernel(void) { return g_last_pbs_kernel.load(); }

@@ -65,4 +65,12 @@ void launch_closest_representable(hipStream_t st, const uint64_t *in, uint64_t *
   HX_LAUNCH(closest_representable_kernel, dim3(1), dim3(1), 0, st, in, out, base_log, level);
 }
 
+__global__ void iota_u64_kernel(uint64_t *out, uint32_t count) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count) out[i] = i;
+}
+void launch_iota_u64(hipStream_t st, uint64_t *out, uint32_t count) {
+  if (count) HX_LAUNCH(iota_u64_kernel, dim3((count + 255) / 256), dim3(256), 0, st, out, count);
+}
+
 }  // namespace tfhe_hip

@@ -133,7 +133,7 @@ static T *dev_upload(hipStream_t st, const std::vector<T> &h) {
 // (ksks[i], bsks[i]) and scratch, and sends the results back for a scatter on GPU 0.  Events order the streams;
 // no host synchronisation, no collective.  The same code runs with several streams on ONE device (the
 // reference's debug-fake-multi-gpu idea), which is how the 1-GPU test box exercises it.
-static uint32_t g_multi_gpu_min_blocks = 512;  // blocks per GPU below which a round stays on fewer GPUs
+static std::atomic<uint32_t> g_multi_gpu_min_blocks{512};  // blocks per GPU below which a round stays on fewer GPUs
 
 static uint32_t num_inputs_on_gpu(uint32_t total, uint32_t gpu, uint32_t gpus) {  // helper_multi_gpu.cu:71-101
   if (gpus > total) return gpu < total ? 1u : 0u;
@@ -242,7 +242,8 @@ struct LutDriver {
     for (uint32_t off = 0; off < count; off += cap) {
       const uint32_t c = std::min(cap, count - off);
       // helper_multi_gpu.cu:39-48 (get_active_gpu_count): as many GPUs as the round can keep busy
-      const uint32_t active = std::max(1u, std::min(avail, (c + g_multi_gpu_min_blocks - 1) / g_multi_gpu_min_blocks));
+      const uint32_t min_blocks = g_multi_gpu_min_blocks.load();
+      const uint32_t active = std::max(1u, std::min(avail, (c + min_blocks - 1) / min_blocks));
       const uint64_t *ii = in_idx ? in_idx + off : nullptr, *oi = out_idx ? out_idx + off : nullptr;
       const uint64_t *in0 = in_idx ? in : in + off * w;
       uint64_t *out0 = out_idx ? out : out + off * w;
@@ -960,12 +961,14 @@ void cuda_add_lwe_ciphertext_vector_inplace_64(void *stream, uint32_t gpu_index,
 // ---- cuda/include/integer/integer.h:383-413 --------------------------------------------------
 // num_blocks = blocks per integer; the ciphertexts handed to the launch may hold any whole number
 // of integers up to the capacity given through hip_integer_scratch_batch (default 1).
-static uint32_t g_scratch_batch = 1;
+// read by the NEXT scratch_* call of the same host thread (the radix scratch entry points have no batch parameter in
+// the reference's prototypes): thread-local, so that concurrent host threads size their own scratches
+static thread_local uint32_t g_scratch_batch = 1;
 void hip_integer_scratch_batch(uint32_t num_integers) { g_scratch_batch = num_integers ? num_integers : 1; }
 // blocks per GPU from which a KS -> PBS round spreads over one more GPU of the stream set (default 512; the
 // reference's THRESHOLD_MULTI_GPU_* constants, helper_multi_gpu.cu:12-48); tests lower it
 void hip_integer_set_multi_gpu_threshold(uint32_t blocks_per_gpu) {
-  radix::g_multi_gpu_min_blocks = blocks_per_gpu ? blocks_per_gpu : 1;
+  radix::g_multi_gpu_min_blocks.store(blocks_per_gpu ? blocks_per_gpu : 1);
 }
 
 uint64_t scratch_cuda_propagate_single_carry_64_inplace_async(CudaStreamsFFI streams, int8_t **mem_ptr,

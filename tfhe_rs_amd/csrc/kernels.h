@@ -1,5 +1,6 @@
 // kernels.h — host-callable launchers of the backend's kernels (internal to the library).
 #pragma once
+#include <atomic>
 #include "pbs_common.h"
 
 namespace tfhe_hip {
@@ -46,12 +47,11 @@ void launch_keyswitch_64_32(hipStream_t st, uint32_t *lwe_out, const uint64_t *o
 // cache of the matrix-core key layout (keyswitch.hip): drop what overlaps device memory about to be freed / written
 void ksm_invalidate_range(int device, const void *p, size_t bytes);
 size_t ksm_cache_entries();
-extern bool g_keyswitch_use_mfma;
+extern std::atomic<bool> g_keyswitch_use_mfma;
 extern bool g_ntt_kernel_serial;
-extern bool g_multibit_latency_block;
-extern bool g_multibit_share;
 
 // small helpers — ciphertext.hip
+void launch_iota_u64(hipStream_t st, uint64_t *out, uint32_t count);  // out[i] = i
 void launch_modulus_switch(hipStream_t st, uint64_t *out, const uint64_t *in, uint32_t size, uint32_t log_modulus);
 void launch_centered_modulus_switch(hipStream_t st, uint64_t *out, const uint64_t *in, uint32_t lwe_dim, uint32_t log_modulus);
 void launch_sample_extract(hipStream_t st, uint64_t *lwe_out, const uint64_t *glwe_in, const uint32_t *nth,

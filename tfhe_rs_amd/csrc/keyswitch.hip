@@ -20,7 +20,7 @@ constexpr int KS_TPB = 256;  // output columns per workgroup
 constexpr int KS_TB = 16;    // samples per workgroup
 constexpr int KS_IC = 32;    // mask elements decomposed per LDS stage
 constexpr int KS_MAXL = 8;   // max levels staged (level_count <= 8 for every shortint set)
-bool g_keyswitch_use_mfma = true;  // hip_backend_set_keyswitch_kernel: matrix-core path when its conditions hold
+std::atomic<bool> g_keyswitch_use_mfma{true};  // hip_backend_set_keyswitch_kernel: matrix-core path when its conditions hold
 
 // DigitT: int32_t when base_log <= 31 (every shortint set), int64_t for wider bases
 template <typename DigitT>
@@ -258,6 +258,21 @@ __global__ void __launch_bounds__(256) ksk_planes_kernel(int8_t *planes, uint64_
   }
 }
 
+// Fingerprint of a key: KSM_FP words sampled from end to end.  Taken when the matrix-core layout is built and
+// compared by every keyswitch launch (one wave of workgroup (0, 0): 64 loads): a key REWRITTEN IN PLACE behind the
+// library's back (a caller's own kernel, a raw hipMemcpy, a peer copy issued under another gpu_index) while its
+// cached layout is still alive makes the launch trap — loud — instead of keyswitching with stale planes.  Writes
+// through this library's own entry points invalidate the cache and never get here (ksm_invalidate_range).
+constexpr int KSM_FP = 64;
+HX_DEV size_t ksm_fp_index(int l, size_t words) {
+  const size_t step = words / KSM_FP;
+  return step ? (size_t)l * step + ((size_t)l * 977u) % step : (size_t)l % (words ? words : 1);
+}
+template <typename KeyT>
+__global__ void __launch_bounds__(64) ksk_fingerprint_kernel(uint64_t *fp, const KeyT *ksk, size_t words) {
+  fp[threadIdx.x] = (uint64_t)ksk[ksm_fp_index((int)threadIdx.x, words)];
+}
+
 // PADDED: `level` < LEVEL real levels per mask word, the rest zero digits against zero key rows
 // OutT = uint32_t: the 64->32 keyswitch (4 planes, arithmetic mod 2^32, body rounded to 32 bits)
 // KSPLIT = 4 (batches of at most 32 LWEs: one tile of samples per workgroup): the four waves of a workgroup take a
@@ -269,8 +284,13 @@ __global__ void __launch_bounds__(256) ks_mfma_kernel(OutT *lwe_out, const uint6
                                                       const uint64_t *in_idx, const int8_t *planes,
                                                       const uint64_t *colsum, uint32_t n_in, uint32_t n_out,
                                                       uint32_t base_log, uint32_t num_samples, uint32_t col_tiles,
-                                                      uint32_t level) {  // level <= LEVEL (the padded count)
+                                                      uint32_t level,  // level <= LEVEL (the padded count)
+                                                      const OutT *ksk_raw, size_t ksk_words) {
   constexpr int PLANES = (int)sizeof(OutT);
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < KSM_FP) {  // the planes must still be this key's
+    const uint64_t *fp = colsum + (size_t)col_tiles * KSM_CT;
+    if ((uint64_t)ksk_raw[ksm_fp_index((int)threadIdx.x, ksk_words)] != fp[threadIdx.x]) __builtin_trap();
+  }
   __shared__ int32_t sa[4][2][32];  // per wave: sum of the shifted digits of every row, per k half
   __shared__ int32_t red[KSPLIT > 1 ? 2 : 1][KSPLIT > 1 ? PLANES_OF(OutT) : 1][KSPLIT > 1 ? 16 : 1][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -426,7 +446,9 @@ static std::mutex g_ksm_mutex;
 static uint64_t g_ksm_tick = 0;
 constexpr size_t kKsmMaxEntries = 32;
 
-static void ksm_release(KsmEntry &e) {
+// hipFree synchronises the device: never under g_ksm_mutex (other host threads launch keyswitches meanwhile) —
+// entries are unlinked under the lock and released after it
+static void ksm_release(const KsmEntry &e) {
   int cur = 0;
   HX_CHECK(hipGetDevice(&cur));
   HX_CHECK(hipSetDevice(e.device));
@@ -435,21 +457,36 @@ static void ksm_release(KsmEntry &e) {
   HX_CHECK(hipSetDevice(cur));
 }
 
+static bool stream_is_capturing(hipStream_t st) {
+#if defined(TFHE_HIPEMU)
+  (void)st;
+  return false;
+#else
+  hipStreamCaptureStatus status = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &status) != hipSuccess) return false;
+  return status != hipStreamCaptureStatusNone;
+#endif
+}
+
 // device memory [p, p + bytes) of `device` is about to be freed or written
 void ksm_invalidate_range(int device, const void *p, size_t bytes) {
   if (p == nullptr) return;
-  std::lock_guard<std::mutex> lock(g_ksm_mutex);
-  const char *lo = (const char *)p, *hi = lo + (bytes ? bytes : 1);
-  for (size_t i = 0; i < g_ksm_cache.size();) {
-    KsmEntry &e = g_ksm_cache[i];
-    const char *klo = (const char *)e.ksk, *khi = klo + e.ksk_bytes;
-    if (e.device == device && klo < hi && lo < khi) {
-      ksm_release(e);
-      g_ksm_cache.erase(g_ksm_cache.begin() + i);
-    } else {
-      ++i;
+  std::vector<KsmEntry> dead;
+  {
+    std::lock_guard<std::mutex> lock(g_ksm_mutex);
+    const char *lo = (const char *)p, *hi = lo + (bytes ? bytes : 1);
+    for (size_t i = 0; i < g_ksm_cache.size();) {
+      KsmEntry &e = g_ksm_cache[i];
+      const char *klo = (const char *)e.ksk, *khi = klo + e.ksk_bytes;
+      if (e.device == device && klo < hi && lo < khi) {
+        dead.push_back(e);
+        g_ksm_cache.erase(g_ksm_cache.begin() + i);
+      } else {
+        ++i;
+      }
     }
   }
+  for (const KsmEntry &e : dead) ksm_release(e);
 }
 size_t ksm_cache_entries() {
   std::lock_guard<std::mutex> lock(g_ksm_mutex);
@@ -470,11 +507,17 @@ static bool keyswitch_mfma(hipStream_t st, OutT *lwe_out, const uint64_t *out_id
   if (level_pad > 16 || K % 32 != 0 || base_log > 6 || base_log + 7 + log_k > 31) return false;
   const uint32_t ncols = n_out + 1, col_tiles = (ncols + KSM_CT - 1) / KSM_CT;
   const size_t plane_bytes = (size_t)(K / 16) * col_tiles * sizeof(OutT) * KSM_CT * 16;
-  const size_t need = plane_bytes + (size_t)col_tiles * KSM_CT * sizeof(uint64_t);
+  const size_t need = plane_bytes + ((size_t)col_tiles * KSM_CT + KSM_FP) * sizeof(uint64_t);  // planes, column sums, fingerprint
+  const size_t ksk_words = (size_t)n_in * level * ncols;
   int device = 0;
   HX_CHECK(hipGetDevice(&device));
   int8_t *planes = nullptr;
   uint64_t *colsum = nullptr;
+  // Under stream capture the cache is read-only: building an entry allocates and frees (neither may be captured) and
+  // would record `ready` inside the capture, where later launches of other streams could not wait for it.  A key
+  // that is not warm yet takes the scalar kernel for the captured launch (same bits).
+  const bool capturing = stream_is_capturing(st);
+  std::vector<KsmEntry> evicted;
   {
     std::lock_guard<std::mutex> lock(g_ksm_mutex);
     KsmEntry *hit = nullptr;
@@ -484,12 +527,13 @@ static bool keyswitch_mfma(hipStream_t st, OutT *lwe_out, const uint64_t *out_id
         hit = &e;
         break;
       }
+    if (hit == nullptr && capturing) return false;
     if (hit == nullptr) {
-      if (g_ksm_cache.size() >= kKsmMaxEntries) {  // least recently used key goes
+      if (g_ksm_cache.size() >= kKsmMaxEntries) {  // least recently used key goes (released after the lock)
         size_t lru = 0;
         for (size_t i = 1; i < g_ksm_cache.size(); ++i)
           if (g_ksm_cache[i].last_use < g_ksm_cache[lru].last_use) lru = i;
-        ksm_release(g_ksm_cache[lru]);
+        evicted.push_back(g_ksm_cache[lru]);
         g_ksm_cache.erase(g_ksm_cache.begin() + lru);
       }
       KsmEntry e{};
@@ -504,6 +548,8 @@ static bool keyswitch_mfma(hipStream_t st, OutT *lwe_out, const uint64_t *out_id
       HX_CHECK(hipMemsetAsync(cs, 0, (size_t)col_tiles * KSM_CT * sizeof(uint64_t), st));
       HX_LAUNCH((ksk_planes_kernel<OutT>), dim3((col_tiles * KSM_CT + 255) / 256, K / 16), dim3(256), 0, st,
                 (int8_t *)e.planes, cs, ksk, K, ncols, col_tiles, level, level_pad);
+      HX_LAUNCH((ksk_fingerprint_kernel<OutT>), dim3(1), dim3(KSM_FP), 0, st, cs + (size_t)col_tiles * KSM_CT, ksk,
+                ksk_words);
       HX_CHECK(hipEventRecord(e.ready, st));
       e.builder = st;
       e.done = false;
@@ -513,12 +559,14 @@ static bool keyswitch_mfma(hipStream_t st, OutT *lwe_out, const uint64_t *out_id
       // another stream: behind the layout kernel unless it is known to be over (a query, so that a launch under
       // stream capture does not pick up an event from outside the capture once the key is warm)
       if (hipEventQuery(hit->ready) == hipSuccess) hit->done = true;
+      else if (capturing) return false;  // an event from outside the capture cannot be waited for inside it
       else HX_CHECK(hipStreamWaitEvent(st, hit->ready, 0));
     }
     hit->last_use = ++g_ksm_tick;
     planes = (int8_t *)hit->planes;
     colsum = (uint64_t *)((char *)hit->planes + hit->plane_bytes);
   }
+  for (const KsmEntry &e : evicted) ksm_release(e);
   // up to 32 LWEs: one tile of samples, the four waves of a workgroup split K (needs steps = K / 32 divisible by 4)
   const bool split = num_samples <= 32 && (K / 32) % 4 == 0;
   const dim3 grid(col_tiles, split ? 1 : (num_samples + 127) / 128);
@@ -526,16 +574,16 @@ static bool keyswitch_mfma(hipStream_t st, OutT *lwe_out, const uint64_t *out_id
   do {                                                                                                               \
     if (split && level == L)                                                                                         \
       HX_LAUNCH((ks_mfma_kernel<L, false, OutT, 4>), grid, dim3(256), 0, st, lwe_out, out_idx, lwe_in, in_idx,       \
-                planes, colsum, n_in, n_out, base_log, num_samples, col_tiles, level);                               \
+                planes, colsum, n_in, n_out, base_log, num_samples, col_tiles, level, ksk, ksk_words);               \
     else if (split)                                                                                                  \
       HX_LAUNCH((ks_mfma_kernel<L, true, OutT, 4>), grid, dim3(256), 0, st, lwe_out, out_idx, lwe_in, in_idx,        \
-                planes, colsum, n_in, n_out, base_log, num_samples, col_tiles, level);                               \
+                planes, colsum, n_in, n_out, base_log, num_samples, col_tiles, level, ksk, ksk_words);               \
     else if (level == L)                                                                                             \
       HX_LAUNCH((ks_mfma_kernel<L, false, OutT>), grid, dim3(256), 0, st, lwe_out, out_idx, lwe_in, in_idx, planes,   \
-                colsum, n_in, n_out, base_log, num_samples, col_tiles, level);                                       \
+                colsum, n_in, n_out, base_log, num_samples, col_tiles, level, ksk, ksk_words);                       \
     else                                                                                                             \
       HX_LAUNCH((ks_mfma_kernel<L, true, OutT>), grid, dim3(256), 0, st, lwe_out, out_idx, lwe_in, in_idx, planes,    \
-                colsum, n_in, n_out, base_log, num_samples, col_tiles, level);                                       \
+                colsum, n_in, n_out, base_log, num_samples, col_tiles, level, ksk, ksk_words);                       \
   } while (0)
   switch (level_pad) {
     case 1: KSM_LAUNCH(1); break;
@@ -554,7 +602,7 @@ void launch_keyswitch(hipStream_t st, uint64_t *lwe_out, const uint64_t *out_idx
   HX_PANIC_IF_FALSE(base_log >= 1 && level >= 1 && base_log * level < 64,
                     "keyswitch: unsupported decomposition (base_log=%u, level=%u)", base_log, level);
   if (num_samples == 0) return;
-  if (g_keyswitch_use_mfma &&
+  if (g_keyswitch_use_mfma.load() &&
       keyswitch_mfma(st, lwe_out, out_idx, lwe_in, in_idx, ksk, n_in, n_out, base_log, level, num_samples))
     return;
   // the scalar kernels stage at most KS_MAXL levels per mask element (the matrix-core path above takes up to 16)
@@ -585,7 +633,7 @@ void launch_keyswitch_64_32(hipStream_t st, uint32_t *lwe_out, const uint64_t *o
   HX_PANIC_IF_FALSE(base_log >= 1 && level >= 1 && base_log * level <= 32,
                     "keyswitch 64->32: unsupported decomposition (base_log=%u, level=%u)", base_log, level);
   if (num_samples == 0) return;
-  if (g_keyswitch_use_mfma &&
+  if (g_keyswitch_use_mfma.load() &&
       keyswitch_mfma(st, lwe_out, out_idx, lwe_in, in_idx, ksk, n_in, n_out, base_log, level, num_samples))
     return;
   HX_PANIC_IF_FALSE(level <= KS_MAXL, "keyswitch 64->32: level_count %u > %d is only supported by the matrix-core kernel",

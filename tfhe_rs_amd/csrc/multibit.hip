@@ -18,7 +18,6 @@
 #include "kernels.h"
 
 namespace tfhe_hip {
-bool g_multibit_latency_block = true;  // hip_backend_set_fft_kernel(6): generic accumulate kernels instead (comparison)
 
 // keybundle element of polynomial `poly` (index inside one GGSW) at storage slot `slot` / position `pos`
 template <int N>
@@ -326,7 +325,7 @@ static void launch_mb_latency(hipStream_t st, const MultiBitArgs &m, const FftTa
       HX_LAUNCH((mb_keybundle_kernel<N, K1, MB_KB_TILE>), dim3(gpass * kb_polys, (a.num_samples + MB_KB_TILE - 1) / MB_KB_TILE),
                 dim3(GenericCfg<N>::TPB), MB_KB_TILE * 16 * sizeof(uint32_t), st, a, m.grouping_factor, kb_lat, tb, g0,
                 group_chunk);
-    if (N == 2048 && K1 == 2 && a.level <= 8 && !g_ntt_kernel_serial && g_multibit_latency_block)
+    if (N == 2048 && K1 == 2 && a.level <= 8 && !g_ntt_kernel_serial && !a.mb_generic_products)
       // the latency kernel's structure (registers + wave-local exchanges, 4 barriers per product)
       launch_mb_accumulate_block(st, a, tb, (const cplx *)kb_lat, acc_g, group_chunk, gpass, (int)(g0 == 0),
                                  (int)(g0 + gpass == groups));

@@ -35,6 +35,10 @@ struct PbsArgs {
   // the workgroups of an XCD stay within a few groups of each other so that a group's key is fetched from HBM
   // once per XCD instead of once per workgroup
   uint32_t *pace = nullptr;
+  // host side only (kernel selection of THIS call; comparison choices of hip_backend_set_fft_kernel): carried in the
+  // arguments, not in globals, so that concurrent host threads on different streams cannot change each other's kernel
+  bool mb_no_share = false;          // choice 7: every wave pair loads its own key
+  bool mb_generic_products = false;  // choice 6: latency path with the products on the generic kernels
 };
 
 constexpr int ilog2_c(int x) { return x <= 1 ? 0 : 1 + ilog2_c(x / 2); }

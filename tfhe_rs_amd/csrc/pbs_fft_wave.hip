@@ -119,7 +119,6 @@
 #endif
 
 namespace tfhe_hip {
-bool g_multibit_share = true;  // hip_backend_set_fft_kernel(7) on the multi-bit entry point: pairs only (comparison)
 namespace wavek {
 
 constexpr int N = 2048, n = 1024, LOG2N2 = 12;
@@ -1338,10 +1337,11 @@ static void launch_wave_mb_t(hipStream_t st, const PbsArgs &a, const FftTables &
   using namespace wavek;
   if (a.pace) HX_CHECK(hipMemsetAsync(a.pace, 0, 8 * 32 * sizeof(uint32_t), st));
   unsigned per_block = lwes_per_block(a.num_samples);
-  if (per_block == 3 && g_multibit_share) per_block = 4;  // 513 .. 768 LWEs: fuller workgroups that can share (4-12 % faster)
+  const bool share = !a.mb_no_share;  // hip_backend_set_fft_kernel(7) on the multi-bit entry point: pairs only (comparison)
+  if (per_block == 3 && share) per_block = 4;  // 513 .. 768 LWEs: fuller workgroups that can share (4-12 % faster)
   const unsigned blocks = (a.num_samples + per_block - 1) / per_block;
   // an even number of LWEs per workgroup: quads of waves share the key loads of their two LWEs (SHARE)
-  if (per_block % 2 == 0 && g_multibit_share) {
+  if (per_block % 2 == 0 && share) {
     hx_set_dynamic_smem_once<pbs_fft_wave_kernel<L, B, G, true>>(SMEM_BYTES);
     HX_LAUNCH((pbs_fft_wave_kernel<L, B, G, true>), dim3(blocks), dim3(128 * per_block), SMEM_BYTES, st, a, tb);
   } else {

@@ -64,6 +64,8 @@ SIGNATURES = {
     "cuda_programmable_bootstrap_64_async":
         (None, [_v, _u32, _v, _v, _v, _v, _v, _v, _v, _v, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _u32]),
     "cleanup_cuda_programmable_bootstrap_64": (None, [_v, _u32, _i8pp]),
+    "hip_scratch_keyswitch_programmable_bootstrap_64_async":
+        (_u64, [_v, _u32, _i8pp, _u32, _u32, _u32, _u32, _u32, _b, _u32]),
     "hip_keyswitch_programmable_bootstrap_64_async":
         (None, [_v, _u32, _v, _v, _v, _v, _v, _v, _v, _v, _v, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _u32,
                 _u32]),
