@@ -175,6 +175,10 @@ def centered_ms_edge_vectors(n, log_mod, seed=5):
         "all_ones": [M] * n,
         "zeros": [0] * n,
         "mixed": [[tie[i], (tie[i] - 1) & M, (tie[i] + 1) & M, (r[i] << s) & M, M][i % 5] for i in range(n)],
+        # errors of alternating sign around the tie, largest magnitudes: the halving errors cancel pairwise (n even) or
+        # leave one (n odd)
+        "alternating": [((tie[i] - 1) if i % 2 else (tie[i] + 1)) & M for i in range(n)],
+        "alternating_multiples": [(((r[i] << s) - 1) if i % 2 else ((r[i] << s) + 1)) & M for i in range(n)],
     }
     bodies = [0, (1 << (s - 1)) - 1, 1 << (s - 1), (1 << 63) + (1 << (s - 1)), M]
     out = {}
