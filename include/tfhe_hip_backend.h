@@ -245,6 +245,30 @@ void hip_programmable_bootstrap_ntt64_crt_async(
     uint32_t polynomial_size, uint32_t base_log, uint32_t level_count,
     uint32_t num_samples, uint32_t num_many_lut, uint32_t lut_stride);
 
+/* The same engine on the f64 transform machinery of the throughput kernel (pbs_fft_wave.hip, split-key form): every
+ * key word, switched to the prime and centred, is cut into 4 balanced 16-bit limbs kept in the Fourier domain; per
+ * CMUX the digit transform is multiplied with each limb, the inverse transforms are rounded to the exact integer
+ * products (|.| < 2^49; the distance from an integer is checked on every coefficient, the launch traps above 1/4) and
+ * recombined modulo the prime.  Identical outputs to hip_programmable_bootstrap_ntt64_async.  Accepts N = 2048,
+ * k = 1, one level, base_log 22 or 23 (hip_programmable_bootstrap_ntt64_split_supported).  The key buffer takes FOUR
+ * times the bytes of the standard key: n*(k+1)^2*N*32.  The first launch on a scratch allocates the accumulators'
+ * device buffer (not capturable; later launches are). */
+bool hip_programmable_bootstrap_ntt64_split_supported(
+    uint32_t glwe_dimension, uint32_t polynomial_size, uint32_t level_count,
+    uint32_t base_log);
+void hip_convert_lwe_programmable_bootstrap_key_ntt64_split_async(
+    void *stream, uint32_t gpu_index, void *dest, void const *src,
+    uint32_t input_lwe_dim, uint32_t glwe_dim, uint32_t level_count,
+    uint32_t polynomial_size);
+void hip_programmable_bootstrap_ntt64_split_async(
+    void *stream, uint32_t gpu_index, void *lwe_array_out,
+    void const *lwe_output_indexes, void const *lut_vector,
+    void const *lut_vector_indexes, void const *lwe_array_in,
+    void const *lwe_input_indexes, void const *bootstrapping_key,
+    int8_t *buffer, uint32_t lwe_dimension, uint32_t glwe_dimension,
+    uint32_t polynomial_size, uint32_t base_log, uint32_t level_count,
+    uint32_t num_samples, uint32_t num_many_lut, uint32_t lut_stride);
+
 /* Exact-integer engine (negacyclic convolution mod 2^64 on the standard-domain key,
  * cc/algorithms/lwe_programmable_bootstrapping/karatsuba_pbs.rs:71-116,199-413).  O(N^2): a
  * verification engine; it reproduces the reference's golden *_karatsuba vectors bit for bit. */

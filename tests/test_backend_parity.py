@@ -99,6 +99,24 @@ def test_arith_hooks_match_oracle(kind):
     for op, fn in ((8, L.orc_gl_mul), (9, L.orc_gl_add), (10, L.orc_gl_sub)):
         got = run_arith(lib, st, op, pairs, in_per=2)
         assert all(int(g) == fn(int(a), int(b)) for g, a, b in zip(got, pairs[0::2], pairs[1::2]))
+    # lean forms of the split-key exact engine, against big-integer formulas: the modulus switch back for EVERY class
+    # of v (edges of the carries it folds), the 16-bit Horner step on lazy states (compared modulo p), the final
+    # bias removal (canonical)
+    near = [v % p for b in (0, 1 << 32, 1 << 63, p >> 1, p) for v in range(b - 3, b + 4)]
+    vs2 = np.array(sorted(set(near + [int(v) for v in vs])), dtype=np.uint64)
+    got = run_arith(lib, st, 12, vs2)
+    assert all(int(g) == (((int(v) << 64) + (p >> 1)) // p) % (1 << 64) for g, v in zip(got, vs2))
+    c0 = 0x4338000000000000
+    hs = np.array([[r, c0 + s] for r in list(xs[:40]) + [M64, p, p - 1, (1 << 48) - 1, 1 << 48]
+                   for s in (0, 1, -1, (1 << 50) - 1, -(1 << 50) + 1, 12345678901234, -98765432109876)],
+                  dtype=np.uint64).reshape(-1)
+    got = run_arith(lib, st, 13, hs, in_per=2)
+    assert all(int(g) % p == ((int(r) << 16) + int(x)) % p for g, r, x in zip(got, hs[0::2], hs[1::2]))
+    bias = (c0 * 0x0001000100010001) % p
+    assert bias == 0x86704337bcc77990
+    sb = np.array([[r, bias] for r in xs[:200]], dtype=np.uint64).reshape(-1)
+    got = run_arith(lib, st, 14, sb, in_per=2)
+    assert all(int(g) == (int(r) - bias) % p for g, r in zip(got, sb[0::2]))
 
 
 @pytest.mark.parametrize("kind", BACKENDS)
@@ -148,7 +166,9 @@ PBS_CASES = [(TOY_K1, "fft64"), (TOY_K1, "ntt64"), (TOY_K1_L1, "fft64"), (TOY_K2
              # the NTT engine's second implementation, on the FP64 pipes modulo two 50-bit primes (pbs_ntt_crt.hip):
              # same function, same oracle
              (TOY_K1, "ntt64_crt"), (TOY_K2, "ntt64_crt"), (TOY_K3, "ntt64_crt"), (TOY_2048, "ntt64_crt"),
-             (TOY_1024_K2, "ntt64_crt")]
+             (TOY_1024_K2, "ntt64_crt"),
+             # its third form, on the throughput kernel's f64 transforms with the key in 16-bit limbs (split-key form)
+             (TOY_2048, "ntt64_split")]
 
 
 @pytest.mark.parametrize("kind", BACKENDS)
@@ -161,7 +181,7 @@ def test_pbs_bit_exact_and_decrypts(kind, p, engine):
     lut = orc.generate_lut(p.k, p.N, p.plaintext_modulus, p.delta, f)
     out = c.pbs(cts, lut)
     if engine.startswith("ntt64"):
-        assert use_backend(kind).hip_backend_last_pbs_kernel() == (12 if engine == "ntt64_crt" else 3)
+        assert use_backend(kind).hip_backend_last_pbs_kernel() == {"ntt64_crt": 12, "ntt64_split": 13}.get(engine, 3)
     ref = oracle_pbs(p, c.keys, engine, cts, lut)
     assert np.array_equal(out, ref), "raw PBS output differs from the oracle"
     assert [decrypt_big(p, c.keys, o) for o in out] == [f(m) for m in msgs]
@@ -761,7 +781,7 @@ def test_multi_bit_full_size(which):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("engine", ["ntt64", "ntt64_crt"])
+@pytest.mark.parametrize("engine", ["ntt64", "ntt64_crt", "ntt64_split"])
 def test_full_size_ntt_engine_wide_batch_bit_exact(engine):
     """Config 3 at production size (n=918, N=2048): 259 LWEs (ragged against every tile size of the launch)
     through the NTT engine, every output word against the oracle; all of them decrypt.  Both implementations: the
@@ -776,7 +796,7 @@ def test_full_size_ntt_engine_wide_batch_bit_exact(engine):
     f = lambda x: (x * x + 1) % 16
     lut = orc.generate_lut(p.k, p.N, p.plaintext_modulus, p.delta, f)
     out = Ctx("hip", p, keys, engine).pbs(cts, lut)
-    assert use_backend("hip").hip_backend_last_pbs_kernel() == (12 if engine == "ntt64_crt" else 3)
+    assert use_backend("hip").hip_backend_last_pbs_kernel() == {"ntt64_crt": 12, "ntt64_split": 13}.get(engine, 3)
     assert np.array_equal(out, oracle_pbs(p, keys, "ntt64", cts, lut))
     assert [decrypt_big(p, keys, o) for o in out] == [f(m) for m in msgs]
 

@@ -174,8 +174,12 @@ class CudaLweBootstrapKey:
         self.decomp_base_log = int(decomp_base_log)
         self.decomp_level_count = int(decomp_level_count)
         self.ms_noise_reduction = bool(ms_noise_reduction)
-        self.engine = "ntt64" if engine == "ntt64_crt" else engine
+        self.engine = "ntt64" if engine in ("ntt64_crt", "ntt64_split") else engine
         self.engine_impl = "ntt64_int" if engine == "ntt64" else engine
+        if engine == "ntt64_split":
+            assert _lib().hip_programmable_bootstrap_ntt64_split_supported(
+                glwe_dimension, polynomial_size, decomp_level_count, decomp_base_log), \
+                "parameter set outside the split-key form of the NTT engine"
         if engine == "ntt64_crt":
             assert _lib().hip_programmable_bootstrap_ntt64_crt_supported(
                 glwe_dimension, polynomial_size, decomp_level_count, decomp_base_log), \
@@ -187,10 +191,11 @@ class CudaLweBootstrapKey:
         # n*(k+1)^2*l*N f64 per GPU — the byte size of the standard key; two residues per value for 'ntt64_crt'
         self.d_vecs = []
         for i in range(len(streams)):
-            d = CudaVec(elems * (2 if engine == "ntt64_crt" else 1), streams, i, np.float64)
+            d = CudaVec(elems * {"ntt64_crt": 2, "ntt64_split": 4}.get(engine, 1), streams, i, np.float64)
             conv = {"fft64": _lib().cuda_convert_lwe_programmable_bootstrap_key_64_async,
                     "ntt64_int": _lib().hip_convert_lwe_programmable_bootstrap_key_ntt64_async,
                     "ntt64_crt": _lib().hip_convert_lwe_programmable_bootstrap_key_ntt64_crt_async,
+                    "ntt64_split": _lib().hip_convert_lwe_programmable_bootstrap_key_ntt64_split_async,
                     "exact64": _lib().hip_convert_lwe_programmable_bootstrap_key_exact64_async,
                     "ref64": _lib().hip_convert_lwe_programmable_bootstrap_key_ref64_async}[engine]
             conv(streams.ptr[i], streams.gpu_indexes[i], d.ptr, h_bsk.ctypes.data_as(C.c_void_p),
@@ -280,6 +285,7 @@ def cuda_programmable_bootstrap_lwe_ciphertext(input, output, accumulator, lut_i
     launch = {"fft64": lib.cuda_programmable_bootstrap_64_async,
               "ntt64_int": lib.hip_programmable_bootstrap_ntt64_async,
               "ntt64_crt": lib.hip_programmable_bootstrap_ntt64_crt_async,
+              "ntt64_split": lib.hip_programmable_bootstrap_ntt64_split_async,
               "exact64": lib.hip_programmable_bootstrap_exact64_async,
               "ref64": lib.hip_programmable_bootstrap_ref64_async}[bsk.engine_impl]
     launch(s, g, output.d_vec.ptr, output_indexes.ptr, accumulator.d_vec.ptr, lut_indexes.ptr,

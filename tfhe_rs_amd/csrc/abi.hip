@@ -32,6 +32,7 @@ struct PbsBuffer {
   NttTables ntt;
   CrtTables crt;
   uint64_t *acc_scratch = nullptr;
+  uint64_t *split_acc = nullptr;  // exact engine, split-key form: (k+1) N accumulator words per sample in device memory
   uint64_t *ks_out = nullptr;  // hip_keyswitch_programmable_bootstrap_64_async: the keyswitched LWEs (small key)
   uint64_t *trivial = nullptr; // 0, 1, ..., max_samples - 1 (indexes of that list)
 };
@@ -425,6 +426,57 @@ void hip_programmable_bootstrap_ntt64_crt_async(void *stream, uint32_t gpu_index
   g_last_pbs_kernel.store(12);
 }
 
+// ---- the exact engine in its split-key f64 form (pbs_fft_wave.hip, LIMBS mode): the same function as
+// hip_programmable_bootstrap_ntt64_async — bit for bit — for N = 2048, k = 1, one level, base_log 22 / 23, on the
+// throughput kernel's machinery.  The key takes NTT_SPLIT_LIMBS times the bytes of the classic Fourier key.
+bool hip_programmable_bootstrap_ntt64_split_supported(uint32_t glwe_dimension, uint32_t polynomial_size,
+                                                      uint32_t level_count, uint32_t base_log) {
+  return pbs_ntt_split_supported(polynomial_size, glwe_dimension, level_count, base_log);
+}
+void hip_convert_lwe_programmable_bootstrap_key_ntt64_split_async(void *stream, uint32_t gpu_index, void *dest,
+                                                                  void const *src, uint32_t input_lwe_dim,
+                                                                  uint32_t glwe_dim, uint32_t level_count,
+                                                                  uint32_t polynomial_size) {
+  set_device(gpu_index);
+  HX_PANIC_IF_FALSE(dest != nullptr && src != nullptr, "bootstrap key conversion: null pointer");
+  HX_PANIC_IF_FALSE(polynomial_size == 2048 && glwe_dim == 1 && level_count == 1,
+                    "split-key exact engine: parameter set not supported (N = 2048, k = 1, one level)");
+  const size_t polys = (size_t)input_lwe_dim * level_count * (glwe_dim + 1) * (glwe_dim + 1);
+  const size_t bytes = polys * polynomial_size * sizeof(uint64_t);
+  void *tmp = nullptr;
+  HX_CHECK(hipMalloc(&tmp, bytes));
+  HX_CHECK(hipMemcpyAsync(tmp, src, bytes, hipMemcpyHostToDevice, S(stream)));
+  launch_bsk_to_split(S(stream), polynomial_size, (const uint64_t *)tmp, dest, polys,
+                      get_fft_tables(gpu_index, S(stream), polynomial_size));
+  HX_CHECK(hipStreamSynchronize(S(stream)));  // the staging buffer must outlive the kernel
+  HX_CHECK(hipFree(tmp));
+}
+void hip_programmable_bootstrap_ntt64_split_async(void *stream, uint32_t gpu_index, void *lwe_array_out,
+                                                  void const *lwe_output_indexes, void const *lut_vector,
+                                                  void const *lut_vector_indexes, void const *lwe_array_in,
+                                                  void const *lwe_input_indexes, void const *bootstrapping_key,
+                                                  int8_t *buffer, uint32_t lwe_dimension, uint32_t glwe_dimension,
+                                                  uint32_t polynomial_size, uint32_t base_log, uint32_t level_count,
+                                                  uint32_t num_samples, uint32_t num_many_lut, uint32_t lut_stride) {
+  set_device(gpu_index);
+  PbsBuffer *b = checked_buffer(buffer, lwe_dimension, glwe_dimension, polynomial_size, level_count, num_samples);
+  HX_PANIC_IF_FALSE(pbs_ntt_split_supported(polynomial_size, glwe_dimension, level_count, base_log),
+                    "split-key exact engine: parameter set not supported (N=%u, k=%u, level=%u, base_log=%u)",
+                    polynomial_size, glwe_dimension, level_count, base_log);
+  if (num_samples == 0) return;
+  if (b->split_acc == nullptr) {
+    // first use of this engine with this scratch: the accumulators' home (an allocation — not under stream capture;
+    // a capture must be preceded by one plain launch, like the keyswitch's first use of a key)
+    HX_CHECK(hipMalloc((void **)&b->split_acc, (size_t)b->max_samples * (glwe_dimension + 1) * polynomial_size * sizeof(uint64_t)));
+  }
+  PbsArgs a = make_args(lwe_array_out, lwe_output_indexes, lut_vector, lut_vector_indexes, lwe_array_in,
+                        lwe_input_indexes, bootstrapping_key, lwe_dimension, base_log, level_count, num_samples,
+                        num_many_lut, lut_stride, b->ms_type);
+  a.acc_scratch = b->split_acc;
+  launch_pbs_ntt_split_wave(S(stream), a, b->fft);
+  g_last_pbs_kernel.store(13);
+}
+
 // ---- reference-order f64 engine (pbs_ref64.hip): the key in tfhe-fft's dif4 transform order
 void hip_convert_lwe_programmable_bootstrap_key_ref64_async(void *stream, uint32_t gpu_index, void *dest,
                                                             void const *src, uint32_t input_lwe_dim,
@@ -497,6 +549,7 @@ void cleanup_cuda_programmable_bootstrap_64(void *stream, uint32_t gpu_index, in
   HX_PANIC_IF_FALSE(b != nullptr && b->magic == kPbsMagic, "cleanup of a foreign PBS buffer");
   HX_CHECK(hipStreamSynchronize(S(stream)));  // cleanup_* synchronises (pbs_utilities.h:261-271)
   if (b->acc_scratch) HX_CHECK(hipFree(b->acc_scratch));
+  if (b->split_acc) HX_CHECK(hipFree(b->split_acc));
   if (b->ks_out) HX_CHECK(hipFree(b->ks_out));
   if (b->trivial) HX_CHECK(hipFree(b->trivial));
   b->magic = 0;

@@ -13,6 +13,7 @@
 #include "hipemu_runtime.h"
 #define HX_WAVE_SYNC() hx_wave_sync_emu()
 #define HX_UNROLL _Pragma("GCC unroll 64")
+#define HX_NO_UNROLL _Pragma("GCC unroll 1")
 #define HX_SCHED_FENCE() do { } while (0)
 #define HX_OPAQUE(v) do { } while (0)
 #define HX_LAUNDER(v) do { } while (0)
@@ -38,6 +39,7 @@
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
   } while (0)
 #define HX_UNROLL _Pragma("unroll")
+#define HX_NO_UNROLL _Pragma("unroll 1")
 // compile-time scheduling fence: keeps the instruction scheduler from hoisting loads of a later
 // chunk across this point (bounds live ranges, hence VGPR pressure)
 #define HX_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)

@@ -10,6 +10,12 @@ void launch_pbs_fft_generic(hipStream_t st, uint32_t N, uint32_t glwe_dim, const
 void launch_pbs_ntt_generic(hipStream_t st, uint32_t N, uint32_t glwe_dim, const PbsArgs &a, const NttTables &tb);
 void launch_pbs_exact_generic(hipStream_t st, uint32_t N, uint32_t glwe_dim, const PbsArgs &a);
 void launch_bsk_to_fourier(hipStream_t st, uint32_t N, uint32_t glwe_dim, const uint64_t *src_dev, void *dst, size_t polys, const FftTables &tb);
+// exact engine in its split-key f64 form (pbs_fft_wave.hip, LIMBS mode): 4 balanced 16-bit limbs per key word
+constexpr int NTT_SPLIT_LIMBS = 4;
+bool pbs_ntt_split_supported(uint32_t N, uint32_t glwe_dim, uint32_t level, uint32_t base_log);
+void launch_pbs_ntt_split_wave(hipStream_t st, const PbsArgs &a, const FftTables &tb);
+// polys standard-domain key polynomials (level_count = 1) -> NTT_SPLIT_LIMBS Fourier-domain limb polynomials each
+void launch_bsk_to_split(hipStream_t st, uint32_t N, const uint64_t *src_dev, void *dst, size_t polys, const FftTables &tb);
 bool pbs_ntt_crt_supported(uint32_t N, uint32_t glwe_dim, uint32_t level, uint32_t base_log);
 void launch_pbs_ntt_crt(hipStream_t st, uint32_t N, uint32_t glwe_dim, const PbsArgs &a, const CrtTables &tb);
 void launch_bsk_to_crt(hipStream_t st, uint32_t N, const uint64_t *src_dev, void *dst, size_t polys, const CrtTables &tb);

@@ -390,7 +390,9 @@ HX_DEV void inverse_pass1_group(cplx (&o)[16], int g) {
 // OVERWRITE (multi-bit: dst = 0 + src (x) GGSW): the result replaces the accumulator and is not staged.
 // NEG: the registers hold MINUS the accumulator (see make_digits); from_torus is odd, so the negated
 // term is the conversion of the negated real, whose sign rides on the untwist multiplication for free.
-template <bool PASS1_DONE, bool OVERWRITE = false, bool NEG = false>
+// RAW (exact engine, split-key form): no torus conversion — o[r] becomes (t_re, t_im), the untwisted real values of
+// coefficients r*64 + lane and 1024 + r*64 + lane; nothing is staged, the accumulator registers are not touched.
+template <bool PASS1_DONE, bool OVERWRITE = false, bool NEG = false, bool RAW = false>
 HX_DEV void wave_inverse_accumulate(cplx (&o)[16], uint64_t (&acc_re)[16], uint64_t (&acc_im)[16], WaveCtx c) {
   uint64_t *stg = (uint64_t *)c.buf;
   HX_OPAQUE(c.lane);
@@ -508,7 +510,9 @@ HX_DEV void wave_inverse_accumulate(cplx (&o)[16], uint64_t (&acc_re)[16], uint6
     }
     const double tr = NEG ? fma(o[r].im, u.im, -o[r].re * u.re) : fma(-o[r].im, u.im, o[r].re * u.re);
     const double ti = NEG ? fma(-o[r].im, u.re, -o[r].re * u.im) : fma(o[r].im, u.re, o[r].re * u.im);
-    if constexpr (OVERWRITE) {
+    if constexpr (RAW) {
+      o[r] = cplx{tr, ti};
+    } else if constexpr (OVERWRITE) {
       acc_re[r] = from_torus(tr);
       acc_im[r] = from_torus(ti);
     } else {
@@ -538,10 +542,29 @@ HX_DEV void wave_inverse_accumulate(cplx (&o)[16], uint64_t (&acc_re)[16], uint6
 // differ, the key does not), reads the four digit transforms from the quad's buffers, and hands the half it
 // computed for the other LWE back through LDS before the inverse transforms.  Same products in the same order
 // per output point: identical bits.  Workgroup barriers replace the pair flags.
-template <int LEVEL_CT, int BASE_LOG_CT, int GROUPING = 0, bool SHARE = false>
+//
+// LIMBS > 0: the EXACT engine (tfhe-ntt semantics, cc/algorithms/lwe_programmable_bootstrapping/ntt64_bnf_pbs.rs
+// :208-280, commons/math/ntt/ntt64.rs:144-245) on this kernel's f64 machinery.  The reference's result per CMUX is
+// the negacyclic product  R = sum_rows digit_poly (*) key_poly  modulo the Goldilocks prime P (key words switched to
+// P, digits as signed integers), switched back to 2^64 — a property of the integers involved, not of the
+// transform.  Here the centred key word kc in (-P/2, P/2] is split into LIMBS balanced 16-bit limbs,
+// kc = sum_m c_m 2^(16 m), each limb polynomial is kept in the Fourier domain (integer inputs, no torus scaling),
+// and per CMUX the digit transform F is multiplied with every limb in turn: S_m = sum_rows d (*) c_m is an integer of
+// magnitude below (k+1) l N (B/2) 2^15 = 2^49 that the f64 transform reproduces to within about 2^-9 (RMS; the
+// distance from the nearest integer is checked on every coefficient and the launch TRAPS above 1/4 — the round-off
+// check of every FFT-based exact multiplication), so rint() of the inverse transform IS S_m, and
+//     R = sum_m S_m 2^(16 m)  mod P          (Horner, most significant limb first, 64-bit Goldilocks arithmetic)
+// is the reference's value, bit for bit.  Order of the blind rotation as in the NTT path: acc starts as the LUT,
+// ct1 = acc X^a_hat - acc per CMUX, the rotation by -b_hat comes last.  The accumulator lives in device memory
+// between its two touches per CMUX (PbsArgs::acc_scratch, L2 / Infinity Cache resident): the registers carry the
+// Horner states (64), the digit transform (64: re-published to the pair's LDS buffer after every limb's inverse
+// transposition has used that buffer) and the product being transformed back (64).
+template <int LEVEL_CT, int BASE_LOG_CT, int GROUPING = 0, bool SHARE = false, int LIMBS = 0>
 __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables tb) {
   constexpr bool MULTIBIT = GROUPING > 0;
   static_assert(!SHARE || MULTIBIT, "SHARE is a mode of the multi-bit loop");
+  static_assert(LIMBS == 0 || (!MULTIBIT && LEVEL_CT == 1 && BASE_LOG_CT != 0 && BASE_LOG_CT <= 23),
+                "split-key exact engine: one level, base_log <= 23 (the products must stay below 2^49)");
   HX_DYN_SMEM(smem);
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -655,6 +678,11 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
   HX_UNROLL
   for (int r = 0; r < 16; ++r) {
     bool neg;
+    if constexpr (LIMBS > 0) {  // the rotation by -b_hat comes last on this path (ntt64_bnf_pbs.rs:262-271)
+      acc_re[r] = (uint64_t)0 - lut[r * 64 + lane];
+      acc_im[r] = (uint64_t)0 - lut[1024 + r * 64 + lane];
+      continue;
+    }
     uint32_t src = monomial_div_src(r * 64 + lane, b_hat, N, neg);
     uint64_t v = lut[src];
     acc_re[r] = (neg != NEGACC) ? (uint64_t)0 - v : v;
@@ -752,11 +780,12 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
   };
 
   // key rows of GGSW_i: [i][idx][row][c = w][storage s = r*64 + lane], consumed in 4 chunks of 4 points
+  const uint32_t key_levels = LIMBS > 0 ? (uint32_t)LIMBS : level;  // split-key form: [i][limb][row][col][slot]
   auto key_rows = [&](uint32_t i, uint32_t idx, const cplx *&b0, const cplx *&b1) {
     int lane = ctx.lane;
     HX_OPAQUE(lane);
-    b0 = bsk + ((((size_t)i * level + idx) * 2 + 0) * 2 + w) * n + lane;
-    b1 = bsk + ((((size_t)i * level + idx) * 2 + 1) * 2 + w) * n + lane;
+    b0 = bsk + ((((size_t)i * key_levels + idx) * 2 + 0) * 2 + w) * n + lane;
+    b1 = bsk + ((((size_t)i * key_levels + idx) * 2 + 1) * 2 + w) * n + lane;
   };
   auto key_request = [&](cplx (&k0)[4], cplx (&k1)[4], const cplx *b0, const cplx *b1, int ch) {
     HX_UNROLL
@@ -778,7 +807,7 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
     const int lane = ctx.lane;
     // wave_forward left my transform in my buffer (mapping M3)
     if (lane == 0) flag_set(f_ready_me, epoch);
-    constexpr int early = (LEVEL_CT == 1 && !MULTIBIT) ? WAVE_EARLY_CHUNKS : 0;  // otherwise requested here
+    constexpr int early = (LEVEL_CT == 1 && !MULTIBIT && LIMBS == 0) ? WAVE_EARLY_CHUNKS : 0;  // otherwise requested here
     if (early < 1) key_request(ka0, ka1, b0, b1, 0);
     if (early < 2) key_request(kb0, kb1, b0, b1, 1);
     HX_SCHED_FENCE();
@@ -1233,6 +1262,85 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
       pace_arrive();
 #endif
     }
+  } else if constexpr (LIMBS > 0) {
+    struct alignas(16) U64x2 { uint64_t x, y; };
+    U64x2 *gacc = (U64x2 *)(a.acc_scratch + ((size_t)sample * 2 + (size_t)w) * N) + lane;  // slot r*64 + lane: coefficients c, 1024 + c
+    auto acc_load = [&]() {
+      HX_UNROLL
+      for (int r = 0; r < 16; ++r) {
+        const U64x2 v = gacc[r * 64];
+        acc_re[r] = v.x;
+        acc_im[r] = v.y;
+      }
+    };
+    auto acc_store = [&]() {
+      HX_UNROLL
+      for (int r = 0; r < 16; ++r) gacc[r * 64] = U64x2{acc_re[r], acc_im[r]};
+    };
+    acc_store();
+    double worst = 0.0;  // largest distance from an integer seen by this lane (round-off check)
+    // t = S + error, S integer: the Horner state takes the raw bits of t + 1.5 2^52 (= GL_SPLIT_C0 + S; the bias of
+    // the four limbs comes off once at the end), R <- R 2^16 + bits (mod P), lazy Goldilocks forms
+    auto fold = [&](uint64_t &R, double t) {
+      const double MAGIC = 6755399441055744.0;  // 1.5 * 2^52: t + MAGIC has its unit bit at 2^0 for |t| < 2^51
+      const double tm = t + MAGIC;
+      const double fr = t - (tm - MAGIC);
+      worst = __builtin_fmax(worst, __builtin_fabs(fr));
+      R = gl_horner16(R, f64_bits(tm));
+    };
+    uint32_t it = 0;
+    uint64_t mask_next = lwe[0];
+    for (uint32_t i = 0; i < a.n; ++i) {
+      const uint64_t mask_cur = mask_next;
+      mask_next = lwe[i + 1];
+      const uint32_t a_hat = HX_UNIFORM((uint32_t)modulus_switch(mask_cur, LOG2N2));
+      if (a_hat == 0) continue;
+      ++it;
+      acc_load();
+      stage_acc();
+      cplx d[16];
+      HX_PRIO(WAVE_PRIO_A);
+      make_digits(d, a_hat, 0);
+      HX_PRIO(WAVE_PRIO_B);
+      wave_forward(d, ctx);  // d = F, my row of the digit transform; also in my buffer (mapping M3)
+      uint64_t R_re[16], R_im[16];
+      HX_UNROLL
+      for (int r = 0; r < 16; ++r) R_re[r] = R_im[r] = 0;
+      HX_NO_UNROLL  // one body: unrolled, the scheduler overlaps the limbs and spills hundreds of registers
+      for (int limb = 0; limb < LIMBS; ++limb) {  // key limb index 0 = most significant
+        cplx o[16], ka0[4], ka1[4], kb0[4], kb1[4];
+        const cplx *b0, *b1;
+        key_rows(i, (uint32_t)limb, b0, b1);
+        HX_PRIO(WAVE_PRIO_C);
+        mac(o, o, ka0, ka1, kb0, kb1, b0, b1, 0, (it - 1) * (uint32_t)LIMBS + (uint32_t)limb + 1,
+            std::integral_constant<bool, WAVE_FUSE_PASS1 != 0>{});
+        HX_PRIO(WAVE_PRIO_D);
+        wave_inverse_accumulate<WAVE_FUSE_PASS1 != 0, false, false, true>(o, acc_re, acc_im, ctx);
+        HX_UNROLL
+        for (int r = 0; r < 16; ++r) {
+          fold(R_re[r], o[r].re);
+          fold(R_im[r], o[r].im);
+        }
+        if (limb + 1 < LIMBS) {  // my buffer held the inverse transposition: the pair needs F again
+          WaveCtx cx = ctx0;
+          HX_OPAQUE(cx.lane);
+          cplx *p3 = buf + base_m3(cx);
+          HX_UNROLL
+          for (int r = 0; r < 16; ++r) p3[r] = d[r];
+          HX_WAVE_SYNC();
+        }
+      }
+      // acc += modswitch_to_2^64(R mod P) (ntt64.rs:162-177); the registers hold MINUS the accumulator
+      acc_load();
+      HX_UNROLL
+      for (int r = 0; r < 16; ++r) {
+        acc_re[r] -= gl_modswitch_to_pow2_lean(gl_sub_canon(R_re[r], GL_SPLIT_BIAS));
+        acc_im[r] -= gl_modswitch_to_pow2_lean(gl_sub_canon(R_im[r], GL_SPLIT_BIAS));
+      }
+      acc_store();
+    }
+    if (worst > 0.25) __builtin_trap();  // an f64 product was not within 1/4 of an integer: never with these bounds
+    acc_load();
   } else {
     stage_acc();
     uint32_t it = 0;  // executed iterations (flag epoch)
@@ -1287,7 +1395,22 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
   for (uint32_t t = 0; t < a.num_many_lut; ++t) {
     const uint32_t nth = t * a.lut_stride;
     uint64_t *out = a.lwe_out + (size_t)t * a.num_samples * out_sz + (size_t)a.out_idx[sample] * out_sz;
-    if (w == 0) {
+    if constexpr (LIMBS > 0) {
+      // the accumulator is rotated by -b_hat first: coefficient c moves to t = (c - b_hat) mod 2N, i.e. to j = t mod N
+      // with its sign flipped when t >= N; then the extraction below on index j
+      HX_UNROLL
+      for (int r = 0; r < 16; ++r) {
+        HX_UNROLL
+        for (int half = 0; half < 2; ++half) {
+          const uint32_t c = (uint32_t)(half * 1024 + r * 64 + lane);
+          const uint64_t A = (uint64_t)0 - (half ? acc_im[r] : acc_re[r]);  // the registers hold minus the accumulator
+          const uint32_t e = (c - b_hat) & (2u * N - 1u), j = e & (N - 1u);
+          const uint64_t v = (e >= (uint32_t)N) ? (uint64_t)0 - A : A;
+          if (w == 0) out[j <= nth ? nth - j : N + nth - j] = (j <= nth) ? v : (uint64_t)0 - v;
+          else if (j == nth) out[N] = v;
+        }
+      }
+    } else if (w == 0) {
       // mask: out[j] = A[nth - j] (j <= nth), -A[N + nth - j] otherwise; I hold A[c]
       HX_UNROLL
       for (int r = 0; r < 16; ++r) {
@@ -1326,6 +1449,26 @@ static void launch_wave_t(hipStream_t st, const PbsArgs &a, const FftTables &tb)
   const unsigned per_block = lwes_per_block(a.num_samples);
   const unsigned blocks = (a.num_samples + per_block - 1) / per_block;
   HX_LAUNCH((pbs_fft_wave_kernel<L, B>), dim3(blocks), dim3(128 * per_block), SMEM_BYTES, st, a, tb);
+}
+
+// exact engine, split-key form (LIMBS = 4): N = 2048, k = 1, one level, base_log 22 or 23
+bool pbs_ntt_split_supported(uint32_t N, uint32_t glwe_dim, uint32_t level, uint32_t base_log) {
+  return N == 2048 && glwe_dim == 1 && level == 1 && (base_log == 23 || base_log == 22);
+}
+template <int B>
+static void launch_split_t(hipStream_t st, const PbsArgs &a, const FftTables &tb) {
+  using namespace wavek;
+  hx_set_dynamic_smem_once<pbs_fft_wave_kernel<1, B, 0, false, NTT_SPLIT_LIMBS>>(SMEM_BYTES);
+  const unsigned per_block = lwes_per_block(a.num_samples);
+  const unsigned blocks = (a.num_samples + per_block - 1) / per_block;
+  HX_LAUNCH((pbs_fft_wave_kernel<1, B, 0, false, NTT_SPLIT_LIMBS>), dim3(blocks), dim3(128 * per_block), SMEM_BYTES, st, a,
+            tb);
+}
+// a.bsk = split-key Fourier form (launch_bsk_to_split), a.acc_scratch = 2 N words per sample
+void launch_pbs_ntt_split_wave(hipStream_t st, const PbsArgs &a, const FftTables &tb) {
+  HX_PANIC_IF_FALSE(a.acc_scratch != nullptr, "split-key exact engine: no accumulator scratch");
+  if (a.base_log == 23) launch_split_t<23>(st, a, tb);
+  else launch_split_t<22>(st, a, tb);
 }
 
 bool pbs_multi_bit_wave_supported(uint32_t N, uint32_t glwe_dim, uint32_t level, uint32_t base_log, uint32_t grouping) {

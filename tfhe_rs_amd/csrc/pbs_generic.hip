@@ -410,6 +410,37 @@ __global__ void __launch_bounds__(GenericCfg<N>::TPB) bsk_to_fourier_kernel(cons
     o[slot_order == 1 ? bsk_slot<2048, 2>(j) : slot_order == 2 ? bsk_slot<1024, 2>(j) : j] = fbuf[j];
 }
 
+// Split-key form of the exact engine (pbs_fft_wave.hip, LIMBS mode): key word x -> k = round(x P / 2^64)
+// (ntt64.rs:144-160), centred into (-P/2, P/2], cut into NTT_SPLIT_LIMBS balanced 16-bit limbs
+// kc = sum_m c_m 2^(16 m), c_m in [-2^15, 2^15] — and the polynomial of every limb transformed as INTEGERS (no torus
+// scaling).  Workgroup (p, q): limb index q (0 = most significant) of source polynomial p = (i*2 + row)*2 + col
+// goes to destination polynomial (i*LIMBS + q)*4 + row*2 + col, in the throughput kernel's slot order.
+template <int N>
+__global__ void __launch_bounds__(GenericCfg<N>::TPB) bsk_to_split_kernel(const uint64_t *src, cplx *dst, FftTables tb) {
+  constexpr int n = N / 2, TPB = GenericCfg<N>::TPB, L = NTT_SPLIT_LIMBS;
+  HX_DYN_SMEM(smem);
+  const FBuf fbuf{(cplx *)smem};
+  const int tid = threadIdx.x;
+  const uint64_t *p = src + (size_t)blockIdx.x * N;
+  const int m = L - 1 - (int)blockIdx.y;  // limb exponent: value c_m 2^(16 m)
+  auto limb = [&](uint64_t x) {
+    const uint64_t v = gl_modswitch_from_pow2(x);
+    int64_t kc = v > (GL_P >> 1) ? (int64_t)(v - GL_P) : (int64_t)v;
+    int64_t c = 0;
+    for (int q = 0; q <= m; ++q) {
+      c = q == L - 1 ? kc : (int64_t)(int16_t)(uint16_t)kc;  // the top limb takes what is left (|.| <= 2^15)
+      kc = (kc - c) >> 16;
+    }
+    return (double)(int32_t)c;
+  };
+  for (int j = tid; j < n; j += TPB) fbuf[j] = cplx{limb(p[j]), limb(p[j + n])};
+  __syncthreads();
+  lds_fft_forward<N, TPB>(fbuf, tb.fwd, tid);
+  const size_t i = blockIdx.x >> 2, rc = blockIdx.x & 3;
+  cplx *o = dst + ((i * L + blockIdx.y) * 4 + rc) * n;
+  for (int j = tid; j < n; j += TPB) o[bsk_slot<2048, 2>(j)] = fbuf[j];
+}
+
 template <int N>
 __global__ void __launch_bounds__(GenericCfg<N>::TPB) bsk_to_ntt_kernel(const uint64_t *src, uint64_t *dst, NttTables tb) {
   constexpr int TPB = GenericCfg<N>::TPB;
@@ -519,6 +550,11 @@ void launch_bsk_to_fourier(hipStream_t st, uint32_t N, uint32_t glwe_dim, const 
   if (N == 8192) return launch_conv_f<8192>(st, src_dev, dst, polys, tb, slot_order);
   if (N == 16384) return launch_conv_f<16384>(st, src_dev, dst, polys, tb, slot_order);
   HX_DISPATCH_N(launch_conv_f, st, src_dev, dst, polys, tb, slot_order);
+}
+void launch_bsk_to_split(hipStream_t st, uint32_t N, const uint64_t *src_dev, void *dst, size_t polys, const FftTables &tb) {
+  HX_PANIC_IF_FALSE(N == 2048, "split-key exact engine: polynomial_size %u not supported (2048)", N);
+  HX_LAUNCH((bsk_to_split_kernel<2048>), dim3((unsigned)polys, NTT_SPLIT_LIMBS), dim3(GenericCfg<2048>::TPB),
+            fbuf_bytes(2048), st, src_dev, (cplx *)dst, tb);
 }
 void launch_bsk_to_ntt(hipStream_t st, uint32_t N, const uint64_t *src_dev, void *dst, size_t polys, const NttTables &tb) {
   HX_DISPATCH_N(launch_conv_n, st, src_dev, dst, polys, tb);

@@ -79,6 +79,7 @@ def pbs_case(p, B, engine="fft64", kernel=0, steps=3):
         lib.scratch_cuda_programmable_bootstrap_64_async(S, G, C.byref(buf), p.n, p.k, p.N, p.pbs_level, B, True,
                                                          p.ms_type)
         launch = (lib.cuda_programmable_bootstrap_64_async if engine == "fft64"
+                  else lib.hip_programmable_bootstrap_ntt64_split_async if bsk.engine_impl == "ntt64_split"
                   else lib.hip_programmable_bootstrap_ntt64_crt_async if bsk.engine_impl == "ntt64_crt"
                   else lib.hip_programmable_bootstrap_ntt64_async)
 
@@ -156,6 +157,8 @@ if __name__ == "__main__":
         pbs_case(C1, 4096, kernel=1)
     if "ntt" in which:
         pbs_case(C1, 4096, engine="ntt64", steps=2)       # integer-Goldilocks form
+    if "ntt_split" in which:
+        pbs_case(C1, 4096, engine="ntt64_split", steps=2)  # split-key f64 form (throughput kernel machinery)
     if "ntt_crt" in which:
         pbs_case(C1, 4096, engine="ntt64_crt", steps=2)   # two-prime FP64 form
     if "mb" in which:
