@@ -224,27 +224,6 @@ void hip_programmable_bootstrap_ntt64_async(
     uint32_t polynomial_size, uint32_t base_log, uint32_t level_count,
     uint32_t num_samples, uint32_t num_many_lut, uint32_t lut_stride);
 
-/* The same engine computed on the FP64 pipes (pbs_ntt_crt.hip): the products are taken modulo two primes below
- * 2^49.5 with exact 6-instruction FP64 modular multiplications and recombined; identical outputs to
- * hip_programmable_bootstrap_ntt64_async, about twice as fast on the MI355X.  Accepts the parameter sets for which
- * hip_programmable_bootstrap_ntt64_crt_supported() holds (ceil(log2((k+1) l N)) + base_log <= 35: the exact integer
- * product must stay below p1 p2 / 2).  The key buffer takes TWICE the bytes of the standard key: n*(k+1)^2*l*N*16. */
-bool hip_programmable_bootstrap_ntt64_crt_supported(
-    uint32_t glwe_dimension, uint32_t polynomial_size, uint32_t level_count,
-    uint32_t base_log);
-void hip_convert_lwe_programmable_bootstrap_key_ntt64_crt_async(
-    void *stream, uint32_t gpu_index, void *dest, void const *src,
-    uint32_t input_lwe_dim, uint32_t glwe_dim, uint32_t level_count,
-    uint32_t polynomial_size);
-void hip_programmable_bootstrap_ntt64_crt_async(
-    void *stream, uint32_t gpu_index, void *lwe_array_out,
-    void const *lwe_output_indexes, void const *lut_vector,
-    void const *lut_vector_indexes, void const *lwe_array_in,
-    void const *lwe_input_indexes, void const *bootstrapping_key,
-    int8_t *buffer, uint32_t lwe_dimension, uint32_t glwe_dimension,
-    uint32_t polynomial_size, uint32_t base_log, uint32_t level_count,
-    uint32_t num_samples, uint32_t num_many_lut, uint32_t lut_stride);
-
 /* The same engine on the f64 transform machinery of the throughput kernel (pbs_fft_wave.hip, split-key form): every
  * key word, switched to the prime and centred, is cut into 4 balanced 16-bit limbs kept in the Fourier domain; per
  * CMUX the digit transform is multiplied with each limb, the inverse transforms are rounded to the exact integer

@@ -99,7 +99,7 @@ class Ctx:
 def oracle_bsk(p, keys, engine):
     if engine == "fft64":
         return orc.convert_bsk_fft(keys.bsk, p.n, p.k, p.N, p.pbs_level), orc.ENGINE_FFT
-    if engine in ("ntt64", "ntt64_crt", "ntt64_split"):
+    if engine in ("ntt64", "ntt64_split"):
         return orc.convert_bsk_ntt(keys.bsk, p.n, p.k, p.N, p.pbs_level), orc.ENGINE_NTT
     return keys.bsk, orc.ENGINE_EXACT
 

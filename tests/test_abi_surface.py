@@ -131,18 +131,14 @@ def test_rust_crate_bindings_are_generated_from_the_header_and_equal_the_referen
         assert os.path.exists(os.path.join(ROOT, "backends", "tfhe-hip-backend", f))
 
 
-def test_two_prime_ntt_engine_accepts_exactly_the_sets_its_primes_can_carry():
-    """hip_programmable_bootstrap_ntt64_crt_supported is a pure host predicate: the exact integer products of a CMUX
-    are below (k+1) l N 2^(base_log-1) 2^63 and must stay under p1 p2 / 2 = 2^97.99..., i.e.
-    ceil(log2((k+1) l N)) + base_log <= 35."""
+def test_split_key_ntt_engine_accepts_exactly_the_sets_its_limb_products_stay_exact_for():
+    """hip_programmable_bootstrap_ntt64_split_supported is a pure host predicate: N = 2048, k = 1, one level, base_log 22
+    or 23 — the sets the throughput kernel's LIMBS mode is instantiated for, with limb products
+    (k+1) l N 2^(base_log-1) 2^15 <= 2^49 that the f64 transforms reproduce to well within 1/4."""
     import tfhe_rs_amd  # noqa: F401
     from tfhe_rs_amd import ffi
     if not os.path.exists(LIB):
         pytest.skip("product library not built")
-    ok = ffi.Library(LIB).hip_programmable_bootstrap_ntt64_crt_supported
-    assert ok(1, 2048, 1, 23)          # PARAM_MESSAGE_2_CARRY_2: 12 + 23 = 35, the tightest accepted case
-    assert not ok(1, 2048, 1, 24)
-    assert not ok(1, 2048, 2, 23)      # two levels of 23 bits: 13 + 23
-    assert ok(1, 2048, 2, 15) and ok(2, 1024, 1, 23) and ok(3, 512, 2, 18)
-    assert not ok(1, 8192, 1, 15)      # rings the kernel is not instantiated for
-    assert not ok(3, 2048, 1, 10)
+    ok = ffi.Library(LIB).hip_programmable_bootstrap_ntt64_split_supported
+    assert ok(1, 2048, 1, 23) and ok(1, 2048, 1, 22)     # PARAM_MESSAGE_2_CARRY_2 and the GPU multi-bit sets' base
+    assert not ok(1, 2048, 1, 24) and not ok(1, 2048, 2, 15) and not ok(2, 1024, 1, 23) and not ok(1, 4096, 1, 22)

@@ -163,11 +163,8 @@ PBS_CASES = [(TOY_K1, "fft64"), (TOY_K1, "ntt64"), (TOY_K1_L1, "fft64"), (TOY_K2
              (TOY_K3, "fft64"), (TOY_K3, "ntt64"), (TOY_2048, "fft64"), (TOY_2048, "ntt64"),
              (TOY_2048_L2, "fft64"), (TOY_1024_K2, "fft64"), (TOY_1024_K2, "ntt64"), (TOY_1024_K1_L2, "fft64"),
              (TOY_K1, "exact64"), (TOY_K2, "exact64"), (TOY_K3, "exact64"), (TOY_8192, "fft64"), (TOY_16384, "fft64"),
-             # the NTT engine's second implementation, on the FP64 pipes modulo two 50-bit primes (pbs_ntt_crt.hip):
-             # same function, same oracle
-             (TOY_K1, "ntt64_crt"), (TOY_K2, "ntt64_crt"), (TOY_K3, "ntt64_crt"), (TOY_2048, "ntt64_crt"),
-             (TOY_1024_K2, "ntt64_crt"),
-             # its third form, on the throughput kernel's f64 transforms with the key in 16-bit limbs (split-key form)
+             # the NTT engine's second form, on the throughput kernel's f64 transforms with the key in 16-bit limbs
+             # (split-key form, pbs_fft_wave.hip LIMBS mode): same function, same oracle
              (TOY_2048, "ntt64_split")]
 
 
@@ -181,7 +178,7 @@ def test_pbs_bit_exact_and_decrypts(kind, p, engine):
     lut = orc.generate_lut(p.k, p.N, p.plaintext_modulus, p.delta, f)
     out = c.pbs(cts, lut)
     if engine.startswith("ntt64"):
-        assert use_backend(kind).hip_backend_last_pbs_kernel() == {"ntt64_crt": 12, "ntt64_split": 13}.get(engine, 3)
+        assert use_backend(kind).hip_backend_last_pbs_kernel() == (13 if engine == "ntt64_split" else 3)
     ref = oracle_pbs(p, c.keys, engine, cts, lut)
     assert np.array_equal(out, ref), "raw PBS output differs from the oracle"
     assert [decrypt_big(p, c.keys, o) for o in out] == [f(m) for m in msgs]
@@ -781,12 +778,11 @@ def test_multi_bit_full_size(which):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("engine", ["ntt64", "ntt64_crt", "ntt64_split"])
+@pytest.mark.parametrize("engine", ["ntt64", "ntt64_split"])
 def test_full_size_ntt_engine_wide_batch_bit_exact(engine):
     """Config 3 at production size (n=918, N=2048): 259 LWEs (ragged against every tile size of the launch)
     through the NTT engine, every output word against the oracle; all of them decrypt.  Both implementations: the
-    integer-Goldilocks kernel and the two-prime FP64 one (at this set the exact integer products reach 2^97, one bit
-    below what its primes can carry: the tightest case it accepts)."""
+    integer-Goldilocks kernel and the split-key f64 form (limb products up to 2^49 at this set: the largest it accepts)."""
     from .common import C1
     p = C1
     keys = make_keys(p, with_ksk=False)
@@ -796,7 +792,7 @@ def test_full_size_ntt_engine_wide_batch_bit_exact(engine):
     f = lambda x: (x * x + 1) % 16
     lut = orc.generate_lut(p.k, p.N, p.plaintext_modulus, p.delta, f)
     out = Ctx("hip", p, keys, engine).pbs(cts, lut)
-    assert use_backend("hip").hip_backend_last_pbs_kernel() == {"ntt64_crt": 12, "ntt64_split": 13}.get(engine, 3)
+    assert use_backend("hip").hip_backend_last_pbs_kernel() == (13 if engine == "ntt64_split" else 3)
     assert np.array_equal(out, oracle_pbs(p, keys, "ntt64", cts, lut))
     assert [decrypt_big(p, keys, o) for o in out] == [f(m) for m in msgs]
 

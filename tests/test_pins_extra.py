@@ -49,12 +49,12 @@ def test_ntt_engines_stay_within_the_key_modswitch_bound_of_the_pinned_exact_pat
     lut = rng.integers(0, 1 << 64, size=(k + 1) * N, dtype=np.uint64)  # a full-width accumulator: every digit in play
     d_lut = gpu.CudaGlweCiphertextList.from_glwe_ciphertext_list(lut, k, N, st)
     outs = {}
-    for e in ("exact64", "ntt64", "ntt64_crt"):
+    for e in ("exact64", "ntt64", "ntt64_split"):
         bsk = gpu.CudaLweBootstrapKey.from_lwe_bootstrap_key(ggsw0, 1, k, N, P["pbs_base_log"], P["pbs_level"], st, engine=e)
         d_o = gpu.CudaLweCiphertextList.new(k * N, B, st)
         gpu.cuda_programmable_bootstrap_lwe_ciphertext(d_in, d_o, d_lut, lidx, idx, idx, bsk, st)
         outs[e] = d_o.to_lwe_ciphertext_list(st)
-    assert np.array_equal(outs["ntt64"], outs["ntt64_crt"])
+    assert np.array_equal(outs["ntt64"], outs["ntt64_split"])
     diff = (outs["ntt64"] - outs["exact64"]).astype(np.int64)          # wrapping difference, signed
     assert np.abs(diff).max() <= (1 << 33) + 1, int(np.abs(diff).max()).bit_length()
     live = diff[np.any(diff != 0, axis=1)]                             # rows whose mask element switched to 0 rotate nothing

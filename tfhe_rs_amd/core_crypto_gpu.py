@@ -154,9 +154,9 @@ class CudaGlweCiphertextList:
 class CudaLweBootstrapKey:
     """Bootstrap key converted once per GPU of `streams` (lwe_bootstrap_key.rs:57-104,
     gpu/ffi.rs:744-787).  engine 'fft64' is the reference GPU path; 'ntt64' the Goldilocks
-    extension (integer arithmetic modulo 2^64 - 2^32 + 1), 'ntt64_crt' the same function computed on the FP64 pipes
-    modulo two 50-bit primes (a key of twice the bytes; identical outputs, measured 8 % slower on the MI355X: kept as a
-    second, independent implementation of the exact engine); 'exact64' the O(N^2)
+    extension (integer arithmetic modulo 2^64 - 2^32 + 1: any parameter set), 'ntt64_split' the same function — same
+    bits — on the throughput kernel's f64 transforms with the key in four 16-bit limbs (N = 2048, k = 1, one level;
+    a key of four times the bytes; 1.56x the integer kernel's rate on the MI355X); 'exact64' the O(N^2)
     exact-convolution verification engine, 'ref64' the reference-order f64 verification engine (tfhe-fft's dif4
     plan: reproduces the reference's f64 golden vectors)."""
 
@@ -174,27 +174,23 @@ class CudaLweBootstrapKey:
         self.decomp_base_log = int(decomp_base_log)
         self.decomp_level_count = int(decomp_level_count)
         self.ms_noise_reduction = bool(ms_noise_reduction)
-        self.engine = "ntt64" if engine in ("ntt64_crt", "ntt64_split") else engine
+        self.engine = "ntt64" if engine == "ntt64_split" else engine
         self.engine_impl = "ntt64_int" if engine == "ntt64" else engine
         if engine == "ntt64_split":
             assert _lib().hip_programmable_bootstrap_ntt64_split_supported(
                 glwe_dimension, polynomial_size, decomp_level_count, decomp_base_log), \
                 "parameter set outside the split-key form of the NTT engine"
-        if engine == "ntt64_crt":
-            assert _lib().hip_programmable_bootstrap_ntt64_crt_supported(
-                glwe_dimension, polynomial_size, decomp_level_count, decomp_base_log), \
-                "parameter set outside the two-prime form of the NTT engine"
         engine = self.engine_impl
         h_bsk = np.ascontiguousarray(h_bsk, dtype=U64)
         elems = (self.input_lwe_dimension * (glwe_dimension + 1) ** 2 * decomp_level_count * polynomial_size)
         assert h_bsk.size == elems, "bootstrap key container has the wrong size"
-        # n*(k+1)^2*l*N f64 per GPU — the byte size of the standard key; two residues per value for 'ntt64_crt'
+        # n*(k+1)^2*l*N f64 per GPU — the byte size of the standard key; four limb polynomials per key polynomial for
+        # 'ntt64_split'
         self.d_vecs = []
         for i in range(len(streams)):
-            d = CudaVec(elems * {"ntt64_crt": 2, "ntt64_split": 4}.get(engine, 1), streams, i, np.float64)
+            d = CudaVec(elems * (4 if engine == "ntt64_split" else 1), streams, i, np.float64)
             conv = {"fft64": _lib().cuda_convert_lwe_programmable_bootstrap_key_64_async,
                     "ntt64_int": _lib().hip_convert_lwe_programmable_bootstrap_key_ntt64_async,
-                    "ntt64_crt": _lib().hip_convert_lwe_programmable_bootstrap_key_ntt64_crt_async,
                     "ntt64_split": _lib().hip_convert_lwe_programmable_bootstrap_key_ntt64_split_async,
                     "exact64": _lib().hip_convert_lwe_programmable_bootstrap_key_exact64_async,
                     "ref64": _lib().hip_convert_lwe_programmable_bootstrap_key_ref64_async}[engine]
@@ -284,7 +280,6 @@ def cuda_programmable_bootstrap_lwe_ciphertext(input, output, accumulator, lut_i
         bsk.decomp_level_count, num_samples, True, 1 if bsk.ms_noise_reduction else 0)
     launch = {"fft64": lib.cuda_programmable_bootstrap_64_async,
               "ntt64_int": lib.hip_programmable_bootstrap_ntt64_async,
-              "ntt64_crt": lib.hip_programmable_bootstrap_ntt64_crt_async,
               "ntt64_split": lib.hip_programmable_bootstrap_ntt64_split_async,
               "exact64": lib.hip_programmable_bootstrap_exact64_async,
               "ref64": lib.hip_programmable_bootstrap_ref64_async}[bsk.engine_impl]

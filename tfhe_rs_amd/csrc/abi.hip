@@ -30,7 +30,6 @@ struct PbsBuffer {
   bool gpu_memory_allocated;
   FftTables fft;
   NttTables ntt;
-  CrtTables crt;
   uint64_t *acc_scratch = nullptr;
   uint64_t *split_acc = nullptr;  // exact engine, split-key form: (k+1) N accumulator words per sample in device memory
   uint64_t *ks_out = nullptr;  // hip_keyswitch_programmable_bootstrap_64_async: the keyswitched LWEs (small key)
@@ -247,7 +246,6 @@ uint64_t scratch_cuda_programmable_bootstrap_64_async(void *stream, uint32_t gpu
     b->fft = get_fft_tables(gpu_index, S(stream), polynomial_size);
     if (polynomial_size <= 4096) {
       b->ntt = get_ntt_tables(gpu_index, S(stream), polynomial_size);
-      b->crt = get_crt_tables(gpu_index, S(stream), polynomial_size);
     }
   }
   // bytes of device scratch: none up to N = 4096 (the accumulator never leaves the chip), one accumulator per
@@ -382,48 +380,6 @@ void hip_programmable_bootstrap_ntt64_async(void *stream, uint32_t gpu_index, vo
                               num_samples, num_many_lut, lut_stride, b->ms_type);
   launch_pbs_ntt_generic(S(stream), polynomial_size, glwe_dimension, a, b->ntt);
   g_last_pbs_kernel.store(3);
-}
-
-// ---- the NTT engine on the FP64 pipes (pbs_ntt_crt.hip): same function, same bits as the integer-Goldilocks form;
-// its key takes TWICE the bytes of the standard key (two residues per value)
-bool hip_programmable_bootstrap_ntt64_crt_supported(uint32_t glwe_dimension, uint32_t polynomial_size,
-                                                    uint32_t level_count, uint32_t base_log) {
-  return pbs_ntt_crt_supported(polynomial_size, glwe_dimension, level_count, base_log);
-}
-void hip_convert_lwe_programmable_bootstrap_key_ntt64_crt_async(void *stream, uint32_t gpu_index, void *dest,
-                                                                void const *src, uint32_t input_lwe_dim,
-                                                                uint32_t glwe_dim, uint32_t level_count,
-                                                                uint32_t polynomial_size) {
-  set_device(gpu_index);
-  check_pow2_poly(polynomial_size, 4096);
-  HX_PANIC_IF_FALSE(dest != nullptr && src != nullptr, "bootstrap key conversion: null pointer");
-  const size_t polys = (size_t)input_lwe_dim * level_count * (glwe_dim + 1) * (glwe_dim + 1);
-  const size_t bytes = polys * polynomial_size * sizeof(uint64_t);
-  void *tmp = nullptr;
-  HX_CHECK(hipMalloc(&tmp, bytes));
-  HX_CHECK(hipMemcpyAsync(tmp, src, bytes, hipMemcpyHostToDevice, S(stream)));
-  launch_bsk_to_crt(S(stream), polynomial_size, (const uint64_t *)tmp, dest, polys,
-                    get_crt_tables(gpu_index, S(stream), polynomial_size));
-  HX_CHECK(hipStreamSynchronize(S(stream)));  // the staging buffer must outlive the kernel
-  HX_CHECK(hipFree(tmp));
-}
-void hip_programmable_bootstrap_ntt64_crt_async(void *stream, uint32_t gpu_index, void *lwe_array_out,
-                                                void const *lwe_output_indexes, void const *lut_vector,
-                                                void const *lut_vector_indexes, void const *lwe_array_in,
-                                                void const *lwe_input_indexes, void const *bootstrapping_key,
-                                                int8_t *buffer, uint32_t lwe_dimension, uint32_t glwe_dimension,
-                                                uint32_t polynomial_size, uint32_t base_log, uint32_t level_count,
-                                                uint32_t num_samples, uint32_t num_many_lut, uint32_t lut_stride) {
-  set_device(gpu_index);
-  PbsBuffer *b = checked_buffer(buffer, lwe_dimension, glwe_dimension, polynomial_size, level_count, num_samples);
-  HX_PANIC_IF_FALSE(base_log >= 1 && base_log * level_count < 64, "invalid decomposition (base_log=%u, level=%u)",
-                    base_log, level_count);
-  if (num_samples == 0) return;
-  const PbsArgs a = make_args(lwe_array_out, lwe_output_indexes, lut_vector, lut_vector_indexes, lwe_array_in,
-                              lwe_input_indexes, bootstrapping_key, lwe_dimension, base_log, level_count,
-                              num_samples, num_many_lut, lut_stride, b->ms_type);
-  launch_pbs_ntt_crt(S(stream), polynomial_size, glwe_dimension, a, b->crt);
-  g_last_pbs_kernel.store(12);
 }
 
 // ---- the exact engine in its split-key f64 form (pbs_fft_wave.hip, LIMBS mode): the same function as

@@ -16,9 +16,6 @@ bool pbs_ntt_split_supported(uint32_t N, uint32_t glwe_dim, uint32_t level, uint
 void launch_pbs_ntt_split_wave(hipStream_t st, const PbsArgs &a, const FftTables &tb);
 // polys standard-domain key polynomials (level_count = 1) -> NTT_SPLIT_LIMBS Fourier-domain limb polynomials each
 void launch_bsk_to_split(hipStream_t st, uint32_t N, const uint64_t *src_dev, void *dst, size_t polys, const FftTables &tb);
-bool pbs_ntt_crt_supported(uint32_t N, uint32_t glwe_dim, uint32_t level, uint32_t base_log);
-void launch_pbs_ntt_crt(hipStream_t st, uint32_t N, uint32_t glwe_dim, const PbsArgs &a, const CrtTables &tb);
-void launch_bsk_to_crt(hipStream_t st, uint32_t N, const uint64_t *src_dev, void *dst, size_t polys, const CrtTables &tb);
 void launch_bsk_to_ntt(hipStream_t st, uint32_t N, const uint64_t *src_dev, void *dst, size_t polys, const NttTables &tb);
 
 // reference-order f64 verification engine (tfhe-fft radix-4 DIF plan, x86 conversion forms) — pbs_ref64.hip

@@ -739,8 +739,13 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
         const uint64_t M0 = ((uint64_t)m0 << 32) | m0, M1 = ((uint64_t)m1 << 32) | m1;
         const uint64_t s0 = *(const uint64_t *)(staged + (u0 & 0x3ff8));
         const uint64_t s1 = *(const uint64_t *)(staged + (u1 & 0x3ff8));
-        x0 = ((acc_re[r] ^ M0) + s0) ^ M0;
-        x1 = ((acc_im[r] ^ M1) + s1) ^ M1;
+        uint64_t a0 = acc_re[r], a1 = acc_im[r];
+        if constexpr (LIMBS > 0) {  // the accumulator is not in registers here: my own coefficients from the staged copy
+          a0 = *(const uint64_t *)(staged + (lane + r * 64) * 8);
+          a1 = *(const uint64_t *)(staged + (1024 + lane + r * 64) * 8);
+        }
+        x0 = ((a0 ^ M0) + s0) ^ M0;
+        x1 = ((a1 ^ M1) + s1) ^ M1;
       }
       if constexpr (LEVEL_CT == 1 && BASE_LOG_CT != 0 && BASE_LOG_CT <= 30) {
         // one level: the digit is the decomposer's initial state and depends on the high dword only
@@ -1278,6 +1283,7 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
       for (int r = 0; r < 16; ++r) gacc[r * 64] = U64x2{acc_re[r], acc_im[r]};
     };
     acc_store();
+    stage_acc();  // the rotation of the first CMUX reads the staged copy
     double worst = 0.0;  // largest distance from an integer seen by this lane (round-off check)
     // t = S + error, S integer: the Horner state takes the raw bits of t + 1.5 2^52 (= GL_SPLIT_C0 + S; the bias of
     // the four limbs comes off once at the end), R <- R 2^16 + bits (mod P), lazy Goldilocks forms
@@ -1296,24 +1302,25 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
       const uint32_t a_hat = HX_UNIFORM((uint32_t)modulus_switch(mask_cur, LOG2N2));
       if (a_hat == 0) continue;
       ++it;
-      acc_load();
-      stage_acc();
       cplx d[16];
       HX_PRIO(WAVE_PRIO_A);
-      make_digits(d, a_hat, 0);
+      make_digits(d, a_hat, 0);  // both operands of the rotation from the staged copy (the registers are not the accumulator's)
       HX_PRIO(WAVE_PRIO_B);
       wave_forward(d, ctx);  // d = F, my row of the digit transform; also in my buffer (mapping M3)
       uint64_t R_re[16], R_im[16];
       HX_UNROLL
       for (int r = 0; r < 16; ++r) R_re[r] = R_im[r] = 0;
-      HX_NO_UNROLL  // one body: unrolled, the scheduler overlaps the limbs and spills hundreds of registers
-      for (int limb = 0; limb < LIMBS; ++limb) {  // key limb index 0 = most significant
+      // one limb: product with the limb's key rows, back to the coefficients, into the Horner states.  LAST: F is dead
+      // after the product, the accumulator is requested from device memory under the inverse transform
+      auto limb_step = [&](uint32_t limb, auto last_tag) {
+        constexpr bool LAST = decltype(last_tag)::value;
         cplx o[16], ka0[4], ka1[4], kb0[4], kb1[4];
         const cplx *b0, *b1;
-        key_rows(i, (uint32_t)limb, b0, b1);
+        key_rows(i, limb, b0, b1);
         HX_PRIO(WAVE_PRIO_C);
-        mac(o, o, ka0, ka1, kb0, kb1, b0, b1, 0, (it - 1) * (uint32_t)LIMBS + (uint32_t)limb + 1,
+        mac(o, o, ka0, ka1, kb0, kb1, b0, b1, 0, (it - 1) * (uint32_t)LIMBS + limb + 1,
             std::integral_constant<bool, WAVE_FUSE_PASS1 != 0>{});
+        if constexpr (LAST) acc_load();
         HX_PRIO(WAVE_PRIO_D);
         wave_inverse_accumulate<WAVE_FUSE_PASS1 != 0, false, false, true>(o, acc_re, acc_im, ctx);
         HX_UNROLL
@@ -1321,7 +1328,7 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
           fold(R_re[r], o[r].re);
           fold(R_im[r], o[r].im);
         }
-        if (limb + 1 < LIMBS) {  // my buffer held the inverse transposition: the pair needs F again
+        if constexpr (!LAST) {  // my buffer held the inverse transposition: the pair needs F again
           WaveCtx cx = ctx0;
           HX_OPAQUE(cx.lane);
           cplx *p3 = buf + base_m3(cx);
@@ -1329,15 +1336,18 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
           for (int r = 0; r < 16; ++r) p3[r] = d[r];
           HX_WAVE_SYNC();
         }
-      }
+      };
+      HX_NO_UNROLL  // one body: unrolled, the scheduler overlaps the limbs and spills hundreds of registers
+      for (uint32_t limb = 0; limb + 1 < (uint32_t)LIMBS; ++limb) limb_step(limb, std::false_type{});  // limb 0 = most significant
+      limb_step((uint32_t)LIMBS - 1, std::true_type{});
       // acc += modswitch_to_2^64(R mod P) (ntt64.rs:162-177); the registers hold MINUS the accumulator
-      acc_load();
       HX_UNROLL
       for (int r = 0; r < 16; ++r) {
         acc_re[r] -= gl_modswitch_to_pow2_lean(gl_sub_canon(R_re[r], GL_SPLIT_BIAS));
         acc_im[r] -= gl_modswitch_to_pow2_lean(gl_sub_canon(R_im[r], GL_SPLIT_BIAS));
       }
       acc_store();
+      stage_acc();  // for the next CMUX's rotation (my buffer is free: the last inverse transposition is over)
     }
     if (worst > 0.25) __builtin_trap();  // an f64 product was not within 1/4 of an integer: never with these bounds
     acc_load();

@@ -34,19 +34,6 @@ struct NttTables {
   uint64_t n_inv;
 };
 
-// Two-prime FP64 form of the NTT engine (pbs_ntt_crt.hip): primes below 2^49.5 with p = 1 mod 8192, p1 p2 > 2^98.99
-static constexpr double CRT_P1 = 796131458875393.0, CRT_P2 = 796131458826241.0;
-static constexpr uint64_t CRT_P1_U64 = 796131458875393ull, CRT_P2_U64 = 796131458826241ull;
-static constexpr uint64_t CRT_ROOT8192_1 = 400979902871355ull, CRT_ROOT8192_2 = 584437071288690ull;  // of order 8192
-static constexpr double CRT_P1_INV_MOD_P2 = -16197335995.0;  // p1^-1 mod p2, centred
-// tw[q][m+g] = psi_q^bitrev(m+g) (centred residues as doubles), itw likewise for psi_q^-1; n_inv[q] = N^-1 mod p_q
-struct CrtTables {
-  const double *tw[2];
-  const double *itw[2];
-  double n_inv[2];
-};
-CrtTables get_crt_tables(uint32_t gpu_index, hipStream_t stream, uint32_t N);
-void fill_crt_tables_host(uint32_t N, int q, double *tw, double *itw, double *n_inv);
 
 // Lazily built, cached per (device, N); `stream` orders the upload before first use.
 FftTables get_fft_tables(uint32_t gpu_index, hipStream_t stream, uint32_t N);

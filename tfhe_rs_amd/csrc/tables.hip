@@ -195,38 +195,7 @@ void fill_ntt_tables_host(uint32_t N, uint64_t *tw, uint64_t *itw, uint64_t *n_i
   *n_inv = gl_pow_host(N, GL_P - 2);
 }
 
-// ---- two-prime FP64 NTT tables
-static uint64_t crt_mulmod_host(uint64_t a, uint64_t b, uint64_t p) { return (uint64_t)((unsigned __int128)a * b % p); }
-static uint64_t crt_pow_host(uint64_t a, uint64_t e, uint64_t p) {
-  uint64_t r = 1;
-  a %= p;
-  while (e) {
-    if (e & 1) r = crt_mulmod_host(r, a, p);
-    a = crt_mulmod_host(a, a, p);
-    e >>= 1;
-  }
-  return r;
-}
-static double crt_centred(uint64_t v, uint64_t p) { return v > p / 2 ? -(double)(p - v) : (double)v; }
-void fill_crt_tables_host(uint32_t N, int q, double *tw, double *itw, double *n_inv) {
-  const uint64_t p = q ? CRT_P2_U64 : CRT_P1_U64;
-  const uint64_t psi = crt_pow_host(q ? CRT_ROOT8192_2 : CRT_ROOT8192_1, 8192u / (2u * N), p);  // of order 2N
-  const uint64_t psi_inv = crt_pow_host(psi, p - 2, p);
-  const uint32_t lg = ilog2(N);
-  for (uint32_t i = 0; i < N; ++i) {
-    const uint32_t e = bitrev(i, lg);
-    tw[i] = crt_centred(crt_pow_host(psi, e, p), p);
-    itw[i] = crt_centred(crt_pow_host(psi_inv, e, p), p);
-  }
-  *n_inv = crt_centred(crt_pow_host(N, p - 2, p), p);
-}
-
 namespace {
-struct CrtEntry {
-  double *tw[2], *itw[2];
-  double n_inv[2];
-};
-std::map<std::pair<uint32_t, uint32_t>, CrtEntry> g_crt;
 struct FftEntry {
   double *fwd, *inv, *untw, *mono;
 };
@@ -290,27 +259,6 @@ FftTables get_fft_tables(uint32_t gpu_index, hipStream_t stream, uint32_t N) {
   return FftTables{it->second.fwd, it->second.inv, it->second.untw, it->second.mono};
 }
 
-CrtTables get_crt_tables(uint32_t gpu_index, hipStream_t stream, uint32_t N) {
-  std::lock_guard<std::mutex> lk(g_mu);
-  auto key = std::make_pair(gpu_index, N);
-  auto it = g_crt.find(key);
-  if (it == g_crt.end()) {
-    CrtEntry e;
-    HX_CHECK(hipSetDevice((int)gpu_index));
-    for (int q = 0; q < 2; ++q) {
-      std::vector<double> tw(N), itw(N);
-      fill_crt_tables_host(N, q, tw.data(), itw.data(), &e.n_inv[q]);
-      HX_CHECK(hipMalloc((void **)&e.tw[q], sizeof(double) * N));
-      HX_CHECK(hipMalloc((void **)&e.itw[q], sizeof(double) * N));
-      HX_CHECK(hipMemcpy(e.tw[q], tw.data(), sizeof(double) * N, hipMemcpyHostToDevice));
-      HX_CHECK(hipMemcpy(e.itw[q], itw.data(), sizeof(double) * N, hipMemcpyHostToDevice));
-    }
-    (void)stream;
-    it = g_crt.emplace(key, e).first;
-  }
-  const CrtEntry &e = it->second;
-  return CrtTables{{e.tw[0], e.tw[1]}, {e.itw[0], e.itw[1]}, {e.n_inv[0], e.n_inv[1]}};
-}
 
 NttTables get_ntt_tables(uint32_t gpu_index, hipStream_t stream, uint32_t N) {
   std::lock_guard<std::mutex> lk(g_mu);

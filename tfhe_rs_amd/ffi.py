@@ -96,10 +96,6 @@ SIGNATURES = {
     "hip_convert_lwe_programmable_bootstrap_key_ntt64_async": (None, [_v, _u32, _v, _v, _u32, _u32, _u32, _u32]),
     "hip_programmable_bootstrap_ntt64_async":
         (None, [_v, _u32, _v, _v, _v, _v, _v, _v, _v, _v, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _u32]),
-    "hip_programmable_bootstrap_ntt64_crt_supported": (C.c_bool, [_u32, _u32, _u32, _u32]),
-    "hip_convert_lwe_programmable_bootstrap_key_ntt64_crt_async": (None, [_v, _u32, _v, _v, _u32, _u32, _u32, _u32]),
-    "hip_programmable_bootstrap_ntt64_crt_async":
-        (None, [_v, _u32, _v, _v, _v, _v, _v, _v, _v, _v, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _u32]),
     "hip_programmable_bootstrap_ntt64_split_supported": (C.c_bool, [_u32, _u32, _u32, _u32]),
     "hip_convert_lwe_programmable_bootstrap_key_ntt64_split_async": (None, [_v, _u32, _v, _v, _u32, _u32, _u32, _u32]),
     "hip_programmable_bootstrap_ntt64_split_async":

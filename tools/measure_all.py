@@ -30,7 +30,7 @@ def rand_u64(n):
 
 
 def timed(fn, steps=3, warmup=1):
-    if any(a in sys.argv for a in ("mb1", "mb4one", "lat1", "ntt1", "n1024x", "wave1", "ntt4096", "n1024x4096", "ks1")):
+    if any(a in sys.argv for a in ("mb1", "mb4one", "lat1", "ntt1", "n1024x", "wave1", "ntt4096", "nttsplit4096", "n1024x4096", "ks1")):
         warmup = 0   # exactly one launch: the PMC passes of tools/pmc_record.py
     for _ in range(warmup):
         fn()
@@ -80,7 +80,6 @@ def pbs_case(p, B, engine="fft64", kernel=0, steps=3):
                                                          p.ms_type)
         launch = (lib.cuda_programmable_bootstrap_64_async if engine == "fft64"
                   else lib.hip_programmable_bootstrap_ntt64_split_async if bsk.engine_impl == "ntt64_split"
-                  else lib.hip_programmable_bootstrap_ntt64_crt_async if bsk.engine_impl == "ntt64_crt"
                   else lib.hip_programmable_bootstrap_ntt64_async)
 
         def run():
@@ -159,12 +158,12 @@ if __name__ == "__main__":
         pbs_case(C1, 4096, engine="ntt64", steps=2)       # integer-Goldilocks form
     if "ntt_split" in which:
         pbs_case(C1, 4096, engine="ntt64_split", steps=2)  # split-key f64 form (throughput kernel machinery)
-    if "ntt_crt" in which:
-        pbs_case(C1, 4096, engine="ntt64_crt", steps=2)   # two-prime FP64 form
     if "mb" in which:
         pbs_case(C4, 4096, steps=2)
     if "wave1" in which:   # one launch each, no warm-up (PMC passes, tools/pmc_record.py)
         pbs_case(C1, 4096, kernel=2, steps=1)
+    if "nttsplit4096" in which:
+        pbs_case(C1, 4096, engine="ntt64_split", steps=1)
     if "ntt4096" in which:
         pbs_case(C1, 4096, engine="ntt64", steps=1)
     if "n1024x4096" in which:

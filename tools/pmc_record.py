@@ -30,7 +30,8 @@ PASSES = [
 # target -> (tools/measure_all.py selector that issues exactly one launch, substring of the kernel name)
 TARGETS = {
     "fft": ("wave1", "pbs_fft_wave_kernel"),
-    "ntt": ("ntt4096", "pbs_ntt"),
+    "ntt": ("nttsplit4096", "pbs_fft_wave_kernel"),      # config 3's default engine: the split-key f64 form
+    "ntt_int": ("ntt4096", "pbs_ntt"),
     "mb_g3": ("mb1", "pbs_"),
     "mb_g4": ("mb4one", "pbs_"),
     "n1024": ("n1024x4096", "pbs_fft_wave3"),
@@ -112,7 +113,7 @@ def main():
                     print("sqlite:", e, file=sys.stderr)
                     continue
                 for name, cn, v, n in rows:
-                    if needle in name and "to_fourier" not in name and "to_ntt" not in name and "planes" not in name:
+                    if needle in name and "to_fourier" not in name and "to_ntt" not in name and "to_split" not in name and "planes" not in name:
                         kname = name
                         sums[cn] = v / max(n, 1)   # per launch
         with open(os.path.join(out_dir, f"pmc_{tag}_{t}.txt"), "w") as f:
