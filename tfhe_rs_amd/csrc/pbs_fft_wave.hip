@@ -114,6 +114,12 @@
 #ifndef WAVE_MB_BASES
 #define WAVE_MB_BASES 2  // multi-bit monomial bases gathered 0: once per group, 1: per level ahead of the key requests, 2: per level behind the first ones
 #endif
+#ifndef WAVE_SPLIT_LWES
+#define WAVE_SPLIT_LWES 4   // exact engine, split-key form: LWEs per workgroup (the accumulators of a CU's LWEs live in L2)
+#endif
+#ifndef WAVE_SPLIT_NT
+#define WAVE_SPLIT_NT 0     // 1: accumulator loads / stores nontemporal
+#endif
 #ifndef WAVE_FUSE_PASS1
 #define WAVE_FUSE_PASS1 1    // first inverse pass interleaved with the MAC chunks
 #endif
@@ -1270,17 +1276,33 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
   } else if constexpr (LIMBS > 0) {
     struct alignas(16) U64x2 { uint64_t x, y; };
     U64x2 *gacc = (U64x2 *)(a.acc_scratch + ((size_t)sample * 2 + (size_t)w) * N) + lane;  // slot r*64 + lane: coefficients c, 1024 + c
+    typedef uint64_t v2u64 __attribute__((ext_vector_type(2)));
     auto acc_load = [&]() {
       HX_UNROLL
       for (int r = 0; r < 16; ++r) {
+#if WAVE_SPLIT_NT && !defined(TFHE_HIPEMU)
+        const v2u64 v = __builtin_nontemporal_load((const v2u64 *)&gacc[r * 64]);
+        acc_re[r] = v.x;
+        acc_im[r] = v.y;
+#else
         const U64x2 v = gacc[r * 64];
         acc_re[r] = v.x;
         acc_im[r] = v.y;
+#endif
       }
     };
     auto acc_store = [&]() {
       HX_UNROLL
-      for (int r = 0; r < 16; ++r) gacc[r * 64] = U64x2{acc_re[r], acc_im[r]};
+      for (int r = 0; r < 16; ++r) {
+#if WAVE_SPLIT_NT && !defined(TFHE_HIPEMU)
+        v2u64 v;
+        v.x = acc_re[r];
+        v.y = acc_im[r];
+        __builtin_nontemporal_store(v, (v2u64 *)&gacc[r * 64]);
+#else
+        gacc[r * 64] = U64x2{acc_re[r], acc_im[r]};
+#endif
+      }
     };
     acc_store();
     stage_acc();  // the rotation of the first CMUX reads the staged copy
@@ -1469,7 +1491,8 @@ template <int B>
 static void launch_split_t(hipStream_t st, const PbsArgs &a, const FftTables &tb) {
   using namespace wavek;
   hx_set_dynamic_smem_once<pbs_fft_wave_kernel<1, B, 0, false, NTT_SPLIT_LIMBS>>(SMEM_BYTES);
-  const unsigned per_block = lwes_per_block(a.num_samples);
+  unsigned per_block = lwes_per_block(a.num_samples);
+  if (per_block > WAVE_SPLIT_LWES) per_block = WAVE_SPLIT_LWES;
   const unsigned blocks = (a.num_samples + per_block - 1) / per_block;
   HX_LAUNCH((pbs_fft_wave_kernel<1, B, 0, false, NTT_SPLIT_LIMBS>), dim3(blocks), dim3(128 * per_block), SMEM_BYTES, st, a,
             tb);
