@@ -406,8 +406,9 @@ void hip_backend_set_fft_kernel(uint32_t which);
 /* test hook: cap of the groups the multi-bit latency path processes per pass (0 = what the scratch holds) */
 void hip_backend_set_multibit_latency_groups(uint32_t groups);
 /* keyswitch kernel: 0 = automatic (int8 matrix-core GEMM, any batch size, when level <= 16 (padded to a power of
- * two), base_log <= 6 and n_in*padded level is a multiple of 32; scalar kernels otherwise), 1 = scalar kernels only.
- * Identical bits either way. */
+ * two), base_log <= 6 and n_in*padded level is a multiple of 32 — from 129 LWEs on as a digit pass followed by an
+ * LDS-staged GEMM; scalar kernels otherwise), 1 = scalar kernels only, 2 = the one-launch matrix-core kernel at every
+ * batch size (comparison).  Identical bits in all three. */
 void hip_backend_set_keyswitch_kernel(uint32_t which);
 /* generic kernels (f64 and NTT engines): 0 = one thread group per GLWE polynomial (default), 1 = single-group
  * kernels. Same bits. */

@@ -59,6 +59,7 @@ static inline void hx_wave_sync_emu() { hipemu::yield_barrier(2); }
 static inline unsigned long long atomicAdd(unsigned long long *p, unsigned long long v) {
   return __atomic_fetch_add(p, v, __ATOMIC_RELAXED);
 }
+static inline int atomicAdd(int *p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 static inline void __threadfence_block() {}
 static inline void __threadfence() {}
 

@@ -319,6 +319,41 @@ def test_keyswitch_matrix_core_path_with_padded_levels(kind, p):
 
 
 @pytest.mark.parametrize("kind", BACKENDS)
+@pytest.mark.parametrize("p", [TOY_2048, TOY_2048_L2], ids=lambda p: p.name)
+def test_keyswitch_large_batch_digit_pass_and_staged_gemm(kind, p):
+    """From 129 LWEs on the keyswitch is two launches — the shifted digits of every sample once (ks_digits_kernel),
+    then an int8 GEMM whose B operand is staged in LDS once per workgroup (ks_gemm_kernel).  131 and 261 LWEs (ragged
+    against the 32-row tiles and the 4-tile workgroups; one and three workgroup rows), power-of-two and padded
+    level counts, permuted input and output indexes: against the one-launch matrix-core kernel (choice 2), the scalar
+    kernels (1) and the oracle, bit for bit."""
+    c = ctx(kind, p, "fft64", with_ksk=True)
+    lib = use_backend(kind)
+    st = c.streams
+    for count in (131, 261):
+        msgs = [(5 * m + 2) % p.plaintext_modulus for m in range(count)]
+        cts = encrypt_big(p, c.keys, msgs, seed=70 + count)
+        rng = np.random.default_rng(count)
+        in_idx, out_idx = rng.permutation(count).astype(np.uint64), rng.permutation(count).astype(np.uint64)
+        ref = orc.keyswitch_batch(cts[in_idx.astype(np.int64)], c.keys.ksk, p.k * p.N, p.n, p.ks_base_log, p.ks_level)
+        want = np.zeros_like(ref)
+        want[out_idx.astype(np.int64)] = ref
+        d_in = gpu.CudaLweCiphertextList.from_lwe_ciphertext_list(cts, st)
+        d_ii, d_oi = gpu.CudaVec.from_cpu_async(in_idx, st), gpu.CudaVec.from_cpu_async(out_idx, st)
+        outs = {}
+        try:
+            for choice in (0, 2, 1):
+                lib.hip_backend_set_keyswitch_kernel(choice)
+                d_out = gpu.CudaLweCiphertextList.new(p.n, count, st)
+                gpu.cuda_keyswitch_lwe_ciphertext(c.ksk, d_in, d_out, d_ii, d_oi, False, st)
+                outs[choice] = d_out.to_lwe_ciphertext_list(st)
+        finally:
+            lib.hip_backend_set_keyswitch_kernel(0)
+        for choice, out in outs.items():
+            assert np.array_equal(out, want), (count, choice)
+        assert [decrypt_small(p, c.keys, o) for o in outs[0][out_idx.astype(np.int64)]] == [msgs[i] for i in in_idx.astype(np.int64)]
+
+
+@pytest.mark.parametrize("kind", BACKENDS)
 def test_keyswitch_key_layout_cache_follows_the_key_memory(kind):
     """The matrix-core path lays the key out once per key pointer and keeps that layout (no per-call re-layout, no
     allocation in the steady state).  The cache must follow the device memory: a key rewritten in place

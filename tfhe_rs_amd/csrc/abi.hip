@@ -95,6 +95,8 @@ void *cuda_create_stream_ffi(uint32_t gpu_index) {
 }
 void cuda_destroy_stream(void *stream, uint32_t gpu_index) {
   set_device(gpu_index);
+  HX_CHECK(hipStreamSynchronize(S(stream)));
+  ksd_release_stream((int)gpu_index, S(stream));
   HX_CHECK(hipStreamDestroy(S(stream)));
 }
 void cuda_synchronize_stream(void *stream, uint32_t gpu_index) {
@@ -744,7 +746,10 @@ void cuda_centered_modulus_switch_64_async(void *stream, uint32_t gpu_index, voi
 
 // =========================================================================== extensions
 void hip_backend_set_fft_kernel(uint32_t which) { g_fft_kernel_choice.store(which); }
-void hip_backend_set_keyswitch_kernel(uint32_t which) { g_keyswitch_use_mfma.store(which != 1); }
+void hip_backend_set_keyswitch_kernel(uint32_t which) {
+  g_keyswitch_use_mfma.store(which != 1);
+  g_keyswitch_split_digits.store(which != 2);
+}
 void hip_backend_set_ntt_kernel(uint32_t which) { g_ntt_kernel_serial = (which == 1); }
 void hip_backend_set_multibit_latency_groups(uint32_t groups) { g_multibit_latency_groups.store(groups); }
 uint32_t hip_backend_last_pbs_kernel(void) { return g_last_pbs_kernel.load(); }

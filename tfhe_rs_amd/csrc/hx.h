@@ -18,6 +18,8 @@
 #define HX_OPAQUE(v) do { } while (0)
 #define HX_LAUNDER(v) do { } while (0)
 #define HX_UNIFORM(v) (v)
+// 16 bytes per lane from global memory straight into LDS at (wave-uniform base) + lane * 16
+#define HX_GLOBAL_TO_LDS16(gsrc, lds_wave_base, lane) __builtin_memcpy((char *)(lds_wave_base) + (lane) * 16, (gsrc), 16)
 #define HX_BLOCK_SYNC_LDS() __syncthreads()
 #else
 #include <hip/hip_runtime.h>
@@ -50,6 +52,11 @@
 #define HX_LAUNDER(v) asm("" : "+v"(v))
 // wave-uniform value into an SGPR
 #define HX_UNIFORM(v) __builtin_amdgcn_readfirstlane(v)
+// 16 bytes per lane from global memory straight into LDS at (wave-uniform base) + lane * 16 (global_load_lds_dwordx4:
+// no staging registers, no ds_write; counted on vmcnt)
+#define HX_GLOBAL_TO_LDS16(gsrc, lds_wave_base, lane)                                                       \
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gsrc),                  \
+                                   (__attribute__((address_space(3))) void *)(lds_wave_base), 16, 0, 0)
 // workgroup barrier for data exchanged through LDS only: waits for this wave's LDS traffic, not for its
 // outstanding global loads (__syncthreads() drains vmcnt too, which would expose the latency of key
 // loads that were deliberately issued early)

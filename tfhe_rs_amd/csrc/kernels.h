@@ -51,6 +51,8 @@ void launch_keyswitch_64_32(hipStream_t st, uint32_t *lwe_out, const uint64_t *o
 void ksm_invalidate_range(int device, const void *p, size_t bytes);
 size_t ksm_cache_entries();
 extern std::atomic<bool> g_keyswitch_use_mfma;
+extern std::atomic<bool> g_keyswitch_split_digits;
+void ksd_release_stream(int device, hipStream_t st);  // the large-batch keyswitch's per-stream scratch
 extern bool g_ntt_kernel_serial;
 
 // small helpers — ciphertext.hip

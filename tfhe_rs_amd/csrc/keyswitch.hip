@@ -20,7 +20,8 @@ constexpr int KS_TPB = 256;  // output columns per workgroup
 constexpr int KS_TB = 16;    // samples per workgroup
 constexpr int KS_IC = 32;    // mask elements decomposed per LDS stage
 constexpr int KS_MAXL = 8;   // max levels staged (level_count <= 8 for every shortint set)
-std::atomic<bool> g_keyswitch_use_mfma{true};  // hip_backend_set_keyswitch_kernel: matrix-core path when its conditions hold
+std::atomic<bool> g_keyswitch_use_mfma{true};
+std::atomic<bool> g_keyswitch_split_digits{true};  // hip_backend_set_keyswitch_kernel(2): one-launch matrix-core kernel at every batch size  // hip_backend_set_keyswitch_kernel: matrix-core path when its conditions hold
 
 // DigitT: int32_t when base_log <= 31 (every shortint set), int64_t for wider bases
 template <typename DigitT>
@@ -423,6 +424,245 @@ __global__ void __launch_bounds__(256) ks_mfma_kernel(OutT *lwe_out, const uint6
   }
 }
 
+// ------------------------------------------------------------------ large batches: digits once, then a plain int8 GEMM
+// ks_mfma_kernel above rebuilds the shifted digits of its 32 samples for every one of the col_tiles column tiles
+// (about 165 vector instructions per step of 8 matrix instructions) and every wave fetches its own copy of the B
+// operand through the CU's vector L1 (8 KB per wave and step against 64 B/clk: twice what the matrix pipe can
+// consume).  Beyond KSD_MIN_SAMPLES LWEs the work is split:
+//   * ks_digits_kernel: one workgroup per tile of 32 samples decomposes the tile ONCE into the A operands of the
+//     GEMM, laid out as the matrix instruction wants them — [tile][step][lane][16 bytes], lane = (k half, row),
+//     byte j <-> k = step*32 + half*16 + j — plus the per-sample sum of the shifted digits (the shift correction);
+//   * ks_gemm_kernel: 4 waves x 32 samples against one column tile; per step of 32 k the workgroup stages the 8 KB
+//     of B (8 byte planes x 32 columns x 32 k) in LDS ONCE (double buffered, one barrier per step), every wave
+//     reads its operands from there and its A operand as one coalesced 16-byte load: no vector arithmetic in the
+//     loop, L1 traffic a quarter.  Same integer sums as ks_mfma_kernel: identical bits.
+constexpr uint32_t KSD_MIN_SAMPLES = 129;  // below: ks_mfma_kernel (one launch, K split over the waves up to 32 LWEs)
+
+template <int LEVEL, bool PADDED>
+HX_DEV hx_i8x16 ksm_build_a(const uint64_t (&xc)[16 / LEVEL], uint32_t base_log, uint32_t level, bool narrow,
+                            uint32_t half_b, int32_t &my_sa) {
+  constexpr int WORDS = 16 / LEVEL;
+  uint32_t bytes[16];
+  HX_UNROLL
+  for (int q = 0; q < WORDS; ++q) {
+    const uint32_t real = PADDED ? level : (uint32_t)LEVEL;
+    if (narrow) {  // wave-uniform: the decomposition on 32-bit registers (arith.h)
+      int32_t state = decomp_init_state32((uint32_t)(xc[q] >> 32), base_log, real);
+      HX_UNROLL
+      for (int lv = 0; lv < LEVEL; ++lv) {
+        const int32_t d = ((!PADDED || (uint32_t)lv < level) ? decompose_one_level32(base_log, state) : 0) + (int32_t)half_b;
+        bytes[q * LEVEL + lv] = (uint32_t)d;
+        my_sa += d;
+      }
+    } else {
+      uint64_t state = decomp_init_state(xc[q], base_log, real);
+      HX_UNROLL
+      for (int lv = 0; lv < LEVEL; ++lv) {
+        const int32_t d = ((!PADDED || (uint32_t)lv < level) ? (int32_t)decompose_one_level(base_log, state) : 0) + (int32_t)half_b;
+        bytes[q * LEVEL + lv] = (uint32_t)d;
+        my_sa += d;
+      }
+    }
+  }
+  hx_i8x16 av;
+  HX_UNROLL
+  for (int q = 0; q < 4; ++q)
+    av.w[q] = (int32_t)(bytes[4 * q] | (bytes[4 * q + 1] << 8) | (bytes[4 * q + 2] << 16) | (bytes[4 * q + 3] << 24));
+  return av;
+}
+
+// grid: (tiles of 32 samples, KSD_SPLIT): workgroup (t, y) takes the steps y*4 + w, y*4 + w + 4*KSD_SPLIT, ... of tile
+// t (w = its wave) and adds its share of the digit sums to suma (zeroed by the launcher; integer sums, any order)
+constexpr int KSD_SPLIT = 4;
+template <int LEVEL, bool PADDED>
+__global__ void __launch_bounds__(256) ks_digits_kernel(int8_t *aplanes, int32_t *suma, const uint64_t *lwe_in,
+                                                        const uint64_t *in_idx, uint32_t n_in, uint32_t base_log,
+                                                        uint32_t level, uint32_t num_samples) {
+  __shared__ int32_t sa[4][2][32];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row = lane & 31, h = lane >> 5;
+  const uint32_t stile = blockIdx.x, s = stile * 32 + row;
+  const uint32_t s_ld = s < num_samples ? s : 0;  // rows past the batch decompose sample 0; the GEMM stores nothing for them
+  const uint64_t *x = lwe_in + (size_t)in_idx[s_ld] * (n_in + 1);
+  const uint32_t half_b = 1u << (base_log - 1), steps = n_in * LEVEL / 32;
+  const bool narrow = base_log * level <= 30;
+  constexpr int WORDS = 16 / LEVEL;
+  int32_t my_sa = 0;
+  int8_t *dst = aplanes + ((size_t)stile * steps) * 1024 + (size_t)lane * 16;
+  for (uint32_t st = blockIdx.y * 4 + (uint32_t)wave; st < steps; st += 4 * KSD_SPLIT) {
+    uint64_t xc[WORDS];
+    HX_UNROLL
+    for (int q = 0; q < WORDS; ++q) xc[q] = x[(st * 32 + h * 16) / LEVEL + q];
+    const hx_i8x16 av = ksm_build_a<LEVEL, PADDED>(xc, base_log, level, narrow, half_b, my_sa);
+    int32_t *o = (int32_t *)(dst + (size_t)st * 1024);
+    o[0] = av.w[0];
+    o[1] = av.w[1];
+    o[2] = av.w[2];
+    o[3] = av.w[3];
+  }
+  sa[wave][h][row] = my_sa;
+  __syncthreads();
+  if (threadIdx.x < 32) {
+    int32_t t = 0;
+    for (int w = 0; w < 4; ++w) t += sa[w][0][threadIdx.x] + sa[w][1][threadIdx.x];
+    atomicAdd(&suma[stile * 32 + threadIdx.x], t);
+  }
+}
+
+template <typename OutT>
+__global__ void __launch_bounds__(256, 2) ks_gemm_kernel(OutT *lwe_out, const uint64_t *out_idx, const uint64_t *lwe_in,
+                                                      const uint64_t *in_idx, const int8_t *planes,
+                                                      const uint64_t *colsum, const int8_t *aplanes,
+                                                      const int32_t *suma, uint32_t n_in, uint32_t n_out,
+                                                      uint32_t base_log, uint32_t num_samples, uint32_t col_tiles,
+                                                      uint32_t steps, const OutT *ksk_raw, size_t ksk_words) {
+  constexpr int PLANES = (int)sizeof(OutT);
+  constexpr int HALF_BYTES = PLANES * KSM_CT * 16;  // one k half of a step: [plane][column][16 bytes]
+  constexpr int CHUNKS = 2 * HALF_BYTES / 16 / 256; // 16-byte chunks of B per thread and step (2 for u64 keys, 1 for u32)
+  __shared__ alignas(16) int8_t bs[2][2][HALF_BYTES];
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < KSM_FP) {  // the planes must still be this key's
+    const uint64_t *fp = colsum + (size_t)col_tiles * KSM_CT;
+    if ((uint64_t)ksk_raw[ksm_fp_index((int)threadIdx.x, ksk_words)] != fp[threadIdx.x]) __builtin_trap();
+  }
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int row = lane & 31, h = lane >> 5;
+  const uint32_t ct = blockIdx.x, stile = blockIdx.y * 4 + wave;
+  const bool live = stile * 32 < num_samples;  // whole wave; dead waves still stage B and meet the barriers
+  hx_i32x16 acc[PLANES];
+  for (int p = 0; p < PLANES; ++p)
+    for (int r = 0; r < 16; ++r) acc[p].v[r] = 0;
+  // B: 16-byte chunk c = tid + q*256 of step st -> k half c / (HALF_BYTES/16), byte offset (c % (HALF_BYTES/16)) * 16.
+  // A wave's 64 chunks are 1 KiB contiguous in the key layout AND in the LDS image: one direct global -> LDS load
+  // each (no staging registers, no ds_write pass).
+  const int8_t *bsrc[CHUNKS];
+  int8_t *bdst[CHUNKS];  // wave-uniform: where lane 0's chunk goes
+  HX_UNROLL
+  for (int q = 0; q < CHUNKS; ++q) {
+    const int c = tid + q * 256, half = c / (HALF_BYTES / 16), off = (c % (HALF_BYTES / 16)) * 16;
+    bsrc[q] = planes + ((size_t)half * col_tiles + ct) * HALF_BYTES + off;  // + st * 2 * col_tiles * HALF_BYTES per step
+    const int c0 = wave * 64 + q * 256, half0 = c0 / (HALF_BYTES / 16), off0 = (c0 % (HALF_BYTES / 16)) * 16;
+    bdst[q] = &bs[0][half0][off0];
+  }
+  const size_t bstep = (size_t)2 * col_tiles * HALF_BYTES;
+  const hx_i8x16 *ap = (const hx_i8x16 *)(aplanes + ((size_t)(live ? stile : 0) * steps) * 1024) + lane;
+  auto stage_b = [&](uint32_t st, int buf) {
+    HX_UNROLL
+    for (int q = 0; q < CHUNKS; ++q)
+      HX_GLOBAL_TO_LDS16(bsrc[q] + (size_t)st * bstep, bdst[q] + buf * (2 * HALF_BYTES), lane);
+  };
+  // Software pipeline: at the top of step st the B image of step st + 1 is requested into the other LDS buffer and
+  // the A operand of step st + 1 into registers; both land under the 8 matrix instructions of step st.  Branch-free
+  // (a conditional around the matrix instructions makes the compiler shuttle the 128 accumulator registers between
+  // the register files every step): the last step re-requests its own operands, waves past the batch multiply the
+  // first tile's digits and store nothing.
+  const uint32_t last = steps - 1;
+  hx_i8x16 av, a1;
+  stage_b(0, 0);
+  av = ap[0];
+  __syncthreads();
+  for (uint32_t st = 0; st < steps; ++st) {
+    const int cur = (int)(st & 1);
+    const uint32_t nx = st + 1 < steps ? st + 1 : last;
+    // this step's operands out of LDS first: the compiler drains every outstanding global -> LDS load before an LDS
+    // read, so the requests for the next step go out behind the reads and land under the matrix instructions
+    hx_i8x16 bv[PLANES];
+    HX_UNROLL
+    for (int p = 0; p < PLANES; ++p) bv[p] = *(const hx_i8x16 *)&bs[cur][h][p * (KSM_CT * 16) + row * 16];
+    HX_SCHED_FENCE();
+#ifndef KSG_SKIP_B  // (timing experiments: wrong results)
+    stage_b(nx, cur ^ 1);
+#endif
+#ifndef KSG_SKIP_A
+    a1 = ap[(size_t)nx * 64];
+#endif
+    HX_SCHED_FENCE();
+#ifndef KSG_SKIP_MFMA
+    HX_UNROLL
+    for (int p = 0; p < PLANES; ++p) acc[p] = hx_mfma_i32_32x32x32_i8(av, bv[p], acc[p]);
+#else
+    HX_UNROLL
+    for (int p = 0; p < PLANES; ++p) acc[p].v[0] += bv[p].w[0] ^ av.w[0];
+#endif
+    HX_SCHED_FENCE();
+    av = a1;
+    __syncthreads();
+  }
+  if (!live) return;
+  // everything the epilogue addresses derives from this lane value, made opaque HERE: otherwise the index, sum and
+  // pointer loads of all 16 output rows are hoisted above the loop and held (or spilled) across it
+  int lane_e = lane;
+  HX_OPAQUE(lane_e);
+  const uint32_t col = ct * KSM_CT + (lane_e & 31);
+  if (col > n_out) return;
+  const uint32_t half_b = 1u << (base_log - 1);
+  const uint64_t corr = (uint64_t)half_b * colsum[col];
+  HX_UNROLL
+  for (int r = 0; r < 16; ++r) {
+    const int orow = (r & 3) + 8 * (r >> 2) + 4 * (lane_e >> 5);
+    const uint32_t so = stile * 32 + orow;
+    if (so >= num_samples) continue;
+    const int64_t sum_a = (int64_t)suma[so];
+    uint64_t v = 0;
+    HX_UNROLL
+    for (int p = 0; p < PLANES; ++p) v += (uint64_t)((int64_t)acc[p].v[r] + 128 * sum_a) << (8 * p);
+    uint64_t o = corr - v;
+    if (col == n_out) {
+      const uint64_t b = lwe_in[(size_t)in_idx[so] * (n_in + 1) + n_in];
+      o += sizeof(OutT) == 8 ? b : ((b >> 31) + 1) >> 1;
+    }
+    lwe_out[(size_t)out_idx[so] * (n_out + 1) + col] = (OutT)o;
+  }
+}
+
+// A operands + digit sums of the large-batch path: one growing buffer per (device, stream) — the keyswitch entry
+// points of the reference carry no scratch argument.  Never grown under stream capture (the launch then takes
+// ks_mfma_kernel); released with the stream (cuda_destroy_stream) or when a larger one replaces it.
+struct KsdScratch {
+  int device;
+  hipStream_t stream;
+  void *buf;
+  size_t bytes;
+};
+static std::vector<KsdScratch> g_ksd;
+static std::mutex g_ksd_mutex;
+static void *ksd_scratch(int device, hipStream_t st, size_t bytes, bool capturing) {
+  void *old = nullptr, *buf = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(g_ksd_mutex);
+    KsdScratch *e = nullptr;
+    for (KsdScratch &k : g_ksd)
+      if (k.device == device && k.stream == st) e = &k;
+    if (e != nullptr && e->bytes >= bytes) return e->buf;
+    if (capturing) return nullptr;
+    if (e == nullptr) {
+      g_ksd.push_back(KsdScratch{device, st, nullptr, 0});
+      e = &g_ksd.back();
+    }
+    old = e->buf;
+    HX_CHECK(hipMalloc(&buf, bytes));
+    e->buf = buf;
+    e->bytes = bytes;
+  }
+  if (old) {
+    HX_CHECK(hipStreamSynchronize(st));  // launches that still read the old buffer
+    HX_CHECK(hipFree(old));
+  }
+  return buf;
+}
+void ksd_release_stream(int device, hipStream_t st) {
+  void *old = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(g_ksd_mutex);
+    for (size_t i = 0; i < g_ksd.size(); ++i)
+      if (g_ksd[i].device == device && g_ksd[i].stream == st) {
+        old = g_ksd[i].buf;
+        g_ksd.erase(g_ksd.begin() + i);
+        break;
+      }
+  }
+  if (old) HX_CHECK(hipFree(old));
+}
+
 // Byte planes + column sums of a keyswitch key, built ONCE per key and kept until the key's device memory is
 // released or overwritten.  The C ABI hands the key over as a plain device array at every call, so the cache is
 // keyed by (device, key pointer, shape); every entry point of the boundary that frees or writes device memory
@@ -567,6 +807,36 @@ static bool keyswitch_mfma(hipStream_t st, OutT *lwe_out, const uint64_t *out_id
     colsum = (uint64_t *)((char *)hit->planes + hit->plane_bytes);
   }
   for (const KsmEntry &e : evicted) ksm_release(e);
+  if (num_samples >= KSD_MIN_SAMPLES && g_keyswitch_split_digits.load()) {
+    // large batch: the digits once (A operands in the stream's scratch), then the LDS-staged GEMM
+    const uint32_t tiles = (num_samples + 31) / 32, steps = K / 32;
+    const size_t a_bytes = (size_t)tiles * steps * 1024, need_s = a_bytes + (size_t)tiles * 32 * sizeof(int32_t);
+    int8_t *scr = (int8_t *)ksd_scratch(device, st, need_s, capturing);
+    if (scr != nullptr) {
+      int32_t *suma = (int32_t *)(scr + a_bytes);
+      HX_CHECK(hipMemsetAsync(suma, 0, (size_t)tiles * 32 * sizeof(int32_t), st));
+#define KSD_LAUNCH(L)                                                                                              \
+  do {                                                                                                               \
+    if (level == L)                                                                                                  \
+      HX_LAUNCH((ks_digits_kernel<L, false>), dim3(tiles, KSD_SPLIT), dim3(256), 0, st, scr, suma, lwe_in, in_idx, n_in, \
+                base_log, level, num_samples);                                                                       \
+    else                                                                                                             \
+      HX_LAUNCH((ks_digits_kernel<L, true>), dim3(tiles, KSD_SPLIT), dim3(256), 0, st, scr, suma, lwe_in, in_idx, n_in,  \
+                base_log, level, num_samples);                                                                       \
+  } while (0)
+      switch (level_pad) {
+        case 1: KSD_LAUNCH(1); break;
+        case 2: KSD_LAUNCH(2); break;
+        case 4: KSD_LAUNCH(4); break;
+        case 8: KSD_LAUNCH(8); break;
+        default: KSD_LAUNCH(16); break;
+      }
+#undef KSD_LAUNCH
+      HX_LAUNCH((ks_gemm_kernel<OutT>), dim3(col_tiles, (tiles + 3) / 4), dim3(256), 0, st, lwe_out, out_idx, lwe_in,
+                in_idx, planes, colsum, scr, suma, n_in, n_out, base_log, num_samples, col_tiles, steps, ksk, ksk_words);
+      return true;
+    }
+  }
   // up to 32 LWEs: one tile of samples, the four waves of a workgroup split K (needs steps = K / 32 divisible by 4)
   const bool split = num_samples <= 32 && (K / 32) % 4 == 0;
   const dim3 grid(col_tiles, split ? 1 : (num_samples + 127) / 128);

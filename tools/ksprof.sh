@@ -1,4 +1,4 @@
-cd /tmp && export TMPDIR=/tmp
-rm -rf $GRAFT_REPO_ROOT/gpurun_out/rocprof_ks
-rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/rocprof_ks -- python $GRAFT_REPO_ROOT/tools/measure_all.py ks > $GRAFT_REPO_ROOT/gpurun_out/rocprof_ks.log 2>&1
-cd $GRAFT_REPO_ROOT && python tools/rocprof_summary.py gpurun_out/rocprof_ks gpurun_out/rocprof_ks_summary.txt | head -8
+# keyswitch 2048 -> 918, 4 levels, batch 4096: the three kernel choices (0 digit pass + staged GEMM, 2 one-launch matrix-core kernel, 1 scalar)
+for c in 0 2; do
+  echo "== choice $c"; TFHE_KS_CHOICE=$c python tools/measure_all.py ks ks32 ks1024 2>&1 | cut -c1-200
+done

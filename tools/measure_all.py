@@ -128,6 +128,8 @@ def ks32_case(p, B, steps=5):
 
 
 if __name__ == "__main__":
+    if os.environ.get("TFHE_KS_CHOICE"):
+        lib.hip_backend_set_keyswitch_kernel(int(os.environ["TFHE_KS_CHOICE"]))
     which = sys.argv[1:] or ["ks", "wave", "generic", "ntt", "mb", "n1024", "sweep"]
     if "ks" in which:
         ks_ms = ks_case(C1, 4096)

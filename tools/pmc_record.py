@@ -35,7 +35,8 @@ TARGETS = {
     "mb_g3": ("mb1", "pbs_"),
     "mb_g4": ("mb4one", "pbs_"),
     "n1024": ("n1024x4096", "pbs_fft_wave3"),
-    "ks": ("ks1", "ks_mfma"),
+    "ks": ("ks1", "ks_gemm"),
+    "ks_onelaunch": ("ks1", "ks_mfma"),
 }
 
 
