@@ -112,7 +112,12 @@
 #define WAVE_MB_SETS 4  // multi-bit: register sets in rotation (SETS - 1 key requests in flight)
 #endif
 #ifndef WAVE_MB_BASES
-#define WAVE_MB_BASES 2  // multi-bit monomial bases gathered 0: once per group, 1: per level ahead of the key requests, 2: per level behind the first ones
+// multi-bit monomial bases gathered 0: once per group (held across the digit and transform phases: the two-level g = 3
+// kernel then spills 55 registers, 8 dword stores + loads per wave and level), 1: per level ahead of the level's key
+// requests (no spills), 2: per level behind the first key requests (no spills).  Measured on one box, batch 4096,
+// g = 3 / g = 4: 0 -> 46.5 / 33.4 ms, 1 -> 48.5 / 35.4 ms, 2 -> 48.2 / 35.6 ms: the gathers' latency in front of the
+// multiply-accumulate costs more than the spill traffic, so 0 stays.
+#define WAVE_MB_BASES 0
 #endif
 #ifndef WAVE_SPLIT_LWES
 #define WAVE_SPLIT_LWES 4   // exact engine, split-key form: LWEs per workgroup (the accumulators of a CU's LWEs live in L2)
