@@ -294,6 +294,9 @@ __global__ void __launch_bounds__(256) ks_mfma_kernel(OutT *lwe_out, const uint6
   }
   __shared__ int32_t sa[4][2][32];  // per wave: sum of the shifted digits of every row, per k half
   __shared__ int32_t red[KSPLIT > 1 ? 2 : 1][KSPLIT > 1 ? PLANES_OF(OutT) : 1][KSPLIT > 1 ? 16 : 1][64];
+  // KSPLIT = 4 with a 64-bit key: 64 KiB of static LDS for the two-round reduction — gfx950 only (160 KiB per CU; this
+  // library is built for that target alone, Makefile ARCH), two workgroups per CU
+  static_assert(sizeof(red) + sizeof(sa) <= 160 * 1024 / 2, "split-K reduction buffers: more than half of a gfx950 CU's LDS");
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int row = lane & 31, h = lane >> 5;
   const uint32_t ct = blockIdx.x;
