@@ -110,6 +110,26 @@ void hip_keyswitch_programmable_bootstrap_64_async(
     uint32_t ks_level, uint32_t base_log, uint32_t level_count, uint32_t num_samples,
     uint32_t num_many_lut, uint32_t lut_stride);
 
+/* extension: the same call for CHAINS of rounds in which a round's keyswitch reads exactly what the previous round's
+ * bootstrap wrote (apply-lookup-table chains): the sample extraction of the bootstrap is fused with the digit pass of
+ * the NEXT keyswitch.  flags: HIP_KSPBS_EMIT_DIGITS — the bootstrap also writes, for every output ciphertext, the
+ * shifted keyswitch digits of its mask (decomposition ks_base_log / ks_level of this call) as the int8 A operands of the
+ * keyswitch GEMM, into the scratch; HIP_KSPBS_INPUT_FROM_PREVIOUS — the caller states that lwe_array_in /
+ * lwe_input_indexes are the lwe_array_out / lwe_output_indexes of the previous call on this scratch and that nothing
+ * wrote to them since: the keyswitch starts from the emitted operands (the library checks pointers, count and
+ * decomposition against what it recorded and falls back to its digit pass otherwise).  Emission is done by the
+ * N = 2048, k = 1 throughput kernel (more than 256 LWEs) for keyswitch level counts padded to 4 or 8 with
+ * base_log * level <= 30; elsewhere the flags change nothing.  Identical bits with and without the flags. */
+#define HIP_KSPBS_EMIT_DIGITS 1u
+#define HIP_KSPBS_INPUT_FROM_PREVIOUS 2u
+void hip_keyswitch_programmable_bootstrap_chain_64_async(
+    void *stream, uint32_t gpu_index, void *lwe_array_out, void const *lwe_output_indexes,
+    void const *lut_vector, void const *lut_vector_indexes, void const *lwe_array_in,
+    void const *lwe_input_indexes, void const *ksk, void const *bootstrapping_key, int8_t *buffer,
+    uint32_t lwe_dimension, uint32_t glwe_dimension, uint32_t polynomial_size, uint32_t ks_base_log,
+    uint32_t ks_level, uint32_t base_log, uint32_t level_count, uint32_t num_samples,
+    uint32_t num_many_lut, uint32_t lut_stride, uint32_t flags);
+
 /* ------------------------------------------------------------------ multi-bit PBS
  * backends/tfhe-cuda-backend/cuda/include/pbs/programmable_bootstrap_multibit.h:9-40
  * called from tfhe/src/core_crypto/gpu/ffi.rs:208-309,789-835
@@ -417,6 +437,9 @@ void hip_backend_set_ntt_kernel(uint32_t which);
  * 5 exact, 6 wave multi-bit, 7 block (latency), 8 block dual-stream, 9 wave f64 for N = 1024,
  * 10 multi-bit latency path, 11 reference-order f64 engine, 12 NTT engine in its two-prime FP64 form */
 uint32_t hip_backend_last_pbs_kernel(void);
+/* last 64-bit keyswitch, for tests: 0 scalar kernels, 1 one-launch matrix-core kernel, 2 digit pass + staged GEMM,
+ * 3 staged GEMM on the digits the previous bootstrap emitted */
+uint32_t hip_backend_last_keyswitch_path(void);
 const char *hip_backend_version(void);
 
 /* HIP events recorded on a backend stream (used by bench.py to time launches) */

@@ -354,6 +354,75 @@ def test_keyswitch_large_batch_digit_pass_and_staged_gemm(kind, p):
 
 
 @pytest.mark.parametrize("kind", BACKENDS)
+def test_chained_ks_pbs_rounds_with_digits_emitted_by_the_bootstrap(kind):
+    """hip_keyswitch_programmable_bootstrap_chain_64_async: three KS -> PBS rounds in which every round reads what the
+    previous one wrote.  With HIP_KSPBS_EMIT_DIGITS the sample extraction of a round's bootstrap also writes the int8
+    operands of the next round's keyswitch GEMM (no digit pass there); with HIP_KSPBS_INPUT_FROM_PREVIOUS the next round
+    takes them.  131 LWEs (ragged tiles) through the throughput kernel, PERMUTED output indexes (round r + 1 reads
+    through the index array round r wrote through): every round's output must equal the flag-free chain and the
+    oracle's keyswitch + bootstrap, bit for bit; a round whose input is NOT the previous output (fresh array) must
+    fall back to its own digit pass even when the flag claims otherwise."""
+    p = TOY_2048
+    c = ctx(kind, p, "fft64", with_ksk=True)
+    lib, st = use_backend(kind), c.streams
+    B = 131
+    msgs = [(7 * m + 3) % p.plaintext_modulus for m in range(B)]
+    cts = encrypt_big(p, c.keys, msgs, seed=91)
+    f = lambda x: (3 * x + 1) % p.plaintext_modulus
+    lut = orc.generate_lut(p.k, p.N, p.plaintext_modulus, p.delta, f)
+    rng = np.random.default_rng(17)
+    perm = rng.permutation(B).astype(np.uint64)
+    s, g = st.ptr[0], 0
+    d_lut = gpu.CudaGlweCiphertextList.from_glwe_ciphertext_list(lut, p.k, p.N, st)
+    lidx = gpu.CudaVec.from_cpu_async(np.zeros(B, dtype=np.uint64), st)
+    d_perm = gpu.CudaVec.from_cpu_async(perm, st)
+    d_triv = gpu.CudaVec.from_cpu_async(np.arange(B, dtype=np.uint64), st)
+    buf = C.c_void_p()
+    lib.hip_scratch_keyswitch_programmable_bootstrap_64_async(s, g, C.byref(buf), p.n, p.k, p.N, p.pbs_level, B, True, p.ms_type)
+    EMIT, FROM_PREV = 1, 2
+
+    def chain(flag_rounds):
+        d_a = gpu.CudaLweCiphertextList.from_lwe_ciphertext_list(cts, st)
+        d_b = gpu.CudaLweCiphertextList.new(p.k * p.N, B, st)
+        outs, src, dst, in_idx = [], d_a, d_b, d_triv
+        for flags in flag_rounds:
+            lib.hip_keyswitch_programmable_bootstrap_chain_64_async(
+                s, g, dst.d_vec.ptr, d_perm.ptr, d_lut.d_vec.ptr, lidx.ptr, src.d_vec.ptr, in_idx.ptr, c.ksk.d_vec.ptr,
+                c.bsk.d_vec.ptr, buf, p.n, p.k, p.N, p.ks_base_log, p.ks_level, p.pbs_base_log, p.pbs_level, B, 1, 0, flags)
+            outs.append(dst.to_lwe_ciphertext_list(st))
+            src, dst, in_idx = dst, src, d_perm
+        return outs
+
+    try:
+        lib.hip_backend_set_fft_kernel(2)   # the throughput kernel also below 257 LWEs
+        plain = chain([0, 0, 0])
+        fused = chain([EMIT, EMIT | FROM_PREV, FROM_PREV])
+        assert lib.hip_backend_last_keyswitch_path() == 3        # the last round's keyswitch ran on emitted digits
+        lied = chain([EMIT, FROM_PREV | EMIT, FROM_PREV])[1:]   # same as fused; then a foreign input under the flag:
+        d_x = gpu.CudaLweCiphertextList.from_lwe_ciphertext_list(cts, st)
+        d_y = gpu.CudaLweCiphertextList.new(p.k * p.N, B, st)
+        lib.hip_keyswitch_programmable_bootstrap_chain_64_async(
+            s, g, d_y.d_vec.ptr, d_perm.ptr, d_lut.d_vec.ptr, lidx.ptr, d_x.d_vec.ptr, d_triv.ptr, c.ksk.d_vec.ptr,
+            c.bsk.d_vec.ptr, buf, p.n, p.k, p.N, p.ks_base_log, p.ks_level, p.pbs_base_log, p.pbs_level, B, 1, 0, FROM_PREV)
+        foreign = d_y.to_lwe_ciphertext_list(st)
+        assert lib.hip_backend_last_keyswitch_path() == 2        # ... and this one made its own
+    finally:
+        lib.hip_backend_set_fft_kernel(0)
+        lib.cleanup_cuda_programmable_bootstrap_64(s, g, C.byref(buf))
+    for r in range(3):
+        assert np.array_equal(fused[r], plain[r]), r
+    assert np.array_equal(lied[0], plain[1]) and np.array_equal(lied[1], plain[2])
+    assert np.array_equal(foreign, plain[0])
+    # round 0 against the oracle: keyswitch then bootstrap of sample i written to block perm[i]
+    ks = orc.keyswitch_batch(cts, c.keys.ksk, p.k * p.N, p.n, p.ks_base_log, p.ks_level)
+    ref = oracle_pbs(p, c.keys, "fft64", ks, lut)
+    want = np.zeros_like(ref)
+    want[perm.astype(np.int64)] = ref
+    assert np.array_equal(plain[0], want)
+    assert [decrypt_big(p, c.keys, plain[0][int(perm[i])]) for i in range(B)] == [f(m) for m in msgs]
+
+
+@pytest.mark.parametrize("kind", BACKENDS)
 def test_keyswitch_key_layout_cache_follows_the_key_memory(kind):
     """The matrix-core path lays the key out once per key pointer and keeps that layout (no per-call re-layout, no
     allocation in the steady state).  The cache must follow the device memory: a key rewritten in place

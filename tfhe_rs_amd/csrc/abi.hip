@@ -32,6 +32,16 @@ struct PbsBuffer {
   NttTables ntt;
   uint64_t *acc_scratch = nullptr;
   uint64_t *split_acc = nullptr;  // exact engine, split-key form: (k+1) N accumulator words per sample in device memory
+  // hip_keyswitch_programmable_bootstrap_chain_64_async: keyswitch operands written by the bootstrap of the previous
+  // call for ITS outputs (what they are valid for is recorded; anything else falls back to the digit pass)
+  int8_t *emit_a = nullptr;
+  int32_t *emit_suma = nullptr;
+  size_t emit_bytes = 0;
+  struct {
+    bool valid = false;
+    const void *array = nullptr, *indexes = nullptr;
+    uint32_t count = 0, steps = 0, base_log = 0, level = 0;
+  } emitted;
   uint64_t *ks_out = nullptr;  // hip_keyswitch_programmable_bootstrap_64_async: the keyswitched LWEs (small key)
   uint64_t *trivial = nullptr; // 0, 1, ..., max_samples - 1 (indexes of that list)
 };
@@ -296,6 +306,38 @@ static PbsBuffer *checked_buffer(int8_t *buffer, uint32_t lwe_dimension, uint32_
   return b;
 }
 
+// kernel choice of the classic f64 PBS; returns the id hip_backend_last_pbs_kernel reports
+static uint32_t launch_classic_pbs(hipStream_t st, PbsArgs &a, PbsBuffer *b, uint32_t glwe_dimension,
+                                   uint32_t polynomial_size) {
+  const uint32_t level_count = a.level, base_log = a.base_log, num_samples = a.num_samples;
+  a.acc_scratch = b->acc_scratch;
+  const uint32_t choice = g_fft_kernel_choice.load();
+  const bool wave_ok = pbs_fft_wave_supported(polynomial_size, glwe_dimension, level_count) && base_log <= 31;
+  const bool wave3_ok = pbs_fft_wave3_supported(polynomial_size, glwe_dimension, level_count);
+  const bool block_ok = pbs_fft_block_supported(polynomial_size, glwe_dimension, level_count);
+  if (choice == 2) HX_PANIC_IF_FALSE(wave_ok || wave3_ok, "throughput kernel requested for an unsupported parameter set");
+  if (choice == 3 || choice == 4) HX_PANIC_IF_FALSE(block_ok, "latency kernel requested for an unsupported parameter set");
+  uint32_t id;
+  // automatic choice: up to one LWE per CU the latency kernel finishes first; beyond, the throughput kernel
+  if (choice == 3 || choice == 4 || (choice == 0 && block_ok && num_samples <= kLatencyKernelMaxBatch)) {
+    // 3 / automatic: one polynomial per half workgroup (512 threads); 4: dual-stream variant (256 threads),
+    // measured slower (4.7 vs 4.2 ms), kept for comparison
+    launch_pbs_fft_block(st, a, b->fft, choice == 4 ? 0 : 1);
+    id = choice == 4 ? 8 : 7;
+  } else if (wave_ok && (choice == 0 || choice == 2)) {
+    launch_pbs_fft_wave(st, a, b->fft);
+    id = 2;
+  } else if (wave3_ok && (choice == 0 || choice == 2)) {  // N = 1024: one wave per polynomial, 512-point transforms
+    launch_pbs_fft_wave3(st, glwe_dimension, a, b->fft);
+    id = 9;
+  } else {
+    launch_pbs_fft_generic(st, polynomial_size, glwe_dimension, a, b->fft);
+    id = 1;
+  }
+  g_last_pbs_kernel.store(id);
+  return id;
+}
+
 void cuda_programmable_bootstrap_64_async(void *stream, uint32_t gpu_index, void *lwe_array_out,
                                           void const *lwe_output_indexes, void const *lut_vector,
                                           void const *lut_vector_indexes, void const *lwe_array_in,
@@ -312,29 +354,8 @@ void cuda_programmable_bootstrap_64_async(void *stream, uint32_t gpu_index, void
   PbsArgs a = make_args(lwe_array_out, lwe_output_indexes, lut_vector, lut_vector_indexes, lwe_array_in,
                         lwe_input_indexes, bootstrapping_key, lwe_dimension, base_log, level_count, num_samples,
                         num_many_lut, lut_stride, b->ms_type);
-  a.acc_scratch = b->acc_scratch;
-  const uint32_t choice = g_fft_kernel_choice.load();
-  const bool wave_ok = pbs_fft_wave_supported(polynomial_size, glwe_dimension, level_count) && base_log <= 31;
-  const bool wave3_ok = pbs_fft_wave3_supported(polynomial_size, glwe_dimension, level_count);
-  const bool block_ok = pbs_fft_block_supported(polynomial_size, glwe_dimension, level_count);
-  if (choice == 2) HX_PANIC_IF_FALSE(wave_ok || wave3_ok, "throughput kernel requested for an unsupported parameter set");
-  if (choice == 3 || choice == 4) HX_PANIC_IF_FALSE(block_ok, "latency kernel requested for an unsupported parameter set");
-  // automatic choice: up to one LWE per CU the latency kernel finishes first; beyond, the throughput kernel
-  if (choice == 3 || choice == 4 || (choice == 0 && block_ok && num_samples <= kLatencyKernelMaxBatch)) {
-    // 3 / automatic: one polynomial per half workgroup (512 threads); 4: dual-stream variant (256 threads),
-    // measured slower (4.7 vs 4.2 ms), kept for comparison
-    launch_pbs_fft_block(S(stream), a, b->fft, choice == 4 ? 0 : 1);
-    g_last_pbs_kernel.store(choice == 4 ? 8 : 7);
-  } else if (wave_ok && (choice == 0 || choice == 2)) {
-    launch_pbs_fft_wave(S(stream), a, b->fft);
-    g_last_pbs_kernel.store(2);
-  } else if (wave3_ok && (choice == 0 || choice == 2)) {  // N = 1024: one wave per polynomial, 512-point transforms
-    launch_pbs_fft_wave3(S(stream), glwe_dimension, a, b->fft);
-    g_last_pbs_kernel.store(9);
-  } else {
-    launch_pbs_fft_generic(S(stream), polynomial_size, glwe_dimension, a, b->fft);
-    g_last_pbs_kernel.store(1);
-  }
+  b->emitted.valid = false;  // whatever a chained call left describes an array this call may overwrite
+  launch_classic_pbs(S(stream), a, b, glwe_dimension, polynomial_size);
 }
 
 // The shortint atomic pattern (tfhe/src/shortint/atomic_pattern/standard.rs:162-199; GPU: integer.cuh:869-990) in
@@ -363,6 +384,80 @@ void hip_keyswitch_programmable_bootstrap_64_async(void *stream, uint32_t gpu_in
                                        lut_vector_indexes, b->ks_out, b->trivial, bootstrapping_key,
                                        buffer, lwe_dimension, glwe_dimension, polynomial_size, base_log, level_count,
                                        num_samples, num_many_lut, lut_stride);
+}
+
+// The same KS -> PBS call for CHAINS of rounds in which a round's keyswitch reads exactly what the previous round's
+// bootstrap wrote (shortint apply-lookup-table chains): the sample extraction of the bootstrap is fused with the
+// digit pass of the NEXT keyswitch.
+//   HIP_KSPBS_EMIT_DIGITS        the bootstrap also writes, for every output ciphertext, the shifted keyswitch digits of
+//                                its mask (decomposition ks_base_log / ks_level of THIS call) as int8 A operands of the
+//                                keyswitch GEMM plus their per-sample sums, into the scratch;
+//   HIP_KSPBS_INPUT_FROM_PREVIOUS the caller states that lwe_array_in / lwe_input_indexes are the lwe_array_out /
+//                                lwe_output_indexes of the previous call on this scratch and that nothing wrote to them
+//                                since: the keyswitch then starts from the emitted operands (no digit pass).  The
+//                                library checks pointers, count and decomposition against what it recorded and falls
+//                                back to the digit pass when they differ or nothing was emitted.
+// Emission is done by the N = 2048, k = 1 throughput kernel (more than 256 LWEs), for keyswitch level counts padded to
+// 4 or 8 and base_log * level <= 30; otherwise the flags change nothing.  Same bits with and without the flags.
+void hip_keyswitch_programmable_bootstrap_chain_64_async(void *stream, uint32_t gpu_index, void *lwe_array_out,
+                                                         void const *lwe_output_indexes, void const *lut_vector,
+                                                         void const *lut_vector_indexes, void const *lwe_array_in,
+                                                         void const *lwe_input_indexes, void const *ksk,
+                                                         void const *bootstrapping_key, int8_t *buffer,
+                                                         uint32_t lwe_dimension, uint32_t glwe_dimension,
+                                                         uint32_t polynomial_size, uint32_t ks_base_log,
+                                                         uint32_t ks_level, uint32_t base_log, uint32_t level_count,
+                                                         uint32_t num_samples, uint32_t num_many_lut,
+                                                         uint32_t lut_stride, uint32_t flags) {
+  set_device(gpu_index);
+  PbsBuffer *b = checked_buffer(buffer, lwe_dimension, glwe_dimension, polynomial_size, level_count, num_samples);
+  HX_PANIC_IF_FALSE(b->ks_out != nullptr || num_samples == 0,
+                    "PBS buffer has no keyswitch scratch: create it with hip_scratch_keyswitch_programmable_bootstrap_64_async");
+  if (num_samples == 0) return;
+  const uint32_t n_big = glwe_dimension * polynomial_size;
+  uint32_t level_pad = 0, steps = 0;
+  const bool emittable = keyswitch_digits_emittable(n_big, ks_base_log, ks_level, &level_pad, &steps);
+  // ---- keyswitch: from the operands the previous bootstrap left, when they are what this call reads
+  KsDigits ready{b->emit_a, b->emit_suma, b->emitted.steps, b->emitted.base_log, b->emitted.level};
+  const bool use_ready = (flags & HIP_KSPBS_INPUT_FROM_PREVIOUS) && b->emitted.valid && b->emitted.array == lwe_array_in &&
+                         b->emitted.indexes == lwe_input_indexes && b->emitted.count == num_samples &&
+                         b->emitted.base_log == ks_base_log && b->emitted.level == ks_level && emittable;
+  launch_keyswitch(S(stream), b->ks_out, b->trivial, (const uint64_t *)lwe_array_in,
+                   (const uint64_t *)lwe_input_indexes, (const uint64_t *)ksk, n_big, lwe_dimension, ks_base_log,
+                   ks_level, num_samples, use_ready ? &ready : nullptr);
+  b->emitted.valid = false;  // the operands described the INPUT of this call; its output replaces them below or not
+  // ---- bootstrap, with the emission when the throughput kernel takes the launch
+  HX_PANIC_IF_FALSE(base_log >= 1 && base_log * level_count < 64, "invalid decomposition (base_log=%u, level=%u)",
+                    base_log, level_count);
+  HX_PANIC_IF_FALSE(num_many_lut >= 1, "num_many_lut must be >= 1");
+  PbsArgs a = make_args(lwe_array_out, lwe_output_indexes, lut_vector, lut_vector_indexes, b->ks_out, b->trivial,
+                        bootstrapping_key, lwe_dimension, base_log, level_count, num_samples, num_many_lut, lut_stride,
+                        b->ms_type);
+  if ((flags & HIP_KSPBS_EMIT_DIGITS) && emittable && num_many_lut == 1 && polynomial_size == 2048 && glwe_dimension == 1) {
+    const size_t a_bytes = (size_t)((b->max_samples + 31) / 32) * steps * 1024;
+    const size_t need = a_bytes + (size_t)((b->max_samples + 31) / 32) * 32 * sizeof(int32_t);
+    if (b->emit_bytes < need) {  // first use (or another decomposition): an allocation, not under stream capture
+      if (b->emit_a) HX_CHECK(hipFree(b->emit_a));
+      HX_CHECK(hipMalloc((void **)&b->emit_a, need));
+      b->emit_bytes = need;
+    }
+    b->emit_suma = (int32_t *)(b->emit_a + a_bytes);
+    a.emit_a = b->emit_a;
+    a.emit_suma = b->emit_suma;
+    a.emit_base_log = ks_base_log;
+    a.emit_level = ks_level;
+    a.emit_level_pad = level_pad;
+    a.emit_steps = steps;
+    b->emitted.valid = true;
+    b->emitted.array = lwe_array_out;
+    b->emitted.indexes = lwe_output_indexes;
+    b->emitted.count = num_samples;
+    b->emitted.steps = steps;
+    b->emitted.base_log = ks_base_log;
+    b->emitted.level = ks_level;
+  }
+  if (launch_classic_pbs(S(stream), a, b, glwe_dimension, polynomial_size) != 2)
+    b->emitted.valid = false;  // only the throughput kernel emits: a launch another kernel took left nothing usable
 }
 
 void hip_programmable_bootstrap_ntt64_async(void *stream, uint32_t gpu_index, void *lwe_array_out,
@@ -508,6 +603,7 @@ void cleanup_cuda_programmable_bootstrap_64(void *stream, uint32_t gpu_index, in
   HX_CHECK(hipStreamSynchronize(S(stream)));  // cleanup_* synchronises (pbs_utilities.h:261-271)
   if (b->acc_scratch) HX_CHECK(hipFree(b->acc_scratch));
   if (b->split_acc) HX_CHECK(hipFree(b->split_acc));
+  if (b->emit_a) HX_CHECK(hipFree(b->emit_a));
   if (b->ks_out) HX_CHECK(hipFree(b->ks_out));
   if (b->trivial) HX_CHECK(hipFree(b->trivial));
   b->magic = 0;
@@ -753,6 +849,7 @@ void hip_backend_set_keyswitch_kernel(uint32_t which) {
 void hip_backend_set_ntt_kernel(uint32_t which) { g_ntt_kernel_serial = (which == 1); }
 void hip_backend_set_multibit_latency_groups(uint32_t groups) { g_multibit_latency_groups.store(groups); }
 uint32_t hip_backend_last_pbs_kernel(void) { return g_last_pbs_kernel.load(); }
+uint32_t hip_backend_last_keyswitch_path(void) { return g_last_keyswitch_path.load(); }
 const char *hip_backend_version(void) {
 #if defined(TFHE_HIPEMU)
   return "tfhe-hip-backend 0.1 (HOST EMULATION - test build, not a product)";

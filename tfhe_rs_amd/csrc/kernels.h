@@ -40,9 +40,16 @@ void launch_mb_accumulate_block(hipStream_t st, const PbsArgs &a, const FftTable
                                 uint32_t gcount, uint32_t gpass, int first, int last);
 
 // keyswitch — keyswitch.hip
+// A operands of the large-batch keyswitch written ahead of it (by the bootstrap that produced its input)
+struct KsDigits {
+  const int8_t *aplanes;
+  const int32_t *suma;
+  uint32_t steps, base_log, level;
+};
+bool keyswitch_digits_emittable(uint32_t n_in, uint32_t base_log, uint32_t level, uint32_t *level_pad, uint32_t *steps);
 void launch_keyswitch(hipStream_t st, uint64_t *lwe_out, const uint64_t *out_idx, const uint64_t *lwe_in,
                       const uint64_t *in_idx, const uint64_t *ksk, uint32_t n_in, uint32_t n_out,
-                      uint32_t base_log, uint32_t level, uint32_t num_samples);
+                      uint32_t base_log, uint32_t level, uint32_t num_samples, const KsDigits *ready = nullptr);
 void launch_keyswitch_64_32(hipStream_t st, uint32_t *lwe_out, const uint64_t *out_idx, const uint64_t *lwe_in,
                             const uint64_t *in_idx, const uint32_t *ksk, uint32_t n_in, uint32_t n_out,
                             uint32_t base_log, uint32_t level, uint32_t num_samples);
@@ -52,6 +59,7 @@ void ksm_invalidate_range(int device, const void *p, size_t bytes);
 size_t ksm_cache_entries();
 extern std::atomic<bool> g_keyswitch_use_mfma;
 extern std::atomic<bool> g_keyswitch_split_digits;
+extern std::atomic<uint32_t> g_last_keyswitch_path;
 void ksd_release_stream(int device, hipStream_t st);  // the large-batch keyswitch's per-stream scratch
 extern bool g_ntt_kernel_serial;
 

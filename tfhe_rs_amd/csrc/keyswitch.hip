@@ -21,7 +21,8 @@ constexpr int KS_TB = 16;    // samples per workgroup
 constexpr int KS_IC = 32;    // mask elements decomposed per LDS stage
 constexpr int KS_MAXL = 8;   // max levels staged (level_count <= 8 for every shortint set)
 std::atomic<bool> g_keyswitch_use_mfma{true};
-std::atomic<bool> g_keyswitch_split_digits{true};  // hip_backend_set_keyswitch_kernel(2): one-launch matrix-core kernel at every batch size  // hip_backend_set_keyswitch_kernel: matrix-core path when its conditions hold
+std::atomic<bool> g_keyswitch_split_digits{true};
+std::atomic<uint32_t> g_last_keyswitch_path{0};  // tests: 0 scalar kernels, 1 one-launch matrix-core kernel, 2 digit pass + GEMM, 3 GEMM on emitted digits  // hip_backend_set_keyswitch_kernel(2): one-launch matrix-core kernel at every batch size  // hip_backend_set_keyswitch_kernel: matrix-core path when its conditions hold
 
 // DigitT: int32_t when base_log <= 31 (every shortint set), int64_t for wider bases
 template <typename DigitT>
@@ -739,7 +740,7 @@ size_t ksm_cache_entries() {
 template <typename OutT>
 static bool keyswitch_mfma(hipStream_t st, OutT *lwe_out, const uint64_t *out_idx, const uint64_t *lwe_in,
                            const uint64_t *in_idx, const OutT *ksk, uint32_t n_in, uint32_t n_out,
-                           uint32_t base_log, uint32_t level, uint32_t num_samples) {
+                           uint32_t base_log, uint32_t level, uint32_t num_samples, const KsDigits *ready = nullptr) {
   uint32_t level_pad = 1;  // levels per mask word in the K dimension: the next power of two
   while (level_pad < level) level_pad <<= 1;
   const uint32_t K = n_in * level_pad;
@@ -810,6 +811,17 @@ static bool keyswitch_mfma(hipStream_t st, OutT *lwe_out, const uint64_t *out_id
     colsum = (uint64_t *)((char *)hit->planes + hit->plane_bytes);
   }
   for (const KsmEntry &e : evicted) ksm_release(e);
+  if (ready != nullptr && num_samples >= KSD_MIN_SAMPLES && g_keyswitch_split_digits.load()) {
+    // the A operands were written by the bootstrap that produced lwe_in (PbsArgs::emit_a): the GEMM alone
+    HX_PANIC_IF_FALSE(ready->steps == K / 32 && ready->base_log == base_log && ready->level == level,
+                      "keyswitch: the digits at hand were made for another decomposition");
+    const uint32_t tiles = (num_samples + 31) / 32;
+    HX_LAUNCH((ks_gemm_kernel<OutT>), dim3(col_tiles, (tiles + 3) / 4), dim3(256), 0, st, lwe_out, out_idx, lwe_in,
+              in_idx, planes, colsum, ready->aplanes, ready->suma, n_in, n_out, base_log, num_samples, col_tiles, K / 32,
+              ksk, ksk_words);
+    g_last_keyswitch_path.store(3);
+    return true;
+  }
   if (num_samples >= KSD_MIN_SAMPLES && g_keyswitch_split_digits.load()) {
     // large batch: the digits once (A operands in the stream's scratch), then the LDS-staged GEMM
     const uint32_t tiles = (num_samples + 31) / 32, steps = K / 32;
@@ -837,6 +849,7 @@ static bool keyswitch_mfma(hipStream_t st, OutT *lwe_out, const uint64_t *out_id
 #undef KSD_LAUNCH
       HX_LAUNCH((ks_gemm_kernel<OutT>), dim3(col_tiles, (tiles + 3) / 4), dim3(256), 0, st, lwe_out, out_idx, lwe_in,
                 in_idx, planes, colsum, scr, suma, n_in, n_out, base_log, num_samples, col_tiles, steps, ksk, ksk_words);
+      g_last_keyswitch_path.store(2);
       return true;
     }
   }
@@ -866,18 +879,34 @@ static bool keyswitch_mfma(hipStream_t st, OutT *lwe_out, const uint64_t *out_id
     default: KSM_LAUNCH(16); break;
   }
 #undef KSM_LAUNCH
+  g_last_keyswitch_path.store(1);
   return true;
+}
+
+// what a bootstrap can emit for the keyswitch that follows it (PbsArgs::emit_a): level_pad 4 or 8, 32-bit decomposition,
+// and the shape the matrix-core path accepts
+bool keyswitch_digits_emittable(uint32_t n_in, uint32_t base_log, uint32_t level, uint32_t *level_pad, uint32_t *steps) {
+  uint32_t lp = 1;
+  while (lp < level) lp <<= 1;
+  const uint32_t K = n_in * lp;
+  uint32_t log_k = 0;
+  while (((uint64_t)1 << log_k) < K) ++log_k;
+  if ((lp != 4 && lp != 8) || K % 32 != 0 || base_log > 6 || base_log + 7 + log_k > 31 || base_log * level > 30) return false;
+  *level_pad = lp;
+  *steps = K / 32;
+  return g_keyswitch_use_mfma.load() && g_keyswitch_split_digits.load();
 }
 
 void launch_keyswitch(hipStream_t st, uint64_t *lwe_out, const uint64_t *out_idx, const uint64_t *lwe_in,
                       const uint64_t *in_idx, const uint64_t *ksk, uint32_t n_in, uint32_t n_out,
-                      uint32_t base_log, uint32_t level, uint32_t num_samples) {
+                      uint32_t base_log, uint32_t level, uint32_t num_samples, const KsDigits *ready) {
   HX_PANIC_IF_FALSE(base_log >= 1 && level >= 1 && base_log * level < 64,
                     "keyswitch: unsupported decomposition (base_log=%u, level=%u)", base_log, level);
   if (num_samples == 0) return;
   if (g_keyswitch_use_mfma.load() &&
-      keyswitch_mfma(st, lwe_out, out_idx, lwe_in, in_idx, ksk, n_in, n_out, base_log, level, num_samples))
+      keyswitch_mfma(st, lwe_out, out_idx, lwe_in, in_idx, ksk, n_in, n_out, base_log, level, num_samples, ready))
     return;
+  g_last_keyswitch_path.store(0);
   // the scalar kernels stage at most KS_MAXL levels per mask element (the matrix-core path above takes up to 16)
   HX_PANIC_IF_FALSE(level <= KS_MAXL, "keyswitch: level_count %u > %d is only supported by the matrix-core kernel (base_log <= 6)",
                     level, KS_MAXL);

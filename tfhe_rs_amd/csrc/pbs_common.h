@@ -35,6 +35,14 @@ struct PbsArgs {
   // the workgroups of an XCD stay within a few groups of each other so that a group's key is fetched from HBM
   // once per XCD instead of once per workgroup
   uint32_t *pace = nullptr;
+  // Throughput kernel for N = 2048, k = 1 only (null otherwise): the sample extraction ALSO writes the keyswitch
+  // operands of its output — for every mask word the shifted digits d + B/2 of the keyswitch that will read this
+  // ciphertext next, as bytes in the A-operand layout of ks_gemm_kernel ([tile of 32 samples][step of 32 k][lane =
+  // (k half, row)][16 bytes], row = this launch's sample index), and per sample the sum of those bytes — so that the
+  // next keyswitch skips its digit pass (keyswitch.hip).  emit_level_pad = 4 or 8, emit_base_log * emit_level <= 30.
+  int8_t *emit_a = nullptr;
+  int32_t *emit_suma = nullptr;
+  uint32_t emit_base_log = 0, emit_level = 0, emit_level_pad = 0, emit_steps = 0;
   // host side only (kernel selection of THIS call; comparison choices of hip_backend_set_fft_kernel): carried in the
   // arguments, not in globals, so that concurrent host threads on different streams cannot change each other's kernel
   bool mb_no_share = false;          // choice 7: every wave pair loads its own key

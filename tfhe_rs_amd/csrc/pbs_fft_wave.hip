@@ -1432,6 +1432,46 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
   for (uint32_t t = 0; t < a.num_many_lut; ++t) {
     const uint32_t nth = t * a.lut_stride;
     uint64_t *out = a.lwe_out + (size_t)t * a.num_samples * out_sz + (size_t)a.out_idx[sample] * out_sz;
+    if constexpr (!MULTIBIT && LIMBS == 0) {
+      if (t == 0 && a.emit_a != nullptr && w == 0) {
+        // the next keyswitch's operands for this ciphertext (PbsArgs::emit_a): word idx of the output mask -> k =
+        // idx * level_pad + lv, byte k % 16 of lane (k half, row) of step k / 32; padded levels hold the shifted zero
+        const uint32_t bl = a.emit_base_log, lv_n = a.emit_level, lp = a.emit_level_pad, half_b = 1u << (bl - 1);
+        int8_t *dst = a.emit_a + ((size_t)(sample >> 5) * a.emit_steps) * 1024 + (size_t)(sample & 31) * 16;
+        int32_t my_sa = 0;
+        HX_UNROLL
+        for (int r = 0; r < 16; ++r) {
+          HX_UNROLL
+          for (int half = 0; half < 2; ++half) {
+            const uint32_t c = (uint32_t)(half * 1024 + r * 64 + lane);
+            const uint64_t reg = half ? acc_im[r] : acc_re[r];
+            const uint64_t v = ((c == 0) != NEGACC) ? reg : (uint64_t)0 - reg;  // out[idx], idx = c ? N - c : 0 (nth = 0)
+            const uint32_t idx = c == 0 ? 0u : (uint32_t)N - c;
+            int32_t state = decomp_init_state32((uint32_t)(v >> 32), bl, lv_n);
+            uint32_t pk[2] = {0u, 0u};
+            for (uint32_t lv = 0; lv < lp; ++lv) {
+              const int32_t d = (lv < lv_n ? decompose_one_level32(bl, state) : 0) + (int32_t)half_b;
+              my_sa += d;
+              pk[lv >> 2] |= (uint32_t)d << (8 * (lv & 3));
+            }
+            const uint32_t k = idx * lp;
+            uint32_t *o = (uint32_t *)(dst + (size_t)(k >> 5) * 1024 + ((k >> 4) & 1) * 512 + (k & 15));
+            o[0] = pk[0];
+            if (lp == 8) o[1] = pk[1];
+          }
+        }
+        // sum over the wave (my buffer is free: the last inverse transform is over)
+        int32_t *red = (int32_t *)buf;
+        HX_WAVE_SYNC();
+        red[lane] = my_sa;
+        HX_WAVE_SYNC();
+        if (lane == 0) {
+          int32_t tot = 0;
+          for (int l = 0; l < 64; ++l) tot += red[l];
+          a.emit_suma[sample] = tot;
+        }
+      }
+    }
     if constexpr (LIMBS > 0) {
       // the accumulator is rotated by -b_hat first: coefficient c moves to t = (c - b_hat) mod 2N, i.e. to j = t mod N
       // with its sign flipped when t >= N; then the extraction below on index j

@@ -66,6 +66,9 @@ SIGNATURES = {
     "cleanup_cuda_programmable_bootstrap_64": (None, [_v, _u32, _i8pp]),
     "hip_scratch_keyswitch_programmable_bootstrap_64_async":
         (_u64, [_v, _u32, _i8pp, _u32, _u32, _u32, _u32, _u32, _b, _u32]),
+    "hip_keyswitch_programmable_bootstrap_chain_64_async":
+        (None, [_v, _u32, _v, _v, _v, _v, _v, _v, _v, _v, _v, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _u32,
+                _u32, _u32]),
     "hip_keyswitch_programmable_bootstrap_64_async":
         (None, [_v, _u32, _v, _v, _v, _v, _v, _v, _v, _v, _v, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _u32,
                 _u32]),
@@ -118,6 +121,7 @@ SIGNATURES = {
     "hip_test_fft_tables_host": (None, [_u32, _v, _v, _v]),
     "hip_test_monomial_table_host": (None, [_u32, _v]),
     "hip_backend_set_keyswitch_kernel": (None, [_u32]),
+    "hip_backend_last_keyswitch_path": (_u32, []),
     "hip_integer_set_multi_gpu_threshold": (None, [_u32]),
     "hip_backend_set_ntt_kernel": (None, [_u32]),
     "hip_backend_set_multibit_latency_groups": (None, [_u32]),

@@ -127,12 +127,45 @@ def ks32_case(p, B, steps=5):
     lib.hip_backend_set_keyswitch_kernel(0)
 
 
+def chain_case(p, B, rounds=6):
+    """KS -> PBS rounds in which every round reads what the previous one wrote (hip_keyswitch_programmable_bootstrap_chain):
+    plain (digit pass in every keyswitch) against the fused form (the bootstrap's sample extraction emits the next
+    keyswitch's operands)."""
+    k1 = p.k + 1
+    bsk = gpu.CudaLweBootstrapKey.from_lwe_bootstrap_key(rand_u64(p.n * p.pbs_level * k1 * k1 * p.N), p.n, p.k, p.N,
+                                                         p.pbs_base_log, p.pbs_level, streams, ms_noise_reduction=bool(p.ms_type))
+    ksk = gpu.CudaLweKeyswitchKey.from_lwe_keyswitch_key(rand_u64(p.big_n * p.ks_level * (p.n + 1)), p.big_n, p.n,
+                                                         p.ks_base_log, p.ks_level, streams)
+    d_a = gpu.CudaLweCiphertextList.from_lwe_ciphertext_list(rand_u64(B * (p.big_n + 1)).reshape(B, -1), streams)
+    d_b = gpu.CudaLweCiphertextList.new(p.big_n, B, streams)
+    d_lut = gpu.CudaGlweCiphertextList.from_glwe_ciphertext_list(rand_u64(k1 * p.N), p.k, p.N, streams)
+    idx = gpu.CudaVec.from_cpu_async(np.arange(B, dtype=np.uint64), streams)
+    lidx = gpu.CudaVec.from_cpu_async(np.zeros(B, dtype=np.uint64), streams)
+    buf = C.c_void_p()
+    lib.hip_scratch_keyswitch_programmable_bootstrap_64_async(S, G, C.byref(buf), p.n, p.k, p.N, p.pbs_level, B, True, p.ms_type)
+    for name, first, later in (("plain", 0, 0), ("sample extraction emits the next keyswitch's digits", 1, 3)):
+        def run():
+            src, dst = d_a, d_b
+            for r in range(rounds):
+                lib.hip_keyswitch_programmable_bootstrap_chain_64_async(
+                    S, G, dst.d_vec.ptr, idx.ptr, d_lut.d_vec.ptr, lidx.ptr, src.d_vec.ptr, idx.ptr, ksk.d_vec.ptr,
+                    bsk.d_vec.ptr, buf, p.n, p.k, p.N, p.ks_base_log, p.ks_level, p.pbs_base_log, p.pbs_level, B, 1, 0,
+                    first if r == 0 else later)
+                src, dst = dst, src
+        ms = timed(run, steps=2) / rounds
+        emit(what="KS -> PBS round in a chain", form=name, params=p.name, batch=B, ms_per_round=ms,
+             ks_pbs_per_s=B / ms * 1e3, last_keyswitch_path=int(lib.hip_backend_last_keyswitch_path()))
+    lib.cleanup_cuda_programmable_bootstrap_64(S, G, C.byref(buf))
+
+
 if __name__ == "__main__":
     if os.environ.get("TFHE_KS_CHOICE"):
         lib.hip_backend_set_keyswitch_kernel(int(os.environ["TFHE_KS_CHOICE"]))
     which = sys.argv[1:] or ["ks", "wave", "generic", "ntt", "mb", "n1024", "sweep"]
     if "ks" in which:
         ks_ms = ks_case(C1, 4096)
+    if "chain" in which:
+        chain_case(C1, 4096)
     if "ks32" in which:
         ks32_case(C1, 4096)
         ks32_case(C1P, 4096)
