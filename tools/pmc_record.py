@@ -55,7 +55,9 @@ def provenance():
         names = [l.split(":", 1)[1].strip() for l in r.splitlines() if "Marketing Name" in l]
         gfx = [l.split(":", 1)[1].strip() for l in r.splitlines() if l.strip().startswith("Name:") and "gfx" in l]
         info["isa"] = sorted(set(gfx))
-        info["gpus"] = [n for n in names if "Instinct" in n or "MI3" in n] or [n for n in names if n][-1:] or info["isa"]
+        cpu = ("EPYC", "Xeon", "Processor", "Ryzen", "Core(TM)")
+        info["gpus"] = ([n for n in names if "Instinct" in n or "MI3" in n] or
+                        [n for n in names if n and not any(c in n for c in cpu)][-1:] or [g for g in info["isa"] if g.startswith("gfx")])
     except Exception as e:  # noqa: BLE001
         info["rocminfo"] = f"unavailable ({e.__class__.__name__})"
     try:
