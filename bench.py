@@ -336,7 +336,16 @@ def main():
                     "(`traffic` then comes from the committed build-stamped record)")
     ap.add_argument("--no-verify", action="store_true", help="skip the decrypt check (timing-ablation builds only)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="PBS count of the CPU baseline sample (0 = auto)")
+    ap.add_argument("--fheuint64-worker", default=None, help=argparse.SUPPRESS)  # child process of the N > 1 config-5 datapoints
     args = ap.parse_args()
+    if args.fheuint64_worker:
+        import tfhe_rs_amd  # noqa: F401
+        from tfhe_rs_amd import ffi
+        from tests.common import C1, make_keys
+        w = json.loads(args.fheuint64_worker)
+        print(json.dumps(fheuint64_datapoint(ffi.default_library(), C1, make_keys(C1, with_ksk=False), w["devices"],
+                                             {"add": 1024, "mul": 128}, in_library=bool(w["in_library"]))))
+        return
 
     # Two ways to N GPUs.  (1) Launched by torch.distributed.run (WORLD_SIZE set): one process per GPU, barrier and
     # max-over-ranks through torch.distributed (RCCL).  (2) Plain `python bench.py --gpus N`: this process drives
@@ -637,10 +646,17 @@ def main():
         # every round GPU-local, and (b) inside the library, one CudaStreamsFFI naming the N GPUs: the
         # ciphertexts live on the first GPU and every KS -> PBS round is split over the GPUs with peer copies
         # (helper_multi_gpu.cuh:170-294).
-        result.setdefault("extra", {})["fheuint64"] = fheuint64_datapoint(lib, p, keys, devices, {"add": 1024, "mul": 128},
-                                                                          in_library=False)
-        result["extra"]["fheuint64_in_library_sharding"] = fheuint64_datapoint(lib, p, keys, devices,
-                                                                               {"add": 1024, "mul": 128}, in_library=True)
+        # Each in its own process: the peer copies of (b) have only ever run between streams of ONE device (the test
+        # boxes have one GPU) — a failure there must not cost the line its headline.
+        import subprocess
+        for key, in_lib in (("fheuint64", False), ("fheuint64_in_library_sharding", True)):
+            try:
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--fheuint64-worker",
+                                    json.dumps({"devices": devices, "in_library": in_lib})], capture_output=True, text=True,
+                                   timeout=900)
+                result.setdefault("extra", {})[key] = json.loads(r.stdout.strip().splitlines()[-1])
+            except Exception as e:  # noqa: BLE001
+                result.setdefault("extra", {})[key] = {"error": f"{e.__class__.__name__}: {e}"[:400]}
     if single and not args.no_cpu_baseline:
         # CPU leg: the oracle's f64 path on the host cores actually available to this process
         # (affinity mask and cgroup quota, not the machine's nominal thread count), on a sample
