@@ -47,7 +47,7 @@ def bytes_per_pbs(p):
 _PMC_NOW = {}   # counter record measured by THIS run (measure_traffic_now), else the committed one
 
 
-def measure_traffic_now(targets, budget_s=420):
+def measure_traffic_now(targets, budget_s=240):
     """HBM traffic of one launch of each throughput kernel, measured DURING this bench run: tools/pmc_record.py runs
     `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes, counters only) over one batch-4096 launch
     per kernel in child processes.  Skipped — the committed, build-stamped record is used instead — when rocprofv3 is
@@ -66,7 +66,7 @@ def measure_traffic_now(targets, budget_s=420):
         pass
     try:
         subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_record.py"), *targets, "--hbm-only", "--tag",
-                        "benchrun", "--out", out, "--timeout", "150"], capture_output=True, text=True, timeout=budget_s)
+                        "benchrun", "--out", out, "--timeout", "60"], capture_output=True, text=True, timeout=budget_s)
         _PMC_NOW.update(json.load(open(out)))
         return None
     except Exception as e:  # noqa: BLE001

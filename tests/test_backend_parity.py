@@ -398,7 +398,7 @@ def test_chained_ks_pbs_rounds_with_digits_emitted_by_the_bootstrap(kind):
         plain = chain([0, 0, 0])
         fused = chain([EMIT, EMIT | FROM_PREV, FROM_PREV])
         assert lib.hip_backend_last_keyswitch_path() == 3        # the last round's keyswitch ran on emitted digits
-        lied = chain([EMIT, FROM_PREV | EMIT, FROM_PREV])[1:]   # same as fused; then a foreign input under the flag:
+        # a foreign input under the flag:
         d_x = gpu.CudaLweCiphertextList.from_lwe_ciphertext_list(cts, st)
         d_y = gpu.CudaLweCiphertextList.new(p.k * p.N, B, st)
         lib.hip_keyswitch_programmable_bootstrap_chain_64_async(
@@ -411,7 +411,6 @@ def test_chained_ks_pbs_rounds_with_digits_emitted_by_the_bootstrap(kind):
         lib.cleanup_cuda_programmable_bootstrap_64(s, g, C.byref(buf))
     for r in range(3):
         assert np.array_equal(fused[r], plain[r]), r
-    assert np.array_equal(lied[0], plain[1]) and np.array_equal(lied[1], plain[2])
     assert np.array_equal(foreign, plain[0])
     # round 0 against the oracle: keyswitch then bootstrap of sample i written to block perm[i]
     ks = orc.keyswitch_batch(cts, c.keys.ksk, p.k * p.N, p.n, p.ks_base_log, p.ks_level)
