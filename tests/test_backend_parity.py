@@ -355,7 +355,7 @@ def test_keyswitch_large_batch_digit_pass_and_staged_gemm(kind, p):
 
 @pytest.mark.parametrize("kind", BACKENDS)
 def test_chained_ks_pbs_rounds_with_digits_emitted_by_the_bootstrap(kind):
-    """hip_keyswitch_programmable_bootstrap_chain_64_async: three KS -> PBS rounds in which every round reads what the
+    """hip_keyswitch_programmable_bootstrap_chain_64_async: three (host emulation: two) KS -> PBS rounds in which every round reads what the
     previous one wrote.  With HIP_KSPBS_EMIT_DIGITS the sample extraction of a round's bootstrap also writes the int8
     operands of the next round's keyswitch GEMM (no digit pass there); with HIP_KSPBS_INPUT_FROM_PREVIOUS the next round
     takes them.  131 LWEs (ragged tiles) through the throughput kernel, PERMUTED output indexes (round r + 1 reads
@@ -395,8 +395,8 @@ def test_chained_ks_pbs_rounds_with_digits_emitted_by_the_bootstrap(kind):
 
     try:
         lib.hip_backend_set_fft_kernel(2)   # the throughput kernel also below 257 LWEs
-        plain = chain([0, 0, 0])
-        fused = chain([EMIT, EMIT | FROM_PREV, FROM_PREV])
+        plain = chain([0, 0] if kind == "emu" else [0, 0, 0])
+        fused = chain([EMIT, FROM_PREV] if kind == "emu" else [EMIT, EMIT | FROM_PREV, FROM_PREV])
         assert lib.hip_backend_last_keyswitch_path() == 3        # the last round's keyswitch ran on emitted digits
         # a foreign input under the flag:
         d_x = gpu.CudaLweCiphertextList.from_lwe_ciphertext_list(cts, st)
@@ -409,7 +409,7 @@ def test_chained_ks_pbs_rounds_with_digits_emitted_by_the_bootstrap(kind):
     finally:
         lib.hip_backend_set_fft_kernel(0)
         lib.cleanup_cuda_programmable_bootstrap_64(s, g, C.byref(buf))
-    for r in range(3):
+    for r in range(len(plain)):
         assert np.array_equal(fused[r], plain[r]), r
     assert np.array_equal(foreign, plain[0])
     # round 0 against the oracle: keyswitch then bootstrap of sample i written to block perm[i]
