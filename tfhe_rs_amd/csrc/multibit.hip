@@ -158,6 +158,84 @@ __global__ void __launch_bounds__(GenericCfg<N>::TPB)
   }
 }
 
+// N = 2048, k = 1 (the key is stored in the throughput kernel's slot order, bsk_slot): the form above walks POSITIONS,
+// so its key loads are 16 bytes at a stride of 1 KB, and it gathers one monomial base per (position, subset,
+// ciphertext) — 480 dependent table loads per thread at S = 8: 0.26 ms for a round of 7-14 radix blocks, 1.1 ms for 32.
+// Here a thread walks the SLOTS tid, tid + 256, ...: the key loads of a wave are contiguous, and its four slots are the
+// positions hi*16 + lo0 + 4q of ONE hi = tid % 64 — one gathered base per (subset, ciphertext) serves all four, the
+// 16th roots come from a 16-entry LDS table (M_d[p] = base(hi, d) * w16[(bitrev4(lo) d) mod 16], pbs_common.h).  The
+// keybundles are parked in position order as before (the accumulate kernel reads 64 contiguous bytes per thread):
+// each ciphertext's polynomial goes through a padded LDS buffer to turn slot order into position order.  Same factors,
+// same multiply-add order per position: identical bits.
+template <int S>
+__global__ void __launch_bounds__(256)
+    mb_keybundle_2048_kernel(PbsArgs a, uint32_t grouping, cplx *kb_lat, FftTables tb, uint32_t g0, uint32_t gcount) {
+  constexpr int N = 2048, n = N / 2, TPB = 256, LOG2N2 = 12;
+  __shared__ uint32_t sdeg[S][16];
+  __shared__ cplx sw16[16];
+  __shared__ cplx xbuf[n + n / 16];
+  const int tid = threadIdx.x;
+  const uint32_t s0 = blockIdx.y * S;
+  const uint32_t count = a.num_samples - s0 < (uint32_t)S ? a.num_samples - s0 : (uint32_t)S;
+  const size_t kb_polys = (size_t)a.level * 4;
+  const uint32_t gl = blockIdx.x / (uint32_t)kb_polys, poly = blockIdx.x % (uint32_t)kb_polys, grp = g0 + gl;
+  const uint32_t per = 1u << grouping;
+  const size_t ggsw_c = kb_polys * n;
+  const cplx *gk = (const cplx *)a.bsk + (size_t)grp * per * ggsw_c + (size_t)poly * n + tid;
+  if (tid < S) {  // the subset degrees of ciphertext s0 + tid
+    uint32_t deg[16];
+    for (int q = 0; q < 16; ++q) deg[q] = 0;
+    if ((uint32_t)tid < count) {
+      const uint64_t *lwe = a.lwe_in + (size_t)a.in_idx[s0 + tid] * (a.n + 1);
+      multi_bit_degrees(lwe + (size_t)grp * grouping, grouping, LOG2N2, deg);
+    }
+    for (int q = 0; q < 16; ++q) sdeg[tid][q] = deg[q];
+  }
+  if (tid >= 64 && tid < 80) {
+    const int t = tid - 64;
+    sw16[t] = cplx{tb.mono[2 * (N / 8) * t], tb.mono[2 * (N / 8) * t + 1]};
+  }
+  __syncthreads();
+  const uint32_t hi = (uint32_t)tid & 63u, lo0 = (uint32_t)tid >> 6;
+  uint32_t br[4];  // bitrev4 of my four lo values
+  HX_UNROLL
+  for (int q = 0; q < 4; ++q) br[q] = __brev(lo0 + 4u * q) >> 28;
+  cplx kb[4][S];
+  HX_UNROLL
+  for (int q = 0; q < 4; ++q) {
+    const cplx k0 = gk[q * TPB];  // subset 0: not rotated
+    HX_UNROLL
+    for (int j = 0; j < S; ++j) kb[q][j] = k0;
+  }
+  for (uint32_t sb = 1; sb < per; ++sb) {
+    cplx ks[4];
+    HX_UNROLL
+    for (int q = 0; q < 4; ++q) ks[q] = gk[(size_t)sb * ggsw_c + q * TPB];
+    HX_UNROLL
+    for (int j = 0; j < S; ++j) {
+      const uint32_t deg = sdeg[j][sb];
+      const uint32_t jb = monomial_base_index<N>(hi, deg);
+      const cplx base{tb.mono[2 * jb], tb.mono[2 * jb + 1]};
+      HX_UNROLL
+      for (int q = 0; q < 4; ++q) kb[q][j] = cmul_add(ks[q], cmul_first(base, sw16[(br[q] * deg) & 15u]), kb[q][j]);
+    }
+  }
+  // slot order -> position order through LDS, one ciphertext at a time
+  const FBuf xb{xbuf};
+  HX_UNROLL
+  for (int j = 0; j < S; ++j) {
+    HX_UNROLL
+    for (int q = 0; q < 4; ++q) xb[(int)(hi * 16u + lo0 + 4u * q)] = kb[q][j];
+    __syncthreads();
+    if ((uint32_t)j < count) {
+      cplx *dst = kb_lat + (((size_t)(s0 + j) * gcount + gl) * kb_polys + poly) * n;
+      HX_UNROLL
+      for (int q = 0; q < 4; ++q) dst[tid + q * TPB] = xb[tid + q * TPB];
+    }
+    __syncthreads();
+  }
+}
+
 template <int N, int K1>
 __global__ void __launch_bounds__(GenericCfg<N>::TPB)
     mb_accumulate_kernel(PbsArgs a, const cplx *kb_lat, FftTables tb, uint64_t *acc_g, uint32_t gcount, uint32_t gpass,
@@ -318,7 +396,13 @@ static void launch_mb_latency(hipStream_t st, const MultiBitArgs &m, const FftTa
     hx_set_dynamic_smem_once<mb_accumulate_kernel<N, K1>>(smem_b);
   for (uint32_t g0 = 0; g0 < groups; g0 += group_chunk) {
     const uint32_t gpass = groups - g0 < group_chunk ? groups - g0 : group_chunk;
-    if (a.num_samples < 4)
+    if (N == 2048 && K1 == 2 && a.num_samples < 4)
+      HX_LAUNCH((mb_keybundle_2048_kernel<1>), dim3(gpass * kb_polys, a.num_samples), dim3(256), 0, st, a,
+                m.grouping_factor, kb_lat, tb, g0, group_chunk);
+    else if (N == 2048 && K1 == 2)
+      HX_LAUNCH((mb_keybundle_2048_kernel<MB_KB_TILE>), dim3(gpass * kb_polys, (a.num_samples + MB_KB_TILE - 1) / MB_KB_TILE),
+                dim3(256), 0, st, a, m.grouping_factor, kb_lat, tb, g0, group_chunk);
+    else if (a.num_samples < 4)
       HX_LAUNCH((mb_keybundle_kernel<N, K1, 1>), dim3(gpass * kb_polys, a.num_samples), dim3(GenericCfg<N>::TPB),
                 16 * sizeof(uint32_t), st, a, m.grouping_factor, kb_lat, tb, g0, group_chunk);
     else
