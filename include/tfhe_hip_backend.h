@@ -420,7 +420,7 @@ uint64_t hip_integer_propagate_pbs_count(uint32_t num_blocks);
  * variant; 2..4 abort on unsupported parameter sets.  For the multi-bit entry point 2 selects the
  * multi-bit mode of the throughput kernel, 1 the generic multi-bit kernel, 5 the two-launch latency path (all
  * keybundles first, one workgroup per polynomial; then the products, for N=2048,k=1 on the latency kernel) that 0
- * takes up to 128 LWEs, 6 the same path with the products on the generic kernels (comparison), 7 the throughput
+ * takes up to 128 LWEs (256 for N = 2048, k = 1), 6 the same path with the products on the generic kernels (comparison), 7 the throughput
  * kernel without the sharing of key loads between the two LWEs of a quad of waves (comparison). */
 void hip_backend_set_fft_kernel(uint32_t which);
 /* test hook: cap of the groups the multi-bit latency path processes per pass (0 = what the scratch holds) */

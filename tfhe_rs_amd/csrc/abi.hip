@@ -68,6 +68,9 @@ void check_pow2_poly(uint32_t N, uint32_t max_n = 4096) {
 
 constexpr uint64_t kMultiBitLatencyBytes = 256ull << 20;  // keybundle scratch of the multi-bit latency path
 constexpr uint32_t kMultiBitLatencyMaxBatch = 128;  // multi-bit PBS: two-launch latency path up to this many LWEs
+// N = 2048, k = 1 (slot-walking keybundle kernel + latency kernel): measured against the throughput kernel
+// (tools/measure_all.py mbcross), g = 4: 256 LWEs 4.35 vs 6.24 ms, 384: 6.76 vs 5.92; g = 3: 7.43 vs 8.52, 11.98 vs 9.89
+constexpr uint32_t kMultiBitLatencyMaxBatch2048 = 256;
 std::atomic<uint32_t> g_multibit_latency_groups{0};  // test hook: cap of the groups per pass (0 = what the scratch holds)
 constexpr uint32_t kLatencyKernelMaxBatch = 256;  // measured (tools/measure_all.py latency): 3.7-3.9 ms vs 5.9 ms up to 256 LWEs, slower beyond
 
@@ -667,7 +670,8 @@ uint64_t scratch_cuda_multi_bit_programmable_bootstrap_64_async(void *stream, ui
   // latency path: up to kMultiBitLatencyMaxBatch ciphertexts; the keybundles of as many groups per pass as
   // kMultiBitLatencyBytes hold (the scratch is sized without knowing n or the grouping factor, like the
   // reference's lwe_chunk_size); allocated here, never inside the launch
-  b->lat_samples = b->chunk < kMultiBitLatencyMaxBatch ? b->chunk : kMultiBitLatencyMaxBatch;
+  const uint32_t lat_cap = (polynomial_size == 2048 && glwe_dimension == 1) ? kMultiBitLatencyMaxBatch2048 : kMultiBitLatencyMaxBatch;
+  b->lat_samples = b->chunk < lat_cap ? b->chunk : lat_cap;
   if (polynomial_size > 4096) b->lat_samples = 0;  // rings of 2^13, 2^14: the one-launch kernel only
   b->kb_per_sample = kb_per_sample;
   uint64_t slots = kMultiBitLatencyBytes / kb_per_sample;  // (ciphertext, group) keybundles held at once

@@ -172,6 +172,11 @@ if __name__ == "__main__":
     if "mb4" in which:  # the reference's GPU default set (grouping factor 4, one level)
         pbs_case(C4G4, 4096, steps=2)
         pbs_case(C4G4, 1, steps=3)
+    if "mbcross" in which:  # where the multi-bit latency path (5) and the throughput kernel (2) cross
+        for p in (C4G4, C4):
+            for B in (128, 192, 256, 384, 512):
+                for kern in (5, 2):
+                    pbs_case(p, B, kernel=kern, steps=3)
     if "mblat" in which:  # multi-bit latency path: products on the latency kernel (5) or the generic kernels (6)
         for p in (C4G4, C4):
             for kern in (5, 6):
