@@ -440,6 +440,9 @@ uint32_t hip_backend_last_pbs_kernel(void);
 /* last 64-bit keyswitch, for tests: 0 scalar kernels, 1 one-launch matrix-core kernel, 2 digit pass + staged GEMM,
  * 3 staged GEMM on the digits the previous bootstrap emitted */
 uint32_t hip_backend_last_keyswitch_path(void);
+/* small-batch keyswitch (<= 32 LWEs): workgroups per column tile that share the K dimension (default 8; 1 = one
+ * workgroup per column tile, no atomics).  Identical bits. */
+void hip_backend_set_keyswitch_kparts(uint32_t parts);
 const char *hip_backend_version(void);
 
 /* HIP events recorded on a backend stream (used by bench.py to time launches) */

@@ -60,6 +60,7 @@ static inline unsigned long long atomicAdd(unsigned long long *p, unsigned long 
   return __atomic_fetch_add(p, v, __ATOMIC_RELAXED);
 }
 static inline int atomicAdd(int *p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+static inline unsigned int atomicAdd(unsigned int *p, unsigned int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 static inline void __threadfence_block() {}
 static inline void __threadfence() {}
 

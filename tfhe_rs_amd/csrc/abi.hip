@@ -854,6 +854,7 @@ void hip_backend_set_ntt_kernel(uint32_t which) { g_ntt_kernel_serial = (which =
 void hip_backend_set_multibit_latency_groups(uint32_t groups) { g_multibit_latency_groups.store(groups); }
 uint32_t hip_backend_last_pbs_kernel(void) { return g_last_pbs_kernel.load(); }
 uint32_t hip_backend_last_keyswitch_path(void) { return g_last_keyswitch_path.load(); }
+void hip_backend_set_keyswitch_kparts(uint32_t parts) { g_keyswitch_kparts.store(parts ? parts : 1); }
 const char *hip_backend_version(void) {
 #if defined(TFHE_HIPEMU)
   return "tfhe-hip-backend 0.1 (HOST EMULATION - test build, not a product)";

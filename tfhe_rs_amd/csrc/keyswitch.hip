@@ -22,7 +22,8 @@ constexpr int KS_IC = 32;    // mask elements decomposed per LDS stage
 constexpr int KS_MAXL = 8;   // max levels staged (level_count <= 8 for every shortint set)
 std::atomic<bool> g_keyswitch_use_mfma{true};
 std::atomic<bool> g_keyswitch_split_digits{true};
-std::atomic<uint32_t> g_last_keyswitch_path{0};  // tests: 0 scalar kernels, 1 one-launch matrix-core kernel, 2 digit pass + GEMM, 3 GEMM on emitted digits  // hip_backend_set_keyswitch_kernel(2): one-launch matrix-core kernel at every batch size  // hip_backend_set_keyswitch_kernel: matrix-core path when its conditions hold
+std::atomic<uint32_t> g_last_keyswitch_path{0};
+std::atomic<uint32_t> g_keyswitch_kparts{8};  // workgroups per column tile of the small-batch kernel (hip_backend_set_keyswitch_kparts)  // tests: 0 scalar kernels, 1 one-launch matrix-core kernel, 2 digit pass + GEMM, 3 GEMM on emitted digits  // hip_backend_set_keyswitch_kernel(2): one-launch matrix-core kernel at every batch size  // hip_backend_set_keyswitch_kernel: matrix-core path when its conditions hold
 
 // DigitT: int32_t when base_log <= 31 (every shortint set), int64_t for wider bases
 template <typename DigitT>
@@ -301,7 +302,10 @@ __global__ void __launch_bounds__(256) ks_mfma_kernel(OutT *lwe_out, const uint6
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int row = lane & 31, h = lane >> 5;
   const uint32_t ct = blockIdx.x;
-  const uint32_t stile = KSPLIT > 1 ? blockIdx.y : blockIdx.y * 4 + wave;
+  // KSPLIT: one tile of samples (<= 32 LWEs); blockIdx.y = which of the gridDim.y parts of K this workgroup takes (the
+  // parts add their integer shares into the zeroed output with atomics: the whole chip streams the key, not 29 CUs)
+  const uint32_t stile = KSPLIT > 1 ? 0u : blockIdx.y * 4 + wave;
+  const uint32_t kparts = KSPLIT > 1 ? gridDim.y : 1u, kpart = KSPLIT > 1 ? blockIdx.y : 0u;
   const uint32_t s = stile * 32 + row;
   const bool live = stile * 32 < num_samples;       // whole wave
   const uint32_t s_ld = s < num_samples ? s : 0;    // rows past the batch compute on sample 0 and store nothing
@@ -318,8 +322,8 @@ __global__ void __launch_bounds__(256) ks_mfma_kernel(OutT *lwe_out, const uint6
     // mask words of step st+1 are requested before step st is decomposed (n_in + 1 words per LWE: the last
     // request of the last step reads at most the body, in range)
     // my share of the steps (all of them unless the waves split K)
-    const uint32_t st_lo = KSPLIT > 1 ? (steps / KSPLIT) * (uint32_t)wave : 0u;
-    const uint32_t st_hi = KSPLIT > 1 ? st_lo + steps / KSPLIT : steps;
+    const uint32_t st_lo = KSPLIT > 1 ? (steps / (KSPLIT * kparts)) * (kpart * KSPLIT + (uint32_t)wave) : 0u;
+    const uint32_t st_hi = KSPLIT > 1 ? st_lo + steps / (KSPLIT * kparts) : steps;
     uint64_t xn[WORDS];
     HX_UNROLL
     for (int q = 0; q < WORDS; ++q) xn[q] = x[(st_lo * 32 + h * 16) / LEVEL + q];
@@ -418,14 +422,27 @@ __global__ void __launch_bounds__(256) ks_mfma_kernel(OutT *lwe_out, const uint6
     uint64_t v = 0;
     HX_UNROLL
     for (int p = 0; p < PLANES; ++p) v += (uint64_t)((int64_t)acc[p].v[r] + 128 * sum_a) << (8 * p);
-    uint64_t o = corr - v;
-    if (col == n_out) {
+    uint64_t o = (kpart == 0 ? corr : 0) - v;  // the part's share: wrapping sums, any order
+    if (col == n_out && kpart == 0) {
       const uint64_t b = lwe_in[(size_t)in_idx[so] * (n_in + 1) + n_in];
       // 32-bit output: the body rounded to the closest multiple of 2^32, as keyswitch_64_32_kernel does
       o += sizeof(OutT) == 8 ? b : ((b >> 31) + 1) >> 1;
     }
-    lwe_out[(size_t)out_idx[so] * (n_out + 1) + col] = (OutT)o;
+    OutT *dst = &lwe_out[(size_t)out_idx[so] * (n_out + 1) + col];
+    if (kparts > 1) {
+      if constexpr (sizeof(OutT) == 8) atomicAdd((unsigned long long *)dst, (unsigned long long)o);
+      else atomicAdd((unsigned int *)dst, (unsigned int)o);
+    } else {
+      *dst = (OutT)o;
+    }
   }
+}
+
+// zeroes the output ciphertexts of a keyswitch whose K dimension is split over workgroups (ks_mfma_kernel, KSPLIT)
+template <typename OutT>
+__global__ void ks_zero_outputs_kernel(OutT *lwe_out, const uint64_t *out_idx, uint32_t n_out, uint32_t num_samples) {
+  const uint32_t col = blockIdx.x * blockDim.x + threadIdx.x, s = blockIdx.y;
+  if (col <= n_out && s < num_samples) lwe_out[(size_t)out_idx[s] * (n_out + 1) + col] = 0;
 }
 
 // ------------------------------------------------------------------ large batches: digits once, then a plain int8 GEMM
@@ -855,7 +872,15 @@ static bool keyswitch_mfma(hipStream_t st, OutT *lwe_out, const uint64_t *out_id
   }
   // up to 32 LWEs: one tile of samples, the four waves of a workgroup split K (needs steps = K / 32 divisible by 4)
   const bool split = num_samples <= 32 && (K / 32) % 4 == 0;
-  const dim3 grid(col_tiles, split ? 1 : (num_samples + 127) / 128);
+  // ... and K over KS_KPARTS workgroups per column tile when it divides: 29 workgroups alone stream the key at what
+  // 29 CUs can pull (0.09 ms for the 121 MB of a 5-level key padded to 8; 0.052 ms at the 2_2 sizes), 232 at what the
+  // memory system delivers (0.027-0.032 / 0.019-0.025 ms; measured 4 parts 0.032 / 0.022, 16 parts 0.034 / 0.026)
+  const uint32_t kparts = (split && g_keyswitch_kparts.load() > 1 && (K / 32) % (4 * g_keyswitch_kparts.load()) == 0)
+                              ? g_keyswitch_kparts.load() : 1u;
+  if (kparts > 1)
+    HX_LAUNCH((ks_zero_outputs_kernel<OutT>), dim3((ncols + 255) / 256, num_samples), dim3(256), 0, st, lwe_out, out_idx,
+              n_out, num_samples);
+  const dim3 grid(col_tiles, split ? kparts : (num_samples + 127) / 128);
 #define KSM_LAUNCH(L)                                                                                              \
   do {                                                                                                               \
     if (split && level == L)                                                                                         \

@@ -122,6 +122,7 @@ SIGNATURES = {
     "hip_test_monomial_table_host": (None, [_u32, _v]),
     "hip_backend_set_keyswitch_kernel": (None, [_u32]),
     "hip_backend_last_keyswitch_path": (_u32, []),
+    "hip_backend_set_keyswitch_kparts": (None, [_u32]),
     "hip_integer_set_multi_gpu_threshold": (None, [_u32]),
     "hip_backend_set_ntt_kernel": (None, [_u32]),
     "hip_backend_set_multibit_latency_groups": (None, [_u32]),

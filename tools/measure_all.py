@@ -164,6 +164,13 @@ if __name__ == "__main__":
     which = sys.argv[1:] or ["ks", "wave", "generic", "ntt", "mb", "n1024", "sweep"]
     if "ks" in which:
         ks_ms = ks_case(C1, 4096)
+    if "kssmall" in which:  # the rounds of one radix operation: 7 .. 32 blocks
+        for prm in (C1, C4G4):
+            for parts in (1, 8):
+                lib.hip_backend_set_keyswitch_kparts(parts)
+                for B in (8, 32):
+                    ms = ks_case(prm, B, steps=20)
+            lib.hip_backend_set_keyswitch_kparts(8)
     if "chain" in which:
         chain_case(C1, 4096)
     if "ks32" in which:
