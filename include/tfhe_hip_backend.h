@@ -426,9 +426,10 @@ void hip_backend_set_fft_kernel(uint32_t which);
 /* test hook: cap of the groups the multi-bit latency path processes per pass (0 = what the scratch holds) */
 void hip_backend_set_multibit_latency_groups(uint32_t groups);
 /* keyswitch kernel: 0 = automatic (int8 matrix-core GEMM, any batch size, when level <= 16 (padded to a power of
- * two), base_log <= 6 and n_in*padded level is a multiple of 32 — from 129 LWEs on as a digit pass followed by an
- * LDS-staged GEMM; scalar kernels otherwise), 1 = scalar kernels only, 2 = the one-launch matrix-core kernel at every
- * batch size (comparison).  Identical bits in all three. */
+ * two), base_log <= 6 and n_in*padded level is a multiple of 32 — one launch up to 768 LWEs (K shared by the waves of
+ * a workgroup and by up to 8 workgroups per column tile), from 769 on a digit pass followed by an LDS-staged GEMM;
+ * scalar kernels otherwise), 1 = scalar kernels only, 2 = the one-launch matrix-core kernel at every batch size, 3 = the
+ * digit pass + GEMM from 129 LWEs on (tests).  Identical bits in all four. */
 void hip_backend_set_keyswitch_kernel(uint32_t which);
 /* generic kernels (f64 and NTT engines): 0 = one thread group per GLWE polynomial (default), 1 = single-group
  * kernels. Same bits. */

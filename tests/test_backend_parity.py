@@ -321,7 +321,7 @@ def test_keyswitch_matrix_core_path_with_padded_levels(kind, p):
 @pytest.mark.parametrize("kind", BACKENDS)
 @pytest.mark.parametrize("p", [TOY_2048, TOY_2048_L2], ids=lambda p: p.name)
 def test_keyswitch_large_batch_digit_pass_and_staged_gemm(kind, p):
-    """From 129 LWEs on the keyswitch is two launches — the shifted digits of every sample once (ks_digits_kernel),
+    """Large batches (automatically from 769 LWEs, here forced from 129 with choice 3): the keyswitch is two launches — the shifted digits of every sample once (ks_digits_kernel),
     then an int8 GEMM whose B operand is staged in LDS once per workgroup (ks_gemm_kernel).  131 and 261 LWEs (ragged
     against the 32-row tiles and the 4-tile workgroups; one and three workgroup rows), power-of-two and padded
     level counts, permuted input and output indexes: against the one-launch matrix-core kernel (choice 2), the scalar
@@ -341,7 +341,7 @@ def test_keyswitch_large_batch_digit_pass_and_staged_gemm(kind, p):
         d_ii, d_oi = gpu.CudaVec.from_cpu_async(in_idx, st), gpu.CudaVec.from_cpu_async(out_idx, st)
         outs = {}
         try:
-            for choice in (0, 2, 1):
+            for choice in (3, 0, 2, 1):   # 3: digit pass + GEMM from 129 LWEs (automatic: from 769), 0 / 2: one launch here
                 lib.hip_backend_set_keyswitch_kernel(choice)
                 d_out = gpu.CudaLweCiphertextList.new(p.n, count, st)
                 gpu.cuda_keyswitch_lwe_ciphertext(c.ksk, d_in, d_out, d_ii, d_oi, False, st)
@@ -350,7 +350,7 @@ def test_keyswitch_large_batch_digit_pass_and_staged_gemm(kind, p):
             lib.hip_backend_set_keyswitch_kernel(0)
         for choice, out in outs.items():
             assert np.array_equal(out, want), (count, choice)
-        assert [decrypt_small(p, c.keys, o) for o in outs[0][out_idx.astype(np.int64)]] == [msgs[i] for i in in_idx.astype(np.int64)]
+        assert [decrypt_small(p, c.keys, o) for o in outs[3][out_idx.astype(np.int64)]] == [msgs[i] for i in in_idx.astype(np.int64)]
 
 
 @pytest.mark.parametrize("kind", BACKENDS)
@@ -394,6 +394,7 @@ def test_chained_ks_pbs_rounds_with_digits_emitted_by_the_bootstrap(kind):
         return outs
 
     try:
+        lib.hip_backend_set_keyswitch_kernel(3)   # digit pass + GEMM from 129 LWEs (automatic: from 769)
         lib.hip_backend_set_fft_kernel(2)   # the throughput kernel also below 257 LWEs
         plain = chain([0, 0] if kind == "emu" else [0, 0, 0])
         fused = chain([EMIT, FROM_PREV] if kind == "emu" else [EMIT, EMIT | FROM_PREV, FROM_PREV])
@@ -408,6 +409,7 @@ def test_chained_ks_pbs_rounds_with_digits_emitted_by_the_bootstrap(kind):
         assert lib.hip_backend_last_keyswitch_path() == 2        # ... and this one made its own
     finally:
         lib.hip_backend_set_fft_kernel(0)
+        lib.hip_backend_set_keyswitch_kernel(0)
         lib.cleanup_cuda_programmable_bootstrap_64(s, g, C.byref(buf))
     for r in range(len(plain)):
         assert np.array_equal(fused[r], plain[r]), r

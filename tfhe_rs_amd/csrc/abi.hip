@@ -849,6 +849,7 @@ void hip_backend_set_fft_kernel(uint32_t which) { g_fft_kernel_choice.store(whic
 void hip_backend_set_keyswitch_kernel(uint32_t which) {
   g_keyswitch_use_mfma.store(which != 1);
   g_keyswitch_split_digits.store(which != 2);
+  g_keyswitch_gemm_min.store(which == 3 ? 129u : 769u);
 }
 void hip_backend_set_ntt_kernel(uint32_t which) { g_ntt_kernel_serial = (which == 1); }
 void hip_backend_set_multibit_latency_groups(uint32_t groups) { g_multibit_latency_groups.store(groups); }

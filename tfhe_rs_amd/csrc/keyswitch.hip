@@ -305,7 +305,8 @@ __global__ void __launch_bounds__(256) ks_mfma_kernel(OutT *lwe_out, const uint6
   // KSPLIT: one tile of samples (<= 32 LWEs); blockIdx.y = which of the gridDim.y parts of K this workgroup takes (the
   // parts add their integer shares into the zeroed output with atomics: the whole chip streams the key, not 29 CUs)
   const uint32_t stile = KSPLIT > 1 ? 0u : blockIdx.y * 4 + wave;
-  const uint32_t kparts = KSPLIT > 1 ? gridDim.y : 1u, kpart = KSPLIT > 1 ? blockIdx.y : 0u;
+  // (without KSPLIT — 33 to 128 LWEs, a wave per tile — the parts are the z dimension of the grid)
+  const uint32_t kparts = KSPLIT > 1 ? gridDim.y : gridDim.z, kpart = KSPLIT > 1 ? blockIdx.y : blockIdx.z;
   const uint32_t s = stile * 32 + row;
   const bool live = stile * 32 < num_samples;       // whole wave
   const uint32_t s_ld = s < num_samples ? s : 0;    // rows past the batch compute on sample 0 and store nothing
@@ -322,8 +323,8 @@ __global__ void __launch_bounds__(256) ks_mfma_kernel(OutT *lwe_out, const uint6
     // mask words of step st+1 are requested before step st is decomposed (n_in + 1 words per LWE: the last
     // request of the last step reads at most the body, in range)
     // my share of the steps (all of them unless the waves split K)
-    const uint32_t st_lo = KSPLIT > 1 ? (steps / (KSPLIT * kparts)) * (kpart * KSPLIT + (uint32_t)wave) : 0u;
-    const uint32_t st_hi = KSPLIT > 1 ? st_lo + steps / (KSPLIT * kparts) : steps;
+    const uint32_t st_lo = KSPLIT > 1 ? (steps / (KSPLIT * kparts)) * (kpart * KSPLIT + (uint32_t)wave) : (steps / kparts) * kpart;
+    const uint32_t st_hi = KSPLIT > 1 ? st_lo + steps / (KSPLIT * kparts) : st_lo + steps / kparts;
     uint64_t xn[WORDS];
     HX_UNROLL
     for (int q = 0; q < WORDS; ++q) xn[q] = x[(st_lo * 32 + h * 16) / LEVEL + q];
@@ -457,7 +458,11 @@ __global__ void ks_zero_outputs_kernel(OutT *lwe_out, const uint64_t *out_idx, u
 //     of B (8 byte planes x 32 columns x 32 k) in LDS ONCE (double buffered, one barrier per step), every wave
 //     reads its operands from there and its A operand as one coalesced 16-byte load: no vector arithmetic in the
 //     loop, L1 traffic a quarter.  Same integer sums as ks_mfma_kernel: identical bits.
-constexpr uint32_t KSD_MIN_SAMPLES = 129;  // below: ks_mfma_kernel (one launch, K split over the waves up to 32 LWEs)
+// below: ks_mfma_kernel (one launch; K shared by the waves of a workgroup up to 32 LWEs and by up to 8 workgroups per
+// column tile).  Measured at the 2_2 sizes (tools/measure_all.py kscross), one launch / digit pass + GEMM: 256 LWEs 0.063 /
+// 0.148 ms, 512: 0.114 / 0.152, 1024: 0.214 / 0.162, 4096: 0.82 / 0.38
+constexpr uint32_t KSD_MIN_SAMPLES = 769;
+std::atomic<uint32_t> g_keyswitch_gemm_min{KSD_MIN_SAMPLES};  // hip_backend_set_keyswitch_kernel(3): 129 (tests)
 
 template <int LEVEL, bool PADDED>
 HX_DEV hx_i8x16 ksm_build_a(const uint64_t (&xc)[16 / LEVEL], uint32_t base_log, uint32_t level, bool narrow,
@@ -828,7 +833,7 @@ static bool keyswitch_mfma(hipStream_t st, OutT *lwe_out, const uint64_t *out_id
     colsum = (uint64_t *)((char *)hit->planes + hit->plane_bytes);
   }
   for (const KsmEntry &e : evicted) ksm_release(e);
-  if (ready != nullptr && num_samples >= KSD_MIN_SAMPLES && g_keyswitch_split_digits.load()) {
+  if (ready != nullptr && num_samples >= g_keyswitch_gemm_min.load() && g_keyswitch_split_digits.load()) {
     // the A operands were written by the bootstrap that produced lwe_in (PbsArgs::emit_a): the GEMM alone
     HX_PANIC_IF_FALSE(ready->steps == K / 32 && ready->base_log == base_log && ready->level == level,
                       "keyswitch: the digits at hand were made for another decomposition");
@@ -839,7 +844,7 @@ static bool keyswitch_mfma(hipStream_t st, OutT *lwe_out, const uint64_t *out_id
     g_last_keyswitch_path.store(3);
     return true;
   }
-  if (num_samples >= KSD_MIN_SAMPLES && g_keyswitch_split_digits.load()) {
+  if (num_samples >= g_keyswitch_gemm_min.load() && g_keyswitch_split_digits.load()) {
     // large batch: the digits once (A operands in the stream's scratch), then the LDS-staged GEMM
     const uint32_t tiles = (num_samples + 31) / 32, steps = K / 32;
     const size_t a_bytes = (size_t)tiles * steps * 1024, need_s = a_bytes + (size_t)tiles * 32 * sizeof(int32_t);
@@ -875,12 +880,15 @@ static bool keyswitch_mfma(hipStream_t st, OutT *lwe_out, const uint64_t *out_id
   // ... and K over KS_KPARTS workgroups per column tile when it divides: 29 workgroups alone stream the key at what
   // 29 CUs can pull (0.09 ms for the 121 MB of a 5-level key padded to 8; 0.052 ms at the 2_2 sizes), 232 at what the
   // memory system delivers (0.027-0.032 / 0.019-0.025 ms; measured 4 parts 0.032 / 0.022, 16 parts 0.034 / 0.026)
-  const uint32_t kparts = (split && g_keyswitch_kparts.load() > 1 && (K / 32) % (4 * g_keyswitch_kparts.load()) == 0)
-                              ? g_keyswitch_kparts.load() : 1u;
+  // (33 .. 128 LWEs: one workgroup row of up to four tiles; the same sharing of K, over the grid's z dimension)
+  // beyond 128 LWEs the grid has several rows of four tiles and proportionally fewer parts
+  uint32_t want = g_keyswitch_kparts.load();
+  for (uint32_t rows = (num_samples + 127) / 128; rows > 1 && want > 1; rows >>= 1) want >>= 1;
+  const uint32_t kparts = (want > 1 && (K / 32) % (4 * want) == 0) ? want : 1u;
   if (kparts > 1)
     HX_LAUNCH((ks_zero_outputs_kernel<OutT>), dim3((ncols + 255) / 256, num_samples), dim3(256), 0, st, lwe_out, out_idx,
               n_out, num_samples);
-  const dim3 grid(col_tiles, split ? kparts : (num_samples + 127) / 128);
+  const dim3 grid(col_tiles, split ? kparts : (num_samples + 127) / 128, split ? 1 : kparts);
 #define KSM_LAUNCH(L)                                                                                              \
   do {                                                                                                               \
     if (split && level == L)                                                                                         \

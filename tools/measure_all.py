@@ -164,11 +164,17 @@ if __name__ == "__main__":
     which = sys.argv[1:] or ["ks", "wave", "generic", "ntt", "mb", "n1024", "sweep"]
     if "ks" in which:
         ks_ms = ks_case(C1, 4096)
+    if "kscross" in which:  # one-launch kernel with K shared by workgroups (choice 2) against digit pass + GEMM (0)
+        for B in (128, 256, 512, 1024, 2048, 4096):
+            for choice in (2, 0):
+                lib.hip_backend_set_keyswitch_kernel(choice)
+                ks_case(C1, B, steps=10)
+        lib.hip_backend_set_keyswitch_kernel(0)
     if "kssmall" in which:  # the rounds of one radix operation: 7 .. 32 blocks
         for prm in (C1, C4G4):
             for parts in (1, 8):
                 lib.hip_backend_set_keyswitch_kparts(parts)
-                for B in (8, 32):
+                for B in (8, 32, 64, 128):
                     ms = ks_case(prm, B, steps=20)
             lib.hip_backend_set_keyswitch_kparts(8)
     if "chain" in which:
