@@ -641,6 +641,19 @@ def main():
             del bsk4, d_in4, d_out4
         # ---- config 5 on ONE GPU: FheUint64 (32 blocks of the 2_2 set) add and mul through the radix layer
         result["extra"]["fheuint64"] = fheuint64_datapoint(lib, p, keys, [g], {"add": 1024, "mul": 128}, in_library=False)
+        # ---- latency of ONE FheUint64 operation on the reference's GPU multi-bit set (what its documentation publishes
+        # for 8 x H100: 9.52 / 31.9 ms); uniform-random key material, the third repetition is reported
+        try:
+            import subprocess
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "latency_integer.py"), "multibit_g4"],
+                               capture_output=True, text=True, timeout=300)
+            lat = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+            result["extra"]["fheuint64_single_operation_latency"] = {
+                "params": C4G4.name, "add_ms": lat[0]["operation_ms"], "mul_ms": lat[1]["operation_ms"],
+                "note": "one ciphertext pair, one stream, one GPU: nine (add) dependent KS -> multi-bit PBS rounds; the "
+                        "reference publishes 9.52 / 31.9 ms with the blocks of a round spread over 8 x H100"}
+        except Exception as e:  # noqa: BLE001
+            result["extra"]["fheuint64_single_operation_latency"] = {"error": f"{e.__class__.__name__}: {e}"[:300]}
     if not single and per_gpu is not None and args.kernel == 0 and not args.no_extra:
         # ---- config 5 on the N GPUs: the batch of 1024 FheUint64 sharded (a) by the caller, 1024 / N integers per GPU,
         # every round GPU-local, and (b) inside the library, one CudaStreamsFFI naming the N GPUs: the
