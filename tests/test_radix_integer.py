@@ -95,15 +95,20 @@ def test_add_and_carry_propagation(kind):
     assert [r[0] for r in decrypt_blocks(p, keys, cout.to_blocks(st))] == [f >> bits for f in full]
 
 
+@pytest.mark.parametrize("many", [False, True], ids=["few_integers", "many_integers"])
 @pytest.mark.parametrize("kind", BACKENDS)
-def test_mul(kind):
+def test_mul(kind, many):
+    """few integers: every term of a column is grouped at once (fewest rounds); 8 or more per call: only full
+    groups are summed and the rest of a column waits (fewest bootstraps) — both plans, same products."""
     p, keys, st, sks, igpu = setup(kind)
-    L = 9 if kind == "emu" else 32   # 9 blocks: columns of up to 17 terms, several reduction steps
+    # 9 blocks: columns of up to 17 terms, several reduction steps
+    L = (5 if many else 9) if kind == "emu" else 32
     bits = 2 * L
     mask = (1 << bits) - 1
     rng = np.random.default_rng(9)
-    a = [int(x) & mask for x in rng.integers(0, 1 << 62, size=2)] + [mask]
-    b = [int(x) & mask for x in rng.integers(0, 1 << 62, size=2)] + [mask]
+    extra = 7 if many else 2
+    a = [int(x) & mask for x in rng.integers(0, 1 << 62, size=extra)] + [mask]
+    b = [int(x) & mask for x in rng.integers(0, 1 << 62, size=extra)] + [mask]
     ca = igpu.CudaUnsignedRadixCiphertext.from_blocks(encrypt_radix(p, keys, a, L, 31), st)
     cb = igpu.CudaUnsignedRadixCiphertext.from_blocks(encrypt_radix(p, keys, b, L, 32), st)
     pbs = sks.mul_assign(ca, cb, st, return_pbs_count=True)
@@ -111,6 +116,8 @@ def test_mul(kind):
     assert all(d < MSG for r in rows for d in r)
     assert recompose(rows) == [(x * y) & mask for x, y in zip(a, b)]
     assert pbs > L * L
+    if L == 32:
+        assert pbs == (1804 if many else 1866)
 
 
 @pytest.mark.parametrize("kind", BACKENDS)

@@ -665,8 +665,15 @@ struct MulMem {
       for (uint32_t c = 0; c < L; ++c) {
         size_t pos = 0;
         const size_t n = cols[c].size();
+        // Many integers per call (throughput): only full groups are summed — a group of `chunk` terms removes
+        // chunk - 2 of them for two PBS, a shorter one removes fewer (a pair: none) for the same price — and what
+        // is left of a column waits for the next step, unless no column can fill a group any more (3.3 % fewer
+        // PBS per 32-block multiplication: 1,804 instead of 1,866; three more but small rounds).  Few integers
+        // (latency): every term is grouped at once, which needs the fewest rounds.
+        const bool wide = max_cts >= 8, only_full = wide && n >= chunk;
         while (pos < n) {
-          const size_t len = std::min<size_t>(chunk, n - pos);
+          size_t len = only_full && n - pos < chunk ? 1 : std::min<size_t>(chunk, n - pos);
+          if (wide && len == 2) len = 1;  // a pair would come back as a pair (message + carry)
           if (len == 1) {  // nothing to add: the term stays as it is
             nc[c].push_back(cols[c][pos]);
           } else {
