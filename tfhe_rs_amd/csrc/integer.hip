@@ -354,15 +354,20 @@ struct ApplyLutMem {
 // q+1 set whatever arrives, and an absorbing block stops it.  The carry into a GROUP comes from a Hillis-Steele
 // scan over the group states; a group's state is read off U = w_0 + .. + w_(G-2) (bit G-1 of U and of U+1:
 // does a carry leave the first G-1 blocks without / with an incoming one) combined with its last block.
-// PBS for 32 blocks: 32 states + 7 + 7 group states + 14 scan + 7 carry bits + 24 inner carries + 32 results
-// = 123 in 9 rounds (a per-block Hillis-Steele scan takes 224).
+// A prefix that is complete (group 0 after the combine with its last block; groups d..2d-1 after the scan step
+// of distance d) is written as the CARRY BIT it stands for (generated -> 1, anything else -> 0) by the same
+// bootstrap that completes it: a carry bit is a valid `prev` for the later steps (0 none, 1 generated), and it
+// is what the inner carries and the first block of the next group add — so the prefix states live in the pool
+// slots of the carries they become, and no separate state -> carry round exists.
+// PBS for 32 blocks: 32 states + 7 + 7 group states + 14 scan + 24 inner carries + 32 results
+// = 116 in 8 rounds (a per-block Hillis-Steele scan takes 224).
 enum : uint64_t {
   LUT_W = 0,           // + q (q = 0..2): state << q
   LUT_W_FIRST = 3,     // block 0 of an integer: a propagate there can receive nothing
   LUT_STATE_LAST = 4,  // last block of a group: plain state, scan encoding
   LUT_GROUP = 5,       // U -> state of the first G-1 blocks, scan encoding
   LUT_COMBINE = 6,     // prev * msg + cur -> cur == propagated ? prev : cur
-  LUT_IS_GEN = 7,      // state -> state == generated
+  LUT_COMBINE_CARRY = 7,  // the same on a prefix that is complete: -> 1 if the result is `generated`, else 0
   LUT_BIT = 8,         // + q (q = 1..3): S -> bit q of S
   LUT_MSG = 12,        // x -> x % msg
   LUT_CARRY = 13,      // x -> x / msg (output carry of an integer's last block, FLAG_CARRY)
@@ -378,22 +383,23 @@ struct PropagateMem {
   uint32_t blocks = 0;   // blocks per integer
   uint32_t max_cts = 0;  // integers the scratch was sized for
   // scratch ciphertexts: pool = [W: T shifted states | C: cts*NG carries into the groups], S: T partial sums /
-  // inner carries, U and GS: cts*NG, P: packed bivariate inputs
-  uint64_t *d_pool = nullptr, *d_s = nullptr, *d_u = nullptr, *d_gs = nullptr, *d_p = nullptr;
+  // inner carries, U: cts*NG, P: packed bivariate inputs.  The prefix state of groups 0..g is kept in the slot
+  // of the carry into group g + 1 (GS = C shifted by one ciphertext).
+  uint64_t *d_pool = nullptr, *d_s = nullptr, *d_u = nullptr, *d_p = nullptr;
   uint32_t cached_cts = 0;
   std::vector<uint64_t *> dev_arrays;
   struct Idx {
     uint64_t *a = nullptr, *b = nullptr, *o = nullptr, *lut = nullptr;
     uint32_t count = 0;
   };
-  Idx rA, csrU, rC1, rC2, rD, csrS, rE, addC, addS, rF, rIO;
+  Idx rA, csrU, rC1, rC2, csrS, rE, addC, addS, rF, rIO;
   std::vector<Idx> scan;
 
   static uint32_t ngroups(uint32_t L) { return (L + G - 1) / G; }
   // PBS one propagation issues per integer
   static uint64_t pbs_count(uint32_t L) {
     const uint32_t NG = ngroups(L);
-    uint64_t n = 2 * (uint64_t)L + 3 * (uint64_t)(NG - 1);  // A, F, C1, C2, D'
+    uint64_t n = 2 * (uint64_t)L + 2 * (uint64_t)(NG - 1);  // A, F, C1, C2
     for (uint32_t d = 1; d + 1 < NG; d <<= 1) n += NG - 1 - d;
     for (uint32_t j = 0; j < L; ++j) n += (j % G != 0);
     return n;
@@ -458,10 +464,10 @@ struct PropagateMem {
         a.push_back(GI(c, g));
         b.push_back(T(c, g * G + G - 1));
         o.push_back(GI(c, g));
-        l.push_back(LUT_COMBINE);
+        l.push_back(g == 0 ? LUT_COMBINE_CARRY : LUT_COMBINE);  // group 0 is its own prefix
       }
     rC2 = make(st, a, b, o, l);
-    // D: inclusive scan of the states of groups 0..NG-2
+    // D: inclusive scan of the states of groups 0..NG-2; step d completes the prefixes of groups d..2d-1
     for (uint32_t d = 1; d + 1 < NG; d <<= 1) {
       reset();
       for (uint32_t c = 0; c < cts; ++c)
@@ -469,19 +475,10 @@ struct PropagateMem {
           a.push_back(GI(c, g - d));
           b.push_back(GI(c, g));
           o.push_back(GI(c, g));
-          l.push_back(LUT_COMBINE);
+          l.push_back(g < 2 * d ? LUT_COMBINE_CARRY : LUT_COMBINE);
         }
       scan.push_back(make(st, a, b, o, l));
     }
-    // D': carry bit entering group g >= 1 -> C (second part of the pool)
-    reset();
-    for (uint32_t c = 0; c < cts; ++c)
-      for (uint32_t g = 1; g < NG; ++g) {
-        a.push_back(GI(c, g - 1));
-        o.push_back((uint64_t)TT + GI(c, g));
-        l.push_back(LUT_IS_GEN);
-      }
-    rD = make(st, a, {}, o, l);
     // E: S_t = C_g + w_0 + .. + w_(q-1) for q >= 1 (CSR over the pool), then bit q of it
     reset();
     a.push_back(0);
@@ -543,7 +540,7 @@ struct PropagateMem {
       return h0 ? 1 : (h1 ? 2 : 0);
     };
     fs[LUT_COMBINE] = [m](uint64_t x) -> uint64_t { return (x % m) == 2 ? (x / m) : (x % m); };
-    fs[LUT_IS_GEN] = [](uint64_t x) -> uint64_t { return x == 1 ? 1 : 0; };
+    fs[LUT_COMBINE_CARRY] = [m](uint64_t x) -> uint64_t { return ((x % m) == 2 ? (x / m) : (x % m)) == 1 ? 1 : 0; };
     for (uint64_t q = 1; q < G; ++q) fs[LUT_BIT + q] = [q](uint64_t x) -> uint64_t { return (x >> q) & 1; };
     fs[LUT_MSG] = [m](uint64_t x) -> uint64_t { return x % m; };
     fs[LUT_CARRY] = [m](uint64_t x) -> uint64_t { return x / m; };
@@ -559,7 +556,6 @@ struct PropagateMem {
     radix_alloc((void **)&d_s, (size_t)T * w * sizeof(uint64_t));
     radix_alloc((void **)&d_p, (size_t)T * w * sizeof(uint64_t));
     radix_alloc((void **)&d_u, (size_t)cts * NG * w * sizeof(uint64_t));
-    radix_alloc((void **)&d_gs, (size_t)cts * NG * w * sizeof(uint64_t));
   }
 
   void group_sum(hipStream_t st, uint64_t *out, const uint64_t *pool, const Idx &csr, uint32_t groups, uint32_t w) {
@@ -582,7 +578,8 @@ struct PropagateMem {
     // A: shifted / plain state of every block
     drv.round(ss, d_pool, rA.o, v, rA.a, rA.lut, rA.count, ksks, bsks);
     if (csrU.count) {
-      // group states: U (dense) -> first G-1 blocks -> whole group -> prefix scan -> carry into each group
+      // group states: U (dense) -> first G-1 blocks -> whole group -> prefix scan = carry into each group
+      uint64_t *d_gs = d_pool + ((size_t)T + 1) * w;  // prefix of groups 0..g in the slot of the carry into g + 1
       group_sum(st, d_u, d_pool, csrU, csrU.count, w);
       drv.round(ss, d_gs, rC1.o, d_u, nullptr, rC1.lut, rC1.count, ksks, bsks);
       axpy(st, d_p, nullptr, d_gs, rC2.a, p.msg, d_pool, rC2.b, w, rC2.count);
@@ -591,7 +588,6 @@ struct PropagateMem {
         axpy(st, d_p, nullptr, d_gs, r.a, p.msg, d_gs, r.b, w, r.count);
         drv.round(ss, d_gs, r.o, d_p, nullptr, r.lut, r.count, ksks, bsks);
       }
-      drv.round(ss, d_pool, rD.o, d_gs, rD.a, rD.lut, rD.count, ksks, bsks);
     }
     // E: inner carries (dense partial sums in P, bit q of each -> S[t])
     group_sum(st, d_p, d_pool, csrS, csrS.count, w);
@@ -607,7 +603,7 @@ struct PropagateMem {
     drv.release(ss);
     for (auto *d : dev_arrays) HX_CHECK(hipFree(d));
     dev_arrays.clear();
-    for (uint64_t *d : {d_pool, d_s, d_p, d_u, d_gs})
+    for (uint64_t *d : {d_pool, d_s, d_p, d_u})
       if (d) HX_CHECK(hipFree(d));
     magic = 0;
   }
@@ -668,7 +664,7 @@ struct MulMem {
         // Many integers per call (throughput): only full groups are summed — a group of `chunk` terms removes
         // chunk - 2 of them for two PBS, a shorter one removes fewer (a pair: none) for the same price — and what
         // is left of a column waits for the next step, unless no column can fill a group any more (3.3 % fewer
-        // PBS per 32-block multiplication: 1,804 instead of 1,866; three more but small rounds).  Few integers
+        // PBS per 32-block multiplication: 1,797 instead of 1,859; three more but small rounds).  Few integers
         // (latency): every term is grouped at once, which needs the fewest rounds.
         const bool wide = max_cts >= 8, only_full = wide && n >= chunk;
         while (pos < n) {
