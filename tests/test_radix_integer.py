@@ -100,6 +100,27 @@ def test_add_and_carry_propagation(kind):
     assert [r[0] for r in decrypt_blocks(p, keys, cout.to_blocks(st))] == [f >> bits for f in full]
 
 
+@pytest.mark.parametrize("kind", BACKENDS)
+def test_add_at_the_widths_where_the_carry_tree_changes_shape(kind):
+    """The look-ahead is a tree of groups of three under a top level of at most four elements: 1 block (no carry
+    at all), 2 and 4 (the top level alone), 10 (four groups under the top), 13 (a group of one block); the 17- and
+    32-block cases above have two levels of groups."""
+    p, keys, st, sks, igpu = setup(kind)
+    rng = np.random.default_rng(77)
+    for L in (1, 2, 4, 10, 13):
+        bits = 2 * L
+        mask = (1 << bits) - 1
+        a = [mask, int(rng.integers(0, 1 << 62)) & mask]
+        b = [1, int(rng.integers(0, 1 << 62)) & mask]
+        ca = igpu.CudaUnsignedRadixCiphertext.from_blocks(encrypt_radix(p, keys, a, L, 41 + L), st)
+        cb = igpu.CudaUnsignedRadixCiphertext.from_blocks(encrypt_radix(p, keys, b, L, 42 + L), st)
+        cout = sks.add_assign(ca, cb, st, want_carry_out=True)
+        full = [x + y for x, y in zip(a, b)]
+        assert recompose(decrypt_blocks(p, keys, ca.to_blocks(st))) == [f & mask for f in full], L
+        assert [r[0] for r in decrypt_blocks(p, keys, cout.to_blocks(st))] == [f >> bits for f in full], L
+        assert int(igpu._lib().hip_integer_propagate_pbs_count(L)) == {1: 1, 2: 4, 4: 10, 10: 31, 13: 42}[L]
+
+
 @pytest.mark.parametrize("many", [False, True], ids=["few_integers", "many_integers"])
 @pytest.mark.parametrize("kind", BACKENDS)
 def test_mul(kind, many):
@@ -122,7 +143,7 @@ def test_mul(kind, many):
     assert recompose(rows) == [(x * y) & mask for x, y in zip(a, b)]
     assert pbs > L * L
     if L == 32:
-        assert pbs == (1797 if many else 1859)   # products + column sums (1,681 or 1,743) + one propagation (116)
+        assert pbs == (1788 if many else 1850)   # products + column sums (1,681 or 1,743) + one propagation (107)
 
 
 @pytest.mark.parametrize("kind", BACKENDS)
