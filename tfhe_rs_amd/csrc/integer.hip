@@ -99,6 +99,23 @@ static void generate_lut(const Params &p, uint64_t *acc, const std::function<uin
   std::rotate(body, body + half, body + p.N);
 }
 
+// shortint's many-LUT accumulator (tfhe/src/shortint/engine/mod.rs:169-254 fill_many_lut_accumulator): the plaintext
+// space is shared by fs.size() functions of inputs below sup / fs.size(); function t sits in sub-table t, which the
+// sample extraction reaches at coefficient t * many_lut_stride(p, fs.size())
+static uint32_t many_lut_stride(const Params &p, uint32_t fn) { return p.N / fn; }
+static void generate_many_lut(const Params &p, uint64_t *acc, const std::vector<std::function<uint64_t(uint64_t)>> &fs) {
+  const uint32_t sup = p.msg * p.carry, box = p.N / sup, fn = (uint32_t)fs.size(), inputs = sup / fn;
+  const uint64_t delta = ((uint64_t)1 << 63) / sup;
+  std::fill(acc, acc + (size_t)(p.k + 1) * p.N, 0);
+  uint64_t *body = acc + (size_t)p.k * p.N;
+  for (uint32_t t = 0; t < fn; ++t)
+    for (uint32_t i = 0; i < inputs; ++i)
+      for (uint32_t j = 0; j < box; ++j) body[(size_t)t * inputs * box + (size_t)i * box + j] = fs[t](i) * delta;
+  const uint32_t half = box / 2;
+  for (uint32_t i = 0; i < half; ++i) body[i] = (uint64_t)0 - body[i];
+  std::rotate(body, body + half, body + p.N);
+}
+
 // scratch_* with allocate_gpu_memory = false only reports the device bytes the scratch would take
 // (gpu/ffi.rs:95-132 "size on gpu" queries): allocations are counted, not made, and nothing is uploaded
 static thread_local bool t_dry = false;
@@ -145,7 +162,7 @@ struct LutDriver {
   static constexpr uint32_t kMagic = 0x52445231;  // "RDR1"
   uint32_t magic = kMagic;
   Params p{};
-  uint32_t cap = 0, num_luts = 0;
+  uint32_t cap = 0, num_luts = 0, many_max = 1;
   struct PerGpu {
     uint32_t gpu = 0;
     uint64_t *d_ks = nullptr, *d_luts = nullptr, *d_trivial = nullptr;  // d_trivial = 0, 1, ..., cap - 1
@@ -153,6 +170,7 @@ struct LutDriver {
     // GPUs other than the first: shard buffers on this GPU and their twins on the first GPU
     uint64_t *d_in = nullptr, *d_out = nullptr, *d_lut_idx = nullptr;   // on this GPU
     uint64_t *d0_in = nullptr, *d0_out = nullptr;                       // on the first GPU
+    uint64_t *d_many = nullptr;  // first GPU only, drivers created for many-LUT rounds: dense outputs before the scatter
     hipEvent_t staged = nullptr, done = nullptr, copied = nullptr;
   };
   std::vector<PerGpu> gpus;
@@ -165,11 +183,13 @@ struct LutDriver {
                                                    !t_dry, (enum PBS_MS_REDUCTION_T)p.ms_type);
   }
 
+  // max_many: the most functions one round extracts per bootstrap (sizes the dense output buffers)
   void init(const CudaStreamsFFI &s, const Params &params, uint32_t capacity,
-            const std::vector<std::vector<uint64_t>> &luts) {
+            const std::vector<std::vector<uint64_t>> &luts, uint32_t max_many = 1) {
     HX_PANIC_IF_FALSE(s.gpu_count >= 1 && s.streams != nullptr, "radix layer: empty stream set");
     p = params;
     cap = capacity;
+    many_max = std::max(1u, max_many);
     num_luts = (uint32_t)luts.size();
     const size_t lw = (size_t)(p.k + 1) * p.N, w = (size_t)p.big_n + 1;
     std::vector<uint64_t> triv(cap);
@@ -185,15 +205,16 @@ struct LutDriver {
       for (uint32_t t = 0; t < num_luts && !t_dry; ++t)
         HX_CHECK(hipMemcpyAsync(g.d_luts + t * lw, luts[t].data(), lw * sizeof(uint64_t), hipMemcpyHostToDevice, st));
       g.d_trivial = dev_upload(st, triv);
+      if (i == 0 && many_max > 1) radix_alloc((void **)&g.d_many, (size_t)many_max * cap * w * sizeof(uint64_t));
       if (i > 0) {
         radix_alloc((void **)&g.d_in, (size_t)cap * w * sizeof(uint64_t));
-        radix_alloc((void **)&g.d_out, (size_t)cap * w * sizeof(uint64_t));
+        radix_alloc((void **)&g.d_out, (size_t)many_max * cap * w * sizeof(uint64_t));
         radix_alloc((void **)&g.d_lut_idx, (size_t)cap * sizeof(uint64_t));
         // An event is recorded on a stream of ITS device only (hipEventRecord rejects a foreign stream): `staged` and
         // `copied` are recorded on the first GPU's stream, `done` on this GPU's; waiting across devices is allowed.
         HX_CHECK(hipSetDevice((int)gpus[0].gpu));
         radix_alloc((void **)&g.d0_in, (size_t)cap * w * sizeof(uint64_t));
-        radix_alloc((void **)&g.d0_out, (size_t)cap * w * sizeof(uint64_t));
+        radix_alloc((void **)&g.d0_out, (size_t)many_max * cap * w * sizeof(uint64_t));
         if (!t_dry) {
           HX_CHECK(hipEventCreateWithFlags(&g.staged, hipEventDisableTiming));
           HX_CHECK(hipEventCreateWithFlags(&g.copied, hipEventDisableTiming));
@@ -233,10 +254,16 @@ struct LutDriver {
            bsks[0], many, stride);
   }
 
-  // one round, split into launches of at most `cap` blocks; a null in_idx / out_idx means "block s"
+  // one round, split into launches of at most `cap` blocks; a null in_idx / out_idx means "block s".
+  // many > 1: every bootstrap extracts `many` functions of its accumulator (coefficients t * stride); out_idx then
+  // holds many * count entries, function t of block s goes to out[out_idx[t * count + s]] (the PBS kernels place
+  // function t behind the launch's own samples, so these rounds go through a dense buffer and a scatter).
   void round(const CudaStreamsFFI &s, uint64_t *out, const uint64_t *out_idx, const uint64_t *in, const uint64_t *in_idx,
-             const uint64_t *lut_idx, uint32_t count, void *const *ksks, void *const *bsks) const {
+             const uint64_t *lut_idx, uint32_t count, void *const *ksks, void *const *bsks, uint32_t many = 1,
+             uint32_t stride = 0) const {
     const size_t w = (size_t)p.big_n + 1;
+    HX_PANIC_IF_FALSE(many >= 1 && many <= many_max && (many == 1 || out_idx != nullptr),
+                      "radix layer: a round of %u functions per bootstrap on a driver created for %u", many, many_max);
     const uint32_t avail = std::min<uint32_t>(s.gpu_count, (uint32_t)gpus.size());
     const hipStream_t st0 = (hipStream_t)s.streams[0];
     for (uint32_t off = 0; off < count; off += cap) {
@@ -267,15 +294,24 @@ struct LutDriver {
         HX_CHECK(hipMemcpyPeerAsync(g.d_in, (int)g.gpu, g.d0_in, (int)gpus[0].gpu, (size_t)ci * w * sizeof(uint64_t), sti));
         HX_CHECK(hipMemcpyPeerAsync(g.d_lut_idx, (int)g.gpu, lut_idx + off + begin, (int)gpus[0].gpu,
                                     (size_t)ci * sizeof(uint64_t), sti));
-        ks_pbs(sti, g, g.d_out, g.d_trivial, g.d_in, g.d_trivial, g.d_lut_idx, ci, ksks[i], bsks[i]);
-        HX_CHECK(hipMemcpyPeerAsync(g.d0_out, (int)gpus[0].gpu, g.d_out, (int)g.gpu, (size_t)ci * w * sizeof(uint64_t), sti));
+        ks_pbs(sti, g, g.d_out, g.d_trivial, g.d_in, g.d_trivial, g.d_lut_idx, ci, ksks[i], bsks[i], many, stride);
+        HX_CHECK(hipMemcpyPeerAsync(g.d0_out, (int)gpus[0].gpu, g.d_out, (int)g.gpu,
+                                    (size_t)many * ci * w * sizeof(uint64_t), sti));
         HX_CHECK(hipEventRecord(g.done, sti));
         begin += ci;
       }
       // the first GPU's own shard, in place
       HX_CHECK(hipSetDevice((int)gpus[0].gpu));
-      ks_pbs(st0, gpus[0], out0, oi ? oi : gpus[0].d_trivial, in0, ii ? ii : gpus[0].d_trivial, lut_idx + off, first,
-             ksks[0], bsks[0]);
+      if (many == 1) {
+        ks_pbs(st0, gpus[0], out0, oi ? oi : gpus[0].d_trivial, in0, ii ? ii : gpus[0].d_trivial, lut_idx + off, first,
+               ksks[0], bsks[0]);
+      } else {
+        ks_pbs(st0, gpus[0], gpus[0].d_many, gpus[0].d_trivial, in0, ii ? ii : gpus[0].d_trivial, lut_idx + off, first,
+               ksks[0], bsks[0], many, stride);
+        for (uint32_t t = 0; t < many; ++t)
+          axpy(st0, out, out_idx + (size_t)t * count + off, gpus[0].d_many + (size_t)t * first * w, nullptr, 1, nullptr,
+               nullptr, (uint32_t)w, first);
+      }
       // results of the other GPUs: scatter on the first GPU
       begin = first;
       for (uint32_t i = 1; i < active; ++i) {
@@ -283,7 +319,11 @@ struct LutDriver {
         const uint32_t ci = num_inputs_on_gpu(c, i, active);
         if (ci == 0) continue;
         HX_CHECK(hipStreamWaitEvent(st0, g.done, 0));
-        if (oi)
+        if (many > 1)
+          for (uint32_t t = 0; t < many; ++t)
+            axpy(st0, out, out_idx + (size_t)t * count + off + begin, g.d0_out + (size_t)t * ci * w, nullptr, 1, nullptr,
+                 nullptr, (uint32_t)w, ci);
+        else if (oi)
           axpy(st0, out0, oi + begin, g.d0_out, nullptr, 1, nullptr, nullptr, (uint32_t)w, ci);
         else
           HX_CHECK(hipMemcpyAsync(out0 + (size_t)begin * w, g.d0_out, (size_t)ci * w * sizeof(uint64_t),
@@ -310,7 +350,7 @@ struct LutDriver {
         else
           cleanup_cuda_programmable_bootstrap_64(st, g.gpu, &g.pbs_buf);
       }
-      for (uint64_t *d : {g.d_ks, g.d_luts, g.d_trivial, g.d_in, g.d_out, g.d_lut_idx})
+      for (uint64_t *d : {g.d_ks, g.d_luts, g.d_trivial, g.d_in, g.d_out, g.d_lut_idx, g.d_many})
         if (d) HX_CHECK(hipFree(d));
       for (hipEvent_t e : {g.staged, g.done, g.copied})
         if (e) HX_CHECK(hipEventDestroy(e));
@@ -345,8 +385,9 @@ struct ApplyLutMem {
 // block.  Block states as in radix_parallel/add.rs (OutputCarry): none, generated, propagated.
 //
 // Carry look-ahead as a TREE OF BINARY ADDITIONS (needs msg*carry >= 16; the same family as the reference's
-// advanced_add_assign_with_carry_at_least_4_bits, add.rs:828-1044).  Among up to three neighbours the carries
-// are resolved by an ordinary binary addition of their states, which is LINEAR in the ciphertexts:
+// advanced_add_assign_with_carry_at_least_4_bits, add.rs:828-1044, which also takes its block states from
+// many-LUT bootstraps).  Among up to three neighbours the carries are resolved by an ordinary binary addition of
+// their states, which is LINEAR in the ciphertexts:
 //   w_q = (generated ? 2 : propagated ? 1 : 0) << q          for the neighbour at position q = 0..2
 //   S_q = carry_in + w_0 + ... + w_(q-1)                       LWE additions, no PBS
 //   carry into neighbour q = bit q of S_q                      (one PBS, q >= 1)
@@ -356,16 +397,26 @@ struct ApplyLutMem {
 // which emits it already shifted for its own position one level up.  So: blocks -> groups of 3 -> groups of 9
 // -> ... until at most 4 elements are left, whose carries are bits 1..3 of the partial sums; then the carries go
 // back down, one level per round (the first element of a group takes the carry of its group as it is).
-// PBS for 32 blocks: 31 block states + 10 + 3 group states + 3 top carries + 7 + 21 carries + 32 results
-// = 107 in 7 rounds (a Hillis-Steele scan over groups of four took 116 in 8, one per block 224).
+// The blocks themselves take no round of their own on the way down: the first bootstrap of a block (its value is
+// below msg*carry / 2, so the accumulator holds two functions) also returns 4 * (value % msg), and the last one
+// reads the result off  4 * (value % msg) + z  with z = (state of the blocks before it in its group of three:
+// 0 none, 1 propagated, 2 generated) + (carry into the group): the block receives a carry iff z >= 2.
+// PBS for 32 blocks: 32 first bootstraps + 10 + 3 group states + 10 states of the first two blocks of a group
+// + 3 top carries + 7 carries into the groups + 32 results = 97 in 6 rounds (round 3, before: 107 in 7 with a
+// round for the carries into the blocks; a Hillis-Steele scan over groups of four 116 in 8; one per block 224).
 enum : uint64_t {
-  LUT_W = 0,         // + q (q = 0..2): state << q
-  LUT_W_FIRST = 3,   // block 0 of an integer: a propagate there can receive nothing
-  LUT_GROUP = 4,     // + 3 (len - 1) + q: U of a group of len = 1..3 -> state of the group << q
-  LUT_BIT = 12,      // + q (q = 1..3): S -> bit q of S
-  LUT_MSG = 16,      // x -> x % msg
-  LUT_CARRY = 17,    // x -> x / msg (output carry of an integer's last block, FLAG_CARRY)
-  LUT_PROP_COUNT = 18
+  LUT_FIRST2 = 0,    // many-LUT accumulators [f, 4 (x % msg)]: + q: f = state << q (q = 0..2);
+                     // + 3: block 0 of an integer, f = state with "propagated" dropped (nothing can arrive);
+                     // + 4: last block of an integer, f = 4 * state (only the output carry reads it)
+  LUT_GROUP = 5,     // + 3 (len - 1) + q: U of a group of len = 1..3 -> state of the group << q
+  LUT_BIT = 13,      // + q (q = 1..3): S -> bit q of S
+  LUT_RES_BIT = 17,  // 4 m + z -> (m + z) % msg, z = the carry itself (first block of a group, or the top level)
+  LUT_RES_Z = 18,    // 4 m + z -> (m + (z >= 2)) % msg
+  LUT_OUT_BIT = 19,  // 4 state + z -> output carry of the integer, z = the carry into its last block
+  LUT_OUT_Z = 20,    // 4 state + z -> the same, the carry into the last block is z >= 2
+  LUT_MSG = 21,      // x -> x % msg                  (single-block integers)
+  LUT_CARRY = 22,    // x -> x / msg
+  LUT_PROP_COUNT = 23
 };
 
 struct PropagateMem {
@@ -376,17 +427,18 @@ struct PropagateMem {
   LutDriver drv;
   uint32_t blocks = 0;   // blocks per integer
   uint32_t max_cts = 0;  // integers the scratch was sized for
-  // scratch ciphertexts: pool = [W of level 0 (the blocks), W of level 1, ... | C of level 1, ...] (shifted states;
-  // carries into the elements of the upper levels), S: carries into the blocks, P: dense sums of one round
-  uint64_t *d_pool = nullptr, *d_s = nullptr, *d_p = nullptr;
+  // scratch ciphertexts: pool = [W of level 0 (the blocks), W of level 1, ... | C of level 0 (top level only), C of
+  // level 1, ... | M: 4 (value % msg) of every block | P: state of the first two blocks of every full group]
+  // (shifted states; carries into the elements); P2: dense sums of one round
+  uint64_t *d_pool = nullptr, *d_p = nullptr;
   uint32_t cached_cts = 0;
   std::vector<uint64_t *> dev_arrays;
   struct Idx {
     uint64_t *a = nullptr, *b = nullptr, *o = nullptr, *lut = nullptr;
     uint32_t count = 0;
   };
-  Idx rA, rTop, addC, addS, rF, rIO;
-  std::vector<Idx> up, down;  // up[l]: states of level l + 1 from level l; down[l]: carries into level l
+  Idx rA, rTop, rRes, rOut, rIO, rOne;
+  std::vector<Idx> up, down;  // up[l]: states of level l + 1 from level l; down[l] (l >= 1): carries into level l
 
   // elements per level: n[0] = blocks, n[l + 1] = ceil(n[l] / 3) until at most TOP are left
   static std::vector<uint32_t> level_sizes(uint32_t L) {
@@ -395,19 +447,21 @@ struct PropagateMem {
     return n;
   }
   static uint64_t pool_slots(uint32_t L) {  // per integer
-    uint64_t s = 0;
     const auto n = level_sizes(L);
-    for (size_t l = 0; l < n.size(); ++l) s += n[l] + (l ? n[l] : 0);
+    uint64_t s = L + (n.size() > 1 ? n[1] : 0);  // M, P
+    for (uint32_t v : n) s += 2 * (uint64_t)v;   // W, C
     return s;
   }
   // PBS one propagation issues per integer
   static uint64_t pbs_count(uint32_t L) {
+    if (L == 1) return 1;
     const auto n = level_sizes(L);
     const size_t top = n.size() - 1;
-    uint64_t c = L;                                   // results
-    for (size_t l = 0; l <= top; ++l) c += n[l] - 1;  // states (every element but the last of its level)
+    uint64_t c = 2 * (uint64_t)L;                     // first bootstraps, results
+    for (size_t l = 1; l <= top; ++l) c += n[l] - 1;  // group states (every group but the last of its level)
+    if (top >= 1) c += L / G;                         // state of the first two blocks of every full group
     c += n[top] - 1;                                  // carries into the top elements
-    for (size_t l = 0; l < top; ++l) c += n[l] - (n[l] + G - 1) / G;  // carries into the elements that are not first in their group
+    for (size_t l = 1; l < top; ++l) c += n[l] - (n[l] + G - 1) / G;  // carries into the groups that are not first in theirs
     return c;
   }
 
@@ -423,7 +477,7 @@ struct PropagateMem {
     r.b = up_(b);
     r.o = up_(o);
     r.lut = up_(l);
-    r.count = (uint32_t)std::max(o.size(), l.size());
+    r.count = (uint32_t)l.size();
     return r;
   }
 
@@ -435,41 +489,43 @@ struct PropagateMem {
     const uint32_t L = blocks;
     const auto n = level_sizes(L);
     const size_t top = n.size() - 1;
-    // pool slots: W[l] at wbase[l] + c n[l] + e; C[l] (l >= 1) at cbase[l] + c n[l] + e
-    std::vector<uint64_t> wbase(n.size()), cbase(n.size(), 0);
+    // pool slots: W[l] at wbase[l] + c n[l] + e, C[l] likewise; M at mbase + c L + j; P at pbase + c n[1] + group
+    std::vector<uint64_t> wbase(n.size()), cbase(n.size());
     uint64_t next = 0;
     for (size_t l = 0; l <= top; ++l) wbase[l] = next, next += (uint64_t)cts * n[l];
-    for (size_t l = 1; l <= top; ++l) cbase[l] = next, next += (uint64_t)cts * n[l];
+    for (size_t l = 0; l <= top; ++l) cbase[l] = next, next += (uint64_t)cts * n[l];
+    const uint64_t mbase = next;
+    next += (uint64_t)cts * L;
+    const uint64_t pbase = next;
     auto W = [&](size_t l, uint32_t c, uint32_t e) { return wbase[l] + (uint64_t)c * n[l] + e; };
+    auto M = [&](uint32_t c, uint32_t j) { return mbase + (uint64_t)c * L + j; };
+    auto P = [&](uint32_t c, uint32_t g) { return pbase + (uint64_t)c * n[1] + g; };
     auto T = [&](uint32_t c, uint32_t j) { return (uint64_t)c * L + j; };
     auto shift = [&](size_t l, uint32_t e) { return l == top ? e : e % G; };
-    // where the carry into element e of level l lives: in the pool (levels >= 1, or the slot of the group whose
-    // first element e is) or in S (level 0); e = 0 of an integer receives none
-    struct Where {
-      bool any, in_pool;
-      uint64_t slot;
-    };
-    std::function<Where(size_t, uint32_t, uint32_t)> carry_of = [&](size_t l, uint32_t c, uint32_t e) -> Where {
-      if (e == 0) return {false, false, 0};
+    // pool slot of the carry into element e of level l (the slot of its group's carry for the first element of
+    // a group); e = 0 of an integer receives none
+    std::function<int64_t(size_t, uint32_t, uint32_t)> carry_of = [&](size_t l, uint32_t c, uint32_t e) -> int64_t {
+      if (e == 0) return -1;
       if (l < top && e % G == 0) return carry_of(l + 1, c, e / G);
-      if (l == 0) return {true, false, T(c, e)};
-      return {true, true, cbase[l] + (uint64_t)c * n[l] + e};
+      return (int64_t)(cbase[l] + (uint64_t)c * n[l] + e);
     };
     std::vector<uint64_t> a, b, o, lut;
     auto reset = [&]() { a.clear(), b.clear(), o.clear(), lut.clear(); };
-    // A: v[t] -> W[0][t] for every block whose state somebody reads (all but the last of the integer)
+    // A (two functions per bootstrap): v[t] -> W[0][t], M[t]; out_idx = [function 0 of every block | function 1]
     for (uint32_t c = 0; c < cts; ++c)
-      for (uint32_t j = 0; j + 1 < L; ++j) {
-        a.push_back(T(c, j));
+      for (uint32_t j = 0; j < L; ++j) {
         o.push_back(W(0, c, j));
-        lut.push_back(j == 0 ? LUT_W_FIRST : LUT_W + shift(0, j));
+        lut.push_back(LUT_FIRST2 + (j + 1 == L ? 4 : j == 0 ? 3 : shift(0, j)));
       }
-    rA = make(st, a, {}, o, lut);
-    // up: U of the children -> shifted state of the parent (CSR over the pool; a = offsets, b = members)
+    for (uint32_t c = 0; c < cts; ++c)
+      for (uint32_t j = 0; j < L; ++j) o.push_back(M(c, j));
+    rA = make(st, {}, {}, o, lut);
+    // up: U of the children -> shifted state of the parent (CSR over the pool; a = offsets, b = members); with the
+    // blocks' round also the state of the first two blocks of every full group of three
     for (size_t l = 0; l < top; ++l) {
       reset();
       a.push_back(0);
-      for (uint32_t c = 0; c < cts; ++c)
+      for (uint32_t c = 0; c < cts; ++c) {
         for (uint32_t pp = 0; pp + 1 < n[l + 1]; ++pp) {
           const uint32_t len = std::min(G, n[l] - pp * G);
           for (uint32_t q = 0; q < len; ++q) b.push_back(W(l, c, pp * G + q));
@@ -477,6 +533,14 @@ struct PropagateMem {
           o.push_back(W(l + 1, c, pp));
           lut.push_back(LUT_GROUP + 3 * (len - 1) + shift(l + 1, pp));
         }
+        for (uint32_t pp = 0; l == 0 && pp * G + 2 < L; ++pp) {
+          b.push_back(W(0, c, pp * G));
+          b.push_back(W(0, c, pp * G + 1));
+          a.push_back(b.size());
+          o.push_back(P(c, pp));
+          lut.push_back(LUT_GROUP + 3 * (2 - 1) + 0);
+        }
+      }
       up.push_back(make(st, a, b, o, lut));
     }
     // top: carry into element j = bit j of w_0 + .. + w_(j-1)
@@ -486,90 +550,110 @@ struct PropagateMem {
       for (uint32_t j = 1; j < n[top]; ++j) {
         for (uint32_t i = 0; i < j; ++i) b.push_back(W(top, c, i));
         a.push_back(b.size());
-        o.push_back(carry_of(top, c, j).slot);
+        o.push_back((uint64_t)carry_of(top, c, j));
         lut.push_back(LUT_BIT + j);
       }
     rTop = make(st, a, b, o, lut);
-    // down: carry into element e = 3 p + q (q >= 1) of level l = bit q of (carry into p) + w_(3p) + .. + w_(e-1)
+    // down (levels >= 1): carry into element e = 3 p + q (q >= 1) = bit q of (carry into p) + w_(3p) + .. + w_(e-1)
     down.resize(top);
-    for (size_t l = top; l-- > 0;) {
+    for (size_t l = top; l-- > 1;) {
       reset();
       a.push_back(0);
       for (uint32_t c = 0; c < cts; ++c)
         for (uint32_t e = 0; e < n[l]; ++e) {
           const uint32_t pp = e / G, q = e % G;
           if (q == 0) continue;
-          const Where cin = carry_of(l + 1, c, pp);
-          if (cin.any) b.push_back(cin.slot);  // levels >= 1: always a pool slot
+          const int64_t cin = carry_of(l + 1, c, pp);
+          if (cin >= 0) b.push_back((uint64_t)cin);
           for (uint32_t i = 0; i < q; ++i) b.push_back(W(l, c, pp * G + i));
           a.push_back(b.size());
-          o.push_back(carry_of(l, c, e).slot);
+          o.push_back((uint64_t)carry_of(l, c, e));
           lut.push_back(LUT_BIT + q);
         }
       down[l] = make(st, a, b, o, lut);
     }
-    // F: v += carry (from the pool for the first block of a group, from S otherwise), message extraction
+    // results: 4 m + z; and the output carry of every integer from 4 (state of the last block) + z
+    std::vector<uint64_t> a2{0}, b2, lut2;
     reset();
-    std::vector<uint64_t> o2;
+    a.push_back(0);
     for (uint32_t c = 0; c < cts; ++c)
-      for (uint32_t j = 1; j < L; ++j) {
-        const Where cw = carry_of(0, c, j);
-        if (cw.in_pool) {
-          a.push_back(cw.slot);
-          o.push_back(T(c, j));
+      for (uint32_t j = 0; j < L; ++j) {
+        const size_t before = b.size();
+        bool z_is_bit = true;
+        if (top == 0) {
+          if (j > 0) b.push_back((uint64_t)carry_of(0, c, j));
         } else {
-          o2.push_back(T(c, j));
+          const uint32_t pp = j / G, q = j % G;
+          const int64_t cin = carry_of(1, c, pp);
+          if (cin >= 0) b.push_back((uint64_t)cin);
+          if (q == 1) b.push_back(W(0, c, pp * G));
+          if (q == 2) b.push_back(P(c, pp));
+          z_is_bit = q == 0;
         }
+        if (j + 1 == L) {  // the same z next to the last block's state
+          b2.insert(b2.end(), b.begin() + (std::ptrdiff_t)before, b.end());
+          b2.push_back(W(0, c, j));
+          a2.push_back(b2.size());
+          lut2.push_back(z_is_bit ? LUT_OUT_BIT : LUT_OUT_Z);
+        }
+        b.push_back(M(c, j));
+        a.push_back(b.size());
+        lut.push_back(z_is_bit ? LUT_RES_BIT : LUT_RES_Z);
       }
-    addC = make(st, a, {}, o, {});
-    addS = make(st, {}, {}, o2, {});
+    rRes = make(st, a, b, {}, lut);
+    rOut = make(st, a2, b2, {}, lut2);
+    // optional input carry (added to block 0 of every integer); single-block integers: message and carry of v
     reset();
-    for (uint32_t t = 0; t < cts * L; ++t) lut.push_back(LUT_MSG);
-    rF = make(st, {}, {}, {}, lut);
-    // optional input carry (added to block 0 of every integer) and output carry (x / msg of the last block
-    // once its incoming carry has been added)
-    reset();
+    std::vector<uint64_t> l1;
     for (uint32_t c = 0; c < cts; ++c) {
       a.push_back(T(c, 0));
-      b.push_back(T(c, L - 1));
       lut.push_back(LUT_CARRY);
+      l1.push_back(LUT_MSG);
     }
-    rIO = make(st, a, b, {}, lut);
-    rIO.count = cts;
+    rIO = make(st, a, {}, {}, lut);
+    rOne = make(st, {}, {}, {}, l1);
     cached_cts = cts;
   }
 
   void init(const CudaStreamsFFI &ss, const Params &p, uint32_t num_blocks, uint32_t cts) {
     blocks = num_blocks;
     max_cts = cts;
-    HX_PANIC_IF_FALSE(p.msg * p.carry >= 16 && p.carry >= p.msg,
+    // 4 bits per block: the binary additions of three shifted states; an accumulator of two functions for values up
+    // to 2 msg - 1; results packed as 4 (msg - 1) + 3
+    HX_PANIC_IF_FALSE(p.msg * p.carry >= 16 && p.carry >= p.msg && 4 * p.msg <= p.msg * p.carry,
                       "carry propagation needs at least 4 bits per block (message_modulus * carry_modulus >= 16)");
     // MESSAGE_1_CARRY_3-class sets (msg = 2) are not covered by any test of this layer: refused, not guessed
     HX_PANIC_IF_FALSE(p.msg >= 3, "carry propagation: message_modulus %u < 3 is not supported", p.msg);
     const uint64_t m = p.msg;
-    std::vector<std::function<uint64_t(uint64_t)>> fs(LUT_PROP_COUNT, [](uint64_t) -> uint64_t { return 0; });
+    using F = std::function<uint64_t(uint64_t)>;
+    const size_t lw = (size_t)(p.k + 1) * p.N;
+    std::vector<std::vector<uint64_t>> luts(LUT_PROP_COUNT, std::vector<uint64_t>(lw, 0));
+    auto one = [&](uint64_t id, const F &f) { generate_lut(p, luts[id].data(), f); };
+    const F low4 = [m](uint64_t x) -> uint64_t { return 4 * (x % m); };
     for (uint64_t q = 0; q < G; ++q)
-      fs[LUT_W + q] = [m, q](uint64_t x) -> uint64_t { return (x >= m ? 2 : (x == m - 1 ? 1 : 0)) << q; };
-    fs[LUT_W_FIRST] = [m](uint64_t x) -> uint64_t { return x >= m ? 2 : 0; };
+      generate_many_lut(p, luts[LUT_FIRST2 + q].data(),
+                        {[m, q](uint64_t x) -> uint64_t { return (x >= m ? 2 : (x == m - 1 ? 1 : 0)) << q; }, low4});
+    generate_many_lut(p, luts[LUT_FIRST2 + 3].data(), {[m](uint64_t x) -> uint64_t { return x >= m ? 2 : 0; }, low4});
+    generate_many_lut(p, luts[LUT_FIRST2 + 4].data(),
+                      {[m](uint64_t x) -> uint64_t { return 4 * (x >= m ? 2 : (x == m - 1 ? 1 : 0)); }, low4});
     for (uint64_t len = 1; len <= G; ++len)
       for (uint64_t q = 0; q < G; ++q)
-        fs[LUT_GROUP + 3 * (len - 1) + q] = [len, q](uint64_t u) -> uint64_t {
+        one(LUT_GROUP + 3 * (len - 1) + q, [len, q](uint64_t u) -> uint64_t {
           const uint64_t h0 = (u >> len) & 1, h1 = ((u + 1) >> len) & 1;  // a carry leaves without / with one coming in
           return (h0 ? 2 : (h1 ? 1 : 0)) << q;
-        };
-    for (uint64_t q = 1; q <= G; ++q) fs[LUT_BIT + q] = [q](uint64_t x) -> uint64_t { return (x >> q) & 1; };
-    fs[LUT_MSG] = [m](uint64_t x) -> uint64_t { return x % m; };
-    fs[LUT_CARRY] = [m](uint64_t x) -> uint64_t { return x / m; };
-    std::vector<std::vector<uint64_t>> luts;
-    for (auto &f : fs) {
-      luts.emplace_back((size_t)(p.k + 1) * p.N);
-      generate_lut(p, luts.back().data(), f);
-    }
+        });
+    for (uint64_t q = 1; q <= G; ++q) one(LUT_BIT + q, [q](uint64_t x) -> uint64_t { return (x >> q) & 1; });
+    one(LUT_RES_BIT, [m](uint64_t x) -> uint64_t { return ((x >> 2) + (x & 3)) % m; });
+    one(LUT_RES_Z, [m](uint64_t x) -> uint64_t { return ((x >> 2) + ((x & 3) >= 2)) % m; });
+    // state 2 generated, 1 propagated: a carry leaves if it is generated, or propagated and one arrives
+    one(LUT_OUT_BIT, [](uint64_t x) -> uint64_t { return ((x >> 2) + (x & 3)) >= 2; });
+    one(LUT_OUT_Z, [](uint64_t x) -> uint64_t { return ((x >> 2) + ((x & 3) >= 2)) >= 2; });
+    one(LUT_MSG, [m](uint64_t x) -> uint64_t { return x % m; });
+    one(LUT_CARRY, [m](uint64_t x) -> uint64_t { return x / m; });
     const uint32_t T = cts * num_blocks;
-    drv.init(ss, p, std::min<uint32_t>(T, 1u << 16), luts);
+    drv.init(ss, p, std::min<uint32_t>(T, 1u << 16), luts, 2);
     const size_t w = p.big_n + 1;
     radix_alloc((void **)&d_pool, (size_t)cts * pool_slots(num_blocks) * w * sizeof(uint64_t));
-    radix_alloc((void **)&d_s, (size_t)T * w * sizeof(uint64_t));
     radix_alloc((void **)&d_p, (size_t)T * w * sizeof(uint64_t));
   }
 
@@ -594,24 +678,27 @@ struct PropagateMem {
     const uint32_t w = p.big_n + 1, T = cts * blocks;
     const size_t top = up.size();
     if (carry_in) axpy(st, v, rIO.a, v, rIO.a, 1, carry_in, nullptr, w, cts);
-    // A: shifted state of every block; up: shifted states of the groups, level by level
-    if (rA.count) drv.round(ss, d_pool, rA.o, v, rA.a, rA.lut, rA.count, ksks, bsks);
+    if (blocks == 1) {  // nothing to propagate: the carry leaves the integer
+      if (carry_out) drv.round(ss, carry_out, nullptr, v, nullptr, rIO.lut, cts, ksks, bsks);
+      drv.round(ss, v, nullptr, v, nullptr, rOne.lut, cts, ksks, bsks);
+      return;
+    }
+    // A: shifted state and 4 (value % msg) of every block; up: shifted states of the groups, level by level
+    drv.round(ss, d_pool, rA.o, v, nullptr, rA.lut, T, ksks, bsks, 2, many_lut_stride(p, 2));
     for (const Idx &r : up) summed_round(ss, d_pool, r, w, ksks, bsks);
-    // carries: top level, then down to the blocks (level 0 carries go to S)
-    summed_round(ss, top == 0 ? d_s : d_pool, rTop, w, ksks, bsks);
-    for (size_t l = top; l-- > 0;) summed_round(ss, l == 0 ? d_s : d_pool, down[l], w, ksks, bsks);
-    // F: add the carries, extract the messages
-    axpy(st, v, addC.o, v, addC.o, 1, d_pool, addC.a, w, addC.count);
-    axpy(st, v, addS.o, v, addS.o, 1, d_s, addS.o, w, addS.count);
-    if (carry_out) drv.round(ss, carry_out, nullptr, v, rIO.b, rIO.lut, cts, ksks, bsks);
-    drv.round(ss, v, nullptr, v, nullptr, rF.lut, T, ksks, bsks);
+    // carries: top level, then down to the groups of three blocks
+    summed_round(ss, d_pool, rTop, w, ksks, bsks);
+    for (size_t l = top; l-- > 1;) summed_round(ss, d_pool, down[l], w, ksks, bsks);
+    // results (and the output carry) from 4 m + z
+    if (carry_out) summed_round(ss, carry_out, rOut, w, ksks, bsks);
+    summed_round(ss, v, rRes, w, ksks, bsks);
   }
 
   void release(const CudaStreamsFFI &ss) {
     drv.release(ss);
     for (auto *d : dev_arrays) HX_CHECK(hipFree(d));
     dev_arrays.clear();
-    for (uint64_t *d : {d_pool, d_s, d_p})
+    for (uint64_t *d : {d_pool, d_p})
       if (d) HX_CHECK(hipFree(d));
     magic = 0;
   }
@@ -672,7 +759,7 @@ struct MulMem {
         // Many integers per call (throughput): only full groups are summed — a group of `chunk` terms removes
         // chunk - 2 of them for two PBS, a shorter one removes fewer (a pair: none) for the same price — and what
         // is left of a column waits for the next step, unless no column can fill a group any more (3.3 % fewer
-        // PBS per 32-block multiplication: 1,788 instead of 1,850; three more but small rounds).  Few integers
+        // PBS per 32-block multiplication: 1,778 instead of 1,840; three more but small rounds).  Few integers
         // (latency): every term is grouped at once, which needs the fewest rounds.
         const bool wide = max_cts >= 8, only_full = wide && n >= chunk;
         while (pos < n) {
