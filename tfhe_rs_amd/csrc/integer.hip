@@ -655,6 +655,7 @@ struct PropagateMem {
     const size_t w = p.big_n + 1;
     radix_alloc((void **)&d_pool, (size_t)cts * pool_slots(num_blocks) * w * sizeof(uint64_t));
     radix_alloc((void **)&d_p, (size_t)T * w * sizeof(uint64_t));
+    if (!t_dry) build_indexes(S0(ss), cts);  // a call with fewer integers rebuilds them
   }
 
   // dense sums of a round's CSR groups, then one KS -> PBS round on them
@@ -819,43 +820,57 @@ struct MulMem {
     radix_alloc((void **)&d_pack, (size_t)sub * n_prod * w * sizeof(uint64_t));
     radix_alloc((void **)&d_sum, std::max<size_t>(1, (size_t)sub * max_groups) * w * sizeof(uint64_t));
     prop.init(ss, p, num_blocks, sub);
+    if (!t_dry) {
+      build_pass(S0(ss), std::min(sub, cts));
+      if (std::min(sub, cts) != sub) prop.build_indexes(S0(ss), std::min(sub, cts));
+    }
   }
 
-  // lhs <- lhs * rhs for `cts` integers
-  void run(const CudaStreamsFFI &ss, uint64_t *lhs, const uint64_t *rhs, uint32_t cts, void *const *ksks,
-           void *const *bsks) {
-    const hipStream_t st = S0(ss);
-    HX_PANIC_IF_FALSE(cts >= 1 && cts <= max_cts, "multiplication: %u integers exceed the scratch capacity %u", cts,
-                      max_cts);
-    const Params &p = drv.p;
-    const uint32_t L = blocks, w = p.big_n + 1;
+  // device index arrays of one pass over nb integers (built when the scratch is created, rebuilt if a call
+  // brings another count): block products, every column-sum step, the final additions
+  struct PassIdx {
+    uint32_t nb = 0;
+    std::vector<uint64_t *> owned;
+    uint64_t *pa = nullptr, *pb = nullptr, *po = nullptr, *pl = nullptr;
+    struct StepIdx {
+      uint64_t *off = nullptr, *mem = nullptr, *in = nullptr, *out = nullptr, *lut = nullptr;
+      uint32_t groups = 0, count = 0;
+    };
+    std::vector<StepIdx> steps;
+    uint64_t *fo = nullptr, *fa = nullptr, *fb = nullptr, *fo1 = nullptr, *fa1 = nullptr;
+    uint32_t n2 = 0, n1 = 0;
+  } pass;
+
+  void free_pass() {
+    for (auto *d : pass.owned) HX_CHECK(hipFree(d));
+    pass = PassIdx();
+  }
+
+  void build_pass(hipStream_t st, uint32_t nb) {
+    free_pass();
+    pass.nb = nb;
+    const uint32_t L = blocks;
     const size_t n_prod = prod_slot.size();
-    for (uint32_t c0 = 0; c0 < cts; c0 += sub) {
-      const uint32_t nb = std::min(sub, cts - c0);
-      uint64_t *l0 = lhs + (size_t)c0 * L * w;
-      const uint64_t *r0 = rhs + (size_t)c0 * L * w;
-      std::vector<uint64_t *> tmp;
-      auto up = [&](const std::vector<uint64_t> &h) {
-        uint64_t *d = dev_upload(st, h);
-        if (d) tmp.push_back(d);
-        return d;
-      };
-      {  // block products
-        std::vector<uint64_t> a(nb * n_prod), b(nb * n_prod), o(nb * n_prod), l(nb * n_prod);
-        for (uint32_t c = 0; c < nb; ++c)
-          for (size_t q = 0; q < n_prod; ++q) {
-            a[c * n_prod + q] = (uint64_t)c * L + prod_lhs[q];
-            b[c * n_prod + q] = (uint64_t)c * L + prod_rhs[q];
-            o[c * n_prod + q] = (uint64_t)c * slots + prod_slot[q];
-            l[c * n_prod + q] = prod_lut[q];
-          }
-        uint64_t *da = up(a), *db = up(b), *dout = up(o), *dl = up(l);
-        axpy(st, d_pack, nullptr, l0, da, p.msg, r0, db, w, (uint32_t)(nb * n_prod));
-        drv.round(ss, d_pool, dout, d_pack, nullptr, dl, (uint32_t)(nb * n_prod), ksks, bsks);
-      }
-      for (const Step &s : steps) {  // column sums
-        const size_t G = s.msg_slot.size();
-        if (G == 0) continue;
+    auto up = [&](const std::vector<uint64_t> &h) {
+      uint64_t *d = dev_upload(st, h);
+      if (d) pass.owned.push_back(d);
+      return d;
+    };
+    {  // block products
+      std::vector<uint64_t> a(nb * n_prod), b(nb * n_prod), o(nb * n_prod), l(nb * n_prod);
+      for (uint32_t c = 0; c < nb; ++c)
+        for (size_t q = 0; q < n_prod; ++q) {
+          a[c * n_prod + q] = (uint64_t)c * L + prod_lhs[q];
+          b[c * n_prod + q] = (uint64_t)c * L + prod_rhs[q];
+          o[c * n_prod + q] = (uint64_t)c * slots + prod_slot[q];
+          l[c * n_prod + q] = prod_lut[q];
+        }
+      pass.pa = up(a), pass.pb = up(b), pass.po = up(o), pass.pl = up(l);
+    }
+    for (const Step &s : steps) {  // column sums
+      PassIdx::StepIdx si;
+      const size_t G = s.msg_slot.size();
+      if (G != 0) {
         std::vector<uint64_t> off(nb * G + 1), mem(nb * s.members.size());
         std::vector<uint64_t> in, out, lut;
         for (uint32_t c = 0; c < nb; ++c) {
@@ -873,35 +888,67 @@ struct MulMem {
           for (size_t m = 0; m < s.members.size(); ++m) mem[c * s.members.size() + m] = (uint64_t)c * slots + s.members[m];
         }
         off[nb * G] = nb * s.members.size();
-        uint64_t *doff = up(off), *dmem = up(mem);
-        HX_LAUNCH(lwe_group_sum_kernel, dim3((unsigned)(nb * G)), dim3(256), 0, st, d_sum, d_pool, doff, dmem, w,
-                  (uint32_t)(nb * G));
-        drv.round(ss, d_pool, up(out), d_sum, up(in), up(lut), (uint32_t)in.size(), ksks, bsks);
+        si.off = up(off), si.mem = up(mem), si.in = up(in), si.out = up(out), si.lut = up(lut);
+        si.groups = (uint32_t)(nb * G);
+        si.count = (uint32_t)in.size();
       }
-      {  // at most two terms per column: add them into lhs, then propagate the carries
-        std::vector<uint64_t> a, b, o, a1, o1;
-        for (uint32_t c = 0; c < nb; ++c)
-          for (uint32_t col = 0; col < L; ++col) {
-            const auto &v = final_cols[col];
-            if (v.size() == 2) {
-              a.push_back((uint64_t)c * slots + v[0]);
-              b.push_back((uint64_t)c * slots + v[1]);
-              o.push_back((uint64_t)c * L + col);
-            } else {
-              a1.push_back((uint64_t)c * slots + v[0]);
-              o1.push_back((uint64_t)c * L + col);
-            }
+      pass.steps.push_back(si);
+    }
+    {  // at most two terms per column
+      std::vector<uint64_t> a, b, o, a1, o1;
+      for (uint32_t c = 0; c < nb; ++c)
+        for (uint32_t col = 0; col < L; ++col) {
+          const auto &v = final_cols[col];
+          if (v.size() == 2) {
+            a.push_back((uint64_t)c * slots + v[0]);
+            b.push_back((uint64_t)c * slots + v[1]);
+            o.push_back((uint64_t)c * L + col);
+          } else {
+            a1.push_back((uint64_t)c * slots + v[0]);
+            o1.push_back((uint64_t)c * L + col);
           }
-        axpy(st, l0, up(o), d_pool, up(a), 1, d_pool, up(b), w, (uint32_t)a.size());
-        axpy(st, l0, up(o1), d_pool, up(a1), 1, nullptr, nullptr, w, (uint32_t)a1.size());
-        prop.run(ss, l0, nb, ksks, bsks);
+        }
+      pass.fo = up(o), pass.fa = up(a), pass.fb = up(b), pass.fo1 = up(o1), pass.fa1 = up(a1);
+      pass.n2 = (uint32_t)a.size();
+      pass.n1 = (uint32_t)a1.size();
+    }
+  }
+
+  // lhs <- lhs * rhs for `cts` integers
+  void run(const CudaStreamsFFI &ss, uint64_t *lhs, const uint64_t *rhs, uint32_t cts, void *const *ksks,
+           void *const *bsks) {
+    const hipStream_t st = S0(ss);
+    HX_PANIC_IF_FALSE(cts >= 1 && cts <= max_cts, "multiplication: %u integers exceed the scratch capacity %u", cts,
+                      max_cts);
+    const Params &p = drv.p;
+    const uint32_t L = blocks, w = p.big_n + 1;
+    const size_t n_prod = prod_slot.size();
+    for (uint32_t c0 = 0; c0 < cts; c0 += sub) {
+      const uint32_t nb = std::min(sub, cts - c0);
+      uint64_t *l0 = lhs + (size_t)c0 * L * w;
+      const uint64_t *r0 = rhs + (size_t)c0 * L * w;
+      if (pass.nb != nb) {
+        HX_CHECK(hipStreamSynchronize(st));  // the previous pass may still read its arrays
+        build_pass(st, nb);
       }
-      HX_CHECK(hipStreamSynchronize(st));
-      for (auto *d : tmp) HX_CHECK(hipFree(d));
+      // block products
+      axpy(st, d_pack, nullptr, l0, pass.pa, p.msg, r0, pass.pb, w, (uint32_t)(nb * n_prod));
+      drv.round(ss, d_pool, pass.po, d_pack, nullptr, pass.pl, (uint32_t)(nb * n_prod), ksks, bsks);
+      for (const auto &si : pass.steps) {  // column sums
+        if (si.groups == 0) continue;
+        HX_LAUNCH(lwe_group_sum_kernel, dim3(si.groups), dim3(256), 0, st, d_sum, d_pool, si.off, si.mem, w, si.groups);
+        drv.round(ss, d_pool, si.out, d_sum, si.in, si.lut, si.count, ksks, bsks);
+      }
+      // at most two terms per column: add them into lhs, then propagate the carries
+      axpy(st, l0, pass.fo, d_pool, pass.fa, 1, d_pool, pass.fb, w, pass.n2);
+      axpy(st, l0, pass.fo1, d_pool, pass.fa1, 1, nullptr, nullptr, w, pass.n1);
+      prop.run(ss, l0, nb, ksks, bsks);
     }
   }
 
   void release(const CudaStreamsFFI &ss) {
+    HX_CHECK(hipStreamSynchronize(S0(ss)));
+    free_pass();
     drv.release(ss);
     prop.release(ss);
     if (d_pool) HX_CHECK(hipFree(d_pool));
