@@ -650,7 +650,7 @@ def main():
             lat = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
             result["extra"]["fheuint64_single_operation_latency"] = {
                 "params": C4G4.name, "add_ms": lat[0]["operation_ms"], "mul_ms": lat[1]["operation_ms"],
-                "note": "one ciphertext pair, one stream, one GPU: nine (add) dependent KS -> multi-bit PBS rounds; the "
+                "note": "one ciphertext pair, one stream, one GPU: six (add) dependent KS -> multi-bit PBS rounds; the "
                         "reference publishes 9.52 / 31.9 ms with the blocks of a round spread over 8 x H100"}
         except Exception as e:  # noqa: BLE001
             result["extra"]["fheuint64_single_operation_latency"] = {"error": f"{e.__class__.__name__}: {e}"[:300]}
