@@ -724,65 +724,108 @@ struct MulMem {
   };
   std::vector<uint64_t> prod_lhs, prod_rhs, prod_slot, prod_lut;  // products
   std::vector<Step> steps;
-  std::vector<std::vector<uint64_t>> final_cols;  // <= 2 slots per column
+  std::vector<std::vector<uint64_t>> final_cols;  // what is left of every column: degrees adding up to 2 msg - 2 at most
 
+  // The column sums are planned on the largest value every term can take (its degree): a low half of a block
+  // product is at most msg - 1, a high half at most (msg - 1)^2 / msg (2 for msg = 4), the carry of a sum S at most
+  // S / msg.  A group may hold any terms whose degrees add up to msg * carry - 1 at most (the reference's
+  // sum_ciphertexts uses the fixed chunk (msg carry - 1) / (msg - 1) = 5; groups of three products' low and three
+  // high halves, or seven carries, fit as well), and a column is finished once its degrees add up to 2 msg - 2,
+  // what one carry propagation accepts — however many terms that is.
   void plan() {
-    const uint32_t L = blocks, chunk = (drv.p.msg * drv.p.carry - 1) / (drv.p.msg - 1);
+    const uint32_t L = blocks, m = drv.p.msg;
+    const uint32_t cap = drv.p.msg * drv.p.carry - 1, final_cap = 2 * m - 2;
     std::vector<std::vector<uint64_t>> cols(L);
+    std::vector<uint32_t> deg;  // by pool slot
     uint64_t next = 0;
+    // TFHE_HIP_MUL_PLAN=uniform (measurements only): every term counted at msg - 1, which is the fixed-chunk plan
+    const char *plan_env = getenv("TFHE_HIP_MUL_PLAN");
+    const bool uniform = plan_env && std::string(plan_env) == "uniform";
+    auto new_slot = [&](uint32_t d) {
+      deg.push_back(uniform ? m - 1 : d);
+      return next++;
+    };
     for (uint32_t i = 0; i < L; ++i)
       for (uint32_t j = 0; i + j < L; ++j) {
         prod_lhs.push_back(j);
         prod_rhs.push_back(i);
         prod_lut.push_back(0);
         prod_slot.push_back(next);
-        cols[i + j].push_back(next++);
+        cols[i + j].push_back(new_slot(m - 1));
         if (i + j + 1 < L) {
           prod_lhs.push_back(j);
           prod_rhs.push_back(i);
           prod_lut.push_back(1);
           prod_slot.push_back(next);
-          cols[i + j + 1].push_back(next++);
+          cols[i + j + 1].push_back(new_slot((m - 1) * (m - 1) / m));
         }
       }
-    auto max_len = [&]() {
-      size_t m = 0;
-      for (auto &c : cols) m = std::max(m, c.size());
-      return m;
+    auto total = [&](const std::vector<uint64_t> &c) {
+      uint32_t t = 0;
+      for (uint64_t x : c) t += deg[x];
+      return t;
     };
-    while (max_len() > 2) {
+    auto unfinished = [&]() {
+      for (auto &c : cols)
+        if (total(c) > final_cap) return true;
+      return false;
+    };
+    // Many integers per call (throughput): a group costs two PBS whatever it holds, so only well-filled groups
+    // (four terms or more, degrees adding up to cap - 2 at least) are summed while any column can form one — what is
+    // left of a column waits for the next step (1,675 PBS per 32-block multiplication, three or four more but small
+    // rounds).  Few integers (latency): every term is grouped at once, which needs the fewest rounds (1,730).
+    const bool wide = max_cts >= 8;
+    while (unfinished()) {
+      // first-fit decreasing: the terms of an unfinished column, largest degree first, into groups of capacity cap
+      std::vector<std::vector<std::vector<uint64_t>>> groups(L);
+      bool any_good = false;
+      auto good = [&](const std::vector<uint64_t> &g) { return g.size() >= 4 && total(g) + 2 >= cap; };
+      for (uint32_t c = 0; c < L; ++c) {
+        if (total(cols[c]) <= final_cap) continue;
+        std::vector<uint64_t> sorted = cols[c];
+        std::stable_sort(sorted.begin(), sorted.end(), [&](uint64_t x, uint64_t y) { return deg[x] > deg[y]; });
+        for (uint64_t x : sorted) {
+          bool placed = false;
+          for (auto &g : groups[c])
+            if (total(g) + deg[x] <= cap) {
+              g.push_back(x);
+              placed = true;
+              break;
+            }
+          if (!placed) groups[c].push_back({x});
+        }
+        for (auto &g : groups[c]) any_good = any_good || good(g);
+      }
       Step s;
       s.offsets.push_back(0);
       std::vector<std::vector<uint64_t>> nc(L);
       for (uint32_t c = 0; c < L; ++c) {
-        size_t pos = 0;
-        const size_t n = cols[c].size();
-        // Many integers per call (throughput): only full groups are summed — a group of `chunk` terms removes
-        // chunk - 2 of them for two PBS, a shorter one removes fewer (a pair: none) for the same price — and what
-        // is left of a column waits for the next step, unless no column can fill a group any more (3.3 % fewer
-        // PBS per 32-block multiplication: 1,778 instead of 1,840; three more but small rounds).  Few integers
-        // (latency): every term is grouped at once, which needs the fewest rounds.
-        const bool wide = max_cts >= 8, only_full = wide && n >= chunk;
-        while (pos < n) {
-          size_t len = only_full && n - pos < chunk ? 1 : std::min<size_t>(chunk, n - pos);
-          if (wide && len == 2) len = 1;  // a pair would come back as a pair (message + carry)
-          if (len == 1) {  // nothing to add: the term stays as it is
-            nc[c].push_back(cols[c][pos]);
-          } else {
-            for (size_t m = 0; m < len; ++m) s.members.push_back(cols[c][pos + m]);
-            s.offsets.push_back(s.members.size());
-            s.msg_slot.push_back(next);
-            nc[c].push_back(next++);
-            if (c + 1 < L) {
-              s.carry_slot.push_back(next);
-              nc[c + 1].push_back(next++);
-            } else {
-              s.carry_slot.push_back(~(uint64_t)0);
-            }
+        if (groups[c].empty()) {  // finished column: stays as it is
+          nc[c].insert(nc[c].end(), cols[c].begin(), cols[c].end());
+          continue;
+        }
+        for (auto &g : groups[c]) {
+          const bool emit = g.size() >= 2 && (!wide || (any_good ? good(g) : g.size() >= 3));
+          if (!emit) {
+            nc[c].insert(nc[c].end(), g.begin(), g.end());
+            continue;
           }
-          pos += len;
+          const uint32_t sum = total(g);
+          s.members.insert(s.members.end(), g.begin(), g.end());
+          s.offsets.push_back(s.members.size());
+          const uint64_t ms = new_slot(std::min(m - 1, sum));
+          s.msg_slot.push_back(ms);
+          nc[c].push_back(ms);
+          if (c + 1 < L && sum >= m) {
+            const uint64_t cs = new_slot(sum / m);
+            s.carry_slot.push_back(cs);
+            nc[c + 1].push_back(cs);
+          } else {
+            s.carry_slot.push_back(~(uint64_t)0);
+          }
         }
       }
+      HX_PANIC_IF_FALSE(!s.msg_slot.empty(), "multiplication plan: no progress");
       cols.swap(nc);
       steps.push_back(std::move(s));
     }
@@ -837,8 +880,7 @@ struct MulMem {
       uint32_t groups = 0, count = 0;
     };
     std::vector<StepIdx> steps;
-    uint64_t *fo = nullptr, *fa = nullptr, *fb = nullptr, *fo1 = nullptr, *fa1 = nullptr;
-    uint32_t n2 = 0, n1 = 0;
+    uint64_t *foff = nullptr, *fmem = nullptr;
   } pass;
 
   void free_pass() {
@@ -894,23 +936,14 @@ struct MulMem {
       }
       pass.steps.push_back(si);
     }
-    {  // at most two terms per column
-      std::vector<uint64_t> a, b, o, a1, o1;
+    {  // what is left of every column (degrees adding up to 2 msg - 2 at most): CSR over the pool, in lhs order
+      std::vector<uint64_t> off{0}, mem;
       for (uint32_t c = 0; c < nb; ++c)
         for (uint32_t col = 0; col < L; ++col) {
-          const auto &v = final_cols[col];
-          if (v.size() == 2) {
-            a.push_back((uint64_t)c * slots + v[0]);
-            b.push_back((uint64_t)c * slots + v[1]);
-            o.push_back((uint64_t)c * L + col);
-          } else {
-            a1.push_back((uint64_t)c * slots + v[0]);
-            o1.push_back((uint64_t)c * L + col);
-          }
+          for (uint64_t x : final_cols[col]) mem.push_back((uint64_t)c * slots + x);
+          off.push_back(mem.size());
         }
-      pass.fo = up(o), pass.fa = up(a), pass.fb = up(b), pass.fo1 = up(o1), pass.fa1 = up(a1);
-      pass.n2 = (uint32_t)a.size();
-      pass.n1 = (uint32_t)a1.size();
+      pass.foff = up(off), pass.fmem = up(mem);
     }
   }
 
@@ -939,9 +972,8 @@ struct MulMem {
         HX_LAUNCH(lwe_group_sum_kernel, dim3(si.groups), dim3(256), 0, st, d_sum, d_pool, si.off, si.mem, w, si.groups);
         drv.round(ss, d_pool, si.out, d_sum, si.in, si.lut, si.count, ksks, bsks);
       }
-      // at most two terms per column: add them into lhs, then propagate the carries
-      axpy(st, l0, pass.fo, d_pool, pass.fa, 1, d_pool, pass.fb, w, pass.n2);
-      axpy(st, l0, pass.fo1, d_pool, pass.fa1, 1, nullptr, nullptr, w, pass.n1);
+      // the remaining terms of every column added into lhs, then one carry propagation
+      HX_LAUNCH(lwe_group_sum_kernel, dim3(nb * L), dim3(256), 0, st, l0, d_pool, pass.foff, pass.fmem, w, nb * L);
       prop.run(ss, l0, nb, ksks, bsks);
     }
   }
