@@ -21,6 +21,7 @@
 
 #include <algorithm>
 #include <functional>
+#include <string>
 #include <vector>
 
 namespace tfhe_hip {
