@@ -61,6 +61,7 @@ TOY_K1_L1 = Params("toy_k1_N512_l1", 32, 1, 512, 23, 1, 4, 5, 40, 12, 4, ms_type
 TOY_K2 = Params("toy_k2_N256", 20, 2, 256, 12, 3, 3, 6, 40, 20, 4, ms_type=1)
 TOY_K3 = Params("toy_k3_N512", 16, 3, 512, 18, 2, 4, 5, 40, 18, 8, ms_type=0)
 TOY_2048 = Params("toy_k1_N2048_l1", 12, 1, 2048, 23, 1, 4, 4, 45, 17, 16, ms_type=1)
+TOY_2048_P64 = Params("toy_k1_N2048_l1_p64", 12, 1, 2048, 23, 1, 4, 4, 45, 17, 64, ms_type=1)   # 3 message + 3 carry bits
 TOY_2048_L2 = Params("toy_k1_N2048_l2", 9, 1, 2048, 15, 2, 3, 6, 45, 17, 16, ms_type=0)
 TOY_1024_K2 = Params("toy_k2_N1024_l1", 10, 2, 1024, 23, 1, 3, 5, 46, 24, 8, ms_type=0)
 TOY_1024_K1_L2 = Params("toy_k1_N1024_l2", 11, 1, 1024, 15, 2, 3, 5, 46, 20, 8, ms_type=1)

@@ -9,14 +9,14 @@ import numpy as np
 import pytest
 
 from . import oracle as orc
-from .common import C1, TOY_2048, decrypt_big, encrypt_big, make_keys
+from .common import C1, TOY_2048, TOY_2048_P64, decrypt_big, encrypt_big, make_keys
 from .harness import use_backend
 
 BACKENDS = [pytest.param("emu", id="emu"), pytest.param("hip", id="hip", marks=pytest.mark.gpu)]
 MSG = 4  # message_modulus = carry_modulus = 4
 
 
-def setup(kind, p=None, gpu_indexes=(0,)):
+def setup(kind, p=None, gpu_indexes=(0,), msg=MSG):
     from tfhe_rs_amd import core_crypto_gpu as gpu
     from tfhe_rs_amd import integer_gpu as igpu
     use_backend(kind)
@@ -30,12 +30,12 @@ def setup(kind, p=None, gpu_indexes=(0,)):
     else:
         bsk = gpu.CudaLweBootstrapKey.from_lwe_bootstrap_key(keys.bsk, p.n, p.k, p.N, p.pbs_base_log, p.pbs_level, st,
                                                              ms_noise_reduction=bool(p.ms_type))
-    return p, keys, st, igpu.CudaServerKey(ksk, bsk, MSG, MSG), igpu
+    return p, keys, st, igpu.CudaServerKey(ksk, bsk, msg, msg), igpu
 
 
-def encrypt_radix(p, keys, values, num_blocks, seed):
-    """[integer][block] big-key encryptions of the base-4 digits, least significant first."""
-    digits = [[(int(v) >> (2 * j)) & 3 for j in range(num_blocks)] for v in values]
+def encrypt_radix(p, keys, values, num_blocks, seed, msg=MSG):
+    """[integer][block] big-key encryptions of the base-msg digits, least significant first."""
+    digits = [[(int(v) // msg ** j) % msg for j in range(num_blocks)] for v in values]
     flat = encrypt_big(p, keys, [d for row in digits for d in row], seed=seed)
     return flat.reshape(len(values), num_blocks, -1)
 
@@ -44,8 +44,8 @@ def decrypt_blocks(p, keys, blocks):
     return [[decrypt_big(p, keys, b) for b in row] for row in blocks]
 
 
-def recompose(rows):
-    return [sum(int(d) << (2 * j) for j, d in enumerate(row)) for row in rows]
+def recompose(rows, msg=MSG):
+    return [sum(int(d) * msg ** j for j, d in enumerate(row)) for row in rows]
 
 
 @pytest.mark.parametrize("kind", BACKENDS)
@@ -119,6 +119,30 @@ def test_add_at_the_widths_where_the_carry_tree_changes_shape(kind):
         assert recompose(decrypt_blocks(p, keys, ca.to_blocks(st))) == [f & mask for f in full], L
         assert [r[0] for r in decrypt_blocks(p, keys, cout.to_blocks(st))] == [f >> bits for f in full], L
         assert int(igpu._lib().hip_integer_propagate_pbs_count(L)) == {1: 1, 2: 5, 4: 11, 10: 29, 13: 39}[L]
+
+
+def test_add_and_mul_with_three_message_and_three_carry_bits():
+    """message_modulus = carry_modulus = 8 (the MESSAGE_3_CARRY_3 shape) on a toy key: nothing in the carry tree, the
+    two-function first bootstrap, the 4 m + z results or the column sums planned on bounds is specific to base 4."""
+    m = 8
+    p, keys, st, sks, igpu = setup("emu", p=TOY_2048_P64, msg=m)
+    L = 5
+    top = m ** L
+    a = [top - 1, 0o52525, 0o17071]
+    b = [1, 0o25253, 0o60707]
+    ca = igpu.CudaUnsignedRadixCiphertext.from_blocks(encrypt_radix(p, keys, a, L, 61, m), st)
+    cb = igpu.CudaUnsignedRadixCiphertext.from_blocks(encrypt_radix(p, keys, b, L, 62, m), st)
+    cm = ca.duplicate(st)
+    cout = sks.add_assign(ca, cb, st, want_carry_out=True)
+    full = [x + y for x, y in zip(a, b)]
+    rows = decrypt_blocks(p, keys, ca.to_blocks(st))
+    assert all(d < m for r in rows for d in r)
+    assert recompose(rows, m) == [f % top for f in full]
+    assert [r[0] for r in decrypt_blocks(p, keys, cout.to_blocks(st))] == [f // top for f in full]
+    sks.mul_assign(cm, cb, st)
+    rows = decrypt_blocks(p, keys, cm.to_blocks(st))
+    assert all(d < m for r in rows for d in r)
+    assert recompose(rows, m) == [(x * y) % top for x, y in zip(a, b)]
 
 
 @pytest.mark.parametrize("many", [False, True], ids=["few_integers", "many_integers"])

@@ -190,6 +190,10 @@ if __name__ == "__main__":
             for B in (128, 192, 256, 384, 512):
                 for kern in (5, 2):
                     pbs_case(p, B, kernel=kern, steps=3)
+    if "mbmid" in which:  # mid-size batches (the rounds of ONE multiplication): key loads shared by LWE pairs (2) or not (7)
+        for B in (384, 512, 768, 1024, 2048):
+            for kern in (2, 7):
+                pbs_case(C4G4, B, kernel=kern, steps=3)
     if "mblat" in which:  # multi-bit latency path: products on the latency kernel (5) or the generic kernels (6)
         for p in (C4G4, C4):
             for kern in (5, 6):
