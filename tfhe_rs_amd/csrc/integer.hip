@@ -729,13 +729,14 @@ struct MulMem {
 
   // The column sums are planned on the largest value every term can take (its degree): a low half of a block
   // product is at most msg - 1, a high half at most (msg - 1)^2 / msg (2 for msg = 4), the carry of a sum S at most
-  // S / msg.  A group may hold any terms whose degrees add up to msg * carry - 1 at most (the reference's
-  // sum_ciphertexts uses the fixed chunk (msg carry - 1) / (msg - 1) = 5; groups of three products' low and three
-  // high halves, or seven carries, fit as well), and a column is finished once its degrees add up to 2 msg - 2,
-  // what one carry propagation accepts — however many terms that is.
+  // S / msg.  A group holds at most max_terms = (msg carry - 1) / (msg - 1) = 5 terms — every term is a fresh
+  // bootstrap output, and that count is the noise level the parameter sets are made for (shortint MaxNoiseLevel;
+  // it is also the reference's fixed chunk in sum_ciphertexts) — whose degrees add up to msg * carry - 1 at most;
+  // a group whose degrees stay below msg emits no carry, and a column is finished once it has at most max_terms
+  // terms whose degrees add up to 2 msg - 2, what one carry propagation accepts.
   void plan() {
     const uint32_t L = blocks, m = drv.p.msg;
-    const uint32_t cap = drv.p.msg * drv.p.carry - 1, final_cap = 2 * m - 2;
+    const uint32_t cap = drv.p.msg * drv.p.carry - 1, final_cap = 2 * m - 2, max_terms = cap / (m - 1);
     std::vector<std::vector<uint64_t>> cols(L);
     std::vector<uint32_t> deg;  // by pool slot
     uint64_t next = 0;
@@ -766,29 +767,32 @@ struct MulMem {
       for (uint64_t x : c) t += deg[x];
       return t;
     };
+    auto finished = [&](const std::vector<uint64_t> &c) { return total(c) <= final_cap && c.size() <= max_terms; };
     auto unfinished = [&]() {
       for (auto &c : cols)
-        if (total(c) > final_cap) return true;
+        if (!finished(c)) return true;
       return false;
     };
     // Many integers per call (throughput): a group costs two PBS whatever it holds, so only well-filled groups
-    // (four terms or more, degrees adding up to cap - 2 at least) are summed while any column can form one — what is
-    // left of a column waits for the next step (1,675 PBS per 32-block multiplication, three or four more but small
-    // rounds).  Few integers (latency): every term is grouped at once, which needs the fewest rounds (1,730).
+    // (max_terms terms, or four with degrees adding up to cap - 2 at least) are summed while any column can form one —
+    // what is left of a column waits for the next step (1,762 PBS per 32-block multiplication, three more but small
+    // rounds).  Few integers (latency): every term is grouped at once, which needs the fewest rounds (1,804).
     const bool wide = max_cts >= 8;
     while (unfinished()) {
       // first-fit decreasing: the terms of an unfinished column, largest degree first, into groups of capacity cap
       std::vector<std::vector<std::vector<uint64_t>>> groups(L);
       bool any_good = false;
-      auto good = [&](const std::vector<uint64_t> &g) { return g.size() >= 4 && total(g) + 2 >= cap; };
+      auto good = [&](const std::vector<uint64_t> &g) {
+        return g.size() >= max_terms || (g.size() >= 4 && total(g) + 2 >= cap);
+      };
       for (uint32_t c = 0; c < L; ++c) {
-        if (total(cols[c]) <= final_cap) continue;
+        if (finished(cols[c])) continue;
         std::vector<uint64_t> sorted = cols[c];
         std::stable_sort(sorted.begin(), sorted.end(), [&](uint64_t x, uint64_t y) { return deg[x] > deg[y]; });
         for (uint64_t x : sorted) {
           bool placed = false;
           for (auto &g : groups[c])
-            if (total(g) + deg[x] <= cap) {
+            if (g.size() < max_terms && total(g) + deg[x] <= cap) {
               g.push_back(x);
               placed = true;
               break;
