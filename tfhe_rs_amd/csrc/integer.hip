@@ -21,7 +21,6 @@
 
 #include <algorithm>
 #include <functional>
-#include <string>
 #include <vector>
 
 namespace tfhe_hip {
@@ -740,11 +739,8 @@ struct MulMem {
     std::vector<std::vector<uint64_t>> cols(L);
     std::vector<uint32_t> deg;  // by pool slot
     uint64_t next = 0;
-    // TFHE_HIP_MUL_PLAN=uniform (measurements only): every term counted at msg - 1, which is the fixed-chunk plan
-    const char *plan_env = getenv("TFHE_HIP_MUL_PLAN");
-    const bool uniform = plan_env && std::string(plan_env) == "uniform";
     auto new_slot = [&](uint32_t d) {
-      deg.push_back(uniform ? m - 1 : d);
+      deg.push_back(d);
       return next++;
     };
     for (uint32_t i = 0; i < L; ++i)
