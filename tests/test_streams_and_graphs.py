@@ -200,7 +200,7 @@ def test_concurrent_host_threads_on_their_own_streams_share_the_keys():
 @pytest.mark.parametrize("which", ["classic", "multi_bit_g4"])
 def test_a_whole_radix_addition_is_captured_and_replayed(which):
     """`cuda_add_and_propagate_single_carry_64_inplace_async` between its scratch and cleanup calls only enqueues:
-    the block additions and the nine KS -> PBS rounds of a 16-block addition (index arrays, LUTs and every buffer
+    the block additions and the six KS -> PBS rounds of a 16-block addition (index arrays, LUTs and every buffer
     belong to the scratch) are captured into one HIP graph and replayed on fresh operands; each replay decrypts to
     the sum."""
     from tfhe_rs_amd import core_crypto_gpu as gpu
