@@ -107,18 +107,39 @@ def test_add_at_the_widths_where_the_carry_tree_changes_shape(kind):
     32-block cases above have two levels of groups."""
     p, keys, st, sks, igpu = setup(kind)
     rng = np.random.default_rng(77)
-    for L in (1, 2, 4, 10, 13):
+    # on the MI355X also widths with three and four levels of groups (37, 64, 100 blocks) and ragged last groups
+    widths = (1, 2, 4, 10, 13) if kind == "emu" else (1, 2, 3, 4, 5, 7, 8, 10, 11, 13, 16, 21, 28, 33, 37, 64, 100)
+    for L in widths:
         bits = 2 * L
         mask = (1 << bits) - 1
-        a = [mask, int(rng.integers(0, 1 << 62)) & mask]
-        b = [1, int(rng.integers(0, 1 << 62)) & mask]
+        a = [mask, int.from_bytes(rng.bytes(32), "little") & mask]
+        b = [1, int.from_bytes(rng.bytes(32), "little") & mask]
         ca = igpu.CudaUnsignedRadixCiphertext.from_blocks(encrypt_radix(p, keys, a, L, 41 + L), st)
         cb = igpu.CudaUnsignedRadixCiphertext.from_blocks(encrypt_radix(p, keys, b, L, 42 + L), st)
         cout = sks.add_assign(ca, cb, st, want_carry_out=True)
         full = [x + y for x, y in zip(a, b)]
         assert recompose(decrypt_blocks(p, keys, ca.to_blocks(st))) == [f & mask for f in full], L
         assert [r[0] for r in decrypt_blocks(p, keys, cout.to_blocks(st))] == [f >> bits for f in full], L
-        assert int(igpu._lib().hip_integer_propagate_pbs_count(L)) == {1: 1, 2: 5, 4: 11, 10: 29, 13: 39}[L]
+        if L in (1, 2, 4, 10, 13):
+            assert int(igpu._lib().hip_integer_propagate_pbs_count(L)) == {1: 1, 2: 5, 4: 11, 10: 29, 13: 39}[L]
+
+
+@pytest.mark.parametrize("kind", BACKENDS)
+def test_mul_at_small_and_odd_widths(kind):
+    """1 block (one product, no column sum, no carry), 2 and 3 (columns of at most five terms: no reduction step),
+    and on the MI355X widths whose last group of three is ragged or whose tree has three levels."""
+    p, keys, st, sks, igpu = setup(kind)
+    rng = np.random.default_rng(78)
+    for L in ((1, 2, 3) if kind == "emu" else (1, 2, 3, 5, 8, 13, 21, 40)):
+        mask = (1 << (2 * L)) - 1
+        a = [mask, int.from_bytes(rng.bytes(16), "little") & mask]
+        b = [mask, int.from_bytes(rng.bytes(16), "little") & mask]
+        ca = igpu.CudaUnsignedRadixCiphertext.from_blocks(encrypt_radix(p, keys, a, L, 51 + L), st)
+        cb = igpu.CudaUnsignedRadixCiphertext.from_blocks(encrypt_radix(p, keys, b, L, 52 + L), st)
+        sks.mul_assign(ca, cb, st)
+        rows = decrypt_blocks(p, keys, ca.to_blocks(st))
+        assert all(d < MSG for r in rows for d in r), L
+        assert recompose(rows) == [(x * y) & mask for x, y in zip(a, b)], L
 
 
 def test_add_and_mul_with_three_message_and_three_carry_bits():
