@@ -194,6 +194,9 @@ if __name__ == "__main__":
         for B in (384, 512, 768, 1024, 2048):
             for kern in (2, 7):
                 pbs_case(C4G4, B, kernel=kern, steps=3)
+    if "mblat2" in which:  # the multi-bit latency path at the round sizes of one addition / multiplication
+        for B in (16, 20, 32, 64, 82, 151, 256):
+            pbs_case(C4G4, B, kernel=5, steps=5)
     if "mblat" in which:  # multi-bit latency path: products on the latency kernel (5) or the generic kernels (6)
         for p in (C4G4, C4):
             for kern in (5, 6):
