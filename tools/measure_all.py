@@ -30,7 +30,7 @@ def rand_u64(n):
 
 
 def timed(fn, steps=3, warmup=1):
-    if any(a in sys.argv for a in ("mb1", "mb4one", "lat1", "ntt1", "n1024x", "wave1", "ntt4096", "nttsplit4096", "n1024x4096", "ks1")):
+    if any(a in sys.argv for a in ("mb1", "mb4one", "lat1", "ntt1", "n1024x", "wave1", "ntt4096", "nttsplit4096", "n1024x4096", "ks1", "mblat151")):
         warmup = 0   # exactly one launch: the PMC passes of tools/pmc_record.py
     for _ in range(warmup):
         fn()
@@ -194,6 +194,8 @@ if __name__ == "__main__":
         for B in (384, 512, 768, 1024, 2048):
             for kern in (2, 7):
                 pbs_case(C4G4, B, kernel=kern, steps=3)
+    if "mblat151" in which:  # one launch of the multi-bit latency path (PMC passes over the keybundle kernel)
+        pbs_case(C4G4, 151, kernel=5, steps=1)
     if "mblat2" in which:  # the multi-bit latency path at the round sizes of one addition / multiplication
         for B in (16, 20, 32, 64, 82, 151, 256):
             pbs_case(C4G4, B, kernel=5, steps=5)

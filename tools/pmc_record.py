@@ -37,6 +37,7 @@ TARGETS = {
     "n1024": ("n1024x4096", "pbs_fft_wave3"),
     "ks": ("ks1", "ks_gemm"),
     "ks_onelaunch": ("ks1", "ks_mfma"),
+    "mb_keybundle": ("mblat151", "mb_keybundle_2048"),   # latency path, 151 ciphertexts: the keybundle launches
 }
 
 
