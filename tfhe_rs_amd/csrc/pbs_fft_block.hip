@@ -43,6 +43,9 @@ constexpr size_t STAGE_BYTES = (size_t)2 * N * 8;             // staged accumula
 constexpr size_t WORK_BYTES = (size_t)2 * BUF_SLOTS * 16;     // transform exchanges
 constexpr size_t XCHG_BYTES = (size_t)2 * BUF_SLOTS * 16;     // forward results for the other polynomial's waves
 constexpr size_t SMEM_BYTES = STAGE_BYTES + WORK_BYTES + XCHG_BYTES + 64;
+// multi-bit products: the inverse transform's exchanges have their own buffer, so that a wave may start the next
+// group's forward exchanges while another still reads the last inverse one (one workgroup barrier less per group)
+constexpr size_t SMEM_MB_BYTES = SMEM_BYTES + WORK_BYTES;
 
 HX_DEV cplx ldc(const double *t, int idx) { return cplx{t[2 * idx], t[2 * idx + 1]}; }
 
@@ -128,6 +131,7 @@ __global__ void __launch_bounds__(TPB) pbs_fft_block_kernel(PbsArgs a, FftTables
   const int t = tid & 255;
   uint64_t *stage = (uint64_t *)smem + (size_t)w * N;                       // my polynomial, staged
   cplx *work = (cplx *)(smem + STAGE_BYTES) + (size_t)w * BUF_SLOTS;
+  cplx *work_inv = MB ? (cplx *)(smem + SMEM_BYTES) + (size_t)w * BUF_SLOTS : work;
   cplx *xmy = (cplx *)(smem + STAGE_BYTES + WORK_BYTES) + (size_t)w * BUF_SLOTS;
   const cplx *xot = (const cplx *)(smem + STAGE_BYTES + WORK_BYTES) + (size_t)(w ^ 1) * BUF_SLOTS;
   uint64_t *red = (uint64_t *)(smem + STAGE_BYTES);  // reduction scratch before the loop
@@ -327,12 +331,12 @@ __global__ void __launch_bounds__(TPB) pbs_fft_block_kernel(PbsArgs a, FftTables
         swap_lane54(o);  // lane bits (5,4) <-> register index, as in the forward transform
       } else {
         HX_UNROLL
-        for (int r = 0; r < 4; ++r) work[lay(Q - 1, inv_pos(Q - 1, t, r))] = o[r];
+        for (int r = 0; r < 4; ++r) work_inv[lay(Q - 1, inv_pos(Q - 1, t, r))] = o[r];
         // pass Q regroups threads whose index differs in bits (2Q-1, 2Q-2): other waves only for Q = 4
         if (Q == 4) HX_BLOCK_SYNC_LDS();
         else HX_WAVE_SYNC();
         HX_UNROLL
-        for (int r = 0; r < 4; ++r) o[r] = work[lay(Q - 1, inv_pos(Q, t, r))];
+        for (int r = 0; r < 4; ++r) o[r] = work_inv[lay(Q - 1, inv_pos(Q, t, r))];
         HX_WAVE_SYNC();  // the next exchange reuses these slots in another layout
       }
       inv_pass(o, iw[Q][0], iw[Q][1], iw[Q][2]);
@@ -344,7 +348,9 @@ __global__ void __launch_bounds__(TPB) pbs_fft_block_kernel(PbsArgs a, FftTables
         acc_re[r] = from_torus(fma(-o[r].im, un[r].im, o[r].re * un[r].re));
         acc_im[r] = from_torus(fma(o[r].im, un[r].re, o[r].re * un[r].im));
       }
-      HX_BLOCK_SYNC_LDS();  // xmy / work are rewritten by the next group's forward passes
+      // no barrier here: the next group's forward exchanges use `work` (every wave is past this group's reads of
+      // it: two workgroup barriers lie in between), its publication of the transform comes behind the barrier of the
+      // first forward exchange, and the inverse exchanges live in `work_inv`
     } else {
       HX_UNROLL
       for (int r = 0; r < 4; ++r) {
@@ -618,8 +624,8 @@ static void launch_block_t(hipStream_t st, const PbsArgs &a, const FftTables &tb
 template <int L, int B>
 static void launch_block_mb_t(hipStream_t st, const PbsArgs &a, const FftTables &tb, const blockk::MbLatArgs &mb) {
   using namespace blockk;
-  hx_set_dynamic_smem_once<pbs_fft_block_kernel<L, B, true>>(SMEM_BYTES);
-  HX_LAUNCH((pbs_fft_block_kernel<L, B, true>), dim3(a.num_samples), dim3(TPB), SMEM_BYTES, st, a, tb, mb);
+  hx_set_dynamic_smem_once<pbs_fft_block_kernel<L, B, true>>(SMEM_MB_BYTES);
+  HX_LAUNCH((pbs_fft_block_kernel<L, B, true>), dim3(a.num_samples), dim3(TPB), SMEM_MB_BYTES, st, a, tb, mb);
 }
 // products of the multi-bit latency path (multibit.hip) on the latency kernel: N = 2048, k = 1
 void launch_mb_accumulate_block(hipStream_t st, const PbsArgs &a, const FftTables &tb, const cplx *kb_lat,
