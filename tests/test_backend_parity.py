@@ -823,11 +823,14 @@ def test_multi_bit_latency_path_equals_oracle(kind, which):
     f = lambda x: (3 * x + 2) % p.plaintext_modulus
     lut = orc.generate_lut(p.k, p.N, p.plaintext_modulus, p.delta, f)
     ref = oracle_pbs(p, c.keys, "fft64", cts, lut)
+    cts18 = encrypt_small(p, c.keys, [m % p.plaintext_modulus for m in range(18)], seed=24) if which == "g3_N2048" else None
     try:
         lib.hip_backend_set_fft_kernel(5)
         one_pass = c.pbs(cts, lut)
         assert lib.hip_backend_last_pbs_kernel() == 10
         pair = c.pbs(cts[:2], lut)             # below 4 ciphertexts: one keybundle workgroup per ciphertext
+        # from 17 ciphertexts on the N = 2048 keybundles are parked in the key's slot order (no transposition)
+        many = c.pbs(cts18, lut) if cts18 is not None else None
         lib.hip_backend_set_multibit_latency_groups(2)
         chunked = c.pbs(cts, lut)
         lib.hip_backend_set_ntt_kernel(1)      # products in the single-group kernel instead of one group per row
@@ -846,6 +849,8 @@ def test_multi_bit_latency_path_equals_oracle(kind, which):
         lib.hip_backend_set_multibit_latency_groups(0)
     assert np.array_equal(one_pass, ref)
     assert np.array_equal(pair, ref[:2])
+    if cts18 is not None:
+        assert np.array_equal(many, oracle_pbs(p, c.keys, "fft64", cts18, lut))
     assert np.array_equal(chunked, ref)
     assert np.array_equal(single_group, ref)
     assert np.array_equal(generic_products, ref)

@@ -37,7 +37,7 @@ bool pbs_fft_block_supported(uint32_t N, uint32_t glwe_dim, uint32_t level);
 void launch_pbs_fft_block(hipStream_t st, const PbsArgs &a, const FftTables &tb, int variant);
 // the same kernel running the products of the multi-bit latency path from parked keybundles (multibit.hip)
 void launch_mb_accumulate_block(hipStream_t st, const PbsArgs &a, const FftTables &tb, const cplx *kb_lat, uint64_t *acc_g,
-                                uint32_t gcount, uint32_t gpass, int first, int last);
+                                uint32_t gcount, uint32_t gpass, int first, int last, int slots);
 
 // keyswitch — keyswitch.hip
 // A operands of the large-batch keyswitch written ahead of it (by the bootstrap that produced its input)

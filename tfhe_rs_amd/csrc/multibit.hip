@@ -116,6 +116,9 @@ __global__ void __launch_bounds__(GenericCfg<N>::TPB)
 // ciphertext per workgroup 32 ciphertexts re-read the 241 MB key 32 times from L2 (2.5 ms for a round of 32 blocks
 // of the radix layer).  Same combine order per ciphertext: identical bits.
 constexpr int MB_KB_TILE = 8;  // from 4 ciphertexts up; below, one ciphertext per workgroup (S = 1)
+#ifndef MB_KB_SLOTS_FROM
+#define MB_KB_SLOTS_FROM 17
+#endif
 template <int N, int K1, int S>
 __global__ void __launch_bounds__(GenericCfg<N>::TPB)
     mb_keybundle_kernel(PbsArgs a, uint32_t grouping, cplx *kb_lat, FftTables tb, uint32_t g0, uint32_t gcount) {
@@ -167,7 +170,9 @@ __global__ void __launch_bounds__(GenericCfg<N>::TPB)
 // keybundles are parked in position order as before (the accumulate kernel reads 64 contiguous bytes per thread):
 // each ciphertext's polynomial goes through a padded LDS buffer to turn slot order into position order.  Same factors,
 // same multiply-add order per position: identical bits.
-template <int S>
+// SLOTS: the keybundles are parked in the key's own slot order (what the latency kernel reads, like a classic key:
+// no transposition here); otherwise in position order (the generic product kernels)
+template <int S, bool SLOTS>
 __global__ void __launch_bounds__(256)
     mb_keybundle_2048_kernel(PbsArgs a, uint32_t grouping, cplx *kb_lat, FftTables tb, uint32_t g0, uint32_t gcount) {
   constexpr int N = 2048, n = N / 2, TPB = 256, LOG2N2 = 12;
@@ -219,6 +224,16 @@ __global__ void __launch_bounds__(256)
       HX_UNROLL
       for (int q = 0; q < 4; ++q) kb[q][j] = cmul_add(ks[q], cmul_first(base, sw16[(br[q] * deg) & 15u]), kb[q][j]);
     }
+  }
+  if constexpr (SLOTS) {
+    HX_UNROLL
+    for (int j = 0; j < S; ++j)
+      if ((uint32_t)j < count) {
+        cplx *dst = kb_lat + (((size_t)(s0 + j) * gcount + gl) * kb_polys + poly) * n;
+        HX_UNROLL
+        for (int q = 0; q < 4; ++q) dst[tid + q * TPB] = kb[q][j];
+      }
+    return;
   }
   // slot order -> position order through LDS, one ciphertext at a time
   const FBuf xb{xbuf};
@@ -396,12 +411,27 @@ static void launch_mb_latency(hipStream_t st, const MultiBitArgs &m, const FftTa
     hx_set_dynamic_smem_once<mb_accumulate_kernel<N, K1>>(smem_b);
   for (uint32_t g0 = 0; g0 < groups; g0 += group_chunk) {
     const uint32_t gpass = groups - g0 < group_chunk ? groups - g0 : group_chunk;
-    if (N == 2048 && K1 == 2 && a.num_samples < 4)
-      HX_LAUNCH((mb_keybundle_2048_kernel<1>), dim3(gpass * kb_polys, a.num_samples), dim3(256), 0, st, a,
-                m.grouping_factor, kb_lat, tb, g0, group_chunk);
-    else if (N == 2048 && K1 == 2)
-      HX_LAUNCH((mb_keybundle_2048_kernel<MB_KB_TILE>), dim3(gpass * kb_polys, (a.num_samples + MB_KB_TILE - 1) / MB_KB_TILE),
-                dim3(256), 0, st, a, m.grouping_factor, kb_lat, tb, g0, group_chunk);
+    const bool block_products = N == 2048 && K1 == 2 && a.level <= 8 && !g_ntt_kernel_serial && !a.mb_generic_products;
+    // From MB_KB_SLOTS_FROM ciphertexts on the keybundles stay in the key's slot order (the latency kernel reads them
+    // like a classic key): the keybundle kernel drops its slot -> position transposition, 4-10 % of a round of 32-256
+    // blocks; below, position order — one 64-byte run per thread and row is worth 3 % to a PBS that runs alone
+    const bool slots = block_products && a.num_samples >= (uint32_t)MB_KB_SLOTS_FROM;
+    if (N == 2048 && K1 == 2 && a.num_samples < 4) {
+      if (slots)
+        HX_LAUNCH((mb_keybundle_2048_kernel<1, true>), dim3(gpass * kb_polys, a.num_samples), dim3(256), 0, st, a,
+                  m.grouping_factor, kb_lat, tb, g0, group_chunk);
+      else
+        HX_LAUNCH((mb_keybundle_2048_kernel<1, false>), dim3(gpass * kb_polys, a.num_samples), dim3(256), 0, st, a,
+                  m.grouping_factor, kb_lat, tb, g0, group_chunk);
+    } else if (N == 2048 && K1 == 2) {
+      const dim3 grid(gpass * kb_polys, (a.num_samples + MB_KB_TILE - 1) / MB_KB_TILE);
+      if (slots)
+        HX_LAUNCH((mb_keybundle_2048_kernel<MB_KB_TILE, true>), grid, dim3(256), 0, st, a, m.grouping_factor, kb_lat, tb,
+                  g0, group_chunk);
+      else
+        HX_LAUNCH((mb_keybundle_2048_kernel<MB_KB_TILE, false>), grid, dim3(256), 0, st, a, m.grouping_factor, kb_lat,
+                  tb, g0, group_chunk);
+    }
     else if (a.num_samples < 4)
       HX_LAUNCH((mb_keybundle_kernel<N, K1, 1>), dim3(gpass * kb_polys, a.num_samples), dim3(GenericCfg<N>::TPB),
                 16 * sizeof(uint32_t), st, a, m.grouping_factor, kb_lat, tb, g0, group_chunk);
@@ -409,10 +439,10 @@ static void launch_mb_latency(hipStream_t st, const MultiBitArgs &m, const FftTa
       HX_LAUNCH((mb_keybundle_kernel<N, K1, MB_KB_TILE>), dim3(gpass * kb_polys, (a.num_samples + MB_KB_TILE - 1) / MB_KB_TILE),
                 dim3(GenericCfg<N>::TPB), MB_KB_TILE * 16 * sizeof(uint32_t), st, a, m.grouping_factor, kb_lat, tb, g0,
                 group_chunk);
-    if (N == 2048 && K1 == 2 && a.level <= 8 && !g_ntt_kernel_serial && !a.mb_generic_products)
+    if (block_products)
       // the latency kernel's structure (registers + wave-local exchanges, 4 barriers per product)
       launch_mb_accumulate_block(st, a, tb, (const cplx *)kb_lat, acc_g, group_chunk, gpass, (int)(g0 == 0),
-                                 (int)(g0 + gpass == groups));
+                                 (int)(g0 + gpass == groups), (int)slots);
     else if (par)
       HX_LAUNCH((mb_accumulate_par_kernel<N, K1>), dim3(a.num_samples), dim3(K1 * GenericCfg<N>::TPB), smem_p, st, a,
                 (const cplx *)kb_lat, tb, acc_g, group_chunk, gpass, (int)(g0 == 0), (int)(g0 + gpass == groups));

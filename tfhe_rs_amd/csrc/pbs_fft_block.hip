@@ -121,9 +121,11 @@ struct MbLatArgs {
   uint64_t *acc_g = nullptr;  // [sample][2][N]
   uint32_t gcount = 0, gpass = 0;
   int first = 1, last = 1;
+  int slots = 0;  // keybundles parked in the key's slot order (multibit.hip: from 17 ciphertexts on) or in position order
 };
 
-template <int LEVEL_CT, int BASE_LOG_CT, bool MB = false>
+// MB_SLOTS (multi-bit products): the parked keybundles are in the key's slot order instead of position order
+template <int LEVEL_CT, int BASE_LOG_CT, bool MB = false, bool MB_SLOTS = false>
 __global__ void __launch_bounds__(TPB) pbs_fft_block_kernel(PbsArgs a, FftTables tb, MbLatArgs mb) {
   HX_DYN_SMEM(smem);
   const int tid = threadIdx.x;
@@ -243,7 +245,8 @@ __global__ void __launch_bounds__(TPB) pbs_fft_block_kernel(PbsArgs a, FftTables
       cplx k0[4], k1[4];
       HX_UNROLL
       for (int r = 0; r < 4; ++r) {
-        const int slot = MB ? 4 * t + r : bsk_slot<N, 2>(4 * t + r);  // parked keybundles are in position order
+        // parked keybundles: position order (one 64-byte run per thread and row) or the key's slot order
+        const int slot = (!MB || MB_SLOTS) ? bsk_slot<N, 2>(4 * t + r) : 4 * t + r;
         k0[r] = b0[slot];
         k1[r] = b1[slot];
       }
@@ -624,13 +627,19 @@ static void launch_block_t(hipStream_t st, const PbsArgs &a, const FftTables &tb
 template <int L, int B>
 static void launch_block_mb_t(hipStream_t st, const PbsArgs &a, const FftTables &tb, const blockk::MbLatArgs &mb) {
   using namespace blockk;
-  hx_set_dynamic_smem_once<pbs_fft_block_kernel<L, B, true>>(SMEM_MB_BYTES);
-  HX_LAUNCH((pbs_fft_block_kernel<L, B, true>), dim3(a.num_samples), dim3(TPB), SMEM_MB_BYTES, st, a, tb, mb);
+  if (mb.slots) {
+    hx_set_dynamic_smem_once<pbs_fft_block_kernel<L, B, true, true>>(SMEM_MB_BYTES);
+    HX_LAUNCH((pbs_fft_block_kernel<L, B, true, true>), dim3(a.num_samples), dim3(TPB), SMEM_MB_BYTES, st, a, tb, mb);
+  } else {
+    hx_set_dynamic_smem_once<pbs_fft_block_kernel<L, B, true>>(SMEM_MB_BYTES);
+    HX_LAUNCH((pbs_fft_block_kernel<L, B, true>), dim3(a.num_samples), dim3(TPB), SMEM_MB_BYTES, st, a, tb, mb);
+  }
 }
 // products of the multi-bit latency path (multibit.hip) on the latency kernel: N = 2048, k = 1
 void launch_mb_accumulate_block(hipStream_t st, const PbsArgs &a, const FftTables &tb, const cplx *kb_lat,
-                                uint64_t *acc_g, uint32_t gcount, uint32_t gpass, int first, int last) {
+                                uint64_t *acc_g, uint32_t gcount, uint32_t gpass, int first, int last, int slots) {
   blockk::MbLatArgs mb;
+  mb.slots = slots;
   mb.kb = kb_lat;
   mb.acc_g = acc_g;
   mb.gcount = gcount;
