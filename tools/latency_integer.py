@@ -71,6 +71,26 @@ def main():
         print(json.dumps({"op": f"FheUint64 {op}", "params": p.name, "scratch_ms": (t1 - t0) * 1e3,
                           "operation_ms": (t2 - t1) * 1e3, "cleanup_ms": (t3 - t2) * 1e3,
                           "note": "third repetition; one ciphertext pair, one stream"}))
+    if "--throughput" in sys.argv:
+        # the same operations over a batch of independent integers (timing only: the key material is random; the
+        # decrypt-checked form of this measurement is tools/bench_integer.py)
+        for op, B in (("add", 1024), ("mul", 128)):
+            big = r64(B * L * (p.big_n + 1)).reshape(B, L, -1)
+            ca = igpu.CudaUnsignedRadixCiphertext.from_blocks(big, st)
+            cb = igpu.CudaUnsignedRadixCiphertext.from_blocks(big, st)
+            st.synchronize()
+            t0 = time.perf_counter()
+            if op == "add":
+                sks.add_assign(ca, cb, st)
+                pbs = int(lib.hip_integer_propagate_pbs_count(L))
+            else:
+                pbs = int(sks.mul_assign(ca, cb, st, return_pbs_count=True))
+            st.synchronize()
+            dt = time.perf_counter() - t0
+            print(json.dumps({"op": f"FheUint64 {op}", "params": p.name, "batch": B, "seconds": dt, "ops_per_s": B / dt,
+                              "pbs_per_op": pbs, "ks_pbs_per_s": B * pbs / dt,
+                              "note": "scratch, every round and cleanup inside the timed region; random key material"}))
+            del ca, cb
 
 
 if __name__ == "__main__":
