@@ -112,12 +112,14 @@
 #define WAVE_MB_SETS 4  // multi-bit: register sets in rotation (SETS - 1 key requests in flight)
 #endif
 #ifndef WAVE_MB_BASES
-// multi-bit monomial bases gathered 0: once per group (held across the digit and transform phases: the two-level g = 3
+// multi-bit monomial bases requested 0: once per group (held across the digit and transform phases: the two-level g = 3
 // kernel then spills 55 registers, 8 dword stores + loads per wave and level), 1: per level ahead of the level's key
-// requests (no spills), 2: per level behind the first key requests (no spills).  Measured on one box, batch 4096,
-// g = 3 / g = 4: 0 -> 46.5 / 33.4 ms, 1 -> 48.5 / 35.4 ms, 2 -> 48.2 / 35.6 ms: the gathers' latency in front of the
-// multiply-accumulate costs more than the spill traffic, so 0 stays.
-#define WAVE_MB_BASES 0
+// requests (no spills), 2: per level behind the first key requests (no spills); -1: 1 for several levels, 0 for one.
+// With the bases as 64 scattered table entries per request (rounds 2-3) 0 won everywhere (g = 3 / g = 4: 0 -> 46.5 /
+// 33.4 ms, 1 -> 48.5 / 35.4, 2 -> 48.2 / 35.6: the gathers in front of the multiply-accumulate cost more than the
+// spills); with the lane-order table (one coalesced 1 KB request, tables.h mono_lane) g = 3 / g = 4 on one box:
+// 0 -> 45.1 / 30.2 ms, 1 -> 43.8 / 30.4, 2 -> 43.8 / 30.6: the two-level kernel takes 1 (and spills nothing).
+#define WAVE_MB_BASES -1
 #endif
 #ifndef WAVE_SPLIT_LWES
 #define WAVE_SPLIT_LWES 4   // exact engine, split-key form: LWEs per workgroup (the accumulators of a CU's LWEs live in L2)
@@ -900,8 +902,10 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
     const uint32_t groups = a.n / g;
     const cplx *key = (const cplx *)a.bsk;  // Fourier domain: [group][subset][level][row][col][slot]
     const size_t ggsw_c = (size_t)level * 4 * n;
-    const HxBuffer mono = hx_make_buffer(tb.mono, 2u * N * 16u);
-    const uint32_t a_lane = 1u + 4u * (__brev((uint32_t)lane) >> 26);  // 1 + 4 bitrev6(lane)
+    // tables.h mono_lane: entry [d][lane] = mono[((1 + 4 bitrev6(lane)) d) mod 2N] — a degree's 64 bases are one
+    // 1 KB run (one coalesced request with the degree as the scalar offset) instead of 64 scattered table entries
+    const HxBuffer mono_lane = hx_make_buffer(tb.mono_lane, 2u * N * 64u * 16u);
+    const uint32_t lane16 = (uint32_t)lane * 16u;
 #if WAVE_MB_PACE && !defined(TFHE_HIPEMU)
     // Pacing.  Workgroup b runs on XCD b % 8 (round-robin dispatch; used for speed only, never for correctness),
     // 32 workgroups of an XCD are resident at a time, in index order.  Every wave pair adds 1 to its XCD's counter
@@ -985,7 +989,7 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
       auto bases = [&](const uint32_t (&dg)[per], cplx (&bs)[per]) {
         HX_UNROLL
         for (uint32_t sidx = 1; sidx < per; ++sidx)
-          bs[sidx] = ldc(mono, ((a_lane * dg[sidx]) & (2u * N - 1u)) * 16u, 0u);
+          bs[sidx] = ldc(mono_lane, lane16, dg[sidx] * 1024u);
         bs[0] = cplx{1.0, 0.0};
       };
       uint32_t deg[per];
@@ -996,11 +1000,12 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
       } else {
         degrees(lwe, deg);
       }
-#if WAVE_MB_BASES == 0
-      cplx base[per], base_b[SHARE ? per : 1];
-      bases(deg, base);
-      if constexpr (SHARE) bases(deg_b, base_b);
-#endif
+      constexpr int MB_BASES = WAVE_MB_BASES >= 0 ? WAVE_MB_BASES : (LEVEL_CT >= 2 ? 1 : 0);
+      cplx base[per], base_b[SHARE ? per : 1];  // (re)written per level unless MB_BASES == 0: not live across levels then
+      if constexpr (MB_BASES == 0) {
+        bases(deg, base);
+        if constexpr (SHARE) bases(deg_b, base_b);
+      }
       // the group's 2^g GGSWs as one buffer: uniform base in scalar registers, lane offset in one vector register
 #if WAVE_MB_PACE && !defined(TFHE_HIPEMU)
       auto pace_wait = [&]() {
@@ -1077,13 +1082,10 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
           const cplx *fb0 = (const cplx *)((const char *)qbuf + 2 * BUF_BYTES) + fslot;
           const cplx *fb1 = (const cplx *)((const char *)qbuf + 3 * BUF_BYTES) + fslot;
           constexpr int SETS = WAVE_MB_SHARE_SETS, RW = 8, STEPS = RW * (int)per;
-#if WAVE_MB_BASES != 0
-          cplx base[per], base_b[per];
-#endif
-#if WAVE_MB_BASES == 1
-          bases(deg, base);
-          bases(deg_b, base_b);
-#endif
+          if constexpr (MB_BASES == 1) {
+            bases(deg, base);
+            bases(deg_b, base_b);
+          }
           cplx x0[SETS], x1[SETS];
           auto request = [&](int set, int t) {
             const uint32_t sidx = (uint32_t)(t % (int)per);
@@ -1094,12 +1096,11 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
           HX_UNROLL
           for (int t = 0; t < SETS && t < STEPS; ++t) request(t, t);
           HX_SCHED_FENCE();
-#if WAVE_MB_BASES == 2
-          // behind the first key requests (loads return in order and subset 0 needs no factor)
-          bases(deg, base);
-          bases(deg_b, base_b);
-          HX_SCHED_FENCE();
-#endif
+          if constexpr (MB_BASES == 2) {  // behind the first key requests (loads return in order, subset 0 needs no factor)
+            bases(deg, base);
+            bases(deg_b, base_b);
+            HX_SCHED_FENCE();
+          }
           // ---- all four transforms of the quad are in its buffers (mapping M3: slot lane*17 + r); the first key
           // requests are already on their way
           quad_sync();
@@ -1164,12 +1165,7 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
           // rotate: the set a step frees takes the request of the step SETS ahead, so SETS - 1 requests
           // (2 PTS coalesced 1 KiB wave loads each) are in flight while one set is accumulated.
           constexpr int PTS = WAVE_MB_PTS, SETS = WAVE_MB_SETS, CHUNKS = 16 / PTS, STEPS = CHUNKS * (int)per;
-#if WAVE_MB_BASES != 0
-          cplx base[per];
-#endif
-#if WAVE_MB_BASES == 1
-          bases(deg, base);
-#endif
+          if constexpr (MB_BASES == 1) bases(deg, base);
           cplx x0[SETS][PTS], x1[SETS][PTS];
           auto request = [&](int set, int t) {
             const uint32_t sidx = (uint32_t)(t % (int)per);
@@ -1186,10 +1182,10 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
           HX_UNROLL
           for (int t = 0; t < SETS && t < STEPS; ++t) request(t, t);
           HX_SCHED_FENCE();
-#if WAVE_MB_BASES == 2
-          bases(deg, base);  // behind the first key requests (loads return in order and subset 0 needs no factor)
-          HX_SCHED_FENCE();
-#endif
+          if constexpr (MB_BASES == 2) {  // behind the first key requests
+            bases(deg, base);
+            HX_SCHED_FENCE();
+          }
           flag_wait(f_ready_ot, epoch);
           const cplx *row0 = (w == 0 ? buf : obuf) + base_m3(cx);
           const cplx *row1 = (w == 0 ? obuf : buf) + base_m3(cx);

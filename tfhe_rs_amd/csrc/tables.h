@@ -11,11 +11,15 @@ namespace tfhe_hip {
 // each entry (re, im) as two doubles; index 0 of fwd/inv unused.
 //   mono[j]        = exp(i*pi*j/N), j < 2N (octant-symmetric): the transform of a monomial X^d at position p is
 //                    mono[((1+4*bitrev_{L-4}(p>>4))*d) mod 2N] * mono[(N/8)*((bitrev_4(p&15)*d) mod 16)]  (multi-bit PBS)
+//   mono_lane      (N = 2048 only, else null): the same base factors laid out for a wave — entry [d][h] =
+//                    mono[((1 + 4 bitrev_6(h)) d) mod 2N], d < 2N, h < 64: the 64 lanes of a wave read ONE 1 KB run for a
+//                    degree d instead of 64 scattered 16-byte entries (4 MB; same values)
 struct FftTables {
   const double *fwd;
   const double *inv;
   const double *untw;
   const double *mono;
+  const double *mono_lane;
 };
 
 // Tables of the reference-order f64 engine (pbs_ref64.hip): what tfhe-fft / tfhe build for a radix-4 DIF plan of

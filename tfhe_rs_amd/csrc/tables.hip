@@ -197,7 +197,7 @@ void fill_ntt_tables_host(uint32_t N, uint64_t *tw, uint64_t *itw, uint64_t *n_i
 
 namespace {
 struct FftEntry {
-  double *fwd, *inv, *untw, *mono;
+  double *fwd, *inv, *untw, *mono, *mono_lane;
 };
 struct NttEntry {
   uint64_t *tw, *itw;
@@ -249,6 +249,20 @@ FftTables get_fft_tables(uint32_t gpu_index, hipStream_t stream, uint32_t N) {
     HX_CHECK(hipMalloc((void **)&e.untw, sizeof(double) * N));
     HX_CHECK(hipMalloc((void **)&e.mono, sizeof(double) * 4 * N));
     HX_CHECK(hipMemcpy(e.mono, mono.data(), sizeof(double) * 4 * N, hipMemcpyHostToDevice));
+    e.mono_lane = nullptr;
+    if (N == 2048) {  // tables.h: the base factors of the multi-bit kernels in lane order
+      std::vector<double> ml((size_t)2 * N * 64 * 2);
+      for (uint32_t d = 0; d < 2 * N; ++d)
+        for (uint32_t h = 0; h < 64; ++h) {
+          uint32_t br = 0;
+          for (int b = 0; b < 6; ++b) br |= ((h >> b) & 1u) << (5 - b);
+          const uint32_t j = ((1u + 4u * br) * d) & (2u * N - 1u);
+          ml[((size_t)d * 64 + h) * 2] = mono[2 * (size_t)j];
+          ml[((size_t)d * 64 + h) * 2 + 1] = mono[2 * (size_t)j + 1];
+        }
+      HX_CHECK(hipMalloc((void **)&e.mono_lane, sizeof(double) * ml.size()));
+      HX_CHECK(hipMemcpy(e.mono_lane, ml.data(), sizeof(double) * ml.size(), hipMemcpyHostToDevice));
+    }
     // synchronous copies from pageable host memory: complete before we return
     HX_CHECK(hipMemcpy(e.fwd, fwd.data(), sizeof(double) * N, hipMemcpyHostToDevice));
     HX_CHECK(hipMemcpy(e.inv, inv.data(), sizeof(double) * N, hipMemcpyHostToDevice));
@@ -256,7 +270,7 @@ FftTables get_fft_tables(uint32_t gpu_index, hipStream_t stream, uint32_t N) {
     (void)stream;
     it = g_fft.emplace(key, e).first;
   }
-  return FftTables{it->second.fwd, it->second.inv, it->second.untw, it->second.mono};
+  return FftTables{it->second.fwd, it->second.inv, it->second.untw, it->second.mono, it->second.mono_lane};
 }
 
 
