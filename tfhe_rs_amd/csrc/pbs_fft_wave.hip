@@ -106,7 +106,9 @@
 #define WAVE_MB_TURNS 0  // SHARE: the two quads of a workgroup take the multiply-accumulate in turns (measured slower: 60 vs 54 ms)
 #endif
 #ifndef WAVE_MB_SHARE_SETS
-#define WAVE_MB_SHARE_SETS 3  // SHARE: register sets in rotation (a request = the 2 rows of one point and subset)
+// SHARE: register sets in rotation (a request = the 2 rows of one point and subset); 0: two for one level, three for
+// several (one box, g = 3 / g = 4 per 4096: 2 -> 48.8 / 29.8 ms, 3 -> 43.8 / 30.3, 4 -> 43.0 / 30.7, 5 -> 43.9 / 31.3)
+#define WAVE_MB_SHARE_SETS 0
 #endif
 #ifndef WAVE_MB_SETS
 #define WAVE_MB_SETS 4  // multi-bit: register sets in rotation (SETS - 1 key requests in flight)
@@ -1081,7 +1083,7 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
           const cplx *fa0 = qbuf + fslot, *fa1 = (const cplx *)((const char *)qbuf + BUF_BYTES) + fslot;
           const cplx *fb0 = (const cplx *)((const char *)qbuf + 2 * BUF_BYTES) + fslot;
           const cplx *fb1 = (const cplx *)((const char *)qbuf + 3 * BUF_BYTES) + fslot;
-          constexpr int SETS = WAVE_MB_SHARE_SETS, RW = 8, STEPS = RW * (int)per;
+          constexpr int SETS = WAVE_MB_SHARE_SETS > 0 ? WAVE_MB_SHARE_SETS : (LEVEL_CT == 1 ? 2 : 3), RW = 8, STEPS = RW * (int)per;
           if constexpr (MB_BASES == 1) {
             bases(deg, base);
             bases(deg_b, base_b);
