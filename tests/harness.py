@@ -19,6 +19,8 @@ from . import oracle as orc
 _HERE = os.path.dirname(os.path.abspath(__file__))
 EMU_DIR = os.path.join(_HERE, "emu")
 EMU_LIB = os.path.join(EMU_DIR, "libtfhe_hip_backend_emu.so")
+# a host-emulation build of a tuning variant (tools/build_variants.py --emu), checked by the same tests
+EMU_LIB_OVERRIDE = os.environ.get("TFHE_EMU_LIB")
 
 _libs = {}
 
@@ -32,7 +34,7 @@ def use_backend(kind):
     if kind not in _libs:
         if kind == "emu":
             build_emu()
-            _libs[kind] = ffi.Library(EMU_LIB)
+            _libs[kind] = ffi.Library(EMU_LIB_OVERRIDE or EMU_LIB)
         else:
             _libs[kind] = ffi.Library()  # product library; ImportError if it was not built
     ffi.set_default_library(_libs[kind])

@@ -649,39 +649,69 @@ def reference_fft_noise_variance(n, k, N, base_log, level, mantissa=53.0, log2_q
         N ** 2.22003 * (k + 1) ** 1.01827
 
 
+def _phase_error(p, keys, outs_a, outs_b):
+    sk = keys.glwe_sk
+    d = [(int(orc.lwe_decrypt(a, sk)) - int(orc.lwe_decrypt(b, sk))) & M64 for a, b in zip(outs_a, outs_b)]
+    return np.array([x - (1 << 64) if x >= (1 << 63) else x for x in d], dtype=np.float64)
+
+
 @pytest.mark.parametrize("kind", BACKENDS)
 def test_f64_engine_noise_matches_the_reference_fft_noise_model(kind):
     """one external product in f64 differs from exact arithmetic only by floating-point error,
     whose variance the reference models (noise_formulas/lwe_programmable_bootstrap.rs:46-58, the `fft_mul` term,
-    proportional to the number n of external products).  PARAM_MESSAGE_2_CARRY_2's ring and decomposition with
-    ONE mask element (n = 1: the blind rotation is a single CMUX, so both engines decompose the same
-    accumulator and their outputs differ by the transform error alone — over a full PBS the two engines'
-    decomposition roundings decorrelate after the first iteration and that rounding noise, 2^49.6 at n = 918,
-    swamps the transform error): the f64 engine against the exact-integer engine (the one that reproduces the
-    reference's Karatsuba golden vectors), 8 coefficients extracted per PBS (many-LUT).  Measured: std = 2.1x the
-    model's std for n = 1 (2^44.2 against 2^43.15 in u64 units) — this repository's 6-FMA butterfly reuses the
-    rounded a + s b for the second output, the reference's transform does not; the gate is 2.5x.  A std far below
-    the model would mean the comparison is broken.  (At n = 918 this is 2^49.1, the message spacing being 2^59.)"""
+    proportional to the number n of external products).  PARAM_MESSAGE_2_CARRY_2's ring and decomposition with ONE
+    mask element (n = 1: the blind rotation is a single CMUX, so both engines decompose the same accumulator and
+    their outputs differ by the transform error alone — over a full PBS the engines' decomposition roundings
+    decorrelate after the first iteration and that rounding noise, 2^49.6 at n = 918, swamps the transform error).
+    The f64 engine is compared with the exact-integer engine (the one that reproduces the reference's Karatsuba
+    golden vectors) and, next to it, the oracle's restatement of tfhe-fft's own radix-4 DIF plan (the one that
+    reproduces the reference's f64 golden vectors) with that same exact engine, on the same inputs:
+
+    * GENERIC accumulator (a uniformly random GLWE — what every CMUX after the first few sees, and what the model
+      describes): this repository's transform order gives 0.96x the model's std and 1.05x the reference order's
+      (2^43.09 / 2^43.02 / model 2^43.15 in u64 units on the oracle; the MI355X figure is printed).  Gate: 1.3x the
+      model, 1.25x the reference order.
+    * FIRST CMUX of a bootstrap (the accumulator is the rotated trivial LUT: zero mask, piecewise-constant body, so
+      the digit polynomial is piecewise constant and its transform is concentrated in a few points): the
+      floating-point errors of such an input are correlated across coefficients and BOTH orders leave the model —
+      the reference's by 1.5x, this repository's by 2.4x (2^44.4 against 2^43.8).  It concerns one of the n
+      external products; gate: 2x the reference order on the same input.  (Round 3 measured only this case and
+      attributed the 2.2x to the 6-FMA butterfly; a CPU experiment with four butterfly forms — reused sum, tangent
+      form, separate product, 8 FMAs — puts them within 10 % of one another on both inputs.)"""
     from .common import C1
     p = dataclasses.replace(C1, name="PARAM_MESSAGE_2_CARRY_2_n1", n=1, ms_type=0)
     keys = make_keys(p, with_ksk=False)
     B, M = (24, 4) if kind == "emu" else (192, 8)
     rng = np.random.default_rng(5)
     cts = rng.integers(0, 1 << 64, size=(B, p.n + 1), dtype=np.uint64)   # any mask element / body: one CMUX each
-    lut = orc.generate_lut(p.k, p.N, p.plaintext_modulus, p.delta, lambda x: (7 * x + 3) % 16)
+    lut_first = orc.generate_lut(p.k, p.N, p.plaintext_modulus, p.delta, lambda x: (7 * x + 3) % 16)
+    lut_generic = rng.integers(0, 1 << 64, size=lut_first.shape, dtype=np.uint64)
     stride = p.N // (2 * M)
-    outs = {e: Ctx(kind, p, keys, e).pbs(cts, lut, num_many_lut=M, lut_stride=stride) for e in ("fft64", "exact64")}
-    sk = keys.glwe_sk
-    d = np.array([(int(orc.lwe_decrypt(a, sk)) - int(orc.lwe_decrypt(b, sk))) & M64
-                  for a, b in zip(outs["fft64"], outs["exact64"])], dtype=object)
-    d = np.array([int(x) - (1 << 64) if x >= (1 << 63) else int(x) for x in d], dtype=np.float64)
     std_model = float(np.sqrt(reference_fft_noise_variance(p.n, p.k, p.N, p.pbs_base_log, p.pbs_level))) * 2.0 ** 64
-    std_meas = float(d.std())
-    print(f"f64 external product, phase error: std 2^{np.log2(std_meas):.2f}, reference model 2^{np.log2(std_model):.2f}, "
-          f"max 2^{np.log2(np.abs(d).max()):.2f} over {d.size} samples")
-    assert std_meas <= 2.5 * std_model
-    assert std_meas >= std_model / 32.0
-    assert np.abs(d).max() < 16.0 * std_model
+    bsk_ref = orc.dif4_convert_bsk(keys.bsk, p.n, p.k, p.N, p.pbs_level)
+    log_mod = 12  # log2(2N)
+    for tag, lut, gate_model, gate_ref in (("generic accumulator", lut_generic, 1.3, 1.25),
+                                           ("first CMUX (rotated LUT)", lut_first, 3.0, 2.0)):
+        outs = {e: Ctx(kind, p, keys, e).pbs(cts, lut, num_many_lut=M, lut_stride=stride) for e in ("fft64", "exact64")}
+        d = _phase_error(p, keys, outs["fft64"], outs["exact64"])
+        # the reference's order on the same inputs (oracle, CPU): blind rotation + the same M extractions
+        ref_out, exact_out = [], []
+        for ct in cts:
+            msed = orc.lwe_modulus_switch(ct, log_mod, 0)
+            acc_r = orc.dif4_blind_rotate(lut, msed, bsk_ref, p.n, p.k, p.N, p.pbs_base_log, p.pbs_level)
+            acc_e = orc.blind_rotate_exact(lut, msed, keys.bsk, p.n, p.k, p.N, p.pbs_base_log, p.pbs_level)
+            for t in range(M):
+                ref_out.append(orc.sample_extract(acc_r, p.k, p.N, t * stride))
+                exact_out.append(orc.sample_extract(acc_e, p.k, p.N, t * stride))
+        d_ref = _phase_error(p, keys, ref_out, exact_out)
+        std_meas, std_ref = float(d.std()), float(d_ref.std())
+        print(f"f64 external product, {tag}: phase error std 2^{np.log2(std_meas):.2f} (reference order 2^"
+              f"{np.log2(std_ref):.2f}, reference model 2^{np.log2(std_model):.2f}), max 2^{np.log2(np.abs(d).max()):.2f} "
+              f"over {d.size} samples")
+        assert std_meas <= gate_model * std_model, tag
+        assert std_meas <= gate_ref * std_ref, tag
+        assert std_meas >= std_model / 32.0, tag   # a std far below the model would mean the comparison is broken
+        assert np.abs(d).max() < 16.0 * std_model, tag
 
 
 @pytest.mark.gpu

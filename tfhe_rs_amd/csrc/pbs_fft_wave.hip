@@ -37,8 +37,6 @@
 #ifndef WAVE_EARLY_CHUNKS
 #define WAVE_EARLY_CHUNKS 1  // key chunks requested at the top of an iteration (0, 1 or 2); the rest at the MAC
 #endif
-// 1: transforms as radix 16 -> (permlane swaps) -> radix 4 -> (one LDS transposition) -> radix 16;
-// 0: radix 16 -> LDS -> radix 16 -> LDS -> radix 4 (the first layout of this kernel).  Same bits.
 // Issue priority of a wave by phase of its CMUX iteration (s_setprio, 0..3).  The two waves that share a
 // SIMD belong to different LWEs; with equal priority they interleave instruction by instruction and tend
 // to reach their LDS round trips and pair waits together.  Raising the priority as the iteration advances
@@ -90,9 +88,6 @@
 #ifndef WAVE_FLAG_SLEEP
 #define WAVE_FLAG_SLEEP 1  // s_sleep argument between two polls of a pair flag
 #endif
-#ifndef WAVE_PERMLANE_PASS
-#define WAVE_PERMLANE_PASS 1
-#endif
 #ifndef WAVE_MB_PTS
 #define WAVE_MB_PTS 2   // multi-bit: points per lane and row of one keybundle step (16 / PTS chunks per level)
 #endif
@@ -126,11 +121,37 @@
 #ifndef WAVE_SPLIT_LWES
 #define WAVE_SPLIT_LWES 4   // exact engine, split-key form: LWEs per workgroup (the accumulators of a CU's LWEs live in L2)
 #endif
+#ifndef WAVE_SPLIT_REGACC
+// exact engine, split-key form: 1 = two LWEs per workgroup (one wave per SIMD, up to 512 registers per lane) and the
+// accumulator stays in registers: no accumulator traffic to device memory at all
+#define WAVE_SPLIT_REGACC 0
+#endif
 #ifndef WAVE_SPLIT_NT
 #define WAVE_SPLIT_NT 0     // 1: accumulator loads / stores nontemporal
 #endif
 #ifndef WAVE_FUSE_PASS1
 #define WAVE_FUSE_PASS1 1    // first inverse pass interleaved with the MAC chunks
+#endif
+#ifndef WAVE_UNIFORM_LITERALS
+// 1: the twiddles that are the same in every lane and every launch (forward d = 0..3, inverse half = 4, 8: 12 of the
+// 118 16-byte LDS reads of an iteration) are literals of the instruction stream (scalar moves) instead of broadcast
+// reads of the LDS table; the inverse butterflies whose twiddle is 1 or -i lose their two products (same roundings:
+// fma(x, 1, y) = x + y).  The values are checked against the host tables when the tables are built (tables.hip).
+#define WAVE_UNIFORM_LITERALS 0
+#endif
+#ifndef WAVE_TW_PREFETCH
+// classic one-level loop: 1 = lane-dependent twiddles, untwist factors and the rotation's staged words are requested
+// ahead of their use (wave_forward / wave_inverse_accumulate PFT, make_digits), 0 = just in time
+#define WAVE_TW_PREFETCH 0
+#endif
+#ifndef WAVE_ROT_PREFETCH
+#define WAVE_ROT_PREFETCH 0  // classic one-level loop: coefficient pairs of the rotation requested ahead (0, 4, 8 or 16)
+#endif
+#ifndef WAVE_MAC_OWN_REGS
+// 1 (classic one-level loop): the multiply-accumulate takes the wave's own row of the digit transform from its
+// registers (in place) and only the partner's row from LDS: 16 fewer 16-byte LDS reads per iteration, two copies of
+// the product loop selected by a scalar branch on the wave's polynomial
+#define WAVE_MAC_OWN_REGS 0
 #endif
 
 namespace tfhe_hip {
@@ -168,6 +189,14 @@ constexpr int T_TOTAL = 1489;
 constexpr int FLAGS_BYTES = 64;
 constexpr size_t SMEM_BYTES = (size_t)WAVES * BUF_BYTES + (size_t)T_TOTAL * 16 + FLAGS_BYTES;
 
+// wave-uniform twiddles as literals (WAVE_UNIFORM_LITERALS): fwd[1], fwd[2], fwd[4], fwd[6], fwd[8..14 step 2] and
+// E[64 j] = inv[512 + 64 j] of the N = 2048 tables (long-double angles rounded once, tables.hip)
+constexpr double LIT_F1[8][2] = {{0x1.6a09e667f3bcdp-1, 0x1.6a09e667f3bcdp-1}, {0x1.d906bcf328d46p-1, 0x1.87de2a6aea963p-2},
+                                 {0x1.f6297cff75cbp-1, 0x1.8f8b83c69a60bp-3},  {0x1.1c73b39ae68c8p-1, 0x1.a9b66290ea1a3p-1},
+                                 {0x1.fd88da3d12526p-1, 0x1.917a6bc29b42cp-4}, {0x1.44cf325091dd6p-1, 0x1.8bc806b151741p-1},
+                                 {0x1.c38b2f180bdb1p-1, 0x1.e2b5d3806f63bp-2}, {0x1.294062ed59f06p-2, 0x1.e9f4156c62ddap-1}};
+constexpr double LIT_E64[4][2] = {{1.0, 0.0}, {0x1.d906bcf328d46p-1, -0x1.87de2a6aea963p-2},
+                                  {0x1.6a09e667f3bcdp-1, -0x1.6a09e667f3bcdp-1}, {0x1.87de2a6aea963p-2, -0x1.d906bcf328d46p-1}};
 HX_DEV cplx times_i(const cplx c) { return cplx{-c.im, c.re}; }
 HX_DEV cplx times_mi(const cplx c) { return cplx{c.im, -c.re}; }
 HX_DEV cplx ldg_c(const double *t, int idx) { return cplx{t[2 * idx], t[2 * idx + 1]}; }
@@ -218,6 +247,23 @@ HX_DEV void load_pairs(LD ld) {
     }
 }
 
+// the §4 butterfly with the twiddle 1 and with -i: fma(b.re, 1, a.re) = a.re + b.re and the products by 0 vanish —
+// the same roundings as bfly() with those twiddles (the sign of an exact zero aside, which no later step reads)
+HX_DEV void bfly_one(cplx &a, cplx &b) {
+  const double o1r = a.re + b.re, o1i = a.im + b.im;
+  b.re = fma(2.0, a.re, -o1r);
+  b.im = fma(2.0, a.im, -o1i);
+  a.re = o1r;
+  a.im = o1i;
+}
+HX_DEV void bfly_mi(cplx &a, cplx &b) {
+  const double o1r = a.re + b.im, o1i = a.im - b.re;
+  b.re = fma(2.0, a.re, -o1r);
+  b.im = fma(2.0, a.im, -o1i);
+  a.re = o1r;
+  a.im = o1i;
+}
+
 // Everything a wave needs to know about its place in the workgroup
 struct WaveCtx {
   cplx *buf;         // my exchange buffer
@@ -261,15 +307,43 @@ HX_DEV void swap_regs_lane54(cplx (&d)[16]) {
     }
 }
 
-#if WAVE_PERMLANE_PASS
 // ---- forward transform of 16 points per lane: mapping M1 in, mapping M3 out (and stored in my buffer)
 //   F1 stages 0..3 (position bits 9..6, registers) -> permlane swaps -> F2 stages 4,5 (bits 5,4, registers)
 //   -> LDS transposition MX -> M3 -> F3 stages 6..9 (bits 3..0, registers)
+//
+// PFT: the lane-dependent twiddles are requested a pass ahead of their use (the F2 ones in front of pass F1, the F3
+// ones in front of the last F2 stage) instead of just in time behind the scheduling fence of their stage: every
+// just-in-time read is an LDS round trip the wave sits out, and with two waves per SIMD a wait that coincides with the
+// other wave's costs issue slots.  Same values, same operations.  Costs up to 64 registers for a pass: the caller
+// chooses (the classic one-level loop has them).
+template <bool PFT = false>
 HX_DEV void wave_forward(cplx (&d)[16], WaveCtx c) {
   HX_OPAQUE(c.lane);
   const int lane = c.lane, g4 = c.lane >> 4;
   const cplx *T = c.T;
+  cplx e4[4], e5[4];
+  if constexpr (PFT) {
+    HX_UNROLL
+    for (int j = 0; j < 4; ++j) {
+      e4[j] = T[T_F2 + g4 * 4 + j];
+      e5[j] = T[T_F2 + 16 + g4 * 4 + j];
+    }
+    HX_SCHED_FENCE();
+  }
   {
+#if WAVE_UNIFORM_LITERALS
+    auto lit = [](int x) { return cplx{LIT_F1[x][0], LIT_F1[x][1]}; };
+    const cplx w0 = lit(0);
+    stage<3>(d, [&](int) { return w0; });
+    const cplx e1 = lit(1);
+    stage<2>(d, [&](int r) { return (r >> 3) ? times_i(e1) : e1; });
+    HX_SCHED_FENCE();
+    const cplx e2[2] = {lit(2), lit(3)};
+    stage<1>(d, [&](int r) { return ((r >> 2) & 1) ? times_i(e2[r >> 3]) : e2[r >> 3]; });
+    HX_SCHED_FENCE();
+    const cplx e3[4] = {lit(4), lit(5), lit(6), lit(7)};
+    stage<0>(d, [&](int r) { return ((r >> 1) & 1) ? times_i(e3[r >> 2]) : e3[r >> 2]; });
+#else
     const cplx w0 = T[T_F1 + 0];
     stage<3>(d, [&](int) { return w0; });
     const cplx e1 = T[T_F1 + 1];
@@ -280,16 +354,31 @@ HX_DEV void wave_forward(cplx (&d)[16], WaveCtx c) {
     HX_SCHED_FENCE();
     const cplx e3[4] = {T[T_F1 + 4], T[T_F1 + 5], T[T_F1 + 6], T[T_F1 + 7]};
     stage<0>(d, [&](int r) { return ((r >> 1) & 1) ? times_i(e3[r >> 2]) : e3[r >> 2]; });
+#endif
   }
   HX_SCHED_FENCE();
   swap_regs_lane54(d);
   HX_SCHED_FENCE();
+  cplx w6, e7, e8[2], e9[4];
   {  // stage 4: group (pos >> 6) = (lane>>4)*4 + (r&3); stage 5: group (pos >> 5) = that*2 + (r>>3)
-    const cplx e4[4] = {T[T_F2 + g4 * 4], T[T_F2 + g4 * 4 + 1], T[T_F2 + g4 * 4 + 2], T[T_F2 + g4 * 4 + 3]};
+    if constexpr (!PFT) {
+      HX_UNROLL
+      for (int j = 0; j < 4; ++j) e4[j] = T[T_F2 + g4 * 4 + j];
+    }
     stage<3>(d, [&](int r) { return e4[r & 3]; });
     HX_SCHED_FENCE();
-    const cplx e5[4] = {T[T_F2 + 16 + g4 * 4], T[T_F2 + 16 + g4 * 4 + 1], T[T_F2 + 16 + g4 * 4 + 2],
-                        T[T_F2 + 16 + g4 * 4 + 3]};
+    if constexpr (PFT) {  // pass F3's twiddles, a stage and a transposition ahead
+      w6 = T[T_F6 + lane];
+      e7 = T[T_F2 + 64 + lane];
+      e8[0] = T[T_F3 + lane];
+      e8[1] = T[T_F3 + 64 + lane];
+      HX_UNROLL
+      for (int j = 0; j < 4; ++j) e9[j] = T[T_F3 + 128 + 64 * j + lane];
+      HX_SCHED_FENCE();
+    } else {
+      HX_UNROLL
+      for (int j = 0; j < 4; ++j) e5[j] = T[T_F2 + 16 + g4 * 4 + j];
+    }
     cplx *px = c.buf + base_mx(c);  // transposition MX -> M3, store side
     stage_store<2>(d, [&](int r) { return (r >> 3) ? times_i(e5[r & 3]) : e5[r & 3]; },
                    [&](int r) { px[mx_off(r)] = d[r]; });
@@ -297,86 +386,29 @@ HX_DEV void wave_forward(cplx (&d)[16], WaveCtx c) {
   HX_WAVE_SYNC();
   HX_PRIO_OPT(WAVE_PRIO_F3);
   {  // stages 6..9 over position bits 3..0 (= r bits 3..0), group index = lane . (r bits)
-    const cplx w6 = T[T_F6 + lane];
+    if constexpr (!PFT) w6 = T[T_F6 + lane];
     cplx *p3 = c.buf + base_m3(c);  // transposition MX -> M3, load side
     load_pairs<3>([&](int r) { d[r] = p3[r]; });
     HX_WAVE_SYNC();
     stage<3>(d, [&](int) { return w6; });
-    const cplx e7 = T[T_F2 + 64 + lane];
+    if constexpr (!PFT) e7 = T[T_F2 + 64 + lane];
     stage<2>(d, [&](int r) { return (r >> 3) ? times_i(e7) : e7; });
     HX_SCHED_FENCE();
-    const cplx e8[2] = {T[T_F3 + lane], T[T_F3 + 64 + lane]};
+    if constexpr (!PFT) {
+      e8[0] = T[T_F3 + lane];
+      e8[1] = T[T_F3 + 64 + lane];
+    }
     stage<1>(d, [&](int r) { return ((r >> 2) & 1) ? times_i(e8[r >> 3]) : e8[r >> 3]; });
     HX_SCHED_FENCE();
-    const cplx e9[4] = {T[T_F3 + 128 + lane], T[T_F3 + 192 + lane], T[T_F3 + 256 + lane],
-                        T[T_F3 + 320 + lane]};
+    if constexpr (!PFT) {
+      HX_UNROLL
+      for (int j = 0; j < 4; ++j) e9[j] = T[T_F3 + 128 + 64 * j + lane];
+    }
     stage_store<0>(d, [&](int r) { return ((r >> 1) & 1) ? times_i(e9[r >> 2]) : e9[r >> 2]; },
                    [&](int r) { p3[r] = d[r]; });
   }
   HX_WAVE_SYNC();
 }
-#else
-// ---- forward transform of 16 points per lane: mapping M1 in, mapping M3 out
-HX_DEV void wave_forward(cplx (&d)[16], WaveCtx c) {
-  HX_OPAQUE(c.lane);
-  c.hi4 = c.lane >> 2;
-  c.lo2 = c.lane & 3;
-  const int lane = c.lane, hi4 = c.hi4;
-  const cplx *T = c.T;
-  // pass F1: stages 0..3 over position bits 9..6 (= r bits 3..0); wave-uniform twiddles (LDS broadcast)
-  {
-    const cplx w0 = T[T_F1 + 0];
-    stage<3>(d, [&](int) { return w0; });
-    const cplx e1 = T[T_F1 + 1];
-    stage<2>(d, [&](int r) { return (r >> 3) ? times_i(e1) : e1; });
-    HX_SCHED_FENCE();
-    const cplx e2[2] = {T[T_F1 + 2], T[T_F1 + 3]};
-    stage<1>(d, [&](int r) { return ((r >> 2) & 1) ? times_i(e2[r >> 3]) : e2[r >> 3]; });
-    HX_SCHED_FENCE();
-    const cplx e3[4] = {T[T_F1 + 4], T[T_F1 + 5], T[T_F1 + 6], T[T_F1 + 7]};
-    cplx *p1 = c.buf + base_m1(c);  // transpose M1 -> M2, store side
-    stage_store<0>(d, [&](int r) { return ((r >> 1) & 1) ? times_i(e3[r >> 2]) : e3[r >> 2]; },
-                   [&](int r) { p1[68 * r] = d[r]; });
-  }
-  HX_WAVE_SYNC();
-  // pass F2: stages 4..7 over position bits 5..2; group index = hi4 . (r bits)
-  {
-    const cplx w4 = T[T_F2 + hi4];
-    const cplx *p2 = c.buf + base_m2(c);  // transpose M1 -> M2, load side
-    load_pairs<3>([&](int r) { d[r] = p2[4 * r]; });
-    HX_WAVE_SYNC();
-    stage<3>(d, [&](int) { return w4; });
-    const cplx e5 = T[T_F2 + 16 + hi4];
-    stage<2>(d, [&](int r) { return (r >> 3) ? times_i(e5) : e5; });
-    HX_SCHED_FENCE();
-    const cplx e6[2] = {T[T_F2 + 32 + hi4 * 2], T[T_F2 + 32 + hi4 * 2 + 1]};
-    stage<1>(d, [&](int r) { return ((r >> 2) & 1) ? times_i(e6[r >> 3]) : e6[r >> 3]; });
-    HX_SCHED_FENCE();
-    const cplx e7[4] = {T[T_F2 + 64 + hi4 * 4], T[T_F2 + 64 + hi4 * 4 + 1], T[T_F2 + 64 + hi4 * 4 + 2],
-                        T[T_F2 + 64 + hi4 * 4 + 3]};
-    cplx *p2w = c.buf + base_m2(c);  // transpose M2 -> M3, store side
-    stage_store<0>(d, [&](int r) { return ((r >> 1) & 1) ? times_i(e7[r >> 2]) : e7[r >> 2]; },
-                   [&](int r) { p2w[4 * r + (r >> 2)] = d[r]; });
-  }
-  HX_WAVE_SYNC();
-  // pass F3: stages 8, 9 over position bits 1, 0; the result also goes to my buffer (mapping M3) for
-  // the partner wave
-  {
-    const cplx e8[2] = {T[T_F3 + lane], T[T_F3 + 64 + lane]};
-    cplx *p3 = c.buf + base_m3(c);  // transpose M2 -> M3, load side
-    load_pairs<1>([&](int r) { d[r] = p3[r]; });
-    HX_WAVE_SYNC();
-    stage<1>(d, [&](int r) { return ((r >> 2) & 1) ? times_i(e8[r >> 3]) : e8[r >> 3]; });
-    HX_SCHED_FENCE();
-    const cplx e9[4] = {T[T_F3 + 128 + lane], T[T_F3 + 192 + lane], T[T_F3 + 256 + lane],
-                        T[T_F3 + 320 + lane]};
-    stage_store<0>(d, [&](int r) { return ((r >> 1) & 1) ? times_i(e9[r >> 2]) : e9[r >> 2]; },
-                   [&](int r) { p3[r] = d[r]; });
-  }
-  HX_WAVE_SYNC();
-}
-
-#endif  // WAVE_PERMLANE_PASS (forward)
 
 // ---- inverse transform (mapping M3 in, M1 out), untwist and accumulation into the torus regs.
 // Twiddle of DIT stage `half`, butterfly offset j: inv[half + j] = E[j*512/half] (nested tables),
@@ -402,47 +434,95 @@ HX_DEV void inverse_pass1_group(cplx (&o)[16], int g) {
   }
 }
 
+// inverse stage half = 4 (position bit 2 = r bit 2, twiddle E[128 (r & 1)], times -i for r & 2) on the points
+// r0 .. r0 + 7 (r0 = 0 or 8): literal or table twiddles, same butterflies either way
+HX_DEV void inverse_stage_half4(cplx (&o)[16], int r0, const cplx *T) {
+#if WAVE_UNIFORM_LITERALS
+  (void)T;
+  const cplx a1{LIT_E64[2][0], LIT_E64[2][1]};
+  HX_UNROLL
+  for (int r = r0; r < r0 + 4; ++r) {
+    if ((r & 3) == 0) bfly_one(o[r], o[r | 4]);
+    else if ((r & 3) == 2) bfly_mi(o[r], o[r | 4]);
+    else bfly(o[r], o[r | 4], (r & 2) ? times_mi(a1) : a1);
+  }
+#else
+  const cplx a0 = T[T_INV], a1 = T[T_INV + 128];
+  HX_UNROLL
+  for (int r = r0; r < r0 + 4; ++r) {
+    const cplx e = (r & 1) ? a1 : a0;
+    bfly(o[r], o[r | 4], (r & 2) ? times_mi(e) : e);
+  }
+#endif
+}
+
 // OVERWRITE (multi-bit: dst = 0 + src (x) GGSW): the result replaces the accumulator and is not staged.
 // NEG: the registers hold MINUS the accumulator (see make_digits); from_torus is odd, so the negated
 // term is the conversion of the negated real, whose sign rides on the untwist multiplication for free.
 // RAW (exact engine, split-key form): no torus conversion — o[r] becomes (t_re, t_im), the untwisted real values of
 // coefficients r*64 + lane and 1024 + r*64 + lane; nothing is staged, the accumulator registers are not touched.
-template <bool PASS1_DONE, bool OVERWRITE = false, bool NEG = false, bool RAW = false>
+// PASS1_DONE: 0 nothing done, 1 stages half = 1, 2 done by the caller
+// PFT: as in wave_forward — pass I3's twiddles are requested in front of the transposition reads of pass I2, the
+// untwist factors of coefficients r < 8 in front of pass I3 and those of r >= 8 in front of the conversion.
+template <int PASS1_DONE, bool OVERWRITE = false, bool NEG = false, bool RAW = false, bool PFT = false>
 HX_DEV void wave_inverse_accumulate(cplx (&o)[16], uint64_t (&acc_re)[16], uint64_t (&acc_im)[16], WaveCtx c) {
   uint64_t *stg = (uint64_t *)c.buf;
   HX_OPAQUE(c.lane);
-  c.hi4 = c.lane >> 2;
-  c.lo2 = c.lane & 3;
-  const int lo2 = c.lo2;
-  (void)lo2;
   const cplx *T = c.T;
-  if constexpr (!PASS1_DONE) {
+  if constexpr (PASS1_DONE == 0) {
     HX_UNROLL
     for (int g = 0; g < 4; ++g) inverse_pass1_group(o, g);
   }
-#if WAVE_PERMLANE_PASS
   // pass I1 (continued): stages half = 4, 8 over position bits 2, 3 (= r bits 2, 3); j = r & 3, r & 7, so the
   // twiddles are the same in every lane: E[j*128] and E[j*64]
   {
-    const cplx a0 = T[T_INV], a1 = T[T_INV + 128];
-    stage<2>(o, [&](int r) {
-      const cplx e = (r & 1) ? a1 : a0;
-      return (r & 2) ? times_mi(e) : e;
-    });
+    inverse_stage_half4(o, 0, T);
+    inverse_stage_half4(o, 8, T);
     HX_SCHED_FENCE();
-    const cplx b4[4] = {a0, T[T_INV + 64], a1, T[T_INV + 192]};
     cplx *p3 = c.buf + base_m3(c);  // transposition M3 -> MX, store side
+#if WAVE_UNIFORM_LITERALS
+    HX_UNROLL
+    for (int r = 0; r < 8; ++r) {  // stage half = 8: twiddle E[64 (r & 3)], times -i for r & 4
+      const cplx e{LIT_E64[r & 3][0], LIT_E64[r & 3][1]};
+      if (r == 0) bfly_one(o[r], o[r | 8]);
+      else if (r == 4) bfly_mi(o[r], o[r | 8]);
+      else bfly(o[r], o[r | 8], (r & 4) ? times_mi(e) : e);
+      p3[r] = o[r];
+      p3[r | 8] = o[r | 8];
+    }
+#else
+    const cplx a0 = T[T_INV], a1 = T[T_INV + 128];
+    const cplx b4[4] = {a0, T[T_INV + 64], a1, T[T_INV + 192]};
     stage_store<3>(o, [&](int r) { return (r & 4) ? times_mi(b4[r & 3]) : b4[r & 3]; },
                    [&](int r) { p3[r] = o[r]; });
+#endif
   }
   HX_WAVE_SYNC();
+  int lane = c.lane;
+  HX_OPAQUE(lane);
+  cplx w7, e8, e9[2], e10[4];
+  auto load_i3_a = [&]() {
+    w7 = T[T_W7 + (lane & 31)];
+    e8 = T[T_E8 + lane];
+  };
+  auto load_i3_b = [&]() {
+    e9[0] = T[T_INV + lane * 2];
+    e9[1] = T[T_INV + (64 + lane) * 2];
+  };
+  auto load_i3_c = [&]() {
+    HX_UNROLL
+    for (int j = 0; j < 4; ++j) e10[j] = T[T_INV + 64 * j + lane];
+  };
   // pass I2: stages half = 16, 32 over position bits 4, 5 (= r bits 2, 3 in mapping MX); j = (r bit 2).(lane & 15)
   {
-    int ln = c.lane;
-    HX_OPAQUE(ln);
-    const int l15 = ln & 15;
+    const int l15 = lane & 15;
     cplx w16 = T[T_W16 + (l15 & 7)];
     const cplx e32 = T[T_E32 + l15];
+    if constexpr (PFT) {
+      load_i3_a();
+      load_i3_b();
+      load_i3_c();
+    }
     const cplx *px = c.buf + base_mx(c);  // transposition M3 -> MX, load side
     load_pairs<2>([&](int r) { o[r] = px[mx_off(r)]; });
     HX_WAVE_SYNC();
@@ -453,57 +533,40 @@ HX_DEV void wave_inverse_accumulate(cplx (&o)[16], uint64_t (&acc_re)[16], uint6
   HX_SCHED_FENCE();
   swap_regs_lane54(o);  // MX -> M1
   HX_SCHED_FENCE();
-#else
-  HX_SCHED_FENCE();
-  // transpose M3 -> M2, store side
-  {
-    cplx *p3 = c.buf + base_m3(c);
-    HX_UNROLL
-    for (int r = 0; r < 16; ++r) p3[r] = o[r];
-  }
-  HX_WAVE_SYNC();
-  // pass I2: stages half = 4, 8, 16, 32 over position bits 2..5 (= r bits 0..3); j = (r bits).lo2
-  {
-    cplx w3 = T[T_INV + (lo2 & 1) * 128];
-    const cplx *p2r = c.buf + base_m2(c);  // transpose M3 -> M2, load side
-    load_pairs<0>([&](int r) { o[r] = p2r[4 * r + (r >> 2)]; });
-    HX_WAVE_SYNC();
-    if (lo2 & 2) w3 = times_mi(w3);
-    stage<0>(o, [&](int) { return w3; });
-    const cplx e4 = T[T_INV + lo2 * 64];
-    stage<1>(o, [&](int r) { return (r & 1) ? times_mi(e4) : e4; });
-    HX_SCHED_FENCE();
-    const cplx e5[2] = {T[T_INV + lo2 * 32], T[T_INV + (4 + lo2) * 32]};
-    stage<2>(o, [&](int r) { return (r & 2) ? times_mi(e5[r & 1]) : e5[r & 1]; });
-    HX_SCHED_FENCE();
-    const cplx e6[4] = {T[T_INV + lo2 * 16], T[T_INV + (4 + lo2) * 16], T[T_INV + (8 + lo2) * 16],
-                        T[T_INV + (12 + lo2) * 16]};
-    cplx *p2 = c.buf + base_m2(c);  // transpose M2 -> M1, store side
-    stage_store<3>(o, [&](int r) { return (r & 4) ? times_mi(e6[r & 3]) : e6[r & 3]; },
-                   [&](int r) { p2[4 * r] = o[r]; });
-  }
-  HX_WAVE_SYNC();
-#endif  // WAVE_PERMLANE_PASS (inverse, passes 1-2)
   HX_PRIO_OPT(WAVE_PRIO_I3);
+  // untwist factors: u[r*64 + lane] for r < 8, mirrored above (j = 512 is stored directly)
+  const cplx *Tu_lo = T + T_U + lane;         // u[r*64 + lane]           (r < 8)
+  const cplx *Tu_hi = T + T_U + 1024 - lane;  // u[1024 - (r*64 + lane)]  (r >= 8), mirrored
+  cplx ut[16];
+  auto load_u = [&](int r) {
+    if (r < 8) {
+      ut[r] = Tu_lo[r * 64];
+    } else {
+      const cplx e = Tu_hi[-r * 64];
+      ut[r] = (r == 8 && lane == 0) ? e : cplx{-e.im, -e.re};
+    }
+  };
+  if constexpr (PFT) {
+    HX_UNROLL
+    for (int r = 0; r < 8; ++r) load_u(r);
+    HX_SCHED_FENCE();
+  }
   // pass I3: stages half = 64..512 over position bits 6..9 (= r bits 0..3); j = (r bits).lane
   {
-    int lane = c.lane;
-    HX_OPAQUE(lane);
-    cplx w7 = T[T_W7 + (lane & 31)];
-#if !WAVE_PERMLANE_PASS
-    const cplx *p1 = c.buf + base_m1(c);  // transpose M2 -> M1, load side
-    load_pairs<0>([&](int r) { o[r] = p1[68 * r]; });
-    HX_WAVE_SYNC();
-#endif
+    if constexpr (!PFT) load_i3_a();
     if (lane & 32) w7 = times_mi(w7);
     stage<0>(o, [&](int) { return w7; });
-    const cplx e8 = T[T_E8 + lane];
     stage<1>(o, [&](int r) { return (r & 1) ? times_mi(e8) : e8; });
     HX_SCHED_FENCE();
-    const cplx e9[2] = {T[T_INV + lane * 2], T[T_INV + (64 + lane) * 2]};
+    if constexpr (!PFT) load_i3_b();
     stage<2>(o, [&](int r) { return (r & 2) ? times_mi(e9[r & 1]) : e9[r & 1]; });
     HX_SCHED_FENCE();
-    const cplx e10[4] = {T[T_INV + lane], T[T_INV + 64 + lane], T[T_INV + 128 + lane], T[T_INV + 192 + lane]};
+    if constexpr (!PFT) load_i3_c();
+    if constexpr (PFT) {  // the twiddles of the finished stages are dead: the second half of the untwist factors
+      HX_UNROLL
+      for (int r = 8; r < 16; ++r) load_u(r);
+      HX_SCHED_FENCE();
+    }
     stage<3>(o, [&](int r) { return (r & 4) ? times_mi(e10[r & 3]) : e10[r & 3]; });
   }
   HX_SCHED_FENCE();
@@ -511,18 +574,11 @@ HX_DEV void wave_inverse_accumulate(cplx (&o)[16], uint64_t (&acc_re)[16], uint6
   // untwist, back to the torus, accumulate (fft/mod.rs:311-330)
   int lane_u = c.lane;
   HX_OPAQUE(lane_u);
-  const cplx *Tu_lo = T + T_U + lane_u;         // u[r*64 + lane]           (r < 8)
-  const cplx *Tu_hi = T + T_U + 1024 - lane_u;  // u[1024 - (r*64 + lane)]  (r >= 8), mirrored
   const TorusConsts kt = torus_consts();
   HX_UNROLL
   for (int r = 0; r < 16; ++r) {
-    cplx u;
-    if (r < 8) {
-      u = Tu_lo[r * 64];
-    } else {
-      const cplx e = Tu_hi[-r * 64];
-      u = (r == 8 && lane_u == 0) ? e : cplx{-e.im, -e.re};  // j = 512 is stored directly
-    }
+    if constexpr (!PFT) load_u(r);
+    const cplx u = ut[r];
     const double tr = NEG ? fma(o[r].im, u.im, -o[r].re * u.re) : fma(-o[r].im, u.im, o[r].re * u.re);
     const double ti = NEG ? fma(-o[r].im, u.re, -o[r].re * u.im) : fma(o[r].im, u.re, o[r].re * u.im);
     if constexpr (RAW) {
@@ -534,7 +590,7 @@ HX_DEV void wave_inverse_accumulate(cplx (&o)[16], uint64_t (&acc_re)[16], uint6
       from_torus_add(acc_re[r], tr, kt);
       from_torus_add(acc_im[r], ti, kt);
       // stage the updated coefficients (c = r*64 + lane, 1024 + c) for the next iteration's rotation;
-      // the buffer is free (the M2 -> M1 reads above are complete) and these stores issue under the
+      // the buffer is free (the transposition reads above are complete) and these stores issue under the
       // conversion arithmetic instead of in front of the next rotation
       stg[lane_u + r * 64] = acc_re[r];
       stg[lane_u + 1024 + r * 64] = acc_im[r];
@@ -575,7 +631,7 @@ HX_DEV void wave_inverse_accumulate(cplx (&o)[16], uint64_t (&acc_re)[16], uint6
 // Horner states (64), the digit transform (64: re-published to the pair's LDS buffer after every limb's inverse
 // transposition has used that buffer) and the product being transformed back (64).
 template <int LEVEL_CT, int BASE_LOG_CT, int GROUPING = 0, bool SHARE = false, int LIMBS = 0>
-__global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables tb) {
+__global__ void __launch_bounds__((LIMBS > 0 && WAVE_SPLIT_REGACC) ? 256 : TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables tb) {
   constexpr bool MULTIBIT = GROUPING > 0;
   static_assert(!SHARE || MULTIBIT, "SHARE is a mode of the multi-bit loop");
   static_assert(LIMBS == 0 || (!MULTIBIT && LEVEL_CT == 1 && BASE_LOG_CT != 0 && BASE_LOG_CT <= 23),
@@ -742,6 +798,22 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
     HX_LAUNDER(vzero);  // the staged copy's base in a vector register: a scalar operand doubles the cost of the add
 #endif
     const char *staged = (const char *)buf64 + vzero;
+    // the staged words of the rotation, requested RPF coefficients pairs ahead of the arithmetic that uses them (0:
+    // just in time, every group of four then starts with an LDS round trip)
+    constexpr int RPF = (!MULTIBIT && LIMBS == 0 && LEVEL_CT == 1 && !EXACT) ? WAVE_ROT_PREFETCH : 0;
+    uint64_t sw0[16], sw1[16];
+    auto staged_request = [&](int r) {
+      int32_t ubr = ub;
+      if (RPF > 0) HX_LAUNDER(ubr);  // the offsets are recomputed where the words are used, not kept
+      const int32_t u0 = (int32_t)((uint32_t)ubr + r * 512u), u1 = (int32_t)((uint32_t)u0 + 8192u);
+      sw0[r] = *(const uint64_t *)(staged + (u0 & 0x3ff8));
+      sw1[r] = *(const uint64_t *)(staged + (u1 & 0x3ff8));
+    };
+    if constexpr (RPF > 0) {
+      HX_UNROLL
+      for (int r = 0; r < (RPF < 16 ? RPF : 16); ++r) staged_request(r);
+      HX_SCHED_FENCE();
+    }
     HX_UNROLL
     for (int r = 0; r < 16; ++r) {
       uint64_t x0, x1;
@@ -749,13 +821,20 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
         x0 = acc_re[r];
         x1 = acc_im[r];
       } else {
+        if constexpr (RPF > 0) {
+          if ((r & 3) == 0 && r + RPF < 16) {
+            HX_UNROLL
+            for (int j = 0; j < 4; ++j) staged_request(r + RPF + j);
+          }
+        } else {
+          staged_request(r);
+        }
         const int32_t u0 = (int32_t)((uint32_t)ub + r * 512u), u1 = (int32_t)((uint32_t)u0 + 8192u);
         const uint32_t m0 = (uint32_t)(u0 >> 31), m1 = (uint32_t)(u1 >> 31);  // all-ones: sign +
         const uint64_t M0 = ((uint64_t)m0 << 32) | m0, M1 = ((uint64_t)m1 << 32) | m1;
-        const uint64_t s0 = *(const uint64_t *)(staged + (u0 & 0x3ff8));
-        const uint64_t s1 = *(const uint64_t *)(staged + (u1 & 0x3ff8));
+        const uint64_t s0 = sw0[r], s1 = sw1[r];
         uint64_t a0 = acc_re[r], a1 = acc_im[r];
-        if constexpr (LIMBS > 0) {  // the accumulator is not in registers here: my own coefficients from the staged copy
+        if constexpr (LIMBS > 0 && !WAVE_SPLIT_REGACC) {  // the accumulator is not in registers here: my own coefficients from the staged copy
           a0 = *(const uint64_t *)(staged + (lane + r * 64) * 8);
           a1 = *(const uint64_t *)(staged + (1024 + lane + r * 64) * 8);
         }
@@ -821,7 +900,9 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
   // chunk c + 2 is requested into the registers chunk c has just released.  With FUSE_PASS1 the
   // first inverse pass (which only mixes the 4 points of one chunk) runs right behind each chunk.
   auto mac = [&](cplx (&dst)[16], cplx (&d)[16], cplx (&ka0)[4], cplx (&ka1)[4], cplx (&kb0)[4], cplx (&kb1)[4],
-                 const cplx *b0, const cplx *b1, uint32_t idx, uint32_t epoch, auto fuse_pass1) {
+                 const cplx *b0, const cplx *b1, uint32_t idx, uint32_t epoch, auto fuse_pass1, auto own_tag) {
+    // OWN: dst is d, my own row of the digit transform, updated in place; only the partner's row comes from LDS
+    constexpr bool OWN = decltype(own_tag)::value;
     WaveCtx ctx = ctx0;
     HX_OPAQUE(ctx.lane);
     const int lane = ctx.lane;
@@ -843,49 +924,77 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
     // the LDS reads run WAVE_MAC_PREFETCH points ahead of the products that consume them (issued just in
     // time, each pair exposed a full LDS latency to this wave)
     constexpr int PF = WAVE_MAC_PREFETCH;
-    cplx xn0[PF > 0 ? PF : 1], xn1[PF > 0 ? PF : 1];
-    HX_UNROLL
-    for (int q = 0; q < PF; ++q) {
-      xn0[q] = row0[q];
-      xn1[q] = row1[q];
-    }
-    HX_UNROLL
-    for (int ch = 0; ch < 4; ++ch) {
-      cplx(&k0)[4] = (ch & 1) ? kb0 : ka0;
-      cplx(&k1)[4] = (ch & 1) ? kb1 : ka1;
+    // SEL 2: both rows from LDS; SEL 0 / 1 (OWN): I hold polynomial 0 / 1 — my row is dst itself, in place, and only
+    // the partner's row is read (two copies of the loop, one scalar branch around them)
+    auto products = [&](auto sel_tag) {
+      constexpr int SEL = decltype(sel_tag)::value;
+      const cplx *rowo = obuf + base_m3(ctx);
+      cplx xn0[PF > 0 ? PF : 1], xn1[PF > 0 ? PF : 1];
       HX_UNROLL
-      for (int j = 0; j < 4; ++j) {
-        const int r = ch * 4 + j;
-        cplx x0, x1;
-        if constexpr (PF > 0) {
-          x0 = xn0[r % PF];
-          x1 = xn1[r % PF];
-          if (r + PF < 16) {
-            xn0[r % PF] = row0[r + PF];
-            xn1[r % PF] = row1[r + PF];
-          }
+      for (int q = 0; q < PF; ++q) {
+        if constexpr (SEL == 2) {
+          xn0[q] = row0[q];
+          xn1[q] = row1[q];
         } else {
-          x0 = row0[r];
-          x1 = row1[r];
+          xn0[q] = rowo[q];
         }
-        const cplx t = (idx == 0) ? cmul_first(x0, k0[j]) : cmul_add(x0, k0[j], dst[r]);
-        dst[r] = cmul_add(x1, k1[j], t);
-        // pin the product here: otherwise the FMAs are sunk below the flag wait that follows and
-        // the key loads stay live across it
-        HX_OPAQUE(dst[r].re);
-        HX_OPAQUE(dst[r].im);
       }
-      HX_SCHED_FENCE();
-      if (ch < 2) key_request(k0, k1, b0, b1, ch + 2);
-      if constexpr (decltype(fuse_pass1)::value) {
-        inverse_pass1_group(dst, ch);
+      HX_UNROLL
+      for (int ch = 0; ch < 4; ++ch) {
+        cplx(&k0)[4] = (ch & 1) ? kb0 : ka0;
+        cplx(&k1)[4] = (ch & 1) ? kb1 : ka1;
         HX_UNROLL
         for (int j = 0; j < 4; ++j) {
-          HX_OPAQUE(dst[ch * 4 + j].re);
-          HX_OPAQUE(dst[ch * 4 + j].im);
+          const int r = ch * 4 + j;
+          cplx x0, x1;
+          if constexpr (SEL == 2) {
+            if constexpr (PF > 0) {
+              x0 = xn0[r % PF];
+              x1 = xn1[r % PF];
+              if (r + PF < 16) {
+                xn0[r % PF] = row0[r + PF];
+                xn1[r % PF] = row1[r + PF];
+              }
+            } else {
+              x0 = row0[r];
+              x1 = row1[r];
+            }
+          } else {
+            cplx xo;
+            if constexpr (PF > 0) {
+              xo = xn0[r % PF];
+              if (r + PF < 16) xn0[r % PF] = rowo[r + PF];
+            } else {
+              xo = rowo[r];
+            }
+            x0 = SEL == 0 ? dst[r] : xo;
+            x1 = SEL == 0 ? xo : dst[r];
+          }
+          const cplx t = (idx == 0) ? cmul_first(x0, k0[j]) : cmul_add(x0, k0[j], dst[r]);
+          dst[r] = cmul_add(x1, k1[j], t);
+          // pin the product here: otherwise the FMAs are sunk below the flag wait that follows and
+          // the key loads stay live across it
+          HX_OPAQUE(dst[r].re);
+          HX_OPAQUE(dst[r].im);
         }
+        HX_SCHED_FENCE();
+        if (ch < 2) key_request(k0, k1, b0, b1, ch + 2);
+        if constexpr (decltype(fuse_pass1)::value) {
+          inverse_pass1_group(dst, ch);
+          HX_UNROLL
+          for (int j = 0; j < 4; ++j) {
+            HX_OPAQUE(dst[ch * 4 + j].re);
+            HX_OPAQUE(dst[ch * 4 + j].im);
+          }
+        }
+        HX_SCHED_FENCE();
       }
-      HX_SCHED_FENCE();
+    };
+    if constexpr (OWN) {
+      if (w == 0) products(std::integral_constant<int, 0>{});
+      else products(std::integral_constant<int, 1>{});
+    } else {
+      products(std::integral_constant<int, 2>{});
     }
     HX_WAVE_SYNC();
     if (lane == 0) flag_set(r_done_me, epoch);
@@ -1270,7 +1379,7 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
         HX_WAVE_SYNC();
       }
       HX_PRIO(WAVE_PRIO_MB_D);
-      wave_inverse_accumulate<false, true>(o, acc_re, acc_im, ctx);
+      wave_inverse_accumulate<0, true>(o, acc_re, acc_im, ctx);
       HX_PRIO(WAVE_PRIO_MB_K);
 #if WAVE_MB_PACE && !defined(TFHE_HIPEMU)
       pace_arrive();
@@ -1281,6 +1390,7 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
     U64x2 *gacc = (U64x2 *)(a.acc_scratch + ((size_t)sample * 2 + (size_t)w) * N) + lane;  // slot r*64 + lane: coefficients c, 1024 + c
     typedef uint64_t v2u64 __attribute__((ext_vector_type(2)));
     auto acc_load = [&]() {
+      if (WAVE_SPLIT_REGACC) return;
       HX_UNROLL
       for (int r = 0; r < 16; ++r) {
 #if WAVE_SPLIT_NT && !defined(TFHE_HIPEMU)
@@ -1295,6 +1405,7 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
       }
     };
     auto acc_store = [&]() {
+      if (WAVE_SPLIT_REGACC) return;
       HX_UNROLL
       for (int r = 0; r < 16; ++r) {
 #if WAVE_SPLIT_NT && !defined(TFHE_HIPEMU)
@@ -1344,10 +1455,10 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
         key_rows(i, limb, b0, b1);
         HX_PRIO(WAVE_PRIO_C);
         mac(o, o, ka0, ka1, kb0, kb1, b0, b1, 0, (it - 1) * (uint32_t)LIMBS + limb + 1,
-            std::integral_constant<bool, WAVE_FUSE_PASS1 != 0>{});
+            std::integral_constant<bool, WAVE_FUSE_PASS1 != 0>{}, std::false_type{});
         if constexpr (LAST) acc_load();
         HX_PRIO(WAVE_PRIO_D);
-        wave_inverse_accumulate<WAVE_FUSE_PASS1 != 0, false, false, true>(o, acc_re, acc_im, ctx);
+        wave_inverse_accumulate<(WAVE_FUSE_PASS1 != 0) ? 1 : 0, false, false, true>(o, acc_re, acc_im, ctx);
         HX_UNROLL
         for (int r = 0; r < 16; ++r) {
           fold(R_re[r], o[r].re);
@@ -1398,12 +1509,13 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
         HX_PRIO(WAVE_PRIO_A);
         make_digits(d, a_hat, 0);
         HX_PRIO(WAVE_PRIO_B);
-        wave_forward(d, ctx);
+        wave_forward<WAVE_TW_PREFETCH != 0>(d, ctx);
         HX_PRIO(WAVE_PRIO_C);
         // in place: d becomes the Fourier-domain output of polynomial w, first inverse pass applied
-        mac(d, d, ka0, ka1, kb0, kb1, b0, b1, 0, it, std::integral_constant<bool, WAVE_FUSE_PASS1 != 0>{});
+        mac(d, d, ka0, ka1, kb0, kb1, b0, b1, 0, it, std::integral_constant<bool, WAVE_FUSE_PASS1 != 0>{},
+            std::integral_constant<bool, WAVE_MAC_OWN_REGS != 0>{});
         HX_PRIO(WAVE_PRIO_D);
-        wave_inverse_accumulate<WAVE_FUSE_PASS1 != 0, false, NEGACC>(d, acc_re, acc_im, ctx);
+        wave_inverse_accumulate<(WAVE_FUSE_PASS1 != 0) ? 1 : 0, false, NEGACC, false, WAVE_TW_PREFETCH != 0>(d, acc_re, acc_im, ctx);
       } else {
         cplx o[16];
         for (uint32_t idx = 0; idx < level; ++idx) {
@@ -1416,10 +1528,10 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
           HX_PRIO(WAVE_PRIO_B);
           wave_forward(d, ctx);
           HX_PRIO(WAVE_PRIO_C);
-          mac(o, d, ka0, ka1, kb0, kb1, b0, b1, idx, (it - 1) * level + idx + 1, std::false_type{});
+          mac(o, d, ka0, ka1, kb0, kb1, b0, b1, idx, (it - 1) * level + idx + 1, std::false_type{}, std::false_type{});
         }
         HX_PRIO(WAVE_PRIO_D);
-        wave_inverse_accumulate<false, false, NEGACC>(o, acc_re, acc_im, ctx);
+        wave_inverse_accumulate<0, false, NEGACC>(o, acc_re, acc_im, ctx);
       }
     }
   }
@@ -1536,6 +1648,7 @@ static void launch_split_t(hipStream_t st, const PbsArgs &a, const FftTables &tb
   hx_set_dynamic_smem_once<pbs_fft_wave_kernel<1, B, 0, false, NTT_SPLIT_LIMBS>>(SMEM_BYTES);
   unsigned per_block = lwes_per_block(a.num_samples);
   if (per_block > WAVE_SPLIT_LWES) per_block = WAVE_SPLIT_LWES;
+  if (WAVE_SPLIT_REGACC && per_block > 2) per_block = 2;
   const unsigned blocks = (a.num_samples + per_block - 1) / per_block;
   HX_LAUNCH((pbs_fft_wave_kernel<1, B, 0, false, NTT_SPLIT_LIMBS>), dim3(blocks), dim3(128 * per_block), SMEM_BYTES, st, a,
             tb);
