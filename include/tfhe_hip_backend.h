@@ -268,6 +268,12 @@ void hip_programmable_bootstrap_ntt64_split_async(
     uint32_t polynomial_size, uint32_t base_log, uint32_t level_count,
     uint32_t num_samples, uint32_t num_many_lut, uint32_t lut_stride);
 
+/* Round-off check of the split-key engine: 1 if any launch on this scratch since the last call saw an f64 limb product
+ * further than 1/4 from an integer (outputs not to be trusted; never observed with the supported bounds, which are
+ * statistical: worst-case products of 2^49 leave 4 bits of headroom), else 0.  Synchronises the stream, clears the flag. */
+uint32_t hip_programmable_bootstrap_ntt64_split_roundoff_status(
+    void *stream, uint32_t gpu_index, int8_t *buffer);
+
 /* Exact-integer engine (negacyclic convolution mod 2^64 on the standard-domain key,
  * cc/algorithms/lwe_programmable_bootstrapping/karatsuba_pbs.rs:71-116,199-413).  O(N^2): a
  * verification engine; it reproduces the reference's golden *_karatsuba vectors bit for bit. */

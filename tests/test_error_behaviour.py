@@ -100,13 +100,40 @@ ABORTS = {
             s, C.byref(mem), ffi.CudaLweBootstrapKeyParamsFFI(12, 1, 2048, 23, 1, 2048, 1, 0),
             ffi.CudaLweKeyswitchKeyParamsFFI(2048, 12, 4, 4), 8, 2, 8, 0, True, 0)
         """, "message_modulus 2 < 3 is not supported"),
-    "signed-overflow flag of the carry propagation": ("""
+    "signed-overflow flag without the operands of the addition (integer.cuh:2368-2370)": ("""
         s = ffi.CudaStreamsFFI((C.c_void_p * 1)(S), (C.c_uint32 * 1)(0), 1)
         mem = C.c_void_p()
         lib.scratch_cuda_propagate_single_carry_64_inplace_async(
             s, C.byref(mem), ffi.CudaLweBootstrapKeyParamsFFI(12, 1, 2048, 23, 1, 2048, 1, 0),
             ffi.CudaLweKeyswitchKeyParamsFFI(2048, 12, 4, 4), 8, 4, 4, 1, True, 0)
-        """, "signed-overflow flag is not wired"),
+        v = gpu.CudaVec(9 * 2049, st)
+        ct = ffi.CudaRadixCiphertextFFI(v.ptr, None, None, 8, 8, 2048)
+        one = (C.c_void_p * 1)(v.ptr)
+        lib.cuda_propagate_single_carry_64_inplace_async(s, C.byref(ct), C.byref(ct), C.byref(ct), mem, one, one, 1, 0)
+        """, "single carry propagation is not supported for overflow, try using add_and_propagate_single_carry"),
+    "carry propagation on blocks whose degrees exceed what its first bootstrap separates": ("""
+        s = ffi.CudaStreamsFFI((C.c_void_p * 1)(S), (C.c_uint32 * 1)(0), 1)
+        mem = C.c_void_p()
+        lib.scratch_cuda_propagate_single_carry_64_inplace_async(
+            s, C.byref(mem), ffi.CudaLweBootstrapKeyParamsFFI(12, 1, 2048, 23, 1, 2048, 1, 0),
+            ffi.CudaLweKeyswitchKeyParamsFFI(2048, 12, 4, 4), 8, 4, 4, 0, True, 0)
+        v = gpu.CudaVec(8 * 2049, st)
+        deg = (C.c_uint64 * 8)(*([3] * 7 + [9]))      # 3 + 3 + 3: the sum of three clean blocks, not of two
+        ct = ffi.CudaRadixCiphertextFFI(v.ptr, deg, None, 8, 8, 2048)
+        one = (C.c_void_p * 1)(v.ptr)
+        lib.cuda_propagate_single_carry_64_inplace_async(s, C.byref(ct), None, None, mem, one, one, 0, 0)
+        """, "block 7 has degree 9, the carry propagation accepts at most 6"),
+    "boolean multiplication on a scratch created for a product": ("""
+        s = ffi.CudaStreamsFFI((C.c_void_p * 1)(S), (C.c_uint32 * 1)(0), 1)
+        mem = C.c_void_p()
+        lib.scratch_cuda_integer_mult_inplace_64_async(
+            s, C.byref(mem), False, False, 4, 4, ffi.CudaLweBootstrapKeyParamsFFI(12, 1, 2048, 23, 1, 2048, 1, 0),
+            ffi.CudaLweKeyswitchKeyParamsFFI(2048, 12, 4, 4), 2, True, 0)
+        v = gpu.CudaVec(2 * 2049, st)
+        ct = ffi.CudaRadixCiphertextFFI(v.ptr, None, None, 2, 2, 2048)
+        one = (C.c_void_p * 1)(v.ptr)
+        lib.cuda_integer_mult_inplace_64_async(s, C.byref(ct), False, C.byref(ct), True, one, one, mem, 2048, 2)
+        """, "boolean operands need a scratch created with is_boolean_left / is_boolean_right"),
     "radix layer on a multi-bit key whose grouping factor does not divide n": ("""
         s = ffi.CudaStreamsFFI((C.c_void_p * 1)(S), (C.c_uint32 * 1)(0), 1)
         mem = C.c_void_p()

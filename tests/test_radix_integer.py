@@ -297,3 +297,59 @@ def test_apply_many_lookup_table_extracts_every_function_from_one_bootstrap(kind
     # walks past the polynomial — covered in tests/test_error_behaviour.py style by the size check below
     one = sks.apply_many_lookup_table(ct, many, 1, stride, st, degree=3)
     assert np.array_equal(one.to_blocks(st).reshape(len(vals), 4, -1), blocks[0])
+
+
+def _signed(v, bits):
+    v &= (1 << bits) - 1
+    return v - (1 << bits) if v >> (bits - 1) else v
+
+
+@pytest.mark.parametrize("kind", BACKENDS)
+def test_signed_overflow_flag_of_add_and_propagate(kind):
+    """OutputFlag::Overflow of cuda_add_and_propagate_single_carry (integer.h:39,383-407; integer_utilities.h:2311-2357,
+    :2383-2412): the flag is 1 exactly when the two's-complement sum of the operands (and the input carry) leaves the
+    range of the width — the reference's signed_overflowing_add tests compare with the clear i64 result the same way.
+    Widths: a single block (the input carry is the carry into the sign block), a partial group, the carry tree's
+    three-level shape.  propagate_single_carry alone refuses the flag like the reference (integer.cuh:2368-2370)."""
+    p, keys, st, sks, igpu = setup(kind)
+    rng = np.random.default_rng(31)
+    for L in ((1, 2, 5) if kind == "emu" else (1, 2, 5, 13, 32)):
+        bits = 2 * L
+        top = 1 << (bits - 1)
+        cases = [(top - 1, 1, 0), (top - 1, 0, 1), (top, top, 0), (top, top - 1, 1), (top - 1, top - 1, 1),
+                 ((1 << bits) - 1, 1, 0), (0, 0, 0), (top, (1 << bits) - 1, 0), (top | 1, (1 << bits) - 1, 0)]
+        cases += [(int(rng.integers(0, 1 << bits)) if bits < 63 else int(rng.integers(0, 1 << 62)) * 4 + int(rng.integers(0, 4)),
+                   int(rng.integers(0, 1 << bits)) if bits < 63 else int(rng.integers(0, 1 << 62)) * 4 + int(rng.integers(0, 4)),
+                   int(rng.integers(0, 2))) for _ in range(3 if kind == "emu" else 8)]
+        a, b, c = [x for x, _, _ in cases], [y for _, y, _ in cases], [z for _, _, z in cases]
+        for use_cin in (True, False):
+            ca = igpu.CudaUnsignedRadixCiphertext.from_blocks(encrypt_radix(p, keys, a, L, 41), st)
+            cb = igpu.CudaUnsignedRadixCiphertext.from_blocks(encrypt_radix(p, keys, b, L, 42), st)
+            ca.set_degrees(MSG - 1)
+            cb.set_degrees(MSG - 1)
+            cin = igpu.CudaUnsignedRadixCiphertext.from_blocks(
+                encrypt_big(p, keys, c, seed=43).reshape(len(a), 1, -1), st) if use_cin else None
+            ovf = sks.add_assign(ca, cb, st, carry_in=cin, want_overflow=True)
+            cc = c if use_cin else [0] * len(a)
+            clear = [_signed(x, bits) + _signed(y, bits) + z for x, y, z in zip(a, b, cc)]
+            assert recompose(decrypt_blocks(p, keys, ca.to_blocks(st))) == [v % (1 << bits) for v in clear], (L, use_cin)
+            want = [int(not (-(1 << (bits - 1)) <= v < (1 << (bits - 1)))) for v in clear]
+            assert [r[0] for r in decrypt_blocks(p, keys, ovf.to_blocks(st))] == want, (L, use_cin)
+            assert list(ca.degrees) == [MSG - 1] * ca.total_blocks
+
+
+@pytest.mark.parametrize("kind", BACKENDS)
+def test_multiplication_by_an_encrypted_boolean(kind):
+    """is_boolean_right / is_boolean_left of cuda_integer_mult_inplace (integer.h:173-187; multiplication.cuh:508-520,
+    cmux.cuh:13-46 zero_out_if): every block of the integer is kept where the boolean is 1 and zeroed where it is 0."""
+    p, keys, st, sks, igpu = setup(kind)
+    L = 4 if kind == "emu" else 32
+    bits = 2 * L
+    rng = np.random.default_rng(33)
+    vals = [int(rng.integers(0, 1 << min(bits, 62))) for _ in range(3 if kind == "emu" else 6)] + [(1 << bits) - 1]
+    conds = [i & 1 for i in range(len(vals))]
+    for left in (False, True):
+        ct = igpu.CudaUnsignedRadixCiphertext.from_blocks(encrypt_radix(p, keys, vals, L, 51), st)
+        cb = igpu.CudaUnsignedRadixCiphertext.from_blocks(encrypt_big(p, keys, conds, seed=52).reshape(len(vals), 1, -1), st)
+        out = sks.mul_by_boolean_assign(ct, cb, st, boolean_is_left=left)
+        assert recompose(decrypt_blocks(p, keys, out.to_blocks(st))) == [v * k for v, k in zip(vals, conds)], left

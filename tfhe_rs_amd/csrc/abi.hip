@@ -32,11 +32,13 @@ struct PbsBuffer {
   NttTables ntt;
   uint64_t *acc_scratch = nullptr;
   uint64_t *split_acc = nullptr;  // exact engine, split-key form: (k+1) N accumulator words per sample in device memory
+  uint32_t *split_flag = nullptr; // ... and its round-off flag (PbsArgs::roundoff_flag), allocated with split_acc
   // hip_keyswitch_programmable_bootstrap_chain_64_async: keyswitch operands written by the bootstrap of the previous
   // call for ITS outputs (what they are valid for is recorded; anything else falls back to the digit pass)
   int8_t *emit_a = nullptr;
   int32_t *emit_suma = nullptr;
   size_t emit_bytes = 0;
+  std::vector<void *> emit_retired;  // smaller emit buffers a captured graph may still write: freed with the scratch
   struct {
     bool valid = false;
     const void *array = nullptr, *indexes = nullptr;
@@ -436,28 +438,35 @@ void hip_keyswitch_programmable_bootstrap_chain_64_async(void *stream, uint32_t 
   PbsArgs a = make_args(lwe_array_out, lwe_output_indexes, lut_vector, lut_vector_indexes, b->ks_out, b->trivial,
                         bootstrapping_key, lwe_dimension, base_log, level_count, num_samples, num_many_lut, lut_stride,
                         b->ms_type);
-  if ((flags & HIP_KSPBS_EMIT_DIGITS) && emittable && num_many_lut == 1 && polynomial_size == 2048 && glwe_dimension == 1) {
+  // The operands only pay off where the NEXT keyswitch takes the GEMM path (keyswitch_mfma consumes them from
+  // g_keyswitch_gemm_min LWEs on): below that, the flag changes nothing.
+  if ((flags & HIP_KSPBS_EMIT_DIGITS) && emittable && num_many_lut == 1 && polynomial_size == 2048 && glwe_dimension == 1 &&
+      num_samples >= g_keyswitch_gemm_min.load()) {
     const size_t a_bytes = (size_t)((b->max_samples + 31) / 32) * steps * 1024;
     const size_t need = a_bytes + (size_t)((b->max_samples + 31) / 32) * 32 * sizeof(int32_t);
-    if (b->emit_bytes < need) {  // first use (or another decomposition): an allocation, not under stream capture
-      if (b->emit_a) HX_CHECK(hipFree(b->emit_a));
+    if (b->emit_bytes < need && !stream_is_capturing(S(stream))) {
+      // first use (or another decomposition): an allocation, hence never under stream capture; a buffer that is
+      // replaced is kept until the scratch is cleaned up — a graph captured earlier may hold its address
+      if (b->emit_a) b->emit_retired.push_back(b->emit_a);
       HX_CHECK(hipMalloc((void **)&b->emit_a, need));
       b->emit_bytes = need;
     }
-    b->emit_suma = (int32_t *)(b->emit_a + a_bytes);
-    a.emit_a = b->emit_a;
-    a.emit_suma = b->emit_suma;
-    a.emit_base_log = ks_base_log;
-    a.emit_level = ks_level;
-    a.emit_level_pad = level_pad;
-    a.emit_steps = steps;
-    b->emitted.valid = true;
-    b->emitted.array = lwe_array_out;
-    b->emitted.indexes = lwe_output_indexes;
-    b->emitted.count = num_samples;
-    b->emitted.steps = steps;
-    b->emitted.base_log = ks_base_log;
-    b->emitted.level = ks_level;
+    if (b->emit_bytes >= need) {  // (a capture that found no buffer: no emission, the next keyswitch runs its digit pass)
+      b->emit_suma = (int32_t *)(b->emit_a + a_bytes);
+      a.emit_a = b->emit_a;
+      a.emit_suma = b->emit_suma;
+      a.emit_base_log = ks_base_log;
+      a.emit_level = ks_level;
+      a.emit_level_pad = level_pad;
+      a.emit_steps = steps;
+      b->emitted.valid = true;
+      b->emitted.array = lwe_array_out;
+      b->emitted.indexes = lwe_output_indexes;
+      b->emitted.count = num_samples;
+      b->emitted.steps = steps;
+      b->emitted.base_log = ks_base_log;
+      b->emitted.level = ks_level;
+    }
   }
   if (launch_classic_pbs(S(stream), a, b, glwe_dimension, polynomial_size) != 2)
     b->emitted.valid = false;  // only the throughput kernel emits: a launch another kernel took left nothing usable
@@ -523,14 +532,32 @@ void hip_programmable_bootstrap_ntt64_split_async(void *stream, uint32_t gpu_ind
   if (b->split_acc == nullptr) {
     // first use of this engine with this scratch: the accumulators' home (an allocation — not under stream capture;
     // a capture must be preceded by one plain launch, like the keyswitch's first use of a key)
+    HX_PANIC_IF_FALSE(!stream_is_capturing(S(stream)),
+                      "split-key exact engine: the first launch on a scratch allocates and cannot be captured; run it once before the capture");
     HX_CHECK(hipMalloc((void **)&b->split_acc, (size_t)b->max_samples * (glwe_dimension + 1) * polynomial_size * sizeof(uint64_t)));
+    HX_CHECK(hipMalloc((void **)&b->split_flag, sizeof(uint32_t)));
+    HX_CHECK(hipMemsetAsync(b->split_flag, 0, sizeof(uint32_t), S(stream)));
   }
   PbsArgs a = make_args(lwe_array_out, lwe_output_indexes, lut_vector, lut_vector_indexes, lwe_array_in,
                         lwe_input_indexes, bootstrapping_key, lwe_dimension, base_log, level_count, num_samples,
                         num_many_lut, lut_stride, b->ms_type);
   a.acc_scratch = b->split_acc;
+  a.roundoff_flag = b->split_flag;
   launch_pbs_ntt_split_wave(S(stream), a, b->fft);
   g_last_pbs_kernel.store(13);
+}
+// 1 if any launch of the split-key engine on this scratch since the last call saw an f64 product further than 1/4 from
+// an integer (its outputs are then not to be trusted), else 0; synchronises the stream and clears the flag
+uint32_t hip_programmable_bootstrap_ntt64_split_roundoff_status(void *stream, uint32_t gpu_index, int8_t *buffer) {
+  set_device(gpu_index);
+  PbsBuffer *b = reinterpret_cast<PbsBuffer *>(buffer);
+  HX_PANIC_IF_FALSE(b != nullptr && b->magic == kPbsMagic, "roundoff_status: foreign scratch pointer");
+  if (b->split_flag == nullptr) return 0;
+  uint32_t v = 0;
+  HX_CHECK(hipMemcpyAsync(&v, b->split_flag, sizeof(uint32_t), hipMemcpyDeviceToHost, S(stream)));
+  HX_CHECK(hipStreamSynchronize(S(stream)));
+  if (v != 0) HX_CHECK(hipMemsetAsync(b->split_flag, 0, sizeof(uint32_t), S(stream)));
+  return v;
 }
 
 // ---- reference-order f64 engine (pbs_ref64.hip): the key in tfhe-fft's dif4 transform order
@@ -606,6 +633,8 @@ void cleanup_cuda_programmable_bootstrap_64(void *stream, uint32_t gpu_index, in
   HX_CHECK(hipStreamSynchronize(S(stream)));  // cleanup_* synchronises (pbs_utilities.h:261-271)
   if (b->acc_scratch) HX_CHECK(hipFree(b->acc_scratch));
   if (b->split_acc) HX_CHECK(hipFree(b->split_acc));
+  if (b->split_flag) HX_CHECK(hipFree(b->split_flag));
+  for (void *r : b->emit_retired) HX_CHECK(hipFree(r));
   if (b->emit_a) HX_CHECK(hipFree(b->emit_a));
   if (b->ks_out) HX_CHECK(hipFree(b->ks_out));
   if (b->trivial) HX_CHECK(hipFree(b->trivial));
@@ -679,7 +708,7 @@ uint64_t scratch_cuda_multi_bit_programmable_bootstrap_64_async(void *stream, ui
   slots = slots < b->lat_samples ? b->lat_samples : slots > most ? most : slots;  // at least one group each
   const uint64_t lat_bytes = b->lat_samples ? slots * kb_per_sample : 0;
   if (allocate_gpu_memory) {
-    b->fft = get_fft_tables(gpu_index, S(stream), polynomial_size);
+    b->fft = get_fft_tables(gpu_index, S(stream), polynomial_size, true);
     HX_CHECK(hipMalloc((void **)&b->acc, (size_t)b->chunk * acc_per_sample));
     HX_CHECK(hipMalloc((void **)&b->pace, 8 * 32 * sizeof(uint32_t)));
     if (lat_bytes) HX_CHECK(hipMalloc((void **)&b->kb_lat, lat_bytes));

@@ -214,6 +214,20 @@ HX_DEV cplx load_global_cplx(const cplx *p) {
 #endif
 }
 
+// One table entry at a WAVE-UNIFORM index of a table nobody writes during the launch, through the scalar data cache
+// (s_load: no vector-memory request, no LDS read, the value arrives in scalar registers and feeds the f64
+// instructions as their one scalar operand).  The constant address space is what makes the compiler pick the scalar
+// path for a uniform address.
+HX_DEV cplx load_uniform_cplx(const double *table, uint32_t idx) {
+#if defined(TFHE_HIPEMU)
+  return cplx{table[2 * idx], table[2 * idx + 1]};
+#else
+  typedef const double __attribute__((address_space(4))) *cptr;
+  const cptr t = (cptr)(const void *)table;
+  return cplx{t[2 * idx], t[2 * idx + 1]};
+#endif
+}
+
 // DESIGN.md §4 butterfly: (a, b) -> (a + s*b, 2a - (a + s*b))
 HX_DEV void bfly(cplx &a, cplx &b, const cplx s) {
   const double o1r = fma(-b.im, s.im, fma(b.re, s.re, a.re));

@@ -416,7 +416,13 @@ enum : uint64_t {
   LUT_OUT_Z = 20,    // 4 state + z -> the same, the carry into the last block is z >= 2
   LUT_MSG = 21,      // x -> x % msg                  (single-block integers)
   LUT_CARRY = 22,    // x -> x / msg
-  LUT_PROP_COUNT = 23
+  // signed overflow of an addition (FLAG_OVERFLOW, integer_utilities.h:2311-2357, :2383-2412): the last blocks of the
+  // two operands, packed msg * lhs + rhs BEFORE the addition, give 8 (overflow if a carry arrives) + 4 (if none);
+  // the flag is read off that + z, z as in LUT_OUT_*
+  LUT_OVF_PREP = 23,
+  LUT_OVF_BIT = 24,  // 8 o1 + 4 o0 + z -> z ? o1 : o0      (z = the carry into the last block itself)
+  LUT_OVF_Z = 25,    // 8 o1 + 4 o0 + z -> (z >= 2) ? o1 : o0
+  LUT_PROP_COUNT = 26
 };
 
 struct PropagateMem {
@@ -428,7 +434,8 @@ struct PropagateMem {
   uint32_t blocks = 0;   // blocks per integer
   uint32_t max_cts = 0;  // integers the scratch was sized for
   // scratch ciphertexts: pool = [W of level 0 (the blocks), W of level 1, ... | C of level 0 (top level only), C of
-  // level 1, ... | M: 4 (value % msg) of every block | P: state of the first two blocks of every full group]
+  // level 1, ... | M: 4 (value % msg) of every block | P: state of the first two blocks of every full group | O: the
+  // overflow preparation of every integer (FLAG_OVERFLOW)]
   // (shifted states; carries into the elements); P2: dense sums of one round
   uint64_t *d_pool = nullptr, *d_p = nullptr;
   uint32_t cached_cts = 0;
@@ -437,7 +444,8 @@ struct PropagateMem {
     uint64_t *a = nullptr, *b = nullptr, *o = nullptr, *lut = nullptr;
     uint32_t count = 0;
   };
-  Idx rA, rTop, rRes, rOut, rIO, rOne;
+  Idx rA, rTop, rRes, rOut, rOvf, rOvfPrep, rIO, rOne, rLast, rOne1;
+  uint64_t *d_pack = nullptr;  // msg * (last block of lhs) + (last block of rhs), one per integer (FLAG_OVERFLOW)
   std::vector<Idx> up, down;  // up[l]: states of level l + 1 from level l; down[l] (l >= 1): carries into level l
 
   // elements per level: n[0] = blocks, n[l + 1] = ceil(n[l] / 3) until at most TOP are left
@@ -448,7 +456,7 @@ struct PropagateMem {
   }
   static uint64_t pool_slots(uint32_t L) {  // per integer
     const auto n = level_sizes(L);
-    uint64_t s = L + (n.size() > 1 ? n[1] : 0);  // M, P
+    uint64_t s = L + (n.size() > 1 ? n[1] : 0) + 1;  // M, P, O (overflow preparation of the integer)
     for (uint32_t v : n) s += 2 * (uint64_t)v;   // W, C
     return s;
   }
@@ -497,6 +505,9 @@ struct PropagateMem {
     const uint64_t mbase = next;
     next += (uint64_t)cts * L;
     const uint64_t pbase = next;
+    next += (uint64_t)cts * (n.size() > 1 ? n[1] : 0);
+    const uint64_t obase = next;
+    auto O = [&](uint32_t c) { return obase + c; };
     auto W = [&](size_t l, uint32_t c, uint32_t e) { return wbase[l] + (uint64_t)c * n[l] + e; };
     auto M = [&](uint32_t c, uint32_t j) { return mbase + (uint64_t)c * L + j; };
     auto P = [&](uint32_t c, uint32_t g) { return pbase + (uint64_t)c * n[1] + g; };
@@ -573,7 +584,7 @@ struct PropagateMem {
       down[l] = make(st, a, b, o, lut);
     }
     // results: 4 m + z; and the output carry of every integer from 4 (state of the last block) + z
-    std::vector<uint64_t> a2{0}, b2, lut2;
+    std::vector<uint64_t> a2{0}, b2, lut2, a3{0}, b3, lut3, o3, l3;
     reset();
     a.push_back(0);
     for (uint32_t c = 0; c < cts; ++c)
@@ -595,6 +606,13 @@ struct PropagateMem {
           b2.push_back(W(0, c, j));
           a2.push_back(b2.size());
           lut2.push_back(z_is_bit ? LUT_OUT_BIT : LUT_OUT_Z);
+          // ... and next to the overflow preparation
+          b3.insert(b3.end(), b.begin() + (std::ptrdiff_t)before, b.end());
+          b3.push_back(O(c));
+          a3.push_back(b3.size());
+          lut3.push_back(z_is_bit ? LUT_OVF_BIT : LUT_OVF_Z);
+          o3.push_back(O(c));
+          l3.push_back(LUT_OVF_PREP);
         }
         b.push_back(M(c, j));
         a.push_back(b.size());
@@ -602,6 +620,8 @@ struct PropagateMem {
       }
     rRes = make(st, a, b, {}, lut);
     rOut = make(st, a2, b2, {}, lut2);
+    rOvf = make(st, a3, b3, {}, lut3);
+    rOvfPrep = make(st, {}, {}, o3, l3);
     // optional input carry (added to block 0 of every integer); single-block integers: message and carry of v
     reset();
     std::vector<uint64_t> l1;
@@ -612,6 +632,17 @@ struct PropagateMem {
     }
     rIO = make(st, a, {}, {}, lut);
     rOne = make(st, {}, {}, {}, l1);
+    {  // last block of every integer (operand views); single-block integers: the preparation alone as a "group"
+      std::vector<uint64_t> last, a1{0}, b1, lo;
+      for (uint32_t c = 0; c < cts; ++c) {
+        last.push_back(T(c, L - 1));
+        b1.push_back(O(c));
+        a1.push_back(b1.size());
+        lo.push_back(LUT_OVF_BIT);
+      }
+      rLast = make(st, last, {}, {}, {});
+      rOne1 = make(st, a1, b1, {}, lo);
+    }
     cached_cts = cts;
   }
 
@@ -650,11 +681,29 @@ struct PropagateMem {
     one(LUT_OUT_Z, [](uint64_t x) -> uint64_t { return ((x >> 2) + ((x & 3) >= 2)) >= 2; });
     one(LUT_MSG, [m](uint64_t x) -> uint64_t { return x % m; });
     one(LUT_CARRY, [m](uint64_t x) -> uint64_t { return x / m; });
+    {
+      uint32_t bits = 0;
+      while ((1ull << bits) < m) ++bits;
+      // integer_utilities.h:2326-2352 (f_overflow_fp): the carry into the sign bit against the carry out of the block
+      one(LUT_OVF_PREP, [m, bits](uint64_t x) -> uint64_t {
+        const uint64_t lhs = x / m, rhs = x % m, mask = (1ull << (bits - 1)) - 1;
+        uint64_t r = 0;
+        for (uint64_t cin = 0; cin < 2; ++cin) {
+          const uint64_t out_c = ((lhs + rhs + cin) >> bits) & 1;
+          const uint64_t in_c = (((lhs & mask) + (rhs & mask) + cin) >> (bits - 1)) & 1;
+          r |= (uint64_t)(in_c != out_c) << (2 + cin);
+        }
+        return r;
+      });
+      one(LUT_OVF_BIT, [](uint64_t x) -> uint64_t { return (x & 3) ? (x >> 3) & 1 : (x >> 2) & 1; });
+      one(LUT_OVF_Z, [](uint64_t x) -> uint64_t { return (x & 3) >= 2 ? (x >> 3) & 1 : (x >> 2) & 1; });
+    }
     const uint32_t T = cts * num_blocks;
     drv.init(ss, p, std::min<uint32_t>(T, 1u << 16), luts, 2);
     const size_t w = p.big_n + 1;
     radix_alloc((void **)&d_pool, (size_t)cts * pool_slots(num_blocks) * w * sizeof(uint64_t));
     radix_alloc((void **)&d_p, (size_t)T * w * sizeof(uint64_t));
+    radix_alloc((void **)&d_pack, (size_t)cts * w * sizeof(uint64_t));
     if (!t_dry) build_indexes(S0(ss), cts);  // a call with fewer integers rebuilds them
   }
 
@@ -669,8 +718,17 @@ struct PropagateMem {
   // in place on v (cts integers of `blocks` blocks).  carry_in (one block per integer, value 0/1) is added to
   // block 0 first — a first block of value <= 2 msg - 1 still emits at most one carry and receives none;
   // carry_out (one block per integer) receives the carry leaving the last block.  Either may be null.
+  // overflow_out (one block per integer, add_and_propagate only): the signed-overflow flag of the addition whose last
+  // operand blocks the caller packed into d_pack before adding (pack_last_blocks).
+  void pack_last_blocks(const CudaStreamsFFI &ss, const uint64_t *lhs, const uint64_t *rhs, uint32_t cts) {
+    const Params &p = drv.p;
+    const uint32_t w = p.big_n + 1;
+    // block (c + 1) * blocks - 1 of both operands: strided views, one launch per integer batch through index arrays
+    if (cached_cts != cts) build_indexes(S0(ss), cts);
+    axpy(S0(ss), d_pack, nullptr, lhs, rLast.a, p.msg, rhs, rLast.a, w, cts);
+  }
   void run(const CudaStreamsFFI &ss, uint64_t *v, uint32_t cts, void *const *ksks, void *const *bsks,
-           const uint64_t *carry_in = nullptr, uint64_t *carry_out = nullptr) {
+           const uint64_t *carry_in = nullptr, uint64_t *carry_out = nullptr, uint64_t *overflow_out = nullptr) {
     const hipStream_t st = S0(ss);  // linear operations and index uploads: first GPU only, like the reference
     HX_PANIC_IF_FALSE(cts >= 1 && cts <= max_cts, "carry propagation: %u integers exceed the scratch capacity %u", cts,
                       max_cts);
@@ -679,7 +737,14 @@ struct PropagateMem {
     const uint32_t w = p.big_n + 1, T = cts * blocks;
     const size_t top = up.size();
     if (carry_in) axpy(st, v, rIO.a, v, rIO.a, 1, carry_in, nullptr, w, cts);
+    if (overflow_out)  // 8 o1 + 4 o0 of every integer, from the operands' last blocks
+      drv.round(ss, d_pool, rOvfPrep.o, d_pack, nullptr, rOvfPrep.lut, cts, ksks, bsks);
     if (blocks == 1) {  // nothing to propagate: the carry leaves the integer
+      if (overflow_out) {  // the carry into the only block is the input carry itself
+        HX_LAUNCH(lwe_group_sum_kernel, dim3(cts), dim3(256), 0, st, d_p, d_pool, rOne1.a, rOne1.b, w, cts);
+        if (carry_in) axpy(st, d_p, nullptr, d_p, nullptr, 1, carry_in, nullptr, w, cts);
+        drv.round(ss, overflow_out, nullptr, d_p, nullptr, rOne1.lut, cts, ksks, bsks);
+      }
       if (carry_out) drv.round(ss, carry_out, nullptr, v, nullptr, rIO.lut, cts, ksks, bsks);
       drv.round(ss, v, nullptr, v, nullptr, rOne.lut, cts, ksks, bsks);
       return;
@@ -692,6 +757,7 @@ struct PropagateMem {
     for (size_t l = top; l-- > 1;) summed_round(ss, d_pool, down[l], w, ksks, bsks);
     // results (and the output carry) from 4 m + z
     if (carry_out) summed_round(ss, carry_out, rOut, w, ksks, bsks);
+    if (overflow_out) summed_round(ss, overflow_out, rOvf, w, ksks, bsks);
     summed_round(ss, v, rRes, w, ksks, bsks);
   }
 
@@ -699,7 +765,7 @@ struct PropagateMem {
     drv.release(ss);
     for (auto *d : dev_arrays) HX_CHECK(hipFree(d));
     dev_arrays.clear();
-    for (uint64_t *d : {d_pool, d_p})
+    for (uint64_t *d : {d_pool, d_p, d_pack})
       if (d) HX_CHECK(hipFree(d));
     magic = 0;
   }
@@ -991,6 +1057,52 @@ struct MulMem {
   }
 };
 
+// Multiplication by an encrypted boolean (integer.h:173-177 is_boolean_left / is_boolean_right; multiplication.h:28-49,
+// cmux.cuh:13-46 zero_out_if): every block of the integer packed with the boolean's single block, one bivariate
+// table (condition == 0 ? 0 : block): one KS -> PBS round of `blocks` bootstraps per integer.
+struct BoolMulMem {
+  static constexpr uint32_t kMagic = 0x424D554C;  // "BMUL"
+  uint32_t magic = kMagic;
+  bool size_only = false;
+  LutDriver drv;
+  uint32_t blocks = 0, max_cts = 0;
+  uint64_t *d_pack = nullptr, *d_cond_idx = nullptr, *d_lut_idx = nullptr;
+
+  void init(const CudaStreamsFFI &ss, const Params &p, uint32_t num_blocks, uint32_t cts) {
+    blocks = num_blocks;
+    max_cts = cts;
+    const uint64_t m = p.msg;
+    std::vector<std::vector<uint64_t>> luts(1, std::vector<uint64_t>((size_t)(p.k + 1) * p.N));
+    generate_lut(p, luts[0].data(), [m](uint64_t x) -> uint64_t { return (x % m) == 0 ? 0 : x / m; });
+    const uint32_t T = cts * num_blocks;
+    drv.init(ss, p, std::min<uint32_t>(T, 1u << 16), luts);
+    radix_alloc((void **)&d_pack, (size_t)T * (p.big_n + 1) * sizeof(uint64_t));
+    if (!t_dry) {
+      std::vector<uint64_t> ci(T), li(T, 0);
+      for (uint32_t i = 0; i < T; ++i) ci[i] = i / num_blocks;  // the boolean of integer c is block c of its operand
+      d_cond_idx = dev_upload(S0(ss), ci);
+      d_lut_idx = dev_upload(S0(ss), li);
+    }
+  }
+  // out <- condition ? value : 0; `cond` holds one block per integer
+  void run(const CudaStreamsFFI &ss, uint64_t *out, const uint64_t *value, const uint64_t *cond, uint32_t cts,
+           void *const *ksks, void *const *bsks) {
+    HX_PANIC_IF_FALSE(cts >= 1 && cts <= max_cts, "boolean multiplication: %u integers exceed the scratch capacity %u",
+                      cts, max_cts);
+    const Params &p = drv.p;
+    const uint32_t T = cts * blocks;
+    axpy(S0(ss), d_pack, nullptr, value, nullptr, p.msg, cond, d_cond_idx, p.big_n + 1, T);
+    drv.round(ss, out, nullptr, d_pack, nullptr, d_lut_idx, T, ksks, bsks);
+  }
+  void release(const CudaStreamsFFI &ss) {
+    HX_CHECK(hipStreamSynchronize(S0(ss)));
+    drv.release(ss);
+    for (uint64_t *d : {d_pack, d_cond_idx, d_lut_idx})
+      if (d) HX_CHECK(hipFree(d));
+    magic = 0;
+  }
+};
+
 static uint32_t batch_of(const CudaRadixCiphertextFFI *ct, uint32_t blocks, const char *what) {
   HX_PANIC_IF_FALSE(ct != nullptr && ct->ptr != nullptr, "%s: null radix ciphertext", what);
   HX_PANIC_IF_FALSE(blocks != 0 && ct->num_radix_blocks % blocks == 0,
@@ -1136,6 +1248,20 @@ void cuda_add_lwe_ciphertext_vector_inplace_64(void *stream, uint32_t gpu_index,
   }
 }
 
+// The carry tree's first bootstrap holds two functions in its accumulator, so a block's value must stay below
+// msg * carry / 2: at most 2 msg - 2 (two clean blocks added), one more for block 0 of an integer when an input carry
+// is added to it.  A caller that tracks degrees gets the call refused instead of a wrong result.
+static void check_propagation_degrees(const CudaRadixCiphertextFFI *ct, uint32_t msg, bool /*with_carry_in*/,
+                                      uint32_t /*blocks_per_integer*/, const char *who) {
+  if (ct == nullptr || ct->degrees == nullptr) return;
+  for (uint32_t i = 0; i < ct->num_radix_blocks; ++i) {
+    const uint64_t limit = 2ull * msg - 2;  // (the input carry itself comes on top of block 0: 2 msg - 1 there is fine)
+    HX_PANIC_IF_FALSE(ct->degrees[i] <= limit,
+                      "%s: block %u has degree %llu, the carry propagation accepts at most %llu (propagate the operands first)",
+                      who, i, (unsigned long long)ct->degrees[i], (unsigned long long)limit);
+  }
+}
+
 // ---- cuda/include/integer/integer.h:383-413 --------------------------------------------------
 // num_blocks = blocks per integer; the ciphertexts handed to the launch may hold any whole number
 // of integers up to the capacity given through hip_integer_scratch_batch (default 1).
@@ -1156,8 +1282,7 @@ uint64_t scratch_cuda_propagate_single_carry_64_inplace_async(CudaStreamsFFI str
                                                               uint32_t carry_modulus, uint32_t requested_flag,
                                                               bool allocate_gpu_memory,
                                                               enum PBS_MS_REDUCTION_T noise_reduction_type) {
-  HX_PANIC_IF_FALSE(requested_flag == 0 /* FLAG_NONE */ || requested_flag == 2 /* FLAG_CARRY */,
-                    "propagate_single_carry: the signed-overflow flag is not wired (requested_flag=%u)", requested_flag);
+  HX_PANIC_IF_FALSE(requested_flag <= 2, "propagate_single_carry: unknown output flag %u", requested_flag);
   const Params p = make_params(bsk_params, ksk_params, message_modulus, carry_modulus, (uint32_t)noise_reduction_type);
   t_dry = !allocate_gpu_memory;
   t_bytes = 0;
@@ -1185,9 +1310,13 @@ void cuda_propagate_single_carry_64_inplace_async(CudaStreamsFFI streams, CudaRa
   auto *m = reinterpret_cast<PropagateMem *>(mem_ptr);
   HX_PANIC_IF_FALSE(m && m->magic == PropagateMem::kMagic, "propagate_single_carry: foreign scratch pointer");
   HX_PANIC_IF_FALSE(!m->size_only, "propagate_single_carry: scratch was created with allocate_gpu_memory=false");
-  HX_PANIC_IF_FALSE(requested_flag == 0 || requested_flag == 2,
-                    "propagate_single_carry: the signed-overflow flag is not wired (requested_flag=%u)", requested_flag);
+  // integer.cuh:2368-2370: the overflow flag needs the operands of the addition
+  HX_PANIC_IF_FALSE(requested_flag != 1, "single carry propagation is not supported for overflow, try using "
+                                         "add_and_propagate_single_carry");
+  HX_PANIC_IF_FALSE(requested_flag == 0 || requested_flag == 2, "propagate_single_carry: unknown output flag %u",
+                    requested_flag);
   const uint32_t cts = batch_of(lwe_array, m->blocks, "propagate_single_carry");
+  check_propagation_degrees(lwe_array, m->drv.p.msg, uses_carry != 0, m->blocks, "propagate_single_carry");
   // the reference's Rust caller always hands over carry_in / carry_out structs (integer/gpu/ffi.rs:2213-2237);
   // they are read / written only when uses_carry / requested_flag say so
   const uint64_t *cin = nullptr;
@@ -1222,9 +1351,52 @@ void cuda_add_and_propagate_single_carry_64_inplace_async(CudaStreamsFFI streams
                                                           const CudaRadixCiphertextFFI *carry_in, int8_t *mem_ptr,
                                                           void *const *bsks, void *const *ksks,
                                                           uint32_t requested_flag, uint32_t uses_carry) {
+  if (requested_flag != 1) {
+    cuda_add_lwe_ciphertext_vector_inplace_64(streams.streams[0], G0(streams), lhs_array, rhs_array);
+    cuda_propagate_single_carry_64_inplace_async(streams, lhs_array, carry_out, carry_in, mem_ptr, bsks, ksks,
+                                                 requested_flag, uses_carry);
+    return;
+  }
+  // FLAG_OVERFLOW (integer.cuh:2493-2520, integer_utilities.h:2311-2357): carry_out receives the signed-overflow flag of
+  // lhs + rhs (+ carry_in) — the carry into the sign bit against the carry out of the last block.  The operands' last
+  // blocks are read before the addition; both operands are clean (degrees <= msg - 1: the preparation is a bivariate
+  // table of the two last blocks).
+  auto *m = reinterpret_cast<PropagateMem *>(mem_ptr);
+  HX_PANIC_IF_FALSE(m && m->magic == PropagateMem::kMagic, "add_and_propagate_single_carry: foreign scratch pointer");
+  HX_PANIC_IF_FALSE(!m->size_only, "add_and_propagate_single_carry: scratch was created with allocate_gpu_memory=false");
+  HX_PANIC_IF_FALSE(lhs_array && rhs_array && lhs_array->num_radix_blocks == rhs_array->num_radix_blocks &&
+                        lhs_array->lwe_dimension == rhs_array->lwe_dimension,
+                    "add_and_propagate_single_carry: operands must have the same shape");
+  const uint32_t cts = batch_of(lhs_array, m->blocks, "add_and_propagate_single_carry");
+  HX_PANIC_IF_FALSE(carry_out && carry_out->ptr && carry_out->num_radix_blocks >= cts &&
+                        carry_out->lwe_dimension == lhs_array->lwe_dimension,
+                    "when requesting FLAG_CARRY or FLAG_OVERFLOW, carry_out must be a valid pointer (one block per integer)");
+  const uint32_t msg = m->drv.p.msg;
+  for (const CudaRadixCiphertextFFI *op : {(const CudaRadixCiphertextFFI *)lhs_array, rhs_array})
+    if (op->degrees)
+      for (uint32_t c = 0; c < cts; ++c)
+        HX_PANIC_IF_FALSE(op->degrees[(size_t)(c + 1) * m->blocks - 1] <= msg - 1,
+                          "add_and_propagate_single_carry: FLAG_OVERFLOW needs clean last blocks (degree %llu > %u)",
+                          (unsigned long long)op->degrees[(size_t)(c + 1) * m->blocks - 1], msg - 1);
+  const uint64_t *cin = nullptr;
+  if (uses_carry != 0) {
+    HX_PANIC_IF_FALSE(carry_in && carry_in->ptr && carry_in->num_radix_blocks >= cts &&
+                          carry_in->lwe_dimension == lhs_array->lwe_dimension,
+                      "add_and_propagate_single_carry: uses_carry needs one input carry block per integer");
+    cin = (const uint64_t *)carry_in->ptr;
+  }
+  m->pack_last_blocks(streams, (const uint64_t *)lhs_array->ptr, (const uint64_t *)rhs_array->ptr, cts);
   cuda_add_lwe_ciphertext_vector_inplace_64(streams.streams[0], G0(streams), lhs_array, rhs_array);
-  cuda_propagate_single_carry_64_inplace_async(streams, lhs_array, carry_out, carry_in, mem_ptr, bsks, ksks,
-                                               requested_flag, uses_carry);
+  check_propagation_degrees(lhs_array, msg, uses_carry != 0, m->blocks, "add_and_propagate_single_carry");
+  m->run(streams, (uint64_t *)lhs_array->ptr, cts, ksks, bsks, cin, nullptr, (uint64_t *)carry_out->ptr);
+  for (uint32_t i = 0; i < cts; ++i) {
+    if (carry_out->degrees) carry_out->degrees[i] = 1;
+    if (carry_out->noise_levels) carry_out->noise_levels[i] = 1;
+  }
+  for (uint32_t i = 0; i < lhs_array->num_radix_blocks; ++i) {
+    if (lhs_array->degrees) lhs_array->degrees[i] = msg - 1;
+    if (lhs_array->noise_levels) lhs_array->noise_levels[i] = 1;
+  }
 }
 
 void cleanup_cuda_propagate_single_carry_64_inplace(CudaStreamsFFI streams, int8_t **mem_ptr_void) {
@@ -1246,10 +1418,17 @@ uint64_t scratch_cuda_integer_mult_inplace_64_async(CudaStreamsFFI streams, int8
                                                     CudaLweKeyswitchKeyParamsFFI ksk_params, uint32_t num_blocks,
                                                     bool allocate_gpu_memory,
                                                     enum PBS_MS_REDUCTION_T noise_reduction_type) {
-  HX_PANIC_IF_FALSE(!is_boolean_left && !is_boolean_right, "integer_mult: boolean operands are not wired");
   const Params p = make_params(bsk_params, ksk_params, message_modulus, carry_modulus, (uint32_t)noise_reduction_type);
   t_dry = !allocate_gpu_memory;
   t_bytes = 0;
+  if (is_boolean_left || is_boolean_right) {  // one operand is an encrypted boolean: a select, not a product
+    auto *bm = new BoolMulMem();
+    bm->init(streams, p, num_blocks, g_scratch_batch);
+    bm->size_only = t_dry;
+    t_dry = false;
+    *mem_ptr = reinterpret_cast<int8_t *>(bm);
+    return t_bytes;
+  }
   auto *m = new MulMem();
   m->init(streams, p, num_blocks, g_scratch_batch);
   m->size_only = t_dry;
@@ -1262,11 +1441,35 @@ void cuda_integer_mult_inplace_64_async(CudaStreamsFFI streams, CudaRadixCiphert
                                         bool const is_bool_left, CudaRadixCiphertextFFI const *radix_lwe_right,
                                         bool const is_bool_right, void *const *bsks, void *const *ksks,
                                         int8_t *mem_ptr, uint32_t polynomial_size, uint32_t num_blocks) {
+  if (is_bool_left || is_bool_right) {
+    // multiplication.cuh:508-520: the boolean operand is ONE block (here: one per integer of the batch, packed at the
+    // start of its ciphertext); the other operand's blocks are kept or zeroed.  In place on radix_lwe_inout, which
+    // holds the full-width integers either way (as the left operand, or as the destination when it is the boolean).
+    auto *bm = reinterpret_cast<BoolMulMem *>(mem_ptr);
+    HX_PANIC_IF_FALSE(bm && bm->magic == BoolMulMem::kMagic,
+                      "integer_mult: boolean operands need a scratch created with is_boolean_left / is_boolean_right");
+    HX_PANIC_IF_FALSE(!bm->size_only, "integer_mult: scratch was created with allocate_gpu_memory=false");
+    HX_PANIC_IF_FALSE(polynomial_size == bm->drv.p.N && num_blocks == bm->blocks, "integer_mult: call does not match the scratch");
+    HX_PANIC_IF_FALSE(radix_lwe_inout && radix_lwe_right && radix_lwe_inout->lwe_dimension == radix_lwe_right->lwe_dimension,
+                      "integer_mult: input and output lwe dimensions should be the same");
+    const uint32_t cts = batch_of(radix_lwe_inout, bm->blocks, "integer_mult");
+    const CudaRadixCiphertextFFI *cond = is_bool_right ? radix_lwe_right : radix_lwe_inout;
+    const CudaRadixCiphertextFFI *value = is_bool_right ? (const CudaRadixCiphertextFFI *)radix_lwe_inout : radix_lwe_right;
+    HX_PANIC_IF_FALSE(cond->num_radix_blocks >= cts && value->num_radix_blocks >= cts * bm->blocks,
+                      "integer_mult: input or output does not have enough radix blocks");
+    // (a boolean that sits in the destination is read by the packing launch before the bootstrap overwrites it)
+    bm->run(streams, (uint64_t *)radix_lwe_inout->ptr, (const uint64_t *)value->ptr, (const uint64_t *)cond->ptr, cts,
+            ksks, bsks);
+    for (uint32_t i = 0; i < cts * bm->blocks; ++i) {
+      if (radix_lwe_inout->degrees) radix_lwe_inout->degrees[i] = bm->drv.p.msg - 1;
+      if (radix_lwe_inout->noise_levels) radix_lwe_inout->noise_levels[i] = 1;
+    }
+    return;
+  }
   auto *m = reinterpret_cast<MulMem *>(mem_ptr);
   HX_PANIC_IF_FALSE(m && m->magic == MulMem::kMagic, "integer_mult: foreign scratch pointer");
   HX_PANIC_IF_FALSE(!m->size_only, "integer_mult: scratch was created with allocate_gpu_memory=false");
-  HX_PANIC_IF_FALSE(!is_bool_left && !is_bool_right && polynomial_size == m->drv.p.N && num_blocks == m->blocks,
-                    "integer_mult: call does not match the scratch");
+  HX_PANIC_IF_FALSE(polynomial_size == m->drv.p.N && num_blocks == m->blocks, "integer_mult: call does not match the scratch");
   const uint32_t cts = batch_of(radix_lwe_inout, m->blocks, "integer_mult");
   HX_PANIC_IF_FALSE(radix_lwe_right && radix_lwe_right->num_radix_blocks == radix_lwe_inout->num_radix_blocks,
                     "integer_mult: operands must have the same shape");
@@ -1278,6 +1481,13 @@ void cuda_integer_mult_inplace_64_async(CudaStreamsFFI streams, CudaRadixCiphert
 }
 
 void cleanup_cuda_integer_mult_inplace_64(CudaStreamsFFI streams, int8_t **mem_ptr_void) {
+  if (*mem_ptr_void && reinterpret_cast<BoolMulMem *>(*mem_ptr_void)->magic == BoolMulMem::kMagic) {
+    auto *bm = reinterpret_cast<BoolMulMem *>(*mem_ptr_void);
+    bm->release(streams);
+    delete bm;
+    *mem_ptr_void = nullptr;
+    return;
+  }
   auto *m = reinterpret_cast<MulMem *>(*mem_ptr_void);
   HX_PANIC_IF_FALSE(m && m->magic == MulMem::kMagic, "cleanup integer_mult: foreign scratch pointer");
   m->release(streams);
@@ -1288,6 +1498,8 @@ void cleanup_cuda_integer_mult_inplace_64(CudaStreamsFFI streams, int8_t **mem_p
 // number of PBS one carry propagation / one multiplication of `num_blocks` blocks issues (for benches)
 uint64_t hip_integer_propagate_pbs_count(uint32_t num_blocks) { return PropagateMem::pbs_count(num_blocks); }
 uint64_t hip_integer_mult_pbs_count(int8_t *mem_ptr) {
+  if (mem_ptr && reinterpret_cast<BoolMulMem *>(mem_ptr)->magic == BoolMulMem::kMagic)
+    return reinterpret_cast<BoolMulMem *>(mem_ptr)->blocks;
   auto *m = reinterpret_cast<MulMem *>(mem_ptr);
   HX_PANIC_IF_FALSE(m && m->magic == MulMem::kMagic, "hip_integer_mult_pbs_count: foreign scratch pointer");
   uint64_t n = m->prod_slot.size();

@@ -62,6 +62,7 @@ extern std::atomic<bool> g_keyswitch_split_digits;
 extern std::atomic<uint32_t> g_last_keyswitch_path;
 extern std::atomic<uint32_t> g_keyswitch_kparts;
 extern std::atomic<uint32_t> g_keyswitch_gemm_min;
+bool stream_is_capturing(hipStream_t st);  // keyswitch.hip: the stream is recording a graph (nothing may allocate)
 void ksd_release_stream(int device, hipStream_t st);  // the large-batch keyswitch's per-stream scratch
 extern bool g_ntt_kernel_serial;
 

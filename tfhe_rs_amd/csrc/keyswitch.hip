@@ -20,10 +20,14 @@ constexpr int KS_TPB = 256;  // output columns per workgroup
 constexpr int KS_TB = 16;    // samples per workgroup
 constexpr int KS_IC = 32;    // mask elements decomposed per LDS stage
 constexpr int KS_MAXL = 8;   // max levels staged (level_count <= 8 for every shortint set)
-std::atomic<bool> g_keyswitch_use_mfma{true};
-std::atomic<bool> g_keyswitch_split_digits{true};
-std::atomic<uint32_t> g_last_keyswitch_path{0};
-std::atomic<uint32_t> g_keyswitch_kparts{8};  // workgroups per column tile of the small-batch kernel (hip_backend_set_keyswitch_kparts)  // tests: 0 scalar kernels, 1 one-launch matrix-core kernel, 2 digit pass + GEMM, 3 GEMM on emitted digits  // hip_backend_set_keyswitch_kernel(2): one-launch matrix-core kernel at every batch size  // hip_backend_set_keyswitch_kernel: matrix-core path when its conditions hold
+// kernel selection (hip_backend_set_keyswitch_kernel: 0 = automatic, 1 = scalar kernels, 2 = the one-launch matrix-core
+// kernel at every batch size, 3 = digit pass + GEMM from 129 LWEs on; tests and measurements)
+std::atomic<bool> g_keyswitch_use_mfma{true};       // false: scalar kernels only
+std::atomic<bool> g_keyswitch_split_digits{true};   // false: never the digit pass + GEMM
+std::atomic<uint32_t> g_last_keyswitch_path{0};     // which path the last launch took: 0 scalar kernels, 1 one-launch
+                                                    // matrix-core kernel, 2 digit pass + GEMM, 3 GEMM on emitted digits
+std::atomic<uint32_t> g_keyswitch_kparts{8};        // workgroups per column tile of the one-launch kernel at small
+                                                    // batches (hip_backend_set_keyswitch_kparts)
 
 // DigitT: int32_t when base_log <= 31 (every shortint set), int64_t for wider bases
 template <typename DigitT>
@@ -640,14 +644,22 @@ __global__ void __launch_bounds__(256, 2) ks_gemm_kernel(OutT *lwe_out, const ui
   }
 }
 
-// A operands + digit sums of the large-batch path: one growing buffer per (device, stream) — the keyswitch entry
-// points of the reference carry no scratch argument.  Never grown under stream capture (the launch then takes
-// ks_mfma_kernel); released with the stream (cuda_destroy_stream) or when a larger one replaces it.
+// A operands + digit sums of the large-batch path: buffers per (device, stream) — the keyswitch entry points of the
+// reference carry no scratch argument.  Two buffers, so that nothing a captured graph refers to is ever freed, replaced
+// or shared with live launches:
+//   * `live`  serves launches outside stream capture; it grows by allocate-new / synchronise the stream / free-old;
+//   * `cap`   serves launches recorded under stream capture.  Capture allocates nothing: the first captured launch that
+//             finds a large enough `live` buffer takes it over (it becomes `cap`, later plain launches allocate a new
+//             `live`); a captured launch that finds neither takes the one-launch kernel.  `cap` is only released with
+//             the stream (cuda_destroy_stream), after every graph instantiated from the capture must be gone
+//             (graphs).
 struct KsdScratch {
   int device;
   hipStream_t stream;
-  void *buf;
-  size_t bytes;
+  void *live;
+  size_t live_bytes;
+  void *cap;
+  size_t cap_bytes;
 };
 static std::vector<KsdScratch> g_ksd;
 static std::mutex g_ksd_mutex;
@@ -658,35 +670,46 @@ static void *ksd_scratch(int device, hipStream_t st, size_t bytes, bool capturin
     KsdScratch *e = nullptr;
     for (KsdScratch &k : g_ksd)
       if (k.device == device && k.stream == st) e = &k;
-    if (e != nullptr && e->bytes >= bytes) return e->buf;
-    if (capturing) return nullptr;
+    if (capturing) {
+      if (e == nullptr) return nullptr;
+      if (e->cap != nullptr) return e->cap_bytes >= bytes ? e->cap : nullptr;
+      if (e->live == nullptr || e->live_bytes < bytes) return nullptr;
+      e->cap = e->live;  // from now on this buffer belongs to the graphs captured on this stream
+      e->cap_bytes = e->live_bytes;
+      e->live = nullptr;
+      e->live_bytes = 0;
+      return e->cap;
+    }
+    if (e != nullptr && e->live_bytes >= bytes) return e->live;
     if (e == nullptr) {
-      g_ksd.push_back(KsdScratch{device, st, nullptr, 0});
+      g_ksd.push_back(KsdScratch{device, st, nullptr, 0, nullptr, 0});
       e = &g_ksd.back();
     }
-    old = e->buf;
+    old = e->live;
     HX_CHECK(hipMalloc(&buf, bytes));
-    e->buf = buf;
-    e->bytes = bytes;
+    e->live = buf;
+    e->live_bytes = bytes;
   }
   if (old) {
-    HX_CHECK(hipStreamSynchronize(st));  // launches that still read the old buffer
+    HX_CHECK(hipStreamSynchronize(st));  // launches that still read the old buffer (never a captured one: see above)
     HX_CHECK(hipFree(old));
   }
   return buf;
 }
 void ksd_release_stream(int device, hipStream_t st) {
-  void *old = nullptr;
+  void *live = nullptr, *cap = nullptr;
   {
     std::lock_guard<std::mutex> lock(g_ksd_mutex);
     for (size_t i = 0; i < g_ksd.size(); ++i)
       if (g_ksd[i].device == device && g_ksd[i].stream == st) {
-        old = g_ksd[i].buf;
+        live = g_ksd[i].live;
+        cap = g_ksd[i].cap;
         g_ksd.erase(g_ksd.begin() + i);
         break;
       }
   }
-  if (old) HX_CHECK(hipFree(old));
+  if (live) HX_CHECK(hipFree(live));
+  if (cap) HX_CHECK(hipFree(cap));
 }
 
 // Byte planes + column sums of a keyswitch key, built ONCE per key and kept until the key's device memory is
@@ -723,7 +746,7 @@ static void ksm_release(const KsmEntry &e) {
   HX_CHECK(hipSetDevice(cur));
 }
 
-static bool stream_is_capturing(hipStream_t st) {
+bool stream_is_capturing(hipStream_t st) {
 #if defined(TFHE_HIPEMU)
   (void)st;
   return false;

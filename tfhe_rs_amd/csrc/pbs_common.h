@@ -31,6 +31,9 @@ struct PbsArgs {
   // N >= 8192 only: (k+1) N torus words per sample — the accumulator of those rings does not fit in LDS next
   // to the transform buffer and lives in device memory (L2-resident between the iterations of a workgroup)
   uint64_t *acc_scratch = nullptr;
+  // exact engine, split-key form: set to 1 by a lane whose f64 product was not within 1/4 of an integer (the round-off
+  // check of an FFT-based exact multiplication); read back by hip_programmable_bootstrap_ntt64_split_roundoff_status
+  uint32_t *roundoff_flag = nullptr;
   // multi-bit throughput kernel only: 8 progress counters (one per XCD, 128 bytes apart), zeroed by the launch —
   // the workgroups of an XCD stay within a few groups of each other so that a group's key is fetched from HBM
   // once per XCD instead of once per workgroup

@@ -118,13 +118,14 @@
 // 0 -> 45.1 / 30.2 ms, 1 -> 43.8 / 30.4, 2 -> 43.8 / 30.6: the two-level kernel takes 1 (and spills nothing).
 #define WAVE_MB_BASES -1
 #endif
+#ifndef WAVE_MB_W16_SCALAR
+// multi-bit: the 16th roots of unity that complete the monomial factors (wave-uniform index) come through the scalar
+// data cache (1) instead of as broadcast reads of the LDS table (0): 2 (2^g - 1) reads per point fewer — at g = 4 as
+// many LDS instructions as the whole rest of a group
+#define WAVE_MB_W16_SCALAR 1
+#endif
 #ifndef WAVE_SPLIT_LWES
 #define WAVE_SPLIT_LWES 4   // exact engine, split-key form: LWEs per workgroup (the accumulators of a CU's LWEs live in L2)
-#endif
-#ifndef WAVE_SPLIT_REGACC
-// exact engine, split-key form: 1 = two LWEs per workgroup (one wave per SIMD, up to 512 registers per lane) and the
-// accumulator stays in registers: no accumulator traffic to device memory at all
-#define WAVE_SPLIT_REGACC 0
 #endif
 #ifndef WAVE_SPLIT_NT
 #define WAVE_SPLIT_NT 0     // 1: accumulator loads / stores nontemporal
@@ -137,21 +138,10 @@
 // 118 16-byte LDS reads of an iteration) are literals of the instruction stream (scalar moves) instead of broadcast
 // reads of the LDS table; the inverse butterflies whose twiddle is 1 or -i lose their two products (same roundings:
 // fma(x, 1, y) = x + y).  The values are checked against the host tables when the tables are built (tables.hip).
-#define WAVE_UNIFORM_LITERALS 0
+#define WAVE_UNIFORM_LITERALS 1
 #endif
-#ifndef WAVE_TW_PREFETCH
-// classic one-level loop: 1 = lane-dependent twiddles, untwist factors and the rotation's staged words are requested
-// ahead of their use (wave_forward / wave_inverse_accumulate PFT, make_digits), 0 = just in time
-#define WAVE_TW_PREFETCH 0
-#endif
-#ifndef WAVE_ROT_PREFETCH
-#define WAVE_ROT_PREFETCH 0  // classic one-level loop: coefficient pairs of the rotation requested ahead (0, 4, 8 or 16)
-#endif
-#ifndef WAVE_MAC_OWN_REGS
-// 1 (classic one-level loop): the multiply-accumulate takes the wave's own row of the digit transform from its
-// registers (in place) and only the partner's row from LDS: 16 fewer 16-byte LDS reads per iteration, two copies of
-// the product loop selected by a scalar branch on the wave's polynomial
-#define WAVE_MAC_OWN_REGS 0
+#ifndef WAVE_RESIDENT
+#define WAVE_RESIDENT 2  // classic one-level loop: twiddles kept in registers across the iterations (ResidentTwiddles: 0..2)
 #endif
 
 namespace tfhe_hip {
@@ -307,78 +297,68 @@ HX_DEV void swap_regs_lane54(cplx (&d)[16]) {
     }
 }
 
+// Twiddles kept in registers for the whole launch by the classic one-level loop (template parameter RES of the
+// transforms), read from the LDS table once in front of the CMUX loop: level 1 = the eight of pass F2 (they depend on
+// lane >> 4 only), level 2 = also pass I2's two.  Every LDS read that leaves the loop is worth about 0.1 % of the launch
+// (one box, batch 4096: table reads 33.8 ms, literals for the wave-uniform ones 32.9, level 1 32.7, level 2 32.5; a
+// third level — the first two twiddles of passes F3 and I3 — spills and runs at 33.3).
+struct ResidentTwiddles {
+  cplx e4[4], e5[4];  // F2
+  cplx w16, e32;      // I2
+};
+template <int LEVEL>
+HX_DEV void load_resident_twiddles(ResidentTwiddles &t, const cplx *T, int lane) {
+  const int g4 = lane >> 4, l15 = lane & 15;
+  if constexpr (LEVEL >= 1) {
+    HX_UNROLL
+    for (int j = 0; j < 4; ++j) {
+      t.e4[j] = T[T_F2 + g4 * 4 + j];
+      t.e5[j] = T[T_F2 + 16 + g4 * 4 + j];
+    }
+  }
+  if constexpr (LEVEL >= 2) {
+    t.w16 = T[T_W16 + (l15 & 7)];
+    if (l15 & 8) t.w16 = times_mi(t.w16);
+    t.e32 = T[T_E32 + l15];
+  }
+}
+
 // ---- forward transform of 16 points per lane: mapping M1 in, mapping M3 out (and stored in my buffer)
 //   F1 stages 0..3 (position bits 9..6, registers) -> permlane swaps -> F2 stages 4,5 (bits 5,4, registers)
 //   -> LDS transposition MX -> M3 -> F3 stages 6..9 (bits 3..0, registers)
-//
-// PFT: the lane-dependent twiddles are requested a pass ahead of their use (the F2 ones in front of pass F1, the F3
-// ones in front of the last F2 stage) instead of just in time behind the scheduling fence of their stage: every
-// just-in-time read is an LDS round trip the wave sits out, and with two waves per SIMD a wait that coincides with the
-// other wave's costs issue slots.  Same values, same operations.  Costs up to 64 registers for a pass: the caller
-// chooses (the classic one-level loop has them).
-template <bool PFT = false>
-HX_DEV void wave_forward(cplx (&d)[16], WaveCtx c) {
+template <int RES = 0>
+HX_DEV void wave_forward(cplx (&d)[16], WaveCtx c, const ResidentTwiddles *res = nullptr) {
   HX_OPAQUE(c.lane);
   const int lane = c.lane, g4 = c.lane >> 4;
   const cplx *T = c.T;
-  cplx e4[4], e5[4];
-  if constexpr (PFT) {
-    HX_UNROLL
-    for (int j = 0; j < 4; ++j) {
-      e4[j] = T[T_F2 + g4 * 4 + j];
-      e5[j] = T[T_F2 + 16 + g4 * 4 + j];
-    }
-    HX_SCHED_FENCE();
-  }
-  {
+  {  // pass F1: the same twiddles in every lane of every launch
 #if WAVE_UNIFORM_LITERALS
-    auto lit = [](int x) { return cplx{LIT_F1[x][0], LIT_F1[x][1]}; };
-    const cplx w0 = lit(0);
-    stage<3>(d, [&](int) { return w0; });
-    const cplx e1 = lit(1);
-    stage<2>(d, [&](int r) { return (r >> 3) ? times_i(e1) : e1; });
-    HX_SCHED_FENCE();
-    const cplx e2[2] = {lit(2), lit(3)};
-    stage<1>(d, [&](int r) { return ((r >> 2) & 1) ? times_i(e2[r >> 3]) : e2[r >> 3]; });
-    HX_SCHED_FENCE();
-    const cplx e3[4] = {lit(4), lit(5), lit(6), lit(7)};
-    stage<0>(d, [&](int r) { return ((r >> 1) & 1) ? times_i(e3[r >> 2]) : e3[r >> 2]; });
+    auto tw = [](int x) { return cplx{LIT_F1[x][0], LIT_F1[x][1]}; };
 #else
-    const cplx w0 = T[T_F1 + 0];
+    auto tw = [&](int x) { return T[T_F1 + x]; };
+#endif
+    const cplx w0 = tw(0);
     stage<3>(d, [&](int) { return w0; });
-    const cplx e1 = T[T_F1 + 1];
+    const cplx e1 = tw(1);
     stage<2>(d, [&](int r) { return (r >> 3) ? times_i(e1) : e1; });
     HX_SCHED_FENCE();
-    const cplx e2[2] = {T[T_F1 + 2], T[T_F1 + 3]};
+    const cplx e2[2] = {tw(2), tw(3)};
     stage<1>(d, [&](int r) { return ((r >> 2) & 1) ? times_i(e2[r >> 3]) : e2[r >> 3]; });
     HX_SCHED_FENCE();
-    const cplx e3[4] = {T[T_F1 + 4], T[T_F1 + 5], T[T_F1 + 6], T[T_F1 + 7]};
+    const cplx e3[4] = {tw(4), tw(5), tw(6), tw(7)};
     stage<0>(d, [&](int r) { return ((r >> 1) & 1) ? times_i(e3[r >> 2]) : e3[r >> 2]; });
-#endif
   }
   HX_SCHED_FENCE();
   swap_regs_lane54(d);
   HX_SCHED_FENCE();
-  cplx w6, e7, e8[2], e9[4];
   {  // stage 4: group (pos >> 6) = (lane>>4)*4 + (r&3); stage 5: group (pos >> 5) = that*2 + (r>>3)
-    if constexpr (!PFT) {
-      HX_UNROLL
-      for (int j = 0; j < 4; ++j) e4[j] = T[T_F2 + g4 * 4 + j];
-    }
+    cplx e4[4], e5[4];
+    HX_UNROLL
+    for (int j = 0; j < 4; ++j) e4[j] = RES >= 1 ? res->e4[j] : T[T_F2 + g4 * 4 + j];
     stage<3>(d, [&](int r) { return e4[r & 3]; });
     HX_SCHED_FENCE();
-    if constexpr (PFT) {  // pass F3's twiddles, a stage and a transposition ahead
-      w6 = T[T_F6 + lane];
-      e7 = T[T_F2 + 64 + lane];
-      e8[0] = T[T_F3 + lane];
-      e8[1] = T[T_F3 + 64 + lane];
-      HX_UNROLL
-      for (int j = 0; j < 4; ++j) e9[j] = T[T_F3 + 128 + 64 * j + lane];
-      HX_SCHED_FENCE();
-    } else {
-      HX_UNROLL
-      for (int j = 0; j < 4; ++j) e5[j] = T[T_F2 + 16 + g4 * 4 + j];
-    }
+    HX_UNROLL
+    for (int j = 0; j < 4; ++j) e5[j] = RES >= 1 ? res->e5[j] : T[T_F2 + 16 + g4 * 4 + j];
     cplx *px = c.buf + base_mx(c);  // transposition MX -> M3, store side
     stage_store<2>(d, [&](int r) { return (r >> 3) ? times_i(e5[r & 3]) : e5[r & 3]; },
                    [&](int r) { px[mx_off(r)] = d[r]; });
@@ -386,24 +366,19 @@ HX_DEV void wave_forward(cplx (&d)[16], WaveCtx c) {
   HX_WAVE_SYNC();
   HX_PRIO_OPT(WAVE_PRIO_F3);
   {  // stages 6..9 over position bits 3..0 (= r bits 3..0), group index = lane . (r bits)
-    if constexpr (!PFT) w6 = T[T_F6 + lane];
+    const cplx w6 = T[T_F6 + lane];
     cplx *p3 = c.buf + base_m3(c);  // transposition MX -> M3, load side
     load_pairs<3>([&](int r) { d[r] = p3[r]; });
     HX_WAVE_SYNC();
     stage<3>(d, [&](int) { return w6; });
-    if constexpr (!PFT) e7 = T[T_F2 + 64 + lane];
+    const cplx e7 = T[T_F2 + 64 + lane];
     stage<2>(d, [&](int r) { return (r >> 3) ? times_i(e7) : e7; });
     HX_SCHED_FENCE();
-    if constexpr (!PFT) {
-      e8[0] = T[T_F3 + lane];
-      e8[1] = T[T_F3 + 64 + lane];
-    }
+    const cplx e8[2] = {T[T_F3 + lane], T[T_F3 + 64 + lane]};
     stage<1>(d, [&](int r) { return ((r >> 2) & 1) ? times_i(e8[r >> 3]) : e8[r >> 3]; });
     HX_SCHED_FENCE();
-    if constexpr (!PFT) {
-      HX_UNROLL
-      for (int j = 0; j < 4; ++j) e9[j] = T[T_F3 + 128 + 64 * j + lane];
-    }
+    const cplx e9[4] = {T[T_F3 + 128 + lane], T[T_F3 + 192 + lane], T[T_F3 + 256 + lane],
+                        T[T_F3 + 320 + lane]};
     stage_store<0>(d, [&](int r) { return ((r >> 1) & 1) ? times_i(e9[r >> 2]) : e9[r >> 2]; },
                    [&](int r) { p3[r] = d[r]; });
   }
@@ -462,10 +437,9 @@ HX_DEV void inverse_stage_half4(cplx (&o)[16], int r0, const cplx *T) {
 // RAW (exact engine, split-key form): no torus conversion — o[r] becomes (t_re, t_im), the untwisted real values of
 // coefficients r*64 + lane and 1024 + r*64 + lane; nothing is staged, the accumulator registers are not touched.
 // PASS1_DONE: 0 nothing done, 1 stages half = 1, 2 done by the caller
-// PFT: as in wave_forward — pass I3's twiddles are requested in front of the transposition reads of pass I2, the
-// untwist factors of coefficients r < 8 in front of pass I3 and those of r >= 8 in front of the conversion.
-template <int PASS1_DONE, bool OVERWRITE = false, bool NEG = false, bool RAW = false, bool PFT = false>
-HX_DEV void wave_inverse_accumulate(cplx (&o)[16], uint64_t (&acc_re)[16], uint64_t (&acc_im)[16], WaveCtx c) {
+template <int PASS1_DONE, bool OVERWRITE = false, bool NEG = false, bool RAW = false, int RES = 0>
+HX_DEV void wave_inverse_accumulate(cplx (&o)[16], uint64_t (&acc_re)[16], uint64_t (&acc_im)[16], WaveCtx c,
+                                    const ResidentTwiddles *res = nullptr) {
   uint64_t *stg = (uint64_t *)c.buf;
   HX_OPAQUE(c.lane);
   const cplx *T = c.T;
@@ -498,35 +472,25 @@ HX_DEV void wave_inverse_accumulate(cplx (&o)[16], uint64_t (&acc_re)[16], uint6
 #endif
   }
   HX_WAVE_SYNC();
-  int lane = c.lane;
-  HX_OPAQUE(lane);
-  cplx w7, e8, e9[2], e10[4];
-  auto load_i3_a = [&]() {
-    w7 = T[T_W7 + (lane & 31)];
-    e8 = T[T_E8 + lane];
-  };
-  auto load_i3_b = [&]() {
-    e9[0] = T[T_INV + lane * 2];
-    e9[1] = T[T_INV + (64 + lane) * 2];
-  };
-  auto load_i3_c = [&]() {
-    HX_UNROLL
-    for (int j = 0; j < 4; ++j) e10[j] = T[T_INV + 64 * j + lane];
-  };
   // pass I2: stages half = 16, 32 over position bits 4, 5 (= r bits 2, 3 in mapping MX); j = (r bit 2).(lane & 15)
   {
-    const int l15 = lane & 15;
-    cplx w16 = T[T_W16 + (l15 & 7)];
-    const cplx e32 = T[T_E32 + l15];
-    if constexpr (PFT) {
-      load_i3_a();
-      load_i3_b();
-      load_i3_c();
+    int ln = c.lane;
+    HX_OPAQUE(ln);
+    const int l15 = ln & 15;
+    cplx w16, e32;
+    if constexpr (RES >= 2) {
+      w16 = res->w16;
+      e32 = res->e32;
+    } else {
+      w16 = T[T_W16 + (l15 & 7)];
+      e32 = T[T_E32 + l15];
     }
     const cplx *px = c.buf + base_mx(c);  // transposition M3 -> MX, load side
     load_pairs<2>([&](int r) { o[r] = px[mx_off(r)]; });
     HX_WAVE_SYNC();
-    if (l15 & 8) w16 = times_mi(w16);
+    if constexpr (RES < 2) {
+      if (l15 & 8) w16 = times_mi(w16);
+    }
     stage<2>(o, [&](int) { return w16; });
     stage<3>(o, [&](int r) { return (r & 4) ? times_mi(e32) : e32; });
   }
@@ -534,39 +498,20 @@ HX_DEV void wave_inverse_accumulate(cplx (&o)[16], uint64_t (&acc_re)[16], uint6
   swap_regs_lane54(o);  // MX -> M1
   HX_SCHED_FENCE();
   HX_PRIO_OPT(WAVE_PRIO_I3);
-  // untwist factors: u[r*64 + lane] for r < 8, mirrored above (j = 512 is stored directly)
-  const cplx *Tu_lo = T + T_U + lane;         // u[r*64 + lane]           (r < 8)
-  const cplx *Tu_hi = T + T_U + 1024 - lane;  // u[1024 - (r*64 + lane)]  (r >= 8), mirrored
-  cplx ut[16];
-  auto load_u = [&](int r) {
-    if (r < 8) {
-      ut[r] = Tu_lo[r * 64];
-    } else {
-      const cplx e = Tu_hi[-r * 64];
-      ut[r] = (r == 8 && lane == 0) ? e : cplx{-e.im, -e.re};
-    }
-  };
-  if constexpr (PFT) {
-    HX_UNROLL
-    for (int r = 0; r < 8; ++r) load_u(r);
-    HX_SCHED_FENCE();
-  }
   // pass I3: stages half = 64..512 over position bits 6..9 (= r bits 0..3); j = (r bits).lane
   {
-    if constexpr (!PFT) load_i3_a();
+    int lane = c.lane;
+    HX_OPAQUE(lane);
+    cplx w7 = T[T_W7 + (lane & 31)];
     if (lane & 32) w7 = times_mi(w7);
     stage<0>(o, [&](int) { return w7; });
+    const cplx e8 = T[T_E8 + lane];
     stage<1>(o, [&](int r) { return (r & 1) ? times_mi(e8) : e8; });
     HX_SCHED_FENCE();
-    if constexpr (!PFT) load_i3_b();
+    const cplx e9[2] = {T[T_INV + lane * 2], T[T_INV + (64 + lane) * 2]};
     stage<2>(o, [&](int r) { return (r & 2) ? times_mi(e9[r & 1]) : e9[r & 1]; });
     HX_SCHED_FENCE();
-    if constexpr (!PFT) load_i3_c();
-    if constexpr (PFT) {  // the twiddles of the finished stages are dead: the second half of the untwist factors
-      HX_UNROLL
-      for (int r = 8; r < 16; ++r) load_u(r);
-      HX_SCHED_FENCE();
-    }
+    const cplx e10[4] = {T[T_INV + lane], T[T_INV + 64 + lane], T[T_INV + 128 + lane], T[T_INV + 192 + lane]};
     stage<3>(o, [&](int r) { return (r & 4) ? times_mi(e10[r & 3]) : e10[r & 3]; });
   }
   HX_SCHED_FENCE();
@@ -574,11 +519,18 @@ HX_DEV void wave_inverse_accumulate(cplx (&o)[16], uint64_t (&acc_re)[16], uint6
   // untwist, back to the torus, accumulate (fft/mod.rs:311-330)
   int lane_u = c.lane;
   HX_OPAQUE(lane_u);
+  const cplx *Tu_lo = T + T_U + lane_u;         // u[r*64 + lane]           (r < 8)
+  const cplx *Tu_hi = T + T_U + 1024 - lane_u;  // u[1024 - (r*64 + lane)]  (r >= 8), mirrored
   const TorusConsts kt = torus_consts();
   HX_UNROLL
   for (int r = 0; r < 16; ++r) {
-    if constexpr (!PFT) load_u(r);
-    const cplx u = ut[r];
+    cplx u;
+    if (r < 8) {
+      u = Tu_lo[r * 64];
+    } else {
+      const cplx e = Tu_hi[-r * 64];
+      u = (r == 8 && lane_u == 0) ? e : cplx{-e.im, -e.re};  // j = 512 is stored directly
+    }
     const double tr = NEG ? fma(o[r].im, u.im, -o[r].re * u.re) : fma(-o[r].im, u.im, o[r].re * u.re);
     const double ti = NEG ? fma(-o[r].im, u.re, -o[r].re * u.im) : fma(o[r].im, u.re, o[r].re * u.im);
     if constexpr (RAW) {
@@ -622,7 +574,7 @@ HX_DEV void wave_inverse_accumulate(cplx (&o)[16], uint64_t (&acc_re)[16], uint6
 // kc = sum_m c_m 2^(16 m), each limb polynomial is kept in the Fourier domain (integer inputs, no torus scaling),
 // and per CMUX the digit transform F is multiplied with every limb in turn: S_m = sum_rows d (*) c_m is an integer of
 // magnitude below (k+1) l N (B/2) 2^15 = 2^49 that the f64 transform reproduces to within about 2^-9 (RMS; the
-// distance from the nearest integer is checked on every coefficient and the launch TRAPS above 1/4 — the round-off
+// distance from the nearest integer is checked on every coefficient and the launch raises the scratch's round-off flag above 1/4 — the round-off
 // check of every FFT-based exact multiplication), so rint() of the inverse transform IS S_m, and
 //     R = sum_m S_m 2^(16 m)  mod P          (Horner, most significant limb first, 64-bit Goldilocks arithmetic)
 // is the reference's value, bit for bit.  Order of the blind rotation as in the NTT path: acc starts as the LUT,
@@ -631,7 +583,7 @@ HX_DEV void wave_inverse_accumulate(cplx (&o)[16], uint64_t (&acc_re)[16], uint6
 // Horner states (64), the digit transform (64: re-published to the pair's LDS buffer after every limb's inverse
 // transposition has used that buffer) and the product being transformed back (64).
 template <int LEVEL_CT, int BASE_LOG_CT, int GROUPING = 0, bool SHARE = false, int LIMBS = 0>
-__global__ void __launch_bounds__((LIMBS > 0 && WAVE_SPLIT_REGACC) ? 256 : TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables tb) {
+__global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables tb) {
   constexpr bool MULTIBIT = GROUPING > 0;
   static_assert(!SHARE || MULTIBIT, "SHARE is a mode of the multi-bit loop");
   static_assert(LIMBS == 0 || (!MULTIBIT && LEVEL_CT == 1 && BASE_LOG_CT != 0 && BASE_LOG_CT <= 23),
@@ -798,22 +750,6 @@ __global__ void __launch_bounds__((LIMBS > 0 && WAVE_SPLIT_REGACC) ? 256 : TPB) 
     HX_LAUNDER(vzero);  // the staged copy's base in a vector register: a scalar operand doubles the cost of the add
 #endif
     const char *staged = (const char *)buf64 + vzero;
-    // the staged words of the rotation, requested RPF coefficients pairs ahead of the arithmetic that uses them (0:
-    // just in time, every group of four then starts with an LDS round trip)
-    constexpr int RPF = (!MULTIBIT && LIMBS == 0 && LEVEL_CT == 1 && !EXACT) ? WAVE_ROT_PREFETCH : 0;
-    uint64_t sw0[16], sw1[16];
-    auto staged_request = [&](int r) {
-      int32_t ubr = ub;
-      if (RPF > 0) HX_LAUNDER(ubr);  // the offsets are recomputed where the words are used, not kept
-      const int32_t u0 = (int32_t)((uint32_t)ubr + r * 512u), u1 = (int32_t)((uint32_t)u0 + 8192u);
-      sw0[r] = *(const uint64_t *)(staged + (u0 & 0x3ff8));
-      sw1[r] = *(const uint64_t *)(staged + (u1 & 0x3ff8));
-    };
-    if constexpr (RPF > 0) {
-      HX_UNROLL
-      for (int r = 0; r < (RPF < 16 ? RPF : 16); ++r) staged_request(r);
-      HX_SCHED_FENCE();
-    }
     HX_UNROLL
     for (int r = 0; r < 16; ++r) {
       uint64_t x0, x1;
@@ -821,20 +757,13 @@ __global__ void __launch_bounds__((LIMBS > 0 && WAVE_SPLIT_REGACC) ? 256 : TPB) 
         x0 = acc_re[r];
         x1 = acc_im[r];
       } else {
-        if constexpr (RPF > 0) {
-          if ((r & 3) == 0 && r + RPF < 16) {
-            HX_UNROLL
-            for (int j = 0; j < 4; ++j) staged_request(r + RPF + j);
-          }
-        } else {
-          staged_request(r);
-        }
         const int32_t u0 = (int32_t)((uint32_t)ub + r * 512u), u1 = (int32_t)((uint32_t)u0 + 8192u);
         const uint32_t m0 = (uint32_t)(u0 >> 31), m1 = (uint32_t)(u1 >> 31);  // all-ones: sign +
         const uint64_t M0 = ((uint64_t)m0 << 32) | m0, M1 = ((uint64_t)m1 << 32) | m1;
-        const uint64_t s0 = sw0[r], s1 = sw1[r];
+        const uint64_t s0 = *(const uint64_t *)(staged + (u0 & 0x3ff8));
+        const uint64_t s1 = *(const uint64_t *)(staged + (u1 & 0x3ff8));
         uint64_t a0 = acc_re[r], a1 = acc_im[r];
-        if constexpr (LIMBS > 0 && !WAVE_SPLIT_REGACC) {  // the accumulator is not in registers here: my own coefficients from the staged copy
+        if constexpr (LIMBS > 0) {  // the accumulator is not in registers here: my own coefficients from the staged copy
           a0 = *(const uint64_t *)(staged + (lane + r * 64) * 8);
           a1 = *(const uint64_t *)(staged + (1024 + lane + r * 64) * 8);
         }
@@ -900,9 +829,7 @@ __global__ void __launch_bounds__((LIMBS > 0 && WAVE_SPLIT_REGACC) ? 256 : TPB) 
   // chunk c + 2 is requested into the registers chunk c has just released.  With FUSE_PASS1 the
   // first inverse pass (which only mixes the 4 points of one chunk) runs right behind each chunk.
   auto mac = [&](cplx (&dst)[16], cplx (&d)[16], cplx (&ka0)[4], cplx (&ka1)[4], cplx (&kb0)[4], cplx (&kb1)[4],
-                 const cplx *b0, const cplx *b1, uint32_t idx, uint32_t epoch, auto fuse_pass1, auto own_tag) {
-    // OWN: dst is d, my own row of the digit transform, updated in place; only the partner's row comes from LDS
-    constexpr bool OWN = decltype(own_tag)::value;
+                 const cplx *b0, const cplx *b1, uint32_t idx, uint32_t epoch, auto fuse_pass1) {
     WaveCtx ctx = ctx0;
     HX_OPAQUE(ctx.lane);
     const int lane = ctx.lane;
@@ -924,77 +851,49 @@ __global__ void __launch_bounds__((LIMBS > 0 && WAVE_SPLIT_REGACC) ? 256 : TPB) 
     // the LDS reads run WAVE_MAC_PREFETCH points ahead of the products that consume them (issued just in
     // time, each pair exposed a full LDS latency to this wave)
     constexpr int PF = WAVE_MAC_PREFETCH;
-    // SEL 2: both rows from LDS; SEL 0 / 1 (OWN): I hold polynomial 0 / 1 — my row is dst itself, in place, and only
-    // the partner's row is read (two copies of the loop, one scalar branch around them)
-    auto products = [&](auto sel_tag) {
-      constexpr int SEL = decltype(sel_tag)::value;
-      const cplx *rowo = obuf + base_m3(ctx);
-      cplx xn0[PF > 0 ? PF : 1], xn1[PF > 0 ? PF : 1];
+    cplx xn0[PF > 0 ? PF : 1], xn1[PF > 0 ? PF : 1];
+    HX_UNROLL
+    for (int q = 0; q < PF; ++q) {
+      xn0[q] = row0[q];
+      xn1[q] = row1[q];
+    }
+    HX_UNROLL
+    for (int ch = 0; ch < 4; ++ch) {
+      cplx(&k0)[4] = (ch & 1) ? kb0 : ka0;
+      cplx(&k1)[4] = (ch & 1) ? kb1 : ka1;
       HX_UNROLL
-      for (int q = 0; q < PF; ++q) {
-        if constexpr (SEL == 2) {
-          xn0[q] = row0[q];
-          xn1[q] = row1[q];
+      for (int j = 0; j < 4; ++j) {
+        const int r = ch * 4 + j;
+        cplx x0, x1;
+        if constexpr (PF > 0) {
+          x0 = xn0[r % PF];
+          x1 = xn1[r % PF];
+          if (r + PF < 16) {
+            xn0[r % PF] = row0[r + PF];
+            xn1[r % PF] = row1[r + PF];
+          }
         } else {
-          xn0[q] = rowo[q];
+          x0 = row0[r];
+          x1 = row1[r];
         }
+        const cplx t = (idx == 0) ? cmul_first(x0, k0[j]) : cmul_add(x0, k0[j], dst[r]);
+        dst[r] = cmul_add(x1, k1[j], t);
+        // pin the product here: otherwise the FMAs are sunk below the flag wait that follows and
+        // the key loads stay live across it
+        HX_OPAQUE(dst[r].re);
+        HX_OPAQUE(dst[r].im);
       }
-      HX_UNROLL
-      for (int ch = 0; ch < 4; ++ch) {
-        cplx(&k0)[4] = (ch & 1) ? kb0 : ka0;
-        cplx(&k1)[4] = (ch & 1) ? kb1 : ka1;
+      HX_SCHED_FENCE();
+      if (ch < 2) key_request(k0, k1, b0, b1, ch + 2);
+      if constexpr (decltype(fuse_pass1)::value) {
+        inverse_pass1_group(dst, ch);
         HX_UNROLL
         for (int j = 0; j < 4; ++j) {
-          const int r = ch * 4 + j;
-          cplx x0, x1;
-          if constexpr (SEL == 2) {
-            if constexpr (PF > 0) {
-              x0 = xn0[r % PF];
-              x1 = xn1[r % PF];
-              if (r + PF < 16) {
-                xn0[r % PF] = row0[r + PF];
-                xn1[r % PF] = row1[r + PF];
-              }
-            } else {
-              x0 = row0[r];
-              x1 = row1[r];
-            }
-          } else {
-            cplx xo;
-            if constexpr (PF > 0) {
-              xo = xn0[r % PF];
-              if (r + PF < 16) xn0[r % PF] = rowo[r + PF];
-            } else {
-              xo = rowo[r];
-            }
-            x0 = SEL == 0 ? dst[r] : xo;
-            x1 = SEL == 0 ? xo : dst[r];
-          }
-          const cplx t = (idx == 0) ? cmul_first(x0, k0[j]) : cmul_add(x0, k0[j], dst[r]);
-          dst[r] = cmul_add(x1, k1[j], t);
-          // pin the product here: otherwise the FMAs are sunk below the flag wait that follows and
-          // the key loads stay live across it
-          HX_OPAQUE(dst[r].re);
-          HX_OPAQUE(dst[r].im);
+          HX_OPAQUE(dst[ch * 4 + j].re);
+          HX_OPAQUE(dst[ch * 4 + j].im);
         }
-        HX_SCHED_FENCE();
-        if (ch < 2) key_request(k0, k1, b0, b1, ch + 2);
-        if constexpr (decltype(fuse_pass1)::value) {
-          inverse_pass1_group(dst, ch);
-          HX_UNROLL
-          for (int j = 0; j < 4; ++j) {
-            HX_OPAQUE(dst[ch * 4 + j].re);
-            HX_OPAQUE(dst[ch * 4 + j].im);
-          }
-        }
-        HX_SCHED_FENCE();
       }
-    };
-    if constexpr (OWN) {
-      if (w == 0) products(std::integral_constant<int, 0>{});
-      else products(std::integral_constant<int, 1>{});
-    } else {
-      products(std::integral_constant<int, 2>{});
+      HX_SCHED_FENCE();
     }
     HX_WAVE_SYNC();
     if (lane == 0) flag_set(r_done_me, epoch);
@@ -1070,6 +969,14 @@ __global__ void __launch_bounds__((LIMBS > 0 && WAVE_SPLIT_REGACC) ? 256 : TPB) 
     auto mac_leave = [&](uint32_t m) {  // after the quad_sync that ends it
       if (two_quads && (wave & 3) == 0 && lane == 0) flag_set(flags + 8, 2u * m + (uint32_t)(pair >> 1) + 1u);
     };
+    // e^{2 pi i t / 16} = mono[t N / 8], t wave-uniform
+    auto w16_root = [&](uint32_t t) {
+#if WAVE_MB_W16_SCALAR
+      return load_uniform_cplx(tb.mono, (uint32_t)(N / 8) * t);
+#else
+      return T[T_W16X + t];
+#endif
+    };
     const uint32_t ggsw_bytes = (uint32_t)(ggsw_c * sizeof(cplx));
     auto ldc = [](HxBuffer b, uint32_t voff, uint32_t soff) {
       const hx_f64x2 v = hx_buffer_load_f64x2(b, voff, soff);
@@ -1096,7 +1003,8 @@ __global__ void __launch_bounds__((LIMBS > 0 && WAVE_SPLIT_REGACC) ? 256 : TPB) 
       // the multiply-accumulate that uses them, not per group: held across the digit and forward-transform phases
       // they cost 4 (2^g - 1) registers per LWE (56 at g = 3 in SHARE mode) exactly where the transform needs the
       // file, and the two-level g = 3 kernel spilled 55 registers (5.4 GB of scratch writes per launch).  The
-      // 64 KB table is L1/L2 resident; the requests are issued ahead of the level's first key requests.
+      // lane-order table (tables.h mono_lane, 4 MB per device) is L2 resident; the requests are issued ahead of the
+      // level's first key requests.
       auto bases = [&](const uint32_t (&dg)[per], cplx (&bs)[per]) {
         HX_UNROLL
         for (uint32_t sidx = 1; sidx < per; ++sidx)
@@ -1231,8 +1139,8 @@ __global__ void __launch_bounds__((LIMBS > 0 && WAVE_SPLIT_REGACC) ? 256 : TPB) 
               } else {
                 constexpr uint32_t br4[8] = {0, 8, 4, 12, 2, 10, 6, 14};  // bitrev4(8 h + j) = bitrev4(j) + h
                 const uint32_t br = br4[j] + (uint32_t)quad_lwe;
-                const cplx mfa = cmul_first(base[si], T[T_W16X + ((br * deg[si]) & 15u)]);
-                const cplx mfb = cmul_first(base_b[si], T[T_W16X + ((br * deg_b[si]) & 15u)]);
+                const cplx mfa = cmul_first(base[si], w16_root((br * deg[si]) & 15u));
+                const cplx mfb = cmul_first(base_b[si], w16_root((br * deg_b[si]) & 15u));
                 ka0 = cmul_add(x0[set], mfa, ka0);
                 ka1 = cmul_add(x1[set], mfa, ka1);
                 kb0 = cmul_add(x0[set], mfb, kb0);
@@ -1317,7 +1225,7 @@ __global__ void __launch_bounds__((LIMBS > 0 && WAVE_SPLIT_REGACC) ? 256 : TPB) 
                 HX_UNROLL
                 for (int j = 0; j < PTS; ++j) {
                   constexpr uint32_t br4[16] = {0, 8, 4, 12, 2, 10, 6, 14, 1, 9, 5, 13, 3, 11, 7, 15};
-                  const cplx wr = T[T_W16X + ((br4[ch * PTS + j] * deg[sidx]) & 15u)];
+                  const cplx wr = w16_root((br4[ch * PTS + j] * deg[sidx]) & 15u);
                   const cplx mf = cmul_first(base[sidx], wr);
                   kb0[j] = cmul_add(x0[set][j], mf, kb0[j]);
                   kb1[j] = cmul_add(x1[set][j], mf, kb1[j]);
@@ -1388,9 +1296,10 @@ __global__ void __launch_bounds__((LIMBS > 0 && WAVE_SPLIT_REGACC) ? 256 : TPB) 
   } else if constexpr (LIMBS > 0) {
     struct alignas(16) U64x2 { uint64_t x, y; };
     U64x2 *gacc = (U64x2 *)(a.acc_scratch + ((size_t)sample * 2 + (size_t)w) * N) + lane;  // slot r*64 + lane: coefficients c, 1024 + c
+#if WAVE_SPLIT_NT && !defined(TFHE_HIPEMU)
     typedef uint64_t v2u64 __attribute__((ext_vector_type(2)));
+#endif
     auto acc_load = [&]() {
-      if (WAVE_SPLIT_REGACC) return;
       HX_UNROLL
       for (int r = 0; r < 16; ++r) {
 #if WAVE_SPLIT_NT && !defined(TFHE_HIPEMU)
@@ -1405,7 +1314,6 @@ __global__ void __launch_bounds__((LIMBS > 0 && WAVE_SPLIT_REGACC) ? 256 : TPB) 
       }
     };
     auto acc_store = [&]() {
-      if (WAVE_SPLIT_REGACC) return;
       HX_UNROLL
       for (int r = 0; r < 16; ++r) {
 #if WAVE_SPLIT_NT && !defined(TFHE_HIPEMU)
@@ -1455,7 +1363,7 @@ __global__ void __launch_bounds__((LIMBS > 0 && WAVE_SPLIT_REGACC) ? 256 : TPB) 
         key_rows(i, limb, b0, b1);
         HX_PRIO(WAVE_PRIO_C);
         mac(o, o, ka0, ka1, kb0, kb1, b0, b1, 0, (it - 1) * (uint32_t)LIMBS + limb + 1,
-            std::integral_constant<bool, WAVE_FUSE_PASS1 != 0>{}, std::false_type{});
+            std::integral_constant<bool, WAVE_FUSE_PASS1 != 0>{});
         if constexpr (LAST) acc_load();
         HX_PRIO(WAVE_PRIO_D);
         wave_inverse_accumulate<(WAVE_FUSE_PASS1 != 0) ? 1 : 0, false, false, true>(o, acc_re, acc_im, ctx);
@@ -1485,10 +1393,22 @@ __global__ void __launch_bounds__((LIMBS > 0 && WAVE_SPLIT_REGACC) ? 256 : TPB) 
       acc_store();
       stage_acc();  // for the next CMUX's rotation (my buffer is free: the last inverse transposition is over)
     }
-    if (worst > 0.25) __builtin_trap();  // an f64 product was not within 1/4 of an integer: never with these bounds
+    // an f64 product was not within 1/4 of an integer: reported through the scratch's flag (no trap: a trap kills the
+    // whole HIP context of the process).  The bound is statistical, not a proof — worst-case magnitudes of 2^49 leave
+    // about 4 bits of f64 headroom, the typical product is 2^12 smaller; an error beyond 1/2 would alias to a small
+    // distance and pass, so the check guards against drift, not against arbitrary corruption.
+    if (worst > 0.25 && a.roundoff_flag != nullptr) {
+#if defined(TFHE_HIPEMU)
+      *a.roundoff_flag = 1u;
+#else
+      __hip_atomic_store(a.roundoff_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+    }
     acc_load();
   } else {
     stage_acc();
+    ResidentTwiddles res_tw;
+    if constexpr (LEVEL_CT == 1) load_resident_twiddles<WAVE_RESIDENT>(res_tw, T, lane);
     uint32_t it = 0;  // executed iterations (flag epoch)
     uint64_t mask_next = lwe[0];
     for (uint32_t i = 0; i < a.n; ++i) {
@@ -1509,13 +1429,12 @@ __global__ void __launch_bounds__((LIMBS > 0 && WAVE_SPLIT_REGACC) ? 256 : TPB) 
         HX_PRIO(WAVE_PRIO_A);
         make_digits(d, a_hat, 0);
         HX_PRIO(WAVE_PRIO_B);
-        wave_forward<WAVE_TW_PREFETCH != 0>(d, ctx);
+        wave_forward<WAVE_RESIDENT>(d, ctx, &res_tw);
         HX_PRIO(WAVE_PRIO_C);
         // in place: d becomes the Fourier-domain output of polynomial w, first inverse pass applied
-        mac(d, d, ka0, ka1, kb0, kb1, b0, b1, 0, it, std::integral_constant<bool, WAVE_FUSE_PASS1 != 0>{},
-            std::integral_constant<bool, WAVE_MAC_OWN_REGS != 0>{});
+        mac(d, d, ka0, ka1, kb0, kb1, b0, b1, 0, it, std::integral_constant<bool, WAVE_FUSE_PASS1 != 0>{});
         HX_PRIO(WAVE_PRIO_D);
-        wave_inverse_accumulate<(WAVE_FUSE_PASS1 != 0) ? 1 : 0, false, NEGACC, false, WAVE_TW_PREFETCH != 0>(d, acc_re, acc_im, ctx);
+        wave_inverse_accumulate<(WAVE_FUSE_PASS1 != 0) ? 1 : 0, false, NEGACC, false, WAVE_RESIDENT>(d, acc_re, acc_im, ctx, &res_tw);
       } else {
         cplx o[16];
         for (uint32_t idx = 0; idx < level; ++idx) {
@@ -1528,7 +1447,7 @@ __global__ void __launch_bounds__((LIMBS > 0 && WAVE_SPLIT_REGACC) ? 256 : TPB) 
           HX_PRIO(WAVE_PRIO_B);
           wave_forward(d, ctx);
           HX_PRIO(WAVE_PRIO_C);
-          mac(o, d, ka0, ka1, kb0, kb1, b0, b1, idx, (it - 1) * level + idx + 1, std::false_type{}, std::false_type{});
+          mac(o, d, ka0, ka1, kb0, kb1, b0, b1, idx, (it - 1) * level + idx + 1, std::false_type{});
         }
         HX_PRIO(WAVE_PRIO_D);
         wave_inverse_accumulate<0, false, NEGACC>(o, acc_re, acc_im, ctx);
@@ -1618,6 +1537,17 @@ __global__ void __launch_bounds__((LIMBS > 0 && WAVE_SPLIT_REGACC) ? 256 : TPB) 
 
 }  // namespace wavek
 
+// host side of WAVE_UNIFORM_LITERALS: the literals are the table entries they stand for (checked when the tables are
+// built, tables.hip)
+bool wave_literal_twiddles_match(const double *fwd, const double *inv) {
+  static const int fidx[8] = {1, 2, 4, 6, 8, 10, 12, 14};
+  for (int x = 0; x < 8; ++x)
+    if (fwd[2 * fidx[x]] != wavek::LIT_F1[x][0] || fwd[2 * fidx[x] + 1] != wavek::LIT_F1[x][1]) return false;
+  for (int j = 0; j < 4; ++j)
+    if (inv[2 * (512 + 64 * j)] != wavek::LIT_E64[j][0] || inv[2 * (512 + 64 * j) + 1] != wavek::LIT_E64[j][1]) return false;
+  return true;
+}
+
 // LWEs per workgroup (= per CU): as few as keeps every one of the 256 CUs busy — a lone wave pair runs an
 // iteration in 7.6 us, four pairs sharing a CU need 12.4 us each
 static unsigned lwes_per_block(uint32_t num_samples) {
@@ -1648,7 +1578,6 @@ static void launch_split_t(hipStream_t st, const PbsArgs &a, const FftTables &tb
   hx_set_dynamic_smem_once<pbs_fft_wave_kernel<1, B, 0, false, NTT_SPLIT_LIMBS>>(SMEM_BYTES);
   unsigned per_block = lwes_per_block(a.num_samples);
   if (per_block > WAVE_SPLIT_LWES) per_block = WAVE_SPLIT_LWES;
-  if (WAVE_SPLIT_REGACC && per_block > 2) per_block = 2;
   const unsigned blocks = (a.num_samples + per_block - 1) / per_block;
   HX_LAUNCH((pbs_fft_wave_kernel<1, B, 0, false, NTT_SPLIT_LIMBS>), dim3(blocks), dim3(128 * per_block), SMEM_BYTES, st, a,
             tb);

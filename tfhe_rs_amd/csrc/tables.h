@@ -11,7 +11,7 @@ namespace tfhe_hip {
 // each entry (re, im) as two doubles; index 0 of fwd/inv unused.
 //   mono[j]        = exp(i*pi*j/N), j < 2N (octant-symmetric): the transform of a monomial X^d at position p is
 //                    mono[((1+4*bitrev_{L-4}(p>>4))*d) mod 2N] * mono[(N/8)*((bitrev_4(p&15)*d) mod 16)]  (multi-bit PBS)
-//   mono_lane      (N = 2048 only, else null): the same base factors laid out for a wave — entry [d][h] =
+//   mono_lane      (N = 2048 and requested, else null): the same base factors laid out for a wave — entry [d][h] =
 //                    mono[((1 + 4 bitrev_6(h)) d) mod 2N], d < 2N, h < 64: the 64 lanes of a wave read ONE 1 KB run for a
 //                    degree d instead of 64 scattered 16-byte entries (4 MB; same values)
 struct FftTables {
@@ -40,7 +40,8 @@ struct NttTables {
 
 
 // Lazily built, cached per (device, N); `stream` orders the upload before first use.
-FftTables get_fft_tables(uint32_t gpu_index, hipStream_t stream, uint32_t N);
+// with_mono_lane: the caller runs multi-bit kernels (mono_lane is built on first such request, 4 MB at N = 2048)
+FftTables get_fft_tables(uint32_t gpu_index, hipStream_t stream, uint32_t N, bool with_mono_lane = false);
 NttTables get_ntt_tables(uint32_t gpu_index, hipStream_t stream, uint32_t N);
 RefTables get_ref_tables(uint32_t gpu_index, hipStream_t stream, uint32_t N);
 

@@ -234,7 +234,10 @@ RefTables get_ref_tables(uint32_t gpu_index, hipStream_t stream, uint32_t N) {
   return RefTables{it->second.twist, it->second.w, it->second.w_inv};
 }
 
-FftTables get_fft_tables(uint32_t gpu_index, hipStream_t stream, uint32_t N) {
+// pbs_fft_wave.hip: the twiddles that kernel carries as literals of its instruction stream
+bool wave_literal_twiddles_match(const double *fwd, const double *inv);
+
+FftTables get_fft_tables(uint32_t gpu_index, hipStream_t stream, uint32_t N, bool with_mono_lane) {
   std::lock_guard<std::mutex> lk(g_mu);
   auto key = std::make_pair(gpu_index, N);
   auto it = g_fft.find(key);
@@ -242,6 +245,9 @@ FftTables get_fft_tables(uint32_t gpu_index, hipStream_t stream, uint32_t N) {
     std::vector<double> fwd(N), inv(N), untw(N), mono(4 * (size_t)N);
     fill_fft_tables_host(N, fwd.data(), inv.data(), untw.data());
     fill_monomial_table_host(N, mono.data());
+    if (N == 2048)
+      HX_PANIC_IF_FALSE(wave_literal_twiddles_match(fwd.data(), inv.data()),
+                        "the literal twiddles of the N = 2048 throughput kernel differ from the host tables");
     FftEntry e;
     HX_CHECK(hipSetDevice((int)gpu_index));
     HX_CHECK(hipMalloc((void **)&e.fwd, sizeof(double) * N));
@@ -250,25 +256,30 @@ FftTables get_fft_tables(uint32_t gpu_index, hipStream_t stream, uint32_t N) {
     HX_CHECK(hipMalloc((void **)&e.mono, sizeof(double) * 4 * N));
     HX_CHECK(hipMemcpy(e.mono, mono.data(), sizeof(double) * 4 * N, hipMemcpyHostToDevice));
     e.mono_lane = nullptr;
-    if (N == 2048) {  // tables.h: the base factors of the multi-bit kernels in lane order
-      std::vector<double> ml((size_t)2 * N * 64 * 2);
-      for (uint32_t d = 0; d < 2 * N; ++d)
-        for (uint32_t h = 0; h < 64; ++h) {
-          uint32_t br = 0;
-          for (int b = 0; b < 6; ++b) br |= ((h >> b) & 1u) << (5 - b);
-          const uint32_t j = ((1u + 4u * br) * d) & (2u * N - 1u);
-          ml[((size_t)d * 64 + h) * 2] = mono[2 * (size_t)j];
-          ml[((size_t)d * 64 + h) * 2 + 1] = mono[2 * (size_t)j + 1];
-        }
-      HX_CHECK(hipMalloc((void **)&e.mono_lane, sizeof(double) * ml.size()));
-      HX_CHECK(hipMemcpy(e.mono_lane, ml.data(), sizeof(double) * ml.size(), hipMemcpyHostToDevice));
-    }
     // synchronous copies from pageable host memory: complete before we return
     HX_CHECK(hipMemcpy(e.fwd, fwd.data(), sizeof(double) * N, hipMemcpyHostToDevice));
     HX_CHECK(hipMemcpy(e.inv, inv.data(), sizeof(double) * N, hipMemcpyHostToDevice));
     HX_CHECK(hipMemcpy(e.untw, untw.data(), sizeof(double) * N, hipMemcpyHostToDevice));
     (void)stream;
     it = g_fft.emplace(key, e).first;
+  }
+  if (with_mono_lane && N == 2048 && it->second.mono_lane == nullptr) {
+    // tables.h: the base factors of the multi-bit kernels in lane order (4 MB): built for the first multi-bit scratch
+    // of the device, not for callers of the classic PBS
+    std::vector<double> mono(4 * (size_t)N);
+    fill_monomial_table_host(N, mono.data());
+    std::vector<double> ml((size_t)2 * N * 64 * 2);
+    for (uint32_t d = 0; d < 2 * N; ++d)
+      for (uint32_t h = 0; h < 64; ++h) {
+        uint32_t br = 0;
+        for (int b = 0; b < 6; ++b) br |= ((h >> b) & 1u) << (5 - b);
+        const uint32_t j = ((1u + 4u * br) * d) & (2u * N - 1u);
+        ml[((size_t)d * 64 + h) * 2] = mono[2 * (size_t)j];
+        ml[((size_t)d * 64 + h) * 2 + 1] = mono[2 * (size_t)j + 1];
+      }
+    HX_CHECK(hipSetDevice((int)gpu_index));
+    HX_CHECK(hipMalloc((void **)&it->second.mono_lane, sizeof(double) * ml.size()));
+    HX_CHECK(hipMemcpy(it->second.mono_lane, ml.data(), sizeof(double) * ml.size(), hipMemcpyHostToDevice));
   }
   return FftTables{it->second.fwd, it->second.inv, it->second.untw, it->second.mono, it->second.mono_lane};
 }

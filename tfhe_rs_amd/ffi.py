@@ -103,6 +103,7 @@ SIGNATURES = {
     "hip_convert_lwe_programmable_bootstrap_key_ntt64_split_async": (None, [_v, _u32, _v, _v, _u32, _u32, _u32, _u32]),
     "hip_programmable_bootstrap_ntt64_split_async":
         (None, [_v, _u32, _v, _v, _v, _v, _v, _v, _v, _v, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _u32]),
+    "hip_programmable_bootstrap_ntt64_split_roundoff_status": (_u32, [_v, _u32, _v]),
     "hip_convert_lwe_programmable_bootstrap_key_exact64_async": (None, [_v, _u32, _v, _v, _u32, _u32, _u32, _u32]),
     "hip_convert_lwe_programmable_bootstrap_key_ref64_async": (None, [_v, _u32, _v, _v, _u32, _u32, _u32, _u32]),
     "hip_programmable_bootstrap_ref64_async":

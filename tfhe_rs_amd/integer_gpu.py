@@ -136,12 +136,16 @@ class CudaServerKey:
         _lib().cleanup_cuda_propagate_single_carry_64_inplace(s, C.byref(mem))
         return cout if want_carry_out else None
 
-    def add_assign(self, lhs, rhs, streams, carry_in=None, want_carry_out=False):
-        """lhs += rhs (+ carry_in) on clean (carry-free) operands: block additions, then one carry propagation."""
+    def add_assign(self, lhs, rhs, streams, carry_in=None, want_carry_out=False, want_overflow=False):
+        """lhs += rhs (+ carry_in) on clean (carry-free) operands: block additions, then one carry propagation.
+        want_carry_out (OutputFlag::Carry): returns the carry leaving the last block; want_overflow
+        (OutputFlag::Overflow, signed integers): returns the signed-overflow flag of the addition instead
+        (integer/gpu/server_key/radix/add.rs signed_overflowing_add)."""
+        assert not (want_carry_out and want_overflow)
         s, keep = self._streams(streams)
         ksks, bsks = self._key_ptrs(streams)
         mem = C.c_void_p()
-        flag = OUTPUT_FLAG_CARRY if want_carry_out else OUTPUT_FLAG_NONE
+        flag = OUTPUT_FLAG_OVERFLOW if want_overflow else OUTPUT_FLAG_CARRY if want_carry_out else OUTPUT_FLAG_NONE
         cin, cout = self._carry_blocks(lhs, carry_in, streams), self._carry_blocks(lhs, None, streams)
         _lib().hip_integer_scratch_batch(lhs.num_integers)
         _lib().scratch_cuda_add_and_propagate_single_carry_64_inplace_async(
@@ -151,7 +155,7 @@ class CudaServerKey:
                                                                     C.byref(cout._ffi()), C.byref(cin._ffi()), mem,
                                                                     bsks, ksks, flag, 1 if carry_in is not None else 0)
         _lib().cleanup_cuda_add_and_propagate_single_carry_64_inplace(s, C.byref(mem))
-        return cout if want_carry_out else None
+        return cout if (want_carry_out or want_overflow) else None
 
     def mul_assign(self, lhs, rhs, streams, return_pbs_count=False):
         """lhs *= rhs (mod 2^bits) on clean operands: schoolbook block products, column sums, propagation."""
@@ -169,6 +173,34 @@ class CudaServerKey:
         return pbs if return_pbs_count else None
 
 
+    def mul_by_boolean_assign(self, ct, boolean, streams, boolean_is_left=False):
+        """ct <- boolean ? ct : 0, block by block (integer_mult with is_boolean_right; with boolean_is_left the
+        roles of the FFI operands are swapped: the boolean sits in the in/out operand, whose blocks receive the
+        result — cuda/src/integer/multiplication.cuh:508-520).  `boolean`: one block per integer, value 0 or 1."""
+        s, keep = self._streams(streams)
+        ksks, bsks = self._key_ptrs(streams)
+        mem = C.c_void_p()
+        assert boolean.total_blocks == ct.num_integers
+        _lib().hip_integer_scratch_batch(ct.num_integers)
+        _lib().scratch_cuda_integer_mult_inplace_64_async(
+            s, C.byref(mem), boolean_is_left, not boolean_is_left, self.message_modulus, self.carry_modulus,
+            self._bsk_params(), self._ksk_params(), ct.num_blocks, True, self._noise_reduction())
+        if boolean_is_left:
+            # in/out operand: full-width buffer whose first `num_integers` blocks hold the booleans
+            out = CudaUnsignedRadixCiphertext.zeros_like(ct, streams)
+            w = ct.lwe_dimension + 1
+            _lib().cuda_memcpy_async_gpu_to_gpu(out.d_blocks.ptr, boolean.d_blocks.ptr, boolean.total_blocks * w * 8,
+                                                streams.ptr[0], streams.gpu_indexes[0])
+            _lib().cuda_integer_mult_inplace_64_async(s, C.byref(out._ffi()), True, C.byref(ct._ffi()), False, bsks,
+                                                      ksks, mem, self.bootstrapping_key.polynomial_size, ct.num_blocks)
+            _lib().cleanup_cuda_integer_mult_inplace_64(s, C.byref(mem))
+            return out
+        _lib().cuda_integer_mult_inplace_64_async(s, C.byref(ct._ffi()), False, C.byref(boolean._ffi()), True, bsks,
+                                                  ksks, mem, self.bootstrapping_key.polynomial_size, ct.num_blocks)
+        _lib().cleanup_cuda_integer_mult_inplace_64(s, C.byref(mem))
+        return ct
+
+
 class CudaUnsignedRadixCiphertext:
     """A batch of unsigned radix integers on the device: [integer][block][lwe_size] u64, least
     significant block first (integer/gpu/ciphertext/mod.rs; one reference ciphertext = batch of 1)."""
@@ -176,11 +208,20 @@ class CudaUnsignedRadixCiphertext:
     def __init__(self, d_blocks: CudaVec, num_integers, num_blocks, lwe_dimension):
         self.d_blocks = d_blocks
         self.num_integers, self.num_blocks, self.lwe_dimension = int(num_integers), int(num_blocks), int(lwe_dimension)
+        # degrees / noise levels as the reference's structs carry them; the backend updates them and refuses operands
+        # whose degrees exceed what an operation accepts.  Default 1: "not tracked" (callers that track set_degrees)
         self._info = np.ones(self.total_blocks, dtype=U64), np.ones(self.total_blocks, dtype=U64)
 
     @property
     def total_blocks(self):
         return self.num_integers * self.num_blocks
+
+    def set_degrees(self, degree):
+        self._info[0][:] = int(degree)
+
+    @property
+    def degrees(self):
+        return self._info[0]
 
     @classmethod
     def from_blocks(cls, h_blocks, streams):
