@@ -110,7 +110,7 @@ class HeadlineShard:
     shape — one host thread and one stream per GPU, key replicas, contiguous shards
     (tfhe-benchmark/benches/core_crypto/pbs_bench.rs:1050-1160, cuda/src/utils/helper_multi_gpu.cuh:170-294)."""
 
-    def __init__(self, lib, p, keys, device, rank, world, B, kernel=0, f=lambda x: x):
+    def __init__(self, lib, p, keys, device, rank, world, B, kernel=0, f=lambda x: x, global_batch=None):
         import numpy as np
         from tfhe_rs_amd import core_crypto_gpu as gpu
         from tfhe_rs_amd.multi_gpu import shard_range
@@ -123,8 +123,13 @@ class HeadlineShard:
         self.bsk = gpu.CudaLweBootstrapKey.from_lwe_bootstrap_key(keys.bsk, p.n, p.k, p.N, p.pbs_base_log, p.pbs_level,
                                                                   self.streams, ms_noise_reduction=bool(p.ms_type),
                                                                   engine="fft64")
-        lo, hi = shard_range(B * world, rank, world)          # this GPU's shard of the global batch (weak scaling)
-        assert hi - lo == B
+        if global_batch is None:
+            lo, hi = shard_range(B * world, rank, world)      # this GPU's shard of the global batch (weak scaling)
+            assert hi - lo == B
+        else:                                                  # a given global batch, split by the reference's rule
+            lo, hi = shard_range(global_batch, rank, world)    # (ragged: the first global_batch % world shards take one more)
+            B = self.B = hi - lo
+        self.lo = lo
         self.msgs = [(lo + i) % p.plaintext_modulus for i in range(B)]
         self.cts = encrypt_small(p, keys, self.msgs, seed=100 + rank)   # B distinct fresh encryptions
         self.lut = orc.generate_lut(p.k, p.N, p.plaintext_modulus, p.delta, f)
@@ -176,7 +181,7 @@ class HeadlineShard:
             self.buf = None
 
 
-def run_in_process(lib, p, keys, devices, B, steps, warmup, kernel=0, verify=True):
+def run_in_process(lib, p, keys, devices, B, steps, warmup, kernel=0, verify=True, global_batch=None):
     """The headline on len(devices) GPUs from ONE process: one host thread, one stream, one key replica and one
     B-LWE shard per GPU (the reference bench's shape, pbs_bench.rs:1050-1160); no exchange between GPUs.  All
     threads meet before the timed region, time their own `steps` launches and drain their stream; the job's time is
@@ -190,7 +195,7 @@ def run_in_process(lib, p, keys, devices, B, steps, warmup, kernel=0, verify=Tru
 
     def work(i):
         try:
-            sh = HeadlineShard(lib, p, keys, devices[i], i, n, B, kernel)
+            sh = HeadlineShard(lib, p, keys, devices[i], i, n, B, kernel, global_batch=global_batch)
             for _ in range(warmup):
                 sh.step()
             sh.sync()
@@ -201,6 +206,7 @@ def run_in_process(lib, p, keys, devices, B, steps, warmup, kernel=0, verify=Tru
             gate.wait()
             bad = sh.undecryptable_rows() if verify else []
             res[i] = {"t0": t0, "t1": t1, "kernel_ms": kernel_ms, "bad": bad, "shard": sh, "device": int(devices[i]),
+                      "lwes": sh.B, "lo": sh.lo,
                       "kernel_id": int(lib.hip_backend_last_pbs_kernel())}
             if i:
                 sh.close()
@@ -216,8 +222,8 @@ def run_in_process(lib, p, keys, devices, B, steps, warmup, kernel=0, verify=Tru
     if errs:
         raise errs[0]
     elapsed = max(r["t1"] for r in res) - min(r["t0"] for r in res)
-    per_gpu = [{"shard": i, "device": r["device"], "lwes": B, "seconds": r["t1"] - r["t0"],
-                "pbs_per_s": B * steps / (r["t1"] - r["t0"]), "kernel_ms_avg": sum(r["kernel_ms"]) / len(r["kernel_ms"]),
+    per_gpu = [{"shard": i, "device": r["device"], "lwes": r["lwes"], "first_lwe": r["lo"], "seconds": r["t1"] - r["t0"],
+                "pbs_per_s": r["lwes"] * steps / (r["t1"] - r["t0"]), "kernel_ms_avg": sum(r["kernel_ms"]) / len(r["kernel_ms"]),
                 "verified": not r["bad"]} for i, r in enumerate(res)]
     for r in res:
         assert not verify or not r["bad"], f"PBS outputs failed to decrypt at rows {r['bad'][:8]}"

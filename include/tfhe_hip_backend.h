@@ -413,9 +413,13 @@ void cleanup_cuda_integer_mult_inplace_64(CudaStreamsFFI streams, int8_t **mem_p
 /* extensions: integers per launch the NEXT scratch_* call is sized for (default 1), and the number
  * of PBS one multiplication issues per integer (for throughput accounting) */
 void hip_integer_scratch_batch(uint32_t num_integers);
-/* blocks per GPU from which a KS -> PBS round of the radix layer spreads over one more GPU of its CudaStreamsFFI
- * (default 512); the stream set may also name the same GPU several times (one stream each) */
+/* blocks per GPU from which a KS -> PBS round of the radix layer spreads over one more GPU of its CudaStreamsFFI.
+ * 0 (default): the reference's rule, cuda/src/utils/helper_multi_gpu.cu:16-48 (get_active_gpu_count) — 12 for
+ * multi-bit keys, (compute units of the first GPU) + 1 for classic ones.  The stream set may also name the same GPU
+ * several times (one stream each).  hip_integer_active_gpu_count: how many GPUs of a set of gpu_count a round of
+ * num_blocks blocks uses under the current setting (pbs_type as PBS_TYPE: MULTI_BIT = 0, CLASSICAL = 1). */
 void hip_integer_set_multi_gpu_threshold(uint32_t blocks_per_gpu);
+uint32_t hip_integer_active_gpu_count(uint32_t num_blocks, uint32_t gpu_count, uint32_t pbs_type, uint32_t first_gpu);
 uint64_t hip_integer_mult_pbs_count(int8_t *mem_ptr);
 uint64_t hip_integer_propagate_pbs_count(uint32_t num_blocks);
 

@@ -58,7 +58,27 @@ static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) {
 static inline hipError_t hipEventQuery(hipEvent_t) { return hipSuccess; }
 static inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { return hipEventCreate(e); }
 #define hipEventDisableTiming 0
-static inline hipError_t hipMemcpyPeerAsync(void *d, int, const void *s, int, size_t n, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
+// Peer model: HIPEMU_NO_PEER=1 makes the pretend devices unable to reach each other's memory; a peer copy between two
+// devices then fails unless access was enabled (the library must ask first and take its host-staged path otherwise).
+#define hipErrorPeerAccessAlreadyEnabled 704
+#define hipErrorPeerAccessUnsupported 217
+inline bool hipemu_peer_enabled[16][16] = {};
+static inline bool hipemu_no_peer() { const char *e = getenv("HIPEMU_NO_PEER"); return e && atoi(e) != 0; }
+static inline hipError_t hipDeviceCanAccessPeer(int *can, int dev, int peer) { *can = (dev != peer && !hipemu_no_peer()) ? 1 : 0; return hipSuccess; }
+static inline hipError_t hipDeviceEnablePeerAccess(int peer, unsigned) {
+  if (hipemu_no_peer()) return hipErrorPeerAccessUnsupported;
+  bool &e = hipemu_peer_enabled[hipemu_current_device & 15][peer & 15];
+  if (e) return hipErrorPeerAccessAlreadyEnabled;
+  e = true;
+  return hipSuccess;
+}
+static inline hipError_t hipMemcpyPeerAsync(void *d, int ddev, const void *s, int sdev, size_t n, hipStream_t) {
+  if (ddev != sdev && !(hipemu_peer_enabled[ddev & 15][sdev & 15] && hipemu_peer_enabled[sdev & 15][ddev & 15])) return hipErrorPeerAccessUnsupported;
+  memcpy(d, s, n);
+  return hipSuccess;
+}
+static inline hipError_t hipHostMalloc(void **p, size_t n, unsigned) { return hipMalloc(p, n); }
+static inline hipError_t hipHostFree(void *p) { free(p); return hipSuccess; }
 static inline hipError_t hipMemGetAddressRange(void **base, size_t *size, void *p) { *base = p; *size = 1; return hipSuccess; }
 template <class F> static inline hipError_t hipFuncSetAttribute(F, int, int) { return hipSuccess; }
 #define hipFuncAttributeMaxDynamicSharedMemorySize 0

@@ -36,6 +36,27 @@ def test_in_process_two_gpus_shards_verified_and_counted(monkeypatch):
     shard0.close()
 
 
+def test_ragged_global_batch_over_three_gpus(monkeypatch):
+    """A global batch that does not divide by the GPU count (11 LWEs over 3 devices: 4 + 4 + 3, the CPU-tier image of
+    4099 over 3) is split by the reference's rule (helper_multi_gpu.cu:71-101: the first B mod G GPUs take one more),
+    contiguously and without a gap or an overlap; every shard is verified and the shards together are the global batch."""
+    monkeypatch.setenv("HIPEMU_DEVICES", "3")
+    import bench
+    from tfhe_rs_amd.multi_gpu import get_num_inputs_on_gpu
+    lib = use_backend("emu")
+    p, keys = TOY_2048, make_keys(TOY_2048)
+    devices, fake = bench.pick_devices(lib, 3)
+    assert devices == [0, 1, 2] and not fake
+    G, steps = 11, 1
+    elapsed, per_gpu, shard0, kernel_ms, _ = bench.run_in_process(lib, p, keys, devices, None, steps, 0, global_batch=G)
+    assert [g["lwes"] for g in per_gpu] == [get_num_inputs_on_gpu(G, i, 3) for i in range(3)] == [4, 4, 3]
+    assert [g["first_lwe"] for g in per_gpu] == [0, 4, 8] and sum(g["lwes"] for g in per_gpu) == G
+    assert all(g["verified"] for g in per_gpu)
+    assert shard0.msgs == [i % p.plaintext_modulus for i in range(4)]
+    assert np.array_equal(shard0.outputs(), oracle_pbs(p, keys, "fft64", shard0.cts, shard0.lut))
+    shard0.close()
+
+
 def test_more_shards_than_gpus_is_refused_unless_faked(monkeypatch):
     monkeypatch.setenv("HIPEMU_DEVICES", "1")
     import bench

@@ -236,7 +236,7 @@ def test_radix_rounds_sharded_over_the_streams_of_the_set(kind):
             sks.mul_assign(cm, cb, st)
             outs[name] = (ca.to_blocks(st), cm.to_blocks(st))
         finally:
-            lib.hip_integer_set_multi_gpu_threshold(512)
+            lib.hip_integer_set_multi_gpu_threshold(0)
     assert np.array_equal(outs["one"][0], outs["three"][0]) and np.array_equal(outs["one"][1], outs["three"][1])
     assert recompose(decrypt_blocks(p, keys, outs["three"][0])) == [(x + y) & mask for x, y in zip(a, b)]
     assert recompose(decrypt_blocks(p, keys, outs["three"][1])) == [(x * y) & mask for x, y in zip(a, b)]
@@ -268,10 +268,58 @@ def test_radix_rounds_on_distinct_devices_record_events_on_their_own_streams(mon
             sks.mul_assign(cm, cb, st)
             outs[name] = (ca.to_blocks(st), cm.to_blocks(st))
         finally:
-            lib.hip_integer_set_multi_gpu_threshold(512)
+            lib.hip_integer_set_multi_gpu_threshold(0)
     assert np.array_equal(outs["one"][0], outs["three"][0]) and np.array_equal(outs["one"][1], outs["three"][1])
     assert recompose(decrypt_blocks(p, keys, outs["three"][0])) == [(x + y) & mask for x, y in zip(a, b)]
     assert recompose(decrypt_blocks(p, keys, outs["three"][1])) == [(x * y) & mask for x, y in zip(a, b)]
+
+
+def test_radix_rounds_on_devices_without_peer_access_take_the_host_staged_copies(monkeypatch):
+    """Three distinct devices that cannot reach each other's memory (HIPEMU_NO_PEER: hipDeviceCanAccessPeer says no,
+    hipDeviceEnablePeerAccess fails, a peer copy between them is an error): the library must have asked and must ship
+    its shards through the pinned host buffer instead.  With peer access available the same stand-in only lets a peer
+    copy through once BOTH directions were enabled (the test above runs that way).  Same bits as the single-device run."""
+    monkeypatch.setenv("HIPEMU_DEVICES", "3")
+    monkeypatch.setenv("HIPEMU_NO_PEER", "1")
+    kind = "emu"
+    lib = use_backend(kind)
+    p, keys, st1, sks1, igpu = setup(kind)
+    _, _, st3, sks3, _ = setup(kind, gpu_indexes=(2, 0, 1))   # the first GPU of the set need not be device 0
+    L, mask = 5, (1 << 10) - 1
+    a, b = [0x2A7, 0x155, mask], [0x1F3, 0x2AB, 1]
+    blocks_a, blocks_b = encrypt_radix(p, keys, a, L, 61), encrypt_radix(p, keys, b, L, 62)
+    outs = {}
+    for name, st, sks, thr in (("one", st1, sks1, 0), ("three", st3, sks3, 2)):
+        lib.hip_integer_set_multi_gpu_threshold(thr)
+        try:
+            ca = igpu.CudaUnsignedRadixCiphertext.from_blocks(blocks_a, st)
+            cb = igpu.CudaUnsignedRadixCiphertext.from_blocks(blocks_b, st)
+            sks.add_assign(ca, cb, st)
+            outs[name] = ca.to_blocks(st)
+        finally:
+            lib.hip_integer_set_multi_gpu_threshold(0)
+    assert np.array_equal(outs["one"], outs["three"])
+    assert recompose(decrypt_blocks(p, keys, outs["three"])) == [(x + y) & mask for x, y in zip(a, b)]
+
+
+def test_active_gpu_count_is_the_reference_rule():
+    """get_active_gpu_count (helper_multi_gpu.cu:16-48): a round spreads over min(G, ceil(blocks / threshold)) GPUs,
+    threshold 12 for multi-bit keys and (compute units of GPU 0) + 1 for classic ones — so ONE FheUint64 operation on
+    the multi-bit set (rounds of 32, 20, 3, 3, 7, 32 blocks) uses 3, 2, 1, 1, 1, 3 GPUs of 8, as on the reference's
+    8 x H100 run; the setter overrides the rule, 0 restores it."""
+    lib = use_backend("emu")
+    MULTI_BIT, CLASSICAL = 0, 1   # pbs/pbs_enums.h:4
+    lib.hip_integer_set_multi_gpu_threshold(0)
+    assert [lib.hip_integer_active_gpu_count(b, 8, MULTI_BIT, 0) for b in (32, 20, 3, 7, 12, 13, 96, 97, 1024)] == \
+        [3, 2, 1, 1, 1, 2, 8, 8, 8]
+    cus = lib.cuda_get_number_of_sms()
+    assert [lib.hip_integer_active_gpu_count(b, 8, CLASSICAL, 0) for b in (1, cus + 1, cus + 2, 4 * (cus + 1), 32768)] == \
+        [1, 1, 2, 4, 8]
+    lib.hip_integer_set_multi_gpu_threshold(3)
+    try:
+        assert lib.hip_integer_active_gpu_count(7, 8, CLASSICAL, 0) == 3
+    finally:
+        lib.hip_integer_set_multi_gpu_threshold(0)
 
 
 @pytest.mark.parametrize("kind", BACKENDS)

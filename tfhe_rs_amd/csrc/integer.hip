@@ -21,6 +21,8 @@
 
 #include <algorithm>
 #include <functional>
+#include <map>
+#include <mutex>
 #include <vector>
 
 namespace tfhe_hip {
@@ -150,7 +152,49 @@ static T *dev_upload(hipStream_t st, const std::vector<T> &h) {
 // (ksks[i], bsks[i]) and scratch, and sends the results back for a scatter on GPU 0.  Events order the streams;
 // no host synchronisation, no collective.  The same code runs with several streams on ONE device (the
 // reference's debug-fake-multi-gpu idea), which is how the 1-GPU test box exercises it.
-static std::atomic<uint32_t> g_multi_gpu_min_blocks{512};  // blocks per GPU below which a round stays on fewer GPUs
+// Blocks per GPU from which a round spreads over one more GPU of the stream set.  0 (default): the reference's rule
+// (get_active_gpu_count, helper_multi_gpu.cu:16-48) — 12 for multi-bit keys, (compute units of the first GPU) + 1 for
+// classic ones; hip_integer_set_multi_gpu_threshold overrides it (tests, tuning).  The crossover on 8 MI355X is not
+// measured (one GPU per box): the rule is the reference's, the setter is there to move it.
+static std::atomic<uint32_t> g_multi_gpu_min_blocks{0};
+static uint32_t multi_gpu_threshold(const Params &p, uint32_t first_gpu) {
+  const uint32_t forced = g_multi_gpu_min_blocks.load();
+  if (forced != 0) return forced;
+  if (p.grouping) return 12;  // THRESHOLD_MULTI_GPU_WITH_MULTI_BIT_PARAMS
+  static std::atomic<uint32_t> cus{0};  // get_threshold_multi_gpu_classical: computed once, first GPU's count
+  uint32_t c = cus.load();
+  if (c == 0) {
+    hipDeviceProp_t prop;
+    HX_CHECK(hipGetDeviceProperties(&prop, (int)first_gpu));
+    c = (uint32_t)prop.multiProcessorCount;
+    cus.store(c);
+  }
+  return c + 1;
+}
+
+// Copies between the GPUs of a stream set: direct (peer access enabled once per ordered pair of devices) where the
+// devices can reach each other, through a pinned host buffer where they cannot (helper_multi_gpu.cuh:170-294 relies on
+// cudaMemcpyPeerAsync's own fallback; here the two paths are explicit so that both are testable).
+static std::mutex g_peer_mutex;
+static std::map<std::pair<int, int>, bool> g_peer_direct;  // (device that issues the copy, other device) -> direct?
+static bool peer_direct(int dev, int other) {
+  if (dev == other) return true;
+  std::lock_guard<std::mutex> lock(g_peer_mutex);
+  auto it = g_peer_direct.find({dev, other});
+  if (it != g_peer_direct.end()) return it->second;
+  int can = 0, cur = 0;
+  HX_CHECK(hipGetDevice(&cur));
+  HX_CHECK(hipDeviceCanAccessPeer(&can, dev, other));
+  if (can) {
+    HX_CHECK(hipSetDevice(dev));
+    const hipError_t e = hipDeviceEnablePeerAccess(other, 0);
+    if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) can = 0;
+    (void)hipGetLastError();
+    HX_CHECK(hipSetDevice(cur));
+  }
+  g_peer_direct[{dev, other}] = can != 0;
+  return can != 0;
+}
 
 static uint32_t num_inputs_on_gpu(uint32_t total, uint32_t gpu, uint32_t gpus) {  // helper_multi_gpu.cu:71-101
   if (gpus > total) return gpu < total ? 1u : 0u;
@@ -171,6 +215,8 @@ struct LutDriver {
     uint64_t *d_in = nullptr, *d_out = nullptr, *d_lut_idx = nullptr;   // on this GPU
     uint64_t *d0_in = nullptr, *d0_out = nullptr;                       // on the first GPU
     uint64_t *d_many = nullptr;  // first GPU only, drivers created for many-LUT rounds: dense outputs before the scatter
+    bool direct = true;          // this GPU and the first one reach each other's memory (peer access enabled)
+    uint64_t *h_stage = nullptr; // pinned host buffer for the copies when they do not
     hipEvent_t staged = nullptr, done = nullptr, copied = nullptr;
   };
   std::vector<PerGpu> gpus;
@@ -220,7 +266,12 @@ struct LutDriver {
           HX_CHECK(hipEventCreateWithFlags(&g.copied, hipEventDisableTiming));
         }
         HX_CHECK(hipSetDevice((int)g.gpu));
-        if (!t_dry) HX_CHECK(hipEventCreateWithFlags(&g.done, hipEventDisableTiming));
+        if (!t_dry) {
+          HX_CHECK(hipEventCreateWithFlags(&g.done, hipEventDisableTiming));
+          // the copies of a round are issued on this GPU's stream in both directions
+          g.direct = peer_direct((int)g.gpu, (int)gpus[0].gpu) && peer_direct((int)gpus[0].gpu, (int)g.gpu);
+          if (!g.direct) HX_CHECK(hipHostMalloc((void **)&g.h_stage, (size_t)many_max * cap * w * sizeof(uint64_t), 0));
+        }
       }
       HX_CHECK(hipStreamSynchronize(st));  // the LUT sources may be temporaries
       scratch_pbs(st, g);
@@ -254,6 +305,17 @@ struct LutDriver {
            bsks[0], many, stride);
   }
 
+  // one copy between this GPU and the first one, on this GPU's stream (stream order keeps the staging buffer safe)
+  static void peer_copy(const PerGpu &g, void *dst, int dst_dev, const void *src, int src_dev, size_t bytes,
+                        hipStream_t st) {
+    if (g.direct) {
+      HX_CHECK(hipMemcpyPeerAsync(dst, dst_dev, src, src_dev, bytes, st));
+    } else {
+      HX_CHECK(hipMemcpyAsync(g.h_stage, src, bytes, hipMemcpyDeviceToHost, st));
+      HX_CHECK(hipMemcpyAsync(dst, g.h_stage, bytes, hipMemcpyHostToDevice, st));
+    }
+  }
+
   // one round, split into launches of at most `cap` blocks; a null in_idx / out_idx means "block s".
   // many > 1: every bootstrap extracts `many` functions of its accumulator (coefficients t * stride); out_idx then
   // holds many * count entries, function t of block s goes to out[out_idx[t * count + s]] (the PBS kernels place
@@ -269,7 +331,7 @@ struct LutDriver {
     for (uint32_t off = 0; off < count; off += cap) {
       const uint32_t c = std::min(cap, count - off);
       // helper_multi_gpu.cu:39-48 (get_active_gpu_count): as many GPUs as the round can keep busy
-      const uint32_t min_blocks = g_multi_gpu_min_blocks.load();
+      const uint32_t min_blocks = multi_gpu_threshold(p, gpus[0].gpu);
       const uint32_t active = std::max(1u, std::min(avail, (c + min_blocks - 1) / min_blocks));
       const uint64_t *ii = in_idx ? in_idx + off : nullptr, *oi = out_idx ? out_idx + off : nullptr;
       const uint64_t *in0 = in_idx ? in : in + off * w;
@@ -291,12 +353,10 @@ struct LutDriver {
         HX_CHECK(hipEventRecord(g.staged, st0));
         HX_CHECK(hipSetDevice((int)g.gpu));
         HX_CHECK(hipStreamWaitEvent(sti, g.staged, 0));
-        HX_CHECK(hipMemcpyPeerAsync(g.d_in, (int)g.gpu, g.d0_in, (int)gpus[0].gpu, (size_t)ci * w * sizeof(uint64_t), sti));
-        HX_CHECK(hipMemcpyPeerAsync(g.d_lut_idx, (int)g.gpu, lut_idx + off + begin, (int)gpus[0].gpu,
-                                    (size_t)ci * sizeof(uint64_t), sti));
+        peer_copy(g, g.d_in, (int)g.gpu, g.d0_in, (int)gpus[0].gpu, (size_t)ci * w * sizeof(uint64_t), sti);
+        peer_copy(g, g.d_lut_idx, (int)g.gpu, lut_idx + off + begin, (int)gpus[0].gpu, (size_t)ci * sizeof(uint64_t), sti);
         ks_pbs(sti, g, g.d_out, g.d_trivial, g.d_in, g.d_trivial, g.d_lut_idx, ci, ksks[i], bsks[i], many, stride);
-        HX_CHECK(hipMemcpyPeerAsync(g.d0_out, (int)gpus[0].gpu, g.d_out, (int)g.gpu,
-                                    (size_t)many * ci * w * sizeof(uint64_t), sti));
+        peer_copy(g, g.d0_out, (int)gpus[0].gpu, g.d_out, (int)g.gpu, (size_t)many * ci * w * sizeof(uint64_t), sti);
         HX_CHECK(hipEventRecord(g.done, sti));
         begin += ci;
       }
@@ -354,6 +414,7 @@ struct LutDriver {
         if (d) HX_CHECK(hipFree(d));
       for (hipEvent_t e : {g.staged, g.done, g.copied})
         if (e) HX_CHECK(hipEventDestroy(e));
+      if (g.h_stage) HX_CHECK(hipHostFree(g.h_stage));
       HX_CHECK(hipSetDevice((int)gpus[0].gpu));
       for (uint64_t *d : {g.d0_in, g.d0_out})
         if (d) HX_CHECK(hipFree(d));
@@ -1269,10 +1330,17 @@ static void check_propagation_degrees(const CudaRadixCiphertextFFI *ct, uint32_t
 // the reference's prototypes): thread-local, so that concurrent host threads size their own scratches
 static thread_local uint32_t g_scratch_batch = 1;
 void hip_integer_scratch_batch(uint32_t num_integers) { g_scratch_batch = num_integers ? num_integers : 1; }
-// blocks per GPU from which a KS -> PBS round spreads over one more GPU of the stream set (default 512; the
-// reference's THRESHOLD_MULTI_GPU_* constants, helper_multi_gpu.cu:12-48); tests lower it
+// blocks per GPU from which a KS -> PBS round spreads over one more GPU of the stream set; 0 restores the default, the
+// reference's THRESHOLD_MULTI_GPU_* rule (helper_multi_gpu.cu:12-48); tests lower it
 void hip_integer_set_multi_gpu_threshold(uint32_t blocks_per_gpu) {
-  radix::g_multi_gpu_min_blocks.store(blocks_per_gpu ? blocks_per_gpu : 1);
+  radix::g_multi_gpu_min_blocks.store(blocks_per_gpu);  // 0: the reference's rule (12 multi-bit, compute units + 1 classic)
+}
+// how many GPUs of a set of `gpu_count` a round of `num_blocks` blocks uses (get_active_gpu_count): for callers and tests
+uint32_t hip_integer_active_gpu_count(uint32_t num_blocks, uint32_t gpu_count, uint32_t pbs_type, uint32_t first_gpu) {
+  radix::Params p{};
+  p.grouping = pbs_type == MULTI_BIT ? 1u : 0u;
+  const uint32_t th = radix::multi_gpu_threshold(p, first_gpu);
+  return std::max(1u, std::min(gpu_count, (num_blocks + th - 1) / th));
 }
 
 uint64_t scratch_cuda_propagate_single_carry_64_inplace_async(CudaStreamsFFI streams, int8_t **mem_ptr,

@@ -140,6 +140,15 @@
 // fma(x, 1, y) = x + y).  The values are checked against the host tables when the tables are built (tables.hip).
 #define WAVE_UNIFORM_LITERALS 1
 #endif
+// ... per loop: the classic one-level loop (measured: 34.6 -> 33.3 ms per 4096 with the resident twiddles below), the
+// multi-bit loops, the split-key exact engine (measured slower with literals: 150.3 -> 156.0 ms per 4096 — the kernel
+// already spills, the literals' scalar moves add to it)
+#ifndef WAVE_LIT_MB
+#define WAVE_LIT_MB 1
+#endif
+#ifndef WAVE_LIT_LIMBS
+#define WAVE_LIT_LIMBS 0
+#endif
 #ifndef WAVE_RESIDENT
 #define WAVE_RESIDENT 2  // classic one-level loop: twiddles kept in registers across the iterations (ResidentTwiddles: 0..2)
 #endif
@@ -326,17 +335,13 @@ HX_DEV void load_resident_twiddles(ResidentTwiddles &t, const cplx *T, int lane)
 // ---- forward transform of 16 points per lane: mapping M1 in, mapping M3 out (and stored in my buffer)
 //   F1 stages 0..3 (position bits 9..6, registers) -> permlane swaps -> F2 stages 4,5 (bits 5,4, registers)
 //   -> LDS transposition MX -> M3 -> F3 stages 6..9 (bits 3..0, registers)
-template <int RES = 0>
+template <int RES = 0, bool LIT = false>
 HX_DEV void wave_forward(cplx (&d)[16], WaveCtx c, const ResidentTwiddles *res = nullptr) {
   HX_OPAQUE(c.lane);
   const int lane = c.lane, g4 = c.lane >> 4;
   const cplx *T = c.T;
   {  // pass F1: the same twiddles in every lane of every launch
-#if WAVE_UNIFORM_LITERALS
-    auto tw = [](int x) { return cplx{LIT_F1[x][0], LIT_F1[x][1]}; };
-#else
-    auto tw = [&](int x) { return T[T_F1 + x]; };
-#endif
+    auto tw = [&](int x) { return LIT ? cplx{LIT_F1[x][0], LIT_F1[x][1]} : T[T_F1 + x]; };
     const cplx w0 = tw(0);
     stage<3>(d, [&](int) { return w0; });
     const cplx e1 = tw(1);
@@ -411,24 +416,24 @@ HX_DEV void inverse_pass1_group(cplx (&o)[16], int g) {
 
 // inverse stage half = 4 (position bit 2 = r bit 2, twiddle E[128 (r & 1)], times -i for r & 2) on the points
 // r0 .. r0 + 7 (r0 = 0 or 8): literal or table twiddles, same butterflies either way
+template <bool LIT>
 HX_DEV void inverse_stage_half4(cplx (&o)[16], int r0, const cplx *T) {
-#if WAVE_UNIFORM_LITERALS
-  (void)T;
-  const cplx a1{LIT_E64[2][0], LIT_E64[2][1]};
-  HX_UNROLL
-  for (int r = r0; r < r0 + 4; ++r) {
-    if ((r & 3) == 0) bfly_one(o[r], o[r | 4]);
-    else if ((r & 3) == 2) bfly_mi(o[r], o[r | 4]);
-    else bfly(o[r], o[r | 4], (r & 2) ? times_mi(a1) : a1);
+  if constexpr (LIT) {
+    const cplx a1{LIT_E64[2][0], LIT_E64[2][1]};
+    HX_UNROLL
+    for (int r = r0; r < r0 + 4; ++r) {
+      if ((r & 3) == 0) bfly_one(o[r], o[r | 4]);
+      else if ((r & 3) == 2) bfly_mi(o[r], o[r | 4]);
+      else bfly(o[r], o[r | 4], (r & 2) ? times_mi(a1) : a1);
+    }
+  } else {
+    const cplx a0 = T[T_INV], a1 = T[T_INV + 128];
+    HX_UNROLL
+    for (int r = r0; r < r0 + 4; ++r) {
+      const cplx e = (r & 1) ? a1 : a0;
+      bfly(o[r], o[r | 4], (r & 2) ? times_mi(e) : e);
+    }
   }
-#else
-  const cplx a0 = T[T_INV], a1 = T[T_INV + 128];
-  HX_UNROLL
-  for (int r = r0; r < r0 + 4; ++r) {
-    const cplx e = (r & 1) ? a1 : a0;
-    bfly(o[r], o[r | 4], (r & 2) ? times_mi(e) : e);
-  }
-#endif
 }
 
 // OVERWRITE (multi-bit: dst = 0 + src (x) GGSW): the result replaces the accumulator and is not staged.
@@ -437,7 +442,7 @@ HX_DEV void inverse_stage_half4(cplx (&o)[16], int r0, const cplx *T) {
 // RAW (exact engine, split-key form): no torus conversion — o[r] becomes (t_re, t_im), the untwisted real values of
 // coefficients r*64 + lane and 1024 + r*64 + lane; nothing is staged, the accumulator registers are not touched.
 // PASS1_DONE: 0 nothing done, 1 stages half = 1, 2 done by the caller
-template <int PASS1_DONE, bool OVERWRITE = false, bool NEG = false, bool RAW = false, int RES = 0>
+template <int PASS1_DONE, bool OVERWRITE = false, bool NEG = false, bool RAW = false, int RES = 0, bool LIT = false>
 HX_DEV void wave_inverse_accumulate(cplx (&o)[16], uint64_t (&acc_re)[16], uint64_t (&acc_im)[16], WaveCtx c,
                                     const ResidentTwiddles *res = nullptr) {
   uint64_t *stg = (uint64_t *)c.buf;
@@ -450,26 +455,26 @@ HX_DEV void wave_inverse_accumulate(cplx (&o)[16], uint64_t (&acc_re)[16], uint6
   // pass I1 (continued): stages half = 4, 8 over position bits 2, 3 (= r bits 2, 3); j = r & 3, r & 7, so the
   // twiddles are the same in every lane: E[j*128] and E[j*64]
   {
-    inverse_stage_half4(o, 0, T);
-    inverse_stage_half4(o, 8, T);
+    inverse_stage_half4<LIT>(o, 0, T);
+    inverse_stage_half4<LIT>(o, 8, T);
     HX_SCHED_FENCE();
     cplx *p3 = c.buf + base_m3(c);  // transposition M3 -> MX, store side
-#if WAVE_UNIFORM_LITERALS
-    HX_UNROLL
-    for (int r = 0; r < 8; ++r) {  // stage half = 8: twiddle E[64 (r & 3)], times -i for r & 4
-      const cplx e{LIT_E64[r & 3][0], LIT_E64[r & 3][1]};
-      if (r == 0) bfly_one(o[r], o[r | 8]);
-      else if (r == 4) bfly_mi(o[r], o[r | 8]);
-      else bfly(o[r], o[r | 8], (r & 4) ? times_mi(e) : e);
-      p3[r] = o[r];
-      p3[r | 8] = o[r | 8];
+    if constexpr (LIT) {
+      HX_UNROLL
+      for (int r = 0; r < 8; ++r) {  // stage half = 8: twiddle E[64 (r & 3)], times -i for r & 4
+        const cplx e{LIT_E64[r & 3][0], LIT_E64[r & 3][1]};
+        if (r == 0) bfly_one(o[r], o[r | 8]);
+        else if (r == 4) bfly_mi(o[r], o[r | 8]);
+        else bfly(o[r], o[r | 8], (r & 4) ? times_mi(e) : e);
+        p3[r] = o[r];
+        p3[r | 8] = o[r | 8];
+      }
+    } else {
+      const cplx a0 = T[T_INV], a1 = T[T_INV + 128];
+      const cplx b4[4] = {a0, T[T_INV + 64], a1, T[T_INV + 192]};
+      stage_store<3>(o, [&](int r) { return (r & 4) ? times_mi(b4[r & 3]) : b4[r & 3]; },
+                     [&](int r) { p3[r] = o[r]; });
     }
-#else
-    const cplx a0 = T[T_INV], a1 = T[T_INV + 128];
-    const cplx b4[4] = {a0, T[T_INV + 64], a1, T[T_INV + 192]};
-    stage_store<3>(o, [&](int r) { return (r & 4) ? times_mi(b4[r & 3]) : b4[r & 3]; },
-                   [&](int r) { p3[r] = o[r]; });
-#endif
   }
   HX_WAVE_SYNC();
   // pass I2: stages half = 16, 32 over position bits 4, 5 (= r bits 2, 3 in mapping MX); j = (r bit 2).(lane & 15)
@@ -1085,7 +1090,7 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
           make_digits(d, 0, idx);
         }
         HX_PRIO(WAVE_PRIO_MB_B);
-        wave_forward(d, ctx);
+        wave_forward<0, WAVE_LIT_MB != 0>(d, ctx);
         HX_PRIO(WAVE_PRIO_MB_C);
         if constexpr (SHARE) {
           WaveCtx cx = ctx0;
@@ -1287,7 +1292,7 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
         HX_WAVE_SYNC();
       }
       HX_PRIO(WAVE_PRIO_MB_D);
-      wave_inverse_accumulate<0, true>(o, acc_re, acc_im, ctx);
+      wave_inverse_accumulate<0, true, false, false, 0, WAVE_LIT_MB != 0>(o, acc_re, acc_im, ctx);
       HX_PRIO(WAVE_PRIO_MB_K);
 #if WAVE_MB_PACE && !defined(TFHE_HIPEMU)
       pace_arrive();
@@ -1350,7 +1355,7 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
       HX_PRIO(WAVE_PRIO_A);
       make_digits(d, a_hat, 0);  // both operands of the rotation from the staged copy (the registers are not the accumulator's)
       HX_PRIO(WAVE_PRIO_B);
-      wave_forward(d, ctx);  // d = F, my row of the digit transform; also in my buffer (mapping M3)
+      wave_forward<0, WAVE_LIT_LIMBS != 0>(d, ctx);  // d = F, my row of the digit transform; also in my buffer (mapping M3)
       uint64_t R_re[16], R_im[16];
       HX_UNROLL
       for (int r = 0; r < 16; ++r) R_re[r] = R_im[r] = 0;
@@ -1366,7 +1371,7 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
             std::integral_constant<bool, WAVE_FUSE_PASS1 != 0>{});
         if constexpr (LAST) acc_load();
         HX_PRIO(WAVE_PRIO_D);
-        wave_inverse_accumulate<(WAVE_FUSE_PASS1 != 0) ? 1 : 0, false, false, true>(o, acc_re, acc_im, ctx);
+        wave_inverse_accumulate<(WAVE_FUSE_PASS1 != 0) ? 1 : 0, false, false, true, 0, WAVE_LIT_LIMBS != 0>(o, acc_re, acc_im, ctx);
         HX_UNROLL
         for (int r = 0; r < 16; ++r) {
           fold(R_re[r], o[r].re);
@@ -1429,12 +1434,12 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
         HX_PRIO(WAVE_PRIO_A);
         make_digits(d, a_hat, 0);
         HX_PRIO(WAVE_PRIO_B);
-        wave_forward<WAVE_RESIDENT>(d, ctx, &res_tw);
+        wave_forward<WAVE_RESIDENT, WAVE_UNIFORM_LITERALS != 0>(d, ctx, &res_tw);
         HX_PRIO(WAVE_PRIO_C);
         // in place: d becomes the Fourier-domain output of polynomial w, first inverse pass applied
         mac(d, d, ka0, ka1, kb0, kb1, b0, b1, 0, it, std::integral_constant<bool, WAVE_FUSE_PASS1 != 0>{});
         HX_PRIO(WAVE_PRIO_D);
-        wave_inverse_accumulate<(WAVE_FUSE_PASS1 != 0) ? 1 : 0, false, NEGACC, false, WAVE_RESIDENT>(d, acc_re, acc_im, ctx, &res_tw);
+        wave_inverse_accumulate<(WAVE_FUSE_PASS1 != 0) ? 1 : 0, false, NEGACC, false, WAVE_RESIDENT, WAVE_UNIFORM_LITERALS != 0>(d, acc_re, acc_im, ctx, &res_tw);
       } else {
         cplx o[16];
         for (uint32_t idx = 0; idx < level; ++idx) {

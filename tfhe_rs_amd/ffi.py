@@ -125,6 +125,7 @@ SIGNATURES = {
     "hip_backend_last_keyswitch_path": (_u32, []),
     "hip_backend_set_keyswitch_kparts": (None, [_u32]),
     "hip_integer_set_multi_gpu_threshold": (None, [_u32]),
+    "hip_integer_active_gpu_count": (_u32, [_u32, _u32, _u32, _u32]),
     "hip_backend_set_ntt_kernel": (None, [_u32]),
     "hip_backend_set_multibit_latency_groups": (None, [_u32]),
     # radix integers
