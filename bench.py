@@ -341,6 +341,9 @@ def main():
     ap.add_argument("--no-pmc", action="store_true", help="do not take rocprofv3 counter passes during the run "
                     "(`traffic` then comes from the committed build-stamped record)")
     ap.add_argument("--no-verify", action="store_true", help="skip the decrypt check (timing-ablation builds only)")
+    ap.add_argument("--parity-sample", type=int, default=0,
+                    help="LWEs of the config-3 / config-4 launches compared word for word with the CPU oracle "
+                         "(0 = the whole batch: about 2.5 min of CPU work on 16 threads)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="PBS count of the CPU baseline sample (0 = auto)")
     ap.add_argument("--fheuint64-worker", default=None, help=argparse.SUPPRESS)  # child process of the N > 1 config-5 datapoints
     args = ap.parse_args()
@@ -541,9 +544,11 @@ def main():
             "pbs_kernel_id": int(lib.hip_backend_last_pbs_kernel())}
     if single and args.kernel == 0 and not args.no_extra:
         # BASELINE.json configs 3 and 4 next to the headline (never part of `value`): batch 4096 on this GPU, HIP-event
-        # time over 3 launches, and the GPU's output words compared with the CPU oracle on the first 64 LWEs.
+        # time over 3 launches, and the GPU's output words compared with the CPU oracle on the WHOLE batch (BASELINE.json
+        # config 3: "batch 4096 ... bit-exact vs CPU NTT") unless --parity-sample asks for a prefix.
         from tests.common import C4
-        PAR = 64
+        PAR = B if args.parity_sample <= 0 else min(B, args.parity_sample)
+        par_txt = f"all {B} LWEs of the launch" if PAR == B else f"first {PAR} LWEs"
 
         def datapoint(q, run_gpu, steps=3):
             run_gpu()
@@ -583,7 +588,8 @@ def main():
                 p.n, p.k, p.N, p.pbs_base_log, p.pbs_level, B, 1, 0), steps=2)
             out3 = d_out3.to_lwe_ciphertext_list(streams)
             dp.update({"engine": label, "gpu_matches_cpu_bits": bool(np.array_equal(ref3, out3[:PAR])),
-                       "parity_sample": f"first {PAR} LWEs, all 2049 words, vs the C oracle's NTT engine ({t_ref3:.1f} s CPU)",
+                       "parity_sample": PAR,
+                       "parity_note": f"{par_txt}, all 2049 words, vs the C oracle's NTT engine ({t_ref3:.1f} s CPU)",
                        "decrypts": all(decrypt_big(p, keys, out3[i]) == f(msgs[i]) for i in range(PAR))})
             ntt[impl] = dp
             del bsk_n
@@ -600,9 +606,9 @@ def main():
         del d_out3
 
         # ---- config 4: multi-bit PBS, grouping factor 3; and the reference's GPU default multi-bit set (g = 4).
-        # Uniform-random key and inputs like the reference's benches: bit parity with the oracle does not need a
-        # valid key, and a real 320 MB key takes minutes to encrypt.
-        from tests.common import C4G4
+        # REAL keys (GGSW encryptions of the products of the key bits, 320 / 241 MB, a few seconds in the C oracle) and
+        # fresh encryptions of the messages i mod 16: the outputs are compared with the oracle AND decrypted.
+        from tests.common import C4G4, encrypt_small, make_keys
         def multibit_flop(q):
             """f64 flop per multi-bit PBS with the keybundle combined in the Fourier domain: per group l (k+1) forward and
             (k+1) inverse transforms at 5 n log2 n, (2^g - 1) l (k+1)^2 n complex multiply-adds for the combine and
@@ -615,11 +621,12 @@ def main():
 
         for tag, q in (("multibit_g3", C4), ("multibit_g4", C4G4)):
             flop = multibit_flop(q)
-            r4 = np.random.default_rng(11)
-            bsk4_h = r4.integers(0, 1 << 64, size=(q.n // q.grouping) * (1 << q.grouping) * q.pbs_level * 4 * q.N,
-                                 dtype=np.uint64)
-            cts4 = r4.integers(0, 1 << 64, size=(B, q.n + 1), dtype=np.uint64)
-            lut4 = r4.integers(0, 1 << 64, size=2 * q.N, dtype=np.uint64)
+            keys4 = make_keys(q, with_ksk=False)
+            bsk4_h = keys4.bsk
+            msgs4 = [i % q.plaintext_modulus for i in range(B)]
+            cts4 = encrypt_small(q, keys4, msgs4, seed=400 + q.grouping)
+            f4 = lambda x: (3 * x + 1) % q.plaintext_modulus  # noqa: E731
+            lut4 = orc.generate_lut(q.k, q.N, q.plaintext_modulus, q.delta, f4)
             bsk4 = gpu.CudaLweMultiBitBootstrapKey.from_lwe_multi_bit_bootstrap_key(
                 bsk4_h, q.n, q.k, q.N, q.pbs_base_log, q.pbs_level, q.grouping, streams)
             d_in4 = gpu.CudaLweCiphertextList.from_lwe_ciphertext_list(cts4, streams)
@@ -641,10 +648,12 @@ def main():
                        "frac_fp64": dp["pbs_per_s"] * flop / (FP64_PEAK_TFLOPS * 1e12), "f64_flop_per_pbs": flop,
                        "hbm_traffic_bytes_per_launch": traffic4, "traffic_source": src4,
                        "gpu_matches_cpu_bits": bool(np.array_equal(ref4, out4[:PAR])),
-                       "parity_sample": f"first {PAR} LWEs, all 2049 words, vs the C oracle's multi-bit f64 path "
-                                        f"({time.perf_counter() - t0:.1f} s CPU); uniform-random key and inputs"})
+                       "parity_sample": PAR,
+                       "parity_note": f"{par_txt}, all 2049 words, vs the C oracle's multi-bit f64 path "
+                                      f"({time.perf_counter() - t0:.1f} s CPU); real key, fresh encryptions",
+                       "decrypts": all(decrypt_big(q, keys4, out4[i]) == f4(msgs4[i]) for i in range(B))})
             result["extra"][tag] = dp
-            del bsk4, d_in4, d_out4
+            del bsk4, d_in4, d_out4, keys4
         # ---- config 5 on ONE GPU: FheUint64 (32 blocks of the 2_2 set) add and mul through the radix layer
         result["extra"]["fheuint64"] = fheuint64_datapoint(lib, p, keys, [g], {"add": 1024, "mul": 128}, in_library=False)
         # ---- latency of ONE FheUint64 operation on the reference's GPU multi-bit set (what its documentation publishes

@@ -32,7 +32,7 @@ constexpr int N = 1024, n = 512, LOG2N2 = 11;
 constexpr int BUF_SLOTS = 576, BUF_BYTES = BUF_SLOTS * 16;
 constexpr int MAX_WAVES = 12;  // 3 waves per SIMD (up to 168 VGPRs; the kernels take 130-150).  Measured at k = 2: 6 waves 118.6 k, 9: 105.7 k, 12: 140.0 k, 15 (128 VGPRs): 108.6 k PBS/s
 // forward twiddles by pass
-constexpr int T_FA = 0;     // stages 0..2: fwd[1..7]
+[[maybe_unused]] constexpr int T_FA = 0;     // stages 0..2: fwd[1..7]
 constexpr int T_FB3 = 7;    // stage 3: fwd[8 + hi3]
 constexpr int T_FB4 = 15;   // stage 4: fwd[16 + 2 hi3 + b] stored [b][hi3]
 constexpr int T_FB5 = 31;   // stage 5: fwd[32 + 4 hi3 + q] stored [q][hi3]
@@ -46,6 +46,23 @@ constexpr int FLAGS_BYTES = 128;
 constexpr size_t smem_bytes(int waves) { return (size_t)waves * BUF_BYTES + (size_t)T_TOTAL * 16 + FLAGS_BYTES; }
 
 HX_DEV cplx ldg_c(const double *t, int idx) { return cplx{t[2 * idx], t[2 * idx + 1]}; }
+
+#ifndef W3_UNIFORM_LITERALS
+// 1: the twiddles that are the same in every lane and every launch (forward stages 0..2: fwd[1..7]; inverse half = 4:
+// inv[4..7]) are literals of the instruction stream instead of broadcast reads of the LDS table, as in the N = 2048
+// kernel (pbs_fft_wave.hip); the inverse butterflies whose twiddle is 1 or -i lose their products (same roundings).
+// fwd[(1 << d) + g] does not depend on N, so these are the N = 2048 kernel's values; checked against the host tables
+// when they are built (tables.hip).
+#define W3_UNIFORM_LITERALS 1
+#endif
+constexpr double W3_LIT_F[7][2] = {{0x1.6a09e667f3bcdp-1, 0x1.6a09e667f3bcdp-1},   // fwd[1]
+                                   {0x1.d906bcf328d46p-1, 0x1.87de2a6aea963p-2},   // fwd[2]
+                                   {-0x1.87de2a6aea963p-2, 0x1.d906bcf328d46p-1},  // fwd[3] = i fwd[2]
+                                   {0x1.f6297cff75cbp-1, 0x1.8f8b83c69a60bp-3},    // fwd[4]
+                                   {-0x1.8f8b83c69a60bp-3, 0x1.f6297cff75cbp-1},   // fwd[5] = i fwd[4]
+                                   {0x1.1c73b39ae68c8p-1, 0x1.a9b66290ea1a3p-1},   // fwd[6]
+                                   {-0x1.a9b66290ea1a3p-1, 0x1.1c73b39ae68c8p-1}}; // fwd[7] = i fwd[6]
+constexpr double W3_LIT_I5[2] = {0x1.6a09e667f3bcdp-1, -0x1.6a09e667f3bcdp-1};    // inv[5] = e^{-i pi / 4}; inv[7] = -i inv[5]
 
 #if defined(TFHE_HIPEMU)
 HX_DEV void flag_set(volatile uint32_t *f, uint32_t v) { *f = v; }
@@ -84,25 +101,76 @@ HX_DEV void bfly_mi(cplx &x, cplx &y) {
   y = o2;
 }
 
+// the §4 butterfly (a, b) -> (a + s b, 2 a - (a + s b)) with s = 1 and s = -i: fma(b.re, 1, a.re) = a.re + b.re, the
+// products by 0 vanish (the sign of an exact zero aside, which no later step reads)
+HX_DEV void bfly_one_fma(cplx &a, cplx &b) {
+  const double o1r = a.re + b.re, o1i = a.im + b.im;
+  b.re = fma(2.0, a.re, -o1r);
+  b.im = fma(2.0, a.im, -o1i);
+  a.re = o1r;
+  a.im = o1i;
+}
+HX_DEV void bfly_mi_fma(cplx &a, cplx &b) {
+  const double o1r = a.re + b.im, o1i = a.im - b.re;
+  b.re = fma(2.0, a.re, -o1r);
+  b.im = fma(2.0, a.im, -o1i);
+  a.re = o1r;
+  a.im = o1i;
+}
+
 struct Ctx {
   cplx *buf;      // my exchange buffer
   const cplx *T;  // table
   int lane;
 };
 
+#ifndef W3_RESIDENT
+// twiddles kept in registers for the whole launch (read once in front of the CMUX loop), as in the N = 2048 kernel:
+// 1 = forward stages 3..5 (seven values that depend on lane >> 3), 2 = also inverse half = 8, 16, 32 (seven on lane & 7)
+#define W3_RESIDENT 1
+#endif
+struct Resident3 {
+  cplx f3, f4[2], f5[4];   // forward stages 3, 4, 5
+  cplx i8, i16[2], i32[4]; // inverse half = 8, 16, 32
+};
+template <int LEVEL>
+HX_DEV void load_resident3(Resident3 &t, const cplx *T, int lane) {
+  const int hi3 = lane >> 3, lo3 = lane & 7;
+  if constexpr (LEVEL >= 1) {
+    t.f3 = T[T_FB3 + hi3];
+    t.f4[0] = T[T_FB4 + hi3];
+    t.f4[1] = T[T_FB4 + 8 + hi3];
+    HX_UNROLL
+    for (int q = 0; q < 4; ++q) t.f5[q] = T[T_FB5 + 8 * q + hi3];
+  }
+  if constexpr (LEVEL >= 2) {
+    t.i8 = T[T_INV + 8 + lo3];
+    t.i16[0] = T[T_INV + 16 + lo3];
+    t.i16[1] = T[T_INV + 24 + lo3];
+    HX_UNROLL
+    for (int q = 0; q < 4; ++q) t.i32[q] = T[T_INV + 32 + 8 * q + lo3];
+  }
+}
+
 // digits (layout LA) -> transform, left in registers (layout LC) and in my buffer at the LC slots
-HX_DEV void forward(cplx (&d)[8], Ctx c) {
+template <int RES = 0>
+HX_DEV void forward(cplx (&d)[8], Ctx c, const Resident3 *res = nullptr) {
   HX_OPAQUE(c.lane);
   const int lane = c.lane, hi3 = lane >> 3, lo3 = lane & 7;
   const cplx *T = c.T;
   {  // stages 0..2: position bits 8, 7, 6 = register bits 2, 1, 0; group = the bits above
-    const cplx w0 = T[T_FA + 0];
+#if W3_UNIFORM_LITERALS
+    auto tw = [](int x) { return cplx{W3_LIT_F[x][0], W3_LIT_F[x][1]}; };
+#else
+    auto tw = [&](int x) { return T[T_FA + x]; };
+#endif
+    const cplx w0 = tw(0);
     stage8<2>(d, [&](int) { return w0; });
     HX_SCHED_FENCE();  // twiddle loads stay next to their stage (hoisted together they cost 80 registers)
-    const cplx w1[2] = {T[T_FA + 1], T[T_FA + 2]};
+    const cplx w1[2] = {tw(1), tw(2)};
     stage8<1>(d, [&](int r) { return w1[r >> 2]; });
     HX_SCHED_FENCE();
-    const cplx w2[4] = {T[T_FA + 3], T[T_FA + 4], T[T_FA + 5], T[T_FA + 6]};
+    const cplx w2[4] = {tw(3), tw(4), tw(5), tw(6)};
     stage8<0>(d, [&](int r) { return w2[r >> 1]; });
     HX_SCHED_FENCE();
   }
@@ -117,13 +185,15 @@ HX_DEV void forward(cplx (&d)[8], Ctx c) {
     HX_UNROLL
     for (int r = 0; r < 8; ++r) d[r] = pb[8 * r];
     HX_WAVE_SYNC();
-    const cplx w3 = T[T_FB3 + hi3];
+    const cplx w3 = RES >= 1 ? res->f3 : T[T_FB3 + hi3];
     stage8<2>(d, [&](int) { return w3; });
     HX_SCHED_FENCE();
-    const cplx w4[2] = {T[T_FB4 + hi3], T[T_FB4 + 8 + hi3]};
+    const cplx w4[2] = {RES >= 1 ? res->f4[0] : T[T_FB4 + hi3], RES >= 1 ? res->f4[1] : T[T_FB4 + 8 + hi3]};
     stage8<1>(d, [&](int r) { return w4[r >> 2]; });
     HX_SCHED_FENCE();
-    const cplx w5[4] = {T[T_FB5 + hi3], T[T_FB5 + 8 + hi3], T[T_FB5 + 16 + hi3], T[T_FB5 + 24 + hi3]};
+    cplx w5[4];
+    HX_UNROLL
+    for (int q = 0; q < 4; ++q) w5[q] = RES >= 1 ? res->f5[q] : T[T_FB5 + 8 * q + hi3];
     stage8<0>(d, [&](int r) { return w5[r >> 1]; });
     HX_SCHED_FENCE();
     cplx *pb2 = c.buf + hi3 * 72 + lo3;  // LB slots of P2
@@ -153,8 +223,9 @@ HX_DEV void forward(cplx (&d)[8], Ctx c) {
 
 // o (layout LC) -> backward transform, untwist, to the torus, added to the (negated) accumulator, which is
 // then staged for the next rotation
-template <bool NEG>
-HX_DEV void inverse_accumulate(cplx (&o)[8], uint64_t (&acc_re)[8], uint64_t (&acc_im)[8], Ctx c) {
+template <bool NEG, int RES = 0>
+HX_DEV void inverse_accumulate(cplx (&o)[8], uint64_t (&acc_re)[8], uint64_t (&acc_im)[8], Ctx c,
+                               const Resident3 *res = nullptr) {
   HX_OPAQUE(c.lane);
   const int lane = c.lane, hi3 = lane >> 3, lo3 = lane & 7;
   const cplx *T = c.T;
@@ -166,8 +237,18 @@ HX_DEV void inverse_accumulate(cplx (&o)[8], uint64_t (&acc_re)[8], uint64_t (&a
     bfly_plain(o[4], o[6]);
     bfly_mi(o[5], o[7]);
     HX_SCHED_FENCE();
+#if W3_UNIFORM_LITERALS
+    {  // half = 4: twiddles 1, e^{-i pi/4}, -i, -i e^{-i pi/4}
+      const cplx a1{W3_LIT_I5[0], W3_LIT_I5[1]};
+      bfly_one_fma(o[0], o[4]);
+      bfly(o[1], o[5], a1);
+      bfly_mi_fma(o[2], o[6]);
+      bfly(o[3], o[7], cplx{a1.im, -a1.re});
+    }
+#else
     const cplx w4[4] = {T[T_INV + 4], T[T_INV + 5], T[T_INV + 6], T[T_INV + 7]};
     stage8<2>(o, [&](int r) { return w4[r & 3]; });
+#endif
     HX_SCHED_FENCE();
     cplx *pc = c.buf + lane * 9;  // LC slots of P2
     HX_UNROLL
@@ -179,13 +260,15 @@ HX_DEV void inverse_accumulate(cplx (&o)[8], uint64_t (&acc_re)[8], uint64_t (&a
     HX_UNROLL
     for (int r = 0; r < 8; ++r) o[r] = pb2[9 * r];
     HX_WAVE_SYNC();
-    const cplx w8 = T[T_INV + 8 + lo3];
+    const cplx w8 = RES >= 2 ? res->i8 : T[T_INV + 8 + lo3];
     stage8<0>(o, [&](int) { return w8; });
     HX_SCHED_FENCE();
-    const cplx w16[2] = {T[T_INV + 16 + lo3], T[T_INV + 24 + lo3]};
+    const cplx w16[2] = {RES >= 2 ? res->i16[0] : T[T_INV + 16 + lo3], RES >= 2 ? res->i16[1] : T[T_INV + 24 + lo3]};
     stage8<1>(o, [&](int r) { return w16[r & 1]; });
     HX_SCHED_FENCE();
-    const cplx w32[4] = {T[T_INV + 32 + lo3], T[T_INV + 40 + lo3], T[T_INV + 48 + lo3], T[T_INV + 56 + lo3]};
+    cplx w32[4];
+    HX_UNROLL
+    for (int q = 0; q < 4; ++q) w32[q] = RES >= 2 ? res->i32[q] : T[T_INV + 32 + 8 * q + lo3];
     stage8<2>(o, [&](int r) { return w32[r & 3]; });
     HX_SCHED_FENCE();
     cplx *pb = c.buf + hi3 * 72 + lo3;  // LB slots of P1
@@ -371,6 +454,8 @@ __global__ void __launch_bounds__(MAX_WAVES * 64) pbs_fft_wave3_kernel(PbsArgs a
   };
 
   stage_acc();
+  Resident3 res3;
+  load_resident3<W3_RESIDENT>(res3, T, lane);
   uint32_t epoch = 0;
   uint64_t mask_next = lwe[0];
   for (uint32_t i = 0; i < a.n; ++i) {
@@ -386,7 +471,7 @@ __global__ void __launch_bounds__(MAX_WAVES * 64) pbs_fft_wave3_kernel(PbsArgs a
       W3_PRIO(0);
       make_digits(d, a_hat, idx);
       W3_PRIO(1);
-      forward(d, ctx0);
+      forward<W3_RESIDENT>(d, ctx0, &res3);
       W3_PRIO(2);
       // my transform is published: tell the others, wait for theirs
       if (lane == 0) flag_set(ready + w, epoch);
@@ -423,7 +508,7 @@ __global__ void __launch_bounds__(MAX_WAVES * 64) pbs_fft_wave3_kernel(PbsArgs a
         if (q != w) flag_wait(done + q, epoch);  // nobody reads my buffer any more: it may be reused
     }
     W3_PRIO(3);
-    inverse_accumulate<true>(o, acc_re, acc_im, ctx0);
+    inverse_accumulate<true, W3_RESIDENT>(o, acc_re, acc_im, ctx0, &res3);
   }
 
   // ---- sample extraction (cc/algorithms/glwe_sample_extraction.rs:119-146); many-LUT outputs
@@ -451,6 +536,15 @@ __global__ void __launch_bounds__(MAX_WAVES * 64) pbs_fft_wave3_kernel(PbsArgs a
 }
 
 }  // namespace wave3k
+
+// host side of W3_UNIFORM_LITERALS: the literals are the table entries they stand for (tables.hip checks when it builds
+// the N = 1024 tables)
+bool wave3_literal_twiddles_match(const double *fwd, const double *inv) {
+  for (int x = 0; x < 7; ++x)
+    if (fwd[2 * (1 + x)] != wave3k::W3_LIT_F[x][0] || fwd[2 * (1 + x) + 1] != wave3k::W3_LIT_F[x][1]) return false;
+  return inv[2 * 4] == 1.0 && inv[2 * 4 + 1] == 0.0 && inv[2 * 5] == wave3k::W3_LIT_I5[0] && inv[2 * 5 + 1] == wave3k::W3_LIT_I5[1] &&
+         inv[2 * 6] == 0.0 && inv[2 * 6 + 1] == -1.0 && inv[2 * 7] == wave3k::W3_LIT_I5[1] && inv[2 * 7 + 1] == -wave3k::W3_LIT_I5[0];
+}
 
 bool pbs_fft_wave3_supported(uint32_t N, uint32_t glwe_dim, uint32_t level) {
   return N == 1024 && (glwe_dim == 1 || glwe_dim == 2) && level >= 1 && level <= 4;

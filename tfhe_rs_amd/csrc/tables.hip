@@ -236,6 +236,7 @@ RefTables get_ref_tables(uint32_t gpu_index, hipStream_t stream, uint32_t N) {
 
 // pbs_fft_wave.hip: the twiddles that kernel carries as literals of its instruction stream
 bool wave_literal_twiddles_match(const double *fwd, const double *inv);
+bool wave3_literal_twiddles_match(const double *fwd, const double *inv);  // pbs_fft_wave3.hip, N = 1024
 
 FftTables get_fft_tables(uint32_t gpu_index, hipStream_t stream, uint32_t N, bool with_mono_lane) {
   std::lock_guard<std::mutex> lk(g_mu);
@@ -248,6 +249,9 @@ FftTables get_fft_tables(uint32_t gpu_index, hipStream_t stream, uint32_t N, boo
     if (N == 2048)
       HX_PANIC_IF_FALSE(wave_literal_twiddles_match(fwd.data(), inv.data()),
                         "the literal twiddles of the N = 2048 throughput kernel differ from the host tables");
+    if (N == 1024)
+      HX_PANIC_IF_FALSE(wave3_literal_twiddles_match(fwd.data(), inv.data()),
+                        "the literal twiddles of the N = 1024 throughput kernel differ from the host tables");
     FftEntry e;
     HX_CHECK(hipSetDevice((int)gpu_index));
     HX_CHECK(hipMalloc((void **)&e.fwd, sizeof(double) * N));
