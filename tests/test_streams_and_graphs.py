@@ -151,6 +151,54 @@ def test_a_launch_is_captured_into_a_hip_graph_and_replayed(name, p, B, with_ksk
         job.close()
 
 
+def test_a_captured_keyswitch_keeps_its_operand_scratch_when_later_launches_grow_theirs():
+    """The large-batch keyswitch (digit pass + GEMM) writes its operands into a scratch of the (device, stream) — the
+    reference's keyswitch entry points carry none.  A launch recorded under stream capture bakes that pointer into the
+    graph, so it must never be freed or handed to live launches afterwards: the captured launch takes the
+    stream's buffer over, a later LARGER live keyswitch on the same stream allocates its own, and replaying the graph
+    still reads and writes valid memory and yields the bytes of the direct call."""
+    from tfhe_rs_amd import core_crypto_gpu as gpu
+    lib = use_backend("hip")
+    p = TOY_2048
+    keys = make_keys(p, with_ksk=True)
+    st = gpu.CudaStreams.new_single_gpu(0)
+    s = st.ptr[0]
+    ksk = gpu.CudaLweKeyswitchKey.from_lwe_keyswitch_key(keys.ksk, p.k * p.N, p.n, p.ks_base_log, p.ks_level, st)
+    lib.hip_backend_set_keyswitch_kernel(3)   # digit pass + GEMM from 129 LWEs on (the automatic choice starts at 769)
+    hip = Hip()
+    try:
+        def make(B, seed):
+            cts = encrypt_big(p, keys, [(seed + m) % p.plaintext_modulus for m in range(B)], seed=seed)
+            d_in = gpu.CudaLweCiphertextList.from_lwe_ciphertext_list(cts, st)
+            d_out = gpu.CudaLweCiphertextList.new(p.n, B, st)
+            idx = gpu.CudaVec.from_cpu_async(np.arange(B, dtype=np.uint64), st)
+            run = lambda: lib.cuda_keyswitch_lwe_ciphertext_vector_64_64_async(  # noqa: E731
+                s, 0, d_out.d_vec.ptr, idx.ptr, d_in.d_vec.ptr, idx.ptr, ksk.d_vec.ptr, p.k * p.N, p.n, p.ks_base_log,
+                p.ks_level, B)
+            return cts, d_in, d_out, idx, run
+        cts_a, in_a, out_a, idx_a, run_a = make(160, 5)
+        run_a()                                   # warms the key layout and creates the stream's live scratch
+        st.synchronize()
+        assert lib.hip_backend_last_keyswitch_path() == 2
+        direct = out_a.to_lwe_ciphertext_list(st)
+        assert np.array_equal(direct, orc.keyswitch_batch(cts_a, keys.ksk, p.k * p.N, p.n, p.ks_base_log, p.ks_level))
+        graph, exe = hip.capture(s, run_a)        # the captured launch now owns that scratch
+        cts_b, in_b, out_b, idx_b, run_b = make(420, 6)
+        run_b()                                   # a larger live launch: must not free or reuse the graph's buffer
+        st.synchronize()
+        assert np.array_equal(out_b.to_lwe_ciphertext_list(st),
+                              orc.keyswitch_batch(cts_b, keys.ksk, p.k * p.N, p.n, p.ks_base_log, p.ks_level))
+        for _ in range(2):
+            lib.cuda_memset_async(out_a.d_vec.ptr, 0, 160 * (p.n + 1) * 8, s, 0)
+            run_b()                               # live traffic on the stream between the replays
+            hip.launch(exe, s)
+            st.synchronize()
+            assert np.array_equal(out_a.to_lwe_ciphertext_list(st), direct)
+        hip.destroy(graph, exe)
+    finally:
+        lib.hip_backend_set_keyswitch_kernel(0)
+
+
 def test_concurrent_host_threads_on_their_own_streams_share_the_keys():
     """Six host threads, one stream and one scratch each, three parameter sets (classic both kernels, multi-bit
     both paths) over shared device keys, all launching at once, ten rounds: every round of every thread gives the
