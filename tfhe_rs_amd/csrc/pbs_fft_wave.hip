@@ -149,6 +149,13 @@
 #ifndef WAVE_LIT_LIMBS
 #define WAVE_LIT_LIMBS 0
 #endif
+#ifndef WAVE_ROT_PAIRS
+// 1: the rotation fetches the staged words of two consecutive register rows (r, r + 1: 512 bytes apart) with ONE
+// two-address LDS read off one computed address; the second address may run 512 bytes past the 16 KiB ring, where the
+// staging keeps a copy of the ring's first 512 bytes (the exchange buffer has 1,008 spare bytes behind the ring).
+// 16 LDS instructions and 16 address computations fewer per CMUX.  0: one read and one address per word.
+#define WAVE_ROT_PAIRS 1
+#endif
 #ifndef WAVE_RESIDENT
 #define WAVE_RESIDENT 2  // classic one-level loop: twiddles kept in registers across the iterations (ResidentTwiddles: 0..2)
 #endif
@@ -551,6 +558,9 @@ HX_DEV void wave_inverse_accumulate(cplx (&o)[16], uint64_t (&acc_re)[16], uint6
       // conversion arithmetic instead of in front of the next rotation
       stg[lane_u + r * 64] = acc_re[r];
       stg[lane_u + 1024 + r * 64] = acc_im[r];
+#if WAVE_ROT_PAIRS
+      if (r == 0) stg[lane_u + 2048] = acc_re[0];  // the ring's first 64 words again behind its end (make_digits)
+#endif
     }
     if ((r & 3) == 3) HX_SCHED_FENCE();
   }
@@ -731,6 +741,9 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
       p[r * 64] = acc_re[r];
       p[1024 + r * 64] = acc_im[r];
     }
+#if WAVE_ROT_PAIRS
+    p[2048] = acc_re[0];  // the ring's first 64 words again behind its end (make_digits)
+#endif
     HX_WAVE_SYNC();
   };
   // EXACT selects the decomposer's own bit sequence; the default for one level is the two-instruction
@@ -755,6 +768,9 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
     HX_LAUNDER(vzero);  // the staged copy's base in a vector register: a scalar operand doubles the cost of the add
 #endif
     const char *staged = (const char *)buf64 + vzero;
+    uint64_t sp0[2] = {0, 0}, sp1[2] = {0, 0};
+    (void)sp0;
+    (void)sp1;
     HX_UNROLL
     for (int r = 0; r < 16; ++r) {
       uint64_t x0, x1;
@@ -765,8 +781,19 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
         const int32_t u0 = (int32_t)((uint32_t)ub + r * 512u), u1 = (int32_t)((uint32_t)u0 + 8192u);
         const uint32_t m0 = (uint32_t)(u0 >> 31), m1 = (uint32_t)(u1 >> 31);  // all-ones: sign +
         const uint64_t M0 = ((uint64_t)m0 << 32) | m0, M1 = ((uint64_t)m1 << 32) | m1;
+#if WAVE_ROT_PAIRS
+        if ((r & 1) == 0) {  // rows r and r + 1 of both halves: the second word sits 512 bytes behind the first
+          const uint64_t *q0 = (const uint64_t *)(staged + (u0 & 0x3ff8)), *q1 = (const uint64_t *)(staged + (u1 & 0x3ff8));
+          sp0[0] = q0[0];
+          sp0[1] = q0[64];
+          sp1[0] = q1[0];
+          sp1[1] = q1[64];
+        }
+        const uint64_t s0 = sp0[r & 1], s1 = sp1[r & 1];
+#else
         const uint64_t s0 = *(const uint64_t *)(staged + (u0 & 0x3ff8));
         const uint64_t s1 = *(const uint64_t *)(staged + (u1 & 0x3ff8));
+#endif
         uint64_t a0 = acc_re[r], a1 = acc_im[r];
         if constexpr (LIMBS > 0) {  // the accumulator is not in registers here: my own coefficients from the staged copy
           a0 = *(const uint64_t *)(staged + (lane + r * 64) * 8);
