@@ -124,6 +124,12 @@ struct Ctx {
   int lane;
 };
 
+#ifndef W3_ROT_PAIRS
+// 1: the rotation fetches the staged words of two consecutive register rows (512 bytes apart) with one two-address
+// LDS read; the ring's first 512 bytes are staged a second time behind its end (the buffer has 1,024 spare bytes), as in
+// the N = 2048 kernel (pbs_fft_wave.hip, WAVE_ROT_PAIRS)
+#define W3_ROT_PAIRS 1
+#endif
 #ifndef W3_RESIDENT
 // twiddles kept in registers for the whole launch (read once in front of the CMUX loop), as in the N = 2048 kernel:
 // 1 = forward stages 3..5 (seven values that depend on lane >> 3), 2 = also inverse half = 8, 16, 32 (seven on lane & 7)
@@ -304,6 +310,9 @@ HX_DEV void inverse_accumulate(cplx (&o)[8], uint64_t (&acc_re)[8], uint64_t (&a
     from_torus_add(acc_im[r], ti, kt);
     stg[r * 64] = acc_re[r];
     stg[512 + r * 64] = acc_im[r];
+#if W3_ROT_PAIRS
+    if (r == 0) stg[1024] = acc_re[0];  // the ring's first 64 words again behind its end
+#endif
     if (r & 1) HX_SCHED_FENCE();
   }
   HX_WAVE_SYNC();
@@ -399,6 +408,9 @@ __global__ void __launch_bounds__(MAX_WAVES * 64) pbs_fft_wave3_kernel(PbsArgs a
       p[r * 64] = acc_re[r];
       p[512 + r * 64] = acc_im[r];
     }
+#if W3_ROT_PAIRS
+    p[1024] = acc_re[0];  // the ring's first 64 words again behind its end
+#endif
     HX_WAVE_SYNC();
   };
 
@@ -416,13 +428,27 @@ __global__ void __launch_bounds__(MAX_WAVES * 64) pbs_fft_wave3_kernel(PbsArgs a
     HX_LAUNDER(vzero);  // base of the staged copy in a vector register (a scalar operand doubles the add's cost)
 #endif
     const char *staged = (const char *)buf64 + vzero;
+    uint64_t sp0[2] = {0, 0}, sp1[2] = {0, 0};
+    (void)sp0;
+    (void)sp1;
     HX_UNROLL
     for (int r = 0; r < 8; ++r) {
       const int32_t u0 = (int32_t)(ub + r * 512u), u1 = (int32_t)(ub + r * 512u + 4096u);
       const uint32_t m0 = (uint32_t)(u0 >> 31), m1 = (uint32_t)(u1 >> 31);
       const uint64_t M0 = ((uint64_t)m0 << 32) | m0, M1 = ((uint64_t)m1 << 32) | m1;
+#if W3_ROT_PAIRS
+      if ((r & 1) == 0) {  // rows r and r + 1 of both halves: the second word sits 512 bytes behind the first
+        const uint64_t *q0 = (const uint64_t *)(staged + (u0 & 0x1ff8)), *q1 = (const uint64_t *)(staged + (u1 & 0x1ff8));
+        sp0[0] = q0[0];
+        sp0[1] = q0[64];
+        sp1[0] = q1[0];
+        sp1[1] = q1[64];
+      }
+      const uint64_t s0 = sp0[r & 1], s1 = sp1[r & 1];
+#else
       const uint64_t s0 = *(const uint64_t *)(staged + (u0 & 0x1ff8));
       const uint64_t s1 = *(const uint64_t *)(staged + (u1 & 0x1ff8));
+#endif
       const uint64_t x0 = ((acc_re[r] ^ M0) + s0) ^ M0, x1 = ((acc_im[r] ^ M1) + s1) ^ M1;
       if constexpr (L1) {
         if constexpr (EXACT) {
