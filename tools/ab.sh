@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU box: A/B of variant libraries on chosen measure_all selectors, interleaved rounds
-# usage: bash tools/r04_ab.sh "<selectors>" "<variants>" [rounds]   -> gpurun_out/r04_ab.txt
-out=gpurun_out/r04_ab.txt; mkdir -p gpurun_out; : > $out
+# usage: bash tools/ab.sh "<selectors>" "<variants>" [rounds]   -> gpurun_out/ab.txt
+out=gpurun_out/ab.txt; mkdir -p gpurun_out; : > $out
 sel=$1; vs=$2; rounds=${3:-2}
 for r in $(seq 1 $rounds); do
   for v in default $vs; do

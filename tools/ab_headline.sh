@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU box: A/B of the round-2 binary and of the tuning variants of the headline kernel (same box, interleaved rounds)
-# usage: bash tools/r04_variants.sh "<wave variants>" "<split variants>"   -> gpurun_out/r04_variants.txt
-out=gpurun_out/r04_variants.txt; mkdir -p gpurun_out; : > $out
+# usage: bash tools/ab_headline.sh "<wave variants>" "<split variants>"   -> gpurun_out/ab_headline.txt
+out=gpurun_out/ab_headline.txt; mkdir -p gpurun_out; : > $out
 wv=${1:-"lit own fuse litfuse all3"}; sv=${2:-"regacc"}
 ms() { grep '"batch": 4096' | sed -e 's/.*"ms": \([0-9.]*\).*pbs_per_s": \([0-9.]*\).*/ms \1 pbs \2/'; }
 echo "== parity of the variants (full-size 2_2 bit-exact test + decomposer boundaries)" | tee -a $out
