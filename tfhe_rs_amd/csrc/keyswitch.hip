@@ -459,7 +459,9 @@ __global__ void ks_zero_outputs_kernel(OutT *lwe_out, const uint64_t *out_idx, u
 //     GEMM, laid out as the matrix instruction wants them — [tile][step][lane][16 bytes], lane = (k half, row),
 //     byte j <-> k = step*32 + half*16 + j — plus the per-sample sum of the shifted digits (the shift correction);
 //   * ks_gemm_kernel: 4 waves x 32 samples against one column tile; per step of 32 k the workgroup stages the 8 KB
-//     of B (8 byte planes x 32 columns x 32 k) in LDS ONCE (double buffered, one barrier per step), every wave
+//     of B (8 byte planes x 32 columns x 32 k) in LDS ONCE (double buffered; round 4: two steps — four with u32 keys —
+//     per workgroup barrier, which pays the barrier, the drain of the global -> LDS loads in front of it and the LDS
+//     round trip behind it once per 16 matrix instructions: 0.373 -> 0.307 ms per 4096 on one box), every wave
 //     reads its operands from there and its A operand as one coalesced 16-byte load: no vector arithmetic in the
 //     loop, L1 traffic a quarter.  Same integer sums as ks_mfma_kernel: identical bits.
 // below: ks_mfma_kernel (one launch; K shared by the waves of a workgroup up to 32 LWEs and by up to 8 workgroups per
@@ -539,7 +541,30 @@ __global__ void __launch_bounds__(256) ks_digits_kernel(int8_t *aplanes, int32_t
   }
 }
 
-template <typename OutT>
+// steps of 32 k between two workgroup barriers of ks_gemm_kernel, by key word size: measured per 4096 LWEs on one box,
+// u64 keys 0.373 / 0.307 / 0.325 ms with 1 / 2 / 4 (4 fills the 64 KB of static LDS), u32 keys 0.279 / 0.216 / 0.203 ms
+#ifndef KSG_STEPS_PER_BARRIER_U64
+#define KSG_STEPS_PER_BARRIER_U64 2
+#endif
+#ifndef KSG_STEPS_PER_BARRIER_U32
+#define KSG_STEPS_PER_BARRIER_U32 4
+#endif
+template <typename OutT, int SPB>
+__global__ void ks_gemm_kernel(OutT *lwe_out, const uint64_t *out_idx, const uint64_t *lwe_in, const uint64_t *in_idx,
+                               const int8_t *planes, const uint64_t *colsum, const int8_t *aplanes, const int32_t *suma,
+                               uint32_t n_in, uint32_t n_out, uint32_t base_log, uint32_t num_samples, uint32_t col_tiles,
+                               uint32_t steps, const OutT *ksk_raw, size_t ksk_words);
+// the widest supported step count per barrier that divides `steps`
+template <typename OutT, typename... Args>
+static void launch_ks_gemm(dim3 grid, hipStream_t st, uint32_t steps, Args... args) {
+  constexpr int WANT = sizeof(OutT) == 8 ? KSG_STEPS_PER_BARRIER_U64 : KSG_STEPS_PER_BARRIER_U32;
+  if (WANT >= 4 && steps % 4 == 0) HX_LAUNCH((ks_gemm_kernel<OutT, 4>), grid, dim3(256), 0, st, args...);
+  else if (WANT >= 2 && steps % 2 == 0) HX_LAUNCH((ks_gemm_kernel<OutT, 2>), grid, dim3(256), 0, st, args...);
+  else HX_LAUNCH((ks_gemm_kernel<OutT, 1>), grid, dim3(256), 0, st, args...);
+}
+// SPB = steps of 32 k per workgroup barrier: with 2 the barrier, the drain of the global -> LDS loads in front of it and
+// the LDS round trip behind it are paid once per 16 matrix instructions instead of once per 8 (32 KB of LDS for u64 keys)
+template <typename OutT, int SPB>
 __global__ void __launch_bounds__(256, 2) ks_gemm_kernel(OutT *lwe_out, const uint64_t *out_idx, const uint64_t *lwe_in,
                                                       const uint64_t *in_idx, const int8_t *planes,
                                                       const uint64_t *colsum, const int8_t *aplanes,
@@ -549,7 +574,7 @@ __global__ void __launch_bounds__(256, 2) ks_gemm_kernel(OutT *lwe_out, const ui
   constexpr int PLANES = (int)sizeof(OutT);
   constexpr int HALF_BYTES = PLANES * KSM_CT * 16;  // one k half of a step: [plane][column][16 bytes]
   constexpr int CHUNKS = 2 * HALF_BYTES / 16 / 256; // 16-byte chunks of B per thread and step (2 for u64 keys, 1 for u32)
-  __shared__ alignas(16) int8_t bs[2][2][HALF_BYTES];
+  __shared__ alignas(16) int8_t bs[2][SPB][2][HALF_BYTES];
   if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < KSM_FP) {  // the planes must still be this key's
     const uint64_t *fp = colsum + (size_t)col_tiles * KSM_CT;
     if ((uint64_t)ksk_raw[ksm_fp_index((int)threadIdx.x, ksk_words)] != fp[threadIdx.x]) __builtin_trap();
@@ -571,50 +596,62 @@ __global__ void __launch_bounds__(256, 2) ks_gemm_kernel(OutT *lwe_out, const ui
     const int c = tid + q * 256, half = c / (HALF_BYTES / 16), off = (c % (HALF_BYTES / 16)) * 16;
     bsrc[q] = planes + ((size_t)half * col_tiles + ct) * HALF_BYTES + off;  // + st * 2 * col_tiles * HALF_BYTES per step
     const int c0 = wave * 64 + q * 256, half0 = c0 / (HALF_BYTES / 16), off0 = (c0 % (HALF_BYTES / 16)) * 16;
-    bdst[q] = &bs[0][half0][off0];
+    bdst[q] = &bs[0][0][half0][off0];
   }
   const size_t bstep = (size_t)2 * col_tiles * HALF_BYTES;
   const hx_i8x16 *ap = (const hx_i8x16 *)(aplanes + ((size_t)(live ? stile : 0) * steps) * 1024) + lane;
-  auto stage_b = [&](uint32_t st, int buf) {
+  // macro step ms = steps ms * SPB .. ms * SPB + SPB - 1
+  auto stage_b = [&](uint32_t ms, int buf) {
     HX_UNROLL
-    for (int q = 0; q < CHUNKS; ++q)
-      HX_GLOBAL_TO_LDS16(bsrc[q] + (size_t)st * bstep, bdst[q] + buf * (2 * HALF_BYTES), lane);
+    for (int u = 0; u < SPB; ++u)
+      HX_UNROLL
+      for (int q = 0; q < CHUNKS; ++q)
+        HX_GLOBAL_TO_LDS16(bsrc[q] + (size_t)(ms * SPB + u) * bstep, bdst[q] + (buf * SPB + u) * (2 * HALF_BYTES), lane);
   };
-  // Software pipeline: at the top of step st the B image of step st + 1 is requested into the other LDS buffer and
-  // the A operand of step st + 1 into registers; both land under the 8 matrix instructions of step st.  Branch-free
-  // (a conditional around the matrix instructions makes the compiler shuttle the 128 accumulator registers between
-  // the register files every step): the last step re-requests its own operands, waves past the batch multiply the
-  // first tile's digits and store nothing.
-  const uint32_t last = steps - 1;
-  hx_i8x16 av, a1;
+  // Software pipeline: at the top of a macro step the B images of the next one are requested into the other LDS buffer
+  // and its A operands into registers; both land under the matrix instructions of this one.  Branch-free (a conditional
+  // around the matrix instructions makes the compiler shuttle the 128 accumulator registers between the register files
+  // every step): the last macro step re-requests its own operands, waves past the batch multiply the first tile's digits
+  // and store nothing.
+  const uint32_t msteps = steps / SPB, last = msteps - 1;
+  hx_i8x16 av[SPB], a1[SPB];
   stage_b(0, 0);
-  av = ap[0];
+  HX_UNROLL
+  for (int u = 0; u < SPB; ++u) av[u] = ap[(size_t)u * 64];
   __syncthreads();
-  for (uint32_t st = 0; st < steps; ++st) {
-    const int cur = (int)(st & 1);
-    const uint32_t nx = st + 1 < steps ? st + 1 : last;
-    // this step's operands out of LDS first: the compiler drains every outstanding global -> LDS load before an LDS
-    // read, so the requests for the next step go out behind the reads and land under the matrix instructions
-    hx_i8x16 bv[PLANES];
+  for (uint32_t ms = 0; ms < msteps; ++ms) {
+    const int cur = (int)(ms & 1);
+    const uint32_t nx = ms + 1 < msteps ? ms + 1 : last;
     HX_UNROLL
-    for (int p = 0; p < PLANES; ++p) bv[p] = *(const hx_i8x16 *)&bs[cur][h][p * (KSM_CT * 16) + row * 16];
-    HX_SCHED_FENCE();
+    for (int u = 0; u < SPB; ++u) {
+      // this step's operands out of LDS first: the compiler drains every outstanding global -> LDS load before an LDS
+      // read, so the requests for the next macro step go out behind the FIRST step's reads and land under the matrix
+      // instructions
+      hx_i8x16 bv[PLANES];
+      HX_UNROLL
+      for (int p = 0; p < PLANES; ++p) bv[p] = *(const hx_i8x16 *)&bs[cur][u][h][p * (KSM_CT * 16) + row * 16];
+      HX_SCHED_FENCE();
+      if (u == SPB - 1) {
 #ifndef KSG_SKIP_B  // (timing experiments: wrong results)
-    stage_b(nx, cur ^ 1);
+        stage_b(nx, cur ^ 1);
 #endif
 #ifndef KSG_SKIP_A
-    a1 = ap[(size_t)nx * 64];
+        HX_UNROLL
+        for (int v = 0; v < SPB; ++v) a1[v] = ap[((size_t)nx * SPB + v) * 64];
 #endif
-    HX_SCHED_FENCE();
+      }
+      HX_SCHED_FENCE();
 #ifndef KSG_SKIP_MFMA
-    HX_UNROLL
-    for (int p = 0; p < PLANES; ++p) acc[p] = hx_mfma_i32_32x32x32_i8(av, bv[p], acc[p]);
+      HX_UNROLL
+      for (int p = 0; p < PLANES; ++p) acc[p] = hx_mfma_i32_32x32x32_i8(av[u], bv[p], acc[p]);
 #else
-    HX_UNROLL
-    for (int p = 0; p < PLANES; ++p) acc[p].v[0] += bv[p].w[0] ^ av.w[0];
+      HX_UNROLL
+      for (int p = 0; p < PLANES; ++p) acc[p].v[0] += bv[p].w[0] ^ av[u].w[0];
 #endif
-    HX_SCHED_FENCE();
-    av = a1;
+      HX_SCHED_FENCE();
+    }
+    HX_UNROLL
+    for (int u = 0; u < SPB; ++u) av[u] = a1[u];
     __syncthreads();
   }
   if (!live) return;
@@ -861,9 +898,9 @@ static bool keyswitch_mfma(hipStream_t st, OutT *lwe_out, const uint64_t *out_id
     HX_PANIC_IF_FALSE(ready->steps == K / 32 && ready->base_log == base_log && ready->level == level,
                       "keyswitch: the digits at hand were made for another decomposition");
     const uint32_t tiles = (num_samples + 31) / 32;
-    HX_LAUNCH((ks_gemm_kernel<OutT>), dim3(col_tiles, (tiles + 3) / 4), dim3(256), 0, st, lwe_out, out_idx, lwe_in,
-              in_idx, planes, colsum, ready->aplanes, ready->suma, n_in, n_out, base_log, num_samples, col_tiles, K / 32,
-              ksk, ksk_words);
+    launch_ks_gemm<OutT>(dim3(col_tiles, (tiles + 3) / 4), st, K / 32, lwe_out, out_idx, lwe_in, in_idx, (const int8_t *)planes,
+                         (const uint64_t *)colsum, (const int8_t *)ready->aplanes, (const int32_t *)ready->suma, n_in, n_out,
+                         base_log, num_samples, col_tiles, K / 32, ksk, ksk_words);
     g_last_keyswitch_path.store(3);
     return true;
   }
@@ -892,8 +929,9 @@ static bool keyswitch_mfma(hipStream_t st, OutT *lwe_out, const uint64_t *out_id
         default: KSD_LAUNCH(16); break;
       }
 #undef KSD_LAUNCH
-      HX_LAUNCH((ks_gemm_kernel<OutT>), dim3(col_tiles, (tiles + 3) / 4), dim3(256), 0, st, lwe_out, out_idx, lwe_in,
-                in_idx, planes, colsum, scr, suma, n_in, n_out, base_log, num_samples, col_tiles, steps, ksk, ksk_words);
+      launch_ks_gemm<OutT>(dim3(col_tiles, (tiles + 3) / 4), st, steps, lwe_out, out_idx, lwe_in, in_idx, (const int8_t *)planes,
+                           (const uint64_t *)colsum, (const int8_t *)scr, (const int32_t *)suma, n_in, n_out, base_log,
+                           num_samples, col_tiles, steps, ksk, ksk_words);
       g_last_keyswitch_path.store(2);
       return true;
     }
