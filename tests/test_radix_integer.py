@@ -242,6 +242,32 @@ def test_radix_rounds_sharded_over_the_streams_of_the_set(kind):
     assert recompose(decrypt_blocks(p, keys, outs["three"][1])) == [(x * y) & mask for x, y in zip(a, b)]
 
 
+@pytest.mark.parametrize("kind", BACKENDS)
+def test_one_operation_spreads_over_the_gpus_by_the_reference_thresholds(kind):
+    """No setter: the library's DEFAULT is the reference's rule (12 blocks per GPU with a multi-bit key), so ONE 32-block
+    addition on a stream set of three spreads its rounds of 32 / 20 / ... blocks over 3 / 2 / 1 GPUs — what makes the
+    reference's published single-operation latencies on 8 GPUs.  Three streams of GPU 0 on the GPU tier, three streams of
+    the one pretend device on the CPU tier; same bits as the single-stream run."""
+    from .common import TOY_MB4_2048
+    p, keys, st1, sks1, igpu = setup(kind, TOY_MB4_2048)
+    _, _, st3, sks3, _ = setup(kind, TOY_MB4_2048, gpu_indexes=(0, 0, 0))
+    lib = use_backend(kind)
+    lib.hip_integer_set_multi_gpu_threshold(0)
+    assert [lib.hip_integer_active_gpu_count(b, 3, 0, 0) for b in (32, 20, 7, 3)] == [3, 2, 1, 1]
+    L = 32
+    mask = (1 << (2 * L)) - 1
+    a, b = [0x9E3779B97F4A7C15 & mask, mask], [0x0123456789ABCDEF & mask, 1]
+    blocks_a, blocks_b = encrypt_radix(p, keys, a, L, 71), encrypt_radix(p, keys, b, L, 72)
+    outs = {}
+    for name, st, sks in (("one", st1, sks1), ("three", st3, sks3)):
+        ca = igpu.CudaUnsignedRadixCiphertext.from_blocks(blocks_a, st)
+        cb = igpu.CudaUnsignedRadixCiphertext.from_blocks(blocks_b, st)
+        sks.add_assign(ca, cb, st)
+        outs[name] = ca.to_blocks(st)
+    assert np.array_equal(outs["one"], outs["three"])
+    assert recompose(decrypt_blocks(p, keys, outs["three"])) == [(x + y) & mask for x, y in zip(a, b)]
+
+
 def test_radix_rounds_on_distinct_devices_record_events_on_their_own_streams(monkeypatch):
     """The same sharded rounds with the stream set naming three DIFFERENT devices.  The CPU tier's runtime stand-in
     models devices (HIPEMU_DEVICES): a stream and an event belong to the device current at their creation and
