@@ -431,7 +431,8 @@ uint64_t hip_integer_propagate_pbs_count(uint32_t num_blocks);
  * multi-bit mode of the throughput kernel, 1 the generic multi-bit kernel, 5 the two-launch latency path (all
  * keybundles first, one workgroup per polynomial; then the products, for N=2048,k=1 on the latency kernel) that 0
  * takes up to 128 LWEs (256 for N = 2048, k = 1), 6 the same path with the products on the generic kernels (comparison), 7 the throughput
- * kernel without the sharing of key loads between the two LWEs of a quad of waves (comparison). */
+ * kernel without the sharing of key loads between the two LWEs of a quad of waves, 8 the throughput kernel with
+ * sharing among quads only, not among all eight waves of a full workgroup of a one-level set (both: comparison). */
 void hip_backend_set_fft_kernel(uint32_t which);
 /* test hook: cap of the groups the multi-bit latency path processes per pass (0 = what the scratch holds) */
 void hip_backend_set_multibit_latency_groups(uint32_t groups);

@@ -793,7 +793,10 @@ def test_multi_bit_throughput_kernel_shared_key_loads(kind, which, B):
     throughput kernel share the key loads of their two LWEs (SHARE mode of pbs_fft_wave_kernel): a wave works on
     one output column at 8 of a lane's 16 points for BOTH LWEs and hands half of its results over through LDS.
     259 and 771 LWEs leave a ragged last workgroup (1 of 2, 3 of 4 LWEs present: the missing pairs redo the last
-    ciphertext and write nothing); 515 is in the range (513 .. 768) that would get 3 LWEs per workgroup and takes 4.  Same bits as the pair-per-LWE form (kernel choice 7) and as the oracle."""
+    ciphertext and write nothing); 515 is in the range (513 .. 768) that would get 3 LWEs per workgroup and takes 4.
+    With 4 LWEs per workgroup the one-level set goes further (OCTET mode): all eight waves share every key load, a
+    wave works on one column at 4 of a lane's 16 points for all FOUR LWEs.  Same bits as the quad form (kernel
+    choice 8), the pair-per-LWE form (choice 7) and the oracle."""
     from .common import TOY_MB_2048, TOY_MB4_2048
     p = TOY_MB_2048 if which == "g3_l2" else TOY_MB4_2048
     c = ctx(kind, p, "fft64")
@@ -809,11 +812,15 @@ def test_multi_bit_throughput_kernel_shared_key_loads(kind, which, B):
         lib.hip_backend_set_fft_kernel(7)
         pairs = c.pbs(cts, lut)
         assert lib.hip_backend_last_pbs_kernel() == 6
+        lib.hip_backend_set_fft_kernel(8)
+        quads = c.pbs(cts, lut)
+        assert lib.hip_backend_last_pbs_kernel() == 6
     finally:
         lib.hip_backend_set_fft_kernel(0)
     ref = oracle_pbs(p, c.keys, "fft64", cts, lut)
     assert np.array_equal(shared, ref)
     assert np.array_equal(pairs, ref)
+    assert np.array_equal(quads, ref)
     assert [decrypt_big(p, c.keys, o) for o in shared[-8:]] == [f(m) for m in msgs[-8:]]
 
 

@@ -757,8 +757,9 @@ void cuda_multi_bit_programmable_bootstrap_64_async(void *stream, uint32_t gpu_i
     gc = (gc == 0 || gc > fit_groups) ? fit_groups : gc;
     launch_pbs_multi_bit_latency(S(stream), polynomial_size, glwe_dimension, m, b->fft, b->kb_lat, gc, b->acc);
     g_last_pbs_kernel.store(10);
-  } else if ((choice == 0 && wave_ok) || choice == 2 || (choice == 7 && wave_ok)) {
+  } else if ((choice == 0 && wave_ok) || choice == 2 || ((choice == 7 || choice == 8) && wave_ok)) {
     m.pbs.mb_no_share = choice == 7;  // 7: every wave pair loads its own key (comparison)
+    m.pbs.mb_no_octet = choice == 8;  // 8: at most quads of waves share the key loads (comparison)
     m.pbs.grouping = grouping_factor;
     m.pbs.pace = b->pace;
     launch_pbs_multi_bit_wave(S(stream), m.pbs, b->fft);

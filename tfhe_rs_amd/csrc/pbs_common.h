@@ -49,6 +49,7 @@ struct PbsArgs {
   // host side only (kernel selection of THIS call; comparison choices of hip_backend_set_fft_kernel): carried in the
   // arguments, not in globals, so that concurrent host threads on different streams cannot change each other's kernel
   bool mb_no_share = false;          // choice 7: every wave pair loads its own key
+  bool mb_no_octet = false;          // choice 8: quads of waves share the key loads even where the whole workgroup could
   bool mb_generic_products = false;  // choice 6: latency path with the products on the generic kernels
 };
 

@@ -105,6 +105,12 @@
 // several (one box, g = 3 / g = 4 per 4096: 2 -> 48.8 / 29.8 ms, 3 -> 43.8 / 30.3, 4 -> 43.0 / 30.7, 5 -> 43.9 / 31.3)
 #define WAVE_MB_SHARE_SETS 0
 #endif
+#ifndef WAVE_MB_OCTET
+#define WAVE_MB_OCTET 1  // one-level sets, four LWEs per workgroup: the eight waves share every key load
+#endif
+#ifndef WAVE_MB_OCTET_SETS
+#define WAVE_MB_OCTET_SETS 3  // OCTET: register sets in rotation (a request = the 2 rows of one point and subset)
+#endif
 #ifndef WAVE_MB_SETS
 #define WAVE_MB_SETS 4  // multi-bit: register sets in rotation (SETS - 1 key requests in flight)
 #endif
@@ -597,10 +603,11 @@ HX_DEV void wave_inverse_accumulate(cplx (&o)[16], uint64_t (&acc_re)[16], uint6
 // between its two touches per CMUX (PbsArgs::acc_scratch, L2 / Infinity Cache resident): the registers carry the
 // Horner states (64), the digit transform (64: re-published to the pair's LDS buffer after every limb's inverse
 // transposition has used that buffer) and the product being transformed back (64).
-template <int LEVEL_CT, int BASE_LOG_CT, int GROUPING = 0, bool SHARE = false, int LIMBS = 0>
+template <int LEVEL_CT, int BASE_LOG_CT, int GROUPING = 0, bool SHARE = false, int LIMBS = 0, bool OCTET = false>
 __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables tb) {
   constexpr bool MULTIBIT = GROUPING > 0;
   static_assert(!SHARE || MULTIBIT, "SHARE is a mode of the multi-bit loop");
+  static_assert(!OCTET || (MULTIBIT && !SHARE && LEVEL_CT == 1), "OCTET is a mode of the one-level multi-bit loop");
   static_assert(LIMBS == 0 || (!MULTIBIT && LEVEL_CT == 1 && BASE_LOG_CT != 0 && BASE_LOG_CT <= 23),
                 "split-key exact engine: one level, base_log <= 23 (the products must stay below 2^49)");
   HX_DYN_SMEM(smem);
@@ -670,7 +677,7 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
   // the launch picks 1..4 LWEs per workgroup (blockDim.x = 128 per LWE): small batches spread over the CUs
   uint32_t sample = blockIdx.x * (blockDim.x >> 7) + pair;
   const bool valid = sample < a.num_samples;
-  if constexpr (SHARE) {
+  if constexpr (SHARE || OCTET) {
     // every wave of the workgroup works for its quad and meets the block barriers: the pairs past the end of a
     // ragged last workgroup redo the last ciphertext and write nothing
     if (!valid) sample = a.num_samples - 1;
@@ -980,6 +987,15 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
       lwe_q0 = a.lwe_in + (size_t)a.in_idx[s0 < last ? s0 : last] * (a.n + 1);
       lwe_q1 = a.lwe_in + (size_t)a.in_idx[s0 + 1 < last ? s0 + 1 : last] * (a.n + 1);
     }
+    const uint64_t *lwe4[OCTET ? 4 : 1];  // OCTET: the four LWEs of the workgroup
+    if constexpr (OCTET) {
+      const uint32_t s0 = blockIdx.x * 4u, last = a.num_samples - 1;
+      HX_UNROLL
+      for (uint32_t L = 0; L < 4; ++L)
+        lwe4[L] = a.lwe_in + (size_t)a.in_idx[s0 + L < last ? s0 + L : last] * (a.n + 1);
+    } else {
+      lwe4[0] = lwe;
+    }
     // SHARE synchronisation, all in the LDS flag words: word v = progress of wave v (quad_sync: each of the four
     // waves of a quad posts its count and waits for the other three), word 8 = mac_turn.  The multiply-accumulate
     // is what loads the key, the transforms are what computes: the two quads of a workgroup (one wave of each per
@@ -1045,7 +1061,9 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
       };
       uint32_t deg[per];
       uint32_t deg_b[SHARE ? per : 1];  // SHARE: deg / base belong to the quad's first LWE, these to its second
-      if constexpr (SHARE) {
+      if constexpr (OCTET) {
+        // per subset, inside the multiply-accumulate
+      } else if constexpr (SHARE) {
         degrees(lwe_q0, deg);
         degrees(lwe_q1, deg_b);
       } else {
@@ -1053,7 +1071,7 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
       }
       constexpr int MB_BASES = WAVE_MB_BASES >= 0 ? WAVE_MB_BASES : (LEVEL_CT >= 2 ? 1 : 0);
       cplx base[per], base_b[SHARE ? per : 1];  // (re)written per level unless MB_BASES == 0: not live across levels then
-      if constexpr (MB_BASES == 0) {
+      if constexpr (MB_BASES == 0 && !OCTET) {
         bases(deg, base);
         if constexpr (SHARE) bases(deg_b, base_b);
       }
@@ -1119,6 +1137,117 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
         HX_PRIO(WAVE_PRIO_MB_B);
         wave_forward<0, WAVE_LIT_MB != 0>(d, ctx);
         HX_PRIO(WAVE_PRIO_MB_C);
+        if constexpr (OCTET) {
+          // All eight waves of the workgroup share every key load: wave (q, w) = (pair, column) combines, for ALL
+          // FOUR LWEs, the keybundle of column w at the quarter 4q .. 4q+3 of a lane's 16 points.  Subset-major:
+          // the four keybundle quarters (4 LWEs x 4 points x 2 rows) stay in registers across the 2^g subsets,
+          // and only the current subset's four monomial bases (and the next one's, in flight) are live.
+          WaveCtx cx = ctx0;
+          HX_OPAQUE(cx.lane);
+          const int ln = cx.lane;
+          const uint32_t lane_off = (uint32_t)ln * 16u;
+          const uint32_t q4 = (uint32_t)pair;
+          const uint32_t brq = ((q4 & 1u) << 1) | (q4 >> 1);  // bitrev4(4 q + j) = 4 bitrev2(j) + bitrev2(q)
+          const uint32_t row0_off = (((idx * 2 + 0) * 2 + (uint32_t)w) * n) * 16u + q4 * 4096u;
+          const uint32_t row1_off = (((idx * 2 + 1) * 2 + (uint32_t)w) * n) * 16u + q4 * 4096u;
+          constexpr int SETS = WAVE_MB_OCTET_SETS, RW = 4, STEPS = RW * (int)per;
+          uint64_t m4[4][g];
+          HX_UNROLL
+          for (int L = 0; L < 4; ++L) {
+            HX_UNROLL
+            for (uint32_t qq = 0; qq < g; ++qq) m4[L][qq] = lwe4[L][(size_t)grp * g + qq];
+          }
+          auto degree_of = [&](int L, uint32_t sidx) {
+            uint64_t sum = 0;
+            HX_UNROLL
+            for (uint32_t qq = 0; qq < g; ++qq)
+              if ((sidx >> (g - 1 - qq)) & 1) sum += m4[L][qq];
+            return HX_UNIFORM((uint32_t)modulus_switch(sum, LOG2N2));
+          };
+          cplx x0[SETS], x1[SETS];
+          auto request = [&](int set, int t) {
+            const uint32_t sidx = (uint32_t)(t / RW);
+            const int j = t % RW;
+            x0[set] = ldc(gk, lane_off, sidx * ggsw_bytes + row0_off + (uint32_t)j * 1024u);
+            x1[set] = ldc(gk, lane_off, sidx * ggsw_bytes + row1_off + (uint32_t)j * 1024u);
+          };
+          uint32_t dg[2][4];
+          cplx bs[2][4];
+          auto request_bases = [&](uint32_t sidx) {
+            HX_UNROLL
+            for (int L = 0; L < 4; ++L) {
+              dg[sidx & 1][L] = degree_of(L, sidx);
+              bs[sidx & 1][L] = ldc(mono_lane, lane16, dg[sidx & 1][L] * 1024u);
+            }
+          };
+          HX_UNROLL
+          for (int t = 0; t < SETS && t < STEPS; ++t) request(t, t);
+          request_bases(1);
+          HX_SCHED_FENCE();
+          HX_BLOCK_SYNC_LDS();  // all eight transforms are in the buffers (mapping M3: slot lane*17 + r)
+          HX_SCHED_FENCE();
+          cplx kq[4][RW][2];
+          HX_UNROLL
+          for (int si = 0; si < (int)per; ++si) {
+            if (si >= 1 && si + 1 < (int)per) request_bases((uint32_t)si + 1);
+            HX_SCHED_FENCE();
+            HX_UNROLL
+            for (int j = 0; j < RW; ++j) {
+              const int t = si * RW + j, set = t % SETS;
+              if (si == 0) {  // subset 0 is not rotated: it initialises the accumulators of all four LWEs
+                HX_UNROLL
+                for (int L = 0; L < 4; ++L) {
+                  kq[L][j][0] = x0[set];
+                  kq[L][j][1] = x1[set];
+                }
+              } else {
+                constexpr uint32_t br2[4] = {0, 2, 1, 3};
+                const uint32_t br = br2[j] * 4u + brq;
+                HX_UNROLL
+                for (int L = 0; L < 4; ++L) {
+                  const cplx mf = cmul_first(bs[si & 1][L], w16_root((br * dg[si & 1][L]) & 15u));
+                  kq[L][j][0] = cmul_add(x0[set], mf, kq[L][j][0]);
+                  kq[L][j][1] = cmul_add(x1[set], mf, kq[L][j][1]);
+                  HX_OPAQUE(kq[L][j][0].re);
+                  HX_OPAQUE(kq[L][j][0].im);
+                  HX_OPAQUE(kq[L][j][1].re);
+                  HX_OPAQUE(kq[L][j][1].im);
+                }
+              }
+              HX_SCHED_FENCE();
+              if (t + SETS < STEPS) request(set, t + SETS);
+              HX_SCHED_FENCE();
+            }
+          }
+          // products with the digit transforms of the four LWEs (rows = the two polynomials of an LWE's pair);
+          // fma(a, b, -0.0) is the rounded product a b with its sign of zero
+          const int fslot = base_m3(cx) + 4 * (int)q4;
+          HX_UNROLL
+          for (int L = 0; L < 4; ++L) {
+            const cplx *f0 = (const cplx *)(smem + (size_t)(2 * L) * BUF_BYTES) + fslot;
+            const cplx *f1 = (const cplx *)(smem + (size_t)(2 * L + 1) * BUF_BYTES) + fslot;
+            HX_UNROLL
+            for (int j = 0; j < RW; ++j) {
+              const cplx xa0 = f0[j], xa1 = f1[j];
+              kq[L][j][0] = cmul_add(xa1, kq[L][j][1], cmul_add(xa0, kq[L][j][0], cplx{-0.0, -0.0}));
+              HX_OPAQUE(kq[L][j][0].re);
+              HX_OPAQUE(kq[L][j][0].im);
+            }
+          }
+          HX_SCHED_FENCE();
+          HX_BLOCK_SYNC_LDS();  // every wave is done with the transforms: the buffers take the results
+          HX_UNROLL
+          for (int L = 0; L < 4; ++L) {
+            cplx *dst = (cplx *)(smem + (size_t)(2 * L + w) * BUF_BYTES) + fslot;  // the wave that owns (LWE L, column w)
+            HX_UNROLL
+            for (int j = 0; j < RW; ++j) dst[j] = kq[L][j][0];
+          }
+          HX_BLOCK_SYNC_LDS();
+          const cplx *mine = buf + base_m3(cx);
+          HX_UNROLL
+          for (int r = 0; r < 16; ++r) o[r] = mine[r];
+          HX_WAVE_SYNC();
+        } else
         if constexpr (SHARE) {
           WaveCtx cx = ctx0;
           HX_OPAQUE(cx.lane);
@@ -1633,6 +1762,14 @@ static void launch_wave_mb_t(hipStream_t st, const PbsArgs &a, const FftTables &
   const bool share = !a.mb_no_share;  // hip_backend_set_fft_kernel(7) on the multi-bit entry point: pairs only (comparison)
   if (per_block == 3 && share) per_block = 4;  // 513 .. 768 LWEs: fuller workgroups that can share (4-12 % faster)
   const unsigned blocks = (a.num_samples + per_block - 1) / per_block;
+  // full workgroups of a one-level set: all eight waves share the key loads of the four LWEs (OCTET)
+  if constexpr (L == 1 && WAVE_MB_OCTET != 0) {
+    if (per_block == 4 && share && !a.mb_no_octet) {
+      hx_set_dynamic_smem_once<pbs_fft_wave_kernel<L, B, G, false, 0, true>>(SMEM_BYTES);
+      HX_LAUNCH((pbs_fft_wave_kernel<L, B, G, false, 0, true>), dim3(blocks), dim3(512), SMEM_BYTES, st, a, tb);
+      return;
+    }
+  }
   // an even number of LWEs per workgroup: quads of waves share the key loads of their two LWEs (SHARE)
   if (per_block % 2 == 0 && share) {
     hx_set_dynamic_smem_once<pbs_fft_wave_kernel<L, B, G, true>>(SMEM_BYTES);
