@@ -824,6 +824,39 @@ def test_multi_bit_throughput_kernel_shared_key_loads(kind, which, B):
     assert [decrypt_big(p, c.keys, o) for o in shared[-8:]] == [f(m) for m in msgs[-8:]]
 
 
+@pytest.mark.parametrize("kind", BACKENDS)
+def test_multi_bit_octet_mode_index_vectors_and_luts(kind):
+    """The all-eight-waves form takes the four LWEs of a workgroup through the index vectors: gathered inputs
+    (a permutation with repeats), scattered outputs, a different LUT per LWE — 773 LWEs (a ragged last workgroup of
+    one present LWE) against the oracle on the same indexes."""
+    from .common import TOY_MB4_2048
+    p = TOY_MB4_2048
+    c = ctx(kind, p, "fft64")
+    lib = use_backend(kind)
+    B, pool = 773, 40
+    msgs = [(3 * m + 1) % 16 for m in range(pool)]
+    cts = encrypt_small(p, c.keys, msgs, seed=41)
+    fs = [lambda x: (x + 5) % 16, lambda x: (7 * x) % 16, lambda x: (x * x) % 16]
+    luts = np.stack([orc.generate_lut(p.k, p.N, p.plaintext_modulus, p.delta, f) for f in fs])
+    rng = np.random.default_rng(5)
+    in_idx = rng.integers(0, pool, B)
+    out_idx = rng.permutation(B)
+    lut_idx = rng.integers(0, 3, B)
+    try:
+        lib.hip_backend_set_fft_kernel(2)
+        out = c.pbs(cts, luts, lut_indexes=lut_idx, in_indexes=in_idx, out_indexes=out_idx)
+        assert lib.hip_backend_last_pbs_kernel() == 6
+    finally:
+        lib.hip_backend_set_fft_kernel(0)
+    ref = np.zeros_like(out)
+    for f_i in range(3):
+        sel = np.nonzero(lut_idx == f_i)[0]
+        ref[out_idx[sel]] = oracle_pbs(p, c.keys, "fft64", cts[in_idx[sel]], luts[f_i])
+    assert np.array_equal(out, ref)
+    for i in (0, 1, 2, B - 1):
+        assert decrypt_big(p, c.keys, out[out_idx[i]]) == fs[lut_idx[i]](msgs[in_idx[i]])
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("which", ["g3_l2", "g4_l1"])
 def test_multi_bit_shared_key_loads_full_launch_ragged(which):
