@@ -190,9 +190,9 @@ if __name__ == "__main__":
             for B in (128, 192, 256, 384, 512):
                 for kern in (5, 2):
                     pbs_case(p, B, kernel=kern, steps=3)
-    if "mbmid" in which:  # mid-size batches (the rounds of ONE multiplication): key loads shared by LWE pairs (2) or not (7)
-        for B in (384, 512, 768, 1024, 2048):
-            for kern in (2, 7):
+    if "mbmid" in which:  # mid-size batches (the rounds of ONE multiplication): key loads shared by all waves / by quads (8) / not (7)
+        for B in (260, 320, 384, 448, 512, 768, 1024, 2048):
+            for kern in (2, 8, 7):
                 pbs_case(C4G4, B, kernel=kern, steps=3)
     if "mblat151" in which:  # one launch of the multi-bit latency path (PMC passes over the keybundle kernel)
         pbs_case(C4G4, 151, kernel=5, steps=1)
