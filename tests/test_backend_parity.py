@@ -99,13 +99,15 @@ def test_arith_hooks_match_oracle(kind):
     for op, fn in ((8, L.orc_gl_mul), (9, L.orc_gl_add), (10, L.orc_gl_sub)):
         got = run_arith(lib, st, op, pairs, in_per=2)
         assert all(int(g) == fn(int(a), int(b)) for g, a, b in zip(got, pairs[0::2], pairs[1::2]))
-    # lean forms of the split-key exact engine, against big-integer formulas: the modulus switch back for EVERY class
-    # of v (edges of the carries it folds), the 16-bit Horner step on lazy states (compared modulo p), the final
-    # bias removal (canonical)
-    near = [v % p for b in (0, 1 << 32, 1 << 63, p >> 1, p) for v in range(b - 3, b + 4)]
-    vs2 = np.array(sorted(set(near + [int(v) for v in vs])), dtype=np.uint64)
+    # lean forms of the split-key exact engine, against big-integer formulas: the modulus switch back on LAZY values
+    # (any 64-bit v stands for v mod p; edges of the carry it folds), the 16-bit Horner step on lazy states (compared
+    # modulo p), and the start value that makes the bias of the four limbs cancel
+    near = [v % (1 << 64) for b in (0, 1 << 32, 1 << 63, p >> 1, p, (p >> 1) + (1 << 32) - 1) for v in range(b - 3, b + 4)]
+    near += [(vh << 32) | vl for vh in (0, 1, (1 << 31) - 1, 1 << 31, (1 << 32) - 2, (1 << 32) - 1)
+             for vl in (0, 1, (1 << 31) - 1, 1 << 31, (1 << 31) + 1, (1 << 32) - 2, (1 << 32) - 1)]
+    vs2 = np.array(sorted(set(near + [int(v) for v in vs] + [int(x) for x in xs])), dtype=np.uint64)
     got = run_arith(lib, st, 12, vs2)
-    assert all(int(g) == (((int(v) << 64) + (p >> 1)) // p) % (1 << 64) for g, v in zip(got, vs2))
+    assert all(int(g) == ((((int(v) % p) << 64) + (p >> 1)) // p) % (1 << 64) for g, v in zip(got, vs2))
     c0 = 0x4338000000000000
     hs = np.array([[r, c0 + s] for r in list(xs[:40]) + [M64, p, p - 1, (1 << 48) - 1, 1 << 48]
                    for s in (0, 1, -1, (1 << 50) - 1, -(1 << 50) + 1, 12345678901234, -98765432109876)],
@@ -113,10 +115,15 @@ def test_arith_hooks_match_oracle(kind):
     got = run_arith(lib, st, 13, hs, in_per=2)
     assert all(int(g) % p == ((int(r) << 16) + int(x)) % p for g, r, x in zip(got, hs[0::2], hs[1::2]))
     bias = (c0 * 0x0001000100010001) % p
-    assert bias == 0x86704337bcc77990
-    sb = np.array([[r, bias] for r in xs[:200]], dtype=np.uint64).reshape(-1)
-    got = run_arith(lib, st, 14, sb, in_per=2)
-    assert all(int(g) == (int(r) - bias) % p for g, r in zip(got, sb[0::2]))
+    r0 = 0x4337bcc7798fbcc8  # arith.h GL_SPLIT_R0
+    assert bias == 0x86704337bcc77990 and (r0 * (1 << 64) + bias) % p == 0
+    S = rng.integers(-(1 << 49), 1 << 49, size=(300, 4)).astype(np.int64)
+    S[0], S[1], S[2] = (1 << 49) - 1, -(1 << 49) + 1, 0
+    state = np.full(len(S), r0, dtype=np.uint64)
+    for m in range(4):  # four Horner steps on the biased bit patterns, most significant limb first
+        step = np.stack([state, (np.uint64(c0) + S[:, m].astype(np.uint64))], axis=1).reshape(-1)
+        state = run_arith(lib, st, 13, step, in_per=2)
+    assert all(int(g) % p == sum(int(sv) << (16 * (3 - m)) for m, sv in enumerate(row)) % p for g, row in zip(state, S))
 
 
 @pytest.mark.parametrize("kind", BACKENDS)

@@ -535,14 +535,16 @@ void hip_programmable_bootstrap_ntt64_split_async(void *stream, uint32_t gpu_ind
     HX_PANIC_IF_FALSE(!stream_is_capturing(S(stream)),
                       "split-key exact engine: the first launch on a scratch allocates and cannot be captured; run it once before the capture");
     HX_CHECK(hipMalloc((void **)&b->split_acc, (size_t)b->max_samples * (glwe_dimension + 1) * polynomial_size * sizeof(uint64_t)));
-    HX_CHECK(hipMalloc((void **)&b->split_flag, sizeof(uint32_t)));
-    HX_CHECK(hipMemsetAsync(b->split_flag, 0, sizeof(uint32_t), S(stream)));
+    // word 0: the round-off flag; words 64 .. 319: the per-XCD progress counters of the paced loop (PbsArgs::pace)
+    HX_CHECK(hipMalloc((void **)&b->split_flag, (64 + 8 * 32) * sizeof(uint32_t)));
+    HX_CHECK(hipMemsetAsync(b->split_flag, 0, (64 + 8 * 32) * sizeof(uint32_t), S(stream)));
   }
   PbsArgs a = make_args(lwe_array_out, lwe_output_indexes, lut_vector, lut_vector_indexes, lwe_array_in,
                         lwe_input_indexes, bootstrapping_key, lwe_dimension, base_log, level_count, num_samples,
                         num_many_lut, lut_stride, b->ms_type);
   a.acc_scratch = b->split_acc;
   a.roundoff_flag = b->split_flag;
+  a.pace = b->split_flag + 64;
   launch_pbs_ntt_split_wave(S(stream), a, b->fft);
   g_last_pbs_kernel.store(13);
 }

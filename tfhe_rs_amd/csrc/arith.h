@@ -340,38 +340,25 @@ HX_HD uint64_t gl_horner16(uint64_t R, uint64_t X) {
   const uint32_t c2 = __builtin_add_overflow((uint64_t)(hi + c) * GL_EPS, U, &V) ? 1u : 0u;  // (hi + c) <= 2^16
   return V + (uint64_t)c2 * GL_EPS;  // a wrapped V is below (hi + c) EPS < 2^48: cannot wrap again
 }
-// bits(1.5 2^52 + S) = GL_SPLIT_C0 + S for an integer |S| < 2^51: the Horner above runs on the raw bit patterns and
-// the bias C0 (1 + 2^16 + 2^32 + 2^48) mod p is taken off once at the end
+// bits(1.5 2^52 + S) = GL_SPLIT_C0 + S for an integer |S| < 2^51: the Horner above runs on the raw bit patterns.  The
+// bias of the four limbs, C0 (1 + 2^16 + 2^32 + 2^48) mod p, never has to be taken off: the Horner states START at
+// R0 with R0 2^64 = -bias (mod p), so after the four steps the state is the plain sum of the S_m 2^(16 (3 - m)) mod p
 static constexpr uint64_t GL_SPLIT_C0 = 0x4338000000000000ull;
 static constexpr uint64_t GL_SPLIT_BIAS = 0x86704337bcc77990ull;  // GL_SPLIT_C0 * 0x0001000100010001 mod p
-// lazy R -> canonical (R - bias) mod p
-HX_HD uint64_t gl_sub_canon(uint64_t R, uint64_t c) {
-  uint64_t d;
-  const bool borrow = __builtin_sub_overflow(R, c, &d);
-  d -= borrow ? GL_EPS : 0;  // -2^64 = -EPS; R - c + 2^64 >= 2^64 - p = EPS, so this cannot wrap
-  return gl_canon(d);
-}
-// gl_modswitch_to_pow2 without 128-bit products or loops:  v 2^64 = v p + v e  (e = EPS), so the result is
-// v + floor(w / p) with w = v e + (p >> 1) = (v << 32) - v + h < 2^97;  w = wh 2^64 + wl = wh p + (wh e + wl) and
-// r = wh e + wl < 2^65 holds at most two more p.  Same value as gl_modswitch_to_pow2 for every v < p
-// (test_arith_hooks_match_oracle).
-HX_HD uint64_t gl_modswitch_to_pow2_lean(uint64_t v) {
-  const uint64_t h = GL_P >> 1;
-  const uint64_t s = v << 32;
-  uint64_t t1, wl;
-  const uint32_t borrow = __builtin_sub_overflow(s, v, &t1) ? 1u : 0u;
-  const uint32_t carry = __builtin_add_overflow(t1, h, &wl) ? 1u : 0u;
-  const uint64_t wh = (v >> 32) - borrow + carry;  // never negative: s < v needs v >> 32 != 0 (s = lo(v) << 32 >= v otherwise)
-  const uint64_t m = wh * GL_EPS;  // wh <= 2^32: below 2^64
-  uint64_t rl, s2;
-  const bool rc = __builtin_add_overflow(m, wl, &rl);
-  const bool ovf = __builtin_add_overflow(rl, GL_EPS, &s2);   // rl >= p  <=>  rl + EPS wraps
-  // no carry: one more p iff rl >= p (= ovf).  carry: r - p = rl + EPS (= s2, never wraps twice: r < 2^65), and one
-  // more iff that is >= p again
-  uint64_t t3;
-  const bool again = __builtin_add_overflow(s2, GL_EPS, &t3);
-  const uint32_t q2 = rc ? 1u + ((ovf || again) ? 1u : 0u) : (ovf ? 1u : 0u);
-  return v + wh + q2;
+static constexpr uint64_t GL_SPLIT_R0 = 0x4337bcc7798fbcc8ull;    // -GL_SPLIT_BIAS / (2^64 mod p) mod p
+// gl_modswitch_to_pow2 of a LAZY value (any 64-bit v, standing for v mod p), seven instructions:
+//   floor((v 2^64 + (p >> 1)) / p) = v + floor(w / p),  w = v e + h  (e = EPS = 2^64 - p, h = p >> 1);
+//   with v = vh 2^32 + vl:  w = vh p + rho,  rho = vl e + h - vh   (vh p = vh 2^32 e + vh, so vh p + rho = v e + h);
+//   0 < h - vh <= rho < 2^64 + 2^63 < 2 p, hence floor(w / p) = vh + [rho >= p], and rho >= p  <=>  rho + e >= 2^64
+//   <=>  the 64-bit sum  vl e + (h + e - vh)  carries (h + e - vh < 2^64, vl e < 2^64).
+// v and v + p give results 2^64 apart: no canonical form is needed in front of it.  Equal to gl_modswitch_to_pow2 for
+// every v < p and to gl_modswitch_to_pow2(v mod p) for every v (test_arith_hooks_match_oracle).
+HX_HD uint64_t gl_modswitch_to_pow2_lazy(uint64_t v) {
+  const uint32_t vh = (uint32_t)(v >> 32), vl = (uint32_t)v;
+  constexpr uint64_t K = (GL_P >> 1) + GL_EPS;
+  uint64_t t;
+  const uint32_t more = __builtin_add_overflow((uint64_t)vl * GL_EPS, K - vh, &t) ? 1u : 0u;
+  return v + vh + more;
 }
 
 }  // namespace tfhe_hip

@@ -139,6 +139,20 @@
 #ifndef WAVE_SPLIT_NT
 #define WAVE_SPLIT_NT 0     // 1: accumulator loads / stores nontemporal
 #endif
+#ifndef WAVE_STAGGER
+// classic one-level loop: waves 4..7 (the second wave of every SIMD) start the loop this many times 4096 cycles after
+// waves 0..3, so that the two waves of a SIMD are in different phases of the CMUX (0: off)
+#define WAVE_STAGGER 0
+#endif
+#ifndef WAVE_SPLIT_PROBE
+#define WAVE_SPLIT_PROBE 0  // timing probes of the split-key loop (wrong results): see the uses
+#endif
+#ifndef WAVE_SPLIT_PACE
+// exact engine, split-key form: CMUXes a wave pair may run ahead of the slowest pair of its XCD, plus 1 (0: no pacing).
+// Unpaced, the 32 workgroups of an XCD drift apart over the 918 iterations and each pulls its own 256 KB key slice
+// through an L2 that the CU-resident accumulators (4 MB per XCD) already fill
+#define WAVE_SPLIT_PACE 0
+#endif
 #ifndef WAVE_FUSE_PASS1
 #define WAVE_FUSE_PASS1 1    // first inverse pass interleaved with the MAC chunks
 #endif
@@ -226,6 +240,9 @@ HX_DEV void flag_set(uint32_t *f, uint32_t v) {
   __hip_atomic_store(f, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 HX_DEV void flag_wait(uint32_t *f, uint32_t v) {
+#if defined(WAVE_SPLIT_PROBE) && WAVE_SPLIT_PROBE == 4  // timing probe (races): no waiting on the partner
+  return;
+#endif
   while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < v) __builtin_amdgcn_s_sleep(WAVE_FLAG_SLEEP);
 }
 #endif
@@ -1488,6 +1505,9 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
     typedef uint64_t v2u64 __attribute__((ext_vector_type(2)));
 #endif
     auto acc_load = [&]() {
+#if WAVE_SPLIT_PROBE == 2  // timing probe (wrong results): no accumulator traffic
+      return;
+#endif
       HX_UNROLL
       for (int r = 0; r < 16; ++r) {
 #if WAVE_SPLIT_NT && !defined(TFHE_HIPEMU)
@@ -1502,6 +1522,9 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
       }
     };
     auto acc_store = [&]() {
+#if WAVE_SPLIT_PROBE == 2
+      return;
+#endif
       HX_UNROLL
       for (int r = 0; r < 16; ++r) {
 #if WAVE_SPLIT_NT && !defined(TFHE_HIPEMU)
@@ -1516,9 +1539,41 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
     };
     acc_store();
     stage_acc();  // the rotation of the first CMUX reads the staged copy
+#if WAVE_SPLIT_PACE && !defined(TFHE_HIPEMU)
+    // Pacing by mask index (the multi-bit loop's scheme, see there): every pair adds 1 to its XCD's counter per mask
+    // element, executed or skipped; speed only, bounded spins, never needed for correctness
+    uint32_t *pace_ctr = a.pace + (blockIdx.x & 7u) * 32u;
+    uint32_t pace_before = 0, pace_mine = 0;
+    bool pacing = a.pace != nullptr;
+    {
+      const uint32_t ppb = blockDim.x >> 7, xcd = blockIdx.x & 7u, my_batch = (blockIdx.x >> 3) / 32u;
+      for (uint32_t j = 0; j < (my_batch + 1) * 32u; ++j) {
+        const uint64_t first = (uint64_t)(xcd + 8u * j) * ppb;
+        const uint32_t cnt = first >= a.num_samples ? 0u : (a.num_samples - first < ppb ? (uint32_t)(a.num_samples - first) : ppb);
+        if (j < my_batch * 32u) pace_before += cnt; else pace_mine += cnt;
+      }
+    }
+    auto pace_wait = [&](uint32_t i) {
+      if (pacing && i >= (uint32_t)WAVE_SPLIT_PACE) {
+        const uint32_t need = pace_before * a.n + pace_mine * (i + 1u - (uint32_t)WAVE_SPLIT_PACE);
+        uint32_t spins = 0;
+        while (__hip_atomic_load(pace_ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+          __builtin_amdgcn_s_sleep(8);
+          if (++spins > (uint32_t)WAVE_MB_PACE_SPINS) {
+            pacing = false;
+            break;
+          }
+        }
+      }
+    };
+    auto pace_arrive = [&]() {
+      if (a.pace != nullptr && w == 0 && lane == 0)
+        __hip_atomic_fetch_add(pace_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+#endif
     double worst = 0.0;  // largest distance from an integer seen by this lane (round-off check)
     // t = S + error, S integer: the Horner state takes the raw bits of t + 1.5 2^52 (= GL_SPLIT_C0 + S; the bias of
-    // the four limbs comes off once at the end), R <- R 2^16 + bits (mod P), lazy Goldilocks forms
+    // the four limbs cancels against the states' start value GL_SPLIT_R0), R <- R 2^16 + bits (mod P), lazy Goldilocks forms
     auto fold = [&](uint64_t &R, double t) {
       const double MAGIC = 6755399441055744.0;  // 1.5 * 2^52: t + MAGIC has its unit bit at 2^0 for |t| < 2^51
       const double tm = t + MAGIC;
@@ -1532,7 +1587,15 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
       const uint64_t mask_cur = mask_next;
       mask_next = lwe[i + 1];
       const uint32_t a_hat = HX_UNIFORM((uint32_t)modulus_switch(mask_cur, LOG2N2));
+#if WAVE_SPLIT_PACE && !defined(TFHE_HIPEMU)
+      if (a_hat == 0) {
+        pace_arrive();
+        continue;
+      }
+      pace_wait(i);
+#else
       if (a_hat == 0) continue;
+#endif
       ++it;
       cplx d[16];
       HX_PRIO(WAVE_PRIO_A);
@@ -1541,14 +1604,20 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
       wave_forward<0, WAVE_LIT_LIMBS != 0>(d, ctx);  // d = F, my row of the digit transform; also in my buffer (mapping M3)
       uint64_t R_re[16], R_im[16];
       HX_UNROLL
-      for (int r = 0; r < 16; ++r) R_re[r] = R_im[r] = 0;
+      for (int r = 0; r < 16; ++r) R_re[r] = R_im[r] = GL_SPLIT_R0;  // the limbs' bias cancels (arith.h)
       // one limb: product with the limb's key rows, back to the coefficients, into the Horner states.  LAST: F is dead
       // after the product, the accumulator is requested from device memory under the inverse transform
       auto limb_step = [&](uint32_t limb, auto last_tag) {
         constexpr bool LAST = decltype(last_tag)::value;
         cplx o[16], ka0[4], ka1[4], kb0[4], kb1[4];
         const cplx *b0, *b1;
+#if WAVE_SPLIT_PROBE == 1  // timing probe (wrong results): every key request hits the same 64 KB
+        key_rows(0, limb, b0, b1);
+#elif WAVE_SPLIT_PROBE == 3  // timing probe (wrong results): ... the same 16 KB per wave (vector L1)
+        key_rows(0, 0, b0, b1);
+#else
         key_rows(i, limb, b0, b1);
+#endif
         HX_PRIO(WAVE_PRIO_C);
         mac(o, o, ka0, ka1, kb0, kb1, b0, b1, 0, (it - 1) * (uint32_t)LIMBS + limb + 1,
             std::integral_constant<bool, WAVE_FUSE_PASS1 != 0>{});
@@ -1575,11 +1644,14 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
       // acc += modswitch_to_2^64(R mod P) (ntt64.rs:162-177); the registers hold MINUS the accumulator
       HX_UNROLL
       for (int r = 0; r < 16; ++r) {
-        acc_re[r] -= gl_modswitch_to_pow2_lean(gl_sub_canon(R_re[r], GL_SPLIT_BIAS));
-        acc_im[r] -= gl_modswitch_to_pow2_lean(gl_sub_canon(R_im[r], GL_SPLIT_BIAS));
+        acc_re[r] -= gl_modswitch_to_pow2_lazy(R_re[r]);
+        acc_im[r] -= gl_modswitch_to_pow2_lazy(R_im[r]);
       }
       acc_store();
       stage_acc();  // for the next CMUX's rotation (my buffer is free: the last inverse transposition is over)
+#if WAVE_SPLIT_PACE && !defined(TFHE_HIPEMU)
+      pace_arrive();
+#endif
     }
     // an f64 product was not within 1/4 of an integer: reported through the scratch's flag (no trap: a trap kills the
     // whole HIP context of the process).  The bound is statistical, not a proof — worst-case magnitudes of 2^49 leave
@@ -1597,6 +1669,11 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
     stage_acc();
     ResidentTwiddles res_tw;
     if constexpr (LEVEL_CT == 1) load_resident_twiddles<WAVE_RESIDENT>(res_tw, T, lane);
+#if WAVE_STAGGER && !defined(TFHE_HIPEMU)
+    if (wave >= 4) {
+      for (int u = 0; u < WAVE_STAGGER; ++u) __builtin_amdgcn_s_sleep(64);
+    }
+#endif
     uint32_t it = 0;  // executed iterations (flag epoch)
     uint64_t mask_next = lwe[0];
     for (uint32_t i = 0; i < a.n; ++i) {
@@ -1767,6 +1844,9 @@ static void launch_split_t(hipStream_t st, const PbsArgs &a, const FftTables &tb
   unsigned per_block = lwes_per_block(a.num_samples);
   if (per_block > WAVE_SPLIT_LWES) per_block = WAVE_SPLIT_LWES;
   const unsigned blocks = (a.num_samples + per_block - 1) / per_block;
+#if WAVE_SPLIT_PACE
+  if (a.pace) HX_CHECK(hipMemsetAsync(a.pace, 0, 8 * 32 * sizeof(uint32_t), st));
+#endif
   HX_LAUNCH((pbs_fft_wave_kernel<1, B, 0, false, NTT_SPLIT_LIMBS>), dim3(blocks), dim3(128 * per_block), SMEM_BYTES, st, a,
             tb);
 }
