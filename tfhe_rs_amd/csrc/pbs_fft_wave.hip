@@ -141,8 +141,10 @@
 #endif
 #ifndef WAVE_STAGGER
 // classic one-level loop: waves 4..7 (the second wave of every SIMD) start the loop this many times 4096 cycles after
-// waves 0..3, so that the two waves of a SIMD are in different phases of the CMUX (0: off)
-#define WAVE_STAGGER 0
+// waves 0..3, so that the two waves of a SIMD are in different phases of the CMUX (0: off).  Same box, ms per 4096,
+// eight interleaved pairs of runs (profiles/r04_ab_stagger*.txt): 0 -> 33.50 / 32.40, 1 -> 33.33 / 32.20 (-0.5 %),
+// 2 -> 32.50, 3 -> 32.24
+#define WAVE_STAGGER 1
 #endif
 #ifndef WAVE_SPLIT_PROBE
 #define WAVE_SPLIT_PROBE 0  // timing probes of the split-key loop (wrong results): see the uses
