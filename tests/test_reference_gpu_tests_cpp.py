@@ -1,0 +1,56 @@
+"""The reference's own GPU tests for the path (tfhe/src/core_crypto/gpu/algorithms/test/*.rs), restated in C++ in
+tests/cpp/reference_gpu_tests.cpp on top of the compiled host mirror tfhe_rs_amd/host/core_crypto_gpu.hpp and LINKED
+against the backend library like the Rust crate would be (the Rust originals cannot be compiled
+here).  [emu] small parameter sets against the host-emulation build of the kernels (CPU tier);
+[hip] the reference's parameter sets (TEST_PARAMS_4_BITS_NATIVE_U64, MULTI_BIT_2_2_{2,3,4}_PARAMS) on the MI355X."""
+import os
+import subprocess
+
+import pytest
+
+from .harness import EMU_LIB, build_emu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+PRODUCT_LIB = os.path.join(ROOT, "tfhe_rs_amd", "lib", "libtfhe_hip_backend.so")
+ORACLE_LIB = os.path.join(ROOT, "oracle", "libtfhe_oracle.so")
+
+
+def build_tests(lib, exe):
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
+    cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-Wextra", "-Werror", "-o", exe,
+           os.path.join(HERE, "cpp", "reference_gpu_tests.cpp"), lib, ORACLE_LIB,
+           "-Wl,-rpath," + os.path.dirname(lib), "-Wl,-rpath," + os.path.dirname(ORACLE_LIB)]
+    subprocess.check_call(cmd)
+    return exe
+
+
+def run(exe, *args, timeout):
+    r = subprocess.run([exe, *args], capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stdout + r.stderr
+    last = r.stdout.strip().splitlines()[-1]
+    assert last.startswith("test result: ok."), r.stdout
+    return r.stdout
+
+
+def test_reference_gpu_tests_on_the_host_emulation(tmp_path):
+    exe = build_tests(build_emu(), str(tmp_path / "reference_gpu_tests_emu"))
+    out = run(exe, "toy", timeout=1500)
+    assert out.count(" ... ok") == 14, out
+
+
+@pytest.mark.gpu
+def test_reference_gpu_tests_with_the_reference_parameter_sets(tmp_path):
+    assert os.path.exists(PRODUCT_LIB)
+    exe = build_tests(PRODUCT_LIB, str(tmp_path / "reference_gpu_tests"))
+    out = run(exe, "reference", timeout=1500)
+    # 4 classic + 3 multi-bit bootstraps + 2 multi-bit keyswitches + modulus switch + panics
+    assert out.count(" ... ok") == 11, out
+    print(out)
+
+
+@pytest.mark.gpu
+def test_reference_gpu_tests_small_sets_on_the_gpu(tmp_path):
+    exe = build_tests(PRODUCT_LIB, str(tmp_path / "reference_gpu_tests"))
+    out = run(exe, "toy", timeout=600)
+    assert out.count(" ... ok") == 14, out

@@ -1,0 +1,587 @@
+// core_crypto_gpu.hpp — compiled host side of the backend: a C++17 mirror of the reference's Rust module
+// `tfhe::core_crypto::gpu` for the PBS hot path, written over NOTHING but the C ABI of
+// include/tfhe_hip_backend.h (plain pointers and sizes).  The reference's host language is Rust; this image has no
+// cargo / rustc, so the compiled host side is C++ — same type and function names, same argument order
+// and meaning, same failure behaviour (a Rust `assert!`/`assert_eq!` panic is a `gpu::Panic` exception carrying the
+// reference's message) — and tests/cpp/reference_gpu_tests.cpp restates the reference's own GPU tests on top of it.
+// tfhe_rs_amd/core_crypto_gpu.py is the same mirror for the Python test harness.
+//
+//   CudaStreams                   tfhe/src/core_crypto/gpu/mod.rs:33-150
+//   CudaVec<T>                    tfhe/src/core_crypto/gpu/vec.rs:40-515
+//   CudaLweCiphertextList         tfhe/src/core_crypto/gpu/entities/lwe_ciphertext_list.rs
+//   CudaGlweCiphertextList        tfhe/src/core_crypto/gpu/entities/glwe_ciphertext_list.rs
+//   CudaLweBootstrapKey           tfhe/src/core_crypto/gpu/entities/lwe_bootstrap_key.rs:57-104
+//   CudaLweMultiBitBootstrapKey   tfhe/src/core_crypto/gpu/entities/lwe_multi_bit_bootstrap_key.rs
+//   CudaLweKeyswitchKey           tfhe/src/core_crypto/gpu/entities/lwe_keyswitch_key.rs
+//   programmable_bootstrap / programmable_bootstrap_multi_bit / keyswitch / extract_lwe_samples…   gpu/ffi.rs:21-92,208-309,503-618,838-883
+//   cuda_programmable_bootstrap_lwe_ciphertext            gpu/algorithms/lwe_programmable_bootstrapping.rs:10-136
+//   cuda_multi_bit_programmable_bootstrap_lwe_ciphertext  gpu/algorithms/lwe_multi_bit_programmable_bootstrapping.rs:10-145
+//   cuda_keyswitch_lwe_ciphertext                         gpu/algorithms/lwe_keyswitch.rs:12-143
+//   cuda_extract_lwe_samples_from_glwe_ciphertext_list    gpu/algorithms/glwe_sample_extraction.rs:12-92
+//
+// Header-only.  A program using it links the backend library directly (the way the Rust crate's build.rs does):
+//   g++ -std=c++17 prog.cpp tfhe_rs_amd/lib/libtfhe_hip_backend.so -Wl,-rpath,…
+// There is no CPU path behind it: without the library or without a GPU the calls abort like the reference's.
+#pragma once
+
+#include <cstdint>
+#include <cstdio>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <type_traits>
+#include <utility>
+#include <vector>
+
+#include "../../include/tfhe_hip_backend.h"
+
+namespace tfhe::core_crypto::gpu {
+
+// A failed `assert!` / `assert_eq!` of the Rust module (a panic there).
+struct Panic : std::logic_error {
+  using std::logic_error::logic_error;
+};
+
+namespace detail {
+template <class A, class B>
+inline void assert_eq(const A &a, const B &b, const char *what) {
+  if (!(a == b)) {
+    std::ostringstream s;
+    s << what << " (left: " << a << ", right: " << b << ")";
+    throw Panic(s.str());
+  }
+}
+inline void assert_true(bool c, const char *what) {
+  if (!c) throw Panic(what);
+}
+}  // namespace detail
+
+// vec.rs:17-38
+struct GpuIndex {
+  uint32_t v = 0;
+  explicit GpuIndex(uint32_t i = 0) : v(i) {}
+  uint32_t get() const { return v; }
+  bool operator==(const GpuIndex &o) const { return v == o.v; }
+};
+inline std::ostream &operator<<(std::ostream &o, const GpuIndex &g) { return o << g.v; }
+
+inline uint32_t get_number_of_gpus() { return (uint32_t)cuda_get_number_of_gpus(); }  // mod.rs:262
+inline bool is_cuda_available() { return cuda_is_available() == 1; }
+
+// mod.rs:33-150: one stream per GPU; dropping the object destroys the streams.
+class CudaStreams {
+ public:
+  std::vector<void *> ptr;
+  std::vector<GpuIndex> gpu_indexes;
+
+  static CudaStreams new_single_gpu(GpuIndex g) {  // mod.rs:62-69
+    CudaStreams s;
+    s.gpu_indexes.push_back(g);
+    s.ptr.push_back(cuda_create_stream_ffi(g.get()));
+    return s;
+  }
+  static CudaStreams new_multi_gpu() {  // mod.rs:47-60
+    CudaStreams s;
+    for (uint32_t g = 0; g < get_number_of_gpus(); ++g) {
+      s.gpu_indexes.emplace_back(g);
+      s.ptr.push_back(cuda_create_stream_ffi(g));
+    }
+    return s;
+  }
+  void synchronize() const {  // mod.rs:111-117
+    for (size_t i = 0; i < ptr.size(); ++i) cuda_synchronize_stream(ptr[i], gpu_indexes[i].get());
+  }
+  void synchronize_one(size_t i) const { cuda_synchronize_stream(ptr[i], gpu_indexes[i].get()); }
+  size_t len() const { return ptr.size(); }
+
+  CudaStreams(CudaStreams &&o) noexcept : ptr(std::move(o.ptr)), gpu_indexes(std::move(o.gpu_indexes)) { o.ptr.clear(); }
+  CudaStreams(const CudaStreams &) = delete;
+  CudaStreams &operator=(const CudaStreams &) = delete;
+  ~CudaStreams() {  // mod.rs:140-150 (Drop)
+    for (size_t i = 0; i < ptr.size(); ++i) cuda_destroy_stream(ptr[i], gpu_indexes[i].get());
+  }
+
+ private:
+  CudaStreams() = default;
+};
+
+// vec.rs:40-515: a typed device array, one allocation per GPU of the streams it was made on.
+template <class T>
+class CudaVec {
+  static_assert(std::is_trivially_copyable<T>::value, "CudaVec holds plain numeric data");
+
+ public:
+  std::vector<void *> ptr;
+  size_t len = 0;
+  std::vector<GpuIndex> gpu_indexes;
+
+  CudaVec() = default;
+  // vec.rs:96-120 `new`: zero-initialised, synchronised
+  CudaVec(size_t len_, const CudaStreams &streams, uint32_t stream_index) {
+    *this = new_async(len_, streams, stream_index);
+    streams.synchronize_one(stream_index);
+  }
+  // vec.rs:122-150 `new_async`
+  static CudaVec new_async(size_t len_, const CudaStreams &streams, uint32_t stream_index) {
+    CudaVec v;
+    v.len = len_;
+    const uint64_t bytes = bytes_of(len_);
+    const GpuIndex g = streams.gpu_indexes[stream_index];
+    void *p = cuda_malloc_async(bytes, streams.ptr[stream_index], g.get());
+    cuda_memset_async(p, 0, bytes, streams.ptr[stream_index], g.get());
+    v.ptr.push_back(p);
+    v.gpu_indexes.push_back(g);
+    return v;
+  }
+  // vec.rs:152-185 `new_multi_gpu`: the same length on every GPU of `streams`
+  static CudaVec new_multi_gpu(size_t len_, const CudaStreams &streams) {
+    CudaVec v;
+    v.len = len_;
+    for (size_t i = 0; i < streams.len(); ++i) {
+      const GpuIndex g = streams.gpu_indexes[i];
+      void *p = cuda_malloc_async(bytes_of(len_), streams.ptr[i], g.get());
+      cuda_memset_async(p, 0, bytes_of(len_), streams.ptr[i], g.get());
+      v.ptr.push_back(p);
+      v.gpu_indexes.push_back(g);
+    }
+    streams.synchronize();
+    return v;
+  }
+  static CudaVec from_cpu_async(const std::vector<T> &src, const CudaStreams &streams, uint32_t stream_index) {
+    CudaVec v = new_async(src.size(), streams, stream_index);
+    v.copy_from_cpu_async(src, streams, stream_index);
+    return v;
+  }
+  // vec.rs:215-245: `src` may be shorter than the vector ("self.len() >= src.len()"); asynchronous: the caller keeps
+  // `src` alive until the stream is synchronised (that is why the Rust function is `unsafe`)
+  void copy_from_cpu_async(const std::vector<T> &src, const CudaStreams &streams, uint32_t stream_index) {
+    copy_from_cpu_async(src.data(), src.size(), streams, stream_index);
+  }
+  void copy_from_cpu_async(const T *src, size_t count, const CudaStreams &streams, uint32_t stream_index) {
+    detail::assert_true(len >= count, "assertion failed: self.len() >= src.len()");
+    if (count)
+      cuda_memcpy_async_to_gpu(ptr[stream_index], src, count * sizeof(T), streams.ptr[stream_index],
+                               streams.gpu_indexes[stream_index].get());
+  }
+  // vec.rs:247-285 `copy_from_cpu_multi_gpu_async`
+  void copy_from_cpu_multi_gpu_async(const T *src, size_t count, const CudaStreams &streams) {
+    detail::assert_true(len >= count, "assertion failed: self.len() >= src.len()");
+    for (size_t i = 0; i < ptr.size() && count; ++i)
+      cuda_memcpy_async_to_gpu(ptr[i], src, count * sizeof(T), streams.ptr[i], streams.gpu_indexes[i].get());
+  }
+  // vec.rs:395-425 `copy_to_cpu_async`
+  void copy_to_cpu_async(T *dest, size_t count, const CudaStreams &streams, uint32_t stream_index) const {
+    detail::assert_true(count >= len, "assertion failed: dest.len() >= self.len()");
+    if (len)
+      cuda_memcpy_async_to_cpu(dest, ptr[stream_index], len * sizeof(T), streams.ptr[stream_index],
+                               streams.gpu_indexes[stream_index].get());
+  }
+  std::vector<T> to_cpu(const CudaStreams &streams, uint32_t stream_index = 0) const {
+    std::vector<T> out(len);
+    copy_to_cpu_async(out.data(), out.size(), streams, stream_index);
+    streams.synchronize_one(stream_index);
+    return out;
+  }
+  // vec.rs:287-330 `copy_from_gpu_async`
+  void copy_from_gpu_async(const CudaVec &src, const CudaStreams &streams, uint32_t stream_index) {
+    detail::assert_true(len >= src.len, "assertion failed: self.len() >= src.len()");
+    if (src.len)
+      cuda_memcpy_async_gpu_to_gpu(ptr[stream_index], src.ptr[stream_index], src.len * sizeof(T),
+                                   streams.ptr[stream_index], streams.gpu_indexes[stream_index].get());
+  }
+  void *as_mut_c_ptr(uint32_t index) { return ptr[index]; }          // vec.rs:447-455
+  const void *as_c_ptr(uint32_t index) const { return ptr[index]; }  // vec.rs:457-465
+  GpuIndex gpu_index(uint32_t index) const { return gpu_indexes[index]; }
+  bool is_empty() const { return len == 0; }
+
+  CudaVec(CudaVec &&o) noexcept { *this = std::move(o); }
+  CudaVec &operator=(CudaVec &&o) noexcept {
+    if (this != &o) {
+      release();
+      ptr = std::move(o.ptr);
+      gpu_indexes = std::move(o.gpu_indexes);
+      len = o.len;
+      o.ptr.clear();
+      o.len = 0;
+    }
+    return *this;
+  }
+  CudaVec(const CudaVec &) = delete;
+  CudaVec &operator=(const CudaVec &) = delete;
+  ~CudaVec() { release(); }  // vec.rs:495-515 (Drop: synchronises the device, then cuda_drop)
+
+ private:
+  static uint64_t bytes_of(size_t n) { return n ? (uint64_t)n * sizeof(T) : 8; }
+  void release() {
+    for (size_t i = 0; i < ptr.size(); ++i) {
+      cuda_synchronize_device(gpu_indexes[i].get());
+      cuda_drop(ptr[i], gpu_indexes[i].get());
+    }
+    ptr.clear();
+  }
+};
+
+// the reference's CiphertextModulus: only the native 2^64 modulus is on this path (the 64-bit FFI of the
+// reference's backend accepts nothing else: lwe_keyswitch.rs:60-67 "assert!(ciphertext_modulus.is_compatible_with_native_modulus())")
+struct CiphertextModulus {
+  uint32_t log2 = 64;
+  static CiphertextModulus new_native() { return {}; }
+  bool is_compatible_with_native_modulus() const { return true; }
+  bool operator==(const CiphertextModulus &o) const { return log2 == o.log2; }
+};
+inline std::ostream &operator<<(std::ostream &o, const CiphertextModulus &m) { return o << "2^" << m.log2; }
+
+// entities/lwe_ciphertext_list.rs
+template <class T = uint64_t>
+class CudaLweCiphertextList {
+ public:
+  CudaVec<T> d_vec;
+  size_t lwe_ciphertext_count_ = 0;
+  size_t lwe_dimension_ = 0;
+  CiphertextModulus ciphertext_modulus_;
+
+  // :20-40 `new`: zeroed list on the first GPU of `streams`
+  CudaLweCiphertextList(size_t lwe_dimension, size_t lwe_ciphertext_count, CiphertextModulus m, const CudaStreams &streams)
+      : d_vec((lwe_dimension + 1) * lwe_ciphertext_count, streams, 0),
+        lwe_ciphertext_count_(lwe_ciphertext_count),
+        lwe_dimension_(lwe_dimension),
+        ciphertext_modulus_(m) {}
+  // :42-70 `from_lwe_ciphertext_list`: flat host container of `count` ciphertexts of `lwe_dimension + 1` words
+  static CudaLweCiphertextList from_lwe_ciphertext_list(const std::vector<T> &h_ct, size_t lwe_dimension, CiphertextModulus m,
+                                                        const CudaStreams &streams) {
+    detail::assert_true(h_ct.size() % (lwe_dimension + 1) == 0, "the container is not a whole number of LWE ciphertexts");
+    CudaLweCiphertextList l(lwe_dimension, h_ct.size() / (lwe_dimension + 1), m, streams);
+    l.d_vec.copy_from_cpu_async(h_ct, streams, 0);
+    streams.synchronize();
+    return l;
+  }
+  // :110-135 `from_lwe_ciphertext`
+  static CudaLweCiphertextList from_lwe_ciphertext(const std::vector<T> &h_ct, CiphertextModulus m, const CudaStreams &streams) {
+    return from_lwe_ciphertext_list(h_ct, h_ct.size() - 1, m, streams);
+  }
+  std::vector<T> to_lwe_ciphertext_list(const CudaStreams &streams) const { return d_vec.to_cpu(streams, 0); }  // :137-160
+  std::vector<T> into_lwe_ciphertext(const CudaStreams &streams) const {                                         // :162-180
+    return d_vec.to_cpu(streams, 0);
+  }
+  size_t lwe_dimension() const { return lwe_dimension_; }
+  size_t lwe_ciphertext_count() const { return lwe_ciphertext_count_; }
+  CiphertextModulus ciphertext_modulus() const { return ciphertext_modulus_; }
+};
+
+// entities/glwe_ciphertext_list.rs
+template <class T = uint64_t>
+class CudaGlweCiphertextList {
+ public:
+  CudaVec<T> d_vec;
+  size_t glwe_ciphertext_count_ = 0;
+  size_t glwe_dimension_ = 0;
+  size_t polynomial_size_ = 0;
+  CiphertextModulus ciphertext_modulus_;
+
+  CudaGlweCiphertextList(size_t glwe_dimension, size_t polynomial_size, size_t count, CiphertextModulus m,
+                         const CudaStreams &streams)
+      : d_vec((glwe_dimension + 1) * polynomial_size * count, streams, 0),
+        glwe_ciphertext_count_(count),
+        glwe_dimension_(glwe_dimension),
+        polynomial_size_(polynomial_size),
+        ciphertext_modulus_(m) {}
+  static CudaGlweCiphertextList from_glwe_ciphertext_list(const std::vector<T> &h_ct, size_t glwe_dimension,
+                                                          size_t polynomial_size, CiphertextModulus m, const CudaStreams &streams) {
+    const size_t one = (glwe_dimension + 1) * polynomial_size;
+    detail::assert_true(h_ct.size() % one == 0, "the container is not a whole number of GLWE ciphertexts");
+    CudaGlweCiphertextList l(glwe_dimension, polynomial_size, h_ct.size() / one, m, streams);
+    l.d_vec.copy_from_cpu_async(h_ct, streams, 0);
+    streams.synchronize();
+    return l;
+  }
+  static CudaGlweCiphertextList from_glwe_ciphertext(const std::vector<T> &h_ct, size_t glwe_dimension, size_t polynomial_size,
+                                                     CiphertextModulus m, const CudaStreams &streams) {
+    return from_glwe_ciphertext_list(h_ct, glwe_dimension, polynomial_size, m, streams);
+  }
+  std::vector<T> to_glwe_ciphertext_list(const CudaStreams &streams) const { return d_vec.to_cpu(streams, 0); }
+  size_t glwe_dimension() const { return glwe_dimension_; }
+  size_t polynomial_size() const { return polynomial_size_; }
+  size_t glwe_ciphertext_count() const { return glwe_ciphertext_count_; }
+  CiphertextModulus ciphertext_modulus() const { return ciphertext_modulus_; }
+};
+
+// entities/lwe_bootstrap_key.rs:18-30
+enum class CudaModulusSwitchNoiseReductionConfiguration { Centered };
+
+// entities/lwe_bootstrap_key.rs:32-140: converted to the Fourier domain once per GPU of `streams`
+class CudaLweBootstrapKey {
+ public:
+  CudaVec<double> d_vec;
+  size_t input_lwe_dimension_, glwe_dimension_, polynomial_size_, decomp_base_log_, decomp_level_count_;
+  bool ms_noise_reduction_configuration = false;  // Option<CudaModulusSwitchNoiseReductionConfiguration>: Some(Centered)
+
+  // :57-104 `from_lwe_bootstrap_key`; `h_bsk` is the standard-domain key container
+  // [n][level l first][k+1 rows][k+1 polys][N] (entities/lwe_bootstrap_key.rs of core_crypto)
+  static CudaLweBootstrapKey from_lwe_bootstrap_key(const std::vector<uint64_t> &h_bsk, size_t input_lwe_dimension,
+                                                    size_t glwe_dimension, size_t polynomial_size, size_t decomp_base_log,
+                                                    size_t decomp_level_count, bool centered_ms, const CudaStreams &streams) {
+    const size_t elems = input_lwe_dimension * (glwe_dimension + 1) * (glwe_dimension + 1) * decomp_level_count * polynomial_size;
+    detail::assert_eq(h_bsk.size(), elems, "bootstrap key container has the wrong size");
+    CudaLweBootstrapKey k;
+    k.input_lwe_dimension_ = input_lwe_dimension;
+    k.glwe_dimension_ = glwe_dimension;
+    k.polynomial_size_ = polynomial_size;
+    k.decomp_base_log_ = decomp_base_log;
+    k.decomp_level_count_ = decomp_level_count;
+    k.ms_noise_reduction_configuration = centered_ms;
+    k.d_vec = CudaVec<double>::new_multi_gpu(elems, streams);
+    for (size_t i = 0; i < streams.len(); ++i)  // gpu/ffi.rs:744-787 convert_lwe_programmable_bootstrap_key_async
+      cuda_convert_lwe_programmable_bootstrap_key_64_async(streams.ptr[i], streams.gpu_indexes[i].get(), k.d_vec.as_mut_c_ptr(i),
+                                                           h_bsk.data(), (uint32_t)input_lwe_dimension, (uint32_t)glwe_dimension,
+                                                           (uint32_t)decomp_level_count, (uint32_t)polynomial_size);
+    streams.synchronize();
+    return k;
+  }
+  size_t input_lwe_dimension() const { return input_lwe_dimension_; }
+  size_t output_lwe_dimension() const { return glwe_dimension_ * polynomial_size_; }
+  size_t glwe_dimension() const { return glwe_dimension_; }
+  size_t polynomial_size() const { return polynomial_size_; }
+  size_t decomp_base_log() const { return decomp_base_log_; }
+  size_t decomp_level_count() const { return decomp_level_count_; }
+};
+
+// entities/lwe_multi_bit_bootstrap_key.rs
+class CudaLweMultiBitBootstrapKey {
+ public:
+  CudaVec<uint64_t> d_vec;
+  size_t input_lwe_dimension_, glwe_dimension_, polynomial_size_, decomp_base_log_, decomp_level_count_, grouping_factor_;
+
+  // `h_bsk`: standard-domain multi-bit key [n/g][2^g][level l first][k+1][k+1][N]
+  static CudaLweMultiBitBootstrapKey from_lwe_multi_bit_bootstrap_key(const std::vector<uint64_t> &h_bsk, size_t input_lwe_dimension,
+                                                                      size_t glwe_dimension, size_t polynomial_size,
+                                                                      size_t decomp_base_log, size_t decomp_level_count,
+                                                                      size_t grouping_factor, const CudaStreams &streams) {
+    detail::assert_true(input_lwe_dimension % grouping_factor == 0, "the grouping factor does not divide the LWE dimension");
+    const size_t elems = (input_lwe_dimension / grouping_factor) * (size_t(1) << grouping_factor) * (glwe_dimension + 1) *
+                         (glwe_dimension + 1) * decomp_level_count * polynomial_size;
+    detail::assert_eq(h_bsk.size(), elems, "multi-bit bootstrap key container has the wrong size");
+    CudaLweMultiBitBootstrapKey k;
+    k.input_lwe_dimension_ = input_lwe_dimension;
+    k.glwe_dimension_ = glwe_dimension;
+    k.polynomial_size_ = polynomial_size;
+    k.decomp_base_log_ = decomp_base_log;
+    k.decomp_level_count_ = decomp_level_count;
+    k.grouping_factor_ = grouping_factor;
+    k.d_vec = CudaVec<uint64_t>::new_multi_gpu(elems, streams);
+    for (size_t i = 0; i < streams.len(); ++i)  // gpu/ffi.rs:789-835
+      cuda_convert_lwe_multi_bit_programmable_bootstrap_key_64_async(
+          streams.ptr[i], streams.gpu_indexes[i].get(), k.d_vec.as_mut_c_ptr(i), h_bsk.data(), (uint32_t)input_lwe_dimension,
+          (uint32_t)glwe_dimension, (uint32_t)decomp_level_count, (uint32_t)polynomial_size, (uint32_t)grouping_factor);
+    streams.synchronize();
+    return k;
+  }
+  size_t input_lwe_dimension() const { return input_lwe_dimension_; }
+  size_t output_lwe_dimension() const { return glwe_dimension_ * polynomial_size_; }
+  size_t glwe_dimension() const { return glwe_dimension_; }
+  size_t polynomial_size() const { return polynomial_size_; }
+  size_t decomp_base_log() const { return decomp_base_log_; }
+  size_t decomp_level_count() const { return decomp_level_count_; }
+  size_t grouping_factor() const { return grouping_factor_; }
+};
+
+// entities/lwe_keyswitch_key.rs: the key is uploaded as it is (gpu/ffi.rs:620-627 — a plain memcpy), once per GPU
+template <class T = uint64_t>
+class CudaLweKeyswitchKey {
+ public:
+  CudaVec<T> d_vec;
+  size_t input_lwe_size_, output_lwe_size_, decomp_base_log_, decomp_level_count_;
+  CiphertextModulus ciphertext_modulus_;
+
+  static CudaLweKeyswitchKey from_lwe_keyswitch_key(const std::vector<T> &h_ksk, size_t input_key_lwe_dimension,
+                                                    size_t output_key_lwe_dimension, size_t decomp_base_log,
+                                                    size_t decomp_level_count, const CudaStreams &streams) {
+    detail::assert_eq(h_ksk.size(), input_key_lwe_dimension * decomp_level_count * (output_key_lwe_dimension + 1),
+                      "keyswitch key container has the wrong size");
+    CudaLweKeyswitchKey k;
+    k.input_lwe_size_ = input_key_lwe_dimension + 1;
+    k.output_lwe_size_ = output_key_lwe_dimension + 1;
+    k.decomp_base_log_ = decomp_base_log;
+    k.decomp_level_count_ = decomp_level_count;
+    k.d_vec = CudaVec<T>::new_multi_gpu(h_ksk.size(), streams);
+    k.d_vec.copy_from_cpu_multi_gpu_async(h_ksk.data(), h_ksk.size(), streams);
+    streams.synchronize();
+    return k;
+  }
+  size_t input_key_lwe_dimension() const { return input_lwe_size_ - 1; }
+  size_t output_key_lwe_dimension() const { return output_lwe_size_ - 1; }
+  size_t decomposition_base_log() const { return decomp_base_log_; }
+  size_t decomposition_level_count() const { return decomp_level_count_; }
+  CiphertextModulus ciphertext_modulus() const { return ciphertext_modulus_; }
+};
+
+// ---------------------------------------------------------------------------------------------------------------------
+// gpu/ffi.rs — the thin unsafe layer: scratch -> launch -> cleanup on streams.ptr[0]
+// ---------------------------------------------------------------------------------------------------------------------
+
+// gpu/ffi.rs:21-92 `programmable_bootstrap_async` (+ the synchronising wrapper)
+inline void programmable_bootstrap(const CudaStreams &streams, CudaVec<uint64_t> &lwe_array_out,
+                                   const CudaVec<uint64_t> &lwe_out_indexes, const CudaVec<uint64_t> &test_vector,
+                                   const CudaVec<uint64_t> &test_vector_indexes, const CudaVec<uint64_t> &lwe_array_in,
+                                   const CudaVec<uint64_t> &lwe_in_indexes, const CudaVec<double> &bootstrapping_key,
+                                   size_t lwe_dimension, size_t glwe_dimension, size_t polynomial_size, size_t base_log,
+                                   size_t level, uint32_t num_samples, bool centered_ms) {
+  const uint32_t num_many_lut = 1, lut_stride = 0;
+  int8_t *pbs_buffer = nullptr;
+  void *s = streams.ptr[0];
+  const uint32_t g = streams.gpu_indexes[0].get();
+  scratch_cuda_programmable_bootstrap_64_async(s, g, &pbs_buffer, (uint32_t)lwe_dimension, (uint32_t)glwe_dimension,
+                                               (uint32_t)polynomial_size, (uint32_t)level, num_samples, true,
+                                               centered_ms ? PBS_MS_REDUCTION_T::CENTERED : PBS_MS_REDUCTION_T::NO_REDUCTION);
+  cuda_programmable_bootstrap_64_async(s, g, lwe_array_out.as_mut_c_ptr(0), lwe_out_indexes.as_c_ptr(0), test_vector.as_c_ptr(0),
+                                       test_vector_indexes.as_c_ptr(0), lwe_array_in.as_c_ptr(0), lwe_in_indexes.as_c_ptr(0),
+                                       bootstrapping_key.as_c_ptr(0), pbs_buffer, (uint32_t)lwe_dimension, (uint32_t)glwe_dimension,
+                                       (uint32_t)polynomial_size, (uint32_t)base_log, (uint32_t)level, num_samples, num_many_lut,
+                                       lut_stride);
+  cleanup_cuda_programmable_bootstrap_64(s, g, &pbs_buffer);
+}
+
+// gpu/ffi.rs:208-309 `programmable_bootstrap_multi_bit_async`
+inline void programmable_bootstrap_multi_bit(const CudaStreams &streams, CudaVec<uint64_t> &lwe_array_out,
+                                             const CudaVec<uint64_t> &output_indexes, const CudaVec<uint64_t> &test_vector,
+                                             const CudaVec<uint64_t> &test_vector_indexes, const CudaVec<uint64_t> &lwe_array_in,
+                                             const CudaVec<uint64_t> &input_indexes, const CudaVec<uint64_t> &bootstrapping_key,
+                                             size_t lwe_dimension, size_t glwe_dimension, size_t polynomial_size, size_t base_log,
+                                             size_t level, size_t grouping_factor, uint32_t num_samples) {
+  const uint32_t num_many_lut = 1, lut_stride = 0;
+  int8_t *pbs_buffer = nullptr;
+  void *s = streams.ptr[0];
+  const uint32_t g = streams.gpu_indexes[0].get();
+  scratch_cuda_multi_bit_programmable_bootstrap_64_async(s, g, &pbs_buffer, (uint32_t)glwe_dimension, (uint32_t)polynomial_size,
+                                                         (uint32_t)level, num_samples, true);
+  cuda_multi_bit_programmable_bootstrap_64_async(
+      s, g, lwe_array_out.as_mut_c_ptr(0), output_indexes.as_c_ptr(0), test_vector.as_c_ptr(0), test_vector_indexes.as_c_ptr(0),
+      lwe_array_in.as_c_ptr(0), input_indexes.as_c_ptr(0), bootstrapping_key.as_c_ptr(0), pbs_buffer, (uint32_t)lwe_dimension,
+      (uint32_t)glwe_dimension, (uint32_t)polynomial_size, (uint32_t)grouping_factor, (uint32_t)base_log, (uint32_t)level,
+      num_samples, num_many_lut, lut_stride);
+  cleanup_cuda_multi_bit_programmable_bootstrap_64(s, g, &pbs_buffer);
+}
+
+// gpu/ffi.rs:503-618 `keyswitch_async` / `keyswitch_async_gemm`
+inline void keyswitch(const CudaStreams &streams, CudaVec<uint64_t> &lwe_array_out, const CudaVec<uint64_t> &lwe_out_indexes,
+                      const CudaVec<uint64_t> &lwe_array_in, const CudaVec<uint64_t> &lwe_in_indexes, size_t input_lwe_dimension,
+                      size_t output_lwe_dimension, const CudaVec<uint64_t> &keyswitch_key, size_t base_log, size_t l_gadget,
+                      uint32_t num_samples, bool uses_trivial_indices, bool use_gemm_ks) {
+  void *s = streams.ptr[0];
+  const uint32_t g = streams.gpu_indexes[0].get();
+  if (use_gemm_ks)
+    cuda_keyswitch_gemm_64_64_async(s, g, lwe_array_out.as_mut_c_ptr(0), lwe_out_indexes.as_c_ptr(0), lwe_array_in.as_c_ptr(0),
+                                    lwe_in_indexes.as_c_ptr(0), keyswitch_key.as_c_ptr(0), (uint32_t)input_lwe_dimension,
+                                    (uint32_t)output_lwe_dimension, (uint32_t)base_log, (uint32_t)l_gadget, num_samples,
+                                    uses_trivial_indices);
+  else
+    cuda_keyswitch_lwe_ciphertext_vector_64_64_async(s, g, lwe_array_out.as_mut_c_ptr(0), lwe_out_indexes.as_c_ptr(0),
+                                                     lwe_array_in.as_c_ptr(0), lwe_in_indexes.as_c_ptr(0), keyswitch_key.as_c_ptr(0),
+                                                     (uint32_t)input_lwe_dimension, (uint32_t)output_lwe_dimension,
+                                                     (uint32_t)base_log, (uint32_t)l_gadget, num_samples);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// gpu/algorithms — the checked entry points
+// ---------------------------------------------------------------------------------------------------------------------
+
+// gpu/algorithms/lwe_programmable_bootstrapping.rs:10-136 (the assertions and their messages are the reference's)
+inline void cuda_programmable_bootstrap_lwe_ciphertext(const CudaLweCiphertextList<uint64_t> &input,
+                                                       CudaLweCiphertextList<uint64_t> &output,
+                                                       const CudaGlweCiphertextList<uint64_t> &accumulator,
+                                                       const CudaVec<uint64_t> &lut_indexes, const CudaVec<uint64_t> &output_indexes,
+                                                       const CudaVec<uint64_t> &input_indexes, const CudaLweBootstrapKey &bsk,
+                                                       const CudaStreams &streams) {
+  using detail::assert_eq;
+  assert_eq(input.lwe_dimension(), bsk.input_lwe_dimension(), "Mismatched input LweDimension.");
+  assert_eq(output.lwe_dimension(), bsk.output_lwe_dimension(), "Mismatched output LweDimension.");
+  assert_eq(accumulator.glwe_dimension(), bsk.glwe_dimension(), "Mismatched GlweSize.");
+  assert_eq(accumulator.polynomial_size(), bsk.polynomial_size(), "Mismatched PolynomialSize.");
+  assert_eq(output.ciphertext_modulus(), accumulator.ciphertext_modulus(), "Mismatched CiphertextModulus between output and accumulator");
+  assert_eq(streams.gpu_indexes[0], bsk.d_vec.gpu_index(0), "GPU error: first stream and first bsk pointer are on different GPUs");
+  assert_eq(streams.gpu_indexes[0], input.d_vec.gpu_index(0), "GPU error: first stream and first input pointer are on different GPUs");
+  assert_eq(streams.gpu_indexes[0], output.d_vec.gpu_index(0), "GPU error: first stream and first output pointer are on different GPUs");
+  assert_eq(streams.gpu_indexes[0], accumulator.d_vec.gpu_index(0), "GPU error: first stream and first accumulator pointer are on different GPUs");
+  assert_eq(streams.gpu_indexes[0], input_indexes.gpu_index(0), "GPU error: first stream and first input indexes pointer are on different GPUs");
+  assert_eq(streams.gpu_indexes[0], output_indexes.gpu_index(0), "GPU error: first stream and first output indexes pointer are on different GPUs");
+  assert_eq(streams.gpu_indexes[0], lut_indexes.gpu_index(0), "GPU error: first stream and first lut indexes pointer are on different GPUs");
+  programmable_bootstrap(streams, output.d_vec, output_indexes, accumulator.d_vec, lut_indexes, input.d_vec, input_indexes, bsk.d_vec,
+                         input.lwe_dimension(), bsk.glwe_dimension(), bsk.polynomial_size(), bsk.decomp_base_log(),
+                         bsk.decomp_level_count(), (uint32_t)input.lwe_ciphertext_count(), bsk.ms_noise_reduction_configuration);
+}
+
+// gpu/algorithms/lwe_multi_bit_programmable_bootstrapping.rs:10-145
+inline void cuda_multi_bit_programmable_bootstrap_lwe_ciphertext(
+    const CudaLweCiphertextList<uint64_t> &input, CudaLweCiphertextList<uint64_t> &output,
+    const CudaGlweCiphertextList<uint64_t> &accumulator, const CudaVec<uint64_t> &lut_indexes,
+    const CudaVec<uint64_t> &output_indexes, const CudaVec<uint64_t> &input_indexes, const CudaLweMultiBitBootstrapKey &multi_bit_bsk,
+    const CudaStreams &streams) {
+  using detail::assert_eq;
+  assert_eq(input.lwe_dimension(), multi_bit_bsk.input_lwe_dimension(), "Mismatched input LweDimension.");
+  assert_eq(output.lwe_dimension(), multi_bit_bsk.output_lwe_dimension(), "Mismatched output LweDimension.");
+  assert_eq(accumulator.glwe_dimension(), multi_bit_bsk.glwe_dimension(), "Mismatched GlweSize.");
+  assert_eq(accumulator.polynomial_size(), multi_bit_bsk.polynomial_size(), "Mismatched PolynomialSize.");
+  assert_eq(input.ciphertext_modulus(), output.ciphertext_modulus(), "Mismatched CiphertextModulus between input and output");
+  assert_eq(input.ciphertext_modulus(), accumulator.ciphertext_modulus(), "Mismatched CiphertextModulus between input and accumulator");
+  assert_eq(streams.gpu_indexes[0], multi_bit_bsk.d_vec.gpu_index(0), "GPU error: first stream and first bsk pointer are on different GPUs");
+  assert_eq(streams.gpu_indexes[0], input.d_vec.gpu_index(0), "GPU error: first stream and first input pointer are on different GPUs");
+  assert_eq(streams.gpu_indexes[0], output.d_vec.gpu_index(0), "GPU error: first stream and first output pointer are on different GPUs");
+  assert_eq(streams.gpu_indexes[0], accumulator.d_vec.gpu_index(0), "GPU error: first stream and first accumulator pointer are on different GPUs");
+  programmable_bootstrap_multi_bit(streams, output.d_vec, output_indexes, accumulator.d_vec, lut_indexes, input.d_vec, input_indexes,
+                                   multi_bit_bsk.d_vec, input.lwe_dimension(), multi_bit_bsk.glwe_dimension(),
+                                   multi_bit_bsk.polynomial_size(), multi_bit_bsk.decomp_base_log(), multi_bit_bsk.decomp_level_count(),
+                                   multi_bit_bsk.grouping_factor(), (uint32_t)input.lwe_ciphertext_count());
+}
+
+// gpu/algorithms/lwe_keyswitch.rs:12-143.  `input_indexes.len` LWEs are keyswitched (a subset of the input list
+// when shorter: the reference's own test keyswitches half of a list this way)
+inline void cuda_keyswitch_lwe_ciphertext(const CudaLweKeyswitchKey<uint64_t> &lwe_keyswitch_key,
+                                          const CudaLweCiphertextList<uint64_t> &input_lwe_ciphertext,
+                                          CudaLweCiphertextList<uint64_t> &output_lwe_ciphertext,
+                                          const CudaVec<uint64_t> &input_indexes, const CudaVec<uint64_t> &output_indexes,
+                                          bool uses_trivial_indices, const CudaStreams &streams, bool use_gemm_ks) {
+  using detail::assert_eq;
+  assert_eq(lwe_keyswitch_key.input_key_lwe_dimension(), input_lwe_ciphertext.lwe_dimension(),
+            "Mismatched input LweDimension between LweKeyswitchKey and input LweCiphertext.");
+  assert_eq(lwe_keyswitch_key.output_key_lwe_dimension(), output_lwe_ciphertext.lwe_dimension(),
+            "Mismatched output LweDimension between LweKeyswitchKey and output LweCiphertext.");
+  assert_eq(lwe_keyswitch_key.ciphertext_modulus(), output_lwe_ciphertext.ciphertext_modulus(),
+            "Mismatched CiphertextModulus. LweKeyswitchKey CiphertextModulus vs output LweCiphertext CiphertextModulus.");
+  detail::assert_true(lwe_keyswitch_key.ciphertext_modulus().is_compatible_with_native_modulus(),
+                      "This operation currently only supports power of 2 moduli");
+  assert_eq(streams.gpu_indexes[0], input_lwe_ciphertext.d_vec.gpu_index(0), "GPU error: first stream and first input pointer are on different GPUs");
+  assert_eq(streams.gpu_indexes[0], output_lwe_ciphertext.d_vec.gpu_index(0), "GPU error: first stream and first output pointer are on different GPUs");
+  assert_eq(streams.gpu_indexes[0], input_indexes.gpu_index(0), "GPU error: first stream and first input indexes pointer are on different GPUs");
+  assert_eq(streams.gpu_indexes[0], output_indexes.gpu_index(0), "GPU error: first stream and first output indexes pointer are on different GPUs");
+  assert_eq(streams.gpu_indexes[0], lwe_keyswitch_key.d_vec.gpu_index(0), "GPU error: first stream and first ksk pointer are on different GPUs");
+  keyswitch(streams, output_lwe_ciphertext.d_vec, output_indexes, input_lwe_ciphertext.d_vec, input_indexes,
+            input_lwe_ciphertext.lwe_dimension(), output_lwe_ciphertext.lwe_dimension(), lwe_keyswitch_key.d_vec,
+            lwe_keyswitch_key.decomposition_base_log(), lwe_keyswitch_key.decomposition_level_count(), (uint32_t)input_indexes.len,
+            uses_trivial_indices, use_gemm_ks);
+}
+
+// gpu/algorithms/glwe_sample_extraction.rs:12-92 + gpu/ffi.rs:838-883
+inline void cuda_extract_lwe_samples_from_glwe_ciphertext_list(const CudaGlweCiphertextList<uint64_t> &input_glwe_list,
+                                                               CudaLweCiphertextList<uint64_t> &output_lwe_list,
+                                                               const std::vector<uint32_t> &vec_nth, uint32_t lwe_per_glwe,
+                                                               const CudaStreams &streams) {
+  using detail::assert_eq;
+  const size_t in_lwe_dim = input_glwe_list.glwe_dimension() * input_glwe_list.polynomial_size();
+  assert_eq(in_lwe_dim, output_lwe_list.lwe_dimension(),
+            "Mismatch between equivalent LweDimension of input ciphertext and output ciphertext.");
+  assert_eq(vec_nth.size(), output_lwe_list.lwe_ciphertext_count(),
+            "Mismatch between number of nths and number of LWEs in output list");
+  assert_eq(output_lwe_list.lwe_ciphertext_count(), input_glwe_list.glwe_ciphertext_count() * lwe_per_glwe,
+            "Mismatch between number of LWEs to extract and GLWE count times LWEs per GLWE");
+  assert_eq(input_glwe_list.ciphertext_modulus(), output_lwe_list.ciphertext_modulus(),
+            "Mismatched moduli between input_glwe and output_lwe");
+  assert_eq(streams.gpu_indexes[0], input_glwe_list.d_vec.gpu_index(0), "GPU error: first stream and first input pointer are on different GPUs");
+  assert_eq(streams.gpu_indexes[0], output_lwe_list.d_vec.gpu_index(0), "GPU error: first stream and first output pointer are on different GPUs");
+  CudaVec<uint32_t> d_nth_array = CudaVec<uint32_t>::from_cpu_async(vec_nth, streams, 0);
+  cuda_glwe_sample_extract_64_async(streams.ptr[0], streams.gpu_indexes[0].get(), output_lwe_list.d_vec.as_mut_c_ptr(0),
+                                    input_glwe_list.d_vec.as_c_ptr(0), (const uint32_t *)d_nth_array.as_c_ptr(0),
+                                    (uint32_t)vec_nth.size(), lwe_per_glwe, (uint32_t)input_glwe_list.polynomial_size(),
+                                    (uint32_t)input_glwe_list.glwe_dimension(), (uint32_t)input_glwe_list.polynomial_size());
+  streams.synchronize();
+}
+
+}  // namespace tfhe::core_crypto::gpu
