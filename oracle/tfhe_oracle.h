@@ -18,6 +18,11 @@
  *     apps/test-vectors/checksums.sha256 (the .cbor payloads are Git-LFS stubs, the digests are
  *     not).  This pins modulus switch, decomposer, monomial ops, keyswitch, GGSW/GLWE encryption
  *     layout, blind rotation order and sample extraction.
+ *   - PINNED IN PHASE to bytes the reference's GPU backend produced at the BASELINE parameter sets:
+ *     tests/test_pbs_golden.py regenerates keys, bootstrap keys and inputs of the reference's GPU golden-value
+ *     test (tfhe/src/core_crypto/gpu/algorithms/test/pbs_golden: PARAM_MESSAGE_2_CARRY_2 and multi-bit g = 4,
+ *     captured on an H100) from its fixed seed; the golden ciphertexts decrypt under the regenerated key and
+ *     the exact and f64 engines of this oracle (classic AND multi-bit) land within 2^51 of them in phase.
  *   - integer pieces are additionally pinned against the value tables / doc-test vectors of the
  *     reference's unit tests (tests/golden/reference_kats.json, tests/golden/make_golden.py).
  *   - NTT path: exact ring arithmetic over the pinned pieces + the reference's fixed Goldilocks
