@@ -329,9 +329,25 @@ static void base_lwe_encrypt_ks_decrypt_custom_mod(size_t lwe_dimension, double 
         CudaLweCiphertextList<u64> output_ct_list_gpu_bis = zero_out();
         cuda_keyswitch_lwe_ciphertext(d_ksk_big_to_small, input_ct_list_gpu, output_ct_list_gpu_bis, d_input_indexes, d_output_indexes,
                                       use_trivial_indexes, stream, use_gemm);
-        assert_gpu_determinism((use_gemm ? output_ct_list_gpu_gemm : output_ct_list_gpu).to_lwe_ciphertext_list(stream),
-                               output_ct_list_gpu_bis.to_lwe_ciphertext_list(stream),
-                               use_gemm ? "cuda_keyswitch_lwe_ciphertext (GEMM)" : "cuda_keyswitch_lwe_ciphertext");
+        const std::vector<u64> first = (use_gemm ? output_ct_list_gpu_gemm : output_ct_list_gpu).to_lwe_ciphertext_list(stream),
+                               second = output_ct_list_gpu_bis.to_lwe_ciphertext_list(stream);
+        if (first != second) {  // which of the two runs left the checker's keyswitch, and where (sample positions s = tile * 32 + row)
+          for (const std::vector<u64> *run : {&first, &second}) {
+            std::string where;
+            size_t bad = 0;
+            for (size_t i = 0; i < num_blocks_to_ks; ++i) {
+              std::vector<u64> want(lwe_dimension + 1);
+              orc_keyswitch(want.data(), &input_ct_list[lwe_indexes[i] * (big_lwe_sk.size() + 1)], ksk_big_to_small.data(),
+                            (uint32_t)big_lwe_sk.size(), (uint32_t)lwe_dimension, (uint32_t)ks_decomp_base_log, (uint32_t)ks_decomp_level_count);
+              if (!std::equal(want.begin(), want.end(), &(*run)[lwe_indexes_out[i] * (lwe_dimension + 1)])) {
+                if (bad++ < 12) where += " " + std::to_string(i);
+              }
+            }
+            std::printf("  keyswitch of %zu of %zu blocks, %s run: %zu samples differ from the oracle, s =%s\n", num_blocks_to_ks, num_blocks,
+                        run == &first ? "first" : "second", bad, where.c_str());
+          }
+        }
+        assert_gpu_determinism(first, second, use_gemm ? "cuda_keyswitch_lwe_ciphertext (GEMM)" : "cuda_keyswitch_lwe_ciphertext");
       }
       // only the LWEs at the output indices are set; the test checks that the others remain 0
       std::vector<u64> ref_vec(num_blocks, 0);

@@ -4,7 +4,10 @@
 #include "kernels.h"
 
 #include <atomic>
+#include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <unordered_map>
 #include <vector>
 
 using namespace tfhe_hip;
@@ -125,10 +128,41 @@ void *cuda_malloc(uint64_t size, uint32_t gpu_index) {
   HX_CHECK(hipMalloc(&p, size));
   return p;
 }
+// Stream-ordered allocations: the reference pairs cuda_malloc_async with the synchronous cuda_drop (CudaVec::new_async /
+// Drop, tfhe/src/core_crypto/gpu/vec.rs) and falls back to cudaMalloc on devices without memory pools
+// (tfhe-cuda-common/cuda/src/device.cu:176-218).  On this runtime (ROCm 7.2.0, MI355X) hipMallocAsync's pool is not
+// usable that way: in the reference's keyswitch test restated in tests/cpp the index arrays of a LIVE pool allocation
+// changed after other pool allocations were freed and re-made — with hipFree as with hipFreeAsync + device
+// synchronisation, and in a program that uses nothing but the runtime (tools/probes/pool_probe.hip;
+// profiles/r04h_ks_cpp_diag*.txt).  cuda_malloc_async is therefore a plain hipMalloc by default — every launch of this
+// library takes its scratch from scratch_* calls, so nothing on the hot path allocates — and the pool stays
+// selectable for diagnosis: TFHE_HIP_MALLOC_ASYNC=pool (pool pointers remembered with their sizes, returned with
+// hipFreeAsync + hipDeviceSynchronize by cuda_drop) or pool_hipfree (returned with hipFree).
+static std::mutex g_pool_mutex;
+static std::unordered_map<const void *, size_t> g_pool_allocations;
+static int malloc_async_mode() {  // 1 = hipMalloc (default), 0 = pool + tracked free, 2 = pool + hipFree (both: diagnosis)
+  static const int mode = [] {
+    const char *e = std::getenv("TFHE_HIP_MALLOC_ASYNC");
+    if (e == nullptr || !std::strcmp(e, "sync")) return 1;
+    if (!std::strcmp(e, "pool")) return 0;
+    if (!std::strcmp(e, "pool_hipfree")) return 2;
+    HX_PANIC("TFHE_HIP_MALLOC_ASYNC=%s: expected pool, sync or pool_hipfree", e);
+    return 0;
+  }();
+  return mode;
+}
 void *cuda_malloc_async(uint64_t size, void *stream, uint32_t gpu_index) {
   set_device(gpu_index);
   void *p = nullptr;
+  if (malloc_async_mode() == 1) {
+    HX_CHECK(hipMalloc(&p, size));
+    return p;
+  }
   HX_CHECK(hipMallocAsync(&p, size, S(stream)));
+  if (malloc_async_mode() == 0 && p != nullptr) {
+    std::lock_guard<std::mutex> lock(g_pool_mutex);
+    g_pool_allocations[p] = size;
+  }
   return p;
 }
 bool cuda_check_valid_malloc(uint64_t size, uint32_t gpu_index) {
@@ -191,6 +225,23 @@ void cuda_synchronize_device(uint32_t gpu_index) {
 }
 void cuda_drop(void *ptr, uint32_t gpu_index) {
   set_device(gpu_index);
+  size_t pool_bytes = 0;
+  bool from_pool = false;
+  if (ptr != nullptr) {
+    std::lock_guard<std::mutex> lock(g_pool_mutex);
+    auto it = g_pool_allocations.find(ptr);
+    if (it != g_pool_allocations.end()) {
+      from_pool = true;
+      pool_bytes = it->second;
+      g_pool_allocations.erase(it);
+    }
+  }
+  if (from_pool) {
+    ksm_invalidate_range((int)gpu_index, ptr, pool_bytes);  // the allocation's own bytes, not the pool's block
+    HX_CHECK(hipFreeAsync(ptr, nullptr));
+    HX_CHECK(hipDeviceSynchronize());  // cudaFree synchronises; the memory is back in the pool for every stream
+    return;
+  }
   if (ptr != nullptr && ksm_cache_entries() != 0) {
     // a keyswitch key inside this allocation takes its cached matrix-core layout with it
     void *base = ptr;
