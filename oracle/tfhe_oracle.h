@@ -68,6 +68,9 @@ void orc_monomial_mul_and_sub(uint64_t *out, const uint64_t *in, uint32_t N, uin
 void orc_sample_extract(uint64_t *lwe_out, const uint64_t *glwe, uint32_t k, uint32_t N, uint32_t nth);
 void orc_keyswitch(uint64_t *lwe_out, const uint64_t *lwe_in, const uint64_t *ksk,
                    uint32_t n_in, uint32_t n_out, uint32_t base_log, uint32_t level);
+/* u64 ciphertext, u32 key -> u32 ciphertext (keyswitch_lwe_ciphertext_with_scalar_change: the KS32 pattern) */
+void orc_keyswitch_64_32(uint32_t *lwe_out, const uint64_t *lwe_in, const uint32_t *ksk,
+                         uint32_t n_in, uint32_t n_out, uint32_t base_log, uint32_t level);
 void orc_generate_lut(uint64_t *glwe_out, uint32_t k, uint32_t N, uint32_t message_modulus,
                       uint64_t delta, const uint64_t *f_table);
 

@@ -8,6 +8,7 @@
 //   lwe_encrypt_centered_ms_pbs_decrypt            …/lwe_programmable_bootstrapping.rs:202-380
 //   lwe_encrypt_multi_bit_pbs_decrypt_custom_mod   …/lwe_multi_bit_programmable_bootstrapping.rs:11-211
 //   lwe_encrypt_ks_decrypt_custom_mod(_mb)         …/lwe_keyswitch.rs:14-312
+//   lwe_encrypt_ks_decrypt_custom_mod_ks32         …/lwe_keyswitch.rs:314-523
 //   glwe_encrypt_sample_extract_decrypt_custom_mod …/glwe_sample_extraction.rs:14-149
 //   compare_cpu_and_gpu_centered_modulus_switch    …/modulus_switch.rs:276-361, :386-488 (the four cooperative dimensions)
 //   assert_gpu_determinism / should_check_determinism   …/test/mod.rs:34-84
@@ -372,6 +373,58 @@ static void lwe_encrypt_ks_decrypt_custom_mod_mb(const MultiBitTestParams &p) { 
                                          p.decomp_level_count);
 }
 
+// lwe_keyswitch.rs:314-523 `lwe_encrypt_ks_decrypt_ks32_common` on MULTI_BIT_2_2_2_KS32_PARAMS (test/mod.rs:92-108): u64
+// ciphertexts under the big key, a u32 keyswitch key, u32 outputs; classic and GEMM keyswitch equal the CPU's
+// keyswitch_lwe_ciphertext_with_scalar_change word for word and decrypt under the small key on 32 bits
+static void lwe_encrypt_ks_decrypt_custom_mod_ks32() {
+  const size_t lwe_dimension = g_toy ? 24 : 920, glwe_dimension = 1, polynomial_size = g_toy ? 256 : 2048, ks_decomp_base_log = 3,
+               ks_decomp_level_count = 5, message_modulus_log = 2;
+  const uint32_t noise_bound_log2 = 13;
+  const u64 input_msg_modulus = u64(1) << message_modulus_log, input_delta = (u64(1) << 63) / input_msg_modulus;
+  const uint32_t output_delta = (uint32_t(1) << 31) >> message_modulus_log;
+  CudaStreams stream = CudaStreams::new_single_gpu(GpuIndex(0));
+  TestResources rsc(37);
+  const std::vector<u64> lwe_sk = binary_key(rsc, lwe_dimension), big_lwe_sk = binary_key(rsc, glwe_dimension * polynomial_size);
+  // allocate_and_generate_new_lwe_keyswitch_key on u32: block i, level l first, encrypts s_i * 2^(32 - base_log * level)
+  std::vector<uint32_t> ksk(big_lwe_sk.size() * ks_decomp_level_count * (lwe_dimension + 1));
+  orc_rng *r = &rsc.encryption_random_generator;
+  for (size_t i = 0, row = 0; i < big_lwe_sk.size(); ++i)
+    for (size_t lvl = ks_decomp_level_count; lvl >= 1; --lvl, ++row) {
+      uint32_t *ct = &ksk[row * (lwe_dimension + 1)];
+      uint32_t b = (uint32_t)(big_lwe_sk[i] << (32 - ks_decomp_base_log * lvl)) + (uint32_t)orc_rng_tuniform(r, noise_bound_log2);
+      for (size_t j = 0; j < lwe_dimension; ++j) {
+        ct[j] = (uint32_t)orc_rng_next(r);
+        if (lwe_sk[j]) b += ct[j];
+      }
+      ct[lwe_dimension] = b;
+    }
+  const auto d_ksk = CudaLweKeyswitchKey<uint32_t>::from_lwe_keyswitch_key(ksk, big_lwe_sk.size(), lwe_dimension, ks_decomp_base_log,
+                                                                             ks_decomp_level_count, stream);
+  for (u64 msg = input_msg_modulus; msg-- != 0;)
+    for (size_t t = 0; t < nb_tests(); ++t) {
+      const std::vector<u64> ct = encrypt_lwe(rsc, big_lwe_sk, msg * input_delta, tuniform((int)noise_bound_log2));
+      std::vector<uint32_t> output_ct_ref(lwe_dimension + 1);
+      orc_keyswitch_64_32(output_ct_ref.data(), ct.data(), ksk.data(), (uint32_t)big_lwe_sk.size(), (uint32_t)lwe_dimension,
+                          (uint32_t)ks_decomp_base_log, (uint32_t)ks_decomp_level_count);
+      auto decode32 = [&](const std::vector<uint32_t> &c) {
+        uint32_t ph = c[lwe_dimension];
+        for (size_t j = 0; j < lwe_dimension; ++j)
+          if (lwe_sk[j]) ph -= c[j];
+        return (u64)((ph / output_delta + (ph % output_delta >= (output_delta >> 1))) % (uint32_t)input_msg_modulus);
+      };
+      CHECK_EQ(decode32(output_ct_ref), msg);
+      const auto d_ct = CudaLweCiphertextList<u64>::from_lwe_ciphertext(ct, CiphertextModulus::new_native(), stream);
+      CudaLweCiphertextList<uint32_t> d_output_ct(lwe_dimension, 1, CiphertextModulus{32}, stream), d_output_ct_gemm(lwe_dimension, 1, CiphertextModulus{32}, stream);
+      const CudaVec<u64> d_input_indexes = device_indexes({0}, stream), d_output_indexes = device_indexes({0}, stream);
+      cuda_keyswitch_lwe_ciphertext(d_ksk, d_ct, d_output_ct, d_input_indexes, d_output_indexes, true, stream, false);
+      cuda_keyswitch_lwe_ciphertext(d_ksk, d_ct, d_output_ct_gemm, d_input_indexes, d_output_indexes, true, stream, true);
+      const std::vector<uint32_t> output_ct = d_output_ct.into_lwe_ciphertext(stream), output_ct_gemm = d_output_ct_gemm.into_lwe_ciphertext(stream);
+      CHECK(output_ct == output_ct_ref);
+      CHECK(output_ct_gemm == output_ct_ref);
+      CHECK_EQ(decode32(output_ct), msg);
+    }
+}
+
 // glwe_sample_extraction.rs:14-149
 static void glwe_encrypt_sample_extract_decrypt_custom_mod(const ClassicTestParams &params) {
   const size_t glwe_dimension = params.glwe_dimension, polynomial_size = params.polynomial_size;
@@ -515,6 +568,7 @@ int main(int argc, char **argv) {
     // MULTI_BIT_3_3_2 / 3_3_3 (N = 8192): the CPU-side key generation of the checker takes minutes; run by name only
     if (std::strstr(filter, "3_3_2")) multi_bit(MULTI_BIT_3_3_2_PARAMS, true);
   }
+  tests.push_back({"test_gpu_lwe_encrypt_ks_decrypt_custom_mod_ks32_multi_bit_2_2_2_ks32_params", lwe_encrypt_ks_decrypt_custom_mod_ks32});
   tests.push_back({"compare_cpu_and_gpu_centered_modulus_switch", compare_cpu_and_gpu_centered_modulus_switch});
   tests.push_back({"mismatched_dimensions_panic", mismatched_dimensions_panic});
 

@@ -402,6 +402,7 @@ class CudaLweKeyswitchKey {
     k.output_lwe_size_ = output_key_lwe_dimension + 1;
     k.decomp_base_log_ = decomp_base_log;
     k.decomp_level_count_ = decomp_level_count;
+    k.ciphertext_modulus_ = CiphertextModulus{8 * (uint32_t)sizeof(T)};  // native modulus of the key scalar
     k.d_vec = CudaVec<T>::new_multi_gpu(h_ksk.size(), streams);
     k.d_vec.copy_from_cpu_multi_gpu_async(h_ksk.data(), h_ksk.size(), streams);
     streams.synchronize();
@@ -461,23 +462,26 @@ inline void programmable_bootstrap_multi_bit(const CudaStreams &streams, CudaVec
   cleanup_cuda_multi_bit_programmable_bootstrap_64(s, g, &pbs_buffer);
 }
 
-// gpu/ffi.rs:503-618 `keyswitch_async` / `keyswitch_async_gemm`
-inline void keyswitch(const CudaStreams &streams, CudaVec<uint64_t> &lwe_array_out, const CudaVec<uint64_t> &lwe_out_indexes,
+// gpu/ffi.rs:503-618 `keyswitch_async` / `keyswitch_async_gemm`: u64 input ciphertexts; the key scalar selects the 64 -> 64
+// or the 64 -> 32 entry points (the KS32 atomic pattern: u32 key, u32 output ciphertexts)
+template <class KeyT>
+inline void keyswitch(const CudaStreams &streams, CudaVec<KeyT> &lwe_array_out, const CudaVec<uint64_t> &lwe_out_indexes,
                       const CudaVec<uint64_t> &lwe_array_in, const CudaVec<uint64_t> &lwe_in_indexes, size_t input_lwe_dimension,
-                      size_t output_lwe_dimension, const CudaVec<uint64_t> &keyswitch_key, size_t base_log, size_t l_gadget,
+                      size_t output_lwe_dimension, const CudaVec<KeyT> &keyswitch_key, size_t base_log, size_t l_gadget,
                       uint32_t num_samples, bool uses_trivial_indices, bool use_gemm_ks) {
+  static_assert(sizeof(KeyT) == 8 || sizeof(KeyT) == 4, "keyswitch keys are u64 or u32");
   void *s = streams.ptr[0];
   const uint32_t g = streams.gpu_indexes[0].get();
-  if (use_gemm_ks)
-    cuda_keyswitch_gemm_64_64_async(s, g, lwe_array_out.as_mut_c_ptr(0), lwe_out_indexes.as_c_ptr(0), lwe_array_in.as_c_ptr(0),
-                                    lwe_in_indexes.as_c_ptr(0), keyswitch_key.as_c_ptr(0), (uint32_t)input_lwe_dimension,
-                                    (uint32_t)output_lwe_dimension, (uint32_t)base_log, (uint32_t)l_gadget, num_samples,
-                                    uses_trivial_indices);
-  else
-    cuda_keyswitch_lwe_ciphertext_vector_64_64_async(s, g, lwe_array_out.as_mut_c_ptr(0), lwe_out_indexes.as_c_ptr(0),
-                                                     lwe_array_in.as_c_ptr(0), lwe_in_indexes.as_c_ptr(0), keyswitch_key.as_c_ptr(0),
-                                                     (uint32_t)input_lwe_dimension, (uint32_t)output_lwe_dimension,
-                                                     (uint32_t)base_log, (uint32_t)l_gadget, num_samples);
+  void *out = lwe_array_out.as_mut_c_ptr(0);
+  const void *oi = lwe_out_indexes.as_c_ptr(0), *in = lwe_array_in.as_c_ptr(0), *ii = lwe_in_indexes.as_c_ptr(0), *k = keyswitch_key.as_c_ptr(0);
+  const uint32_t ni = (uint32_t)input_lwe_dimension, no = (uint32_t)output_lwe_dimension, bl = (uint32_t)base_log, lv = (uint32_t)l_gadget;
+  if (sizeof(KeyT) == 8) {
+    if (use_gemm_ks) cuda_keyswitch_gemm_64_64_async(s, g, out, oi, in, ii, k, ni, no, bl, lv, num_samples, uses_trivial_indices);
+    else cuda_keyswitch_lwe_ciphertext_vector_64_64_async(s, g, out, oi, in, ii, k, ni, no, bl, lv, num_samples);
+  } else {
+    if (use_gemm_ks) cuda_keyswitch_gemm_64_32_async(s, g, out, oi, in, ii, k, ni, no, bl, lv, num_samples, uses_trivial_indices);
+    else cuda_keyswitch_lwe_ciphertext_vector_64_32_async(s, g, out, oi, in, ii, k, ni, no, bl, lv, num_samples);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -534,9 +538,10 @@ inline void cuda_multi_bit_programmable_bootstrap_lwe_ciphertext(
 
 // gpu/algorithms/lwe_keyswitch.rs:12-143.  `input_indexes.len` LWEs are keyswitched (a subset of the input list
 // when shorter: the reference's own test keyswitches half of a list this way)
-inline void cuda_keyswitch_lwe_ciphertext(const CudaLweKeyswitchKey<uint64_t> &lwe_keyswitch_key,
+template <class KeyT>
+inline void cuda_keyswitch_lwe_ciphertext(const CudaLweKeyswitchKey<KeyT> &lwe_keyswitch_key,
                                           const CudaLweCiphertextList<uint64_t> &input_lwe_ciphertext,
-                                          CudaLweCiphertextList<uint64_t> &output_lwe_ciphertext,
+                                          CudaLweCiphertextList<KeyT> &output_lwe_ciphertext,
                                           const CudaVec<uint64_t> &input_indexes, const CudaVec<uint64_t> &output_indexes,
                                           bool uses_trivial_indices, const CudaStreams &streams, bool use_gemm_ks) {
   using detail::assert_eq;
