@@ -9,6 +9,7 @@
 //   lwe_encrypt_multi_bit_pbs_decrypt_custom_mod   …/lwe_multi_bit_programmable_bootstrapping.rs:11-211
 //   lwe_encrypt_ks_decrypt_custom_mod(_mb)         …/lwe_keyswitch.rs:14-312
 //   lwe_encrypt_ks_decrypt_custom_mod_ks32         …/lwe_keyswitch.rs:314-523
+//   test_(round_to_)closest_representable_gpu      …/lwe_keyswitch.rs:525-609
 //   glwe_encrypt_sample_extract_decrypt_custom_mod …/glwe_sample_extraction.rs:14-149
 //   compare_cpu_and_gpu_centered_modulus_switch    …/modulus_switch.rs:276-361, :386-488 (the four cooperative dimensions)
 //   assert_gpu_determinism / should_check_determinism   …/test/mod.rs:34-84
@@ -425,6 +426,49 @@ static void lwe_encrypt_ks_decrypt_custom_mod_ks32() {
     }
 }
 
+// lwe_keyswitch.rs:525-556
+static u64 test_util_closest_representable_on_gpu(u64 value, uint32_t base_log, uint32_t level_count) {
+  CudaStreams stream = CudaStreams::new_single_gpu(GpuIndex(0));
+  CudaVec<u64> d_input = CudaVec<u64>::new_async(1, stream, 0);
+  const std::vector<u64> h_input{value};
+  d_input.copy_from_cpu_async(h_input, stream, 0);
+  CudaVec<u64> d_output = CudaVec<u64>::new_async(1, stream, 0);
+  cuda_closest_representable(stream, d_input, d_output, base_log, level_count);
+  std::vector<u64> h_output{0};
+  d_output.copy_to_cpu_async(h_output.data(), 1, stream, 0);
+  stream.synchronize();
+  return h_output[0];
+}
+// lwe_keyswitch.rs:558-577: a value whose decomposition state starts negative (a logical shift instead of an arithmetic one
+// on the last level loses the sign when base_log * (level_count + 1) > 64)
+static void test_closest_representable_gpu() {
+  const uint32_t base_log = 17, level_count = 3;
+  const u64 val = 0x800000e355b0c827ull;
+  const u64 rounded = orc_closest_representable(val, base_log, level_count);
+  std::vector<int64_t> digits(level_count);
+  orc_decompose(val, base_log, level_count, digits.data());  // digits[0] <-> level `level_count`
+  u64 recomp = 0;
+  for (uint32_t i = 0; i < level_count; ++i) recomp += (u64)digits[i] << (64 - base_log * (level_count - i));
+  CHECK_EQ(rounded, recomp);
+  CHECK_EQ(test_util_closest_representable_on_gpu(val, base_log, level_count), rounded);
+}
+// lwe_keyswitch.rs:579-609: every valid decomposer (math/decomposition/tests.rs:15-30), random values: moving the GPU's
+// result by less than half a representable step does not change its closest representable
+static void test_round_to_closest_representable_gpu() {
+  const size_t runs_per_decomposer = g_toy ? 3 : 100;
+  TestResources rsc(41);
+  for (uint32_t base_log = 1; base_log < 64; ++base_log)
+    for (uint32_t level_count = 1; level_count < 64 && base_log * level_count < 64; ++level_count)
+      for (size_t run = 0; run < runs_per_decomposer; ++run) {
+        const u64 val = orc_rng_next(&rsc.encryption_random_generator);
+        const u64 rounded = test_util_closest_representable_on_gpu(val, base_log, level_count);
+        const u64 epsilon = (u64(1) << (64 - base_log * level_count - 1)) / 2;
+        CHECK_EQ(rounded, orc_closest_representable(rounded + epsilon, base_log, level_count));
+        CHECK_EQ(rounded, orc_closest_representable(rounded - epsilon, base_log, level_count));
+        CHECK_EQ(rounded, orc_closest_representable(val, base_log, level_count));  // and it is the CPU's value (own addition)
+      }
+}
+
 // glwe_sample_extraction.rs:14-149
 static void glwe_encrypt_sample_extract_decrypt_custom_mod(const ClassicTestParams &params) {
   const size_t glwe_dimension = params.glwe_dimension, polynomial_size = params.polynomial_size;
@@ -569,6 +613,8 @@ int main(int argc, char **argv) {
     if (std::strstr(filter, "3_3_2")) multi_bit(MULTI_BIT_3_3_2_PARAMS, true);
   }
   tests.push_back({"test_gpu_lwe_encrypt_ks_decrypt_custom_mod_ks32_multi_bit_2_2_2_ks32_params", lwe_encrypt_ks_decrypt_custom_mod_ks32});
+  tests.push_back({"test_closest_representable_gpu", test_closest_representable_gpu});
+  tests.push_back({"test_round_to_closest_representable_gpu", test_round_to_closest_representable_gpu});
   tests.push_back({"compare_cpu_and_gpu_centered_modulus_switch", compare_cpu_and_gpu_centered_modulus_switch});
   tests.push_back({"mismatched_dimensions_panic", mismatched_dimensions_panic});
 

@@ -36,7 +36,7 @@ def run(exe, *args, timeout):
 def test_reference_gpu_tests_on_the_host_emulation(tmp_path):
     exe = build_tests(build_emu(), str(tmp_path / "reference_gpu_tests_emu"))
     out = run(exe, "toy", timeout=1500)
-    assert out.count(" ... ok") == 15, out
+    assert out.count(" ... ok") == 17, out
 
 
 @pytest.mark.gpu
@@ -44,8 +44,8 @@ def test_reference_gpu_tests_with_the_reference_parameter_sets(tmp_path):
     assert os.path.exists(PRODUCT_LIB)
     exe = build_tests(PRODUCT_LIB, str(tmp_path / "reference_gpu_tests"))
     out = run(exe, "reference", timeout=1500)
-    # 4 classic + 3 multi-bit bootstraps + 2 multi-bit keyswitches + KS32 keyswitch + modulus switch + panics
-    assert out.count(" ... ok") == 12, out
+    # 4 classic + 3 multi-bit bootstraps + 2 multi-bit keyswitches + KS32 keyswitch + 2 closest-representable + modulus switch + panics
+    assert out.count(" ... ok") == 14, out
     print(out)
 
 
@@ -53,4 +53,4 @@ def test_reference_gpu_tests_with_the_reference_parameter_sets(tmp_path):
 def test_reference_gpu_tests_small_sets_on_the_gpu(tmp_path):
     exe = build_tests(PRODUCT_LIB, str(tmp_path / "reference_gpu_tests"))
     out = run(exe, "toy", timeout=600)
-    assert out.count(" ... ok") == 15, out
+    assert out.count(" ... ok") == 17, out

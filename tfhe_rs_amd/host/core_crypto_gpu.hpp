@@ -484,6 +484,14 @@ inline void keyswitch(const CudaStreams &streams, CudaVec<KeyT> &lwe_array_out, 
   }
 }
 
+// gpu/mod.rs `cuda_closest_representable` (lwe_keyswitch.rs' tests use it): one value rounded to the closest value the
+// decomposer (base_log, level_count) represents
+inline void cuda_closest_representable(const CudaStreams &streams, const CudaVec<uint64_t> &input, CudaVec<uint64_t> &output,
+                                       uint32_t base_log, uint32_t level_count) {
+  cuda_closest_representable_64_async(streams.ptr[0], streams.gpu_indexes[0].get(), input.as_c_ptr(0), output.as_mut_c_ptr(0), base_log,
+                                      level_count);
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // gpu/algorithms — the checked entry points
 // ---------------------------------------------------------------------------------------------------------------------
