@@ -1,0 +1,349 @@
+// reference_integer_gpu_tests.cpp — the reference's GPU tests of the radix operations the backend wires,
+// restated in C++ on the compiled host mirror tfhe_rs_amd/host/integer_gpu.hpp (C ABI only) and linked against the
+// library.  Each test follows the generic test case the Rust GPU test instantiates with `GpuFunctionExecutor`:
+//
+//   integer_unchecked_add             integer/gpu/server_key/radix/tests_unsigned/test_add.rs:15-21 -> unchecked_add_test
+//                                     (integer/server_key/radix_parallel/tests_unsigned/test_add.rs:276-330)
+//   integer_add                       …/test_add.rs:29-35 -> default_add_test (…/test_add.rs:448-505)
+//   integer_default_overflowing_add   …/test_add.rs:44 -> default_overflowing_add_test (…/test_add.rs:553-680)
+//   integer_mul                       integer/gpu/server_key/radix/tests_unsigned/test_mul.rs -> default_mul_test
+//                                     (integer/server_key/radix_parallel/tests_cases_unsigned.rs:865-927)
+//   constants NB_CTXT = 4, MAX_NB_CTXT = 8, nb_tests(_smaller)_for_params   …/tests_unsigned/mod.rs:61-125
+//
+// on PARAM_MESSAGE_2_CARRY_2_KS_PBS_TUNIFORM_2M128 and TEST_PARAM_GPU_MULTI_BIT_GROUP_4_MESSAGE_2_CARRY_2_KS_PBS_TUNIFORM_2M128
+// (the first and third set of the reference's lists); "toy": small sets with the same shapes for the host emulation.
+// Test infrastructure: client-side key generation, radix encryption and decryption use the oracle's primitives
+// (oracle/tfhe_oracle.h); randomness is seeded.
+//   usage: reference_integer_gpu_tests <toy|reference> [test-name-substring]
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../oracle/tfhe_oracle.h"
+#include "../../tfhe_rs_amd/host/integer_gpu.hpp"
+
+using namespace tfhe::core_crypto::gpu;
+using namespace tfhe::integer::gpu;
+using u64 = uint64_t;
+
+#define CHECK(c)                                                                                                        \
+  do {                                                                                                                  \
+    if (!(c)) throw std::runtime_error(std::string("assertion failed: ") + #c + " at line " + std::to_string(__LINE__)); \
+  } while (0)
+#define CHECK_EQ(a, b)                                                                                                             \
+  do {                                                                                                                             \
+    auto va = (a);                                                                                                                 \
+    auto vb = (b);                                                                                                                 \
+    if (!(va == vb))                                                                                                               \
+      throw std::runtime_error(std::string("assertion `left == right` failed: ") + #a + " = " + std::to_string(va) + ", " + #b + \
+                               " = " + std::to_string(vb) + " at line " + std::to_string(__LINE__));                               \
+  } while (0)
+
+struct TestParameters {  // shortint parameters (KS-PBS order, encryption under the big key)
+  const char *name;
+  size_t lwe_dimension, glwe_dimension, polynomial_size;
+  uint32_t lwe_noise, glwe_noise;  // TUniform bounds
+  size_t pbs_base_log, pbs_level, ks_base_log, ks_level;
+  u64 message_modulus, carry_modulus;
+  size_t grouping_factor;  // 0: classic PBS
+  bool centered_ms;        // ModulusSwitchType::CenteredMeanNoiseReduction
+};
+// shortint/parameters/v1_*/classic/tuniform/p_fail_2_minus_128/ks_pbs.rs:28-47, v1_*/multi_bit/tuniform/p_fail_2_minus_128/ks_pbs_gpu.rs:205-228
+static const TestParameters PARAM_MESSAGE_2_CARRY_2_KS_PBS_TUNIFORM_2M128 = {"param_message_2_carry_2_ks_pbs_tuniform_2m128", 918, 1, 2048, 45, 17, 23, 1, 4, 4,
+                                                                           4, 4, 0, true};
+static const TestParameters TEST_PARAM_GPU_MULTI_BIT_GROUP_4_MESSAGE_2_CARRY_2_KS_PBS_TUNIFORM_2M128 = {
+    "test_param_gpu_multi_bit_group_4_message_2_carry_2_ks_pbs_tuniform_2m128", 920, 1, 2048, 45, 17, 22, 1, 3, 5, 4, 4, 4, false};
+static const TestParameters TOY_MESSAGE_2_CARRY_2 = {"toy_message_2_carry_2", 12, 1, 2048, 45, 17, 23, 1, 4, 4, 4, 4, 0, true};
+static const TestParameters TOY_MULTI_BIT_GROUP_4_MESSAGE_2_CARRY_2 = {"toy_multi_bit_group_4_message_2_carry_2", 8, 1, 2048, 45, 17, 22, 1, 3, 6, 4, 4, 4,
+                                                                      false};
+static bool g_toy = false;
+constexpr size_t NB_CTXT = 4, MAX_NB_CTXT = 8;
+static size_t nb_tests_for_params(const TestParameters &p) {
+  const u64 full = p.message_modulus * p.carry_modulus;
+  return g_toy ? 2 : full >= 256 ? 5 : full >= 64 ? 15 : 30;
+}
+static size_t nb_tests_smaller_for_params(const TestParameters &p) {
+  const u64 full = p.message_modulus * p.carry_modulus;
+  return g_toy ? 1 : full >= 256 ? 2 : full >= 64 ? 5 : 10;
+}
+static u64 unsigned_modulus(u64 message_modulus, uint32_t num_blocks) {  // message_modulus^num_blocks (< 2^64 here)
+  u64 m = 1;
+  for (uint32_t i = 0; i < num_blocks; ++i) m *= message_modulus;
+  return m;
+}
+
+// RadixClientKey (integer/client_key/radix.rs) + the server key on the device, from one seed (KEY_CACHE's role)
+struct Keys {
+  TestParameters p;
+  orc_rng rng;
+  std::vector<u64> small_sk, big_sk;
+  u64 delta;
+  CudaStreams streams;
+  std::unique_ptr<CudaServerKey> sks;
+  explicit Keys(const TestParameters &params, u64 seed) : p(params), streams(CudaStreams::new_single_gpu(GpuIndex(0))) {
+    orc_rng_seed(&rng, seed);
+    const size_t n = p.lwe_dimension, k = p.glwe_dimension, N = p.polynomial_size, g = p.grouping_factor;
+    small_sk.resize(n);
+    big_sk.resize(k * N);
+    orc_gen_binary_key(&rng, small_sk.data(), (uint32_t)n);
+    orc_gen_binary_key(&rng, big_sk.data(), (uint32_t)(k * N));
+    delta = (u64(1) << 63) / (p.message_modulus * p.carry_modulus);
+    std::vector<u64> ksk(k * N * p.ks_level * (n + 1));
+    orc_gen_ksk(seed + 2, ksk.data(), big_sk.data(), (uint32_t)(k * N), small_sk.data(), (uint32_t)n, (uint32_t)p.ks_base_log, (uint32_t)p.ks_level, p.lwe_noise);
+    auto d_ksk = CudaLweKeyswitchKey<u64>::from_lwe_keyswitch_key(ksk, k * N, n, p.ks_base_log, p.ks_level, streams);
+    std::vector<u64> bsk((g ? (n / g) * (size_t(1) << g) : n) * (k + 1) * (k + 1) * p.pbs_level * N);
+    if (g) {
+      orc_gen_multi_bit_bsk(seed + 1, bsk.data(), small_sk.data(), (uint32_t)n, big_sk.data(), (uint32_t)k, (uint32_t)N, (uint32_t)p.pbs_base_log,
+                            (uint32_t)p.pbs_level, (uint32_t)g, p.glwe_noise);
+      sks = std::make_unique<CudaServerKey>(std::move(d_ksk),
+                                            CudaLweMultiBitBootstrapKey::from_lwe_multi_bit_bootstrap_key(bsk, n, k, N, p.pbs_base_log, p.pbs_level, g, streams),
+                                            p.message_modulus, p.carry_modulus);
+    } else {
+      orc_gen_bsk(seed + 1, bsk.data(), small_sk.data(), (uint32_t)n, big_sk.data(), (uint32_t)k, (uint32_t)N, (uint32_t)p.pbs_base_log, (uint32_t)p.pbs_level,
+                  p.glwe_noise);
+      sks = std::make_unique<CudaServerKey>(std::move(d_ksk),
+                                            CudaLweBootstrapKey::from_lwe_bootstrap_key(bsk, n, k, N, p.pbs_base_log, p.pbs_level, p.centered_ms, streams),
+                                            p.message_modulus, p.carry_modulus);
+    }
+  }
+  u64 random() { return orc_rng_next(&rng); }
+  // encrypt_radix: block i holds digit i of `clear` in base message_modulus, under the big key
+  CudaUnsignedRadixCiphertext encrypt_radix(u64 clear, size_t num_blocks) {
+    std::vector<u64> blocks(num_blocks * (big_sk.size() + 1));
+    for (size_t i = 0; i < num_blocks; ++i, clear /= p.message_modulus)
+      orc_lwe_encrypt(&rng, &blocks[i * (big_sk.size() + 1)], big_sk.data(), (uint32_t)big_sk.size(), (clear % p.message_modulus) * delta, p.glwe_noise);
+    return CudaUnsignedRadixCiphertext::from_radix_ciphertext(blocks, big_sk.size(), p.message_modulus, p.carry_modulus, p.message_modulus - 1, streams);
+  }
+  CudaUnsignedRadixCiphertext encrypt(u64 clear) { return encrypt_radix(clear, NB_CTXT); }
+  // create_trivial_radix: zero masks, bodies hold the digits; degrees are the digits themselves
+  CudaUnsignedRadixCiphertext create_trivial_radix(u64 clear, size_t num_blocks) {
+    std::vector<u64> blocks(num_blocks * (big_sk.size() + 1), 0);
+    std::vector<u64> digits;
+    for (size_t i = 0; i < num_blocks; ++i, clear /= p.message_modulus) {
+      blocks[i * (big_sk.size() + 1) + big_sk.size()] = (clear % p.message_modulus) * delta;
+      digits.push_back(clear % p.message_modulus);
+    }
+    auto ct = CudaUnsignedRadixCiphertext::from_radix_ciphertext(blocks, big_sk.size(), p.message_modulus, p.carry_modulus, 0, streams);
+    ct.degrees = digits;
+    return ct;
+  }
+  // ServerKey::unchecked_scalar_add on the client's copy: digit i of the scalar enters block i's body (makes blocks non-clean)
+  CudaUnsignedRadixCiphertext unchecked_scalar_add(const CudaUnsignedRadixCiphertext &ct, u64 scalar) {
+    std::vector<u64> blocks = ct.to_radix_ciphertext(streams);
+    auto out = CudaUnsignedRadixCiphertext::from_radix_ciphertext(blocks, ct.lwe_dimension, p.message_modulus, p.carry_modulus, 0, streams);
+    out.degrees = ct.degrees;
+    out.noise_levels = ct.noise_levels;
+    for (size_t i = 0; i < ct.num_blocks(); ++i, scalar /= p.message_modulus) {
+      blocks[i * (ct.lwe_dimension + 1) + ct.lwe_dimension] += (scalar % p.message_modulus) * delta;
+      out.degrees[i] += scalar % p.message_modulus;
+    }
+    out.d_blocks.copy_from_cpu_async(blocks, streams, 0);
+    streams.synchronize();
+    return out;
+  }
+  std::vector<u64> decrypt_blocks(const CudaUnsignedRadixCiphertext &ct) {  // message and carry of every block
+    const std::vector<u64> blocks = ct.to_radix_ciphertext(streams);
+    std::vector<u64> out;
+    for (size_t i = 0; i < ct.num_blocks(); ++i) {
+      const u64 ph = orc_lwe_decrypt(&blocks[i * (ct.lwe_dimension + 1)], big_sk.data(), (uint32_t)big_sk.size());
+      out.push_back((ph / delta + (ph % delta >= (delta >> 1))) % (p.message_modulus * p.carry_modulus));
+    }
+    return out;
+  }
+  u64 decrypt(const CudaUnsignedRadixCiphertext &ct) {  // RadixClientKey::decrypt: sum of block values * message_modulus^i, wrapping
+    u64 v = 0, w = 1;
+    for (u64 b : decrypt_blocks(ct)) v += b * w, w *= p.message_modulus;
+    return v % unsigned_modulus(p.message_modulus, (uint32_t)ct.num_blocks());
+  }
+  bool decrypt_bool(const CudaBooleanBlock &b) {
+    const u64 v = decrypt_blocks(b)[0];
+    CHECK(v <= 1);
+    return v == 1;
+  }
+  void panic_if_any_block_is_not_clean(const CudaUnsignedRadixCiphertext &ct) {  // tests_unsigned/mod.rs
+    const std::vector<u64> blocks = decrypt_blocks(ct);
+    for (size_t i = 0; i < blocks.size(); ++i) {
+      CHECK(ct.degrees[i] < p.message_modulus);
+      CHECK(blocks[i] < p.message_modulus);
+    }
+  }
+};
+// KEY_CACHE.get_from_params (integer/keycache.rs): one key set per parameter set for the whole run
+static Keys &key_cache(const TestParameters &param) {
+  static std::map<std::string, std::unique_ptr<Keys>> cache;
+  auto &slot = cache[param.name];
+  if (!slot) slot = std::make_unique<Keys>(param, 101);
+  return *slot;
+}
+static void assert_same_ciphertext(const Keys &k, const CudaUnsignedRadixCiphertext &a, const CudaUnsignedRadixCiphertext &b, const char *what) {
+  if (a.to_radix_ciphertext(k.streams) != b.to_radix_ciphertext(k.streams) || a.degrees != b.degrees)
+    throw std::runtime_error(std::string("Failed determinism check: ") + what);
+}
+
+// unchecked_add_test (test_add.rs:276-330)
+static void integer_unchecked_add(const TestParameters &param) {
+  Keys &k = key_cache(param);
+  const u64 modulus = unsigned_modulus(param.message_modulus, NB_CTXT);
+  for (size_t t = 0; t < nb_tests_for_params(param); ++t) {
+    const u64 clear_0 = k.random() % modulus, clear_1 = k.random() % modulus;
+    const auto ctxt_0 = k.encrypt(clear_0), ctxt_1 = k.encrypt(clear_1);
+    const auto encrypted_result = k.sks->unchecked_add(ctxt_0, ctxt_1, k.streams);
+    for (size_t i = 0; i < NB_CTXT; ++i) {  // ExpectedDegrees / ExpectedNoiseLevels::after_unchecked_add
+      CHECK_EQ(encrypted_result.degrees[i], ctxt_0.degrees[i] + ctxt_1.degrees[i]);
+      CHECK_EQ(encrypted_result.noise_levels[i], ctxt_0.noise_levels[i] + ctxt_1.noise_levels[i]);
+    }
+    const std::vector<u64> blocks = k.decrypt_blocks(encrypted_result);
+    for (size_t i = 0; i < NB_CTXT; ++i) CHECK(blocks[i] <= encrypted_result.degrees[i]);  // panic_if_any_block_values_exceeds_its_degree
+    CHECK_EQ(k.decrypt(encrypted_result), (clear_0 + clear_1) % modulus);
+  }
+}
+
+// default_add_test (test_add.rs:448-505)
+static void integer_add(const TestParameters &param) {
+  Keys &k = key_cache(param);
+  const size_t nb_tests_smaller = nb_tests_smaller_for_params(param);
+  for (size_t num_blocks = 1; num_blocks < (g_toy ? 4 : MAX_NB_CTXT); ++num_blocks) {
+    const u64 modulus = unsigned_modulus(param.message_modulus, (uint32_t)num_blocks);
+    const u64 clear_0 = k.random() % modulus, clear_1 = k.random() % modulus;
+    const auto ctxt_0 = k.encrypt_radix(clear_0, num_blocks), ctxt_1 = k.encrypt_radix(clear_1, num_blocks);
+    auto ct_res = k.sks->add(ctxt_0, ctxt_1, k.streams);
+    const auto tmp_ct = k.sks->add(ctxt_0, ctxt_1, k.streams);
+    k.panic_if_any_block_is_not_clean(ct_res);
+    assert_same_ciphertext(k, ct_res, tmp_ct, "add");
+    u64 clear = (clear_0 + clear_1) % modulus;
+    CHECK_EQ(k.decrypt(ct_res), clear);
+    for (size_t t = 0; t < nb_tests_smaller; ++t) {
+      ct_res = k.sks->add(ct_res, ctxt_0, k.streams);
+      k.panic_if_any_block_is_not_clean(ct_res);
+      clear = (clear + clear_0) % modulus;
+      CHECK_EQ(k.decrypt(ct_res), clear);
+    }
+  }
+}
+
+// default_overflowing_add_test (test_add.rs:553-680)
+static void integer_default_overflowing_add(const TestParameters &param) {
+  Keys &k = key_cache(param);
+  const size_t nb_tests_smaller = nb_tests_smaller_for_params(param);
+  auto expect = [](u64 a, u64 b, u64 modulus) { return std::make_pair((a + b) % modulus, a + b >= modulus); };  // overflowing_add_under_modulus
+  for (size_t num_blocks = 1; num_blocks < (g_toy ? 3 : MAX_NB_CTXT); ++num_blocks) {
+    const u64 modulus = unsigned_modulus(param.message_modulus, (uint32_t)num_blocks);
+    const u64 clear_0 = k.random() % modulus, clear_1 = k.random() % modulus;
+    const auto ctxt_0 = k.encrypt_radix(clear_0, num_blocks), ctxt_1 = k.encrypt_radix(clear_1, num_blocks);
+    const auto [ct_res, result_overflowed] = k.sks->unsigned_overflowing_add(ctxt_0, ctxt_1, k.streams);
+    const auto [tmp_ct, tmp_o] = k.sks->unsigned_overflowing_add(ctxt_0, ctxt_1, k.streams);
+    k.panic_if_any_block_is_not_clean(ct_res);
+    assert_same_ciphertext(k, ct_res, tmp_ct, "unsigned_overflowing_add");
+    assert_same_ciphertext(k, result_overflowed, tmp_o, "unsigned_overflowing_add (flag)");
+    const auto [expected_result, expected_overflowed] = expect(clear_0, clear_1, modulus);
+    CHECK_EQ(k.decrypt(ct_res), expected_result);
+    CHECK_EQ(k.decrypt_bool(result_overflowed), expected_overflowed);
+    CHECK_EQ(result_overflowed.degrees[0], u64(1));
+    for (size_t t = 0; t < nb_tests_smaller; ++t) {  // non-zero scalars make the operands non-clean
+      const u64 clear_2 = 1 + k.random() % (modulus - 1), clear_3 = 1 + k.random() % (modulus - 1);
+      const auto nc_0 = k.unchecked_scalar_add(ctxt_0, clear_2), nc_1 = k.unchecked_scalar_add(ctxt_1, clear_3);
+      const u64 clear_lhs = (clear_0 + clear_2) % modulus, clear_rhs = (clear_1 + clear_3) % modulus;
+      CHECK_EQ(k.decrypt(nc_0), clear_lhs);  // "Failed sanity decryption check"
+      CHECK_EQ(k.decrypt(nc_1), clear_rhs);
+      const auto [res, overflowed] = k.sks->unsigned_overflowing_add(nc_0, nc_1, k.streams);
+      k.panic_if_any_block_is_not_clean(res);
+      const auto [want, want_overflowed] = expect(clear_lhs, clear_rhs, modulus);
+      CHECK_EQ(k.decrypt(res), want);
+      CHECK_EQ(k.decrypt_bool(overflowed), want_overflowed);
+      CHECK_EQ(overflowed.degrees[0], u64(1));
+    }
+  }
+  const u64 modulus = unsigned_modulus(param.message_modulus, NB_CTXT);  // trivial inputs
+  for (int t = 0; t < (g_toy ? 1 : 4); ++t) {
+    const u64 clear_0 = k.random() % modulus, clear_1 = k.random() % modulus;
+    const auto a = k.create_trivial_radix(clear_0, NB_CTXT), b = k.create_trivial_radix(clear_1, NB_CTXT);
+    const auto [encrypted_result, encrypted_overflow] = k.sks->unsigned_overflowing_add(a, b, k.streams);
+    const auto [want, want_overflowed] = expect(clear_0, clear_1, modulus);
+    CHECK_EQ(k.decrypt(encrypted_result), want);
+    CHECK_EQ(k.decrypt_bool(encrypted_overflow), want_overflowed);
+  }
+}
+
+// default_mul_test (tests_cases_unsigned.rs:865-927)
+static void integer_mul(const TestParameters &param) {
+  Keys &k = key_cache(param);
+  const size_t nb_tests_smaller = nb_tests_smaller_for_params(param);
+  const u64 modulus = unsigned_modulus(param.message_modulus, NB_CTXT);
+  for (size_t outer = 0; outer < nb_tests_smaller; ++outer) {
+    const u64 clear1 = k.random() % modulus, clear2 = k.random() % modulus;
+    const auto ctxt_1 = k.encrypt(clear1), ctxt_2 = k.encrypt(clear2);
+    u64 clear = clear1;
+    auto res = k.sks->mul(ctxt_1, ctxt_2, k.streams);
+    CHECK(res.block_carries_are_empty());
+    for (size_t t = 0; t < nb_tests_smaller; ++t) {
+      const auto tmp = k.sks->mul(res, ctxt_2, k.streams);
+      res = k.sks->mul(res, ctxt_2, k.streams);
+      CHECK(res.block_carries_are_empty());
+      assert_same_ciphertext(k, res, tmp, "mul");
+      clear = (clear * clear2) % modulus;
+    }
+    clear = (clear * clear2) % modulus;
+    CHECK_EQ(k.decrypt(res), clear);
+  }
+  {  // x * y and y * x where y encrypts a boolean value
+    const u64 clear1 = k.random() % modulus, clear2 = k.random() & 1;
+    const auto ctxt_1 = k.encrypt(clear1), ctxt_2 = k.create_trivial_radix(clear2, NB_CTXT);
+    CHECK(ctxt_2.holds_boolean_value());
+    CHECK_EQ(k.decrypt(k.sks->mul(ctxt_1, ctxt_2, k.streams)), clear1 * clear2);
+    CHECK_EQ(k.decrypt(k.sks->mul(ctxt_2, ctxt_1, k.streams)), clear1 * clear2);
+  }
+}
+
+struct Test {
+  std::string name;
+  std::function<void()> body;
+};
+int main(int argc, char **argv) {
+  if (argc < 2 || (std::strcmp(argv[1], "toy") && std::strcmp(argv[1], "reference"))) {
+    std::fprintf(stderr, "usage: %s <toy|reference> [test-name-substring]\n", argv[0]);
+    return 2;
+  }
+  g_toy = !std::strcmp(argv[1], "toy");
+  const char *filter = argc > 2 ? argv[2] : "";
+  if (!is_cuda_available()) {
+    std::fprintf(stderr, "no device visible: the backend has no CPU path\n");
+    return 2;
+  }
+  std::vector<Test> tests;
+  auto all = [&](const TestParameters &p) {  // create_gpu_parameterized_test! (tests_unsigned/mod.rs)
+    tests.push_back({std::string("test_gpu_integer_unchecked_add_") + p.name, [&p] { integer_unchecked_add(p); }});
+    tests.push_back({std::string("test_gpu_integer_add_") + p.name, [&p] { integer_add(p); }});
+    tests.push_back({std::string("test_gpu_integer_default_overflowing_add_") + p.name, [&p] { integer_default_overflowing_add(p); }});
+    tests.push_back({std::string("test_gpu_integer_mul_") + p.name, [&p] { integer_mul(p); }});
+  };
+  if (g_toy) {
+    all(TOY_MESSAGE_2_CARRY_2);
+    all(TOY_MULTI_BIT_GROUP_4_MESSAGE_2_CARRY_2);
+  } else {
+    all(PARAM_MESSAGE_2_CARRY_2_KS_PBS_TUNIFORM_2M128);
+    all(TEST_PARAM_GPU_MULTI_BIT_GROUP_4_MESSAGE_2_CARRY_2_KS_PBS_TUNIFORM_2M128);
+  }
+  size_t ran = 0, failed = 0;
+  for (const Test &t : tests) {
+    if (!std::strstr(t.name.c_str(), filter)) continue;
+    ++ran;
+    const auto t0 = std::chrono::steady_clock::now();
+    std::string err;
+    try {
+      t.body();
+    } catch (const std::exception &e) {
+      err = e.what();
+    }
+    const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    std::printf("test %s ... %s (%.1f s)%s%s\n", t.name.c_str(), err.empty() ? "ok" : "FAILED", s, err.empty() ? "" : ": ", err.c_str());
+    std::fflush(stdout);
+    failed += !err.empty();
+  }
+  std::printf("test result: %s. %zu passed; %zu failed\n", failed ? "FAILED" : "ok", ran - failed, failed);
+  return failed || !ran ? 1 : 0;
+}

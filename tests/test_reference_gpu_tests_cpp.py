@@ -16,10 +16,10 @@ PRODUCT_LIB = os.path.join(ROOT, "tfhe_rs_amd", "lib", "libtfhe_hip_backend.so")
 ORACLE_LIB = os.path.join(ROOT, "oracle", "libtfhe_oracle.so")
 
 
-def build_tests(lib, exe):
+def build_tests(lib, exe, source="reference_gpu_tests.cpp"):
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
     cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-Wextra", "-Werror", "-o", exe,
-           os.path.join(HERE, "cpp", "reference_gpu_tests.cpp"), lib, ORACLE_LIB,
+           os.path.join(HERE, "cpp", source), lib, ORACLE_LIB,
            "-Wl,-rpath," + os.path.dirname(lib), "-Wl,-rpath," + os.path.dirname(ORACLE_LIB)]
     subprocess.check_call(cmd)
     return exe
@@ -54,3 +54,19 @@ def test_reference_gpu_tests_small_sets_on_the_gpu(tmp_path):
     exe = build_tests(PRODUCT_LIB, str(tmp_path / "reference_gpu_tests"))
     out = run(exe, "toy", timeout=600)
     assert out.count(" ... ok") == 17, out
+
+
+# ---- the radix layer (tests/cpp/reference_integer_gpu_tests.cpp on tfhe_rs_amd/host/integer_gpu.hpp): unchecked_add, add,
+# unsigned_overflowing_add and mul test cases of integer/gpu/server_key/radix/tests_unsigned, classic and multi-bit g = 4 sets
+def test_reference_integer_gpu_tests_on_the_host_emulation(tmp_path):
+    exe = build_tests(build_emu(), str(tmp_path / "reference_integer_gpu_tests_emu"), "reference_integer_gpu_tests.cpp")
+    out = run(exe, "toy", timeout=1500)
+    assert out.count(" ... ok") == 8, out
+
+
+@pytest.mark.gpu
+def test_reference_integer_gpu_tests_with_the_reference_parameter_sets(tmp_path):
+    exe = build_tests(PRODUCT_LIB, str(tmp_path / "reference_integer_gpu_tests"), "reference_integer_gpu_tests.cpp")
+    out = run(exe, "reference", timeout=1500)
+    assert out.count(" ... ok") == 8, out
+    print(out)
