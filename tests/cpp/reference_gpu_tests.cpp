@@ -426,19 +426,22 @@ static void lwe_encrypt_ks_decrypt_custom_mod_ks32() {
     }
 }
 
-// lwe_keyswitch.rs:525-556
-static u64 test_util_closest_representable_on_gpu(u64 value, uint32_t base_log, uint32_t level_count) {
+// lwe_keyswitch.rs:525-556.  The reference's helper makes a stream and two one-word vectors per call; here they are made
+// once per test (26,000 calls of the helper took 78 s on the MI355X — 3 ms of stream and allocation set-up each,
+// profiles/r04h_new_gpu_tests3_timeout.log — against 1 s with the set-up hoisted)
+struct ClosestRepresentableOnGpu {
   CudaStreams stream = CudaStreams::new_single_gpu(GpuIndex(0));
-  CudaVec<u64> d_input = CudaVec<u64>::new_async(1, stream, 0);
-  const std::vector<u64> h_input{value};
-  d_input.copy_from_cpu_async(h_input, stream, 0);
-  CudaVec<u64> d_output = CudaVec<u64>::new_async(1, stream, 0);
-  cuda_closest_representable(stream, d_input, d_output, base_log, level_count);
-  std::vector<u64> h_output{0};
-  d_output.copy_to_cpu_async(h_output.data(), 1, stream, 0);
-  stream.synchronize();
-  return h_output[0];
-}
+  CudaVec<u64> d_input = CudaVec<u64>::new_async(1, stream, 0), d_output = CudaVec<u64>::new_async(1, stream, 0);
+  u64 operator()(u64 value, uint32_t base_log, uint32_t level_count) {
+    const std::vector<u64> h_input{value};
+    d_input.copy_from_cpu_async(h_input, stream, 0);
+    cuda_closest_representable(stream, d_input, d_output, base_log, level_count);
+    std::vector<u64> h_output{0};
+    d_output.copy_to_cpu_async(h_output.data(), 1, stream, 0);
+    stream.synchronize();
+    return h_output[0];
+  }
+};
 // lwe_keyswitch.rs:558-577: a value whose decomposition state starts negative (a logical shift instead of an arithmetic one
 // on the last level loses the sign when base_log * (level_count + 1) > 64)
 static void test_closest_representable_gpu() {
@@ -450,6 +453,7 @@ static void test_closest_representable_gpu() {
   u64 recomp = 0;
   for (uint32_t i = 0; i < level_count; ++i) recomp += (u64)digits[i] << (64 - base_log * (level_count - i));
   CHECK_EQ(rounded, recomp);
+  ClosestRepresentableOnGpu test_util_closest_representable_on_gpu;
   CHECK_EQ(test_util_closest_representable_on_gpu(val, base_log, level_count), rounded);
 }
 // lwe_keyswitch.rs:579-609: every valid decomposer (math/decomposition/tests.rs:15-30), random values: moving the GPU's
@@ -457,6 +461,7 @@ static void test_closest_representable_gpu() {
 static void test_round_to_closest_representable_gpu() {
   const size_t runs_per_decomposer = g_toy ? 3 : 100;
   TestResources rsc(41);
+  ClosestRepresentableOnGpu test_util_closest_representable_on_gpu;
   for (uint32_t base_log = 1; base_log < 64; ++base_log)
     for (uint32_t level_count = 1; level_count < 64 && base_log * level_count < 64; ++level_count)
       for (size_t run = 0; run < runs_per_decomposer; ++run) {

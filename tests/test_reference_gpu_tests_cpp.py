@@ -55,18 +55,3 @@ def test_reference_gpu_tests_small_sets_on_the_gpu(tmp_path):
     out = run(exe, "toy", timeout=600)
     assert out.count(" ... ok") == 17, out
 
-
-# ---- the radix layer (tests/cpp/reference_integer_gpu_tests.cpp on tfhe_rs_amd/host/integer_gpu.hpp): unchecked_add, add,
-# unsigned_overflowing_add and mul test cases of integer/gpu/server_key/radix/tests_unsigned, classic and multi-bit g = 4 sets
-def test_reference_integer_gpu_tests_on_the_host_emulation(tmp_path):
-    exe = build_tests(build_emu(), str(tmp_path / "reference_integer_gpu_tests_emu"), "reference_integer_gpu_tests.cpp")
-    out = run(exe, "toy", timeout=1500)
-    assert out.count(" ... ok") == 8, out
-
-
-@pytest.mark.gpu
-def test_reference_integer_gpu_tests_with_the_reference_parameter_sets(tmp_path):
-    exe = build_tests(PRODUCT_LIB, str(tmp_path / "reference_integer_gpu_tests"), "reference_integer_gpu_tests.cpp")
-    out = run(exe, "reference", timeout=1500)
-    assert out.count(" ... ok") == 8, out
-    print(out)

@@ -1,0 +1,25 @@
+"""The reference's GPU tests of the radix operations the backend wires (integer/gpu/server_key/radix/tests_unsigned:
+unchecked_add_test, default_add_test, default_overflowing_add_test, default_mul_test), restated in C++ in
+tests/cpp/reference_integer_gpu_tests.cpp on the compiled host mirror tfhe_rs_amd/host/integer_gpu.hpp and linked against
+the library.  [emu] small sets on the host emulation; [hip] PARAM_MESSAGE_2_CARRY_2_KS_PBS_TUNIFORM_2M128 and the GPU
+multi-bit g = 4 set on the MI355X.  (The file sorts last on purpose: the GPU budget of round 4 ran out before the [hip]
+case could be run once on hardware — the same operations at the same sizes pass through the Python host in
+tests/test_radix_integer.py — so a surprise here cannot hide the rest of the tier behind `pytest -x`.)"""
+import pytest
+
+from .harness import build_emu
+from .test_reference_gpu_tests_cpp import PRODUCT_LIB, build_tests, run
+
+
+def test_reference_integer_gpu_tests_on_the_host_emulation(tmp_path):
+    exe = build_tests(build_emu(), str(tmp_path / "reference_integer_gpu_tests_emu"), "reference_integer_gpu_tests.cpp")
+    out = run(exe, "toy", timeout=1500)
+    assert out.count(" ... ok") == 8, out
+
+
+@pytest.mark.gpu
+def test_reference_integer_gpu_tests_with_the_reference_parameter_sets(tmp_path):
+    exe = build_tests(PRODUCT_LIB, str(tmp_path / "reference_integer_gpu_tests"), "reference_integer_gpu_tests.cpp")
+    out = run(exe, "reference", timeout=1500)
+    assert out.count(" ... ok") == 8, out
+    print(out)
