@@ -5,6 +5,7 @@
 //   integer_unchecked_add             integer/gpu/server_key/radix/tests_unsigned/test_add.rs:15-21 -> unchecked_add_test
 //                                     (integer/server_key/radix_parallel/tests_unsigned/test_add.rs:276-330)
 //   integer_add                       …/test_add.rs:29-35 -> default_add_test (…/test_add.rs:448-505)
+//   multi_device_integer_add          …/test_add.rs:36-42 -> default_add_test through GpuMultiDeviceFunctionExecutor (only with > 1 GPU)
 //   integer_default_overflowing_add   …/test_add.rs:44 -> default_overflowing_add_test (…/test_add.rs:553-680)
 //   integer_mul                       integer/gpu/server_key/radix/tests_unsigned/test_mul.rs -> default_mul_test
 //                                     (integer/server_key/radix_parallel/tests_cases_unsigned.rs:865-927)
@@ -85,7 +86,7 @@ struct Keys {
   u64 delta;
   CudaStreams streams;
   std::unique_ptr<CudaServerKey> sks;
-  explicit Keys(const TestParameters &params, u64 seed) : p(params), streams(CudaStreams::new_single_gpu(GpuIndex(0))) {
+  explicit Keys(const TestParameters &params, u64 seed, CudaStreams set = CudaStreams::new_single_gpu(GpuIndex(0))) : p(params), streams(std::move(set)) {
     orc_rng_seed(&rng, seed);
     const size_t n = p.lwe_dimension, k = p.glwe_dimension, N = p.polynomial_size, g = p.grouping_factor;
     small_sk.resize(n);
@@ -204,8 +205,9 @@ static void integer_unchecked_add(const TestParameters &param) {
 }
 
 // default_add_test (test_add.rs:448-505)
-static void integer_add(const TestParameters &param) {
-  Keys &k = key_cache(param);
+static void integer_add_on(Keys &k, const TestParameters &param);
+static void integer_add(const TestParameters &param) { integer_add_on(key_cache(param), param); }
+static void integer_add_on(Keys &k, const TestParameters &param) {
   const size_t nb_tests_smaller = nb_tests_smaller_for_params(param);
   for (size_t num_blocks = 1; num_blocks < (g_toy ? 4 : MAX_NB_CTXT); ++num_blocks) {
     const u64 modulus = unsigned_modulus(param.message_modulus, (uint32_t)num_blocks);
@@ -224,6 +226,34 @@ static void integer_add(const TestParameters &param) {
       CHECK_EQ(k.decrypt(ct_res), clear);
     }
   }
+}
+
+// multi_device_integer_add (tests_unsigned/test_add.rs:36-42): default_add_test through GpuMultiDeviceFunctionExecutor
+// (tests_signed/mod.rs:653-693) — the server key on a random subset of the GPUs in a random order, one stream each.  The
+// reference's thresholds keep a handful of blocks on the first GPU of the set; the spreading threshold is lowered to one
+// block per GPU so that the blocks of a round really travel (hip_integer_set_multi_gpu_threshold).
+static void integer_add_on(Keys &k, const TestParameters &param);
+static void multi_device_integer_add(const TestParameters &param) {
+  const uint32_t num_gpus = get_number_of_gpus();
+  orc_rng r;
+  orc_rng_seed(&r, 113);
+  std::vector<uint32_t> all(num_gpus);
+  for (uint32_t i = 0; i < num_gpus; ++i) all[i] = i;
+  for (uint32_t i = num_gpus; i > 1; --i) std::swap(all[i - 1], all[orc_rng_next(&r) % i]);
+  const uint32_t num_gpus_to_use = num_gpus > 1 ? 2 + (uint32_t)(orc_rng_next(&r) % (num_gpus - 1)) : 1;  // at least two when there are two
+  std::vector<GpuIndex> gpu_indexes;
+  std::string listed;
+  for (uint32_t i = 0; i < num_gpus_to_use; ++i) gpu_indexes.emplace_back(all[i]), listed += " " + std::to_string(all[i]);
+  std::printf("Setting up server key on GPUs: [%s ]\n", listed.c_str());
+  Keys k(param, 113, CudaStreams::new_multi_gpu_with_indexes(gpu_indexes));
+  hip_integer_set_multi_gpu_threshold(1);
+  try {
+    integer_add_on(k, param);
+  } catch (...) {
+    hip_integer_set_multi_gpu_threshold(0);
+    throw;
+  }
+  hip_integer_set_multi_gpu_threshold(0);
 }
 
 // default_overflowing_add_test (test_add.rs:553-680)
@@ -320,6 +350,7 @@ int main(int argc, char **argv) {
     tests.push_back({std::string("test_gpu_integer_add_") + p.name, [&p] { integer_add(p); }});
     tests.push_back({std::string("test_gpu_integer_default_overflowing_add_") + p.name, [&p] { integer_default_overflowing_add(p); }});
     tests.push_back({std::string("test_gpu_integer_mul_") + p.name, [&p] { integer_mul(p); }});
+    if (get_number_of_gpus() > 1) tests.push_back({std::string("test_gpu_multi_device_integer_add_") + p.name, [&p] { multi_device_integer_add(p); }});
   };
   if (g_toy) {
     all(TOY_MESSAGE_2_CARRY_2);

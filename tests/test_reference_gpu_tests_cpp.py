@@ -25,8 +25,9 @@ def build_tests(lib, exe, source="reference_gpu_tests.cpp"):
     return exe
 
 
-def run(exe, *args, timeout):
-    r = subprocess.run([exe, *args], capture_output=True, text=True, timeout=timeout)
+def run(exe, *args, timeout, env=None):
+    r = subprocess.run([exe, *args], capture_output=True, text=True, timeout=timeout,
+                       env=dict(os.environ, **env) if env else None)
     assert r.returncode == 0, r.stdout + r.stderr
     last = r.stdout.strip().splitlines()[-1]
     assert last.startswith("test result: ok."), r.stdout

@@ -88,6 +88,14 @@ class CudaStreams {
     }
     return s;
   }
+  static CudaStreams new_multi_gpu_with_indexes(const std::vector<GpuIndex> &indexes) {  // mod.rs:71-85
+    CudaStreams s;
+    for (const GpuIndex &g : indexes) {
+      s.gpu_indexes.push_back(g);
+      s.ptr.push_back(cuda_create_stream_ffi(g.get()));
+    }
+    return s;
+  }
   void synchronize() const {  // mod.rs:111-117
     for (size_t i = 0; i < ptr.size(); ++i) cuda_synchronize_stream(ptr[i], gpu_indexes[i].get());
   }
