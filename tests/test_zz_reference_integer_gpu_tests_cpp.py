@@ -11,18 +11,22 @@ from .harness import build_emu
 from .test_reference_gpu_tests_cpp import PRODUCT_LIB, build_tests, run
 
 
-def test_reference_integer_gpu_tests_on_the_host_emulation(tmp_path):
-    exe = build_tests(build_emu(), str(tmp_path / "reference_integer_gpu_tests_emu"), "reference_integer_gpu_tests.cpp")
-    out = run(exe, "toy", timeout=1500)
+@pytest.fixture(scope="module")
+def emu_exe(tmp_path_factory):
+    return build_tests(build_emu(), str(tmp_path_factory.mktemp("cpp") / "reference_integer_gpu_tests_emu"),
+                       "reference_integer_gpu_tests.cpp")
+
+
+def test_reference_integer_gpu_tests_on_the_host_emulation(emu_exe):
+    out = run(emu_exe, "toy", timeout=1500)
     assert out.count(" ... ok") == 8, out
 
 
 @pytest.mark.parametrize("no_peer", [0, 1], ids=["peer_access", "host_staged"])
-def test_multi_device_integer_add_on_the_emulated_device_model(tmp_path, no_peer):
+def test_multi_device_integer_add_on_the_emulated_device_model(emu_exe, no_peer):
     """multi_device_integer_add (GpuMultiDeviceFunctionExecutor: the server key on a random subset of the GPUs in a random
     order) on the emulation's device model — four pretend devices, with and without peer access between them."""
-    exe = build_tests(build_emu(), str(tmp_path / "reference_integer_gpu_tests_emu"), "reference_integer_gpu_tests.cpp")
-    out = run(exe, "toy", "multi_device", timeout=1500, env={"HIPEMU_DEVICES": "4", "HIPEMU_NO_PEER": str(no_peer)})
+    out = run(emu_exe, "toy", "multi_device", timeout=1500, env={"HIPEMU_DEVICES": "4", "HIPEMU_NO_PEER": str(no_peer)})
     assert out.count(" ... ok") == 2 and "Setting up server key on GPUs" in out, out
 
 
