@@ -36,3 +36,10 @@ def test_reference_integer_gpu_tests_with_the_reference_parameter_sets(tmp_path)
     out = run(exe, "reference", timeout=1500)
     assert out.count(" ... ok") == 8, out
     print(out)
+
+
+@pytest.mark.gpu
+def test_reference_integer_gpu_tests_small_sets_on_the_gpu(tmp_path):
+    exe = build_tests(PRODUCT_LIB, str(tmp_path / "reference_integer_gpu_tests"), "reference_integer_gpu_tests.cpp")
+    out = run(exe, "toy", timeout=600)
+    assert out.count(" ... ok") == 8, out
