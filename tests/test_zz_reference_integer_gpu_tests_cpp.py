@@ -34,7 +34,7 @@ def test_multi_device_integer_add_on_the_emulated_device_model(emu_exe, no_peer)
 def test_reference_integer_gpu_tests_with_the_reference_parameter_sets(tmp_path):
     exe = build_tests(PRODUCT_LIB, str(tmp_path / "reference_integer_gpu_tests"), "reference_integer_gpu_tests.cpp")
     out = run(exe, "reference", timeout=1500)
-    assert out.count(" ... ok") == 8, out
+    assert out.count(" ... ok") >= 8, out   # + 2 multi-device additions on a node with several GPUs
     print(out)
 
 
@@ -42,4 +42,4 @@ def test_reference_integer_gpu_tests_with_the_reference_parameter_sets(tmp_path)
 def test_reference_integer_gpu_tests_small_sets_on_the_gpu(tmp_path):
     exe = build_tests(PRODUCT_LIB, str(tmp_path / "reference_integer_gpu_tests"), "reference_integer_gpu_tests.cpp")
     out = run(exe, "toy", timeout=600)
-    assert out.count(" ... ok") == 8, out
+    assert out.count(" ... ok") >= 8, out
