@@ -314,8 +314,10 @@ void hip_programmable_bootstrap_ref64_async(
  * Called from tfhe/src/integer/gpu/mod.rs (cuda_backend_apply_univariate_lut,
  * cuda_backend_propagate_single_carry_assign, cuda_backend_unchecked_mul_assign, ...).
  *
- * Subset wired: classic PBS (pbs_type = CLASSICAL), one GPU (streams[0]), no carry-in / overflow
- * flags, no boolean operands.  Extension: a CudaRadixCiphertextFFI may hold a batch of integers
+ * Wired: classic and multi-bit keys (pbs_type), carry-in (uses_carry), FLAG_CARRY, FLAG_OVERFLOW (add_and_propagate),
+ * boolean operands of integer_mult, many-LUT application; a round spreads over the GPUs of the CudaStreamsFFI by the
+ * reference's thresholds (hip_integer_set_multi_gpu_threshold below).  Operands must be clean up to what an operation
+ * accepts (degrees are checked when given: INTEGRATION.md).  Extension: a CudaRadixCiphertextFFI may hold a batch of integers
  * ([integer][block]); the scratch's num_blocks is the blocks PER integer and the launch handles
  * num_radix_blocks / num_blocks integers in the same rounds (capacity: hip_integer_scratch_batch). */
 typedef struct {
