@@ -50,6 +50,9 @@ void cuda_destroy_stream(void *stream, uint32_t gpu_index);
 void cuda_synchronize_stream(void *stream, uint32_t gpu_index);
 uint32_t cuda_is_available(void);
 void *cuda_malloc(uint64_t size, uint32_t gpu_index);
+/* a plain hipMalloc unless TFHE_HIP_MALLOC_ASYNC=pool (hipMallocAsync's pool corrupted live allocations under the
+ * reference's cuda_malloc_async / cuda_drop pairing on ROCm 7.2.0: INTEGRATION.md; device.cu:176-218 falls back to
+ * cudaMalloc the same way on devices without memory pools) */
 void *cuda_malloc_async(uint64_t size, void *stream, uint32_t gpu_index);
 bool cuda_check_valid_malloc(uint64_t size, uint32_t gpu_index);
 uint64_t cuda_device_total_memory(uint32_t gpu_index);
