@@ -64,9 +64,12 @@ def test_golden_ciphertexts_decrypt_under_the_regenerated_keys(which):
         assert np.count_nonzero(ct & np.uint64(0xFFFFFFFF)) < 64
 
 
-@pytest.mark.parametrize("which", list(SETS))
-@pytest.mark.parametrize("engine", ["exact64", "fft64"])
+@pytest.mark.parametrize("which,engine", [("classical", "exact64"), ("classical", "fft64"), ("classical", "ntt64"),
+                                          ("multi_bit_group_4", "exact64"), ("multi_bit_group_4", "fft64")])
 def test_oracle_is_within_transform_noise_of_the_reference_gpu_golden(which, engine):
+    """exact64: the Karatsuba-semantics path (A17); fft64: the f64 path (A6-A11, A18); ntt64: the NTT-bnf path (A16, which
+    rotates at the end instead of the start and switches to the 64-bit prime and back) — all the same function of the
+    same inputs, so all within transform noise of what the reference's GPU produced."""
     p, keys, lut, inputs, messages, golden, _ = setup(which)
     out = oracle_pbs(p, keys, engine, inputs, lut)
     for m, ct, o in zip(messages, golden, out):
@@ -157,3 +160,18 @@ def parallel_streams(kind, which, specs):
     for (b, mi), out in zip(specs, outs):
         assert out.shape[0] == b and np.all(out == ref[mi]), f"thread with batch {b}, msg={messages[mi]}: cross-stream contamination"
         check_against_golden(out[0], golden[mi], keys.glwe_sk, messages[mi], f"parallel {which}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("engine", ["ntt64", "ntt64_split"])
+def test_ntt_engines_on_the_golden_inputs(engine):
+    """The NTT-bnf engines of the MI355X (integer Goldilocks kernel and its split-key f64 form) on the reference's golden
+    inputs: bit-equal to the oracle's NTT path, within transform noise of the H100's f64 bytes in phase."""
+    p, keys, lut, inputs, messages, golden, _ = setup("classical")
+    c = Ctx("hip", p, keys, engine)
+    out = c.pbs(np.repeat(inputs, 3, axis=0), lut)
+    ref = oracle_pbs(p, keys, "ntt64", inputs, lut)
+    for i, m in enumerate(messages):
+        for lane in range(3):
+            assert np.array_equal(out[3 * i + lane], ref[i]), (engine, m, lane)
+        check_against_golden(out[3 * i], golden[i], keys.glwe_sk, m, f"{engine} engine")
