@@ -161,17 +161,3 @@ def parallel_streams(kind, which, specs):
         assert out.shape[0] == b and np.all(out == ref[mi]), f"thread with batch {b}, msg={messages[mi]}: cross-stream contamination"
         check_against_golden(out[0], golden[mi], keys.glwe_sk, messages[mi], f"parallel {which}")
 
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("engine", ["ntt64", "ntt64_split"])
-def test_ntt_engines_on_the_golden_inputs(engine):
-    """The NTT-bnf engines of the MI355X (integer Goldilocks kernel and its split-key f64 form) on the reference's golden
-    inputs: bit-equal to the oracle's NTT path, within transform noise of the H100's f64 bytes in phase."""
-    p, keys, lut, inputs, messages, golden, _ = setup("classical")
-    c = Ctx("hip", p, keys, engine)
-    out = c.pbs(np.repeat(inputs, 3, axis=0), lut)
-    ref = oracle_pbs(p, keys, "ntt64", inputs, lut)
-    for i, m in enumerate(messages):
-        for lane in range(3):
-            assert np.array_equal(out[3 * i + lane], ref[i]), (engine, m, lane)
-        check_against_golden(out[3 * i], golden[i], keys.glwe_sk, m, f"{engine} engine")
