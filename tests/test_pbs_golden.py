@@ -32,7 +32,7 @@ SETS = {"classical": (pg.CLASSICAL, "classical"), "multi_bit_group_4": (pg.MULTI
 
 
 @functools.lru_cache(maxsize=2)
-def setup(which):
+def golden_setup(which):
     P, key = SETS[which]
     g = pg.load_golden()
     m = pg.material(P, g["seed"], g["messages"])
@@ -55,7 +55,7 @@ def check_against_golden(out, golden, glwe_sk, message, label):
 def test_golden_ciphertexts_decrypt_under_the_regenerated_keys(which):
     """run_*_pbs_golden_batch's own sanity check (mod.rs:331-340): the frozen outputs are correct bootstraps — under OUR
     regeneration of the secret keys, which therefore are the reference's; the regenerated inputs decrypt to the messages."""
-    p, keys, _, inputs, messages, golden, _ = setup(which)
+    p, keys, _, inputs, messages, golden, _ = golden_setup(which)
     for m, ct, inp in zip(messages, golden, inputs):
         assert ct.shape == (p.k * p.N + 1,)
         assert pg.decode(pg.phase(inp, keys.lwe_sk)) == m
@@ -70,7 +70,7 @@ def test_oracle_is_within_transform_noise_of_the_reference_gpu_golden(which, eng
     """exact64: the Karatsuba-semantics path (A17); fft64: the f64 path (A6-A11, A18); ntt64: the NTT-bnf path (A16, which
     rotates at the end instead of the start and switches to the 64-bit prime and back) — all the same function of the
     same inputs, so all within transform noise of what the reference's GPU produced."""
-    p, keys, lut, inputs, messages, golden, _ = setup(which)
+    p, keys, lut, inputs, messages, golden, _ = golden_setup(which)
     out = oracle_pbs(p, keys, engine, inputs, lut)
     for m, ct, o in zip(messages, golden, out):
         check_against_golden(o, ct, keys.glwe_sk, m, f"oracle {engine} {which}")
@@ -79,7 +79,7 @@ def test_oracle_is_within_transform_noise_of_the_reference_gpu_golden(which, eng
 def test_production_kernel_on_the_host_emulation_is_within_transform_noise_of_the_golden():
     """The headline kernel's own code (host emulation) on the golden input with the largest rotation (message 15, next
     to the negacyclic wrap): bit-equal to the oracle's fixed-order restatement, within noise of the H100's bytes."""
-    p, keys, lut, inputs, messages, golden, _ = setup("classical")
+    p, keys, lut, inputs, messages, golden, _ = golden_setup("classical")
     c = Ctx("emu", p, keys, "fft64")
     c.lib.hip_backend_set_fft_kernel(2)
     try:
@@ -98,7 +98,7 @@ def test_regression_pbs_golden(which):
     call per golden message at random batch sizes (one below and one above the latency / throughput switch, and the
     BATCH_SIZE the data was captured at); every lane equals lane 0 bit for bit, lane 0 equals the oracle's restatement
     bit for bit and sits within transform noise of the golden ciphertext."""
-    batch_size = setup(which)[6]
+    batch_size = golden_setup(which)[6]
     rng = np.random.default_rng()
     sizes = [int(rng.integers(1, 129)), batch_size, int(rng.integers(257, 1025))]
     print(f"test_regression_{which}_pbs_golden: batch sizes {sizes}")
@@ -107,7 +107,7 @@ def test_regression_pbs_golden(which):
 
 
 def regression(kind, which, sizes):
-    p, keys, lut, inputs, messages, golden, _ = setup(which)
+    p, keys, lut, inputs, messages, golden, _ = golden_setup(which)
     c = Ctx(kind, p, keys, "fft64")
     ref = oracle_pbs(p, keys, "fft64", inputs, lut)
     kernels = set()
@@ -135,7 +135,7 @@ def test_parallel_streams_pbs_golden(which):
 
 
 def parallel_streams(kind, which, specs):
-    p, keys, lut, inputs, messages, golden, _ = setup(which)
+    p, keys, lut, inputs, messages, golden, _ = golden_setup(which)
     c = Ctx(kind, p, keys, "fft64")   # key on the device once; streams per thread below
     ref = oracle_pbs(p, keys, "fft64", inputs, lut)
     from tfhe_rs_amd import core_crypto_gpu as gpu

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 from .harness import Ctx, oracle_pbs
-from .test_pbs_golden import check_against_golden, setup
+from .test_pbs_golden import check_against_golden, golden_setup
 
 
 @pytest.mark.gpu
@@ -13,7 +13,7 @@ from .test_pbs_golden import check_against_golden, setup
 def test_ntt_engines_on_the_golden_inputs(engine):
     """The NTT-bnf engines of the MI355X (integer Goldilocks kernel and its split-key f64 form) on the reference's golden
     inputs: bit-equal to the oracle's NTT path, within transform noise of the H100's f64 bytes in phase."""
-    p, keys, lut, inputs, messages, golden, _ = setup("classical")
+    p, keys, lut, inputs, messages, golden, _ = golden_setup("classical")
     c = Ctx("hip", p, keys, engine)
     out = c.pbs(np.repeat(inputs, 3, axis=0), lut)
     ref = oracle_pbs(p, keys, "ntt64", inputs, lut)
