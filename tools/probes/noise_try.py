@@ -1,3 +1,11 @@
+#!/usr/bin/env python3
+"""Probe behind tests/test_pbs_noise.py: the reference's classic noise-distribution test (16 x 1000 bootstraps of
+NOISE_TEST_PARAMS_4_BITS_NATIVE_U64_132_BITS_GAUSSIAN) through the oracle's f64 engine, with the variance at 2,000 / 4,000 /
+16,000 samples.   python tools/probes/noise_try.py   (about two minutes on 8 cores)"""
+import os
+import sys
+
+sys.path.insert(0, os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), os.pardir, os.pardir)))
 import time, math, numpy as np
 from tests import oracle as orc
 from tests.common import Params, Keys
