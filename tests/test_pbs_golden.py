@@ -161,3 +161,23 @@ def parallel_streams(kind, which, specs):
         assert out.shape[0] == b and np.all(out == ref[mi]), f"thread with batch {b}, msg={messages[mi]}: cross-stream contamination"
         check_against_golden(out[0], golden[mi], keys.glwe_sk, messages[mi], f"parallel {which}")
 
+
+
+def test_committed_golden_fixture_matches_the_reference_tree_when_present():
+    """tests/golden/pbs_golden_v1.json is a transcription (tests/golden/make_pbs_golden.py); where the reference tree is at
+    hand — the build container, not the GPU box — every word and constant must still be the reference's."""
+    import importlib.util
+    import json
+    import os
+    ref = "/root/reference/tfhe/src/core_crypto/gpu/algorithms/test/pbs_golden/pbs_golden_data/pbs_golden_v1.rs"
+    if not os.path.exists(ref):
+        pytest.skip("reference tree absent")
+    here = os.path.dirname(os.path.abspath(__file__))
+    spec = importlib.util.spec_from_file_location("make_pbs_golden", os.path.join(here, "golden", "make_pbs_golden.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    committed = json.load(open(pg.GOLDEN_JSON))
+    out = os.path.join(os.environ.get("TMPDIR", "/tmp"), "pbs_golden_v1.regenerated.json")
+    mod.OUT = out
+    mod.main()
+    assert json.load(open(out)) == committed
