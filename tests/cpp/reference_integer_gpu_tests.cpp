@@ -18,6 +18,7 @@
 //   usage: reference_integer_gpu_tests <toy|reference> [test-name-substring]
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <map>
@@ -62,7 +63,7 @@ static const TestParameters TEST_PARAM_GPU_MULTI_BIT_GROUP_4_MESSAGE_2_CARRY_2_K
 static const TestParameters TOY_MESSAGE_2_CARRY_2 = {"toy_message_2_carry_2", 12, 1, 2048, 45, 17, 23, 1, 4, 4, 4, 4, 0, true};
 static const TestParameters TOY_MULTI_BIT_GROUP_4_MESSAGE_2_CARRY_2 = {"toy_multi_bit_group_4_message_2_carry_2", 8, 1, 2048, 45, 17, 22, 1, 3, 6, 4, 4, 4,
                                                                       false};
-static bool g_toy = false;
+static bool g_toy = false;  // small parameter sets AND short loops; REFERENCE_TESTS_SHORT_LOOPS=1 keeps the reference's sets with the short loops
 constexpr size_t NB_CTXT = 4, MAX_NB_CTXT = 8;
 static size_t nb_tests_for_params(const TestParameters &p) {
   const u64 full = p.message_modulus * p.carry_modulus;
@@ -339,6 +340,8 @@ int main(int argc, char **argv) {
     return 2;
   }
   g_toy = !std::strcmp(argv[1], "toy");
+  const bool reference_sets = !g_toy;
+  if (std::getenv("REFERENCE_TESTS_SHORT_LOOPS")) g_toy = true;  // (the emulation takes 14 s per bootstrap at these sizes)
   const char *filter = argc > 2 ? argv[2] : "";
   if (!is_cuda_available()) {
     std::fprintf(stderr, "no device visible: the backend has no CPU path\n");
@@ -352,7 +355,7 @@ int main(int argc, char **argv) {
     tests.push_back({std::string("test_gpu_integer_mul_") + p.name, [&p] { integer_mul(p); }});
     if (get_number_of_gpus() > 1) tests.push_back({std::string("test_gpu_multi_device_integer_add_") + p.name, [&p] { multi_device_integer_add(p); }});
   };
-  if (g_toy) {
+  if (!reference_sets) {
     all(TOY_MESSAGE_2_CARRY_2);
     all(TOY_MULTI_BIT_GROUP_4_MESSAGE_2_CARRY_2);
   } else {
