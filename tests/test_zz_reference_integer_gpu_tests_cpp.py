@@ -4,7 +4,8 @@ tests/cpp/reference_integer_gpu_tests.cpp on the compiled host mirror tfhe_rs_am
 the library.  [emu] small sets on the host emulation; [hip] PARAM_MESSAGE_2_CARRY_2_KS_PBS_TUNIFORM_2M128 and the GPU
 multi-bit g = 4 set on the MI355X.  (The file sorts last on purpose: the GPU budget of round 4 ran out before the [hip]
 case could be run once on hardware — the same operations at the same sizes pass through the Python host in
-tests/test_radix_integer.py — so a surprise here cannot hide the rest of the tier behind `pytest -x`.)"""
+tests/test_radix_integer.py, and this binary's add / mul / overflowing-add cases pass at the reference's sizes on the host
+emulation (REFERENCE_TESTS_SHORT_LOOPS=1; HISTORY.md) — so a surprise here cannot hide the rest of the tier behind `pytest -x`.)"""
 import pytest
 
 from .harness import build_emu
