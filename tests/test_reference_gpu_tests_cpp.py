@@ -34,6 +34,12 @@ def run(exe, *args, timeout, env=None):
     return r.stdout
 
 
+@pytest.fixture(scope="module")
+def hip_exe(tmp_path_factory):
+    assert os.path.exists(PRODUCT_LIB)
+    return build_tests(PRODUCT_LIB, str(tmp_path_factory.mktemp("cpp") / "reference_gpu_tests"))
+
+
 def test_reference_gpu_tests_on_the_host_emulation(tmp_path):
     exe = build_tests(build_emu(), str(tmp_path / "reference_gpu_tests_emu"))
     out = run(exe, "toy", timeout=1500)
@@ -41,18 +47,15 @@ def test_reference_gpu_tests_on_the_host_emulation(tmp_path):
 
 
 @pytest.mark.gpu
-def test_reference_gpu_tests_with_the_reference_parameter_sets(tmp_path):
-    assert os.path.exists(PRODUCT_LIB)
-    exe = build_tests(PRODUCT_LIB, str(tmp_path / "reference_gpu_tests"))
-    out = run(exe, "reference", timeout=1500)
+def test_reference_gpu_tests_with_the_reference_parameter_sets(hip_exe):
+    out = run(hip_exe, "reference", timeout=1500)
     # 4 classic + 3 multi-bit bootstraps + 2 multi-bit keyswitches + KS32 keyswitch + 2 closest-representable + modulus switch + panics
     assert out.count(" ... ok") == 14, out
     print(out)
 
 
 @pytest.mark.gpu
-def test_reference_gpu_tests_small_sets_on_the_gpu(tmp_path):
-    exe = build_tests(PRODUCT_LIB, str(tmp_path / "reference_gpu_tests"))
-    out = run(exe, "toy", timeout=600)
+def test_reference_gpu_tests_small_sets_on_the_gpu(hip_exe):
+    out = run(hip_exe, "toy", timeout=600)
     assert out.count(" ... ok") == 17, out
 

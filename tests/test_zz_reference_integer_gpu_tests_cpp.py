@@ -18,6 +18,12 @@ def emu_exe(tmp_path_factory):
                        "reference_integer_gpu_tests.cpp")
 
 
+@pytest.fixture(scope="module")
+def hip_exe(tmp_path_factory):
+    return build_tests(PRODUCT_LIB, str(tmp_path_factory.mktemp("cpp") / "reference_integer_gpu_tests"),
+                       "reference_integer_gpu_tests.cpp")
+
+
 def test_reference_integer_gpu_tests_on_the_host_emulation(emu_exe):
     out = run(emu_exe, "toy", timeout=1500)
     assert out.count(" ... ok") == 8, out
@@ -32,15 +38,13 @@ def test_multi_device_integer_add_on_the_emulated_device_model(emu_exe, no_peer)
 
 
 @pytest.mark.gpu
-def test_reference_integer_gpu_tests_with_the_reference_parameter_sets(tmp_path):
-    exe = build_tests(PRODUCT_LIB, str(tmp_path / "reference_integer_gpu_tests"), "reference_integer_gpu_tests.cpp")
-    out = run(exe, "reference", timeout=1500)
+def test_reference_integer_gpu_tests_with_the_reference_parameter_sets(hip_exe):
+    out = run(hip_exe, "reference", timeout=1500)
     assert out.count(" ... ok") >= 8, out   # + 2 multi-device additions on a node with several GPUs
     print(out)
 
 
 @pytest.mark.gpu
-def test_reference_integer_gpu_tests_small_sets_on_the_gpu(tmp_path):
-    exe = build_tests(PRODUCT_LIB, str(tmp_path / "reference_integer_gpu_tests"), "reference_integer_gpu_tests.cpp")
-    out = run(exe, "toy", timeout=600)
+def test_reference_integer_gpu_tests_small_sets_on_the_gpu(hip_exe):
+    out = run(hip_exe, "toy", timeout=600)
     assert out.count(" ... ok") >= 8, out
