@@ -8,7 +8,7 @@ import subprocess
 
 import pytest
 
-from .harness import EMU_LIB, build_emu
+from .harness import build_emu
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
