@@ -273,3 +273,20 @@ def test_oracle_multi_bit(p):
     for eng in (orc.ENGINE_EXACT, orc.ENGINE_FFT):
         o = orc.pbs_multi_bit(eng, cts, lut, keys.bsk, p.n, p.k, p.N, p.pbs_base_log, p.pbs_level, p.grouping)
         assert [decrypt_big(p, keys, c) for c in o] == [f(m) for m in msgs]
+
+
+def test_prime_to_pow2_switch_equals_the_wide_division():
+    """orc_modswitch_prime_to_pow2 = floor((v * 2^64 + (p - 1) / 2) / p) (commons/math/ntt/ntt64.rs:162-177, output width 64):
+    compared with Python's integers on edge values, random values and the values on both sides of quotient steps."""
+    import random
+    P = 0xFFFFFFFF00000001
+    rng = random.Random(7)
+    vals = [0, 1, 2, P - 1, P - 2, (P - 1) // 2, (P + 1) // 2, 2 ** 32 - 1, 2 ** 32, 2 ** 32 + 1, 2 ** 63 - 1, 2 ** 63, 2 ** 63 + 1,
+            P - 2 ** 32, P - 2 ** 32 + 1]
+    vals += [rng.randrange(P) for _ in range(20000)]
+    for _ in range(5000):   # smallest v whose quotient reaches q, and its predecessor
+        q = rng.randrange(1, 1 << 64)
+        v = -((-(q * P - (P >> 1))) >> 64)
+        vals += [x for x in (v - 1, v, v + 1) if 0 <= x < P]
+    for v in vals:
+        assert orc.lib().orc_modswitch_prime_to_pow2(v) == (((v << 64) + (P >> 1)) // P) % (1 << 64), v
