@@ -23,6 +23,9 @@
  */
 #include "tfhe_oracle.h"
 #include "tfhe_oracle_internal.h"
+#if defined(__AVX2__) && defined(__FMA__)
+#include <immintrin.h>
+#endif
 #include <math.h>
 #include <omp.h>
 #include <stdlib.h>
@@ -146,16 +149,28 @@ static uint32_t bitrev_u32(uint32_t x, uint32_t bits) {
   return r;
 }
 
-/* M_d[p] for p < N/2 (re, im interleaved) */
-void orc_monomial_fourier(uint32_t N, uint64_t degree, const double *z, double *m) {
+/* M_d[p] for p < N/2 (re, im interleaved).  The two index factors of position p depend on N alone: tabulated once per
+ * bootstrap (the bit reversals cost more than the products they feed) */
+static void monomial_index_tables(uint32_t N, uint32_t *tab_b, uint32_t *tab_w) {
   uint32_t n = N / 2, L = orc_log2_u32(n);
+  for (uint32_t p = 0; p < n; ++p) { tab_b[p] = 1 + 4 * bitrev_u32(p >> 4, L - 4); tab_w[p] = bitrev_u32(p & 15, 4); }
+}
+static void monomial_fourier_tab(uint32_t N, uint64_t degree, const double *z, const uint32_t *tab_b, const uint32_t *tab_w,
+                                 double *m) {
+  const uint32_t n = N / 2, d = (uint32_t)(degree % (2 * N)), mask = 2 * N - 1;  /* 2N is a power of two */
   for (uint32_t p = 0; p < n; ++p) {
-    uint32_t jb = (uint32_t)(((uint64_t)(1 + 4 * bitrev_u32(p >> 4, L - 4)) * degree) % (2 * N));
-    uint32_t jw = (N / 8) * (uint32_t)((bitrev_u32(p & 15, 4) * degree) % 16);
+    uint32_t jb = (tab_b[p] * d) & mask;                 /* ((1 + 4 bitrev(p >> 4)) * degree) mod 2N */
+    uint32_t jw = (N / 8) * ((tab_w[p] * d) & 15);       /* (N / 8) * ((bitrev(p & 15) * degree) mod 16) */
     double xr = z[2 * jb], xi = z[2 * jb + 1], yr = z[2 * jw], yi = z[2 * jw + 1];
     m[2 * p] = fma(-xi, yi, xr * yr);
     m[2 * p + 1] = fma(xi, yr, xr * yi);
   }
+}
+void orc_monomial_fourier(uint32_t N, uint64_t degree, const double *z, double *m) {
+  uint32_t *tab = (uint32_t *)malloc(sizeof(uint32_t) * N);
+  monomial_index_tables(N, tab, tab + N / 2);
+  monomial_fourier_tab(N, degree, z, tab, tab + N / 2, m);
+  free(tab);
 }
 
 /* standard-domain multi-bit key -> Fourier domain, same nesting [group][subset][level][row][col], each
@@ -188,6 +203,8 @@ void orc_pbs_multi_bit_fft(uint64_t *lwe_out, const uint64_t *lwe_in, const uint
   double *z = (double *)malloc(sizeof(double) * 4 * N);
   double *mono = (double *)malloc(sizeof(double) * N);
   orc_monomial_table(N, z);
+  uint32_t *tab = (uint32_t *)malloc(sizeof(uint32_t) * N);
+  monomial_index_tables(N, tab, tab + N / 2);
   for (uint32_t p = 0; p <= k; ++p) orc_monomial_div(ct0 + (size_t)p * N, lut + (size_t)p * N, N, body_hat);
   uint64_t *src = ct0, *dst = ct1;
   for (uint32_t grp = 0; grp < groups; ++grp) {
@@ -195,22 +212,37 @@ void orc_pbs_multi_bit_fft(uint64_t *lwe_out, const uint64_t *lwe_in, const uint
     memcpy(kb_f, group, sizeof(double) * ggsw_sz);
     for (uint32_t s = 1; s < per; ++s) {
       const double *ks = group + (size_t)s * ggsw_sz;
-      orc_monomial_fourier(N, deg[(size_t)grp * per + s], z, mono);
-      for (size_t poly = 0; poly < ggsw_sz / N; ++poly)
-        for (uint32_t p = 0; p < nn; ++p) {
+      monomial_fourier_tab(N, deg[(size_t)grp * per + s], z, tab, tab + N / 2, mono);
+      for (size_t poly = 0; poly < ggsw_sz / N; ++poly) {
+        uint32_t p = 0;
+#if defined(__AVX2__) && defined(__FMA__)
+        /* two points per register, lane by lane the scalar operations below in the same order: inner = fma(kr, m, o),
+         * then fma(ki, [-mi, mr], inner) — (-ki) * mi and ki * (-mi) are the same product */
+        const __m256d sgn = _mm256_setr_pd(-0.0, 0.0, -0.0, 0.0);
+        for (; p + 2 <= nn; p += 2) {
+          const __m256d kv = _mm256_loadu_pd(ks + poly * N + 2 * p), mv = _mm256_loadu_pd(mono + 2 * p);
+          double *o = kb_f + poly * N + 2 * p;
+          const __m256d krr = _mm256_movedup_pd(kv), kii = _mm256_permute_pd(kv, 0xF);
+          const __m256d msw = _mm256_xor_pd(_mm256_permute_pd(mv, 0x5), sgn);  /* [-mi mr] */
+          const __m256d inner = _mm256_fmadd_pd(krr, mv, _mm256_loadu_pd(o));
+          _mm256_storeu_pd(o, _mm256_fmadd_pd(kii, msw, inner));
+        }
+#endif
+        for (; p < nn; ++p) {
           double kr = ks[poly * N + 2 * p], ki = ks[poly * N + 2 * p + 1];
           double mr = mono[2 * p], mi = mono[2 * p + 1];
           double *o = kb_f + poly * N + 2 * p;
           o[0] = fma(-ki, mi, fma(kr, mr, o[0]));
           o[1] = fma(ki, mr, fma(kr, mi, o[1]));
         }
+      }
     }
     memset(dst, 0, sizeof(uint64_t) * gl);
     orc_ext_product_fft(dst, src, kb_f, k, N, base_log, level, states, digits, fbuf, outbuf);
     uint64_t *t = src; src = dst; dst = t;
   }
   orc_sample_extract(lwe_out, src, k, N, 0);
-  free(deg); free(buf); free(digits); free(kb_f); free(fbuf); free(z); free(mono);
+  free(deg); free(buf); free(digits); free(kb_f); free(fbuf); free(z); free(mono); free(tab);
 }
 
 void orc_pbs_multi_bit_fft_batch(uint64_t *lwe_out, const uint64_t *lwe_in, const uint64_t *lut,
