@@ -11,7 +11,8 @@ scaling); the barrier/max-over-ranks timing uses torch.distributed (RCCL).
 Prints ONE JSON line (contract in the task statement) with `roofline` and `cpu_baseline`.  At N = 1 the line
 also carries `extra`: the single-PBS latency, the N=1024/k=2 datapoint, BASELINE.json's configs 3 (NTT engine) and
 4 (multi-bit g = 3, plus the reference's GPU default g = 4), each at batch 4096 with its oracle-parity bit, and
-config 5 on one GPU (FheUint64 add / mul through the radix layer, results decrypted) — none of them part of `value`.
+config 5 on one GPU (FheUint64 add / mul through the radix layer, results decrypted), and the reference's own GPU golden
+ciphertexts (its pbs_golden test: distance in phase, tools/golden_datapoint.py) — none of them part of `value`.
 """
 import argparse
 import ctypes as C
@@ -676,6 +677,16 @@ def main():
                             "decrypt-checked: tools/bench_integer.py --params multibit_g4"}
         except Exception as e:  # noqa: BLE001
             result["extra"]["fheuint64_single_operation_latency"] = {"error": f"{e.__class__.__name__}: {e}"[:300]}
+        # ---- the reference's own GPU golden ciphertexts (pbs_golden, captured on an H100) at the metric's parameter set and
+        # the GPU multi-bit g = 4 set, on keys / inputs regenerated from the test's seed: lanes, oracle bits, distance in phase.
+        # In its own process: a surprise there must not cost the line its headline.
+        try:
+            import subprocess
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "golden_datapoint.py")], capture_output=True,
+                               text=True, timeout=300)
+            result["extra"]["reference_gpu_golden"] = json.loads(r.stdout.strip().splitlines()[-1])
+        except Exception as e:  # noqa: BLE001
+            result["extra"]["reference_gpu_golden"] = {"error": f"{e.__class__.__name__}: {e}"[:300]}
     if not single and per_gpu is not None and args.kernel == 0 and not args.no_extra:
         # ---- config 5 on the N GPUs: the batch of 1024 FheUint64 sharded (a) by the caller, 1024 / N integers per GPU,
         # every round GPU-local, and (b) inside the library, one CudaStreamsFFI naming the N GPUs: the
