@@ -185,7 +185,22 @@
 #define WAVE_RESIDENT 2  // classic one-level loop: twiddles kept in registers across the iterations (ResidentTwiddles: 0..2)
 #endif
 
+#ifndef WAVE_PROBE_TS
+// measurement builds only (tools/cumask_sweep.hip, variants/lib_ts.so): every workgroup records where it ran
+// (HW_ID, XCC_ID) and the 100 MHz / shader-clock timestamps around its CMUX loop; hip_probe_wave_timestamps() sets the
+// record buffer and can pin the LWEs per workgroup.  Never defined in the product library.
+#define WAVE_PROBE_TS 0
+#endif
+
 namespace tfhe_hip {
+#if WAVE_PROBE_TS
+__device__ uint64_t *g_wave_ts = nullptr;
+static unsigned g_wave_force_per_block = 0;
+extern "C" void hip_probe_wave_timestamps(uint64_t *dev_records, uint32_t lwes_per_block) {
+  HX_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_wave_ts), &dev_records, sizeof(dev_records)));
+  g_wave_force_per_block = lwes_per_block;
+}
+#endif
 namespace wavek {
 
 constexpr int N = 2048, n = 1024, LOG2N2 = 12;
@@ -695,6 +710,14 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
     if (tid < FLAGS_BYTES / 4) flags[tid] = 0;
   }
   __syncthreads();
+#if WAVE_PROBE_TS
+  uint64_t *ts_rec = g_wave_ts ? g_wave_ts + (size_t)blockIdx.x * 8 : nullptr;
+  if (ts_rec && tid == 0) {
+    ts_rec[0] = __builtin_amdgcn_s_memrealtime();
+    ts_rec[1] = __builtin_amdgcn_s_memtime();
+    ts_rec[2] = (uint64_t)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((uint64_t)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
+  }
+#endif
 
   // the launch picks 1..4 LWEs per workgroup (blockDim.x = 128 per LWE): small batches spread over the CUs
   uint32_t sample = blockIdx.x * (blockDim.x >> 7) + pair;
@@ -1722,6 +1745,12 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
     }
   }
 
+#if WAVE_PROBE_TS
+  if (ts_rec && tid == 0) {
+    ts_rec[3] = __builtin_amdgcn_s_memrealtime();
+    ts_rec[4] = __builtin_amdgcn_s_memtime();
+  }
+#endif
   // ---- sample extraction (cc/algorithms/glwe_sample_extraction.rs:119-146); many-LUT outputs
   if (!valid) return;  // SHARE: a pair past the end of the batch
   const size_t out_sz = (size_t)N + 1;
@@ -1818,6 +1847,9 @@ bool wave_literal_twiddles_match(const double *fwd, const double *inv) {
 // LWEs per workgroup (= per CU): as few as keeps every one of the 256 CUs busy — a lone wave pair runs an
 // iteration in 7.6 us, four pairs sharing a CU need 12.4 us each
 static unsigned lwes_per_block(uint32_t num_samples) {
+#if WAVE_PROBE_TS
+  if (g_wave_force_per_block) return g_wave_force_per_block;
+#endif
   const unsigned want = (num_samples + 255) / 256;
   return want < 1 ? 1 : (want > (unsigned)wavek::LWES_PER_BLOCK ? (unsigned)wavek::LWES_PER_BLOCK : want);
 }
