@@ -165,6 +165,29 @@ void cuda_multi_bit_programmable_bootstrap_64_async(
 
 void cleanup_cuda_multi_bit_programmable_bootstrap_64(void *stream, uint32_t gpu_index, int8_t **pbs_buffer);
 
+/* The variant the reference's noise tests call (cuda/include/pbs/programmable_bootstrap_multibit.h:44-60; bound by
+ * tfhe/src/core_crypto/gpu/ffi.rs:322-397): the input has ALREADY been through cuda_modulus_switch_multi_bit_64_async —
+ * lwe_array_in = [ ciphertext, lwe_dimension + 1 words | its output, (lwe_dimension / grouping_factor) * 2^grouping_factor
+ * words ] — and the keybundle reads its monomial degrees from the second part.  num_samples must be 1 and
+ * polynomial_size 2048 (anything else panics, as there); scratch and cleanup are the standard ones. */
+uint64_t scratch_cuda_multi_bit_programmable_bootstrap_noise_tests_64_async(
+    void *stream, uint32_t gpu_index, int8_t **pbs_buffer,
+    uint32_t glwe_dimension, uint32_t polynomial_size, uint32_t level_count,
+    uint32_t input_lwe_ciphertext_count, bool allocate_gpu_memory);
+
+void cleanup_cuda_multi_bit_programmable_bootstrap_noise_tests_64(
+    void *stream, uint32_t gpu_index, int8_t **pbs_buffer);
+
+void cuda_multi_bit_programmable_bootstrap_noise_tests_64_async(
+    void *stream, uint32_t gpu_index, void *lwe_array_out,
+    void const *lwe_output_indexes, void const *lut_vector,
+    void const *lut_vector_indexes, void const *lwe_array_in,
+    void const *lwe_input_indexes, void const *bootstrapping_key,
+    int8_t *buffer, uint32_t lwe_dimension, uint32_t glwe_dimension,
+    uint32_t polynomial_size, uint32_t grouping_factor, uint32_t base_log,
+    uint32_t level_count, uint32_t num_samples, uint32_t num_many_lut,
+    uint32_t lut_stride);
+
 /* ------------------------------------------------------------------ keyswitch
  * backends/tfhe-cuda-backend/cuda/include/keyswitch/keyswitch.h:16-21,35-41,69-72
  * called from tfhe/src/core_crypto/gpu/ffi.rs:503-618 (KSK upload is a plain memcpy, :620-627) */
@@ -228,6 +251,16 @@ void cuda_centered_modulus_switch_64_async(void *stream, uint32_t gpu_index,
                                            void *lwe_out, const void *lwe_in,
                                            uint32_t lwe_dimension,
                                            uint32_t log_modulus);
+/* cuda/include/ciphertext.h:45-50 (tfhe/src/core_crypto/gpu/ffi.rs:914-936): the multi-bit switch as its own launch
+ * (noise tests only; production fuses it into the keybundle).  `size` words of lwe_array_in are read as
+ * size / grouping_factor groups, 2^grouping_factor degrees are written per group ([group][subset], subset 0 = 0).
+ * As in the reference the switch goes to 2 * degree whatever log_modulus says, and only degree 2048 is accepted. */
+void cuda_modulus_switch_multi_bit_64_async(void *stream, uint32_t gpu_index,
+                                            void *lwe_array_out,
+                                            void *lwe_array_in, uint32_t size,
+                                            uint32_t log_modulus,
+                                            uint32_t degree,
+                                            uint32_t grouping_factor);
 
 /* ------------------------------------------------------------------ extensions (hip_*)
  * Goldilocks-NTT engine: same argument meaning as the classic PBS triple above, the key

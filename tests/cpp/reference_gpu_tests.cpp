@@ -273,6 +273,66 @@ static void lwe_encrypt_multi_bit_pbs_decrypt_custom_mod(const MultiBitTestParam
   }
 }
 
+// integer/gpu/server_key/radix/tests_noise_distribution/utils/noise_simulation.rs:1186-1362 `multi_bit_mod_switch` followed by
+// `apply_generic_blind_rotation` (what the reference's noise tests do around the multi-bit blind rotation): the output buffer
+// takes the input ciphertext first, cuda_modulus_switch_multi_bit_64_async writes behind it, and
+// programmable_bootstrap_multi_bit_noise_tests bootstraps from that buffer.  Checked here: the result IS the standard multi-bit
+// bootstrap of the same ciphertext (same bits) and decrypts to f(msg).  N = 2048 only, as in the reference.
+static void multi_bit_mod_switch_then_blind_rotation(const MultiBitTestParams &params) {
+  const size_t input_lwe_dimension = params.input_lwe_dimension, glwe_dimension = params.glwe_dimension,
+               polynomial_size = params.polynomial_size, grouping_factor = params.grouping_factor;
+  const u64 msg_modulus = u64(1) << params.message_modulus_log;
+  const CiphertextModulus ciphertext_modulus = CiphertextModulus::new_native();
+  const u64 delta = (u64(1) << 63) / msg_modulus;
+  CudaStreams stream = CudaStreams::new_single_gpu(GpuIndex(0));
+  TestResources rsc(29 + grouping_factor);
+  auto f = [&](u64 x) { return (x * 3 + 1) % msg_modulus; };
+  const std::vector<u64> accumulator = generate_lut(polynomial_size, glwe_dimension, msg_modulus, delta, f);
+  const std::vector<u64> input_lwe_secret_key = binary_key(rsc, input_lwe_dimension);
+  const std::vector<u64> output_glwe_secret_key = binary_key(rsc, glwe_dimension * polynomial_size);
+  const size_t output_lwe_dimension = output_glwe_secret_key.size(), lwe_size = input_lwe_dimension + 1;
+  std::vector<u64> bsk((input_lwe_dimension / grouping_factor) * (size_t(1) << grouping_factor) * (glwe_dimension + 1) * (glwe_dimension + 1) *
+                       params.decomp_level_count * polynomial_size);
+  orc_gen_multi_bit_bsk(rsc.key_seed, bsk.data(), input_lwe_secret_key.data(), (uint32_t)input_lwe_dimension, output_glwe_secret_key.data(),
+                        (uint32_t)glwe_dimension, (uint32_t)polynomial_size, (uint32_t)params.decomp_base_log,
+                        (uint32_t)params.decomp_level_count, (uint32_t)grouping_factor, key_noise_bound(params.glwe_noise_std));
+  const CudaLweMultiBitBootstrapKey d_bsk = CudaLweMultiBitBootstrapKey::from_lwe_multi_bit_bootstrap_key(
+      bsk, input_lwe_dimension, glwe_dimension, polynomial_size, params.decomp_base_log, params.decomp_level_count, grouping_factor, stream);
+  const auto d_accumulator =
+      CudaGlweCiphertextList<u64>::from_glwe_ciphertext(accumulator, glwe_dimension, polynomial_size, ciphertext_modulus, stream);
+  const CudaVec<u64> zero_index = device_indexes({0}, stream);
+  for (u64 msg = 0; msg < msg_modulus; msg += (g_toy ? 1 : 5)) {
+    const std::vector<u64> lwe_ciphertext_in = encrypt_lwe(rsc, input_lwe_secret_key, msg * delta, params.lwe_noise_std);
+    const auto d_input = CudaLweCiphertextList<u64>::from_lwe_ciphertext(lwe_ciphertext_in, ciphertext_modulus, stream);
+    // allocate_multi_bit_mod_switch_result: (1 << grouping_factor) + 1 ciphertexts of the input's size
+    CudaLweCiphertextList<u64> d_switched(input_lwe_dimension, (size_t(1) << grouping_factor) + 1, ciphertext_modulus, stream);
+    // multi_bit_mod_switch: the input into the first slot, the switch behind it
+    d_switched.d_vec.copy_from_cpu_async(lwe_ciphertext_in, stream, 0);
+    stream.synchronize();
+    CudaVec<u64> input_copy = CudaVec<u64>::from_cpu_async(lwe_ciphertext_in, stream, 0);
+    cuda_modulus_switch_multi_bit_ciphertext(stream, d_switched.d_vec, input_copy, 12, (uint32_t)polynomial_size, (uint32_t)grouping_factor,
+                                             lwe_size);
+    // the switch's words are what the CPU switch gives (lwe_multi_bit_programmable_bootstrapping.rs:30-65)
+    {
+      std::vector<u64> deg((input_lwe_dimension / grouping_factor) << grouping_factor);
+      const std::vector<u64> host = d_switched.d_vec.to_cpu(stream, 0);
+      u64 body = 0;
+      orc_multi_bit_modulus_switch(lwe_ciphertext_in.data(), (uint32_t)input_lwe_dimension, 12, (uint32_t)grouping_factor, deg.data(), &body);
+      for (size_t i = 0; i < deg.size(); ++i) CHECK_EQ(host[lwe_size + i], deg[i]);
+    }
+    // apply_generic_blind_rotation
+    CudaLweCiphertextList<u64> d_out(output_lwe_dimension, 1, ciphertext_modulus, stream), d_std(output_lwe_dimension, 1, ciphertext_modulus, stream);
+    programmable_bootstrap_multi_bit_noise_tests(stream, d_out.d_vec, zero_index, d_accumulator.d_vec, zero_index, d_switched.d_vec, zero_index,
+                                                 d_bsk.d_vec, input_lwe_dimension, glwe_dimension, polynomial_size, params.decomp_base_log,
+                                                 params.decomp_level_count, grouping_factor, 1);
+    cuda_multi_bit_programmable_bootstrap_lwe_ciphertext(d_input, d_std, d_accumulator, zero_index, zero_index, zero_index, d_bsk, stream);
+    const std::vector<u64> out = d_out.to_lwe_ciphertext_list(stream), std_out = d_std.to_lwe_ciphertext_list(stream);
+    assert_gpu_determinism(std_out, out, "programmable_bootstrap_multi_bit_noise_tests vs the standard multi-bit bootstrap");
+    const u64 decrypted = orc_lwe_decrypt(out.data(), output_glwe_secret_key.data(), (uint32_t)output_lwe_dimension);
+    CHECK_EQ(round_decode(decrypted, delta) % msg_modulus, f(msg));
+  }
+}
+
 // lwe_keyswitch.rs:72-312 `base_lwe_encrypt_ks_decrypt_custom_mod`: GEMM and classic keyswitch decrypt correctly, are
 // bit-wise equal, and only a subset of the LWEs can be keyswitched (the others stay zero)
 static void base_lwe_encrypt_ks_decrypt_custom_mod(size_t lwe_dimension, double lwe_noise_std, size_t message_modulus_log, size_t glwe_dimension,
@@ -603,13 +663,19 @@ int main(int argc, char **argv) {
     if (ks)
       tests.push_back({std::string("test_gpu_lwe_encrypt_ks_decrypt_custom_mod_mb_") + p.name, [&p] { lwe_encrypt_ks_decrypt_custom_mod_mb(p); }});
   };
+  auto mb_noise = [&](const MultiBitTestParams &p) {
+    tests.push_back({std::string("noise_tests_multi_bit_mod_switch_then_blind_rotation_") + p.name, [&p] { multi_bit_mod_switch_then_blind_rotation(p); }});
+  };
   if (g_toy) {
     classic(TOY_4_BITS_N2048);
     classic(TOY_2_BITS_K2_N256);
     multi_bit(TOY_MB_2, true);
     multi_bit(TOY_MB_3, false);
     multi_bit(TOY_MB_4, false);
+    mb_noise(TOY_MB_4);
   } else {
+    mb_noise(MULTI_BIT_2_2_3_PARAMS);
+    mb_noise(MULTI_BIT_2_2_4_PARAMS);
     classic(TEST_PARAMS_4_BITS_NATIVE_U64);
     multi_bit(MULTI_BIT_2_2_2_PARAMS, true);
     multi_bit(MULTI_BIT_2_2_3_PARAMS, true);

@@ -73,6 +73,24 @@ ABORTS = {
         v = gpu.CudaVec(4096, st)
         lib.cuda_keyswitch_lwe_ciphertext_vector_64_64_async(S, G, v.ptr, v.ptr, v.ptr, v.ptr, v.ptr, 16, 4, 16, 4, 1)
         """, "keyswitch: unsupported decomposition"),
+    "multi-bit modulus switch outside degree 2048 (cuda/src/crypto/torus.cuh:641-650)": ("""
+        v = gpu.CudaVec(4096, st)
+        lib.cuda_modulus_switch_multi_bit_64_async(S, G, v.ptr, v.ptr, 919, 11, 1024, 3)
+        """, "unsupported polynomial size"),
+    "noise-tests multi-bit bootstrap with more than one ciphertext (programmable_bootstrap_multibit.cu:683-685)": ("""
+        buf = C.c_void_p()
+        lib.scratch_cuda_multi_bit_programmable_bootstrap_noise_tests_64_async(S, G, C.byref(buf), 1, 2048, 1, 2, True)
+        v = gpu.CudaVec(4 * 4100, st)
+        lib.cuda_multi_bit_programmable_bootstrap_noise_tests_64_async(S, G, v.ptr, v.ptr, v.ptr, v.ptr, v.ptr, v.ptr, v.ptr,
+                                                                       buf, 8, 1, 2048, 4, 22, 1, 2, 1, 0)
+        """, "should be 1"),
+    "noise-tests multi-bit bootstrap outside N = 2048 (programmable_bootstrap_multibit.cu:690-693)": ("""
+        buf = C.c_void_p()
+        lib.scratch_cuda_multi_bit_programmable_bootstrap_noise_tests_64_async(S, G, C.byref(buf), 1, 1024, 1, 1, True)
+        v = gpu.CudaVec(4 * 4100, st)
+        lib.cuda_multi_bit_programmable_bootstrap_noise_tests_64_async(S, G, v.ptr, v.ptr, v.ptr, v.ptr, v.ptr, v.ptr, v.ptr,
+                                                                       buf, 8, 1, 1024, 4, 22, 1, 1, 1, 0)
+        """, "only polynomial size 2048 is supported"),
     "cleanup of a foreign buffer": ("""
         junk = (C.c_uint64 * 64)()
         p = C.c_void_p(C.addressof(junk))

@@ -391,6 +391,36 @@ def cuda_modulus_switch_ciphertext(output_vec, input_vec, lwe_dimension, log_mod
         _lib().cuda_modulus_switch_64_async(s, g, output_vec.ptr, input_vec.ptr, lwe_dimension + 1, log_modulus)
 
 
+def cuda_modulus_switch_multi_bit_ciphertext(streams, lwe_array_out, lwe_array_in, log_modulus, polynomial_size,
+                                             grouping_factor):
+    """gpu/ffi.rs:914-936: the multi-bit modulus switch as its own launch (the reference's noise tests); `lwe_array_in`
+    is a CudaVec of len() words read as len() // grouping_factor groups, 2^grouping_factor degrees written per group."""
+    _lib().cuda_modulus_switch_multi_bit_64_async(streams.ptr[0], streams.gpu_indexes[0], lwe_array_out.ptr,
+                                                  lwe_array_in.ptr, lwe_array_in.len, log_modulus, polynomial_size,
+                                                  grouping_factor)
+    streams.synchronize()
+
+
+def programmable_bootstrap_multi_bit_noise_tests(streams, lwe_array_out, output_indexes, test_vector, test_vector_indexes,
+                                                 lwe_array_in, input_indexes, bootstrapping_key, lwe_dimension,
+                                                 glwe_dimension, polynomial_size, base_log, level, grouping_factor,
+                                                 num_samples):
+    """gpu/ffi.rs:322-397: multi-bit PBS on an input that already carries the output of the multi-bit modulus switch
+    behind the ciphertext ([lwe | degrees]); CudaVec arguments, one ciphertext, N = 2048."""
+    assert polynomial_size == 2048, (
+        f"programmable_bootstrap_multi_bit_noise_tests only supports polynomial size 2048, got {polynomial_size}")
+    lib = _lib()
+    buf = C.c_void_p()
+    s, g = streams.ptr[0], streams.gpu_indexes[0]
+    lib.scratch_cuda_multi_bit_programmable_bootstrap_noise_tests_64_async(s, g, C.byref(buf), glwe_dimension,
+                                                                           polynomial_size, level, num_samples, True)
+    lib.cuda_multi_bit_programmable_bootstrap_noise_tests_64_async(
+        s, g, lwe_array_out.ptr, output_indexes.ptr, test_vector.ptr, test_vector_indexes.ptr, lwe_array_in.ptr,
+        input_indexes.ptr, bootstrapping_key.ptr, buf, lwe_dimension, glwe_dimension, polynomial_size, grouping_factor,
+        base_log, level, num_samples, 1, 0)
+    lib.cleanup_cuda_multi_bit_programmable_bootstrap_noise_tests_64(s, g, C.byref(buf))
+
+
 def get_number_of_gpus():
     return _lib().cuda_get_number_of_gpus()
 

@@ -836,6 +836,52 @@ void cleanup_cuda_multi_bit_programmable_bootstrap_64(void *stream, uint32_t gpu
   *pbs_buffer = nullptr;
 }
 
+// The reference's noise tests run the blind rotation on an input that the multi-bit switch has ALREADY been applied to
+// (cuda/include/pbs/programmable_bootstrap_multibit.h:44-60, cuda/src/pbs/programmable_bootstrap_multibit.cu:650-760;
+// bound by tfhe/src/core_crypto/gpu/ffi.rs:322-397): lwe_array_in = [ the input ciphertext, n + 1 words | the output of
+// cuda_modulus_switch_multi_bit_64_async, (n / g) 2^g words ]; the keybundle takes its monomial degrees from the second
+// part (programmable_bootstrap_multibit.cuh:85-107), the body and everything else are read where they always are.
+// One ciphertext per call and N = 2048 only, as there.  scratch / cleanup are the standard ones under their own names.
+uint64_t scratch_cuda_multi_bit_programmable_bootstrap_noise_tests_64_async(void *stream, uint32_t gpu_index,
+                                                                            int8_t **pbs_buffer, uint32_t glwe_dimension,
+                                                                            uint32_t polynomial_size, uint32_t level_count,
+                                                                            uint32_t input_lwe_ciphertext_count,
+                                                                            bool allocate_gpu_memory) {
+  return scratch_cuda_multi_bit_programmable_bootstrap_64_async(stream, gpu_index, pbs_buffer, glwe_dimension,
+                                                                polynomial_size, level_count, input_lwe_ciphertext_count,
+                                                                allocate_gpu_memory);
+}
+void cleanup_cuda_multi_bit_programmable_bootstrap_noise_tests_64(void *stream, uint32_t gpu_index, int8_t **pbs_buffer) {
+  cleanup_cuda_multi_bit_programmable_bootstrap_64(stream, gpu_index, pbs_buffer);
+}
+void cuda_multi_bit_programmable_bootstrap_noise_tests_64_async(
+    void *stream, uint32_t gpu_index, void *lwe_array_out, void const *lwe_output_indexes, void const *lut_vector,
+    void const *lut_vector_indexes, void const *lwe_array_in, void const *lwe_input_indexes, void const *bootstrapping_key,
+    int8_t *buffer, uint32_t lwe_dimension, uint32_t glwe_dimension, uint32_t polynomial_size, uint32_t grouping_factor,
+    uint32_t base_log, uint32_t level_count, uint32_t num_samples, uint32_t num_many_lut, uint32_t lut_stride) {
+  set_device(gpu_index);
+  HX_PANIC_IF_FALSE(num_samples == 1, "(multi-bit PBS): num_samples (%u) should be 1", num_samples);
+  HX_PANIC_IF_FALSE(base_log <= 64, "(multi-bit PBS): base log (%u) should be <= 64", base_log);
+  HX_PANIC_IF_FALSE(polynomial_size == 2048, "(multi-bit PBS noise tests): only polynomial size 2048 is supported, got %u.",
+                    polynomial_size);
+  auto *b = reinterpret_cast<MultiBitBuffer *>(buffer);
+  HX_PANIC_IF_FALSE(b != nullptr && b->magic == kMbMagic, "multi-bit PBS buffer was not created by its scratch function");
+  HX_PANIC_IF_FALSE(b->gpu_memory_allocated, "multi-bit PBS buffer was created with allocate_gpu_memory=false");
+  HX_PANIC_IF_FALSE(b->glwe_dimension == glwe_dimension && b->polynomial_size == polynomial_size &&
+                        b->level_count == level_count && num_samples <= b->max_samples,
+                    "multi-bit PBS buffer parameters do not match the call");
+  HX_PANIC_IF_FALSE(grouping_factor >= 1 && grouping_factor <= 4 && lwe_dimension % grouping_factor == 0,
+                    "unsupported grouping_factor %u for lwe_dimension %u", grouping_factor, lwe_dimension);
+  MultiBitArgs m;
+  m.pbs = make_args(lwe_array_out, lwe_output_indexes, lut_vector, lut_vector_indexes, lwe_array_in, lwe_input_indexes,
+                    bootstrapping_key, lwe_dimension, base_log, level_count, num_samples, num_many_lut, lut_stride, 0);
+  m.grouping_factor = grouping_factor;
+  m.pbs.mb_degrees = (const uint64_t *)lwe_array_in + (lwe_dimension + 1);
+  // one ciphertext, read once: the one-launch kernel (the only one that takes its degrees from memory)
+  launch_pbs_multi_bit(S(stream), polynomial_size, glwe_dimension, m, b->fft, b->acc);
+  g_last_pbs_kernel.store(4);
+}
+
 // =========================================================================== keyswitch
 void cuda_keyswitch_lwe_ciphertext_vector_64_64_async(void *stream, uint32_t gpu_index, void *lwe_array_out,
                                                       void const *lwe_output_indexes, void const *lwe_array_in,
@@ -925,6 +971,20 @@ void cuda_centered_modulus_switch_64_async(void *stream, uint32_t gpu_index, voi
   HX_PANIC_IF_FALSE(lwe_out != lwe_in, "Output and input pointers must be different for out-of-place operations");
   launch_centered_modulus_switch(S(stream), (uint64_t *)lwe_out, (const uint64_t *)lwe_in, lwe_dimension,
                                  log_modulus);
+}
+// cuda/include/ciphertext.h:45-50, cuda/src/crypto/{ciphertext.cu:166-178, torus.cuh:612-653}: `size` words of
+// lwe_array_in are read as size / grouping_factor groups (the reference's caller passes the whole ciphertext, body
+// included; the integer division drops it), 2^g words per group are written.  As in the reference the switch goes to
+// 2 * degree whatever log_modulus says (torus.cuh:158 uses params::log2_degree + 1) and only degree 2048 is accepted.
+void cuda_modulus_switch_multi_bit_64_async(void *stream, uint32_t gpu_index, void *lwe_array_out, void *lwe_array_in,
+                                            uint32_t size, uint32_t log_modulus, uint32_t degree,
+                                            uint32_t grouping_factor) {
+  set_device(gpu_index);
+  (void)log_modulus;
+  HX_PANIC_IF_FALSE(degree == 2048, "unsupported polynomial size. Supported N's are powers of two in the interval [2048].");
+  HX_PANIC_IF_FALSE(grouping_factor >= 1 && grouping_factor <= 4, "unsupported grouping_factor %u", grouping_factor);
+  launch_modulus_switch_multi_bit(S(stream), (uint64_t *)lwe_array_out, (const uint64_t *)lwe_array_in,
+                                  size / grouping_factor, 12, grouping_factor);
 }
 
 // =========================================================================== extensions

@@ -45,6 +45,28 @@ __global__ void closest_representable_kernel(const uint64_t *in, uint64_t *out, 
   out[0] = res << shift;
 }
 
+// The multi-bit switch as a launch of its own (only the reference's noise tests call it; in production it is fused into the
+// keybundle): per group of g mask words the 2^g subset degrees, subset s summing word m when bit (g - 1 - m) of s is set,
+// the sum wrapping BEFORE the switch (cuda/src/crypto/torus.cuh:148-159,612-630; slot 0 = switch(0) = 0, as there)
+__global__ void modulus_switch_multi_bit_kernel(uint64_t *out, const uint64_t *in, uint32_t groups, uint32_t log_modulus,
+                                                uint32_t g) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= groups) return;
+  const uint32_t per = 1u << g;
+  const uint64_t *grp = in + (size_t)t * g;
+  for (uint32_t s = 0; s < per; ++s) {
+    uint64_t sum = 0;
+    for (uint32_t m = 0; m < g; ++m)
+      if ((s >> (g - 1 - m)) & 1) sum += grp[m];
+    out[(size_t)t * per + s] = modulus_switch(sum, log_modulus);
+  }
+}
+void launch_modulus_switch_multi_bit(hipStream_t st, uint64_t *out, const uint64_t *in, uint32_t groups, uint32_t log_modulus,
+                                     uint32_t g) {
+  if (!groups) return;
+  HX_LAUNCH(modulus_switch_multi_bit_kernel, dim3((groups + 255) / 256), dim3(256), 0, st, out, in, groups, log_modulus, g);
+}
+
 void launch_modulus_switch(hipStream_t st, uint64_t *out, const uint64_t *in, uint32_t size, uint32_t log_modulus) {
   if (!size) return;
   HX_LAUNCH(modulus_switch_kernel, dim3((size + 255) / 256), dim3(256), 0, st, out, in, size, log_modulus);

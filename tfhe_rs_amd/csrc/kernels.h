@@ -69,6 +69,8 @@ extern bool g_ntt_kernel_serial;
 // small helpers — ciphertext.hip
 void launch_iota_u64(hipStream_t st, uint64_t *out, uint32_t count);  // out[i] = i
 void launch_modulus_switch(hipStream_t st, uint64_t *out, const uint64_t *in, uint32_t size, uint32_t log_modulus);
+void launch_modulus_switch_multi_bit(hipStream_t st, uint64_t *out, const uint64_t *in, uint32_t groups, uint32_t log_modulus,
+                                     uint32_t g);
 void launch_centered_modulus_switch(hipStream_t st, uint64_t *out, const uint64_t *in, uint32_t lwe_dim, uint32_t log_modulus);
 void launch_sample_extract(hipStream_t st, uint64_t *lwe_out, const uint64_t *glwe_in, const uint32_t *nth,
                            uint32_t num_nths, uint32_t lwe_per_glwe, uint32_t stored_per_glwe, uint32_t glwe_dim,

@@ -62,7 +62,12 @@ __global__ void __launch_bounds__(GenericCfg<N>::TPB)
   for (uint32_t grp = 0; grp < groups; ++grp) {
     const cplx *gk = bsk + (size_t)grp * per * ggsw_c;
     uint32_t deg[16];
-    multi_bit_degrees(lwe + (size_t)grp * grouping, grouping, LOG2N2, deg);
+    if (a.mb_degrees != nullptr) {  // noise-test entry point: degrees switched ahead, [input][group][subset]
+      const uint64_t *pre = a.mb_degrees + ((size_t)a.in_idx[sample] * groups + grp) * per;
+      for (uint32_t s = 1; s < per; ++s) deg[s] = (uint32_t)pre[s];
+    } else {
+      multi_bit_degrees(lwe + (size_t)grp * grouping, grouping, LOG2N2, deg);
+    }
     // ---- dst = 0 + src (x) keybundle   (ggsw.rs:483-602 with a zeroed output), keybundle built point by point
     cplx facc[K1][PER];
     bool first = true;

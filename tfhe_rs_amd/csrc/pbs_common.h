@@ -38,6 +38,11 @@ struct PbsArgs {
   // the workgroups of an XCD stay within a few groups of each other so that a group's key is fetched from HBM
   // once per XCD instead of once per workgroup
   uint32_t *pace = nullptr;
+  // multi-bit PBS of the reference's noise tests only (cuda_multi_bit_programmable_bootstrap_noise_tests_64_async): the
+  // subset degrees of every group, already modulus switched by cuda_modulus_switch_multi_bit_64_async, as 2^g words per
+  // group ([group][subset]) per input — the keybundle reads them instead of switching the mask sums itself
+  // (programmable_bootstrap_multibit.cuh:85-107)
+  const uint64_t *mb_degrees = nullptr;
   // Throughput kernel for N = 2048, k = 1 only (null otherwise): the sample extraction ALSO writes the keyswitch
   // operands of its output — for every mask word the shifted digits d + B/2 of the keyswitch that will read this
   // ciphertext next, as bytes in the A-operand layout of ks_gemm_kernel ([tile of 32 samples][step of 32 k][lane =

@@ -80,6 +80,10 @@ SIGNATURES = {
     "cuda_multi_bit_programmable_bootstrap_64_async":
         (None, [_v, _u32, _v, _v, _v, _v, _v, _v, _v, _v, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _u32]),
     "cleanup_cuda_multi_bit_programmable_bootstrap_64": (None, [_v, _u32, _i8pp]),
+    "scratch_cuda_multi_bit_programmable_bootstrap_noise_tests_64_async": (_u64, [_v, _u32, _i8pp, _u32, _u32, _u32, _u32, _b]),
+    "cuda_multi_bit_programmable_bootstrap_noise_tests_64_async":
+        (None, [_v, _u32, _v, _v, _v, _v, _v, _v, _v, _v, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _u32]),
+    "cleanup_cuda_multi_bit_programmable_bootstrap_noise_tests_64": (None, [_v, _u32, _i8pp]),
     # keyswitch
     "cuda_keyswitch_lwe_ciphertext_vector_64_64_async":
         (None, [_v, _u32, _v, _v, _v, _v, _v, _u32, _u32, _u32, _u32, _u32]),
@@ -95,6 +99,7 @@ SIGNATURES = {
     "cuda_modulus_switch_inplace_64_async": (None, [_v, _u32, _v, _u32, _u32]),
     "cuda_modulus_switch_64_async": (None, [_v, _u32, _v, _v, _u32, _u32]),
     "cuda_centered_modulus_switch_64_async": (None, [_v, _u32, _v, _v, _u32, _u32]),
+    "cuda_modulus_switch_multi_bit_64_async": (None, [_v, _u32, _v, _v, _u32, _u32, _u32, _u32]),
     # extensions
     "hip_convert_lwe_programmable_bootstrap_key_ntt64_async": (None, [_v, _u32, _v, _v, _u32, _u32, _u32, _u32]),
     "hip_programmable_bootstrap_ntt64_async":

@@ -470,6 +470,39 @@ inline void programmable_bootstrap_multi_bit(const CudaStreams &streams, CudaVec
   cleanup_cuda_multi_bit_programmable_bootstrap_64(s, g, &pbs_buffer);
 }
 
+// gpu/ffi.rs:322-397 `programmable_bootstrap_multi_bit_noise_tests` (#[cfg(test)] there): the multi-bit bootstrap on an input
+// that already carries the multi-bit modulus switch's output behind the ciphertext
+inline void programmable_bootstrap_multi_bit_noise_tests(
+    const CudaStreams &streams, CudaVec<uint64_t> &lwe_array_out, const CudaVec<uint64_t> &output_indexes,
+    const CudaVec<uint64_t> &test_vector, const CudaVec<uint64_t> &test_vector_indexes, const CudaVec<uint64_t> &lwe_array_in,
+    const CudaVec<uint64_t> &input_indexes, const CudaVec<uint64_t> &bootstrapping_key, size_t lwe_dimension, size_t glwe_dimension,
+    size_t polynomial_size, size_t base_log, size_t level, size_t grouping_factor, uint32_t num_samples) {
+  detail::assert_eq(polynomial_size, (size_t)2048, "programmable_bootstrap_multi_bit_noise_tests only supports polynomial size 2048");
+  const uint32_t num_many_lut = 1, lut_stride = 0;
+  int8_t *pbs_buffer = nullptr;
+  void *s = streams.ptr[0];
+  const uint32_t g = streams.gpu_indexes[0].get();
+  scratch_cuda_multi_bit_programmable_bootstrap_noise_tests_64_async(s, g, &pbs_buffer, (uint32_t)glwe_dimension,
+                                                                     (uint32_t)polynomial_size, (uint32_t)level, num_samples, true);
+  cuda_multi_bit_programmable_bootstrap_noise_tests_64_async(
+      s, g, lwe_array_out.as_mut_c_ptr(0), output_indexes.as_c_ptr(0), test_vector.as_c_ptr(0), test_vector_indexes.as_c_ptr(0),
+      lwe_array_in.as_c_ptr(0), input_indexes.as_c_ptr(0), bootstrapping_key.as_c_ptr(0), pbs_buffer, (uint32_t)lwe_dimension,
+      (uint32_t)glwe_dimension, (uint32_t)polynomial_size, (uint32_t)grouping_factor, (uint32_t)base_log, (uint32_t)level,
+      num_samples, num_many_lut, lut_stride);
+  cleanup_cuda_multi_bit_programmable_bootstrap_noise_tests_64(s, g, &pbs_buffer);
+}
+
+// gpu/ffi.rs:914-936 `cuda_modulus_switch_multi_bit_ciphertext`; `out_offset_words` stands for the reference caller's
+// `as_mut_c_ptr(0).add(lwe_size)` (noise_simulation.rs:1337-1352: the switch writes behind the copied input)
+inline void cuda_modulus_switch_multi_bit_ciphertext(const CudaStreams &streams, CudaVec<uint64_t> &lwe_array_out,
+                                                     CudaVec<uint64_t> &lwe_array_in, uint32_t log_modulus, uint32_t polynomial_size,
+                                                     uint32_t grouping_factor, size_t out_offset_words = 0) {
+  cuda_modulus_switch_multi_bit_64_async(streams.ptr[0], streams.gpu_indexes[0].get(),
+                                         (uint64_t *)lwe_array_out.as_mut_c_ptr(0) + out_offset_words, lwe_array_in.as_mut_c_ptr(0),
+                                         (uint32_t)lwe_array_in.len, log_modulus, polynomial_size, grouping_factor);
+  streams.synchronize();
+}
+
 // gpu/ffi.rs:503-618 `keyswitch_async` / `keyswitch_async_gemm`: u64 input ciphertexts; the key scalar selects the 64 -> 64
 // or the 64 -> 32 entry points (the KS32 atomic pattern: u32 key, u32 output ciphertexts)
 template <class KeyT>
