@@ -50,9 +50,10 @@ void cuda_destroy_stream(void *stream, uint32_t gpu_index);
 void cuda_synchronize_stream(void *stream, uint32_t gpu_index);
 uint32_t cuda_is_available(void);
 void *cuda_malloc(uint64_t size, uint32_t gpu_index);
-/* a plain hipMalloc unless TFHE_HIP_MALLOC_ASYNC=pool (hipMallocAsync's pool corrupted live allocations under the
- * reference's cuda_malloc_async / cuda_drop pairing on ROCm 7.2.0: INTEGRATION.md; device.cu:176-218 falls back to
- * cudaMalloc the same way on devices without memory pools) */
+/* stream-ordered: an enqueue on `stream`, no device synchronisation, usable under stream capture — served by the library's own
+ * arena (hip_backend_trim_allocator below; TFHE_HIP_MALLOC_ASYNC=sync|pool|pool_hipfree select a plain hipMalloc or the
+ * runtime's hipMallocAsync pool, which corrupted live allocations on ROCm 7.2.0: INTEGRATION.md).  cuda_drop returns such a
+ * block in stream order behind the work queued on `stream` so far (device.cu:176-226, 457-491). */
 void *cuda_malloc_async(uint64_t size, void *stream, uint32_t gpu_index);
 bool cuda_check_valid_malloc(uint64_t size, uint32_t gpu_index);
 uint64_t cuda_device_total_memory(uint32_t gpu_index);
@@ -472,6 +473,12 @@ uint64_t hip_integer_propagate_pbs_count(uint32_t num_blocks);
  * kernel without the sharing of key loads between the two LWEs of a quad of waves, 8 the throughput kernel with
  * sharing among quads only, not among all eight waves of a full workgroup of a one-level set (both: comparison). */
 void hip_backend_set_fft_kernel(uint32_t which);
+/* The stream-ordered arena behind cuda_malloc_async / cuda_drop (tfhe_rs_amd/csrc/arena.hip; the reference's device pool,
+ * tfhe-cuda-common/cuda/src/device.cu:70-120,176-226).  trim: every idle cached block goes back to the runtime, returns the
+ * bytes released (the reference's pool keeps a release threshold instead).  stats: out7 = allocations, re-uses, blocks taken
+ * from the runtime, drops, re-uses that made the new stream wait for the old one's event, live bytes, cached bytes. */
+uint64_t hip_backend_trim_allocator(uint32_t gpu_index);
+void hip_backend_allocator_stats(uint32_t gpu_index, uint64_t *out7);
 /* test hook: cap of the groups the multi-bit latency path processes per pass (0 = what the scratch holds) */
 void hip_backend_set_multibit_latency_groups(uint32_t groups);
 /* keyswitch kernel: 0 = automatic (int8 matrix-core GEMM, any batch size, when level <= 16 (padded to a power of

@@ -16,6 +16,7 @@
 // Test infrastructure: client-side key generation, radix encryption and decryption use the oracle's primitives
 // (oracle/tfhe_oracle.h); randomness is seeded.
 //   usage: reference_integer_gpu_tests <toy|reference> [test-name-substring]
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -330,11 +331,51 @@ static void integer_mul(const TestParameters &param) {
   }
 }
 
+// One FheUint64 (32 blocks) addition / multiplication at a time the way the reference's host issues it — operands duplicated
+// into a fresh CudaVec, scratch made, operation launched, scratch cleaned up, temporaries dropped, stream synchronised (radix/
+// add.rs `add`, mul.rs `mul`) — timed on the host clock.  `latency` mode: one JSON line per (parameter set, operation), with the
+// allocator's counters, so that TFHE_HIP_MALLOC_ASYNC=sync (hipMalloc / hipFree per CudaVec and per scratch array) and the
+// default arena can be compared on the same box.
+static void latency_mode(const TestParameters &param, size_t adds, size_t muls) {
+  Keys &k = key_cache(param);
+  const size_t blocks = 32;
+  const auto a = k.encrypt_radix(k.random(), blocks), b = k.encrypt_radix(k.random(), blocks);
+  auto timed = [&](const char *what, size_t reps, const std::function<CudaUnsignedRadixCiphertext()> &op) {
+    { auto warm = op(); k.streams.synchronize(); }
+    uint64_t s0[7], s1[7];
+    hip_backend_allocator_stats(0, s0);
+    std::vector<double> ms;
+    for (size_t i = 0; i < reps; ++i) {
+      const auto t0 = std::chrono::steady_clock::now();
+      { auto r = op(); k.streams.synchronize(); }
+      ms.push_back(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    }
+    hip_backend_allocator_stats(0, s1);
+    std::sort(ms.begin(), ms.end());
+    const char *mode = std::getenv("TFHE_HIP_MALLOC_ASYNC");
+    std::printf("{\"what\": \"%s\", \"params\": \"%s\", \"blocks\": %zu, \"reps\": %zu, \"allocator\": \"%s\", \"ms_median\": %.3f, \"ms_min\": %.3f, "
+                "\"ms_max\": %.3f, \"arena_allocations_per_op\": %.1f, \"arena_runtime_allocations\": %llu, \"arena_cached_bytes\": %llu}\n",
+                what, param.name, blocks, reps, mode ? mode : "arena", ms[ms.size() / 2], ms.front(), ms.back(), double(s1[0] - s0[0]) / reps,
+                (unsigned long long)(s1[2] - s0[2]), (unsigned long long)s1[6]);
+    std::fflush(stdout);
+  };
+  timed("fheuint64_add", adds, [&] { return k.sks->add(a, b, k.streams); });
+  timed("fheuint64_mul", muls, [&] { return k.sks->mul(a, b, k.streams); });
+}
+
 struct Test {
   std::string name;
   std::function<void()> body;
 };
 int main(int argc, char **argv) {
+  if (argc >= 2 && !std::strcmp(argv[1], "latency")) {
+    if (!is_cuda_available()) return 2;
+    const bool toy = argc > 2 && !std::strcmp(argv[2], "toy");
+    latency_mode(toy ? TOY_MESSAGE_2_CARRY_2 : PARAM_MESSAGE_2_CARRY_2_KS_PBS_TUNIFORM_2M128, toy ? 3 : 30, toy ? 1 : 8);
+    latency_mode(toy ? TOY_MULTI_BIT_GROUP_4_MESSAGE_2_CARRY_2 : TEST_PARAM_GPU_MULTI_BIT_GROUP_4_MESSAGE_2_CARRY_2_KS_PBS_TUNIFORM_2M128, toy ? 3 : 30,
+                 toy ? 1 : 8);
+    return 0;
+  }
   if (argc < 2 || (std::strcmp(argv[1], "toy") && std::strcmp(argv[1], "reference"))) {
     std::fprintf(stderr, "usage: %s <toy|reference> [test-name-substring]\n", argv[0]);
     return 2;

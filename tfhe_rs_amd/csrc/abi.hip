@@ -2,6 +2,7 @@
 // interface each one replaces, in include/tfhe_hip_backend.h).
 #include "../../include/tfhe_hip_backend.h"
 #include "kernels.h"
+#include "arena.h"
 
 #include <atomic>
 #include <cstdlib>
@@ -115,6 +116,7 @@ void cuda_destroy_stream(void *stream, uint32_t gpu_index) {
   set_device(gpu_index);
   HX_CHECK(hipStreamSynchronize(S(stream)));
   ksd_release_stream((int)gpu_index, S(stream));
+  arena_release_stream((int)gpu_index, S(stream));
   HX_CHECK(hipStreamDestroy(S(stream)));
 }
 void cuda_synchronize_stream(void *stream, uint32_t gpu_index) {
@@ -128,25 +130,23 @@ void *cuda_malloc(uint64_t size, uint32_t gpu_index) {
   HX_CHECK(hipMalloc(&p, size));
   return p;
 }
-// Stream-ordered allocations: the reference pairs cuda_malloc_async with the synchronous cuda_drop (CudaVec::new_async /
-// Drop, tfhe/src/core_crypto/gpu/vec.rs) and falls back to cudaMalloc on devices without memory pools
-// (tfhe-cuda-common/cuda/src/device.cu:176-218).  On this runtime (ROCm 7.2.0, MI355X) hipMallocAsync's pool is not
-// usable that way: in the reference's keyswitch test restated in tests/cpp the index arrays of a LIVE pool allocation
-// changed after other pool allocations were freed and re-made — with hipFree as with hipFreeAsync + device
-// synchronisation, and in a program that uses nothing but the runtime (tools/probes/pool_probe.hip;
-// profiles/r04h_ks_cpp_diag*.txt).  cuda_malloc_async is therefore a plain hipMalloc by default — every launch of this
-// library takes its scratch from scratch_* calls, so nothing on the hot path allocates — and the pool stays
-// selectable for diagnosis: TFHE_HIP_MALLOC_ASYNC=pool (pool pointers remembered with their sizes, returned with
-// hipFreeAsync + hipDeviceSynchronize by cuda_drop) or pool_hipfree (returned with hipFree).
+// Stream-ordered allocations (the reference: cudaMallocAsync on the device pool, tfhe-cuda-common/cuda/src/device.cu:176-226;
+// CudaVec::new_async / Drop allocate and drop per operation, tfhe/src/core_crypto/gpu/vec.rs:94-150,487-495).  Default: the
+// library's own arena (arena.hip) — an allocation is an enqueue, never a device synchronisation, and works under stream
+// capture.  hipMallocAsync's pool is not usable on this runtime (ROCm 7.2.0, MI355X: a LIVE pool allocation changed after
+// other pool allocations were freed and re-made, in a program that uses nothing but the runtime — tools/probes/
+// pool_probe.hip, profiles/r04h_ks_cpp_diag*.txt); it and the plain hipMalloc / hipFree pair of round 4 stay selectable for
+// comparison: TFHE_HIP_MALLOC_ASYNC=arena (default) | sync | pool | pool_hipfree.
 static std::mutex g_pool_mutex;
 static std::unordered_map<const void *, size_t> g_pool_allocations;
-static int malloc_async_mode() {  // 1 = hipMalloc (default), 0 = pool + tracked free, 2 = pool + hipFree (both: diagnosis)
+static int malloc_async_mode() {  // 3 = arena (default), 1 = hipMalloc, 0 = pool + tracked free, 2 = pool + hipFree
   static const int mode = [] {
     const char *e = std::getenv("TFHE_HIP_MALLOC_ASYNC");
-    if (e == nullptr || !std::strcmp(e, "sync")) return 1;
+    if (e == nullptr || !std::strcmp(e, "arena")) return 3;
+    if (!std::strcmp(e, "sync")) return 1;
     if (!std::strcmp(e, "pool")) return 0;
     if (!std::strcmp(e, "pool_hipfree")) return 2;
-    HX_PANIC("TFHE_HIP_MALLOC_ASYNC=%s: expected pool, sync or pool_hipfree", e);
+    HX_PANIC("TFHE_HIP_MALLOC_ASYNC=%s: expected arena, sync, pool or pool_hipfree", e);
     return 0;
   }();
   return mode;
@@ -154,6 +154,7 @@ static int malloc_async_mode() {  // 1 = hipMalloc (default), 0 = pool + tracked
 void *cuda_malloc_async(uint64_t size, void *stream, uint32_t gpu_index) {
   set_device(gpu_index);
   void *p = nullptr;
+  if (malloc_async_mode() == 3) return arena_alloc((int)gpu_index, size, S(stream));
   if (malloc_async_mode() == 1) {
     HX_CHECK(hipMalloc(&p, size));
     return p;
@@ -227,6 +228,14 @@ void cuda_drop(void *ptr, uint32_t gpu_index) {
   set_device(gpu_index);
   size_t pool_bytes = 0;
   bool from_pool = false;
+  {
+    // an arena block goes back to the arena in stream order: no runtime call, no synchronisation (arena.hip)
+    size_t user_bytes = 0;
+    if (ptr != nullptr && arena_free((int)gpu_index, ptr, &user_bytes)) {
+      ksm_invalidate_range((int)gpu_index, ptr, user_bytes);  // a keyswitch key in it takes its cached layout along
+      return;
+    }
+  }
   if (ptr != nullptr) {
     std::lock_guard<std::mutex> lock(g_pool_mutex);
     auto it = g_pool_allocations.find(ptr);
@@ -321,7 +330,7 @@ uint64_t scratch_cuda_programmable_bootstrap_64_async(void *stream, uint32_t gpu
   const uint64_t bytes = polynomial_size <= 4096 ? 0
                                                  : (uint64_t)input_lwe_ciphertext_count * (glwe_dimension + 1) *
                                                        polynomial_size * sizeof(uint64_t);
-  if (allocate_gpu_memory && bytes) HX_CHECK(hipMalloc((void **)&b->acc_scratch, bytes));
+  if (allocate_gpu_memory && bytes) b->acc_scratch = (uint64_t *)scratch_alloc(bytes);
   *buffer = reinterpret_cast<int8_t *>(b);
   return bytes;
 }
@@ -342,8 +351,8 @@ uint64_t hip_scratch_keyswitch_programmable_bootstrap_64_async(void *stream, uin
   const uint64_t ks_bytes = (uint64_t)input_lwe_ciphertext_count * (lwe_dimension + 1) * sizeof(uint64_t);
   const uint64_t idx_bytes = (uint64_t)input_lwe_ciphertext_count * sizeof(uint64_t);
   if (allocate_gpu_memory && ks_bytes) {
-    HX_CHECK(hipMalloc((void **)&b->ks_out, ks_bytes));
-    HX_CHECK(hipMalloc((void **)&b->trivial, idx_bytes));
+    b->ks_out = (uint64_t *)scratch_alloc(ks_bytes);
+    b->trivial = (uint64_t *)scratch_alloc(idx_bytes);
     launch_iota_u64(S(stream), b->trivial, input_lwe_ciphertext_count);
   }
   return bytes + ks_bytes + idx_bytes;
@@ -499,7 +508,7 @@ void hip_keyswitch_programmable_bootstrap_chain_64_async(void *stream, uint32_t 
       // first use (or another decomposition): an allocation, hence never under stream capture; a buffer that is
       // replaced is kept until the scratch is cleaned up — a graph captured earlier may hold its address
       if (b->emit_a) b->emit_retired.push_back(b->emit_a);
-      HX_CHECK(hipMalloc((void **)&b->emit_a, need));
+      b->emit_a = (int8_t *)scratch_alloc(need);
       b->emit_bytes = need;
     }
     if (b->emit_bytes >= need) {  // (a capture that found no buffer: no emission, the next keyswitch runs its digit pass)
@@ -585,9 +594,9 @@ void hip_programmable_bootstrap_ntt64_split_async(void *stream, uint32_t gpu_ind
     // a capture must be preceded by one plain launch, like the keyswitch's first use of a key)
     HX_PANIC_IF_FALSE(!stream_is_capturing(S(stream)),
                       "split-key exact engine: the first launch on a scratch allocates and cannot be captured; run it once before the capture");
-    HX_CHECK(hipMalloc((void **)&b->split_acc, (size_t)b->max_samples * (glwe_dimension + 1) * polynomial_size * sizeof(uint64_t)));
+    b->split_acc = (uint64_t *)scratch_alloc((size_t)b->max_samples * (glwe_dimension + 1) * polynomial_size * sizeof(uint64_t));
     // word 0: the round-off flag; words 64 .. 319: the per-XCD progress counters of the paced loop (PbsArgs::pace)
-    HX_CHECK(hipMalloc((void **)&b->split_flag, (64 + 8 * 32) * sizeof(uint32_t)));
+    b->split_flag = (uint32_t *)scratch_alloc((64 + 8 * 32) * sizeof(uint32_t));
     HX_CHECK(hipMemsetAsync(b->split_flag, 0, (64 + 8 * 32) * sizeof(uint32_t), S(stream)));
   }
   PbsArgs a = make_args(lwe_array_out, lwe_output_indexes, lut_vector, lut_vector_indexes, lwe_array_in,
@@ -684,13 +693,13 @@ void cleanup_cuda_programmable_bootstrap_64(void *stream, uint32_t gpu_index, in
   auto *b = reinterpret_cast<PbsBuffer *>(*pbs_buffer);
   HX_PANIC_IF_FALSE(b != nullptr && b->magic == kPbsMagic, "cleanup of a foreign PBS buffer");
   HX_CHECK(hipStreamSynchronize(S(stream)));  // cleanup_* synchronises (pbs_utilities.h:261-271)
-  if (b->acc_scratch) HX_CHECK(hipFree(b->acc_scratch));
-  if (b->split_acc) HX_CHECK(hipFree(b->split_acc));
-  if (b->split_flag) HX_CHECK(hipFree(b->split_flag));
-  for (void *r : b->emit_retired) HX_CHECK(hipFree(r));
-  if (b->emit_a) HX_CHECK(hipFree(b->emit_a));
-  if (b->ks_out) HX_CHECK(hipFree(b->ks_out));
-  if (b->trivial) HX_CHECK(hipFree(b->trivial));
+  if (b->acc_scratch) scratch_free(b->acc_scratch);
+  if (b->split_acc) scratch_free(b->split_acc);
+  if (b->split_flag) scratch_free(b->split_flag);
+  for (void *r : b->emit_retired) scratch_free(r);
+  if (b->emit_a) scratch_free(b->emit_a);
+  if (b->ks_out) scratch_free(b->ks_out);
+  if (b->trivial) scratch_free(b->trivial);
   b->magic = 0;
   delete b;
   *pbs_buffer = nullptr;
@@ -762,9 +771,9 @@ uint64_t scratch_cuda_multi_bit_programmable_bootstrap_64_async(void *stream, ui
   const uint64_t lat_bytes = b->lat_samples ? slots * kb_per_sample : 0;
   if (allocate_gpu_memory) {
     b->fft = get_fft_tables(gpu_index, S(stream), polynomial_size, true);
-    HX_CHECK(hipMalloc((void **)&b->acc, (size_t)b->chunk * acc_per_sample));
-    HX_CHECK(hipMalloc((void **)&b->pace, 8 * 32 * sizeof(uint32_t)));
-    if (lat_bytes) HX_CHECK(hipMalloc((void **)&b->kb_lat, lat_bytes));
+    b->acc = (uint64_t *)scratch_alloc((size_t)b->chunk * acc_per_sample);
+    b->pace = (uint32_t *)scratch_alloc(8 * 32 * sizeof(uint32_t));
+    if (lat_bytes) b->kb_lat = (cplx *)scratch_alloc(lat_bytes);
   }
   b->lat_bytes = lat_bytes;
   *pbs_buffer = reinterpret_cast<int8_t *>(b);
@@ -828,9 +837,9 @@ void cleanup_cuda_multi_bit_programmable_bootstrap_64(void *stream, uint32_t gpu
   auto *b = reinterpret_cast<MultiBitBuffer *>(*pbs_buffer);
   HX_PANIC_IF_FALSE(b != nullptr && b->magic == kMbMagic, "cleanup of a foreign multi-bit PBS buffer");
   HX_CHECK(hipStreamSynchronize(S(stream)));
-  if (b->acc) HX_CHECK(hipFree(b->acc));
-  if (b->kb_lat) HX_CHECK(hipFree(b->kb_lat));
-  if (b->pace) HX_CHECK(hipFree(b->pace));
+  if (b->acc) scratch_free(b->acc);
+  if (b->kb_lat) scratch_free(b->kb_lat);
+  if (b->pace) scratch_free(b->pace);
   b->magic = 0;
   delete b;
   *pbs_buffer = nullptr;
@@ -989,6 +998,15 @@ void cuda_modulus_switch_multi_bit_64_async(void *stream, uint32_t gpu_index, vo
 
 // =========================================================================== extensions
 void hip_backend_set_fft_kernel(uint32_t which) { g_fft_kernel_choice.store(which); }
+uint64_t hip_backend_trim_allocator(uint32_t gpu_index) {
+  set_device(gpu_index);
+  return arena_trim((int)gpu_index);
+}
+void hip_backend_allocator_stats(uint32_t gpu_index, uint64_t *out7) {
+  const ArenaStats s = arena_stats((int)gpu_index);
+  out7[0] = s.allocations; out7[1] = s.reuses; out7[2] = s.runtime_allocations; out7[3] = s.frees;
+  out7[4] = s.cross_stream_waits; out7[5] = s.live_bytes; out7[6] = s.cached_bytes;
+}
 void hip_backend_set_keyswitch_kernel(uint32_t which) {
   g_keyswitch_use_mfma.store(which != 1);
   g_keyswitch_split_digits.store(which != 2);

@@ -1,0 +1,25 @@
+// arena.h — stream-ordered device allocator behind cuda_malloc_async / cuda_drop (arena.hip)
+#pragma once
+#include "hx.h"
+#include <cstddef>
+#include <cstdint>
+
+namespace tfhe_hip {
+
+struct ArenaStats {
+  uint64_t allocations, reuses, runtime_allocations, frees, cross_stream_waits, live_bytes, cached_bytes;
+};
+// a block of at least `bytes` for work queued on `stream` from now on (never null: panics when the device is full)
+void *arena_alloc(int device, size_t bytes, hipStream_t stream);
+// false: `p` is not an arena block (the caller frees it its own way); *user_bytes = the size it was asked for
+bool arena_free(int device, void *p, size_t *user_bytes);
+void arena_release_stream(int device, hipStream_t stream);
+size_t arena_trim(int device);  // idle blocks back to the runtime; bytes released
+ArenaStats arena_stats(int device);
+bool arena_enabled();  // TFHE_HIP_MALLOC_ASYNC unset or "arena"
+// scratch of the library's own scratch_* / cleanup_* pairs, on the current device: arena blocks of no particular stream when
+// the arena is on (idle when handed out, idle by contract when returned), hipMalloc / hipFree otherwise
+void *scratch_alloc(size_t bytes);
+void scratch_free(void *p);
+
+}  // namespace tfhe_hip

@@ -17,6 +17,7 @@
 //   * rounds are described by device index arrays (gather / scatter / LUT index per block), so no
 //     ciphertext is ever moved to be "aligned" for a round.
 #include "kernels.h"
+#include "arena.h"
 #include "../../include/tfhe_hip_backend.h"
 
 #include <algorithm>
@@ -125,7 +126,7 @@ static thread_local uint64_t t_bytes = 0;
 static void radix_alloc(void **p, size_t bytes) {
   t_bytes += bytes;
   *p = nullptr;
-  if (!t_dry) HX_CHECK(hipMalloc(p, bytes));
+  if (!t_dry) *p = scratch_alloc(bytes);
 }
 
 template <class T>
@@ -136,7 +137,7 @@ static T *dev_upload(hipStream_t st, const std::vector<T> &h) {
     t_bytes += h.size() * sizeof(T);
     return d;
   }
-  HX_CHECK(hipMalloc((void **)&d, h.size() * sizeof(T)));
+  d = (T *)scratch_alloc(h.size() * sizeof(T));
   HX_CHECK(hipMemcpyAsync(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, st));
   HX_CHECK(hipStreamSynchronize(st));  // h may be a temporary
   return d;
@@ -411,13 +412,13 @@ struct LutDriver {
           cleanup_cuda_programmable_bootstrap_64(st, g.gpu, &g.pbs_buf);
       }
       for (uint64_t *d : {g.d_ks, g.d_luts, g.d_trivial, g.d_in, g.d_out, g.d_lut_idx, g.d_many})
-        if (d) HX_CHECK(hipFree(d));
+        if (d) scratch_free(d);
       for (hipEvent_t e : {g.staged, g.done, g.copied})
         if (e) HX_CHECK(hipEventDestroy(e));
       if (g.h_stage) HX_CHECK(hipHostFree(g.h_stage));
       HX_CHECK(hipSetDevice((int)gpus[0].gpu));
       for (uint64_t *d : {g.d0_in, g.d0_out})
-        if (d) HX_CHECK(hipFree(d));
+        if (d) scratch_free(d);
     }
     gpus.clear();
     magic = 0;
@@ -551,7 +552,8 @@ struct PropagateMem {
   }
 
   void build_indexes(hipStream_t st, uint32_t cts) {
-    for (auto *d : dev_arrays) HX_CHECK(hipFree(d));
+    if (!dev_arrays.empty()) HX_CHECK(hipStreamSynchronize(st));  // launches of the previous shape may still read them
+    for (auto *d : dev_arrays) scratch_free(d);
     dev_arrays.clear();
     up.clear();
     down.clear();
@@ -824,10 +826,10 @@ struct PropagateMem {
 
   void release(const CudaStreamsFFI &ss) {
     drv.release(ss);
-    for (auto *d : dev_arrays) HX_CHECK(hipFree(d));
+    for (auto *d : dev_arrays) scratch_free(d);
     dev_arrays.clear();
     for (uint64_t *d : {d_pool, d_p, d_pack})
-      if (d) HX_CHECK(hipFree(d));
+      if (d) scratch_free(d);
     magic = 0;
   }
 };
@@ -1012,11 +1014,12 @@ struct MulMem {
   } pass;
 
   void free_pass() {
-    for (auto *d : pass.owned) HX_CHECK(hipFree(d));
+    for (auto *d : pass.owned) scratch_free(d);
     pass = PassIdx();
   }
 
   void build_pass(hipStream_t st, uint32_t nb) {
+    if (!pass.owned.empty()) HX_CHECK(hipStreamSynchronize(st));  // launches of the previous shape may still read them
     free_pass();
     pass.nb = nb;
     const uint32_t L = blocks;
@@ -1111,9 +1114,9 @@ struct MulMem {
     free_pass();
     drv.release(ss);
     prop.release(ss);
-    if (d_pool) HX_CHECK(hipFree(d_pool));
-    if (d_pack) HX_CHECK(hipFree(d_pack));
-    if (d_sum) HX_CHECK(hipFree(d_sum));
+    if (d_pool) scratch_free(d_pool);
+    if (d_pack) scratch_free(d_pack);
+    if (d_sum) scratch_free(d_sum);
     magic = 0;
   }
 };
@@ -1159,7 +1162,7 @@ struct BoolMulMem {
     HX_CHECK(hipStreamSynchronize(S0(ss)));
     drv.release(ss);
     for (uint64_t *d : {d_pack, d_cond_idx, d_lut_idx})
-      if (d) HX_CHECK(hipFree(d));
+      if (d) scratch_free(d);
     magic = 0;
   }
 };
@@ -1254,7 +1257,7 @@ void cleanup_cuda_apply_univariate_lut_64(CudaStreamsFFI streams, int8_t **mem_p
   auto *m = reinterpret_cast<ApplyLutMem *>(*mem_ptr_void);
   HX_PANIC_IF_FALSE(m && m->magic == ApplyLutMem::kMagic, "cleanup apply_univariate_lut: foreign scratch pointer");
   m->drv.release(streams);
-  if (m->d_lut_idx) HX_CHECK(hipFree(m->d_lut_idx));
+  if (m->d_lut_idx) scratch_free(m->d_lut_idx);
   m->magic = 0;
   delete m;
   *mem_ptr_void = nullptr;

@@ -117,6 +117,8 @@ SIGNATURES = {
         (None, [_v, _u32, _v, _v, _v, _v, _v, _v, _v, _v, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _u32]),
     "hip_backend_set_fft_kernel": (None, [_u32]),
     "hip_backend_last_pbs_kernel": (_u32, []),
+    "hip_backend_trim_allocator": (_u64, [_u32]),
+    "hip_backend_allocator_stats": (None, [_u32, C.POINTER(C.c_uint64)]),
     "hip_backend_version": (C.c_char_p, []),
     "hip_event_create": (_v, []),
     "hip_event_record": (None, [_v, _v]),

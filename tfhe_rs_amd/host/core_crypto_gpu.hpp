@@ -216,15 +216,12 @@ class CudaVec {
   }
   CudaVec(const CudaVec &) = delete;
   CudaVec &operator=(const CudaVec &) = delete;
-  ~CudaVec() { release(); }  // vec.rs:495-515 (Drop: synchronises the device, then cuda_drop)
+  ~CudaVec() { release(); }  // vec.rs:487-495 (Drop: cuda_drop per GPU — stream-ordered behind the owner's stream for a new_async vector)
 
  private:
   static uint64_t bytes_of(size_t n) { return n ? (uint64_t)n * sizeof(T) : 8; }
   void release() {
-    for (size_t i = 0; i < ptr.size(); ++i) {
-      cuda_synchronize_device(gpu_indexes[i].get());
-      cuda_drop(ptr[i], gpu_indexes[i].get());
-    }
+    for (size_t i = 0; i < ptr.size(); ++i) cuda_drop(ptr[i], gpu_indexes[i].get());
     ptr.clear();
   }
 };
