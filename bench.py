@@ -346,8 +346,13 @@ def main():
                     help="LWEs of the config-3 / config-4 launches compared word for word with the CPU oracle "
                          "(0 = the whole batch: about 2.5 min of CPU work on 16 threads)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="PBS count of the CPU baseline sample (0 = auto)")
+    ap.add_argument("--scale-quick", action="store_true",
+                    help="headline only (= --no-extra --no-cpu-baseline --no-pmc): the form for a 1/2/4/8-GPU scaling sweep — no CPU-oracle "
+                         "legs (they are 95 %% of the default run's wall time), per-GPU ms_per_step and config 5's active-GPU count in the line")
     ap.add_argument("--fheuint64-worker", default=None, help=argparse.SUPPRESS)  # child process of the N > 1 config-5 datapoints
     args = ap.parse_args()
+    if args.scale_quick:
+        args.no_extra = args.no_cpu_baseline = args.no_pmc = True
     if args.fheuint64_worker:
         import tfhe_rs_amd  # noqa: F401
         from tfhe_rs_amd import ffi
@@ -404,10 +409,14 @@ def main():
             import torch
             torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
+        rank_ms = None
         if dist is not None:
             import torch
             t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
             dist.barrier()
+            every = [torch.zeros_like(t) for _ in range(world)]
+            dist.all_gather(every, t)     # per-rank times for the line (16 bytes per rank; outside the timed region)
+            rank_ms = [float(x.item()) / args.steps * 1e3 for x in every]
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         kernel_id = lib.hip_backend_last_pbs_kernel()
@@ -500,6 +509,20 @@ def main():
     if per_gpu is not None:
         result["per_gpu"] = per_gpu
         result["fake_multi_gpu"] = fake
+        result["per_gpu_ms_per_step"] = [g_["seconds"] / args.steps * 1e3 for g_ in per_gpu]
+    elif launched and rank_ms is not None:
+        result["per_gpu_ms_per_step"] = rank_ms
+    if args.scale_quick:
+        # config 5 on this many GPUs: how many of them a KS -> PBS round of the radix layer would use under the reference's
+        # thresholds (helper_multi_gpu.cu:39-101: a GPU is added per `threshold` blocks; classic = compute units + 1,
+        # multi-bit = 12) — 1024 FheUint64 of 32 blocks enter the first round of an addition as 32768 blocks
+        cus = lib.cuda_get_number_of_sms()
+        blocks = 1024 * 32
+        result["config5_active_gpus"] = {"gpus": n_gpus, "blocks_in_first_round": blocks,
+                                         "classic": min(n_gpus, -(-blocks // (cus + 1))), "multi_bit": min(n_gpus, -(-blocks // 12)),
+                                         "thresholds": {"classic": cus + 1, "multi_bit": 12},
+                                         "one_fheuint64_classic": min(n_gpus, -(-32 // (cus + 1))),
+                                         "one_fheuint64_multi_bit": min(n_gpus, -(-32 // 12))}
     if latency_ms is not None:
         result["extra"] = {"single_pbs_latency_ms": latency_ms,
                            "single_pbs_kernel": {7: "block_latency", 2: "wave_throughput"}.get(latency_kernel,
