@@ -307,7 +307,9 @@ void hip_programmable_bootstrap_ntt64_split_async(
 
 /* Round-off check of the split-key engine: 1 if any launch on this scratch since the last call saw an f64 limb product
  * further than 1/4 from an integer (outputs not to be trusted; never observed with the supported bounds, which are
- * statistical: worst-case products of 2^49 leave 4 bits of headroom), else 0.  Synchronises the stream, clears the flag. */
+ * statistical: worst-case products of 2^49 leave 4 bits of headroom), else 0.  Synchronises the stream, clears the flag.
+ * A flag that is still set when the scratch is cleaned up makes cleanup_cuda_programmable_bootstrap_64 panic: a host that
+ * never polls cannot miss it. */
 uint32_t hip_programmable_bootstrap_ntt64_split_roundoff_status(
     void *stream, uint32_t gpu_index, int8_t *buffer);
 

@@ -693,6 +693,14 @@ void cleanup_cuda_programmable_bootstrap_64(void *stream, uint32_t gpu_index, in
   auto *b = reinterpret_cast<PbsBuffer *>(*pbs_buffer);
   HX_PANIC_IF_FALSE(b != nullptr && b->magic == kPbsMagic, "cleanup of a foreign PBS buffer");
   HX_CHECK(hipStreamSynchronize(S(stream)));  // cleanup_* synchronises (pbs_utilities.h:261-271)
+  if (b->split_flag) {
+    // the split-key exact engine's round-off flag is checked here even if nobody polled it: a caller that never asks
+    // hip_programmable_bootstrap_ntt64_split_roundoff_status (a C or Rust host) must not keep untrustworthy "exact" outputs
+    uint32_t v = 0;
+    HX_CHECK(hipMemcpy(&v, b->split_flag, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    HX_PANIC_IF_FALSE(v == 0, "split-key exact engine: an f64 limb product was further than 1/4 from an integer in a launch on "
+                              "this scratch since the last status poll — its outputs are not the exact ones");
+  }
   if (b->acc_scratch) scratch_free(b->acc_scratch);
   if (b->split_acc) scratch_free(b->split_acc);
   if (b->split_flag) scratch_free(b->split_flag);

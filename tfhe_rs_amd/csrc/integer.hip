@@ -1528,6 +1528,16 @@ void cuda_integer_mult_inplace_64_async(CudaStreamsFFI streams, CudaRadixCiphert
     const CudaRadixCiphertextFFI *value = is_bool_right ? (const CudaRadixCiphertextFFI *)radix_lwe_inout : radix_lwe_right;
     HX_PANIC_IF_FALSE(cond->num_radix_blocks >= cts && value->num_radix_blocks >= cts * bm->blocks,
                       "integer_mult: input or output does not have enough radix blocks");
+    // the packing msg * value + condition must stay below the padding bit: clean value blocks, a boolean that IS one
+    if (value->degrees)
+      for (uint32_t i = 0; i < cts * bm->blocks; ++i)
+        HX_PANIC_IF_FALSE(value->degrees[i] <= bm->drv.p.msg - 1,
+                          "integer_mult: block %u of the non-boolean operand has degree %llu, at most %u is accepted (propagate it first)",
+                          i, (unsigned long long)value->degrees[i], bm->drv.p.msg - 1);
+    if (cond->degrees)
+      for (uint32_t c = 0; c < cts; ++c)
+        HX_PANIC_IF_FALSE(cond->degrees[c] <= 1, "integer_mult: the boolean operand's block %u has degree %llu", c,
+                          (unsigned long long)cond->degrees[c]);
     // (a boolean that sits in the destination is read by the packing launch before the bootstrap overwrites it)
     bm->run(streams, (uint64_t *)radix_lwe_inout->ptr, (const uint64_t *)value->ptr, (const uint64_t *)cond->ptr, cts,
             ksks, bsks);

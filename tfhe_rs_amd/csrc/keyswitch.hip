@@ -625,8 +625,8 @@ __global__ void __launch_bounds__(256, 2) ks_gemm_kernel(OutT *lwe_out, const ui
     HX_UNROLL
     for (int u = 0; u < SPB; ++u) {
       // this step's operands out of LDS first: the compiler drains every outstanding global -> LDS load before an LDS
-      // read, so the requests for the next macro step go out behind the FIRST step's reads and land under the matrix
-      // instructions
+      // read, so the requests for the next macro step go out behind the LAST step's reads (u == SPB - 1) and land under the
+      // matrix instructions of that step and the barrier
       hx_i8x16 bv[PLANES];
       HX_UNROLL
       for (int p = 0; p < PLANES; ++p) bv[p] = *(const hx_i8x16 *)&bs[cur][u][h][p * (KSM_CT * 16) + row * 16];
