@@ -105,6 +105,25 @@ def pmc_record(target):
                                        f"host {pv.get('host')}")
 
 
+def pmc_counters(target):
+    """All counters of `target` from the PMC passes of this run, else from the committed build-stamped record; {} if neither
+    is of this build."""
+    from tools.build_id import source_build_id
+    mine = source_build_id()
+    for rec in (_PMC_NOW, None):
+        if rec is None:
+            try:
+                rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
+            except Exception:  # noqa: BLE001
+                return {}
+        if rec.get("build_id") == mine and target in rec.get("kernels", {}):
+            return rec["kernels"][target]
+    return {}
+
+
+VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 4   # wave-instructions per second: 256 CUs x 4 SIMDs, one 4-cycle VALU instruction at a time
+
+
 class HeadlineShard:
     """One GPU's part of the headline workload: a replica of the bootstrap key, this GPU's shard of the global batch
     resident in HBM, its scratch, and the launches through the C ABI.  The reference's throughput bench has the same
@@ -472,7 +491,7 @@ def main():
     tflops = ALGO_FLOP_PER_PBS * B / avg_kernel_s / 1e12
     if single and not args.no_pmc and args.kernel == 0:
         # after the timed region: one launch per kernel under `rocprofv3 --pmc`, in child processes
-        why = measure_traffic_now(["fft"] if args.no_extra else ["fft", "ntt", "mb_g3", "mb_g4"])
+        why = measure_traffic_now(["fft"] if args.no_extra else ["fft", "ntt", "ntt_int", "mb_g3", "mb_g4"], budget_s=420)
         if why:
             _PMC_NOW["skipped"] = why
     traffic, traffic_src = pmc_record("fft")
@@ -494,6 +513,19 @@ def main():
                 "note": "achieved = algorithmic f64 flop (SURVEY §8d, 2.48e8 per PBS) / HIP-event launch time; "
                         "peak = FP64 vector 78.6 TFLOP/s; traffic = HBM bytes per launch from PMC passes of this "
                         "exact kernel build (null when the committed record is of another build)"}
+    ctr = pmc_counters("fft")
+    if ctr.get("GRBM_GUI_ACTIVE") and B == BATCH:
+        # the launch takes the same number of shader cycles however busy the chip is (profiles/r05_penalty_attribution.txt):
+        # cycles of one launch (GRBM_GUI_ACTIVE over the 8 XCCs, a PMC pass of this build) / the timed launches' duration =
+        # the shader clock the chip sustained under this kernel (nominal 2.4 GHz; power management lowers it at full load)
+        cycles = ctr["GRBM_GUI_ACTIVE"] / 8
+        clk = cycles / avg_kernel_s / 1e9
+        roofline.update({"shader_cycles_per_launch": cycles, "sustained_clock_ghz": clk,
+                         "peak_at_sustained_clock": FP64_PEAK_TFLOPS * clk / 2.4,
+                         "frac_at_sustained_clock": tflops / (FP64_PEAK_TFLOPS * clk / 2.4),
+                         "valu_busy": (4 * ctr["SQ_ACTIVE_INST_VALU"] / (cycles * 1024)) if ctr.get("SQ_ACTIVE_INST_VALU") else None,
+                         "clock_note": "`frac` is against the 2.4 GHz datasheet peak; the chip holds sustained_clock_ghz under this "
+                                       "kernel (per-XCC power management: 2.39 GHz with <= 128 CUs busy, 2.0-2.2 GHz with all 256)"})
     result = {
         "metric": "PBS/sec (shortint PARAM_MESSAGE_2_CARRY_2, classic PBS, f64 FFT external product)",
         "value": value, "unit": "PBS/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
@@ -626,6 +658,35 @@ def main():
                                      "multiply-adds at 8 flop, 4 flop per coefficient of rounding and check)",
                    "integer_goldilocks_kernel": {k2: ntt["ntt64"][k2] for k2 in ("ms_per_launch", "pbs_per_s",
                                                                                "gpu_matches_cpu_bits", "pbs_kernel_id")}})
+        # how far each engine is from its own ceiling (VERDICT r04 #3a): VALU instructions are what both are made of
+        roof = {"valu_issue_peak_wave_instructions_per_s": VALU_ISSUE_PEAK,
+                "note": "peak = 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave64 VALU instruction; achieved = SQ_INSTS_VALU of one "
+                        "launch (PMC pass of this build) / launch time; floor = the least instructions the engine's arithmetic needs"}
+        c_split, c_int = pmc_counters("ntt"), pmc_counters("ntt_int")
+        if c_split.get("SQ_INSTS_VALU"):
+            per_pbs = c_split["SQ_INSTS_VALU"] / B
+            flop_split = 918 * (2 * 25600 + 4 * (2 * 25600 + 4 * 1024 * 8 + 4 * 2048))
+            roof["split_f64"] = {"valu_wave_instructions_per_pbs": per_pbs, "achieved": per_pbs * dp["pbs_per_s"],
+                                 "frac_valu_issue": per_pbs * dp["pbs_per_s"] / VALU_ISSUE_PEAK,
+                                 "f64_wave_instructions_floor_per_pbs": flop_split / 2 / 64,
+                                 "frac_of_f64_floor": dp["pbs_per_s"] * (flop_split / 2 / 64) / VALU_ISSUE_PEAK,
+                                 "floor_note": "f64 flop model / 2 flop per FMA / 64 lanes: (k+1) forward + 4 x (k+1) inverse transforms, "
+                                               "4 x (k+1)^2 n complex multiply-adds, rounding + round-off check; the Horner recombination "
+                                               "modulo p, digit extraction and lane exchanges come on top"}
+        if c_int.get("SQ_INSTS_VALU"):
+            per_pbs = c_int["SQ_INSTS_VALU"] / B
+            mulmods = 5.2e7   # ~57 k 64-bit modular multiplications per external product x 918
+            rate_i = ntt["ntt64"]["pbs_per_s"]
+            roof["integer_goldilocks"] = {
+                "mulmods_per_pbs": mulmods, "valu_wave_instructions_per_pbs": per_pbs,
+                "valu_lane_instructions_per_mulmod_measured": per_pbs * 64 / mulmods,
+                "valu_instructions_per_butterfly_floor": 40,
+                "floor_note": "one Goldilocks butterfly as this compiler emits it for gfx950: 27 instructions for the modular product "
+                              "(5 v_mad_u64_u32 + the reduction by 2^64 = 2^32 - 1) + 13 for the modular add and subtract",
+                "achieved": per_pbs * rate_i, "frac_valu_issue": per_pbs * rate_i / VALU_ISSUE_PEAK,
+                "ceiling_pbs_per_s_at_floor": VALU_ISSUE_PEAK / (mulmods * 40 / 64),
+                "frac_of_ceiling": rate_i / (VALU_ISSUE_PEAK / (mulmods * 40 / 64))}
+        dp["roofline"] = roof
         result.setdefault("extra", {})["ntt"] = dp
         del d_out3
 

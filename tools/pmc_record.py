@@ -41,7 +41,9 @@ TARGETS = {
 }
 
 
-HBM_PASSES = ["FETCH_SIZE", "WRITE_SIZE"]   # --hbm-only: what bench.py's `traffic` needs, two passes per kernel
+# --hbm-only: what bench.py needs per kernel — `traffic` (two passes) and the launch's shader cycles / VALU instruction count
+# (one pass: sustained clock = cycles / launch time, VALU-issue roofline of the NTT engines)
+HBM_PASSES = ["FETCH_SIZE", "WRITE_SIZE", "GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVES"]
 
 
 def provenance():
