@@ -17,6 +17,7 @@
 #define HX_SCHED_FENCE() do { } while (0)
 #define HX_OPAQUE(v) do { } while (0)
 #define HX_LAUNDER(v) do { } while (0)
+#define HX_OPAQUE_S(v) do { } while (0)
 #define HX_UNIFORM(v) (v)
 // 16 bytes per lane from global memory straight into LDS at (wave-uniform base) + lane * 16
 #define HX_GLOBAL_TO_LDS16(gsrc, lds_wave_base, lane) __builtin_memcpy((char *)(lds_wave_base) + (lane) * 16, (gsrc), 16)
@@ -50,6 +51,8 @@
 #define HX_OPAQUE(v) asm volatile("" : "+v"(v))
 // same, but free to move: only hides the value's origin from the optimiser's pattern matching
 #define HX_LAUNDER(v) asm("" : "+v"(v))
+// the same fence for a wave-uniform value that lives in a scalar register
+#define HX_OPAQUE_S(v) asm volatile("" : "+s"(v))
 // wave-uniform value into an SGPR
 #define HX_UNIFORM(v) __builtin_amdgcn_readfirstlane(v)
 // 16 bytes per lane from global memory straight into LDS at (wave-uniform base) + lane * 16 (global_load_lds_dwordx4:

@@ -133,6 +133,13 @@
 // many LDS instructions as the whole rest of a group
 #define WAVE_MB_W16_SCALAR 1
 #endif
+#ifndef WAVE_MB_ROOT_JIT
+// multi-bit, scalar 16th roots: 1 = the degree is fenced (HX_OPAQUE_S) right where its root is fetched, so the address of every
+// root of a level (2 (2^g - 1) x 8 or 16 pointers) is computed just in time instead of all at once at the top of the level —
+// hoisted, they do not fit the scalar file and travel through vector-register lanes (g = 3 quad kernel: 337 spilled SGPRs,
+// ~700 v_writelane / v_readlane per group)
+#define WAVE_MB_ROOT_JIT 1
+#endif
 #ifndef WAVE_SPLIT_LWES
 #define WAVE_SPLIT_LWES 4   // exact engine, split-key form: LWEs per workgroup (the accumulators of a CU's LWEs live in L2)
 #endif
@@ -1228,8 +1235,13 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
           auto request = [&](int set, int t) {
             const uint32_t sidx = (uint32_t)(t / RW);
             const int j = t % RW;
-            x0[set] = ldc(gk, lane_off, sidx * ggsw_bytes + row0_off + (uint32_t)j * 1024u);
-            x1[set] = ldc(gk, lane_off, sidx * ggsw_bytes + row1_off + (uint32_t)j * 1024u);
+            uint32_t o0 = row0_off, o1 = row1_off;
+#if WAVE_MB_ROOT_JIT
+            HX_OPAQUE_S(o0);  // the scalar offset of a request is one addition: made here, not 2 x 4 x 2^g of them ahead of the
+            HX_OPAQUE_S(o1);  // level and carried through vector-register lanes
+#endif
+            x0[set] = ldc(gk, lane_off, sidx * ggsw_bytes + o0 + (uint32_t)j * 1024u);
+            x1[set] = ldc(gk, lane_off, sidx * ggsw_bytes + o1 + (uint32_t)j * 1024u);
           };
           uint32_t dg[2][4];
           cplx bs[2][4];
@@ -1265,7 +1277,11 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
                 const uint32_t br = br2[j] * 4u + brq;
                 HX_UNROLL
                 for (int L = 0; L < 4; ++L) {
-                  const cplx mf = cmul_first(bs[si & 1][L], w16_root((br * dg[si & 1][L]) & 15u));
+                  uint32_t dgl = dg[si & 1][L];
+#if WAVE_MB_ROOT_JIT && WAVE_MB_W16_SCALAR
+                  HX_OPAQUE_S(dgl);
+#endif
+                  const cplx mf = cmul_first(bs[si & 1][L], w16_root((br * dgl) & 15u));
                   kq[L][j][0] = cmul_add(x0[set], mf, kq[L][j][0]);
                   kq[L][j][1] = cmul_add(x1[set], mf, kq[L][j][1]);
                   HX_OPAQUE(kq[L][j][0].re);
@@ -1330,8 +1346,13 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
           auto request = [&](int set, int t) {
             const uint32_t sidx = (uint32_t)(t % (int)per);
             const int j = t / (int)per;
-            x0[set] = ldc(gk, lane_off, sidx * ggsw_bytes + row0_off + (uint32_t)j * 1024u);
-            x1[set] = ldc(gk, lane_off, sidx * ggsw_bytes + row1_off + (uint32_t)j * 1024u);
+            uint32_t o0 = row0_off, o1 = row1_off;
+#if WAVE_MB_ROOT_JIT
+            HX_OPAQUE_S(o0);
+            HX_OPAQUE_S(o1);
+#endif
+            x0[set] = ldc(gk, lane_off, sidx * ggsw_bytes + o0 + (uint32_t)j * 1024u);
+            x1[set] = ldc(gk, lane_off, sidx * ggsw_bytes + o1 + (uint32_t)j * 1024u);
           };
           HX_UNROLL
           for (int t = 0; t < SETS && t < STEPS; ++t) request(t, t);
@@ -1360,8 +1381,13 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
               } else {
                 constexpr uint32_t br4[8] = {0, 8, 4, 12, 2, 10, 6, 14};  // bitrev4(8 h + j) = bitrev4(j) + h
                 const uint32_t br = br4[j] + (uint32_t)quad_lwe;
-                const cplx mfa = cmul_first(base[si], w16_root((br * deg[si]) & 15u));
-                const cplx mfb = cmul_first(base_b[si], w16_root((br * deg_b[si]) & 15u));
+                uint32_t dga = deg[si], dgb = deg_b[si];
+#if WAVE_MB_ROOT_JIT && WAVE_MB_W16_SCALAR
+                HX_OPAQUE_S(dga);
+                HX_OPAQUE_S(dgb);
+#endif
+                const cplx mfa = cmul_first(base[si], w16_root((br * dga) & 15u));
+                const cplx mfb = cmul_first(base_b[si], w16_root((br * dgb) & 15u));
                 ka0 = cmul_add(x0[set], mfa, ka0);
                 ka1 = cmul_add(x1[set], mfa, ka1);
                 kb0 = cmul_add(x0[set], mfb, kb0);
