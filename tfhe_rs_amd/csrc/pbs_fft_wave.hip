@@ -143,9 +143,6 @@
 #ifndef WAVE_SPLIT_LWES
 #define WAVE_SPLIT_LWES 4   // exact engine, split-key form: LWEs per workgroup (the accumulators of a CU's LWEs live in L2)
 #endif
-#ifndef WAVE_SPLIT_NT
-#define WAVE_SPLIT_NT 0     // 1: accumulator loads / stores nontemporal
-#endif
 #ifndef WAVE_STAGGER
 // classic one-level loop: waves 4..7 (the second wave of every SIMD) start the loop this many times 4096 cycles after
 // waves 0..3, so that the two waves of a SIMD are in different phases of the CMUX (0: off).  Same box, ms per 4096,
@@ -900,17 +897,46 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
 
   // key rows of GGSW_i: [i][idx][row][c = w][storage s = r*64 + lane], consumed in 4 chunks of 4 points
   const uint32_t key_levels = LIMBS > 0 ? (uint32_t)LIMBS : level;  // split-key form: [i][limb][row][col][slot]
+#ifndef WAVE_KEY_BUFFER
+// The key rows requested through ONE buffer descriptor over the whole key — lane offsets in one vector register, the row's
+// byte offset as a scalar — instead of through two per-lane 64-bit pointers (plus one more pointer pair per 4 KB window of
+// immediate offsets the sweep of 16 KB crosses).  0: never, 1: always, 2: in the split-key exact engine only (same box, ms per
+// 4096: split-key engine 137.9 -> 135.0; classic loop 33.4 -> 33.5: its register file is full either way and the descriptor
+// costs scalar registers — profiles/r05_ab_split_buffers.txt)
+#define WAVE_KEY_BUFFER 2
+#endif
+  constexpr bool KEYBUF = WAVE_KEY_BUFFER == 1 || (WAVE_KEY_BUFFER == 2 && LIMBS > 0);
+  const HxBuffer bskb = hx_make_buffer(a.bsk, KEYBUF ? (uint32_t)((size_t)a.n * key_levels * 4 * n * sizeof(cplx)) : 0u);
   auto key_rows = [&](uint32_t i, uint32_t idx, const cplx *&b0, const cplx *&b1) {
-    int lane = ctx.lane;
-    HX_OPAQUE(lane);
-    b0 = bsk + ((((size_t)i * key_levels + idx) * 2 + 0) * 2 + w) * n + lane;
-    b1 = bsk + ((((size_t)i * key_levels + idx) * 2 + 1) * 2 + w) * n + lane;
+    if constexpr (KEYBUF) {
+      // the "pointers" carry the rows' byte offsets (wave-uniform): < 2^32 for every supported key
+      b0 = (const cplx *)(uintptr_t)(((((size_t)i * key_levels + idx) * 2 + 0) * 2 + w) * n * sizeof(cplx));
+      b1 = (const cplx *)(uintptr_t)(((((size_t)i * key_levels + idx) * 2 + 1) * 2 + w) * n * sizeof(cplx));
+    } else {
+      int lane = ctx.lane;
+      HX_OPAQUE(lane);
+      b0 = bsk + ((((size_t)i * key_levels + idx) * 2 + 0) * 2 + w) * n + lane;
+      b1 = bsk + ((((size_t)i * key_levels + idx) * 2 + 1) * 2 + w) * n + lane;
+    }
   };
   auto key_request = [&](cplx (&k0)[4], cplx (&k1)[4], const cplx *b0, const cplx *b1, int ch) {
-    HX_UNROLL
-    for (int j = 0; j < 4; ++j) {
-      k0[j] = load_global_cplx<false>(&b0[(ch * 4 + j) * 64]);
-      k1[j] = load_global_cplx<false>(&b1[(ch * 4 + j) * 64]);
+    if constexpr (KEYBUF) {
+      int lane = ctx.lane;
+      HX_OPAQUE(lane);
+      const uint32_t o0 = (uint32_t)(uintptr_t)b0, o1 = (uint32_t)(uintptr_t)b1;
+      HX_UNROLL
+      for (int j = 0; j < 4; ++j) {
+        const hx_f64x2 v0 = hx_buffer_load_f64x2(bskb, (uint32_t)lane * 16u, o0 + (uint32_t)(ch * 4 + j) * 1024u);
+        const hx_f64x2 v1 = hx_buffer_load_f64x2(bskb, (uint32_t)lane * 16u, o1 + (uint32_t)(ch * 4 + j) * 1024u);
+        k0[j] = cplx{v0.x, v0.y};
+        k1[j] = cplx{v1.x, v1.y};
+      }
+    } else {
+      HX_UNROLL
+      for (int j = 0; j < 4; ++j) {
+        k0[j] = load_global_cplx<false>(&b0[(ch * 4 + j) * 64]);
+        k1[j] = load_global_cplx<false>(&b1[(ch * 4 + j) * 64]);
+      }
     }
   };
 
@@ -934,8 +960,13 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
     const cplx *row0 = (w == 0 ? buf : obuf) + base_m3(ctx);
     const cplx *row1 = (w == 0 ? obuf : buf) + base_m3(ctx);
     // the key pointers must not be known before the wait, or the later requests are hoisted above it
-    HX_OPAQUE(b0);
-    HX_OPAQUE(b1);
+    if constexpr (KEYBUF) {
+      HX_OPAQUE_S(b0);
+      HX_OPAQUE_S(b1);
+    } else {
+      HX_OPAQUE(b0);
+      HX_OPAQUE(b1);
+    }
     // Both rows are read from LDS — row 0 from the buffer of the wave that holds polynomial 0, row 1 from
     // the other one — so the roles are a scalar pointer choice: no per-point test of w, no selects, and
     // the registers of my own transform are free during the products.
@@ -1551,20 +1582,28 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
     }
   } else if constexpr (LIMBS > 0) {
     struct alignas(16) U64x2 { uint64_t x, y; };
-    U64x2 *gacc = (U64x2 *)(a.acc_scratch + ((size_t)sample * 2 + (size_t)w) * N) + lane;  // slot r*64 + lane: coefficients c, 1024 + c
-#if WAVE_SPLIT_NT && !defined(TFHE_HIPEMU)
-    typedef uint64_t v2u64 __attribute__((ext_vector_type(2)));
+    // my polynomial's 2 N words in the accumulator scratch as one buffer: slot r*64 + lane holds coefficients c and 1024 + c.
+    // Buffer addressing: ONE vector register of lane offsets serves the 16 requests of a sweep (the scalar offset r * 1024
+    // rides in the instruction); as 64-bit pointers the compiler kept one per 1 KB step beyond the immediate range and
+    // spilled them (32 spilled registers, 51 scratch accesses per CMUX in round 4)
+#ifndef WAVE_SPLIT_ACC_BUFFER
+#define WAVE_SPLIT_ACC_BUFFER 1
 #endif
+    const uint64_t *gacc_base = a.acc_scratch ? a.acc_scratch + ((size_t)sample * 2 + (size_t)w) * N : nullptr;
+    const HxBuffer gaccb = hx_make_buffer(gacc_base, (uint32_t)(N * sizeof(uint64_t)));
+    U64x2 *gacc = (U64x2 *)gacc_base + lane;
+    (void)gacc;
+    (void)gaccb;
     auto acc_load = [&]() {
 #if WAVE_SPLIT_PROBE == 2  // timing probe (wrong results): no accumulator traffic
       return;
 #endif
+      int ln = ctx0.lane;
+      HX_OPAQUE(ln);
       HX_UNROLL
       for (int r = 0; r < 16; ++r) {
-#if WAVE_SPLIT_NT && !defined(TFHE_HIPEMU)
-        const v2u64 v = __builtin_nontemporal_load((const v2u64 *)&gacc[r * 64]);
-        acc_re[r] = v.x;
-        acc_im[r] = v.y;
+#if WAVE_SPLIT_ACC_BUFFER
+        hx_buffer_load_u64x2(gaccb, (uint32_t)ln * 16u, (uint32_t)r * 1024u, acc_re[r], acc_im[r]);
 #else
         const U64x2 v = gacc[r * 64];
         acc_re[r] = v.x;
@@ -1576,13 +1615,12 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
 #if WAVE_SPLIT_PROBE == 2
       return;
 #endif
+      int ln = ctx0.lane;
+      HX_OPAQUE(ln);
       HX_UNROLL
       for (int r = 0; r < 16; ++r) {
-#if WAVE_SPLIT_NT && !defined(TFHE_HIPEMU)
-        v2u64 v;
-        v.x = acc_re[r];
-        v.y = acc_im[r];
-        __builtin_nontemporal_store(v, (v2u64 *)&gacc[r * 64]);
+#if WAVE_SPLIT_ACC_BUFFER
+        hx_buffer_store_u64x2(gaccb, (uint32_t)ln * 16u, (uint32_t)r * 1024u, acc_re[r], acc_im[r]);
 #else
         gacc[r * 64] = U64x2{acc_re[r], acc_im[r]};
 #endif
