@@ -271,7 +271,9 @@ struct LutDriver {
           HX_CHECK(hipEventCreateWithFlags(&g.done, hipEventDisableTiming));
           // the copies of a round are issued on this GPU's stream in both directions
           g.direct = peer_direct((int)g.gpu, (int)gpus[0].gpu) && peer_direct((int)gpus[0].gpu, (int)g.gpu);
-          if (!g.direct) HX_CHECK(hipHostMalloc((void **)&g.h_stage, (size_t)many_max * cap * w * sizeof(uint64_t), 0));
+          // host-staged copies: three pinned regions — shard in, its LUT indexes, results out — so that each leg of a copy
+          // runs on the stream of the device whose memory it touches and no region is rewritten before its reader is done
+          if (!g.direct) HX_CHECK(hipHostMalloc((void **)&g.h_stage, ((size_t)cap * w + cap + (size_t)many_max * cap * w) * sizeof(uint64_t), 0));
         }
       }
       HX_CHECK(hipStreamSynchronize(st));  // the LUT sources may be temporaries
@@ -306,16 +308,14 @@ struct LutDriver {
            bsks[0], many, stride);
   }
 
-  // one copy between this GPU and the first one, on this GPU's stream (stream order keeps the staging buffer safe)
-  static void peer_copy(const PerGpu &g, void *dst, int dst_dev, const void *src, int src_dev, size_t bytes,
-                        hipStream_t st) {
-    if (g.direct) {
-      HX_CHECK(hipMemcpyPeerAsync(dst, dst_dev, src, src_dev, bytes, st));
-    } else {
-      HX_CHECK(hipMemcpyAsync(g.h_stage, src, bytes, hipMemcpyDeviceToHost, st));
-      HX_CHECK(hipMemcpyAsync(dst, g.h_stage, bytes, hipMemcpyHostToDevice, st));
-    }
-  }
+  // Copies between this GPU and the first one.  direct: hipMemcpyPeerAsync on this GPU's stream.  Host-staged (no peer
+  // access): the device-to-host leg on the stream of the device that owns the source, the host-to-device leg on the stream
+  // of the device that owns the destination, ordered by the round's events (staged / done) — a stream never touches another
+  // device's memory.  Not reachable on an MI355X node (every pair of GPUs is an xGMI peer): exercised on the
+  // CPU tier's device model only.
+  uint64_t *h_in(const PerGpu &g) const { return g.h_stage; }
+  uint64_t *h_idx(const PerGpu &g) const { return g.h_stage + (size_t)cap * ((size_t)p.big_n + 1); }
+  uint64_t *h_out(const PerGpu &g) const { return h_idx(g) + cap; }
 
   // one round, split into launches of at most `cap` blocks; a null in_idx / out_idx means "block s".
   // many > 1: every bootstrap extracts `many` functions of its accumulator (coefficients t * stride); out_idx then
@@ -351,13 +351,25 @@ struct LutDriver {
         else  // trivial input indexing: the shard starts at block `begin`
           HX_CHECK(hipMemcpyAsync(g.d0_in, in0 + (size_t)begin * w, (size_t)ci * w * sizeof(uint64_t),
                                   hipMemcpyDeviceToDevice, st0));
+        const size_t in_bytes = (size_t)ci * w * sizeof(uint64_t), idx_bytes = (size_t)ci * sizeof(uint64_t),
+                     out_bytes = (size_t)many * ci * w * sizeof(uint64_t);
+        if (!g.direct) {  // first legs on the first GPU's stream, which owns the sources
+          HX_CHECK(hipMemcpyAsync(h_in(g), g.d0_in, in_bytes, hipMemcpyDeviceToHost, st0));
+          HX_CHECK(hipMemcpyAsync(h_idx(g), lut_idx + off + begin, idx_bytes, hipMemcpyDeviceToHost, st0));
+        }
         HX_CHECK(hipEventRecord(g.staged, st0));
         HX_CHECK(hipSetDevice((int)g.gpu));
         HX_CHECK(hipStreamWaitEvent(sti, g.staged, 0));
-        peer_copy(g, g.d_in, (int)g.gpu, g.d0_in, (int)gpus[0].gpu, (size_t)ci * w * sizeof(uint64_t), sti);
-        peer_copy(g, g.d_lut_idx, (int)g.gpu, lut_idx + off + begin, (int)gpus[0].gpu, (size_t)ci * sizeof(uint64_t), sti);
+        if (g.direct) {
+          HX_CHECK(hipMemcpyPeerAsync(g.d_in, (int)g.gpu, g.d0_in, (int)gpus[0].gpu, in_bytes, sti));
+          HX_CHECK(hipMemcpyPeerAsync(g.d_lut_idx, (int)g.gpu, lut_idx + off + begin, (int)gpus[0].gpu, idx_bytes, sti));
+        } else {
+          HX_CHECK(hipMemcpyAsync(g.d_in, h_in(g), in_bytes, hipMemcpyHostToDevice, sti));
+          HX_CHECK(hipMemcpyAsync(g.d_lut_idx, h_idx(g), idx_bytes, hipMemcpyHostToDevice, sti));
+        }
         ks_pbs(sti, g, g.d_out, g.d_trivial, g.d_in, g.d_trivial, g.d_lut_idx, ci, ksks[i], bsks[i], many, stride);
-        peer_copy(g, g.d0_out, (int)gpus[0].gpu, g.d_out, (int)g.gpu, (size_t)many * ci * w * sizeof(uint64_t), sti);
+        if (g.direct) HX_CHECK(hipMemcpyPeerAsync(g.d0_out, (int)gpus[0].gpu, g.d_out, (int)g.gpu, out_bytes, sti));
+        else HX_CHECK(hipMemcpyAsync(h_out(g), g.d_out, out_bytes, hipMemcpyDeviceToHost, sti));  // second leg below, on st0
         HX_CHECK(hipEventRecord(g.done, sti));
         begin += ci;
       }
@@ -380,6 +392,8 @@ struct LutDriver {
         const uint32_t ci = num_inputs_on_gpu(c, i, active);
         if (ci == 0) continue;
         HX_CHECK(hipStreamWaitEvent(st0, g.done, 0));
+        if (!g.direct)
+          HX_CHECK(hipMemcpyAsync(g.d0_out, h_out(g), (size_t)many * ci * w * sizeof(uint64_t), hipMemcpyHostToDevice, st0));
         if (many > 1)
           for (uint32_t t = 0; t < many; ++t)
             axpy(st0, out, out_idx + (size_t)t * count + off + begin, g.d0_out + (size_t)t * ci * w, nullptr, 1, nullptr,

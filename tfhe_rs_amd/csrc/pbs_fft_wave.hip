@@ -1660,6 +1660,14 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
         __hip_atomic_fetch_add(pace_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
 #endif
+#ifndef WAVE_SPLIT_RES_FWD
+#define WAVE_SPLIT_RES_FWD 0  // split-key engine: forward pass F2's eight twiddles resident (ResidentTwiddles level 1)
+#endif
+#ifndef WAVE_SPLIT_RES_INV
+#define WAVE_SPLIT_RES_INV 0  // ... inverse pass I2's two twiddles resident (level 2; four inverse transforms per CMUX use them)
+#endif
+    ResidentTwiddles res_sp;
+    load_resident_twiddles<(WAVE_SPLIT_RES_INV >= 2 ? 2 : WAVE_SPLIT_RES_FWD)>(res_sp, T, lane);
     double worst = 0.0;  // largest distance from an integer seen by this lane (round-off check)
     // t = S + error, S integer: the Horner state takes the raw bits of t + 1.5 2^52 (= GL_SPLIT_C0 + S; the bias of
     // the four limbs cancels against the states' start value GL_SPLIT_R0), R <- R 2^16 + bits (mod P), lazy Goldilocks forms
@@ -1690,7 +1698,7 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
       HX_PRIO(WAVE_PRIO_A);
       make_digits(d, a_hat, 0);  // both operands of the rotation from the staged copy (the registers are not the accumulator's)
       HX_PRIO(WAVE_PRIO_B);
-      wave_forward<0, WAVE_LIT_LIMBS != 0>(d, ctx);  // d = F, my row of the digit transform; also in my buffer (mapping M3)
+      wave_forward<WAVE_SPLIT_RES_FWD, WAVE_LIT_LIMBS != 0>(d, ctx, &res_sp);  // d = F, my row of the digit transform; also in my buffer (mapping M3)
       uint64_t R_re[16], R_im[16];
       HX_UNROLL
       for (int r = 0; r < 16; ++r) R_re[r] = R_im[r] = GL_SPLIT_R0;  // the limbs' bias cancels (arith.h)
@@ -1712,7 +1720,7 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
             std::integral_constant<bool, WAVE_FUSE_PASS1 != 0>{});
         if constexpr (LAST) acc_load();
         HX_PRIO(WAVE_PRIO_D);
-        wave_inverse_accumulate<(WAVE_FUSE_PASS1 != 0) ? 1 : 0, false, false, true, 0, WAVE_LIT_LIMBS != 0>(o, acc_re, acc_im, ctx);
+        wave_inverse_accumulate<(WAVE_FUSE_PASS1 != 0) ? 1 : 0, false, false, true, WAVE_SPLIT_RES_INV, WAVE_LIT_LIMBS != 0>(o, acc_re, acc_im, ctx, &res_sp);
         HX_UNROLL
         for (int r = 0; r < 16; ++r) {
           fold(R_re[r], o[r].re);

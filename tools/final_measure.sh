@@ -23,6 +23,8 @@ cd $R && python tools/rocprof_summary.py gpurun_out/${tag}_rocprof_extra gpurun_
 python tools/measure_all.py ks ks32 ks1024 wave n1024 mb mb4 mblat ntt ntt_split sweep > gpurun_out/${tag}_measure_all.jsonl 2>&1; cat gpurun_out/${tag}_measure_all.jsonl | cut -c1-260
 # the multi-GPU form of bench.py on the one GPU of this box (two shards as two streams: logic check, not a scaling number)
 TFHE_BENCH_FAKE_MULTI_GPU=1 python bench.py --gpus 2 --steps 3 --no-pmc > gpurun_out/${tag}_bench_fake2gpu.json 2> gpurun_out/${tag}_bench_fake2gpu.err; cut -c1-200 gpurun_out/${tag}_bench_fake2gpu.json
+# the scaling sweep's form of the command (headline only): eight shards, must stay under two minutes of wall time
+( time TFHE_BENCH_FAKE_MULTI_GPU=1 python bench.py --gpus 8 --steps 3 --scale-quick > gpurun_out/${tag}_bench_fake8gpu_scale_quick.json 2> gpurun_out/${tag}_bench_fake8gpu_scale_quick.err ) 2>&1 | grep real; cut -c1-300 gpurun_out/${tag}_bench_fake8gpu_scale_quick.json
 # ... and eight shards (the driver's largest N): 8 streams of the one GPU, config 5 through both shardings
 TFHE_BENCH_FAKE_MULTI_GPU=1 python bench.py --gpus 8 --steps 2 --no-pmc > gpurun_out/${tag}_bench_fake8gpu.json 2> gpurun_out/${tag}_bench_fake8gpu.err; cut -c1-200 gpurun_out/${tag}_bench_fake8gpu.json; tail -2 gpurun_out/${tag}_bench_fake8gpu.err
 python tools/latency_integer.py classic > gpurun_out/${tag}_latency_integer.jsonl 2>&1; python tools/latency_integer.py multibit_g4 >> gpurun_out/${tag}_latency_integer.jsonl 2>&1; cut -c1-200 gpurun_out/${tag}_latency_integer.jsonl
