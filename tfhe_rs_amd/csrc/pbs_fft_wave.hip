@@ -1470,10 +1470,15 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
 #ifdef WAVE_MB_EXPERIMENT_SKIP_LOADS  // timing experiment only (wrong results): 1 of N key requests is issued
             if (t % WAVE_MB_EXPERIMENT_SKIP_LOADS != 0) return;
 #endif
+            uint32_t o0 = row0_off, o1 = row1_off;
+#if WAVE_MB_ROOT_JIT
+            HX_OPAQUE_S(o0);
+            HX_OPAQUE_S(o1);
+#endif
             HX_UNROLL
             for (int j = 0; j < PTS; ++j) {
-              x0[set][j] = ldc(gk, lane_off, sidx * ggsw_bytes + row0_off + (uint32_t)(ch * PTS + j) * 1024u);
-              x1[set][j] = ldc(gk, lane_off, sidx * ggsw_bytes + row1_off + (uint32_t)(ch * PTS + j) * 1024u);
+              x0[set][j] = ldc(gk, lane_off, sidx * ggsw_bytes + o0 + (uint32_t)(ch * PTS + j) * 1024u);
+              x1[set][j] = ldc(gk, lane_off, sidx * ggsw_bytes + o1 + (uint32_t)(ch * PTS + j) * 1024u);
             }
           };
           HX_UNROLL
@@ -1503,7 +1508,11 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
                 HX_UNROLL
                 for (int j = 0; j < PTS; ++j) {
                   constexpr uint32_t br4[16] = {0, 8, 4, 12, 2, 10, 6, 14, 1, 9, 5, 13, 3, 11, 7, 15};
-                  const cplx wr = w16_root((br4[ch * PTS + j] * deg[sidx]) & 15u);
+                  uint32_t dgs = deg[sidx];
+#if WAVE_MB_ROOT_JIT && WAVE_MB_W16_SCALAR
+                  HX_OPAQUE_S(dgs);
+#endif
+                  const cplx wr = w16_root((br4[ch * PTS + j] * dgs) & 15u);
                   const cplx mf = cmul_first(base[sidx], wr);
                   kb0[j] = cmul_add(x0[set][j], mf, kb0[j]);
                   kb1[j] = cmul_add(x1[set][j], mf, kb1[j]);
