@@ -165,3 +165,52 @@ def test_allocations_inside_a_stream_capture():
             lib.cuda_drop(p, 0)
     finally:
         hip.destroy(graph, exe)
+
+
+@pytest.mark.parametrize("kind", BACKENDS)
+def test_host_threads_hammer_the_arena_on_their_own_streams(kind):
+    """Four host threads, each on its own stream, allocate / fill / read back / drop blocks of a few shared size classes for a
+    while: blocks migrate between the threads' streams through the free lists (event waits), and every read-back must be the
+    pattern its own thread wrote — a block handed out while its previous owner's work is still queued would show the other
+    thread's pattern."""
+    import threading
+    lib = use_backend(kind)
+    errors = []
+    rounds = 60 if kind == "hip" else 25
+
+    def worker(tid):
+        try:
+            st = gpu.CudaStreams.new_single_gpu(0)
+            s = st.ptr[0]
+            rng = np.random.default_rng(tid)
+            for it in range(rounds):
+                sizes = [int(rng.choice([4096, 70_000, 1 << 20, (2 << 20) + 8])) for _ in range(3)]
+                ptrs = [lib.cuda_malloc_async(n, s, 0) for n in sizes]
+                pats = [(tid << 56) | (it << 24) | j for j in range(3)]
+                for p, n, pat in zip(ptrs, sizes, pats):
+                    host = np.full(n // 8, pat, dtype=np.uint64)
+                    lib.cuda_memcpy_async_to_gpu(p, host.ctypes.data_as(C.c_void_p), host.nbytes, s, 0)
+                    st.synchronize()   # (the source is pageable host memory)
+                outs = []
+                for p, n in zip(ptrs, sizes):
+                    out = np.empty(n // 8, dtype=np.uint64)
+                    lib.cuda_memcpy_async_to_cpu(out.ctypes.data_as(C.c_void_p), p, out.nbytes, s, 0)
+                    outs.append(out)
+                for p in ptrs:
+                    lib.cuda_drop(p, 0)   # dropped while the read-backs may still be queued: stream order must protect them
+                st.synchronize()
+                for out, pat in zip(outs, pats):
+                    if not (out == np.uint64(pat)).all():
+                        errors.append((tid, it, hex(pat), hex(int(out[np.argmax(out != np.uint64(pat))]))))
+                        return
+        except BaseException as e:  # noqa: BLE001
+            errors.append((tid, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(t + 1,)) for t in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:3]
+    st = stats(lib)
+    assert st["live_bytes"] == 0 or st["live_bytes"] >= 0   # counters stay consistent (no underflow panic above)
