@@ -552,11 +552,11 @@ def main():
         # multi-bit = 12) — 1024 FheUint64 of 32 blocks enter the first round of an addition as 32768 blocks
         cus = lib.cuda_get_number_of_sms()
         blocks = 1024 * 32
+        act = lambda nb, pbs_type: int(lib.hip_integer_active_gpu_count(nb, n_gpus, pbs_type, 0))  # the library's own rule
         result["config5_active_gpus"] = {"gpus": n_gpus, "blocks_in_first_round": blocks,
-                                         "classic": min(n_gpus, -(-blocks // (cus + 1))), "multi_bit": min(n_gpus, -(-blocks // 12)),
+                                         "classic": act(blocks, 1), "multi_bit": act(blocks, 0),
                                          "thresholds": {"classic": cus + 1, "multi_bit": 12},
-                                         "one_fheuint64_classic": min(n_gpus, -(-32 // (cus + 1))),
-                                         "one_fheuint64_multi_bit": min(n_gpus, -(-32 // 12))}
+                                         "one_fheuint64_classic": act(32, 1), "one_fheuint64_multi_bit": act(32, 0)}
     if latency_ms is not None:
         result["extra"] = {"single_pbs_latency_ms": latency_ms,
                            "single_pbs_kernel": {7: "block_latency", 2: "wave_throughput"}.get(latency_kernel,
