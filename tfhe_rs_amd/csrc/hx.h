@@ -98,17 +98,20 @@ static inline uint64_t hx_buffer_load_u64(HxBuffer b, uint32_t byte_offset) {
 struct hx_f64x2 {
   double x, y;
 };
+template <int AUX = 0>
 static inline hx_f64x2 hx_buffer_load_f64x2(HxBuffer b, uint32_t lane_byte_offset, uint32_t uniform_byte_offset) {
   hx_f64x2 v;
   __builtin_memcpy(&v, b.base + lane_byte_offset + uniform_byte_offset, 16);
   return v;
 }
+template <int AUX = 0>
 static inline void hx_buffer_load_u64x2(HxBuffer b, uint32_t lane_byte_offset, uint32_t uniform_byte_offset, uint64_t &x, uint64_t &y) {
   uint64_t v[2];
   __builtin_memcpy(v, b.base + lane_byte_offset + uniform_byte_offset, 16);
   x = v[0];
   y = v[1];
 }
+template <int AUX = 0>
 static inline void hx_buffer_store_u64x2(HxBuffer b, uint32_t lane_byte_offset, uint32_t uniform_byte_offset, uint64_t x, uint64_t y) {
   const uint64_t v[2] = {x, y};
   __builtin_memcpy(const_cast<char *>(b.base) + lane_byte_offset + uniform_byte_offset, v, 16);
@@ -131,23 +134,27 @@ __device__ __forceinline__ uint64_t hx_buffer_load_u64(HxBuffer b, uint32_t byte
 struct hx_f64x2 {
   double x, y;
 };
+template <int AUX = 0>
 __device__ __forceinline__ hx_f64x2 hx_buffer_load_f64x2(HxBuffer b, uint32_t lane_byte_offset,
                                                          uint32_t uniform_byte_offset) {
   typedef unsigned int hx_u32x4 __attribute__((ext_vector_type(4)));
-  const hx_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(b.rsrc, (int)lane_byte_offset, (int)uniform_byte_offset, 0);
+  const hx_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(b.rsrc, (int)lane_byte_offset, (int)uniform_byte_offset, AUX);
   hx_f64x2 r;
   __builtin_memcpy(&r, &v, 16);
   return r;
 }
 // 16 bytes per lane as two 64-bit words, load and store (the split-key engine's accumulator round trip: one vector register
 // of lane offsets for the whole sweep instead of a 64-bit pointer per 4 KB window of immediate offsets)
+// AUX: the instruction's cache-policy bits (gfx940+: 1 = sc0, 2 = nt, 16 = sc1)
+template <int AUX = 0>
 __device__ __forceinline__ void hx_buffer_load_u64x2(HxBuffer b, uint32_t lane_byte_offset, uint32_t uniform_byte_offset, uint64_t &x,
                                                      uint64_t &y) {
   typedef unsigned int hx_u32x4 __attribute__((ext_vector_type(4)));
-  const hx_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(b.rsrc, (int)lane_byte_offset, (int)uniform_byte_offset, 0);
+  const hx_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(b.rsrc, (int)lane_byte_offset, (int)uniform_byte_offset, AUX);
   x = ((uint64_t)v.y << 32) | v.x;
   y = ((uint64_t)v.w << 32) | v.z;
 }
+template <int AUX = 0>
 __device__ __forceinline__ void hx_buffer_store_u64x2(HxBuffer b, uint32_t lane_byte_offset, uint32_t uniform_byte_offset, uint64_t x,
                                                       uint64_t y) {
   typedef unsigned int hx_u32x4 __attribute__((ext_vector_type(4)));
@@ -156,7 +163,7 @@ __device__ __forceinline__ void hx_buffer_store_u64x2(HxBuffer b, uint32_t lane_
   v.y = (uint32_t)(x >> 32);
   v.z = (uint32_t)y;
   v.w = (uint32_t)(y >> 32);
-  __builtin_amdgcn_raw_buffer_store_b128(v, b.rsrc, (int)lane_byte_offset, (int)uniform_byte_offset, 0);
+  __builtin_amdgcn_raw_buffer_store_b128(v, b.rsrc, (int)lane_byte_offset, (int)uniform_byte_offset, AUX);
 }
 #endif
 

@@ -905,6 +905,9 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
 // costs scalar registers — profiles/r05_ab_split_buffers.txt)
 #define WAVE_KEY_BUFFER 2
 #endif
+#ifndef WAVE_KEY_AUX
+#define WAVE_KEY_AUX 0  // cache-policy bits of the buffer-addressed key requests
+#endif
   constexpr bool KEYBUF = WAVE_KEY_BUFFER == 1 || (WAVE_KEY_BUFFER == 2 && LIMBS > 0);
   const HxBuffer bskb = hx_make_buffer(a.bsk, KEYBUF ? (uint32_t)((size_t)a.n * key_levels * 4 * n * sizeof(cplx)) : 0u);
   auto key_rows = [&](uint32_t i, uint32_t idx, const cplx *&b0, const cplx *&b1) {
@@ -926,8 +929,8 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
       const uint32_t o0 = (uint32_t)(uintptr_t)b0, o1 = (uint32_t)(uintptr_t)b1;
       HX_UNROLL
       for (int j = 0; j < 4; ++j) {
-        const hx_f64x2 v0 = hx_buffer_load_f64x2(bskb, (uint32_t)lane * 16u, o0 + (uint32_t)(ch * 4 + j) * 1024u);
-        const hx_f64x2 v1 = hx_buffer_load_f64x2(bskb, (uint32_t)lane * 16u, o1 + (uint32_t)(ch * 4 + j) * 1024u);
+        const hx_f64x2 v0 = hx_buffer_load_f64x2<WAVE_KEY_AUX>(bskb, (uint32_t)lane * 16u, o0 + (uint32_t)(ch * 4 + j) * 1024u);
+        const hx_f64x2 v1 = hx_buffer_load_f64x2<WAVE_KEY_AUX>(bskb, (uint32_t)lane * 16u, o1 + (uint32_t)(ch * 4 + j) * 1024u);
         k0[j] = cplx{v0.x, v0.y};
         k1[j] = cplx{v1.x, v1.y};
       }
@@ -1113,6 +1116,13 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
       const hx_f64x2 v = hx_buffer_load_f64x2(b, voff, soff);
       return cplx{v.x, v.y};
     };
+#ifndef WAVE_MB_KEY_AUX
+#define WAVE_MB_KEY_AUX 0  // cache-policy bits of the multi-bit key requests (hx.h)
+#endif
+    auto ldk = [](HxBuffer b, uint32_t voff, uint32_t soff) {
+      const hx_f64x2 v = hx_buffer_load_f64x2<WAVE_MB_KEY_AUX>(b, voff, soff);
+      return cplx{v.x, v.y};
+    };
 #if WAVE_MB_PREFETCH
     // The workgroups of an XCD walk the key in step (pacing), so every line of a group's key is a first touch for all
     // of them at once.  One load per wave and group, issued before the inverse transform, touches the NEXT group's
@@ -1271,8 +1281,8 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
             HX_OPAQUE_S(o0);  // the scalar offset of a request is one addition: made here, not 2 x 4 x 2^g of them ahead of the
             HX_OPAQUE_S(o1);  // level and carried through vector-register lanes
 #endif
-            x0[set] = ldc(gk, lane_off, sidx * ggsw_bytes + o0 + (uint32_t)j * 1024u);
-            x1[set] = ldc(gk, lane_off, sidx * ggsw_bytes + o1 + (uint32_t)j * 1024u);
+            x0[set] = ldk(gk, lane_off, sidx * ggsw_bytes + o0 + (uint32_t)j * 1024u);
+            x1[set] = ldk(gk, lane_off, sidx * ggsw_bytes + o1 + (uint32_t)j * 1024u);
           };
           uint32_t dg[2][4];
           cplx bs[2][4];
@@ -1382,8 +1392,8 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
             HX_OPAQUE_S(o0);
             HX_OPAQUE_S(o1);
 #endif
-            x0[set] = ldc(gk, lane_off, sidx * ggsw_bytes + o0 + (uint32_t)j * 1024u);
-            x1[set] = ldc(gk, lane_off, sidx * ggsw_bytes + o1 + (uint32_t)j * 1024u);
+            x0[set] = ldk(gk, lane_off, sidx * ggsw_bytes + o0 + (uint32_t)j * 1024u);
+            x1[set] = ldk(gk, lane_off, sidx * ggsw_bytes + o1 + (uint32_t)j * 1024u);
           };
           HX_UNROLL
           for (int t = 0; t < SETS && t < STEPS; ++t) request(t, t);
@@ -1477,8 +1487,8 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
 #endif
             HX_UNROLL
             for (int j = 0; j < PTS; ++j) {
-              x0[set][j] = ldc(gk, lane_off, sidx * ggsw_bytes + o0 + (uint32_t)(ch * PTS + j) * 1024u);
-              x1[set][j] = ldc(gk, lane_off, sidx * ggsw_bytes + o1 + (uint32_t)(ch * PTS + j) * 1024u);
+              x0[set][j] = ldk(gk, lane_off, sidx * ggsw_bytes + o0 + (uint32_t)(ch * PTS + j) * 1024u);
+              x1[set][j] = ldk(gk, lane_off, sidx * ggsw_bytes + o1 + (uint32_t)(ch * PTS + j) * 1024u);
             }
           };
           HX_UNROLL
@@ -1598,6 +1608,12 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
 #ifndef WAVE_SPLIT_ACC_BUFFER
 #define WAVE_SPLIT_ACC_BUFFER 1
 #endif
+#ifndef WAVE_SPLIT_ACC_AUX
+// cache-policy bits of the accumulator's loads and stores (hx.h: 1 = sc0, 2 = nt, 16 = sc1).  16 (agent scope: the lines do not
+// stay in the CU's vector L1, which the four LWEs' key requests share): 131.2 -> 129.6 and 132.0 -> 131.0 ms per 4096 on two
+// boxes; nt, sc0 and the combinations: no gain or worse (profiles/r05_ab_split_cache_policy.txt)
+#define WAVE_SPLIT_ACC_AUX 16
+#endif
     const uint64_t *gacc_base = a.acc_scratch ? a.acc_scratch + ((size_t)sample * 2 + (size_t)w) * N : nullptr;
     const HxBuffer gaccb = hx_make_buffer(gacc_base, (uint32_t)(N * sizeof(uint64_t)));
     U64x2 *gacc = (U64x2 *)gacc_base + lane;
@@ -1612,7 +1628,7 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
       HX_UNROLL
       for (int r = 0; r < 16; ++r) {
 #if WAVE_SPLIT_ACC_BUFFER
-        hx_buffer_load_u64x2(gaccb, (uint32_t)ln * 16u, (uint32_t)r * 1024u, acc_re[r], acc_im[r]);
+        hx_buffer_load_u64x2<WAVE_SPLIT_ACC_AUX>(gaccb, (uint32_t)ln * 16u, (uint32_t)r * 1024u, acc_re[r], acc_im[r]);
 #else
         const U64x2 v = gacc[r * 64];
         acc_re[r] = v.x;
@@ -1629,7 +1645,7 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
       HX_UNROLL
       for (int r = 0; r < 16; ++r) {
 #if WAVE_SPLIT_ACC_BUFFER
-        hx_buffer_store_u64x2(gaccb, (uint32_t)ln * 16u, (uint32_t)r * 1024u, acc_re[r], acc_im[r]);
+        hx_buffer_store_u64x2<WAVE_SPLIT_ACC_AUX>(gaccb, (uint32_t)ln * 16u, (uint32_t)r * 1024u, acc_re[r], acc_im[r]);
 #else
         gacc[r * 64] = U64x2{acc_re[r], acc_im[r]};
 #endif
