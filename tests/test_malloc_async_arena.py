@@ -214,3 +214,22 @@ def test_host_threads_hammer_the_arena_on_their_own_streams(kind):
     assert not errors, errors[:3]
     st = stats(lib)
     assert st["live_bytes"] == 0 or st["live_bytes"] >= 0   # counters stay consistent (no underflow panic above)
+
+
+@pytest.mark.gpu
+def test_a_block_of_a_callers_own_stream_that_is_gone_by_the_time_it_is_dropped():
+    """The stream argument is the caller's (a hipStream_t made and destroyed outside the library's cuda_create_stream_ffi /
+    cuda_destroy_stream): dropping the block afterwards must not trip over the dead handle — the block comes back idle."""
+    lib = use_backend("hip")
+    rt = C.CDLL("libamdhip64.so")
+    own = C.c_void_p()
+    assert rt.hipStreamCreate(C.byref(own)) == 0
+    st = gpu.CudaStreams.new_single_gpu(0)
+    p = lib.cuda_malloc_async(1 << 18, own, 0)
+    lib.cuda_memset_async(p, 0x55, 1 << 18, own, 0)
+    assert rt.hipStreamSynchronize(own) == 0 and rt.hipStreamDestroy(own) == 0
+    before = stats(lib)
+    lib.cuda_drop(p, 0)
+    q = lib.cuda_malloc_async(1 << 18, st.ptr[0], 0)
+    assert q == p and stats(lib)["cross_stream_waits"] == before["cross_stream_waits"]
+    lib.cuda_drop(q, 0)

@@ -120,6 +120,7 @@ size_t trim_locked(DeviceArena &a) {
 }  // namespace
 
 void *arena_alloc(int device, size_t bytes, hipStream_t stream) {
+  HX_PANIC_IF_FALSE(device >= 0 && device < 16, "cuda_malloc_async: device index %d", device);
   DeviceArena &a = g_arena[device];
   const size_t cls = size_class(bytes ? bytes : 1);
   const bool capturing = stream != nullptr && stream_is_capturing(stream);
@@ -176,6 +177,7 @@ void *arena_alloc(int device, size_t bytes, hipStream_t stream) {
 }
 
 bool arena_free(int device, void *p, size_t *user_bytes) {
+  if (device < 0 || device >= 16) return false;
   DeviceArena &a = g_arena[device];
   std::lock_guard<std::mutex> lock(a.m);
   auto it = a.live.find(p);
@@ -189,7 +191,16 @@ bool arena_free(int device, void *p, size_t *user_bytes) {
     fb.pinned = true;  // dropped inside the capture: free at that point of the graph's timeline, for this stream only
   } else if (!lb.pinned && lb.stream != nullptr) {
     fb.ready = take_event(a);
-    HX_CHECK(hipEventRecord(fb.ready, lb.stream));  // everything queued on the owner's stream so far may still use it
+    // everything queued on the owner's stream so far may still use the block
+    if (hipEventRecord(fb.ready, lb.stream) != hipSuccess) {
+      // the stream is gone (a caller's own stream, destroyed without cuda_destroy_stream): its work has drained or will
+      // with the device — wait for the device once and hand the block on as idle
+      (void)hipGetLastError();
+      HX_CHECK(hipDeviceSynchronize());
+      a.spare_events.push_back(fb.ready);
+      fb.ready = nullptr;
+      fb.stream = nullptr;
+    }
   }
   a.free_[lb.cls].push_back(fb);
   a.stats.live_bytes -= lb.cls;
