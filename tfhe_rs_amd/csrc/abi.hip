@@ -110,6 +110,7 @@ void *cuda_create_stream_ffi(uint32_t gpu_index) {
   set_device(gpu_index);
   hipStream_t s;
   HX_CHECK(hipStreamCreate(&s));
+  arena_register_stream((int)gpu_index, s);
   return s;
 }
 void cuda_destroy_stream(void *stream, uint32_t gpu_index) {

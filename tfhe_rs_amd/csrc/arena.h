@@ -13,6 +13,7 @@ struct ArenaStats {
 void *arena_alloc(int device, size_t bytes, hipStream_t stream);
 // false: `p` is not an arena block (the caller frees it its own way); *user_bytes = the size it was asked for
 bool arena_free(int device, void *p, size_t *user_bytes);
+void arena_register_stream(int device, hipStream_t stream);  // cuda_create_stream_ffi: a stream the arena may touch at a drop
 void arena_release_stream(int device, hipStream_t stream);
 size_t arena_trim(int device);  // idle blocks back to the runtime; bytes released
 ArenaStats arena_stats(int device);

@@ -25,6 +25,7 @@
 #include <cstring>
 #include <mutex>
 #include <unordered_map>
+#include <unordered_set>
 #include <map>
 #include <deque>
 #include <vector>
@@ -47,6 +48,7 @@ struct DeviceArena {
   std::mutex m;
   std::unordered_map<const void *, LiveBlock> live;
   std::map<size_t, std::vector<FreeBlock>> free_;
+  std::unordered_set<hipStream_t> known_streams;  // made by cuda_create_stream_ffi and not destroyed yet: safe to touch at a drop
   std::deque<hipEvent_t> spare_events;  // taken from the front, returned to the back: a consumed event rests before its next record
   ArenaStats stats{};
 };
@@ -186,21 +188,20 @@ bool arena_free(int device, void *p, size_t *user_bytes) {
   a.live.erase(it);
   if (user_bytes) *user_bytes = lb.bytes;
   FreeBlock fb{p, lb.stream, nullptr, lb.pinned};
-  const bool capturing = lb.stream != nullptr && stream_is_capturing(lb.stream);
+  // A drop has no stream argument: the block's owner stream is touched only if the library made it and still knows it alive
+  // (cuda_create_stream_ffi / cuda_destroy_stream).  A caller's own stream may be gone by now — recording an event on a dead
+  // handle is undefined in the runtime — so its blocks come back after ONE device synchronisation, idle and nobody's.
+  const bool known = lb.stream != nullptr && a.known_streams.count(lb.stream) != 0;
+  const bool capturing = known && stream_is_capturing(lb.stream);
   if (capturing) {
     fb.pinned = true;  // dropped inside the capture: free at that point of the graph's timeline, for this stream only
+  } else if (lb.stream != nullptr && !known) {
+    HX_CHECK(hipDeviceSynchronize());
+    fb.stream = nullptr;
+    fb.pinned = false;
   } else if (!lb.pinned && lb.stream != nullptr) {
     fb.ready = take_event(a);
-    // everything queued on the owner's stream so far may still use the block
-    if (hipEventRecord(fb.ready, lb.stream) != hipSuccess) {
-      // the stream is gone (a caller's own stream, destroyed without cuda_destroy_stream): its work has drained or will
-      // with the device — wait for the device once and hand the block on as idle
-      (void)hipGetLastError();
-      HX_CHECK(hipDeviceSynchronize());
-      a.spare_events.push_back(fb.ready);
-      fb.ready = nullptr;
-      fb.stream = nullptr;
-    }
+    HX_CHECK(hipEventRecord(fb.ready, lb.stream));  // everything queued on the owner's stream so far may still use the block
   }
   a.free_[lb.cls].push_back(fb);
   a.stats.live_bytes -= lb.cls;
@@ -216,10 +217,18 @@ bool arena_free(int device, void *p, size_t *user_bytes) {
   return true;
 }
 
+void arena_register_stream(int device, hipStream_t stream) {
+  if (device < 0 || device >= 16) return;
+  DeviceArena &a = g_arena[device];
+  std::lock_guard<std::mutex> lock(a.m);
+  a.known_streams.insert(stream);
+}
+
 // the stream is about to be destroyed (already synchronised): its blocks are idle and nobody's
 void arena_release_stream(int device, hipStream_t stream) {
   DeviceArena &a = g_arena[device];
   std::lock_guard<std::mutex> lock(a.m);
+  a.known_streams.erase(stream);
   for (auto &kv : a.live)
     if (kv.second.stream == stream) kv.second.stream = nullptr, kv.second.pinned = false;
   for (auto &kv : a.free_)
