@@ -821,9 +821,17 @@ def main():
                       f"5.64 ms/PBS on one EPYC 9R45 core",
             "gpu_matches_cpu_bits": bool(np.array_equal(ref, out[:count])),
         }
-    print(json.dumps(result))
     if dist is not None:
         dist.destroy_process_group()
+    # the ONE JSON line goes out last: RCCL's version banner sits in the C runtime's stdout buffer (written at communicator
+    # set-up, flushed at exit when stdout is a file or a pipe) and would otherwise land behind it
+    sys.stdout.flush()
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:  # noqa: BLE001
+        pass
+    print(json.dumps(result), flush=True)
 
 
 if __name__ == "__main__":
