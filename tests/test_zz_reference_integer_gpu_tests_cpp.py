@@ -2,10 +2,8 @@
 unchecked_add_test, default_add_test, default_overflowing_add_test, default_mul_test), restated in C++ in
 tests/cpp/reference_integer_gpu_tests.cpp on the compiled host mirror tfhe_rs_amd/host/integer_gpu.hpp and linked against
 the library.  [emu] small sets on the host emulation; [hip] PARAM_MESSAGE_2_CARRY_2_KS_PBS_TUNIFORM_2M128 and the GPU
-multi-bit g = 4 set on the MI355X.  (The file sorts last on purpose: the GPU budget of round 4 ran out before the [hip]
-case could be run once on hardware — the same operations at the same sizes pass through the Python host in
-tests/test_radix_integer.py, and this binary's add / mul / overflowing-add cases pass at the reference's sizes on the host
-emulation (REFERENCE_TESTS_SHORT_LOOPS=1; HISTORY.md) — so a surprise here cannot hide the rest of the tier behind `pytest -x`.)"""
+multi-bit g = 4 set on the MI355X.  (The file sorts last: it is the longest of the tier, and a surprise here must not hide the rest of it behind `pytest -x`;
+it has passed on the MI355X in every full run of round 5, `profiles/r05_gputest.log`.)"""
 import pytest
 
 from .harness import build_emu
