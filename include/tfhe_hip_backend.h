@@ -252,6 +252,14 @@ void cuda_centered_modulus_switch_64_async(void *stream, uint32_t gpu_index,
                                            void *lwe_out, const void *lwe_in,
                                            uint32_t lwe_dimension,
                                            uint32_t log_modulus);
+/* cuda/include/ciphertext.h:34-37 (modulus_switch.rs:386-488 tests it): the same switch with the body correction
+   reduced as the bootstrap kernels reduce it, in one block of shape (block_dim_x, block_dim_y): 128 threads (the
+   (64, 2) block of the throughput kernel: per wave, as pbs_fft_wave.hip's prologue) or 512 (the block kernels'
+   prologue); any other size aborts as in the reference (torus.cuh:460-463) */
+void cuda_centered_modulus_switch_cooperative_64_async(
+    void *stream, uint32_t gpu_index, void *lwe_out, const void *lwe_in,
+    uint32_t lwe_dimension, uint32_t log_modulus, uint32_t block_dim_x,
+    uint32_t block_dim_y);
 /* cuda/include/ciphertext.h:45-50 (tfhe/src/core_crypto/gpu/ffi.rs:914-936): the multi-bit switch as its own launch
  * (noise tests only; production fuses it into the keybundle).  `size` words of lwe_array_in are read as
  * size / grouping_factor groups, 2^grouping_factor degrees are written per group ([group][subset], subset 0 = 0).

@@ -11,7 +11,8 @@
 //   lwe_encrypt_ks_decrypt_custom_mod_ks32         …/lwe_keyswitch.rs:314-523
 //   test_(round_to_)closest_representable_gpu      …/lwe_keyswitch.rs:525-609
 //   glwe_encrypt_sample_extract_decrypt_custom_mod …/glwe_sample_extraction.rs:14-149
-//   compare_cpu_and_gpu_centered_modulus_switch    …/modulus_switch.rs:276-361, :386-488 (the four cooperative dimensions)
+//   compare_cpu_and_gpu_centered_modulus_switch    …/modulus_switch.rs:276-361 (with the four cooperative dimensions)
+//   compare_cpu_and_gpu_cooperative_centered_modulus_switch_{throughput_pbs,generic}_block   …/modulus_switch.rs:380-488
 //   assert_gpu_determinism / should_check_determinism   …/test/mod.rs:34-84
 //   mismatched_dimensions_panic                    the `assert_eq!`s of gpu/algorithms/*.rs (own test: the reference has none)
 //
@@ -598,6 +599,52 @@ static void compare_cpu_and_gpu_centered_modulus_switch() {
   }
 }
 
+// modulus_switch.rs:380-488: the cooperative correction (the one the bootstrap kernels run in their prologue, where a wrong
+// correction is hidden by the decoding of the output) on its own, against the CPU and against the sequential GPU kernel,
+// for the block of the throughput kernel (64, 2) and the generic one (512, 1); 10 ciphertexts per dimension, mask and
+// body varied
+static void check_cuda_cooperative_centered_modulus_switch(uint32_t dim_x, uint32_t dim_y, size_t lwe_dimension) {
+  const size_t NB_TESTS = 10;
+  const double lwe_noise_std = 0.000007069849454709433;
+  const uint32_t log_modulus = 12;
+  const CiphertextModulus ciphertext_modulus = CiphertextModulus::new_native();
+  CudaStreams streams = CudaStreams::new_single_gpu(GpuIndex(0));
+  TestResources rsc(37 + lwe_dimension + dim_x);
+  const std::vector<u64> sk = binary_key(rsc, lwe_dimension);
+  orc_rng random_generator;
+  orc_rng_seed(&random_generator, 41 + lwe_dimension);
+  enum Algorithm { Centered, CenteredCooperative };
+  auto cuda_centered_modulus_switch = [&](Algorithm ms, const std::vector<u64> &lwe) {
+    const auto d_lwe_input = CudaLweCiphertextList<u64>::from_lwe_ciphertext(lwe, ciphertext_modulus, streams);
+    CudaLweCiphertextList<u64> d_lwe_output(lwe_dimension, 1, ciphertext_modulus, streams);
+    if (ms == Centered)
+      cuda_centered_modulus_switch_64_async(streams.ptr[0], streams.gpu_indexes[0].get(), d_lwe_output.d_vec.as_mut_c_ptr(0),
+                                            d_lwe_input.d_vec.as_c_ptr(0), (uint32_t)lwe_dimension, log_modulus);
+    else
+      cuda_centered_modulus_switch_cooperative_64_async(streams.ptr[0], streams.gpu_indexes[0].get(), d_lwe_output.d_vec.as_mut_c_ptr(0),
+                                                        d_lwe_input.d_vec.as_c_ptr(0), (uint32_t)lwe_dimension, log_modulus, dim_x, dim_y);
+    return d_lwe_output.into_lwe_ciphertext(streams);
+  };
+  for (size_t t = 0; t < NB_TESTS; ++t) {
+    const std::vector<u64> lwe = encrypt_lwe(rsc, sk, orc_rng_next(&random_generator), lwe_noise_std);
+    std::vector<u64> cpu_container(lwe_dimension + 1);
+    orc_lwe_modulus_switch(lwe.data(), (uint32_t)lwe_dimension, log_modulus, 1, cpu_container.data());
+    const std::vector<u64> sequential_container = cuda_centered_modulus_switch(Centered, lwe);
+    const std::vector<u64> cooperative_container = cuda_centered_modulus_switch(CenteredCooperative, lwe);
+    const std::vector<u64> cooperative_container_bis = cuda_centered_modulus_switch(CenteredCooperative, lwe);
+    assert_gpu_determinism(cooperative_container, cooperative_container_bis, "cuda_centered_modulus_switch_cooperative_64");
+    CHECK(cpu_container == cooperative_container);
+    CHECK(sequential_container == cooperative_container);
+  }
+}
+static const size_t COOPERATIVE_TEST_LWE_DIMENSIONS[] = {100, 512, 742, 800};
+static void compare_cpu_and_gpu_cooperative_centered_modulus_switch_throughput_pbs_block() {
+  for (size_t lwe_dimension : COOPERATIVE_TEST_LWE_DIMENSIONS) check_cuda_cooperative_centered_modulus_switch(64, 2, lwe_dimension);
+}
+static void compare_cpu_and_gpu_cooperative_centered_modulus_switch_generic_block() {
+  for (size_t lwe_dimension : COOPERATIVE_TEST_LWE_DIMENSIONS) check_cuda_cooperative_centered_modulus_switch(512, 1, lwe_dimension);
+}
+
 // the `assert_eq!`s in front of every launch (gpu/algorithms/*.rs): mismatched operands panic before anything is enqueued
 static void mismatched_dimensions_panic() {
   const CiphertextModulus m = CiphertextModulus::new_native();
@@ -687,6 +734,10 @@ int main(int argc, char **argv) {
   tests.push_back({"test_closest_representable_gpu", test_closest_representable_gpu});
   tests.push_back({"test_round_to_closest_representable_gpu", test_round_to_closest_representable_gpu});
   tests.push_back({"compare_cpu_and_gpu_centered_modulus_switch", compare_cpu_and_gpu_centered_modulus_switch});
+  tests.push_back({"compare_cpu_and_gpu_cooperative_centered_modulus_switch_throughput_pbs_block",
+                   compare_cpu_and_gpu_cooperative_centered_modulus_switch_throughput_pbs_block});
+  tests.push_back({"compare_cpu_and_gpu_cooperative_centered_modulus_switch_generic_block",
+                   compare_cpu_and_gpu_cooperative_centered_modulus_switch_generic_block});
   tests.push_back({"mismatched_dimensions_panic", mismatched_dimensions_panic});
 
   size_t ran = 0, failed = 0;

@@ -519,6 +519,32 @@ def test_modulus_switch_and_sample_extract_helpers(kind):
 
 
 @pytest.mark.parametrize("kind", BACKENDS)
+@pytest.mark.parametrize("block", [(64, 2), (512, 1), (64, 8), (128, 1), (32, 4)])
+def test_cooperative_centered_modulus_switch_equals_the_sequential_one(kind, block):
+    """cuda_centered_modulus_switch_cooperative_64_async (cuda/include/ciphertext.h:34-37; the reference checks it in
+    modulus_switch.rs:380-488 with the blocks (64, 2) and (512, 1) and n in 100, 512, 742, 800): the prologue reduction
+    of the bootstrap kernels as a launch of its own — per wave for blocks one wavefront wide, the block tree otherwise —
+    word for word the oracle, the pure-Python restatement and the one-block kernel, rounding-boundary masks included."""
+    from .common import centered_ms_edge_vectors, centered_ms_reference
+    use_backend(kind)
+    st = gpu.CudaStreams.new_single_gpu(0)
+    rng = np.random.default_rng(block[0] * 7 + block[1])
+    cases = [(n, 12, rng.integers(0, 1 << 64, size=n + 1, dtype=np.uint64)) for n in (100, 512, 742, 800, 1, 63, 65)]
+    cases += [(31, 12, v) for v in centered_ms_edge_vectors(31, 12, seed=3).values()]
+    cases += [(10, 11, v) for v in list(centered_ms_edge_vectors(10, 11, seed=4).values())[::5]]
+    for n, log_mod, lwe in cases:
+        d_in = gpu.CudaVec.from_cpu_async(lwe, st)
+        d_seq, d_coop = gpu.CudaVec(n + 1, st), gpu.CudaVec(n + 1, st)
+        gpu.cuda_modulus_switch_ciphertext(d_seq, d_in, n, log_mod, True, st)
+        gpu.cuda_centered_modulus_switch_cooperative(d_coop, d_in, n, log_mod, block, st)
+        got = d_coop.copy_to_cpu(st)
+        assert np.array_equal(got, orc.lwe_modulus_switch(lwe, log_mod, 1)), (n, log_mod)
+        assert np.array_equal(got, d_seq.copy_to_cpu(st)), (n, log_mod)
+        if n <= 100:
+            assert np.array_equal(got, centered_ms_reference(lwe, log_mod)[0]), (n, log_mod)
+
+
+@pytest.mark.parametrize("kind", BACKENDS)
 def test_centered_modulus_switch_on_rounding_boundaries(kind):
     """The centered-mean switch (what PARAM_MESSAGE_2_CARRY_2 uses) on masks that sit on its rounding boundaries —
     exact ties, tie +- 1 with n odd (the halving of the summed halving errors truncates toward zero from either

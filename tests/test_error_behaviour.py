@@ -152,6 +152,14 @@ ABORTS = {
         one = (C.c_void_p * 1)(v.ptr)
         lib.cuda_integer_mult_inplace_64_async(s, C.byref(ct), False, C.byref(ct), True, one, one, mem, 2048, 2)
         """, "boolean operands need a scratch created with is_boolean_left / is_boolean_right"),
+    "cooperative modulus switch in a block of a size the reference does not take either (torus.cuh:460-463)": ("""
+        a, b = gpu.CudaVec(101, st), gpu.CudaVec(101, st)
+        lib.cuda_centered_modulus_switch_cooperative_64_async(S, 0, b.ptr, a.ptr, 100, 12, 64, 4)
+        """, "supported sizes are 128 and 512 threads per block"),
+    "cooperative modulus switch in place": ("""
+        a = gpu.CudaVec(101, st)
+        lib.cuda_centered_modulus_switch_cooperative_64_async(S, 0, a.ptr, a.ptr, 100, 12, 64, 2)
+        """, "Output and input pointers must be different"),
     "radix layer on a multi-bit key whose grouping factor does not divide n": ("""
         s = ffi.CudaStreamsFFI((C.c_void_p * 1)(S), (C.c_uint32 * 1)(0), 1)
         mem = C.c_void_p()

@@ -43,20 +43,20 @@ def hip_exe(tmp_path_factory):
 def test_reference_gpu_tests_on_the_host_emulation(tmp_path):
     exe = build_tests(build_emu(), str(tmp_path / "reference_gpu_tests_emu"))
     out = run(exe, "toy", timeout=1500)
-    assert out.count(" ... ok") == 18, out
+    assert out.count(" ... ok") == 20, out
 
 
 @pytest.mark.gpu
 def test_reference_gpu_tests_with_the_reference_parameter_sets(hip_exe):
     out = run(hip_exe, "reference", timeout=1500)
     # 4 classic + 3 multi-bit bootstraps + 2 multi-bit keyswitches + 2 noise-test flows (multi-bit switch -> blind rotation)
-    # + KS32 keyswitch + 2 closest-representable + modulus switch + panics
-    assert out.count(" ... ok") == 16, out
+    # + KS32 keyswitch + 2 closest-representable + modulus switch + 2 cooperative modulus switches + panics
+    assert out.count(" ... ok") == 18, out
     print(out)
 
 
 @pytest.mark.gpu
 def test_reference_gpu_tests_small_sets_on_the_gpu(hip_exe):
     out = run(hip_exe, "toy", timeout=600)
-    assert out.count(" ... ok") == 18, out
+    assert out.count(" ... ok") == 20, out
 

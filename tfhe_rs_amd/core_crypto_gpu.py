@@ -391,6 +391,14 @@ def cuda_modulus_switch_ciphertext(output_vec, input_vec, lwe_dimension, log_mod
         _lib().cuda_modulus_switch_64_async(s, g, output_vec.ptr, input_vec.ptr, lwe_dimension + 1, log_modulus)
 
 
+def cuda_centered_modulus_switch_cooperative(output_vec, input_vec, lwe_dimension, log_modulus, block_dim, streams):
+    """cuda_centered_modulus_switch_cooperative_64_async as modulus_switch.rs:405-418 calls it: one LWE, the body
+    correction reduced in a block of shape ``block_dim`` = (x, y) (128 or 512 threads; other sizes abort)."""
+    _lib().cuda_centered_modulus_switch_cooperative_64_async(streams.ptr[0], streams.gpu_indexes[0], output_vec.ptr,
+                                                             input_vec.ptr, lwe_dimension, log_modulus,
+                                                             block_dim[0], block_dim[1])
+
+
 def cuda_modulus_switch_multi_bit_ciphertext(streams, lwe_array_out, lwe_array_in, log_modulus, polynomial_size,
                                              grouping_factor):
     """gpu/ffi.rs:914-936: the multi-bit modulus switch as its own launch (the reference's noise tests); `lwe_array_in`

@@ -990,6 +990,18 @@ void cuda_centered_modulus_switch_64_async(void *stream, uint32_t gpu_index, voi
   launch_centered_modulus_switch(S(stream), (uint64_t *)lwe_out, (const uint64_t *)lwe_in, lwe_dimension,
                                  log_modulus);
 }
+// cuda/include/ciphertext.h:34-37, cuda/src/crypto/{ciphertext.cu:106-116, torus.cuh:435-465}: one LWE, block of shape
+// (block_dim_x, block_dim_y); 128 or 512 threads, anything else panics as there
+void cuda_centered_modulus_switch_cooperative_64_async(void *stream, uint32_t gpu_index, void *lwe_out, const void *lwe_in,
+                                                       uint32_t lwe_dimension, uint32_t log_modulus, uint32_t block_dim_x,
+                                                       uint32_t block_dim_y) {
+  set_device(gpu_index);
+  HX_PANIC_IF_FALSE(lwe_out != lwe_in, "Output and input pointers must be different for out-of-place operations");
+  HX_PANIC_IF_FALSE(launch_centered_modulus_switch_cooperative(S(stream), (uint64_t *)lwe_out, (const uint64_t *)lwe_in,
+                                                               lwe_dimension, log_modulus, block_dim_x, block_dim_y),
+                    "Unsupported block size for the cooperative centered modulus switch, supported sizes are 128 and 512 "
+                    "threads per block");
+}
 // cuda/include/ciphertext.h:45-50, cuda/src/crypto/{ciphertext.cu:166-178, torus.cuh:612-653}: `size` words of
 // lwe_array_in are read as size / grouping_factor groups (the reference's caller passes the whole ciphertext, body
 // included; the integer division drops it), 2^g words per group are written.  As in the reference the switch goes to

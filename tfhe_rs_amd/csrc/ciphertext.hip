@@ -22,6 +22,46 @@ __global__ void __launch_bounds__(256) centered_modulus_switch_kernel(uint64_t *
   for (uint32_t i = tid; i < lwe_dim; i += 256) out[i] = modulus_switch(in[i], log_modulus);
 }
 
+// The same switch with the body correction reduced the way the bootstrap kernels reduce it in their prologue, in a block
+// of the shape of the kernel to mimic (cuda/src/crypto/torus.cuh:404-465: 128 threads = the (64, 2) block of the
+// throughput kernel, 512 = the generic one; the thread index is linearised).  Here: a block whose x extent is one
+// wavefront reduces per wave and redundantly, through 128 words of LDS of its own, as pbs_fft_wave.hip's prologue does;
+// any other shape goes through block_body_modulus_switch, the prologue of the block kernels.  Both are exact integer sums,
+// so every shape gives the words of centered_modulus_switch_kernel.
+template <int TPB, bool WAVES>
+__global__ void __launch_bounds__(TPB) centered_modulus_switch_cooperative_kernel(uint64_t *out, const uint64_t *in,
+                                                                                uint32_t lwe_dim, uint32_t log_modulus) {
+  __shared__ uint64_t scratch[2 * TPB];
+  const int tid = threadIdx.x + threadIdx.y * blockDim.x;
+  uint32_t b;
+  if (WAVES) {
+    const int lane = tid & 63;
+    uint64_t *buf64 = scratch + (tid >> 6) * 128;
+    uint64_t sh = 0;
+    int64_t sd = 0;
+    for (uint32_t i = lane; i < lwe_dim; i += 64) {
+      uint64_t h;
+      int64_t dd;
+      centered_ms_terms(in[i], log_modulus, h, dd);
+      sh += h;
+      sd += dd;
+    }
+    buf64[lane] = sh;
+    buf64[64 + lane] = (uint64_t)sd;
+    HX_WAVE_SYNC();
+    uint64_t th = 0, td = 0;
+    for (int l = 0; l < 64; ++l) {
+      th += buf64[l];
+      td += buf64[64 + l];
+    }
+    b = (uint32_t)modulus_switch(in[lwe_dim] + centered_ms_finish(th, (int64_t)td, log_modulus), log_modulus);
+  } else {
+    b = block_body_modulus_switch<TPB>(in, lwe_dim, log_modulus, 1, scratch, tid);
+  }
+  if (tid == 0) out[lwe_dim] = b;
+  for (uint32_t i = tid; i < lwe_dim; i += TPB) out[i] = modulus_switch(in[i], log_modulus);
+}
+
 // cc/algorithms/glwe_sample_extraction.rs:89-164 ; indexing of cuda/src/crypto/ciphertext.cuh:32-54
 __global__ void sample_extract_kernel(uint64_t *lwe_out, const uint64_t *glwe_in, const uint32_t *nth_array,
                                       uint32_t lwe_per_glwe, uint32_t stored_per_glwe, uint32_t glwe_dim, uint32_t N) {
@@ -75,6 +115,26 @@ void launch_centered_modulus_switch(hipStream_t st, uint64_t *out, const uint64_
                                     uint32_t log_modulus) {
   HX_LAUNCH(centered_modulus_switch_kernel, dim3(1), dim3(256), 2 * 256 * sizeof(uint64_t), st, out, in, lwe_dim,
             log_modulus);
+}
+bool launch_centered_modulus_switch_cooperative(hipStream_t st, uint64_t *out, const uint64_t *in, uint32_t lwe_dim,
+                                                uint32_t log_modulus, uint32_t block_dim_x, uint32_t block_dim_y) {
+  const dim3 block(block_dim_x, block_dim_y, 1);
+  const bool waves = block_dim_x == 64;
+  switch (block_dim_x * block_dim_y) {
+  case 128:
+    if (waves)
+      HX_LAUNCH((centered_modulus_switch_cooperative_kernel<128, true>), dim3(1), block, 0, st, out, in, lwe_dim, log_modulus);
+    else
+      HX_LAUNCH((centered_modulus_switch_cooperative_kernel<128, false>), dim3(1), block, 0, st, out, in, lwe_dim, log_modulus);
+    return true;
+  case 512:
+    if (waves)
+      HX_LAUNCH((centered_modulus_switch_cooperative_kernel<512, true>), dim3(1), block, 0, st, out, in, lwe_dim, log_modulus);
+    else
+      HX_LAUNCH((centered_modulus_switch_cooperative_kernel<512, false>), dim3(1), block, 0, st, out, in, lwe_dim, log_modulus);
+    return true;
+  }
+  return false;
 }
 void launch_sample_extract(hipStream_t st, uint64_t *lwe_out, const uint64_t *glwe_in, const uint32_t *nth,
                            uint32_t num_nths, uint32_t lwe_per_glwe, uint32_t stored_per_glwe, uint32_t glwe_dim,

@@ -72,6 +72,9 @@ void launch_modulus_switch(hipStream_t st, uint64_t *out, const uint64_t *in, ui
 void launch_modulus_switch_multi_bit(hipStream_t st, uint64_t *out, const uint64_t *in, uint32_t groups, uint32_t log_modulus,
                                      uint32_t g);
 void launch_centered_modulus_switch(hipStream_t st, uint64_t *out, const uint64_t *in, uint32_t lwe_dim, uint32_t log_modulus);
+// false = a block size the reference does not take either (128 and 512 threads only)
+bool launch_centered_modulus_switch_cooperative(hipStream_t st, uint64_t *out, const uint64_t *in, uint32_t lwe_dim, uint32_t log_modulus,
+                                                uint32_t block_dim_x, uint32_t block_dim_y);
 void launch_sample_extract(hipStream_t st, uint64_t *lwe_out, const uint64_t *glwe_in, const uint32_t *nth,
                            uint32_t num_nths, uint32_t lwe_per_glwe, uint32_t stored_per_glwe, uint32_t glwe_dim,
                            uint32_t N);

@@ -99,6 +99,7 @@ SIGNATURES = {
     "cuda_modulus_switch_inplace_64_async": (None, [_v, _u32, _v, _u32, _u32]),
     "cuda_modulus_switch_64_async": (None, [_v, _u32, _v, _v, _u32, _u32]),
     "cuda_centered_modulus_switch_64_async": (None, [_v, _u32, _v, _v, _u32, _u32]),
+    "cuda_centered_modulus_switch_cooperative_64_async": (None, [_v, _u32, _v, _v, _u32, _u32, _u32, _u32]),
     "cuda_modulus_switch_multi_bit_64_async": (None, [_v, _u32, _v, _v, _u32, _u32, _u32, _u32]),
     # extensions
     "hip_convert_lwe_programmable_bootstrap_key_ntt64_async": (None, [_v, _u32, _v, _v, _u32, _u32, _u32, _u32]),
