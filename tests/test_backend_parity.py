@@ -108,22 +108,35 @@ def test_arith_hooks_match_oracle(kind):
     vs2 = np.array(sorted(set(near + [int(v) for v in vs] + [int(x) for x in xs])), dtype=np.uint64)
     got = run_arith(lib, st, 12, vs2)
     assert all(int(g) == ((((int(v) % p) << 64) + (p >> 1)) // p) % (1 << 64) for g, v in zip(got, vs2))
-    c0 = 0x4338000000000000
+    # ... and it is odd: modswitch(-x mod p) = -modswitch(x) mod 2^64 (the split-key engine's key limbs are cut from -k / 2)
+    neg = np.array([(p - int(v) % p) % p for v in vs2], dtype=np.uint64)
+    assert all((int(a) + int(b)) % (1 << 64) == 0 for a, b in zip(got, run_arith(lib, st, 12, neg)))
+    # the accumulator update of the engine: acc + modswitch(lazy v) as one written-out sequence (arith.h), every edge of
+    # both halves of v (the carry is a test of vl against 2^31 + 1 and of vh against 2^32 - 1) and of the sums' carries
+    ed = [0, 1, 2, 0x7FFFFFFE, 0x7FFFFFFF, 0x80000000, 0x80000001, 0x80000002, 0x80000003, 0xFFFFFFFE, 0xFFFFFFFF]
+    av = [(vh << 32) | vl for vh in ed for vl in ed] + [int(v) for v in vs2]
+    accs = [0, 1, M64, M64 - 1, 1 << 32, (1 << 32) - 1, 1 << 63, 0x123456789ABCDEF0]
+    am = np.array([[a, v] for a in accs for v in av], dtype=np.uint64).reshape(-1)
+    got = run_arith(lib, st, 14, am, in_per=2)
+    assert all(int(g) == (int(a) + (((int(v) % p) << 64) + (p >> 1)) // p) % (1 << 64) for g, a, v in zip(got, am[0::2], am[1::2]))
+    c0 = 0x4328000000000000  # bits(1.5 * 2^51): bits(t + 1.5 2^51) = c0 + 2 t for an integer |t| < 2^50
+    assert np.float64(1.5 * 2.0 ** 51).view(np.uint64) == c0 and np.float64(-(2.0 ** 49) + 1.5 * 2.0 ** 51).view(np.uint64) == c0 - (1 << 50)
     hs = np.array([[r, c0 + s] for r in list(xs[:40]) + [M64, p, p - 1, (1 << 48) - 1, 1 << 48]
                    for s in (0, 1, -1, (1 << 50) - 1, -(1 << 50) + 1, 12345678901234, -98765432109876)],
                   dtype=np.uint64).reshape(-1)
     got = run_arith(lib, st, 13, hs, in_per=2)
     assert all(int(g) % p == ((int(r) << 16) + int(x)) % p for g, r, x in zip(got, hs[0::2], hs[1::2]))
     bias = (c0 * 0x0001000100010001) % p
-    r0 = 0x4337bcc7798fbcc8  # arith.h GL_SPLIT_R0
-    assert bias == 0x86704337bcc77990 and (r0 * (1 << 64) + bias) % p == 0
+    r0 = 0x4327bcd779afbcd8  # arith.h GL_SPLIT_R0
+    assert bias == 0x86504327bcd779b0 and (r0 * (1 << 64) + bias) % p == 0
     S = rng.integers(-(1 << 49), 1 << 49, size=(300, 4)).astype(np.int64)
     S[0], S[1], S[2] = (1 << 49) - 1, -(1 << 49) + 1, 0
     state = np.full(len(S), r0, dtype=np.uint64)
     for m in range(4):  # four Horner steps on the biased bit patterns, most significant limb first
-        step = np.stack([state, (np.uint64(c0) + S[:, m].astype(np.uint64))], axis=1).reshape(-1)
+        step = np.stack([state, (np.uint64(c0) + (2 * S[:, m]).astype(np.uint64))], axis=1).reshape(-1)
         state = run_arith(lib, st, 13, step, in_per=2)
-    assert all(int(g) % p == sum(int(sv) << (16 * (3 - m)) for m, sv in enumerate(row)) % p for g, row in zip(state, S))
+    # ... of 2 S: the states end at TWICE the recombined value (the key limbs are cut from k / 2 mod p)
+    assert all(int(g) % p == 2 * sum(int(sv) << (16 * (3 - m)) for m, sv in enumerate(row)) % p for g, row in zip(state, S))
 
 
 @pytest.mark.parametrize("kind", BACKENDS)

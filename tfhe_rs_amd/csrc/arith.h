@@ -330,22 +330,33 @@ HX_HD uint64_t gl_modswitch_to_pow2(uint64_t v) {
 }
 
 // ---- split-key form of the exact engine (pbs_fft_wave.hip, LIMBS mode): lean, branch-free forms
-// Horner step  R <- R 2^16 + X  (mod p) on lazy values, X >= 0 below 2^63: one 64-bit shift, one add, the carry and
-// the 16 bits shifted out folded back in with  2^64 = EPS  (two multiply-adds).
+// Horner step  R <- R 2^16 + X  (mod p) on lazy values, X >= 0 below 2^63.  The 16 bits h shifted out come back as
+// h EPS (2^64 = EPS mod p) TOGETHER with X in one multiply-add that cannot wrap (h EPS < 2^48); the one addition that
+// can wrap is worth EPS once more, a second multiply-add (a wrapped V is below 2^63 + 2^48: it cannot wrap again).
+// Seven instructions (round 4's form added X first and carried twice: eleven).
 HX_HD uint64_t gl_horner16(uint64_t R, uint64_t X) {
-  const uint32_t hi = (uint32_t)(R >> 48);
-  uint64_t U;
-  const uint32_t c = __builtin_add_overflow(R << 16, X, &U) ? 1u : 0u;
+  const uint32_t h = (uint32_t)(R >> 48);
+  const uint64_t m = (uint64_t)h * GL_EPS + X;
   uint64_t V;
-  const uint32_t c2 = __builtin_add_overflow((uint64_t)(hi + c) * GL_EPS, U, &V) ? 1u : 0u;  // (hi + c) <= 2^16
-  return V + (uint64_t)c2 * GL_EPS;  // a wrapped V is below (hi + c) EPS < 2^48: cannot wrap again
+  uint32_t c = __builtin_add_overflow(R << 16, m, &V) ? 1u : 0u;
+#if !defined(TFHE_HIPEMU) && defined(__HIP_DEVICE_COMPILE__)
+  asm("" : "+v"(c));  // the carry as a 0 / 1 register: the compiler's select + zero-extension + 64-bit add are three instructions
+#endif
+  return (uint64_t)c * GL_EPS + V;
 }
-// bits(1.5 2^52 + S) = GL_SPLIT_C0 + S for an integer |S| < 2^51: the Horner above runs on the raw bit patterns.  The
-// bias of the four limbs, C0 (1 + 2^16 + 2^32 + 2^48) mod p, never has to be taken off: the Horner states START at
-// R0 with R0 2^64 = -bias (mod p), so after the four steps the state is the plain sum of the S_m 2^(16 (3 - m)) mod p
-static constexpr uint64_t GL_SPLIT_C0 = 0x4338000000000000ull;
-static constexpr uint64_t GL_SPLIT_BIAS = 0x86704337bcc77990ull;  // GL_SPLIT_C0 * 0x0001000100010001 mod p
-static constexpr uint64_t GL_SPLIT_R0 = 0x4337bcc7798fbcc8ull;    // -GL_SPLIT_BIAS / (2^64 mod p) mod p
+// The limb products leave the inverse transform as t = S + error, S integer, |S| <= 2^49.  bits(t + 1.5 2^51) =
+// GL_SPLIT_C0 + 2 S + q: the unit of that binade is 1/2, so bit 0 (q) says "t was not within 1/4 of an integer" — the
+// round-off check is an OR of the raw words — and the Horner above runs on the raw bit patterns, i.e. on 2 S.  The factor
+// 2 is taken out of the KEY (bsk_to_split_kernel cuts -k / 2 mod p into limbs; the sign because the engine's registers
+// hold minus the accumulator), the bias of the four limbs,
+// C0 (1 + 2^16 + 2^32 + 2^48) mod p, out of the states' start value: R0 2^64 = -bias (mod p), so after the four steps the
+// state is  sum_m 2 S_m 2^(16 (3 - m)) = -(digits (x) key)  mod p.
+static constexpr double GL_SPLIT_MAGIC = 3377699720527872.0;           // 1.5 * 2^51
+static constexpr uint64_t GL_SPLIT_C0 = 0x4328000000000000ull;         // its bit pattern
+static constexpr uint64_t GL_SPLIT_BIAS = 0x86504327bcd779b0ull;       // GL_SPLIT_C0 * 0x0001000100010001 mod p
+static constexpr uint64_t GL_SPLIT_R0 = 0x4327bcd779afbcd8ull;         // -GL_SPLIT_BIAS / (2^64 mod p) mod p
+// k / 2 mod p for k < p (p odd): k even -> k / 2, k odd -> (k + p) / 2 = (k >> 1) + (p >> 1) + 1
+HX_HD uint64_t gl_half(uint64_t k) { return (k >> 1) + ((k & 1) ? (GL_P >> 1) + 1 : 0); }
 // gl_modswitch_to_pow2 of a LAZY value (any 64-bit v, standing for v mod p), seven instructions:
 //   floor((v 2^64 + (p >> 1)) / p) = v + floor(w / p),  w = v e + h  (e = EPS = 2^64 - p, h = p >> 1);
 //   with v = vh 2^32 + vl:  w = vh p + rho,  rho = vl e + h - vh   (vh p = vh 2^32 e + vh, so vh p + rho = v e + h);
@@ -359,6 +370,36 @@ HX_HD uint64_t gl_modswitch_to_pow2_lazy(uint64_t v) {
   uint64_t t;
   const uint32_t more = __builtin_add_overflow((uint64_t)vl * GL_EPS, K - vh, &t) ? 1u : 0u;
   return v + vh + more;
+}
+
+// acc + gl_modswitch_to_pow2_lazy(v) in six instructions.  The carry of the lazy form above reduces to a test of the
+// halves of v:  vl e + (h + e - vh) >= 2^64  <=>  (vl + 2^31 - 1) 2^32 + (2^31 + ~vh - vl) >= 2^64  <=>  vl > 2^31 + 1, or
+// vl = 2^31 + 1 and vh != 2^32 - 1  <=>  vl + (2^31 - 2) + [vh != 2^32 - 1] carries out of 32 bits — a borrow feeding a carry
+// (test_arith_hooks_match_oracle op 14 against the big-integer formula, every edge of both halves).  On the device the
+// sequence is written out (the compiler's own lowering of the lazy form is thirteen instructions, zero-extensions included);
+// two wait states between a carry's producer and its consumer, as the compiler leaves them.
+HX_HD uint64_t gl_acc_modswitch_to_pow2_lazy(uint64_t acc, uint64_t v) {
+#if !defined(TFHE_HIPEMU) && defined(__HIP_DEVICE_COMPILE__)
+  const uint32_t vh = (uint32_t)(v >> 32), vl = (uint32_t)v, k = 0x7FFFFFFEu;
+  uint32_t t;
+  uint64_t x, sc;
+  asm("v_subrev_co_u32_e32 %[t], vcc, -1, %[vh]\n\t"      // borrow = [vh != 2^32 - 1]
+      "v_mad_u64_u32 %[x], %[sc], %[vh], 1, %[v]\n\t"     // x = v + vh
+      "s_nop 0\n\t"
+      "v_addc_co_u32_e32 %[t], vcc, %[k], %[vl], vcc\n\t"  // carry = the "more" of the lazy form
+      "v_lshl_add_u64 %[x], %[x], 0, %[acc]\n\t"
+      "s_nop 0\n\t"
+      "v_addc_co_u32_e64 %[t], %[sc], 0, 0, vcc\n\t"
+      "v_mad_u64_u32 %[x], %[sc], %[t], 1, %[x]"
+      : [t] "=&v"(t), [x] "=&v"(x), [sc] "=&s"(sc)
+      : [vh] "v"(vh), [vl] "v"(vl), [v] "v"(v), [acc] "v"(acc), [k] "v"(k)  // k in a vector register: with the carry-in a scalar would be a second constant-bus operand
+      : "vcc");
+  return x;
+#else
+  const uint32_t vh = (uint32_t)(v >> 32), vl = (uint32_t)v;
+  const uint64_t more = ((uint64_t)vl + 0x7FFFFFFEu + (vh != 0xFFFFFFFFu ? 1u : 0u)) >> 32;
+  return acc + v + vh + more;
+#endif
 }
 
 }  // namespace tfhe_hip

@@ -175,6 +175,9 @@
 #ifndef WAVE_LIT_MB
 #define WAVE_LIT_MB 1
 #endif
+#ifndef WAVE_SPLIT_TAIL_ASM
+#define WAVE_SPLIT_TAIL_ASM 1  // split-key engine: the accumulator update as arith.h's six-instruction sequence
+#endif
 #ifndef WAVE_LIT_LIMBS
 #define WAVE_LIT_LIMBS 0
 #endif
@@ -1693,15 +1696,16 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
 #endif
     ResidentTwiddles res_sp;
     load_resident_twiddles<(WAVE_SPLIT_RES_INV >= 2 ? 2 : WAVE_SPLIT_RES_FWD)>(res_sp, T, lane);
-    double worst = 0.0;  // largest distance from an integer seen by this lane (round-off check)
-    // t = S + error, S integer: the Horner state takes the raw bits of t + 1.5 2^52 (= GL_SPLIT_C0 + S; the bias of
-    // the four limbs cancels against the states' start value GL_SPLIT_R0), R <- R 2^16 + bits (mod P), lazy Goldilocks forms
+    uint32_t worst = 0;  // OR of the low words of every product's bit pattern: bit 0 = some product was not within 1/4 of an integer
+    // t = S + error, S integer: the Horner state takes the raw bits of t + 1.5 2^51 (= GL_SPLIT_C0 + 2 S + q, arith.h: the
+    // factor 2 is out of the key, the bias of the four limbs cancels against the states' start value GL_SPLIT_R0, q is
+    // the round-off check), R <- R 2^16 + bits (mod P), lazy Goldilocks forms: one f64 addition, one OR, seven integer
+    // instructions per product (round 4: four f64 instructions with the distance to the nearest integer, eleven integer)
     auto fold = [&](uint64_t &R, double t) {
-      const double MAGIC = 6755399441055744.0;  // 1.5 * 2^52: t + MAGIC has its unit bit at 2^0 for |t| < 2^51
-      const double tm = t + MAGIC;
-      const double fr = t - (tm - MAGIC);
-      worst = __builtin_fmax(worst, __builtin_fabs(fr));
-      R = gl_horner16(R, f64_bits(tm));
+      const uint64_t bits = f64_bits(t + GL_SPLIT_MAGIC);
+      worst |= (uint32_t)bits;
+      HX_LAUNDER(worst);  // one OR per product: as a tree the compiler keeps all 32 low words of a limb live and spills
+      R = gl_horner16(R, bits);
     };
     uint32_t it = 0;
     uint64_t mask_next = lwe[0];
@@ -1763,11 +1767,18 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
       HX_NO_UNROLL  // one body: unrolled, the scheduler overlaps the limbs and spills hundreds of registers
       for (uint32_t limb = 0; limb + 1 < (uint32_t)LIMBS; ++limb) limb_step(limb, std::false_type{});  // limb 0 = most significant
       limb_step((uint32_t)LIMBS - 1, std::true_type{});
-      // acc += modswitch_to_2^64(R mod P) (ntt64.rs:162-177); the registers hold MINUS the accumulator
+      // acc += modswitch_to_2^64(product mod P) (ntt64.rs:162-177).  The registers hold MINUS the accumulator and the key
+      // limbs are cut from MINUS the key, R = -product: modswitch(-x mod P) = -modswitch(x) mod 2^64 exactly (P odd: the
+      // rounding is symmetric), so the update is one 64-bit addition
       HX_UNROLL
       for (int r = 0; r < 16; ++r) {
-        acc_re[r] -= gl_modswitch_to_pow2_lazy(R_re[r]);
-        acc_im[r] -= gl_modswitch_to_pow2_lazy(R_im[r]);
+#if WAVE_SPLIT_TAIL_ASM
+        acc_re[r] = gl_acc_modswitch_to_pow2_lazy(acc_re[r], R_re[r]);
+        acc_im[r] = gl_acc_modswitch_to_pow2_lazy(acc_im[r], R_im[r]);
+#else
+        acc_re[r] += gl_modswitch_to_pow2_lazy(R_re[r]);
+        acc_im[r] += gl_modswitch_to_pow2_lazy(R_im[r]);
+#endif
       }
       acc_store();
       stage_acc();  // for the next CMUX's rotation (my buffer is free: the last inverse transposition is over)
@@ -1779,7 +1790,7 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
     // whole HIP context of the process).  The bound is statistical, not a proof — worst-case magnitudes of 2^49 leave
     // about 4 bits of f64 headroom, the typical product is 2^12 smaller; an error beyond 1/2 would alias to a small
     // distance and pass, so the check guards against drift, not against arbitrary corruption.
-    if (worst > 0.25 && a.roundoff_flag != nullptr) {
+    if ((worst & 1u) && a.roundoff_flag != nullptr) {
 #if defined(TFHE_HIPEMU)
       *a.roundoff_flag = 1u;
 #else

@@ -411,7 +411,7 @@ __global__ void __launch_bounds__(GenericCfg<N>::TPB) bsk_to_fourier_kernel(cons
 }
 
 // Split-key form of the exact engine (pbs_fft_wave.hip, LIMBS mode): key word x -> k = round(x P / 2^64)
-// (ntt64.rs:144-160), centred into (-P/2, P/2], cut into NTT_SPLIT_LIMBS balanced 16-bit limbs
+// (ntt64.rs:144-160), negated and halved modulo p (the engine recombines 2 S into minus the accumulator: arith.h GL_SPLIT_*), centred into (-P/2, P/2], cut into NTT_SPLIT_LIMBS balanced 16-bit limbs
 // kc = sum_m c_m 2^(16 m), c_m in [-2^15, 2^15] — and the polynomial of every limb transformed as INTEGERS (no torus
 // scaling).  Workgroup (p, q): limb index q (0 = most significant) of source polynomial p = (i*2 + row)*2 + col
 // goes to destination polynomial (i*LIMBS + q)*4 + row*2 + col, in the throughput kernel's slot order.
@@ -424,7 +424,8 @@ __global__ void __launch_bounds__(GenericCfg<N>::TPB) bsk_to_split_kernel(const 
   const uint64_t *p = src + (size_t)blockIdx.x * N;
   const int m = L - 1 - (int)blockIdx.y;  // limb exponent: value c_m 2^(16 m)
   auto limb = [&](uint64_t x) {
-    const uint64_t v = gl_modswitch_from_pow2(x);
+    // -k / 2 mod p: the engine's Horner states carry 2 S, and its registers hold MINUS the accumulator (arith.h GL_SPLIT_*)
+    const uint64_t k = gl_modswitch_from_pow2(x), v = gl_half(k ? GL_P - k : 0);
     int64_t kc = v > (GL_P >> 1) ? (int64_t)(v - GL_P) : (int64_t)v;
     int64_t c = 0;
     for (int q = 0; q <= m; ++q) {

@@ -30,6 +30,7 @@ __global__ void test_arith_kernel(uint32_t op, const uint64_t *in, uint64_t *out
     case 11: out[i] = (uint64_t)(int64_t)decomp_digit_l1_hi((uint32_t)(in[i] >> 32), p0); break;
     case 12: out[i] = gl_modswitch_to_pow2_lazy(in[i]); break;                 // any in[i] (lazy value)
     case 13: out[i] = gl_horner16(in[2 * i], in[2 * i + 1]); break;            // lazy result: compare mod p
+    case 14: out[i] = gl_acc_modswitch_to_pow2_lazy(in[2 * i], in[2 * i + 1]); break;  // acc + modswitch(lazy v)
     default: out[i] = 0;
   }
 }
