@@ -175,6 +175,12 @@
 #ifndef WAVE_LIT_MB
 #define WAVE_LIT_MB 1
 #endif
+#ifndef WAVE_SPLIT_SYNC
+// split-key engine: a bare workgroup barrier every so many mask elements (0: none) keeps the four LWEs of a workgroup on the
+// same key rows.  Same box, ms per 4096, two interleaved rounds: none 121.0, every 1 / 4 / 8 / 16 / 32: 119.4 / 118.6 /
+// 119.1 / 118.9 / 118.7 (profiles/r05_ab_split_sync.txt)
+#define WAVE_SPLIT_SYNC 16
+#endif
 #ifndef WAVE_SPLIT_TAIL_ASM
 #define WAVE_SPLIT_TAIL_ASM 1  // split-key engine: the accumulator update as arith.h's six-instruction sequence
 #endif
@@ -1713,6 +1719,11 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
       const uint64_t mask_cur = mask_next;
       mask_next = lwe[i + 1];
       const uint32_t a_hat = HX_UNIFORM((uint32_t)modulus_switch(mask_cur, LOG2N2));
+#if WAVE_SPLIT_SYNC && !defined(TFHE_HIPEMU)
+      // the workgroup's LWEs in step (speed only: no memory ordering rides on it; waves that have left do not count):
+      // every WAVE_SPLIT_SYNC-th mask element a bare s_barrier, executed before the a_hat == 0 skip by every wave
+      if (i % (uint32_t)WAVE_SPLIT_SYNC == 0) __builtin_amdgcn_s_barrier();
+#endif
 #if WAVE_SPLIT_PACE && !defined(TFHE_HIPEMU)
       if (a_hat == 0) {
         pace_arrive();

@@ -80,6 +80,12 @@ def main():
             i = argv.index(name)
             opts[name] = argv[i + 1]
             del argv[i:i + 2]
+    if "--extra-passes" in argv:   # ad-hoc counter groups, ';'-separated, in front of the standard ones ("--extra-only": instead of)
+        i = argv.index("--extra-passes")
+        PASSES = [g.strip() for g in argv[i + 1].split(";") if g.strip()] + ([] if "--extra-only" in argv else PASSES)
+        del argv[i:i + 2]
+        if "--extra-only" in argv:
+            argv.remove("--extra-only")
     if "--hbm-only" in argv:
         argv.remove("--hbm-only")
         PASSES = HBM_PASSES
