@@ -175,10 +175,26 @@
 #ifndef WAVE_LIT_MB
 #define WAVE_LIT_MB 1
 #endif
+#ifndef WAVE_SPLIT_EARLY_RESTORE
+// split-key engine: handshakes posted early / waited for late (see the limb step).  Same box, ms per 4096: 115.28 -> 114.73
+// (profiles/r05_ab_split_restore.txt) — the pair waits are cheap, as in the classic loop:
+#define WAVE_SPLIT_EARLY_RESTORE 1
+#endif
+#ifndef WAVE_DEFER_DONE
+// classic one-level loop: the "done" wait in front of the inverse transposition's first store instead of behind the products:
+// 32.17 -> 32.16 ms per 4096, three interleaved rounds (profiles/r05_ab_classic_defer.txt): not kept
+#define WAVE_DEFER_DONE 0
+#endif
+#ifndef WAVE_CLASSIC_SYNC
+// classic loop: the same barrier (0: none).  Same box, ms per 4096, three interleaved rounds: none 33.27, every 4 / 16 / 64:
+// 34.30 / 33.42 / 33.27 (profiles/r05_ab_classic_sync.txt) — its 60 MB key stays in L2 either way
+#define WAVE_CLASSIC_SYNC 0
+#endif
 #ifndef WAVE_SPLIT_SYNC
 // split-key engine: a bare workgroup barrier every so many mask elements (0: none) keeps the four LWEs of a workgroup on the
 // same key rows.  Same box, ms per 4096, two interleaved rounds: none 121.0, every 1 / 4 / 8 / 16 / 32: 119.4 / 118.6 /
-// 119.1 / 118.9 / 118.7 (profiles/r05_ab_split_sync.txt)
+// 119.1 / 118.9 / 118.7 (profiles/r05_ab_split_sync.txt); de-phasing the upper four waves behind the barrier (the classic
+// loop's WAVE_STAGGER) by 1 / 2 / 4 s_sleep(64): 117.8 -> 118.7 / 118.3 / 118.8
 #define WAVE_SPLIT_SYNC 16
 #endif
 #ifndef WAVE_SPLIT_TAIL_ASM
@@ -505,9 +521,17 @@ HX_DEV void inverse_stage_half4(cplx (&o)[16], int r0, const cplx *T) {
 // RAW (exact engine, split-key form): no torus conversion — o[r] becomes (t_re, t_im), the untwisted real values of
 // coefficients r*64 + lane and 1024 + r*64 + lane; nothing is staged, the accumulator registers are not touched.
 // PASS1_DONE: 0 nothing done, 1 stages half = 1, 2 done by the caller
-template <int PASS1_DONE, bool OVERWRITE = false, bool NEG = false, bool RAW = false, int RES = 0, bool LIT = false>
+// before_store(): called in front of the first store to the exchange buffer (the caller's deferred wait for the partner's
+// "done with your buffer").  after_load(): called when the transposition has left the buffer, which nothing below touches in
+// RAW mode (the split-key engine puts its digit transform back there at once, so that the partner never waits for it).
+struct WaveNoHook {
+  HX_DEV void operator()() const {}
+};
+template <int PASS1_DONE, bool OVERWRITE = false, bool NEG = false, bool RAW = false, int RES = 0, bool LIT = false,
+          class BeforeStore = WaveNoHook, class AfterLoad = WaveNoHook>
 HX_DEV void wave_inverse_accumulate(cplx (&o)[16], uint64_t (&acc_re)[16], uint64_t (&acc_im)[16], WaveCtx c,
-                                    const ResidentTwiddles *res = nullptr) {
+                                    const ResidentTwiddles *res = nullptr, BeforeStore before_store = BeforeStore{},
+                                    AfterLoad after_load = AfterLoad{}) {
   uint64_t *stg = (uint64_t *)c.buf;
   HX_OPAQUE(c.lane);
   const cplx *T = c.T;
@@ -521,6 +545,7 @@ HX_DEV void wave_inverse_accumulate(cplx (&o)[16], uint64_t (&acc_re)[16], uint6
     inverse_stage_half4<LIT>(o, 0, T);
     inverse_stage_half4<LIT>(o, 8, T);
     HX_SCHED_FENCE();
+    before_store();
     cplx *p3 = c.buf + base_m3(c);  // transposition M3 -> MX, store side
     if constexpr (LIT) {
       HX_UNROLL
@@ -556,6 +581,7 @@ HX_DEV void wave_inverse_accumulate(cplx (&o)[16], uint64_t (&acc_re)[16], uint6
     const cplx *px = c.buf + base_mx(c);  // transposition M3 -> MX, load side
     load_pairs<2>([&](int r) { o[r] = px[mx_off(r)]; });
     HX_WAVE_SYNC();
+    after_load();
     if constexpr (RES < 2) {
       if (l15 & 8) w16 = times_mi(w16);
     }
@@ -957,13 +983,17 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
   // Chunks 0 and 1 of the key were requested by the caller at the top of the iteration (ka*, kb*);
   // chunk c + 2 is requested into the registers chunk c has just released.  With FUSE_PASS1 the
   // first inverse pass (which only mixes the 4 points of one chunk) runs right behind each chunk.
-  auto mac = [&](cplx (&dst)[16], cplx (&d)[16], cplx (&ka0)[4], cplx (&ka1)[4], cplx (&kb0)[4], cplx (&kb1)[4],
-                 const cplx *b0, const cplx *b1, uint32_t idx, uint32_t epoch, auto fuse_pass1) {
+  // publish: my transform's "ready" flag is set here (false: the caller set it earlier).  wait_done (a type): the wait for
+  // the partner's "done with your buffer" closes the multiply-accumulate; std::false_type: the caller waits itself, right in
+  // front of its next store to the buffer (wave_inverse_accumulate's before_store), with the butterflies in between as slack
+  auto mac_impl = [&](cplx (&dst)[16], cplx (&d)[16], cplx (&ka0)[4], cplx (&ka1)[4], cplx (&kb0)[4], cplx (&kb1)[4],
+                      const cplx *b0, const cplx *b1, uint32_t idx, uint32_t epoch, auto fuse_pass1, bool publish,
+                      auto wait_done) {
     WaveCtx ctx = ctx0;
     HX_OPAQUE(ctx.lane);
     const int lane = ctx.lane;
     // wave_forward left my transform in my buffer (mapping M3)
-    if (lane == 0) flag_set(f_ready_me, epoch);
+    if (publish && lane == 0) flag_set(f_ready_me, epoch);
     constexpr int early = (LEVEL_CT == 1 && !MULTIBIT && LIMBS == 0) ? WAVE_EARLY_CHUNKS : 0;  // otherwise requested here
     if (early < 1) key_request(ka0, ka1, b0, b1, 0);
     if (early < 2) key_request(kb0, kb1, b0, b1, 1);
@@ -1031,7 +1061,11 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
     }
     HX_WAVE_SYNC();
     if (lane == 0) flag_set(r_done_me, epoch);
-    flag_wait(r_done_ot, epoch);  // the partner must be done with my buffer before I reuse it
+    if constexpr (decltype(wait_done)::value) flag_wait(r_done_ot, epoch);  // the partner must be done with my buffer before I reuse it
+  };
+  auto mac = [&](cplx (&dst)[16], cplx (&d)[16], cplx (&ka0)[4], cplx (&ka1)[4], cplx (&kb0)[4], cplx (&kb1)[4],
+                 const cplx *b0, const cplx *b1, uint32_t idx, uint32_t epoch, auto fuse_pass1) {
+    mac_impl(dst, d, ka0, ka1, kb0, kb1, b0, b1, idx, epoch, fuse_pass1, true, std::true_type{});
   };
 
   if constexpr (MULTIBIT) {
@@ -1756,8 +1790,37 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
         key_rows(i, limb, b0, b1);
 #endif
         HX_PRIO(WAVE_PRIO_C);
-        mac(o, o, ka0, ka1, kb0, kb1, b0, b1, 0, (it - 1) * (uint32_t)LIMBS + limb + 1,
-            std::integral_constant<bool, WAVE_FUSE_PASS1 != 0>{});
+        const uint32_t epoch = (it - 1) * (uint32_t)LIMBS + limb + 1;
+#if WAVE_SPLIT_EARLY_RESTORE
+        // Eight handshakes per CMUX (two per limb) instead of the classic loop's two: none of them is waited for where it is
+        // posted.  "Ready" of limbs 1 .. 3 is posted by the previous limb's inverse transform as soon as its transposition
+        // has left the buffer (F goes back there at once, after_load), "done" is waited for in front of the inverse
+        // transposition's first store (before_store), two butterfly stages after the products.
+        mac_impl(o, o, ka0, ka1, kb0, kb1, b0, b1, 0, epoch, std::integral_constant<bool, WAVE_FUSE_PASS1 != 0>{}, limb == 0,
+                 std::false_type{});
+        if constexpr (LAST) acc_load();
+        HX_PRIO(WAVE_PRIO_D);
+        auto before_store = [&]() { flag_wait(r_done_ot, epoch); };
+        auto after_load = [&]() {
+          if constexpr (!LAST) {  // my buffer held the inverse transposition: the pair needs F again
+            WaveCtx cx = ctx0;
+            HX_OPAQUE(cx.lane);
+            cplx *p3 = buf + base_m3(cx);
+            HX_UNROLL
+            for (int r = 0; r < 16; ++r) p3[r] = d[r];
+            HX_WAVE_SYNC();
+            if (cx.lane == 0) flag_set(f_ready_me, epoch + 1);
+          }
+        };
+        wave_inverse_accumulate<(WAVE_FUSE_PASS1 != 0) ? 1 : 0, false, false, true, WAVE_SPLIT_RES_INV, WAVE_LIT_LIMBS != 0>(
+            o, acc_re, acc_im, ctx, &res_sp, before_store, after_load);
+        HX_UNROLL
+        for (int r = 0; r < 16; ++r) {
+          fold(R_re[r], o[r].re);
+          fold(R_im[r], o[r].im);
+        }
+#else
+        mac(o, o, ka0, ka1, kb0, kb1, b0, b1, 0, epoch, std::integral_constant<bool, WAVE_FUSE_PASS1 != 0>{});
         if constexpr (LAST) acc_load();
         HX_PRIO(WAVE_PRIO_D);
         wave_inverse_accumulate<(WAVE_FUSE_PASS1 != 0) ? 1 : 0, false, false, true, WAVE_SPLIT_RES_INV, WAVE_LIT_LIMBS != 0>(o, acc_re, acc_im, ctx, &res_sp);
@@ -1774,6 +1837,7 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
           for (int r = 0; r < 16; ++r) p3[r] = d[r];
           HX_WAVE_SYNC();
         }
+#endif
       };
       HX_NO_UNROLL  // one body: unrolled, the scheduler overlaps the limbs and spills hundreds of registers
       for (uint32_t limb = 0; limb + 1 < (uint32_t)LIMBS; ++limb) limb_step(limb, std::false_type{});  // limb 0 = most significant
@@ -1826,6 +1890,15 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
       mask_next = lwe[i + 1];
       // the same word in every lane: as a scalar, the rotation's bounds and signs cost no vector work
       const uint32_t a_hat = HX_UNIFORM((uint32_t)modulus_switch(mask_cur, LOG2N2));
+#if WAVE_CLASSIC_SYNC && !defined(TFHE_HIPEMU)
+      // the workgroup's LWEs back in step every so many mask elements (speed only, as in the split-key engine), the
+      // waves of the upper half of the workgroup de-phased again behind it (WAVE_STAGGER)
+      if (i % (uint32_t)WAVE_CLASSIC_SYNC == 0 && i != 0) {
+        __builtin_amdgcn_s_barrier();
+        if (WAVE_STAGGER && wave >= 4)
+          for (int u = 0; u < WAVE_STAGGER; ++u) __builtin_amdgcn_s_sleep(64);
+      }
+#endif
       if (a_hat == 0) continue;  // uniform over the pair (bootstrap.rs:334)
       ++it;
       if constexpr (LEVEL_CT == 1) {
@@ -1841,9 +1914,16 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
         wave_forward<WAVE_RESIDENT, WAVE_UNIFORM_LITERALS != 0>(d, ctx, &res_tw);
         HX_PRIO(WAVE_PRIO_C);
         // in place: d becomes the Fourier-domain output of polynomial w, first inverse pass applied
+#if WAVE_DEFER_DONE
+        mac_impl(d, d, ka0, ka1, kb0, kb1, b0, b1, 0, it, std::integral_constant<bool, WAVE_FUSE_PASS1 != 0>{}, true, std::false_type{});
+        HX_PRIO(WAVE_PRIO_D);
+        wave_inverse_accumulate<(WAVE_FUSE_PASS1 != 0) ? 1 : 0, false, NEGACC, false, WAVE_RESIDENT, WAVE_UNIFORM_LITERALS != 0>(
+            d, acc_re, acc_im, ctx, &res_tw, [&]() { flag_wait(r_done_ot, it); });
+#else
         mac(d, d, ka0, ka1, kb0, kb1, b0, b1, 0, it, std::integral_constant<bool, WAVE_FUSE_PASS1 != 0>{});
         HX_PRIO(WAVE_PRIO_D);
         wave_inverse_accumulate<(WAVE_FUSE_PASS1 != 0) ? 1 : 0, false, NEGACC, false, WAVE_RESIDENT, WAVE_UNIFORM_LITERALS != 0>(d, acc_re, acc_im, ctx, &res_tw);
+#endif
       } else {
         cplx o[16];
         for (uint32_t idx = 0; idx < level; ++idx) {
