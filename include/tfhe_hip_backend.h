@@ -260,6 +260,33 @@ void cuda_centered_modulus_switch_cooperative_64_async(
     void *stream, uint32_t gpu_index, void *lwe_out, const void *lwe_in,
     uint32_t lwe_dimension, uint32_t log_modulus, uint32_t block_dim_x,
     uint32_t block_dim_y);
+/* cuda/include/pbs/programmable_bootstrap.h:8-45: the transform of the path as launches of its own, what the reference's
+   backend tests drive (tests_and_benchmarks/tests/test_fft.cpp, test_forward_fft16x4x16.cpp, test_fft16x4x16.cpp;
+   gpu/algorithms/test/fft/mod.rs:268-294 + its golden spectrum; gpu/ffi.rs:1070-1085).  Polynomials "compressed":
+   complex[i] = (p[i], p[i + N/2]).  polynomial_mul: negacyclic product, input1 is overwritten with its spectrum (as in the
+   reference), sizes 256 .. 16384.  forward_fft_classic: spectrum in the native (tree) order; forward_fft16x4x16: in NATURAL
+   frequency order, natural f <-> tree index bitreverse((N/2 - f) mod N/2); backward_fft16x4x16: its inverse WITHOUT the 1/(N/2)
+   scaling.  The last four take polynomial_size 2048 only (abort otherwise, as the reference); is_supported: true. */
+void cuda_fourier_polynomial_mul_async(void *stream, uint32_t gpu_index,
+                                       void const *input1, void const *input2,
+                                       void *output, uint32_t polynomial_size,
+                                       uint32_t total_polynomials);
+void cuda_fourier_polynomial_mul_fft16x4x16_async(
+    void *stream, uint32_t gpu_index, void const *input1, void const *input2,
+    void *output, uint32_t polynomial_size, uint32_t total_polynomials);
+void cuda_forward_fft_classic_async(void *stream, uint32_t gpu_index,
+                                    void const *input, void *output,
+                                    uint32_t polynomial_size,
+                                    uint32_t total_polynomials);
+void cuda_forward_fft16x4x16_async(void *stream, uint32_t gpu_index,
+                                   void const *input, void *output,
+                                   uint32_t polynomial_size,
+                                   uint32_t total_polynomials);
+void cuda_backward_fft16x4x16_async(void *stream, uint32_t gpu_index,
+                                    void const *input, void *output,
+                                    uint32_t polynomial_size,
+                                    uint32_t total_polynomials);
+bool cuda_fft16x4x16_is_supported_async(uint32_t gpu_index);
 /* cuda/include/ciphertext.h:45-50 (tfhe/src/core_crypto/gpu/ffi.rs:914-936): the multi-bit switch as its own launch
  * (noise tests only; production fuses it into the keybundle).  `size` words of lwe_array_in are read as
  * size / grouping_factor groups, 2^grouping_factor degrees are written per group ([group][subset], subset 0 = 0).

@@ -889,6 +889,39 @@ void orc_fft_forward_torus(double *out, const uint64_t *poly, uint32_t N) {
   fft_forward_inplace(out, N);
 }
 
+/* The transform on plain f64 data, "compressed" polynomials (complex[i] = (p[i], p[i + N/2])): what the reference's backend
+   tests drive through cuda_forward_fft_classic_async / cuda_fourier_polynomial_mul_async
+   (backends/tfhe-cuda-backend/cuda/include/pbs/programmable_bootstrap.h:8-24; src/fft/bnsmfft.cuh:520-545, :695-768).
+   The spectrum comes out in the tree order of DESIGN.md's transform spec = the native order of the reference's NSMFFT_direct:
+   natural frequency f at index bitreverse((n - f) mod n) (tests/test_fourier_entry_points.py pins it on the reference's
+   golden spectrum). */
+void orc_fft_forward_f64(double *out, const double *in, uint32_t N) {
+  memcpy(out, in, sizeof(double) * N);
+  fft_forward_inplace(out, N);
+}
+/* negacyclic product of two compressed polynomials: pointwise product of the spectra, backward transform, untwist (1/n in
+   the untwist table) — batch_polynomial_mul's data flow */
+void orc_fft_polynomial_mul_f64(double *out, const double *a, const double *b, uint32_t N) {
+  const fft_plan *pl = fft_get_plan(N);
+  uint32_t n = N / 2;
+  double *fa = (double *)malloc(sizeof(double) * N), *fb = (double *)malloc(sizeof(double) * N);
+  orc_fft_forward_f64(fa, a, N);
+  orc_fft_forward_f64(fb, b, N);
+  for (uint32_t j = 0; j < n; ++j) {  /* fb * fa, the product order of the device's cmul_first(x, y) */
+    double xr = fb[2 * j], xi = fb[2 * j + 1], yr = fa[2 * j], yi = fa[2 * j + 1];
+    fb[2 * j] = fma(-xi, yi, xr * yr);
+    fb[2 * j + 1] = fma(xi, yr, xr * yi);
+  }
+  fft_inverse_inplace(fb, N);
+  for (uint32_t j = 0; j < n; ++j) {
+    double yr = fb[2 * j], yi = fb[2 * j + 1], ur = pl->untw[2 * j], ui = pl->untw[2 * j + 1];
+    out[2 * j] = fma(-yi, ui, yr * ur);
+    out[2 * j + 1] = fma(yi, ur, yr * ui);
+  }
+  free(fa);
+  free(fb);
+}
+
 /* fft/mod.rs:311-330 (convert_add_backward_torus) */
 void orc_fft_backward_add(uint64_t *poly, double *fourier, uint32_t N) {
   const fft_plan *pl = fft_get_plan(N);

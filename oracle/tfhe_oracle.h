@@ -130,6 +130,8 @@ void orc_fft_tables(uint32_t N, double *fwd /* 2*(N/2) */, double *inv /* 2*(N/2
 void orc_fft_forward_int(double *out /* 2*(N/2) */, const int64_t *digits, uint32_t N);
 void orc_fft_forward_torus(double *out, const uint64_t *poly, uint32_t N);
 void orc_fft_backward_add(uint64_t *poly, double *fourier /* clobbered */, uint32_t N);
+void orc_fft_forward_f64(double *out /* 2*(N/2) */, const double *in /* compressed polynomial */, uint32_t N);
+void orc_fft_polynomial_mul_f64(double *out, const double *a, const double *b, uint32_t N);
 int64_t orc_f64_to_i64_sat(double x);
 uint64_t orc_from_torus(double t);
 void orc_convert_bsk_fft(double *bsk_f, const uint64_t *bsk_std, uint32_t n, uint32_t k,

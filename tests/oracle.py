@@ -310,6 +310,21 @@ def fft_forward_torus(poly):
     return out
 
 
+def fft_forward_f64(compressed):
+    x = np.ascontiguousarray(compressed, dtype=np.float64)
+    out = np.zeros(len(x), dtype=np.float64)
+    lib().orc_fft_forward_f64(_p(out), _p(x), u32(len(x)))
+    return out
+
+
+def fft_polynomial_mul_f64(a, b):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    out = np.zeros(len(a), dtype=np.float64)
+    lib().orc_fft_polynomial_mul_f64(_p(out), _p(a), _p(b), u32(len(a)))
+    return out
+
+
 def fft_backward_add(poly, fourier):
     poly = _u64(poly).copy()
     f = np.ascontiguousarray(fourier, dtype=np.float64).copy()

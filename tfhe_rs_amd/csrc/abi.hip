@@ -1061,6 +1061,45 @@ float hip_event_elapsed_ms(void *start, void *stop) {
 }
 void hip_event_destroy(void *event) { HX_CHECK(hipEventDestroy((hipEvent_t)event)); }
 
+// ---- the transform's own entry points (cuda/include/pbs/programmable_bootstrap.h:8-45; csrc/fourier.hip)
+// cuda/src/pbs/bootstrapping_key.cu:175-355: sizes 256 .. 16384, any other falls through without a launch, as there
+void cuda_fourier_polynomial_mul_async(void *stream, uint32_t gpu_index, void const *input1, void const *input2, void *output,
+                                       uint32_t polynomial_size, uint32_t total_polynomials) {
+  set_device(gpu_index);
+  launch_fourier(S(stream), gpu_index, 3, const_cast<void *>(input1), input2, output, polynomial_size, total_polynomials);
+}
+// The reference restricts the next four to polynomial_size == 2048 (its throughput kernel's transform) and to sm_90; here they
+// run the same generic transform at 2048 on any gfx950 device — same restriction on the size, same messages.
+void cuda_fourier_polynomial_mul_fft16x4x16_async(void *stream, uint32_t gpu_index, void const *input1, void const *input2,
+                                                  void *output, uint32_t polynomial_size, uint32_t total_polynomials) {
+  set_device(gpu_index);
+  HX_PANIC_IF_FALSE(polynomial_size == 2048, "cuda_fourier_polynomial_mul_fft16x4x16_async only supports polynomial_size == 2048");
+  launch_fourier(S(stream), gpu_index, 3, const_cast<void *>(input1), input2, output, polynomial_size, total_polynomials);
+}
+void cuda_forward_fft_classic_async(void *stream, uint32_t gpu_index, void const *input, void *output, uint32_t polynomial_size,
+                                    uint32_t total_polynomials) {
+  set_device(gpu_index);
+  HX_PANIC_IF_FALSE(polynomial_size == 2048, "cuda_forward_fft_classic_async only supports polynomial_size == 2048");
+  launch_fourier(S(stream), gpu_index, 0, const_cast<void *>(input), nullptr, output, polynomial_size, total_polynomials);
+}
+void cuda_forward_fft16x4x16_async(void *stream, uint32_t gpu_index, void const *input, void *output, uint32_t polynomial_size,
+                                   uint32_t total_polynomials) {
+  set_device(gpu_index);
+  HX_PANIC_IF_FALSE(polynomial_size == 2048, "cuda_forward_fft16x4x16_async only supports polynomial_size == 2048");
+  launch_fourier(S(stream), gpu_index, 1, const_cast<void *>(input), nullptr, output, polynomial_size, total_polynomials);
+}
+void cuda_backward_fft16x4x16_async(void *stream, uint32_t gpu_index, void const *input, void *output, uint32_t polynomial_size,
+                                    uint32_t total_polynomials) {
+  set_device(gpu_index);
+  HX_PANIC_IF_FALSE(polynomial_size == 2048, "cuda_backward_fft16x4x16_async only supports polynomial_size == 2048");
+  launch_fourier(S(stream), gpu_index, 2, const_cast<void *>(input), nullptr, output, polynomial_size, total_polynomials);
+}
+// the reference answers "compute capability 9.x"; these entry points exist on every device this library runs on
+bool cuda_fft16x4x16_is_supported_async(uint32_t gpu_index) {
+  set_device(gpu_index);
+  return true;
+}
+
 void hip_test_arith_async(void *stream, uint32_t gpu_index, uint32_t op, void const *in, void *out, uint32_t count,
                           uint32_t p0, uint32_t p1) {
   set_device(gpu_index);

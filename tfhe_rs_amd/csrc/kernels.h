@@ -94,5 +94,8 @@ void launch_pbs_multi_bit_latency(hipStream_t st, uint32_t N, uint32_t glwe_dim,
 // unit-test kernels (device functions exposed for parity tests) — testhooks.hip
 void launch_test_arith(hipStream_t st, uint32_t op, const uint64_t *in, uint64_t *out, uint32_t count, uint32_t p0, uint32_t p1);
 void launch_test_transform(hipStream_t st, uint32_t op, uint32_t N, const void *in, void *out, uint32_t gpu_index);
+// fourier.hip: the transform as launches of its own (op: 0 forward, tree order; 1 forward, natural order; 2 backward from
+// natural order, unscaled; 3 negacyclic product, in1 is overwritten with its spectrum).  false: no transform of that size
+bool launch_fourier(hipStream_t st, uint32_t gpu_index, int op, void *in1, const void *in2, void *out, uint32_t N, uint32_t total);
 
 }  // namespace tfhe_hip

@@ -101,6 +101,12 @@ SIGNATURES = {
     "cuda_centered_modulus_switch_64_async": (None, [_v, _u32, _v, _v, _u32, _u32]),
     "cuda_centered_modulus_switch_cooperative_64_async": (None, [_v, _u32, _v, _v, _u32, _u32, _u32, _u32]),
     "cuda_modulus_switch_multi_bit_64_async": (None, [_v, _u32, _v, _v, _u32, _u32, _u32, _u32]),
+    "cuda_fourier_polynomial_mul_async": (None, [_v, _u32, _v, _v, _v, _u32, _u32]),
+    "cuda_fourier_polynomial_mul_fft16x4x16_async": (None, [_v, _u32, _v, _v, _v, _u32, _u32]),
+    "cuda_forward_fft_classic_async": (None, [_v, _u32, _v, _v, _u32, _u32]),
+    "cuda_forward_fft16x4x16_async": (None, [_v, _u32, _v, _v, _u32, _u32]),
+    "cuda_backward_fft16x4x16_async": (None, [_v, _u32, _v, _v, _u32, _u32]),
+    "cuda_fft16x4x16_is_supported_async": (C.c_bool, [_u32]),
     # extensions
     "hip_convert_lwe_programmable_bootstrap_key_ntt64_async": (None, [_v, _u32, _v, _v, _u32, _u32, _u32, _u32]),
     "hip_programmable_bootstrap_ntt64_async":
