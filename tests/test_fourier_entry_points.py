@@ -118,7 +118,10 @@ def test_regression_fft16x4x16_against_the_reference_golden_spectrum(kind):
     assert lib.cuda_fft16x4x16_is_supported_async(0) is True
     n, G = golden()
     x = reference_input(n)
-    out = run(lib, st, "cuda_forward_fft16x4x16_async", n, x)
+    d_input = gpu.CudaVec.from_cpu_async(x.view(np.uint64), st)     # run_fft16x4x16_forward (mod.rs:76-103) on the host mirror
+    d_output = gpu.CudaVec(n, st)
+    gpu.forward_fft16x4x16_async(st, d_input, d_output, n, 1)
+    out = d_output.copy_to_cpu(st).view(np.float64)
     F = out[0::2] + 1j * out[1::2]
     scale = np.max(np.abs(G))
     assert np.max(np.abs(F - G)) < 64 * np.finfo(np.float64).eps * scale, np.max(np.abs(F - G)) / scale

@@ -399,6 +399,13 @@ def cuda_centered_modulus_switch_cooperative(output_vec, input_vec, lwe_dimensio
                                                              block_dim[0], block_dim[1])
 
 
+def forward_fft16x4x16_async(streams, input_vec, output_vec, polynomial_size, total_polynomials):
+    """gpu/ffi.rs:1054-1085: compressed real polynomials (f64 bit patterns in the CudaVecs) -> spectra in natural frequency
+    order; polynomial_size 2048 only (the library aborts otherwise, as the reference)."""
+    _lib().cuda_forward_fft16x4x16_async(streams.ptr[0], streams.gpu_indexes[0], input_vec.ptr, output_vec.ptr,
+                                         polynomial_size, total_polynomials)
+
+
 def cuda_modulus_switch_multi_bit_ciphertext(streams, lwe_array_out, lwe_array_in, log_modulus, polynomial_size,
                                              grouping_factor):
     """gpu/ffi.rs:914-936: the multi-bit modulus switch as its own launch (the reference's noise tests); `lwe_array_in`

@@ -500,6 +500,14 @@ inline void cuda_modulus_switch_multi_bit_ciphertext(const CudaStreams &streams,
   streams.synchronize();
 }
 
+// gpu/ffi.rs:1054-1085 `forward_fft16x4x16_async`: `total_polynomials` compressed real polynomials (polynomial_size f64 each:
+// [re, im, ...] with complex[i] = (poly[i], poly[i + N/2])) -> their spectra in natural frequency order; 2048 only
+inline void forward_fft16x4x16_async(const CudaStreams &streams, const CudaVec<double> &input, CudaVec<double> &output,
+                                     uint32_t polynomial_size, uint32_t total_polynomials) {
+  cuda_forward_fft16x4x16_async(streams.ptr[0], streams.gpu_indexes[0].get(), input.as_c_ptr(0), output.as_mut_c_ptr(0),
+                                polynomial_size, total_polynomials);
+}
+
 // gpu/ffi.rs:503-618 `keyswitch_async` / `keyswitch_async_gemm`: u64 input ciphertexts; the key scalar selects the 64 -> 64
 // or the 64 -> 32 entry points (the KS32 atomic pattern: u32 key, u32 output ciphertexts)
 template <class KeyT>
