@@ -13,6 +13,8 @@
 //   glwe_encrypt_sample_extract_decrypt_custom_mod …/glwe_sample_extraction.rs:14-149
 //   compare_cpu_and_gpu_centered_modulus_switch    …/modulus_switch.rs:276-361 (with the four cooperative dimensions)
 //   compare_cpu_and_gpu_cooperative_centered_modulus_switch_{throughput_pbs,generic}_block   …/modulus_switch.rs:380-488
+//   cuda_fft_mult, forward_matches_classic_fft     backends/tfhe-cuda-backend/cuda/tests_and_benchmarks/tests/{test_fft,test_forward_fft16x4x16}.cpp
+//   test_regression_fft16x4x16                     …/test/fft/mod.rs:268-294 (golden spectrum)
 //   assert_gpu_determinism / should_check_determinism   …/test/mod.rs:34-84
 //   mismatched_dimensions_panic                    the `assert_eq!`s of gpu/algorithms/*.rs (own test: the reference has none)
 //
@@ -30,6 +32,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <numeric>
@@ -645,6 +648,132 @@ static void compare_cpu_and_gpu_cooperative_centered_modulus_switch_generic_bloc
   for (size_t lwe_dimension : COOPERATIVE_TEST_LWE_DIMENSIONS) check_cuda_cooperative_centered_modulus_switch(512, 1, lwe_dimension);
 }
 
+// ---- the transform's own entry points: the reference backend's C++ FFT tests and the Rust golden-spectrum regression
+// compressed polynomial of the reference's tests: complex[i] = (p[i], p[i + N/2]) as [re, im, re, im, ...]
+static std::vector<double> compress_poly(const std::vector<double> &p) {
+  const size_t n = p.size();
+  std::vector<double> c(n);
+  for (size_t i = 0; i < n / 2; ++i) c[2 * i] = p[i], c[2 * i + 1] = p[i + n / 2];
+  return c;
+}
+static std::vector<double> random_poly(orc_rng *r, size_t n) {  // fft_setup (setup_and_teardown.cpp:407-415): uniform in [-1, 1)
+  std::vector<double> p(n);
+  for (double &x : p) x = (double)(int64_t)orc_rng_next(r) * (1.0 / 9223372036854775808.0);
+  return p;
+}
+// tests_and_benchmarks/tests/test_fft.cpp:82-146 `cuda_fft_mult`: the product of two random polynomials through
+// cuda_fourier_polynomial_mul_async (output aliased onto input2, as there) against the schoolbook negacyclic product, 1e-9
+static void cuda_fft_mult() {
+  CudaStreams streams = CudaStreams::new_single_gpu(GpuIndex(0));
+  orc_rng r;
+  orc_rng_seed(&r, 97);
+  struct P { size_t polynomial_size; int samples; };
+  const std::vector<P> params = g_toy ? std::vector<P>{{256, 3}, {1024, 2}, {2048, 2}}
+                                      : std::vector<P>{{256, 100}, {512, 100}, {1024, 100}, {2048, 100}, {4096, 100}, {8192, 50}, {16384, 10}};
+  for (const P &pr : params) {
+    const size_t N = pr.polynomial_size;
+    std::vector<std::vector<double>> poly1, poly2;
+    std::vector<double> h_cpoly1, h_cpoly2;
+    for (int s = 0; s < pr.samples; ++s) {
+      poly1.push_back(random_poly(&r, N));
+      poly2.push_back(random_poly(&r, N));
+      const auto c1 = compress_poly(poly1.back()), c2 = compress_poly(poly2.back());
+      h_cpoly1.insert(h_cpoly1.end(), c1.begin(), c1.end());
+      h_cpoly2.insert(h_cpoly2.end(), c2.begin(), c2.end());
+    }
+    auto d_cpoly1 = CudaVec<double>::from_cpu_async(h_cpoly1, streams, 0);
+    auto d_cpoly2 = CudaVec<double>::from_cpu_async(h_cpoly2, streams, 0);
+    cuda_fourier_polynomial_mul_async(streams.ptr[0], 0, d_cpoly1.as_mut_c_ptr(0), d_cpoly2.as_c_ptr(0), d_cpoly2.as_mut_c_ptr(0),
+                                      (uint32_t)N, (uint32_t)pr.samples);
+    const std::vector<double> res = d_cpoly2.to_cpu(streams);
+    const int checked = N > 4096 ? 2 : pr.samples;  // the schoolbook product is quadratic
+    for (int s = 0; s < checked; ++s) {
+      std::vector<double> expected(2 * N, 0.0);
+      for (size_t i = 0; i < N; ++i)
+        for (size_t j = 0; j < N; ++j) expected[i + j] += poly1[s][i] * poly2[s][j];
+      for (size_t i = 0; i < N; ++i) {
+        const double want = expected[i] - expected[i + N];
+        const double got = i < N / 2 ? res[(size_t)s * N + 2 * i] : res[(size_t)s * N + 2 * (i - N / 2) + 1];
+        CHECK(std::fabs(got - want) < 1e-9);
+      }
+    }
+  }
+}
+static size_t bitreverse_10(size_t x) {
+  size_t r = 0;
+  for (int i = 0; i < 10; i++) r = (r << 1) | ((x >> i) & 1u);
+  return r;
+}
+// tests_and_benchmarks/tests/test_forward_fft16x4x16.cpp:118-152: natural order against the classic transform's native order
+// through classic_index(f) = bitreverse_10((1024 - f) mod 1024), tolerance 2^-20
+static void forward_matches_classic_fft() {
+  CudaStreams streams = CudaStreams::new_single_gpu(GpuIndex(0));
+  CHECK(cuda_fft16x4x16_is_supported_async(0));
+  orc_rng r;
+  orc_rng_seed(&r, 98);
+  const size_t polynomial_size = 2048, half = 1024;
+  const int samples = g_toy ? 3 : 100;
+  std::vector<double> h_in;
+  for (int s = 0; s < samples; ++s) {
+    const auto c = compress_poly(random_poly(&r, polynomial_size));
+    h_in.insert(h_in.end(), c.begin(), c.end());
+  }
+  const auto d_in = CudaVec<double>::from_cpu_async(h_in, streams, 0);
+  CudaVec<double> d_out_fft16(polynomial_size * samples, streams, 0), d_out_classic(polynomial_size * samples, streams, 0);
+  forward_fft16x4x16_async(streams, d_in, d_out_fft16, (uint32_t)polynomial_size, (uint32_t)samples);
+  cuda_forward_fft_classic_async(streams.ptr[0], 0, d_in.as_c_ptr(0), d_out_classic.as_mut_c_ptr(0), (uint32_t)polynomial_size, (uint32_t)samples);
+  const std::vector<double> h_fft16 = d_out_fft16.to_cpu(streams), h_classic = d_out_classic.to_cpu(streams);
+  const double tol = std::pow(2.0, -20);
+  for (int p = 0; p < samples; ++p)
+    for (size_t f = 0; f < half; ++f) {
+      const size_t c = bitreverse_10((half - f) % half);
+      CHECK(std::fabs(h_fft16[((size_t)p * half + f) * 2] - h_classic[((size_t)p * half + c) * 2]) <= tol);
+      CHECK(std::fabs(h_fft16[((size_t)p * half + f) * 2 + 1] - h_classic[((size_t)p * half + c) * 2 + 1]) <= tol);
+    }
+}
+// gpu/algorithms/test/fft/mod.rs:268-294 `test_regression_fft16x4x16` on the golden spectrum of
+// fft_data/fft16x4x16_golden_v1.rs (tests/golden/fft16x4x16_golden_v1.json; path in TFHE_FFT_GOLDEN).  The reference asserts
+// the bits of its own kernel on an H100; another operation order has no bits in common to assert: values within 64 ulp of the
+// spectrum's scale (measured: 0.3).
+static void test_regression_fft16x4x16() {
+  const char *path = std::getenv("TFHE_FFT_GOLDEN");
+  CHECK(path != nullptr);
+  std::FILE *fp = std::fopen(path, "r");
+  CHECK(fp != nullptr);
+  std::string text;
+  char buf[4096];
+  size_t got;
+  while ((got = std::fread(buf, 1, sizeof buf, fp)) > 0) text.append(buf, got);
+  std::fclose(fp);
+  std::vector<u64> words;
+  for (size_t pos = text.find("\"0x"); pos != std::string::npos; pos = text.find("\"0x", pos + 1))
+    words.push_back(std::strtoull(text.c_str() + pos + 1, nullptr, 16));
+  const size_t n = 2048, half = 1024;
+  CHECK(words.size() == 2 * half);
+  std::vector<double> input(n);  // fft16x4x16_reference_input (mod.rs:51-71)
+  auto poly_coeff = [](u64 k) {
+    u64 bits = k * 0x517cc1b727220a95ull;
+    bits = (bits << 17) | (bits >> 47);
+    bits ^= 0xdeadbeefcafebabeull;
+    return (double)(int64_t)bits / (double)INT64_MAX;
+  };
+  for (size_t i = 0; i < half; ++i) input[2 * i] = poly_coeff(i), input[2 * i + 1] = poly_coeff(i + half);
+  CudaStreams stream = CudaStreams::new_single_gpu(GpuIndex(0));
+  const auto d_input = CudaVec<double>::from_cpu_async(input, stream, 0);
+  CudaVec<double> d_output(n, stream, 0);
+  forward_fft16x4x16_async(stream, d_input, d_output, (uint32_t)n, 1);
+  const std::vector<double> output = d_output.to_cpu(stream);
+  double scale = 0, worst = 0;
+  for (size_t i = 0; i < half; ++i) {
+    double re, im;
+    std::memcpy(&re, &words[i], 8);
+    std::memcpy(&im, &words[half + i], 8);
+    scale = std::max(scale, std::hypot(re, im));
+    worst = std::max(worst, std::hypot(output[2 * i] - re, output[2 * i + 1] - im));
+  }
+  CHECK(worst < 64 * 2.220446049250313e-16 * scale);
+}
+
 // the `assert_eq!`s in front of every launch (gpu/algorithms/*.rs): mismatched operands panic before anything is enqueued
 static void mismatched_dimensions_panic() {
   const CiphertextModulus m = CiphertextModulus::new_native();
@@ -738,6 +867,9 @@ int main(int argc, char **argv) {
                    compare_cpu_and_gpu_cooperative_centered_modulus_switch_throughput_pbs_block});
   tests.push_back({"compare_cpu_and_gpu_cooperative_centered_modulus_switch_generic_block",
                    compare_cpu_and_gpu_cooperative_centered_modulus_switch_generic_block});
+  tests.push_back({"cuda_fft_mult", cuda_fft_mult});
+  tests.push_back({"forward_matches_classic_fft", forward_matches_classic_fft});
+  tests.push_back({"test_regression_fft16x4x16", test_regression_fft16x4x16});
   tests.push_back({"mismatched_dimensions_panic", mismatched_dimensions_panic});
 
   size_t ran = 0, failed = 0;

@@ -26,8 +26,8 @@ def build_tests(lib, exe, source="reference_gpu_tests.cpp"):
 
 
 def run(exe, *args, timeout, env=None):
-    r = subprocess.run([exe, *args], capture_output=True, text=True, timeout=timeout,
-                       env=dict(os.environ, **env) if env else None)
+    env = dict(env or {}, TFHE_FFT_GOLDEN=os.path.join(HERE, "golden", "fft16x4x16_golden_v1.json"))
+    r = subprocess.run([exe, *args], capture_output=True, text=True, timeout=timeout, env=dict(os.environ, **env))
     assert r.returncode == 0, r.stdout + r.stderr
     last = r.stdout.strip().splitlines()[-1]
     assert last.startswith("test result: ok."), r.stdout
@@ -43,20 +43,20 @@ def hip_exe(tmp_path_factory):
 def test_reference_gpu_tests_on_the_host_emulation(tmp_path):
     exe = build_tests(build_emu(), str(tmp_path / "reference_gpu_tests_emu"))
     out = run(exe, "toy", timeout=1500)
-    assert out.count(" ... ok") == 20, out
+    assert out.count(" ... ok") == 23, out
 
 
 @pytest.mark.gpu
 def test_reference_gpu_tests_with_the_reference_parameter_sets(hip_exe):
     out = run(hip_exe, "reference", timeout=1500)
     # 4 classic + 3 multi-bit bootstraps + 2 multi-bit keyswitches + 2 noise-test flows (multi-bit switch -> blind rotation)
-    # + KS32 keyswitch + 2 closest-representable + modulus switch + 2 cooperative modulus switches + panics
-    assert out.count(" ... ok") == 18, out
+    # + KS32 keyswitch + 2 closest-representable + modulus switch + 2 cooperative modulus switches + 3 transform tests + panics
+    assert out.count(" ... ok") == 21, out
     print(out)
 
 
 @pytest.mark.gpu
 def test_reference_gpu_tests_small_sets_on_the_gpu(hip_exe):
     out = run(hip_exe, "toy", timeout=600)
-    assert out.count(" ... ok") == 20, out
+    assert out.count(" ... ok") == 23, out
 
