@@ -154,6 +154,13 @@ HX_DEV uint64_t f64_bits(double x) {
   __builtin_memcpy(&u, &x, 8);
   return u;
 }
+// x with the bits of `hi_mask` flipped in its high dword (bit 31: the sign) — one 32-bit xor
+HX_DEV double f64_xor_hi(double x, uint32_t hi_mask) {
+  const uint64_t u = f64_bits(x) ^ ((uint64_t)hi_mask << 32);
+  double r;
+  __builtin_memcpy(&r, &u, 8);
+  return r;
+}
 HX_DEV uint64_t from_torus(double t) {
   const double MAGIC = 6755399441055744.0;               // 1.5 * 2^52
   const double MAGIC_H = 6755399441055744.0 + 3167223808.0;  // + (2^32 - 0x43380000)

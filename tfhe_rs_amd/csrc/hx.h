@@ -199,6 +199,21 @@ __device__ __forceinline__ void hx_permlane16_swap(uint32_t &a, uint32_t &b) {
 }
 #endif
 
+// ---- one lane's 32-bit value as a wave-uniform scalar (v_readlane_b32 with a literal lane: one instruction)
+#if defined(TFHE_HIPEMU)
+static inline uint32_t hx_readlane(uint32_t v, int src_lane) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t *x = (uint32_t *)hipemu::g_wave_xchg[wave];
+  x[lane] = v;
+  hipemu::yield_barrier(2);
+  const uint32_t r = x[src_lane];
+  hipemu::yield_barrier(2);
+  return r;
+}
+#else
+__device__ __forceinline__ uint32_t hx_readlane(uint32_t v, int src_lane) { return __builtin_amdgcn_readlane(v, src_lane); }
+#endif
+
 // ---- int8 matrix core: D(32x32, i32) = A(32x32, i8) * B(32x32, i8) + C, one instruction per wave.
 // Lane l supplies 16 bytes of row (l & 31) of A and of column (l & 31) of B, both for the same 16 values of
 // k (the half selected by l >> 5); it receives D[row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)][col = l & 31]

@@ -108,6 +108,11 @@
 #ifndef WAVE_MB_OCTET
 #define WAVE_MB_OCTET 1  // one-level sets, four LWEs per workgroup: the eight waves share every key load
 #endif
+#ifndef WAVE_MB_OCTET_K_FIRST
+// OCTET: 1 = the keybundle (which depends on the mask and the key only) is combined BEFORE the barrier that publishes the
+// eight transforms, so the waves meet once per group (barrier, products, barrier) and run free in between
+#define WAVE_MB_OCTET_K_FIRST 0
+#endif
 #ifndef WAVE_MB_PREFETCH
 #define WAVE_MB_PREFETCH 1  // multi-bit (pair and quad modes): a load per wave and group touches the next group's key lines
 #endif
@@ -1116,14 +1121,10 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
       lwe_q0 = a.lwe_in + (size_t)a.in_idx[s0 < last ? s0 : last] * (a.n + 1);
       lwe_q1 = a.lwe_in + (size_t)a.in_idx[s0 + 1 < last ? s0 + 1 : last] * (a.n + 1);
     }
-    const uint64_t *lwe4[OCTET ? 4 : 1];  // OCTET: the four LWEs of the workgroup
+    const uint64_t *lwe_lane = lwe;  // OCTET: lane 16 L + s reads the mask of the workgroup's LWE L
     if constexpr (OCTET) {
-      const uint32_t s0 = blockIdx.x * 4u, last = a.num_samples - 1;
-      HX_UNROLL
-      for (uint32_t L = 0; L < 4; ++L)
-        lwe4[L] = a.lwe_in + (size_t)a.in_idx[s0 + L < last ? s0 + L : last] * (a.n + 1);
-    } else {
-      lwe4[0] = lwe;
+      const uint32_t sL = blockIdx.x * 4u + ((uint32_t)lane >> 4), last = a.num_samples - 1;
+      lwe_lane = a.lwe_in + (size_t)a.in_idx[sL < last ? sL : last] * (a.n + 1);
     }
     // SHARE synchronisation, all in the LDS flag words: word v = progress of wave v (quad_sync: each of the four
     // waves of a quad posts its count and waits for the other three), word 8 = mac_turn.  The multiply-accumulate
@@ -1289,50 +1290,53 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
         wave_forward<0, WAVE_LIT_MB != 0>(d, ctx);
         HX_PRIO(WAVE_PRIO_MB_C);
         if constexpr (OCTET) {
-          // All eight waves of the workgroup share every key load: wave (q, w) = (pair, column) combines, for ALL
-          // FOUR LWEs, the keybundle of column w at the quarter 4q .. 4q+3 of a lane's 16 points.  Subset-major:
-          // the four keybundle quarters (4 LWEs x 4 points x 2 rows) stay in registers across the 2^g subsets,
-          // and only the current subset's four monomial bases (and the next one's, in flight) are live.
+          // All eight waves of the workgroup share every key load: wave v combines, for ALL FOUR LWEs, the keybundle of
+          // BOTH columns at the points r = 2 v, 2 v + 1 of a lane's 16.  Subset-major: the keybundle (4 LWEs x 2 points x
+          // 2 columns x 2 rows) stays in registers across the 2^g subsets.  A monomial factor serves the four key elements
+          // of its point (both rows, both columns), and the factor of the odd point is the even point's up to the sign
+          // (-1)^deg (bitrev4(2 v + 1) = bitrev4(2 v) + 8: half a turn of the 16th root per unit of the degree) — 2^g - 1
+          // factors per LWE and group are computed, not 4 (2^g - 1) as with one column at four points per wave.  The
+          // products read and write the SAME slots of the eight buffers (points 2 v, 2 v + 1 belong to this wave alone), so
+          // nothing separates them: two workgroup barriers per group.
           WaveCtx cx = ctx0;
           HX_OPAQUE(cx.lane);
           const int ln = cx.lane;
           const uint32_t lane_off = (uint32_t)ln * 16u;
-          const uint32_t q4 = (uint32_t)pair;
-          const uint32_t brq = ((q4 & 1u) << 1) | (q4 >> 1);  // bitrev4(4 q + j) = 4 bitrev2(j) + bitrev2(q)
-          const uint32_t row0_off = (((idx * 2 + 0) * 2 + (uint32_t)w) * n) * 16u + q4 * 4096u;
-          const uint32_t row1_off = (((idx * 2 + 1) * 2 + (uint32_t)w) * n) * 16u + q4 * 4096u;
+          const uint32_t v8 = (uint32_t)wave;
+          const uint32_t brv = ((v8 & 1u) << 2) | (v8 & 2u) | (v8 >> 2);  // bitrev4(2 v) = bitrev3(v)
+          const uint32_t lvl_off = idx * 4u * (uint32_t)n * 16u + v8 * 2048u;
           constexpr int SETS = WAVE_MB_OCTET_SETS, RW = 4, STEPS = RW * (int)per;
-          uint64_t m4[4][g];
-          HX_UNROLL
-          for (int L = 0; L < 4; ++L) {
-            HX_UNROLL
-            for (uint32_t qq = 0; qq < g; ++qq) m4[L][qq] = lwe4[L][(size_t)grp * g + qq];
-          }
-          auto degree_of = [&](int L, uint32_t sidx) {
+          // monomial degrees: lane 16 L + s holds the degree of subset s of LWE L (one vector computation per group, a
+          // v_readlane per use, instead of 4 g mask words in scalar registers and a scalar adder chain per use)
+          uint32_t dv;
+          {
+            const uint64_t *lw = lwe_lane + (size_t)grp * g;
             uint64_t sum = 0;
             HX_UNROLL
-            for (uint32_t qq = 0; qq < g; ++qq)
-              if ((sidx >> (g - 1 - qq)) & 1) sum += m4[L][qq];
-            return HX_UNIFORM((uint32_t)modulus_switch(sum, LOG2N2));
-          };
+            for (uint32_t qq = 0; qq < g; ++qq) {
+              const uint64_t mq = lw[qq];
+              if (((uint32_t)ln >> (g - 1 - qq)) & 1u) sum += mq;
+            }
+            dv = (uint32_t)modulus_switch(sum, LOG2N2);
+          }
           cplx x0[SETS], x1[SETS];
-          auto request = [&](int set, int t) {
+          auto request = [&](int set, int t) {  // step t = (subset, point, column): rows 0 and 1
             const uint32_t sidx = (uint32_t)(t / RW);
-            const int j = t % RW;
-            uint32_t o0 = row0_off, o1 = row1_off;
+            const uint32_t pc = (uint32_t)(t % RW);  // 2 p + c
+            uint32_t o0 = lvl_off;
 #if WAVE_MB_ROOT_JIT
             HX_OPAQUE_S(o0);  // the scalar offset of a request is one addition: made here, not 2 x 4 x 2^g of them ahead of the
-            HX_OPAQUE_S(o1);  // level and carried through vector-register lanes
-#endif
-            x0[set] = ldk(gk, lane_off, sidx * ggsw_bytes + o0 + (uint32_t)j * 1024u);
-            x1[set] = ldk(gk, lane_off, sidx * ggsw_bytes + o1 + (uint32_t)j * 1024u);
+#endif                // level and carried through vector-register lanes
+            const uint32_t rc = (pc & 1u) * (uint32_t)n * 16u + (pc >> 1) * 1024u;
+            x0[set] = ldk(gk, lane_off, sidx * ggsw_bytes + o0 + rc);
+            x1[set] = ldk(gk, lane_off, sidx * ggsw_bytes + o0 + rc + 2u * (uint32_t)n * 16u);
           };
           uint32_t dg[2][4];
           cplx bs[2][4];
           auto request_bases = [&](uint32_t sidx) {
             HX_UNROLL
             for (int L = 0; L < 4; ++L) {
-              dg[sidx & 1][L] = degree_of(L, sidx);
+              dg[sidx & 1][L] = hx_readlane(dv, L * 16 + (int)sidx);
               bs[sidx & 1][L] = ldc(mono_lane, lane16, dg[sidx & 1][L] * 1024u);
             }
           };
@@ -1340,13 +1344,26 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
           for (int t = 0; t < SETS && t < STEPS; ++t) request(t, t);
           request_bases(1);
           HX_SCHED_FENCE();
+#if !WAVE_MB_OCTET_K_FIRST
           HX_BLOCK_SYNC_LDS();  // all eight transforms are in the buffers (mapping M3: slot lane*17 + r)
           HX_SCHED_FENCE();
-          cplx kq[4][RW][2];
+#endif
+          cplx kq[4][RW][2];  // [LWE][2 p + c][row]
           HX_UNROLL
           for (int si = 0; si < (int)per; ++si) {
             if (si >= 1 && si + 1 < (int)per) request_bases((uint32_t)si + 1);
             HX_SCHED_FENCE();
+            cplx mf[4];
+            if (si >= 1) {
+              HX_UNROLL
+              for (int L = 0; L < 4; ++L) {
+                uint32_t dgl = dg[si & 1][L];
+#if WAVE_MB_ROOT_JIT && WAVE_MB_W16_SCALAR
+                HX_OPAQUE_S(dgl);
+#endif
+                mf[L] = cmul_first(bs[si & 1][L], w16_root((brv * dgl) & 15u));
+              }
+            }
             HX_UNROLL
             for (int j = 0; j < RW; ++j) {
               const int t = si * RW + j, set = t % SETS;
@@ -1357,17 +1374,18 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
                   kq[L][j][1] = x1[set];
                 }
               } else {
-                constexpr uint32_t br2[4] = {0, 2, 1, 3};
-                const uint32_t br = br2[j] * 4u + brq;
+                if (j == 2) {  // the odd point: the factor times (-1)^deg
+                  HX_UNROLL
+                  for (int L = 0; L < 4; ++L) {
+                    const uint32_t sgn = dg[si & 1][L] << 31;
+                    mf[L].re = f64_xor_hi(mf[L].re, sgn);
+                    mf[L].im = f64_xor_hi(mf[L].im, sgn);
+                  }
+                }
                 HX_UNROLL
                 for (int L = 0; L < 4; ++L) {
-                  uint32_t dgl = dg[si & 1][L];
-#if WAVE_MB_ROOT_JIT && WAVE_MB_W16_SCALAR
-                  HX_OPAQUE_S(dgl);
-#endif
-                  const cplx mf = cmul_first(bs[si & 1][L], w16_root((br * dgl) & 15u));
-                  kq[L][j][0] = cmul_add(x0[set], mf, kq[L][j][0]);
-                  kq[L][j][1] = cmul_add(x1[set], mf, kq[L][j][1]);
+                  kq[L][j][0] = cmul_add(x0[set], mf[L], kq[L][j][0]);
+                  kq[L][j][1] = cmul_add(x1[set], mf[L], kq[L][j][1]);
                   HX_OPAQUE(kq[L][j][0].re);
                   HX_OPAQUE(kq[L][j][0].im);
                   HX_OPAQUE(kq[L][j][1].re);
@@ -1379,30 +1397,30 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
               HX_SCHED_FENCE();
             }
           }
-          // products with the digit transforms of the four LWEs (rows = the two polynomials of an LWE's pair);
-          // fma(a, b, -0.0) is the rounded product a b with its sign of zero
-          const int fslot = base_m3(cx) + 4 * (int)q4;
+#if WAVE_MB_OCTET_K_FIRST
+          HX_SCHED_FENCE();
+          HX_BLOCK_SYNC_LDS();  // all eight transforms are in the buffers (mapping M3: slot lane*17 + r)
+          HX_SCHED_FENCE();
+#endif
+          // products with the digit transforms of the four LWEs (rows = the two polynomials of an LWE's pair), both
+          // columns, written back over the transforms they were made of; fma(a, b, -0.0) is the rounded product a b
+          // with its sign of zero
+          const int fslot = base_m3(cx) + 2 * (int)v8;
           HX_UNROLL
           for (int L = 0; L < 4; ++L) {
-            const cplx *f0 = (const cplx *)(smem + (size_t)(2 * L) * BUF_BYTES) + fslot;
-            const cplx *f1 = (const cplx *)(smem + (size_t)(2 * L + 1) * BUF_BYTES) + fslot;
+            cplx *f0 = (cplx *)(smem + (size_t)(2 * L) * BUF_BYTES) + fslot;      // row 0 in, column 0 out
+            cplx *f1 = (cplx *)(smem + (size_t)(2 * L + 1) * BUF_BYTES) + fslot;  // row 1 in, column 1 out
             HX_UNROLL
-            for (int j = 0; j < RW; ++j) {
-              const cplx xa0 = f0[j], xa1 = f1[j];
-              kq[L][j][0] = cmul_add(xa1, kq[L][j][1], cmul_add(xa0, kq[L][j][0], cplx{-0.0, -0.0}));
-              HX_OPAQUE(kq[L][j][0].re);
-              HX_OPAQUE(kq[L][j][0].im);
+            for (int pp = 0; pp < 2; ++pp) {
+              const cplx xa0 = f0[pp], xa1 = f1[pp];
+              const cplx c0 = cmul_add(xa1, kq[L][2 * pp][1], cmul_add(xa0, kq[L][2 * pp][0], cplx{-0.0, -0.0}));
+              const cplx c1 = cmul_add(xa1, kq[L][2 * pp + 1][1], cmul_add(xa0, kq[L][2 * pp + 1][0], cplx{-0.0, -0.0}));
+              f0[pp] = c0;
+              f1[pp] = c1;
             }
           }
           HX_SCHED_FENCE();
-          HX_BLOCK_SYNC_LDS();  // every wave is done with the transforms: the buffers take the results
-          HX_UNROLL
-          for (int L = 0; L < 4; ++L) {
-            cplx *dst = (cplx *)(smem + (size_t)(2 * L + w) * BUF_BYTES) + fslot;  // the wave that owns (LWE L, column w)
-            HX_UNROLL
-            for (int j = 0; j < RW; ++j) dst[j] = kq[L][j][0];
-          }
-          HX_BLOCK_SYNC_LDS();
+          HX_BLOCK_SYNC_LDS();  // every wave has put its two points into the buffers
           const cplx *mine = buf + base_m3(cx);
           HX_UNROLL
           for (int r = 0; r < 16; ++r) o[r] = mine[r];
