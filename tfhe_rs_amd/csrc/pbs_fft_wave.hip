@@ -1113,7 +1113,6 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
     }
 #endif
     // SHARE: the quad = waves 4q .. 4q+3 = (LWE 2q, column 0), (2q, 1), (2q+1, 0), (2q+1, 1)
-    const int quad_lwe = pair & 1;  // which LWE of its quad this wave owns = which half of a lane's 16 points it works on
     const uint64_t *lwe_q0 = lwe, *lwe_q1 = lwe;
     if constexpr (SHARE) {
       const uint32_t s0 = blockIdx.x * (blockDim.x >> 7) + (uint32_t)(pair & ~1);
@@ -1222,11 +1221,8 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
         degrees(lwe, deg);
       }
       constexpr int MB_BASES = WAVE_MB_BASES >= 0 ? WAVE_MB_BASES : (LEVEL_CT >= 2 ? 1 : 0);
-      cplx base[per], base_b[SHARE ? per : 1];  // (re)written per level unless MB_BASES == 0: not live across levels then
-      if constexpr (MB_BASES == 0 && !OCTET) {
-        bases(deg, base);
-        if constexpr (SHARE) bases(deg_b, base_b);
-      }
+      cplx base[SHARE ? 1 : per];  // pair mode; (re)written per level unless MB_BASES == 0: not live across levels then
+      if constexpr (MB_BASES == 0 && !OCTET && !SHARE) bases(deg, base);
       // the group's 2^g GGSWs as one buffer: uniform base in scalar registers, lane offset in one vector register
 #if WAVE_MB_PACE && !defined(TFHE_HIPEMU)
       auto pace_wait = [&]() {
@@ -1250,7 +1246,7 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
 #endif
       const HxBuffer gk = hx_make_buffer(key + (size_t)grp * per * ggsw_c, per * ggsw_bytes);
       cplx o[16];
-      cplx oq_a[SHARE ? 8 : 1], oq_b[SHARE ? 8 : 1];  // SHARE: my column at my 8 points, first / second LWE of the quad
+      cplx oq_a[SHARE ? 8 : 1], oq_b[SHARE ? 8 : 1];  // SHARE: [point 4 u + j][column] at index 2 j + column, first / second LWE of the quad
       if constexpr (SHARE) {
         HX_UNROLL
         for (int j = 0; j < 8; ++j) oq_a[j] = oq_b[j] = cplx{-0.0, -0.0};
@@ -1427,97 +1423,122 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
           HX_WAVE_SYNC();
         } else
         if constexpr (SHARE) {
+          // Wave u of the quad (u = 2 (LWE of the quad) + column of the polynomial it transforms) combines, for BOTH LWEs,
+          // the keybundle of BOTH columns at the points r = 4 u .. 4 u + 3 of a lane's 16, a PAIR of points at a time
+          // (bitrev4(4 u + j) = 4 bitrev2(j) + bitrev2(u): j and j + 1 are half a turn of the 16th root apart, so the odd
+          // point's monomial factor is the even point's times (-1)^deg).  A factor serves the four key elements of its
+          // point; (2^g - 1) x 2 factors per LWE and level are computed (8 x (2^g - 1) with one column at eight points).
+          // Only the bases of the subset at hand and of the next one are live (requested as the loop goes).
           WaveCtx cx = ctx0;
           HX_OPAQUE(cx.lane);
           const int ln = cx.lane;
           const uint32_t lane_off = (uint32_t)ln * 16u;
-          const uint32_t r0 = 8u * (uint32_t)quad_lwe;  // my points: r0 .. r0 + 7 of every lane, column w, both LWEs
-          const uint32_t row0_off = (((idx * 2 + 0) * 2 + (uint32_t)w) * n) * 16u + r0 * 1024u;
-          const uint32_t row1_off = (((idx * 2 + 1) * 2 + (uint32_t)w) * n) * 16u + r0 * 1024u;
+          const uint32_t u4 = (uint32_t)(wave & 3);
+          const uint32_t bru = ((u4 & 1u) << 1) | (u4 >> 1);  // bitrev2(u)
+          const uint32_t lvl_off = idx * 4u * (uint32_t)n * 16u + u4 * 4096u;
           const cplx *qbuf = (const cplx *)(smem + (size_t)(wave & ~3) * BUF_BYTES);
-          const int fslot = base_m3(cx) + (int)r0;
+          const int fslot = base_m3(cx) + 4 * (int)u4;
           const cplx *fa0 = qbuf + fslot, *fa1 = (const cplx *)((const char *)qbuf + BUF_BYTES) + fslot;
           const cplx *fb0 = (const cplx *)((const char *)qbuf + 2 * BUF_BYTES) + fslot;
           const cplx *fb1 = (const cplx *)((const char *)qbuf + 3 * BUF_BYTES) + fslot;
-          constexpr int SETS = WAVE_MB_SHARE_SETS > 0 ? WAVE_MB_SHARE_SETS : (LEVEL_CT == 1 ? 2 : 3), RW = 8, STEPS = RW * (int)per;
-          if constexpr (MB_BASES == 1) {
-            bases(deg, base);
-            bases(deg_b, base_b);
-          }
+          constexpr int SETS = WAVE_MB_SHARE_SETS > 0 ? WAVE_MB_SHARE_SETS : 3, STEPS = 8 * (int)per;
           cplx x0[SETS], x1[SETS];
-          auto request = [&](int set, int t) {
-            const uint32_t sidx = (uint32_t)(t % (int)per);
-            const int j = t / (int)per;
-            uint32_t o0 = row0_off, o1 = row1_off;
+          auto request = [&](int set, int t) {  // step t = (pair of points, subset, point of the pair, column): rows 0 and 1
+            const uint32_t sidx = (uint32_t)((t >> 2) % (int)per);
+            const uint32_t j = (uint32_t)((t >> 2) / (int)per) * 2u + (uint32_t)((t >> 1) & 1), c = (uint32_t)(t & 1);
+            uint32_t o0 = lvl_off;
 #if WAVE_MB_ROOT_JIT
             HX_OPAQUE_S(o0);
-            HX_OPAQUE_S(o1);
 #endif
-            x0[set] = ldk(gk, lane_off, sidx * ggsw_bytes + o0 + (uint32_t)j * 1024u);
-            x1[set] = ldk(gk, lane_off, sidx * ggsw_bytes + o1 + (uint32_t)j * 1024u);
+            const uint32_t rc = c * (uint32_t)n * 16u + j * 1024u;
+            x0[set] = ldk(gk, lane_off, sidx * ggsw_bytes + o0 + rc);
+            x1[set] = ldk(gk, lane_off, sidx * ggsw_bytes + o0 + rc + 2u * (uint32_t)n * 16u);
+          };
+          cplx bsa[2], bsb[2];
+          auto request_bases = [&](uint32_t sidx) {
+            bsa[sidx & 1] = ldc(mono_lane, lane16, deg[sidx] * 1024u);
+            bsb[sidx & 1] = ldc(mono_lane, lane16, deg_b[sidx] * 1024u);
           };
           HX_UNROLL
           for (int t = 0; t < SETS && t < STEPS; ++t) request(t, t);
+          if (per > 1) request_bases(1);
           HX_SCHED_FENCE();
-          if constexpr (MB_BASES == 2) {  // behind the first key requests (loads return in order, subset 0 needs no factor)
-            bases(deg, base);
-            bases(deg_b, base_b);
-            HX_SCHED_FENCE();
-          }
           // ---- all four transforms of the quad are in its buffers (mapping M3: slot lane*17 + r); the first key
           // requests are already on their way
           quad_sync();
           mac_enter(grp * level + idx);
           HX_SCHED_FENCE();
-          cplx ka0, ka1, kb0, kb1;
           HX_UNROLL
-          for (int j = 0; j < RW; ++j) {
+          for (int pr = 0; pr < 2; ++pr) {
+            cplx kk[2][2][2][2];  // [point of the pair][column][LWE of the quad][row]
             HX_UNROLL
             for (int si = 0; si < (int)per; ++si) {
-              const int t = j * (int)per + si, set = t % SETS;
-              if (si == 0) {  // subset 0 is not rotated: it initialises the accumulators of both LWEs
-                ka0 = x0[set];
-                ka1 = x1[set];
-                kb0 = x0[set];
-                kb1 = x1[set];
-              } else {
-                constexpr uint32_t br4[8] = {0, 8, 4, 12, 2, 10, 6, 14};  // bitrev4(8 h + j) = bitrev4(j) + h
-                const uint32_t br = br4[j] + (uint32_t)quad_lwe;
+              cplx mfa, mfb;
+              if (si >= 1) {
+                // the bases of the next subset that has any (the next pair starts over at subset 1)
+                const int nx = si + 1 < (int)per ? si + 1 : 1;
+                const cplx ba = bsa[si & 1], bb = bsb[si & 1];
                 uint32_t dga = deg[si], dgb = deg_b[si];
 #if WAVE_MB_ROOT_JIT && WAVE_MB_W16_SCALAR
                 HX_OPAQUE_S(dga);
                 HX_OPAQUE_S(dgb);
 #endif
-                const cplx mfa = cmul_first(base[si], w16_root((br * dga) & 15u));
-                const cplx mfb = cmul_first(base_b[si], w16_root((br * dgb) & 15u));
-                ka0 = cmul_add(x0[set], mfa, ka0);
-                ka1 = cmul_add(x1[set], mfa, ka1);
-                kb0 = cmul_add(x0[set], mfb, kb0);
-                kb1 = cmul_add(x1[set], mfb, kb1);
-                HX_OPAQUE(ka0.re);
-                HX_OPAQUE(ka0.im);
-                HX_OPAQUE(ka1.re);
-                HX_OPAQUE(ka1.im);
-                HX_OPAQUE(kb0.re);
-                HX_OPAQUE(kb0.im);
-                HX_OPAQUE(kb1.re);
-                HX_OPAQUE(kb1.im);
+                const uint32_t br = (uint32_t)pr * 4u + bru;
+                mfa = cmul_first(ba, w16_root((br * dga) & 15u));
+                mfb = cmul_first(bb, w16_root((br * dgb) & 15u));
+                if (per > 2 && (si + 1 < (int)per || pr == 0)) request_bases((uint32_t)nx);
               }
               HX_SCHED_FENCE();
-              if (t + SETS < STEPS) request(set, t + SETS);
-              HX_SCHED_FENCE();
+              HX_UNROLL
+              for (int pc = 0; pc < 4; ++pc) {
+                const int pj = pc >> 1, c = pc & 1;
+                const int t = ((pr * (int)per + si) << 2) + pc, set = t % SETS;
+                if (si == 0) {  // subset 0 is not rotated: it initialises the accumulators of both LWEs
+                  kk[pj][c][0][0] = kk[pj][c][1][0] = x0[set];
+                  kk[pj][c][0][1] = kk[pj][c][1][1] = x1[set];
+                } else {
+                  if (pc == 2) {  // the odd point: the factors times (-1)^deg
+                    const uint32_t sa = deg[si] << 31, sb = deg_b[si] << 31;
+                    mfa.re = f64_xor_hi(mfa.re, sa);
+                    mfa.im = f64_xor_hi(mfa.im, sa);
+                    mfb.re = f64_xor_hi(mfb.re, sb);
+                    mfb.im = f64_xor_hi(mfb.im, sb);
+                  }
+                  kk[pj][c][0][0] = cmul_add(x0[set], mfa, kk[pj][c][0][0]);
+                  kk[pj][c][0][1] = cmul_add(x1[set], mfa, kk[pj][c][0][1]);
+                  kk[pj][c][1][0] = cmul_add(x0[set], mfb, kk[pj][c][1][0]);
+                  kk[pj][c][1][1] = cmul_add(x1[set], mfb, kk[pj][c][1][1]);
+                  HX_UNROLL
+                  for (int q = 0; q < 4; ++q) {
+                    HX_OPAQUE(kk[pj][c][q >> 1][q & 1].re);
+                    HX_OPAQUE(kk[pj][c][q >> 1][q & 1].im);
+                  }
+                }
+                HX_SCHED_FENCE();
+                if (t + SETS < STEPS) request(set, t + SETS);
+                HX_SCHED_FENCE();
+              }
             }
-            const cplx xa0 = fa0[j], xa1 = fa1[j], xb0 = fb0[j], xb1 = fb1[j];
-            oq_a[j] = cmul_add(xa1, ka1, cmul_add(xa0, ka0, oq_a[j]));
-            oq_b[j] = cmul_add(xb1, kb1, cmul_add(xb0, kb0, oq_b[j]));
-            HX_OPAQUE(oq_a[j].re);
-            HX_OPAQUE(oq_a[j].im);
-            HX_OPAQUE(oq_b[j].re);
-            HX_OPAQUE(oq_b[j].im);
+            HX_UNROLL
+            for (int pj = 0; pj < 2; ++pj) {
+              const int j = pr * 2 + pj;
+              const cplx xa0 = fa0[j], xa1 = fa1[j], xb0 = fb0[j], xb1 = fb1[j];
+              HX_UNROLL
+              for (int c = 0; c < 2; ++c) {
+                oq_a[j * 2 + c] = cmul_add(xa1, kk[pj][c][0][1], cmul_add(xa0, kk[pj][c][0][0], oq_a[j * 2 + c]));
+                oq_b[j * 2 + c] = cmul_add(xb1, kk[pj][c][1][1], cmul_add(xb0, kk[pj][c][1][0], oq_b[j * 2 + c]));
+                HX_OPAQUE(oq_a[j * 2 + c].re);
+                HX_OPAQUE(oq_a[j * 2 + c].im);
+                HX_OPAQUE(oq_b[j * 2 + c].re);
+                HX_OPAQUE(oq_b[j * 2 + c].im);
+              }
+            }
             HX_SCHED_FENCE();
           }
-          quad_sync();  // every wave of the quad is done with the transforms of this level
-          mac_leave(grp * level + idx);
+          if (idx + 1 < level) {
+            quad_sync();  // every wave of the quad is done with the transforms of this level (the last level: see below)
+            mac_leave(grp * level + idx);
+          }
         } else
         {  // publish my transform, fetch the partner's, build the keybundle chunks and multiply-accumulate
           const uint32_t epoch = grp * level + idx + 1;
@@ -1617,32 +1638,30 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
         }
       }
       if constexpr (SHARE) {
-        // the half I computed for the quad's other LWE goes to the wave that owns that polynomial (same column),
-        // its half for my LWE comes back the same way (the buffers are free: barrier above)
-        cplx *pbuf = (cplx *)(smem + (size_t)(wave ^ 2) * BUF_BYTES) + base_m3(ctx0) + 8 * quad_lwe;
-        const cplx *mine = buf + base_m3(ctx0) + 8 * (quad_lwe ^ 1);
-        if (quad_lwe == 0) {
+        // my four points of the quad's four polynomials go to the waves that own them, over the transforms they were made
+        // of (slots 4 u .. 4 u + 3 of the quad's buffers are read and written by this wave alone: nothing to wait for);
+        // then the quad meets and every wave collects its polynomial
+        {
+          WaveCtx cx = ctx0;
+          HX_OPAQUE(cx.lane);
+          const int fslot = base_m3(cx) + 4 * (wave & 3);
+          char *qb = smem + (size_t)(wave & ~3) * BUF_BYTES;
           HX_UNROLL
-          for (int j = 0; j < 8; ++j) pbuf[j] = oq_b[j];
-        } else {
-          HX_UNROLL
-          for (int j = 0; j < 8; ++j) pbuf[j] = oq_a[j];
-        }
-        quad_sync();
-        if (quad_lwe == 0) {
-          HX_UNROLL
-          for (int j = 0; j < 8; ++j) {
-            o[j] = oq_a[j];
-            o[8 + j] = mine[j];
+          for (int c = 0; c < 2; ++c) {
+            cplx *da = (cplx *)(qb + (size_t)c * BUF_BYTES) + fslot, *db = (cplx *)(qb + (size_t)(2 + c) * BUF_BYTES) + fslot;
+            HX_UNROLL
+            for (int j = 0; j < 4; ++j) {
+              da[j] = oq_a[j * 2 + c];
+              db[j] = oq_b[j * 2 + c];
+            }
           }
-        } else {
+          quad_sync();
+          mac_leave(grp * level + (level - 1));
+          const cplx *mine = buf + base_m3(cx);
           HX_UNROLL
-          for (int j = 0; j < 8; ++j) {
-            o[j] = mine[j];
-            o[8 + j] = oq_b[j];
-          }
+          for (int r = 0; r < 16; ++r) o[r] = mine[r];
+          HX_WAVE_SYNC();
         }
-        HX_WAVE_SYNC();
       }
 #if WAVE_MB_PREFETCH
       if constexpr (!OCTET) {
