@@ -94,6 +94,15 @@
 #ifndef WAVE_MB_PACE
 #define WAVE_MB_PACE 1  // multi-bit: groups a wave pair may run ahead of the slowest pair of its XCD, plus 1 (0: no pacing)
 #endif
+#ifndef WAVE_MB_PACE_AT_KEY
+// multi-bit pacing: 1 = a wave waits for its XCD right in front of the group's first key request (digits and forward transform
+// do not touch the key: they run under the wait for the slower workgroups) and reports a group as soon as its last key
+// request is out; 0 = wait at the top of the group, report at its end (rounds 3-5)
+#define WAVE_MB_PACE_AT_KEY 1
+#endif
+#ifndef WAVE_MB_PACE_SLEEP
+#define WAVE_MB_PACE_SLEEP 2  // s_sleep argument between two polls of the XCD's counter (64 cycles each)
+#endif
 #ifndef WAVE_MB_PACE_SPINS
 #define WAVE_MB_PACE_SPINS 4096  // polls (with s_sleep) before a wave gives up pacing for the rest of the launch
 #endif
@@ -106,7 +115,7 @@
 #define WAVE_MB_SHARE_SETS 0
 #endif
 #ifndef WAVE_MB_OCTET
-#define WAVE_MB_OCTET 1  // one-level sets, four LWEs per workgroup: the eight waves share every key load
+#define WAVE_MB_OCTET 2  // four LWEs per workgroup: the eight waves share every key load (1: one-level sets only, 2: also the sets with a compile-time level count >= 2)
 #endif
 #ifndef WAVE_MB_OCTET_K_FIRST
 // OCTET: 1 = the keybundle (which depends on the mask and the key only) is combined BEFORE the barrier that publishes the
@@ -226,8 +235,15 @@
 #define WAVE_PROBE_TS 0
 #endif
 
+#ifndef WAVE_MB_PROBE
+// measurement builds only (tools/mb_phase_probe.py): every wave of the multi-bit loop sums the shader-clock cycles of its
+// phases (s_memtime at the phase boundaries: the waits for its own LDS / scalar traffic fall into the phase that issued
+// them) and writes the eight sums to the record buffer of hip_probe_wave_timestamps().  Never defined in the product library.
+#define WAVE_MB_PROBE 0
+#endif
+
 namespace tfhe_hip {
-#if WAVE_PROBE_TS
+#if WAVE_PROBE_TS || WAVE_MB_PROBE
 __device__ uint64_t *g_wave_ts = nullptr;
 static unsigned g_wave_force_per_block = 0;
 extern "C" void hip_probe_wave_timestamps(uint64_t *dev_records, uint32_t lwes_per_block) {
@@ -688,7 +704,7 @@ template <int LEVEL_CT, int BASE_LOG_CT, int GROUPING = 0, bool SHARE = false, i
 __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables tb) {
   constexpr bool MULTIBIT = GROUPING > 0;
   static_assert(!SHARE || MULTIBIT, "SHARE is a mode of the multi-bit loop");
-  static_assert(!OCTET || (MULTIBIT && !SHARE && LEVEL_CT == 1), "OCTET is a mode of the one-level multi-bit loop");
+  static_assert(!OCTET || (MULTIBIT && !SHARE && LEVEL_CT >= 1), "OCTET is a mode of the multi-bit loop with the level count fixed at compile time");
   static_assert(LIMBS == 0 || (!MULTIBIT && LEVEL_CT == 1 && BASE_LOG_CT != 0 && BASE_LOG_CT <= 23),
                 "split-key exact engine: one level, base_log <= 23 (the products must stay below 2^49)");
   HX_DYN_SMEM(smem);
@@ -1083,6 +1099,17 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
     // subset and group; the 16th roots sit in the LDS table (wave-uniform index: broadcast reads).
     constexpr uint32_t g = GROUPING, per = 1u << g;
     const uint32_t groups = a.n / g;
+#if WAVE_MB_PROBE
+    uint64_t mbp_t = __builtin_amdgcn_s_memtime(), mbp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define MBP(k)                                               \
+  do {                                                       \
+    const uint64_t t_ = __builtin_amdgcn_s_memtime();        \
+    mbp[k] += t_ - mbp_t;                                    \
+    mbp_t = t_;                                              \
+  } while (0)
+#else
+#define MBP(k) do { } while (0)
+#endif
     const cplx *key = (const cplx *)a.bsk;  // Fourier domain: [group][subset][level][row][col][slot]
     const size_t ggsw_c = (size_t)level * 4 * n;
     // tables.h mono_lane: entry [d][lane] = mono[((1 + 4 bitrev6(lane)) d) mod 2N] — a degree's 64 bases are one
@@ -1230,8 +1257,8 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
           const uint32_t need = pace_before * groups + pace_mine * (grp + 1u - (uint32_t)WAVE_MB_PACE);
           uint32_t spins = 0;
           while (__hip_atomic_load(pace_ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
-            __builtin_amdgcn_s_sleep(8);
-            if (++spins > (uint32_t)WAVE_MB_PACE_SPINS) {
+            __builtin_amdgcn_s_sleep(WAVE_MB_PACE_SLEEP);
+            if (++spins > (uint32_t)WAVE_MB_PACE_SPINS * 8u / (uint32_t)WAVE_MB_PACE_SLEEP) {
               pacing = false;
               break;
             }
@@ -1242,12 +1269,18 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
         if (a.pace != nullptr && valid && w == 0 && lane == 0)
           __hip_atomic_fetch_add(pace_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       };
+#if !WAVE_MB_PACE_AT_KEY
       pace_wait();
+      MBP(0);
+#endif
+#else
+      auto pace_wait = []() {};
+      auto pace_arrive = []() {};
 #endif
       const HxBuffer gk = hx_make_buffer(key + (size_t)grp * per * ggsw_c, per * ggsw_bytes);
       cplx o[16];
-      cplx oq_a[SHARE ? 8 : 1], oq_b[SHARE ? 8 : 1];  // SHARE: [point 4 u + j][column] at index 2 j + column, first / second LWE of the quad
-      if constexpr (SHARE) {
+      cplx oq_a[(SHARE || (OCTET && LEVEL_CT != 1)) ? 8 : 1], oq_b[(SHARE || (OCTET && LEVEL_CT != 1)) ? 8 : 1];  // SHARE: [point 4 u + j][column] at index 2 j + column, first / second LWE of the quad
+      if constexpr (SHARE || (OCTET && LEVEL_CT != 1)) {  // OCTET, several levels: [LWE][point][column] over the two arrays
         HX_UNROLL
         for (int j = 0; j < 8; ++j) oq_a[j] = oq_b[j] = cplx{-0.0, -0.0};
       }
@@ -1265,6 +1298,22 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
           st_im[r] = decomp_init_state32((uint32_t)(acc_im[r] >> 32), BASE_LOG_CT, LEVEL_CT);
         }
       }
+      // OCTET: lane 16 L + s holds the degree of subset s of LWE L (one vector computation per group, a v_readlane per
+      // use, instead of 4 g mask words in scalar registers and a scalar adder chain per use)
+      uint32_t dv = 0;
+      if constexpr (OCTET) {
+        int ln = ctx0.lane;
+        HX_OPAQUE(ln);
+        const uint64_t *lw = lwe_lane + (size_t)grp * g;
+        uint64_t sum = 0;
+        HX_UNROLL
+        for (uint32_t qq = 0; qq < g; ++qq) {
+          const uint64_t mq = lw[qq];
+          if (((uint32_t)ln >> (g - 1 - qq)) & 1u) sum += mq;
+        }
+        dv = (uint32_t)modulus_switch(sum, LOG2N2);
+      }
+      (void)dv;
       for (uint32_t idx = 0; idx < level; ++idx) {
         cplx d[16];
         HX_PRIO(WAVE_PRIO_MB_A);
@@ -1282,9 +1331,120 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
         } else {
           make_digits(d, 0, idx);
         }
+        MBP(1);
         HX_PRIO(WAVE_PRIO_MB_B);
         wave_forward<0, WAVE_LIT_MB != 0>(d, ctx);
+        MBP(2);
         HX_PRIO(WAVE_PRIO_MB_C);
+        if constexpr (OCTET && LEVEL_CT != 1) {
+          // Several levels, all eight waves sharing every key load: as the one-level form below (wave v: both columns at
+          // the points 2 v, 2 v + 1 for the four LWEs), but POINT-major — the products of the levels add up in registers
+          // (16 complex), so only one point's keybundle (4 LWEs x 2 columns x 2 rows) is live next to them; every factor
+          // is computed (no sign trick across the points: the other point's factors would have to be kept).
+          WaveCtx cx = ctx0;
+          HX_OPAQUE(cx.lane);
+          const int ln = cx.lane;
+          const uint32_t lane_off = (uint32_t)ln * 16u;
+          const uint32_t v8 = (uint32_t)wave;
+          const uint32_t brv = ((v8 & 1u) << 2) | (v8 & 2u) | (v8 >> 2);  // bitrev4(2 v) = bitrev3(v)
+          const uint32_t lvl_off = idx * 4u * (uint32_t)n * 16u + v8 * 2048u;
+          constexpr int SETS = WAVE_MB_OCTET_SETS, STEPS = 4 * (int)per;
+          cplx x0[SETS], x1[SETS];
+          auto request = [&](int set, int t) {  // step t = (point, subset, column): rows 0 and 1
+            const uint32_t sidx = (uint32_t)((t >> 1) % (int)per), pp = (uint32_t)((t >> 1) / (int)per), c = (uint32_t)(t & 1);
+            uint32_t o0 = lvl_off;
+#if WAVE_MB_ROOT_JIT
+            HX_OPAQUE_S(o0);
+#endif
+            const uint32_t rc = c * (uint32_t)n * 16u + pp * 1024u;
+            x0[set] = ldk(gk, lane_off, sidx * ggsw_bytes + o0 + rc);
+            x1[set] = ldk(gk, lane_off, sidx * ggsw_bytes + o0 + rc + 2u * (uint32_t)n * 16u);
+          };
+          uint32_t dg[1][4];
+          cplx bs[1][4];  // consumed into the factors before the next subset's are requested
+          auto request_bases = [&](uint32_t sidx) {
+            HX_UNROLL
+            for (int L = 0; L < 4; ++L) {
+              dg[0][L] = hx_readlane(dv, L * 16 + (int)sidx);
+              bs[0][L] = ldc(mono_lane, lane16, dg[0][L] * 1024u);
+            }
+          };
+#if WAVE_MB_PACE_AT_KEY
+          if (idx == 0) {
+            pace_wait();
+            MBP(0);
+          }
+#endif
+          HX_UNROLL
+          for (int t = 0; t < SETS && t < STEPS; ++t) request(t, t);
+          if (per > 1) request_bases(1);
+          HX_SCHED_FENCE();
+          HX_BLOCK_SYNC_LDS();  // all eight transforms of this level are in the buffers (mapping M3: slot lane*17 + r)
+          MBP(3);
+          HX_SCHED_FENCE();
+          const int fslot = base_m3(cx) + 2 * (int)v8;
+          HX_UNROLL
+          for (int pp = 0; pp < 2; ++pp) {
+            cplx kk[4][2][2];  // [LWE][column][row]
+            HX_UNROLL
+            for (int si = 0; si < (int)per; ++si) {
+              cplx mf[4];
+              if (si >= 1) {
+                const int nx = si + 1 < (int)per ? si + 1 : 1;
+                HX_UNROLL
+                for (int L = 0; L < 4; ++L) {
+                  uint32_t dgl = dg[0][L];
+#if WAVE_MB_ROOT_JIT && WAVE_MB_W16_SCALAR
+                  HX_OPAQUE_S(dgl);
+#endif
+                  mf[L] = cmul_first(bs[0][L], w16_root(((brv + 8u * (uint32_t)pp) * dgl) & 15u));
+                }
+                if (per > 2 && (si + 1 < (int)per || pp == 0)) request_bases((uint32_t)nx);
+              }
+              HX_SCHED_FENCE();
+              HX_UNROLL
+              for (int c = 0; c < 2; ++c) {
+                const int t = ((pp * (int)per + si) << 1) + c, set = t % SETS;
+                HX_UNROLL
+                for (int L = 0; L < 4; ++L) {
+                  if (si == 0) {  // subset 0 is not rotated: it initialises the accumulators of all four LWEs
+                    kk[L][c][0] = x0[set];
+                    kk[L][c][1] = x1[set];
+                  } else {
+                    kk[L][c][0] = cmul_add(x0[set], mf[L], kk[L][c][0]);
+                    kk[L][c][1] = cmul_add(x1[set], mf[L], kk[L][c][1]);
+                    HX_OPAQUE(kk[L][c][0].re);
+                    HX_OPAQUE(kk[L][c][0].im);
+                    HX_OPAQUE(kk[L][c][1].re);
+                    HX_OPAQUE(kk[L][c][1].im);
+                  }
+                }
+                HX_SCHED_FENCE();
+                if (t + SETS < STEPS) request(set, t + SETS);
+                HX_SCHED_FENCE();
+              }
+            }
+            // this point's products with the digit transforms of the four LWEs, added to the earlier levels'
+            HX_UNROLL
+            for (int L = 0; L < 4; ++L) {
+              const cplx xa0 = ((const cplx *)(smem + (size_t)(2 * L) * BUF_BYTES) + fslot)[pp];
+              const cplx xa1 = ((const cplx *)(smem + (size_t)(2 * L + 1) * BUF_BYTES) + fslot)[pp];
+              cplx(&oq)[8] = L < 2 ? oq_a : oq_b;
+              HX_UNROLL
+              for (int c = 0; c < 2; ++c) {
+                cplx &acc = oq[((L & 1) * 2 + pp) * 2 + c];
+                acc = cmul_add(xa1, kk[L][c][1], cmul_add(xa0, kk[L][c][0], acc));
+                HX_OPAQUE(acc.re);
+                HX_OPAQUE(acc.im);
+              }
+            }
+            HX_SCHED_FENCE();
+          }
+          // every wave is done with this level's transforms: the next level's may take the buffers (the last level: below)
+          MBP(4);
+          if (idx + 1 < level) HX_BLOCK_SYNC_LDS();
+          MBP(5);
+        } else
         if constexpr (OCTET) {
           // All eight waves of the workgroup share every key load: wave v combines, for ALL FOUR LWEs, the keybundle of
           // BOTH columns at the points r = 2 v, 2 v + 1 of a lane's 16.  Subset-major: the keybundle (4 LWEs x 2 points x
@@ -1302,19 +1462,6 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
           const uint32_t brv = ((v8 & 1u) << 2) | (v8 & 2u) | (v8 >> 2);  // bitrev4(2 v) = bitrev3(v)
           const uint32_t lvl_off = idx * 4u * (uint32_t)n * 16u + v8 * 2048u;
           constexpr int SETS = WAVE_MB_OCTET_SETS, RW = 4, STEPS = RW * (int)per;
-          // monomial degrees: lane 16 L + s holds the degree of subset s of LWE L (one vector computation per group, a
-          // v_readlane per use, instead of 4 g mask words in scalar registers and a scalar adder chain per use)
-          uint32_t dv;
-          {
-            const uint64_t *lw = lwe_lane + (size_t)grp * g;
-            uint64_t sum = 0;
-            HX_UNROLL
-            for (uint32_t qq = 0; qq < g; ++qq) {
-              const uint64_t mq = lw[qq];
-              if (((uint32_t)ln >> (g - 1 - qq)) & 1u) sum += mq;
-            }
-            dv = (uint32_t)modulus_switch(sum, LOG2N2);
-          }
           cplx x0[SETS], x1[SETS];
           auto request = [&](int set, int t) {  // step t = (subset, point, column): rows 0 and 1
             const uint32_t sidx = (uint32_t)(t / RW);
@@ -1336,12 +1483,19 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
               bs[sidx & 1][L] = ldc(mono_lane, lane16, dg[sidx & 1][L] * 1024u);
             }
           };
+#if WAVE_MB_PACE_AT_KEY
+          if (idx == 0) {
+            pace_wait();
+            MBP(0);
+          }
+#endif
           HX_UNROLL
           for (int t = 0; t < SETS && t < STEPS; ++t) request(t, t);
           request_bases(1);
           HX_SCHED_FENCE();
 #if !WAVE_MB_OCTET_K_FIRST
           HX_BLOCK_SYNC_LDS();  // all eight transforms are in the buffers (mapping M3: slot lane*17 + r)
+          MBP(3);
           HX_SCHED_FENCE();
 #endif
           cplx kq[4][RW][2];  // [LWE][2 p + c][row]
@@ -1396,6 +1550,7 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
 #if WAVE_MB_OCTET_K_FIRST
           HX_SCHED_FENCE();
           HX_BLOCK_SYNC_LDS();  // all eight transforms are in the buffers (mapping M3: slot lane*17 + r)
+          MBP(3);
           HX_SCHED_FENCE();
 #endif
           // products with the digit transforms of the four LWEs (rows = the two polynomials of an LWE's pair), both
@@ -1416,6 +1571,7 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
             }
           }
           HX_SCHED_FENCE();
+          MBP(4);
           HX_BLOCK_SYNC_LDS();  // every wave has put its two points into the buffers
           const cplx *mine = buf + base_m3(cx);
           HX_UNROLL
@@ -1459,6 +1615,12 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
             bsa[sidx & 1] = ldc(mono_lane, lane16, deg[sidx] * 1024u);
             bsb[sidx & 1] = ldc(mono_lane, lane16, deg_b[sidx] * 1024u);
           };
+#if WAVE_MB_PACE_AT_KEY
+          if (idx == 0) {
+            pace_wait();
+            MBP(0);
+          }
+#endif
           HX_UNROLL
           for (int t = 0; t < SETS && t < STEPS; ++t) request(t, t);
           if (per > 1) request_bases(1);
@@ -1466,6 +1628,7 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
           // ---- all four transforms of the quad are in its buffers (mapping M3: slot lane*17 + r); the first key
           // requests are already on their way
           quad_sync();
+          MBP(3);
           mac_enter(grp * level + idx);
           HX_SCHED_FENCE();
           HX_UNROLL
@@ -1535,8 +1698,10 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
             }
             HX_SCHED_FENCE();
           }
+          MBP(4);
           if (idx + 1 < level) {
             quad_sync();  // every wave of the quad is done with the transforms of this level (the last level: see below)
+            MBP(5);
             mac_leave(grp * level + idx);
           }
         } else
@@ -1573,6 +1738,12 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
               x1[set][j] = ldk(gk, lane_off, sidx * ggsw_bytes + o1 + (uint32_t)(ch * PTS + j) * 1024u);
             }
           };
+#if WAVE_MB_PACE_AT_KEY
+          if (idx == 0) {
+            pace_wait();
+            MBP(0);
+          }
+#endif
           HX_UNROLL
           for (int t = 0; t < SETS && t < STEPS; ++t) request(t, t);
           HX_SCHED_FENCE();
@@ -1581,6 +1752,7 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
             HX_SCHED_FENCE();
           }
           flag_wait(f_ready_ot, epoch);
+          MBP(3);
           const cplx *row0 = (w == 0 ? buf : obuf) + base_m3(cx);
           const cplx *row1 = (w == 0 ? obuf : buf) + base_m3(cx);
           cplx kb0[PTS], kb1[PTS];
@@ -1634,8 +1806,33 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
           }
           HX_WAVE_SYNC();
           if (ln == 0) flag_set(r_done_me, epoch);
+          MBP(4);
           flag_wait(r_done_ot, epoch);  // the partner must be done with my buffer before I reuse it
+          MBP(5);
         }
+      }
+      if constexpr (OCTET && LEVEL_CT != 1) {
+        // the sums over the levels go back over the last level's transforms (slots 2 v, 2 v + 1 of the eight buffers are
+        // read and written by this wave alone: nothing to wait for), the workgroup meets, every wave collects its polynomial
+        WaveCtx cx = ctx0;
+        HX_OPAQUE(cx.lane);
+        const int fslot = base_m3(cx) + 2 * wave;
+        HX_UNROLL
+        for (int L = 0; L < 4; ++L) {
+          cplx(&oq)[8] = L < 2 ? oq_a : oq_b;
+          HX_UNROLL
+          for (int c = 0; c < 2; ++c) {
+            cplx *dst = (cplx *)(smem + (size_t)(2 * L + c) * BUF_BYTES) + fslot;
+            HX_UNROLL
+            for (int pp = 0; pp < 2; ++pp) dst[pp] = oq[((L & 1) * 2 + pp) * 2 + c];
+          }
+        }
+        HX_SCHED_FENCE();
+        HX_BLOCK_SYNC_LDS();
+        const cplx *mine = buf + base_m3(cx);
+        HX_UNROLL
+        for (int r = 0; r < 16; ++r) o[r] = mine[r];
+        HX_WAVE_SYNC();
       }
       if constexpr (SHARE) {
         // my four points of the quad's four polynomials go to the waves that own them, over the transforms they were made
@@ -1672,13 +1869,23 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
         }
       }
 #endif
+#if WAVE_MB_PACE_AT_KEY
+      pace_arrive();
+#endif
+      MBP(6);
       HX_PRIO(WAVE_PRIO_MB_D);
       wave_inverse_accumulate<0, true, false, false, 0, WAVE_LIT_MB != 0>(o, acc_re, acc_im, ctx);
       HX_PRIO(WAVE_PRIO_MB_K);
-#if WAVE_MB_PACE && !defined(TFHE_HIPEMU)
+      MBP(7);
+#if !WAVE_MB_PACE_AT_KEY
       pace_arrive();
 #endif
     }
+#if WAVE_MB_PROBE
+    if (g_wave_ts && lane == 0) {
+      for (int k = 0; k < 8; ++k) g_wave_ts[((size_t)blockIdx.x * 8 + (size_t)wave) * 8 + k] = mbp[k];
+    }
+#endif
   } else if constexpr (LIMBS > 0) {
     struct alignas(16) U64x2 { uint64_t x, y; };
     // my polynomial's 2 N words in the accumulator scratch as one buffer: slot r*64 + lane holds coefficients c and 1024 + c.
@@ -2083,7 +2290,7 @@ bool wave_literal_twiddles_match(const double *fwd, const double *inv) {
 // LWEs per workgroup (= per CU): as few as keeps every one of the 256 CUs busy — a lone wave pair runs an
 // iteration in 7.6 us, four pairs sharing a CU need 12.4 us each
 static unsigned lwes_per_block(uint32_t num_samples) {
-#if WAVE_PROBE_TS
+#if WAVE_PROBE_TS || WAVE_MB_PROBE
   if (g_wave_force_per_block) return g_wave_force_per_block;
 #endif
   const unsigned want = (num_samples + 255) / 256;
@@ -2140,7 +2347,7 @@ static void launch_wave_mb_t(hipStream_t st, const PbsArgs &a, const FftTables &
   if (per_block == 3 && share) per_block = 4;  // 513 .. 768 LWEs: fuller workgroups that can share (4-12 % faster)
   const unsigned blocks = (a.num_samples + per_block - 1) / per_block;
   // full workgroups of a one-level set: all eight waves share the key loads of the four LWEs (OCTET)
-  if constexpr (L == 1 && WAVE_MB_OCTET != 0) {
+  if constexpr ((L == 1 || (L >= 2 && WAVE_MB_OCTET >= 2)) && WAVE_MB_OCTET != 0) {
     if (per_block == 4 && share && !a.mb_no_octet) {
       hx_set_dynamic_smem_once<pbs_fft_wave_kernel<L, B, G, false, 0, true>>(SMEM_BYTES);
       HX_LAUNCH((pbs_fft_wave_kernel<L, B, G, false, 0, true>), dim3(blocks), dim3(512), SMEM_BYTES, st, a, tb);
