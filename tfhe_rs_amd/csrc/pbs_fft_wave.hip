@@ -94,11 +94,17 @@
 #ifndef WAVE_MB_PACE
 #define WAVE_MB_PACE 1  // multi-bit: groups a wave pair may run ahead of the slowest pair of its XCD, plus 1 (0: no pacing)
 #endif
+#ifndef WAVE_MB_PACE_OCTET
+// ... in OCTET mode (0: none).  With a wave working for all four LWEs of its workgroup and the touch of the next group's key
+// lines below, the workgroups of an XCD do better unpaced: the first to arrive at a line fetches it for the others
+// (g = 4 / g = 3 per 4096, same box: paced 20.8 / 36.5 ms, unpaced 20.6 / 35.9)
+#define WAVE_MB_PACE_OCTET 0
+#endif
 #ifndef WAVE_MB_PACE_AT_KEY
 // multi-bit pacing: 1 = a wave waits for its XCD right in front of the group's first key request (digits and forward transform
 // do not touch the key: they run under the wait for the slower workgroups) and reports a group as soon as its last key
 // request is out; 0 = wait at the top of the group, report at its end (rounds 3-5)
-#define WAVE_MB_PACE_AT_KEY 1
+#define WAVE_MB_PACE_AT_KEY 0
 #endif
 #ifndef WAVE_MB_PACE_SLEEP
 #define WAVE_MB_PACE_SLEEP 2  // s_sleep argument between two polls of the XCD's counter (64 cycles each)
@@ -124,6 +130,25 @@
 #endif
 #ifndef WAVE_MB_PREFETCH
 #define WAVE_MB_PREFETCH 1  // multi-bit (pair and quad modes): a load per wave and group touches the next group's key lines
+#endif
+#ifndef WAVE_MB_EXPERIMENT
+#define WAVE_MB_EXPERIMENT 0  // timing experiments (wrong results): bit 0 = every base request reads one of 16 rows of the table, bit 1 = no scalar root loads
+#endif
+#if WAVE_MB_EXPERIMENT & 1
+#define MB_EXP_ROW(d) ((d) & 15u)
+#else
+#define MB_EXP_ROW(d) (d)
+#endif
+#ifndef WAVE_MB_PF_DIST
+#define WAVE_MB_PF_DIST 1  // ... of the group this many groups ahead
+#endif
+#ifndef WAVE_MB_PF_POS
+#define WAVE_MB_PF_POS 0  // ... issued 0: in front of the inverse transform, 1: at the top of the group
+#endif
+#ifndef WAVE_MB_PREFETCH_OCTET
+// the same touch in OCTET mode: 0 never, 1 always, 2 for the sets with several levels only (g = 3, two levels: 40.3 -> 36.5 ms
+// per 4096; g = 4, one level: 20.9 -> 21.2)
+#define WAVE_MB_PREFETCH_OCTET 2
 #endif
 #ifndef WAVE_MB_OCTET_SETS
 #define WAVE_MB_OCTET_SETS 3  // OCTET: register sets in rotation (a request = the 2 rows of one point and subset)
@@ -1128,8 +1153,9 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
     const uint32_t pclass = SHARE ? (uint32_t)(pair >> 1) : 0u;
     uint32_t *pace_ctr = a.pace + (blockIdx.x & 7u) * 32u + pclass * 16u;
     uint32_t pace_before = 0, pace_mine = 0;  // pairs of earlier batches of my XCD; pairs of my batch
-    bool pacing = a.pace != nullptr;
-    {
+    const bool pace_on = a.pace != nullptr && (!OCTET || WAVE_MB_PACE_OCTET != 0);
+    bool pacing = pace_on;
+    if (pace_on) {
       const uint32_t ppb = blockDim.x >> 7, xcd = blockIdx.x & 7u, my_batch = (blockIdx.x >> 3) / 32u;
       for (uint32_t j = 0; j < (my_batch + 1) * 32u; ++j) {
         const uint64_t first = (uint64_t)(xcd + 8u * j) * ppb;
@@ -1175,6 +1201,9 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
     };
     // e^{2 pi i t / 16} = mono[t N / 8], t wave-uniform
     auto w16_root = [&](uint32_t t) {
+#if WAVE_MB_EXPERIMENT & 2  // timing experiment only (wrong results): no scalar load
+      return cplx{0.5, 0.25};
+#endif
 #if WAVE_MB_W16_SCALAR
       return load_uniform_cplx(tb.mono, (uint32_t)(N / 8) * t);
 #else
@@ -1266,7 +1295,7 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
         }
       };
       auto pace_arrive = [&]() {
-        if (a.pace != nullptr && valid && w == 0 && lane == 0)
+        if (pace_on && valid && w == 0 && lane == 0)
           __hip_atomic_fetch_add(pace_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       };
 #if !WAVE_MB_PACE_AT_KEY
@@ -1278,6 +1307,20 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
       auto pace_arrive = []() {};
 #endif
       const HxBuffer gk = hx_make_buffer(key + (size_t)grp * per * ggsw_c, per * ggsw_bytes);
+#if WAVE_MB_PREFETCH
+      auto touch_next_key = [&]() {
+        if constexpr (!OCTET || WAVE_MB_PREFETCH_OCTET == 1 || (WAVE_MB_PREFETCH_OCTET == 2 && LEVEL_CT != 1)) {
+          HX_OPAQUE(pf_val);
+          if (grp + (uint32_t)WAVE_MB_PF_DIST < groups) {
+            const char *nk = (const char *)(key + (size_t)(grp + (uint32_t)WAVE_MB_PF_DIST) * per * ggsw_c);
+            for (uint32_t off = pf_first; off < per * ggsw_bytes; off += pf_stride) pf_val ^= *(const uint32_t *)(nk + off);
+          }
+        }
+      };
+#if WAVE_MB_PF_POS == 1
+      touch_next_key();
+#endif
+#endif
       cplx o[16];
       cplx oq_a[(SHARE || (OCTET && LEVEL_CT != 1)) ? 8 : 1], oq_b[(SHARE || (OCTET && LEVEL_CT != 1)) ? 8 : 1];  // SHARE: [point 4 u + j][column] at index 2 j + column, first / second LWE of the quad
       if constexpr (SHARE || (OCTET && LEVEL_CT != 1)) {  // OCTET, several levels: [LWE][point][column] over the two arrays
@@ -1366,7 +1409,7 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
             HX_UNROLL
             for (int L = 0; L < 4; ++L) {
               dg[0][L] = hx_readlane(dv, L * 16 + (int)sidx);
-              bs[0][L] = ldc(mono_lane, lane16, dg[0][L] * 1024u);
+              bs[0][L] = ldc(mono_lane, lane16, MB_EXP_ROW(dg[0][L]) * 1024u);
             }
           };
 #if WAVE_MB_PACE_AT_KEY
@@ -1480,7 +1523,7 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
             HX_UNROLL
             for (int L = 0; L < 4; ++L) {
               dg[sidx & 1][L] = hx_readlane(dv, L * 16 + (int)sidx);
-              bs[sidx & 1][L] = ldc(mono_lane, lane16, dg[sidx & 1][L] * 1024u);
+              bs[sidx & 1][L] = ldc(mono_lane, lane16, MB_EXP_ROW(dg[sidx & 1][L]) * 1024u);
             }
           };
 #if WAVE_MB_PACE_AT_KEY
@@ -1860,14 +1903,8 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
           HX_WAVE_SYNC();
         }
       }
-#if WAVE_MB_PREFETCH
-      if constexpr (!OCTET) {
-        HX_OPAQUE(pf_val);
-        if (grp + 1 < groups) {
-          const char *nk = (const char *)(key + (size_t)(grp + 1) * per * ggsw_c);
-          for (uint32_t off = pf_first; off < per * ggsw_bytes; off += pf_stride) pf_val ^= *(const uint32_t *)(nk + off);
-        }
-      }
+#if WAVE_MB_PREFETCH && WAVE_MB_PF_POS == 0
+      touch_next_key();
 #endif
 #if WAVE_MB_PACE_AT_KEY
       pace_arrive();
