@@ -516,6 +516,12 @@ void hip_backend_set_fft_kernel(uint32_t which);
  * from the runtime, drops, re-uses that made the new stream wait for the old one's event, live bytes, cached bytes. */
 uint64_t hip_backend_trim_allocator(uint32_t gpu_index);
 void hip_backend_allocator_stats(uint32_t gpu_index, uint64_t *out7);
+/* Debug mode TFHE_HIP_ARENA_REDZONE=1 (environment, read once): every device block of the library and of cuda_malloc[_async]
+ * sits in a shared slab between two 4 KiB canaries that are checked when it is dropped, a dropped payload is poisoned and
+ * checked when it is handed out again; a finding aborts with the block, its owner and the offset (the memcheck the
+ * reference runs over its GPU tests, scripts/check_memory_errors.sh:1-60).  Returns the canary checks made so far
+ * (0: the mode is off). */
+uint64_t hip_backend_redzone_checks(uint32_t gpu_index);
 /* test hook: cap of the groups the multi-bit latency path processes per pass (0 = what the scratch holds) */
 void hip_backend_set_multibit_latency_groups(uint32_t groups);
 /* keyswitch kernel: 0 = automatic (int8 matrix-core GEMM, any batch size, when level <= 16 (padded to a power of

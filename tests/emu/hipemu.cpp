@@ -2,6 +2,15 @@
 // see hipemu.h).
 #include "hipemu.h"
 #include <omp.h>
+// AddressSanitizer build of the emulation (make SAN=1: the CPU tier's stand-in for the reference's compute-sanitizer runs,
+// scripts/check_memory_errors.sh): the sanitizer must be told about every fiber switch, or it takes a fiber's frames for
+// garbage on the scheduler's stack
+#if defined(__SANITIZE_ADDRESS__)
+#include <sanitizer/common_interface_defs.h>
+#define HIPEMU_ASAN 1
+#else
+#define HIPEMU_ASAN 0
+#endif
 
 namespace hipemu {
 thread_local dim3 g_threadIdx, g_blockIdx, g_blockDim, g_gridDim;
@@ -11,20 +20,37 @@ thread_local char *g_dyn_smem = nullptr;
 thread_local uint64_t g_wave_xchg[32][64 * 4];
 static thread_local const std::function<void()> *g_body = nullptr;
 
-static constexpr size_t kStack = 256 * 1024;
+static constexpr size_t kStack = HIPEMU_ASAN ? 4096 * 1024 : 256 * 1024;  // instrumented frames are several times larger
+#if HIPEMU_ASAN
+static thread_local const void *g_sched_stack = nullptr;
+static thread_local size_t g_sched_stack_size = 0;
+static thread_local void *g_sched_fake = nullptr;
+#endif
 
 void yield_barrier(int kind) {
   ThreadCtx *me = g_cur;
   me->state = kind;
+#if HIPEMU_ASAN
+  __sanitizer_start_switch_fiber(&me->asan_fake, g_sched_stack, g_sched_stack_size);
+#endif
   swapcontext(&me->ctx, &g_sched);
+#if HIPEMU_ASAN
+  __sanitizer_finish_switch_fiber(me->asan_fake, &g_sched_stack, &g_sched_stack_size);
+#endif
   // resumed: restore my identity
   g_cur = me;
   g_threadIdx = me->tid;
 }
 
 static void fiber_entry() {
+#if HIPEMU_ASAN
+  __sanitizer_finish_switch_fiber(nullptr, &g_sched_stack, &g_sched_stack_size);
+#endif
   (*g_body)();
   g_cur->state = 3;
+#if HIPEMU_ASAN
+  __sanitizer_start_switch_fiber(nullptr, g_sched_stack, g_sched_stack_size);  // nullptr: this fiber does not come back
+#endif
   swapcontext(&g_cur->ctx, &g_sched);
 }
 
@@ -53,7 +79,13 @@ static void run_block(dim3 block, size_t smem, std::vector<ThreadCtx> &th, std::
       if (c.state != 0) continue;
       g_cur = &c;
       g_threadIdx = c.tid;
+#if HIPEMU_ASAN
+      __sanitizer_start_switch_fiber(&g_sched_fake, c.stack, kStack);
+#endif
       swapcontext(&g_sched, &c.ctx);
+#if HIPEMU_ASAN
+      __sanitizer_finish_switch_fiber(g_sched_fake, nullptr, nullptr);
+#endif
       progressed = true;
       if (c.state == 3) ++done;
     }

@@ -38,6 +38,7 @@ struct ThreadCtx {
   char *stack = nullptr;
   dim3 tid;
   int state = 0;  // 0 runnable, 1 at block barrier, 2 at wave barrier, 3 done
+  void *asan_fake = nullptr;  // AddressSanitizer builds (make SAN=1): the fiber's fake-stack handle across switches
 };
 extern thread_local dim3 g_threadIdx, g_blockIdx, g_blockDim, g_gridDim;
 extern thread_local ThreadCtx *g_cur;
@@ -61,6 +62,12 @@ static inline unsigned long long atomicAdd(unsigned long long *p, unsigned long 
 }
 static inline int atomicAdd(int *p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 static inline unsigned int atomicAdd(unsigned int *p, unsigned int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+static inline unsigned long long atomicMin(unsigned long long *p, unsigned long long v) {
+  unsigned long long old = __atomic_load_n(p, __ATOMIC_RELAXED);
+  while (v < old && !__atomic_compare_exchange_n(p, &old, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {
+  }
+  return old;
+}
 static inline void __threadfence_block() {}
 static inline void __threadfence() {}
 

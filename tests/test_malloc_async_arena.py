@@ -3,6 +3,7 @@ and Drop, tfhe/src/core_crypto/gpu/vec.rs:94-150,487-495): an allocation is stre
 the library's own arena (tfhe_rs_amd/csrc/arena.hip).  [emu] the book-keeping on the host build (no GPU); [hip] stream order across
 streams, stream capture and the reference's alloc / drop-per-operation pattern on the MI355X."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -21,6 +22,8 @@ def stats(lib):
 
 
 @pytest.mark.parametrize("kind", BACKENDS)
+@pytest.mark.skipif(os.environ.get("TFHE_HIP_ARENA_REDZONE", "0") not in ("", "0"),
+                    reason="red-zone mode carves blocks out of slabs: nothing goes back to the runtime at a trim")
 def test_blocks_are_recycled_by_size_class_and_trimmed(kind):
     lib = use_backend(kind)
     st = gpu.CudaStreams.new_single_gpu(0)
@@ -233,3 +236,92 @@ def test_a_block_of_a_callers_own_stream_that_is_gone_by_the_time_it_is_dropped(
     q = lib.cuda_malloc_async(1 << 18, st.ptr[0], 0)
     assert q == p and stats(lib)["cross_stream_waits"] == before["cross_stream_waits"]
     lib.cuda_drop(q, 0)
+
+
+# ---- debug mode TFHE_HIP_ARENA_REDZONE=1 (arena.hip): slabs, canaries around every block, poisoned payloads.  Its counterpart
+# in the reference's tree is compute-sanitizer over the GPU tests (scripts/check_memory_errors.sh:1-60, Makefile:955-962).
+# Each case runs in its own interpreter: the mode is read once per process and a finding aborts.
+_RZ_PRELUDE = """
+import ctypes as C, numpy as np, sys
+sys.path.insert(0, %r)
+import tfhe_rs_amd
+from tfhe_rs_amd import core_crypto_gpu as gpu, ffi
+lib = ffi.default_library()
+st = gpu.CudaStreams.new_single_gpu(0)
+S, G = st.ptr[0], 0
+"""
+
+_RZ_CASES = {
+    "clean": ("""
+        a = lib.cuda_malloc_async(1000, S, G); b = lib.cuda_malloc_async(1000, S, G); c = lib.cuda_malloc(5000, G)
+        assert b - a == 1024 + 2 * 4096, (a, b)   # neighbours in one slab, a red zone on either side of each
+        src = np.arange(1000, dtype=np.uint8)
+        for p in (a, b):
+            lib.cuda_memcpy_async_to_gpu(p, src.ctypes.data_as(C.c_void_p), 1000, S, G)
+        lib.cuda_synchronize_stream(S, G)
+        for p in (a, b, c):
+            lib.cuda_drop(p, G)
+        a2 = lib.cuda_malloc_async(700, S, G)     # the poisoned block, checked and re-armed for 700 bytes
+        assert a2 in (a, b)
+        lib.cuda_drop(a2, G)
+        assert lib.hip_backend_redzone_checks(G) == 4
+        print("clean run ok")
+        """, None),
+    "one byte past the end": ("""
+        a = lib.cuda_malloc_async(1000, S, G)
+        src = np.zeros(1001, dtype=np.uint8)
+        lib.cuda_memcpy_async_to_gpu(a, src.ctypes.data_as(C.c_void_p), 1001, S, G)
+        lib.cuda_synchronize_stream(S, G)
+        lib.cuda_drop(a, G)
+        """, "was written 1 bytes PAST its last byte"),
+    "in front of the payload": ("""
+        a = lib.cuda_malloc_async(4096, S, G)
+        src = np.zeros(8, dtype=np.uint8)
+        lib.cuda_memcpy_async_to_gpu(a - 16, src.ctypes.data_as(C.c_void_p), 8, S, G)
+        lib.cuda_synchronize_stream(S, G)
+        lib.cuda_drop(a, G)
+        """, "was written 16 bytes IN FRONT of its payload"),
+    "write after the drop": ("""
+        a = lib.cuda_malloc_async(2048, S, G)
+        lib.cuda_drop(a, G)
+        src = np.zeros(4, dtype=np.uint8)
+        lib.cuda_memcpy_async_to_gpu(a + 100, src.ctypes.data_as(C.c_void_p), 4, S, G)
+        lib.cuda_synchronize_stream(S, G)
+        b = lib.cuda_malloc_async(2048, S, G)
+        """, "was written at offset 100 AFTER it had been dropped"),
+    "a scratch of the library overrun by its neighbour's owner": ("""
+        buf = C.c_void_p()
+        lib.scratch_cuda_programmable_bootstrap_64_async(S, G, C.byref(buf), 10, 1, 256, 1, 4, True, 0)
+        a = lib.cuda_malloc_async(256, S, G)
+        src = np.zeros(256 + 4096 + 8, dtype=np.uint8)   # through a's red zone into the next block's
+        lib.cuda_memcpy_async_to_gpu(a, src.ctypes.data_as(C.c_void_p), src.size, S, G)
+        lib.cuda_synchronize_stream(S, G)
+        lib.cleanup_cuda_programmable_bootstrap_64(S, G, C.byref(buf))
+        lib.cuda_drop(a, G)
+        """, "arena red zone (drop)"),
+}
+
+
+@pytest.mark.parametrize("kind", BACKENDS)
+@pytest.mark.parametrize("case", list(_RZ_CASES))
+def test_red_zone_mode_finds_overruns_and_writes_after_a_drop(kind, case):
+    import os
+    import signal
+    import subprocess
+    import sys
+    import textwrap
+    from .harness import EMU_LIB, build_emu
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TFHE_HIP_ARENA_REDZONE="1")
+    if kind == "emu":
+        build_emu()
+        env["TFHE_HIP_BACKEND_LIB"] = EMU_LIB
+    snippet, message = _RZ_CASES[case]
+    r = subprocess.run([sys.executable, "-c", _RZ_PRELUDE % root + textwrap.dedent(snippet)], env=env, capture_output=True,
+                       text=True, timeout=600)
+    if message is None:
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert "clean run ok" in r.stdout
+    else:
+        assert r.returncode == -signal.SIGABRT, (r.returncode, r.stderr[-2000:])
+        assert message in r.stderr, r.stderr[-2000:]

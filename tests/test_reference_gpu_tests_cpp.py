@@ -28,6 +28,9 @@ def build_tests(lib, exe, source="reference_gpu_tests.cpp"):
 def run(exe, *args, timeout, env=None):
     env = dict(env or {}, TFHE_FFT_GOLDEN=os.path.join(HERE, "golden", "fft16x4x16_golden_v1.json"))
     r = subprocess.run([exe, *args], capture_output=True, text=True, timeout=timeout, env=dict(os.environ, **env))
+    for line in r.stderr.splitlines():  # TFHE_HIP_ARENA_REDZONE=1 (tools/redzone_pass.sh): what the binary's library checked
+        if "[arena red zone]" in line:
+            print(os.path.basename(exe), " ".join(args), line)
     assert r.returncode == 0, r.stdout + r.stderr
     last = r.stdout.strip().splitlines()[-1]
     assert last.startswith("test result: ok."), r.stdout

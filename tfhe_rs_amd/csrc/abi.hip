@@ -127,9 +127,7 @@ void cuda_synchronize_stream(void *stream, uint32_t gpu_index) {
 uint32_t cuda_is_available(void) { return hipSetDevice(0) == hipSuccess; }
 void *cuda_malloc(uint64_t size, uint32_t gpu_index) {
   set_device(gpu_index);
-  void *p = nullptr;
-  HX_CHECK(hipMalloc(&p, size));
-  return p;
+  return device_alloc_sync(size);  // hipMalloc (an arena block in red-zone mode: cuda_drop knows both)
 }
 // Stream-ordered allocations (the reference: cudaMallocAsync on the device pool, tfhe-cuda-common/cuda/src/device.cu:176-226;
 // CudaVec::new_async / Drop allocate and drop per operation, tfhe/src/core_crypto/gpu/vec.rs:94-150,487-495).  Default: the
@@ -272,8 +270,7 @@ static void convert_bsk_common(bool ntt, void *stream, uint32_t gpu_index, void 
   const size_t polys = (size_t)input_lwe_dim * level_count * (glwe_dim + 1) * (glwe_dim + 1);
   const size_t bytes = polys * polynomial_size * sizeof(uint64_t);
   // stage the standard-domain key on the device, transform polynomial by polynomial
-  void *tmp = nullptr;
-  HX_CHECK(hipMalloc(&tmp, bytes));
+  void *tmp = device_alloc_sync(bytes);
   HX_CHECK(hipMemcpyAsync(tmp, src, bytes, hipMemcpyHostToDevice, S(stream)));
   if (ntt) {
     const NttTables tb = get_ntt_tables(gpu_index, S(stream), polynomial_size);
@@ -284,7 +281,7 @@ static void convert_bsk_common(bool ntt, void *stream, uint32_t gpu_index, void 
   }
   // the staging buffer must outlive the kernel: release it once the stream reaches here
   HX_CHECK(hipStreamSynchronize(S(stream)));
-  HX_CHECK(hipFree(tmp));
+  device_free_sync(tmp);
 }
 
 void cuda_convert_lwe_programmable_bootstrap_key_64_async(void *stream, uint32_t gpu_index, void *dest,
@@ -569,13 +566,12 @@ void hip_convert_lwe_programmable_bootstrap_key_ntt64_split_async(void *stream, 
                     "split-key exact engine: parameter set not supported (N = 2048, k = 1, one level)");
   const size_t polys = (size_t)input_lwe_dim * level_count * (glwe_dim + 1) * (glwe_dim + 1);
   const size_t bytes = polys * polynomial_size * sizeof(uint64_t);
-  void *tmp = nullptr;
-  HX_CHECK(hipMalloc(&tmp, bytes));
+  void *tmp = device_alloc_sync(bytes);
   HX_CHECK(hipMemcpyAsync(tmp, src, bytes, hipMemcpyHostToDevice, S(stream)));
   launch_bsk_to_split(S(stream), polynomial_size, (const uint64_t *)tmp, dest, polys,
                       get_fft_tables(gpu_index, S(stream), polynomial_size));
   HX_CHECK(hipStreamSynchronize(S(stream)));  // the staging buffer must outlive the kernel
-  HX_CHECK(hipFree(tmp));
+  device_free_sync(tmp);
 }
 void hip_programmable_bootstrap_ntt64_split_async(void *stream, uint32_t gpu_index, void *lwe_array_out,
                                                   void const *lwe_output_indexes, void const *lut_vector,
@@ -633,13 +629,12 @@ void hip_convert_lwe_programmable_bootstrap_key_ref64_async(void *stream, uint32
   HX_PANIC_IF_FALSE(dest != nullptr && src != nullptr, "bootstrap key conversion: null pointer");
   const size_t polys = (size_t)input_lwe_dim * level_count * (glwe_dim + 1) * (glwe_dim + 1);
   const size_t bytes = polys * polynomial_size * sizeof(uint64_t);
-  void *tmp = nullptr;
-  HX_CHECK(hipMalloc(&tmp, bytes));
+  void *tmp = device_alloc_sync(bytes);
   HX_CHECK(hipMemcpyAsync(tmp, src, bytes, hipMemcpyHostToDevice, S(stream)));
   launch_bsk_to_ref64(S(stream), polynomial_size, (const uint64_t *)tmp, dest, polys,
                       get_ref_tables(gpu_index, S(stream), polynomial_size));
   HX_CHECK(hipStreamSynchronize(S(stream)));
-  HX_CHECK(hipFree(tmp));
+  device_free_sync(tmp);
 }
 void hip_programmable_bootstrap_ref64_async(void *stream, uint32_t gpu_index, void *lwe_array_out,
                                             void const *lwe_output_indexes, void const *lut_vector,
@@ -737,13 +732,12 @@ void cuda_convert_lwe_multi_bit_programmable_bootstrap_key_64_async(void *stream
   const size_t polys = (size_t)(input_lwe_dim / grouping_factor) * ((size_t)1 << grouping_factor) * level_count *
                        (glwe_dim + 1) * (glwe_dim + 1);
   const size_t bytes = polys * polynomial_size * sizeof(uint64_t);
-  void *tmp = nullptr;
-  HX_CHECK(hipMalloc(&tmp, bytes));
+  void *tmp = device_alloc_sync(bytes);
   HX_CHECK(hipMemcpyAsync(tmp, src, bytes, hipMemcpyHostToDevice, S(stream)));
   const FftTables tb = get_fft_tables(gpu_index, S(stream), polynomial_size);
   launch_bsk_to_fourier(S(stream), polynomial_size, glwe_dim, (const uint64_t *)tmp, dest, polys, tb);
   HX_CHECK(hipStreamSynchronize(S(stream)));  // the staging buffer must outlive the kernel
-  HX_CHECK(hipFree(tmp));
+  device_free_sync(tmp);
 }
 
 uint64_t scratch_cuda_multi_bit_programmable_bootstrap_64_async(void *stream, uint32_t gpu_index,
@@ -1028,6 +1022,7 @@ void hip_backend_allocator_stats(uint32_t gpu_index, uint64_t *out7) {
   out7[0] = s.allocations; out7[1] = s.reuses; out7[2] = s.runtime_allocations; out7[3] = s.frees;
   out7[4] = s.cross_stream_waits; out7[5] = s.live_bytes; out7[6] = s.cached_bytes;
 }
+uint64_t hip_backend_redzone_checks(uint32_t gpu_index) { return arena_redzone_checks((int)gpu_index); }
 void hip_backend_set_keyswitch_kernel(uint32_t which) {
   g_keyswitch_use_mfma.store(which != 1);
   g_keyswitch_split_digits.store(which != 2);

@@ -19,6 +19,16 @@
 //     re-usable only by later allocations of the same stream;
 //   * memory goes back to the runtime when an allocation fails (trim and retry), on hip_backend_trim_allocator() and
 //     when the owning stream is destroyed.
+//
+// Debug mode TFHE_HIP_ARENA_REDZONE=1 (the practice it stands in for: compute-sanitizer memcheck / racecheck over the
+// reference's GPU tests, scripts/check_memory_errors.sh:1-60, Makefile:955-962): blocks are carved out of shared SLABS,
+// so a block's neighbours are other live blocks of the library and its callers, not page padding; every block carries a
+// 4 KiB canary in front of its payload and a canary from the LAST REQUESTED BYTE to 4 KiB past its size class; the canaries
+// are written at every allocation and checked at every drop (cuda_drop, cleanup_*), a mismatch panics with the block's
+// class, size, owner and the offset of the first foreign byte; a dropped payload is poisoned and the poison is checked
+// when the block is handed out again (a write after the drop).  Every check synchronises the device: this mode is for
+// the test suites, never for throughput.  The library's other device allocations (cuda_malloc, key staging, keyswitch
+// planes and scratches) go through the arena too in this mode (device_alloc_sync).
 #include "arena.h"
 #include "kernels.h"
 #include <cstdlib>
@@ -43,7 +53,15 @@ struct LiveBlock {
   size_t cls, bytes;
   hipStream_t stream;
   bool pinned;
+  bool scratch;  // the library's own scratch (no stream: idle when handed out, idle by contract when returned)
+  bool armed;    // red-zone mode: canaries in place (not for a block handed out under stream capture: nothing may synchronise there)
 };
+struct Slab {
+  char *base;
+  size_t size, used;
+};
+constexpr size_t kRedzone = 4096, kSlabBytes = (size_t)64 << 20;
+constexpr int kCanary = 0xA5, kPoison = 0xDD;
 struct DeviceArena {
   std::mutex m;
   std::unordered_map<const void *, LiveBlock> live;
@@ -51,6 +69,11 @@ struct DeviceArena {
   std::unordered_set<hipStream_t> known_streams;  // made by cuda_create_stream_ffi and not destroyed yet: safe to touch at a drop
   std::deque<hipEvent_t> spare_events;  // taken from the front, returned to the back: a consumed event rests before its next record
   ArenaStats stats{};
+  // red-zone mode
+  std::vector<Slab> slabs;
+  std::unordered_set<const void *> poisoned;  // free blocks whose payload holds the poison pattern
+  unsigned long long *scan_result = nullptr;  // device word: offset of the first byte that is not the pattern
+  uint64_t rz_checks = 0;
 };
 DeviceArena g_arena[16];
 
@@ -94,9 +117,79 @@ void *runtime_alloc(size_t bytes, bool capturing) {
   return p;
 }
 
+bool redzone_on() {
+  static const bool on = [] {
+    const char *e = std::getenv("TFHE_HIP_ARENA_REDZONE");
+    return e != nullptr && std::atoi(e) != 0;
+  }();
+  return on;
+}
+
+// offset of the first byte of [p, p + n) that is not `pattern` (n if there is none)
+__global__ void __launch_bounds__(256) arena_scan_kernel(const unsigned char *p, size_t n, unsigned pattern,
+                                                         unsigned long long *first_bad) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    if (p[i] != (unsigned char)pattern) {
+      atomicMin(first_bad, (unsigned long long)i);
+      break;
+    }
+}
+size_t scan_for_foreign_byte(DeviceArena &a, const void *p, size_t n, int pattern) {
+  if (n == 0) return 0;
+  if (a.scan_result == nullptr) HX_CHECK(hipMalloc((void **)&a.scan_result, sizeof(unsigned long long)));
+  unsigned long long v = (unsigned long long)n;
+  HX_CHECK(hipMemcpy(a.scan_result, &v, sizeof(v), hipMemcpyHostToDevice));
+  const unsigned blocks = (unsigned)((n + 256 * 64 - 1) / (256 * 64) < 4096 ? (n + 256 * 64 - 1) / (256 * 64) : 4096);
+  HX_LAUNCH(arena_scan_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, (hipStream_t) nullptr, (const unsigned char *)p, n,
+            (unsigned)pattern, a.scan_result);
+  HX_CHECK(hipDeviceSynchronize());
+  HX_CHECK(hipMemcpy(&v, a.scan_result, sizeof(v), hipMemcpyDeviceToHost));
+  return (size_t)v;
+}
+// a block of RZ + cls + RZ bytes out of the slabs (payload = block + RZ, 256-byte aligned)
+void *slab_carve(DeviceArena &a, size_t cls, bool capturing) {
+  const size_t need = kRedzone + cls + kRedzone;
+  for (Slab &s : a.slabs)
+    if (s.size - s.used >= need) {
+      void *p = s.base + s.used + kRedzone;
+      s.used += need;
+      return p;
+    }
+  Slab s{nullptr, need > kSlabBytes ? need : kSlabBytes, 0};
+  s.base = (char *)runtime_alloc(s.size, capturing);
+  if (s.base == nullptr) return nullptr;
+  s.used = need;
+  a.slabs.push_back(s);
+  return s.base + kRedzone;
+}
+// canaries around the `bytes` the caller asked for; synchronous (debug mode)
+void redzone_arm(void *payload, size_t cls, size_t bytes) {
+  HX_CHECK(hipDeviceSynchronize());
+  HX_CHECK(hipMemsetAsync((char *)payload - kRedzone, kCanary, kRedzone, nullptr));
+  HX_CHECK(hipMemsetAsync((char *)payload + bytes, kCanary, cls - bytes + kRedzone, nullptr));
+  HX_CHECK(hipDeviceSynchronize());
+}
+void redzone_check(DeviceArena &a, const void *payload, const LiveBlock &lb, const char *when) {
+  HX_CHECK(hipDeviceSynchronize());
+  a.rz_checks++;
+  const size_t front = scan_for_foreign_byte(a, (const char *)payload - kRedzone, kRedzone, kCanary);
+  if (front != kRedzone)
+    HX_PANIC("arena red zone (%s): block %p (class %zu, %zu bytes asked for, %s, stream %p) was written %zu bytes IN FRONT of "
+             "its payload", when, payload, lb.cls, lb.bytes, lb.scratch ? "library scratch" : "cuda_malloc_async",
+             (void *)lb.stream, kRedzone - front);
+  const size_t tail = lb.cls - lb.bytes + kRedzone;
+  const size_t back = scan_for_foreign_byte(a, (const char *)payload + lb.bytes, tail, kCanary);
+  if (back != tail)
+    HX_PANIC("arena red zone (%s): block %p (class %zu, %zu bytes asked for, %s, stream %p) was written %zu bytes PAST its "
+             "last byte", when, payload, lb.cls, lb.bytes, lb.scratch ? "library scratch" : "cuda_malloc_async",
+             (void *)lb.stream, back + 1);
+}
+
 // every idle, unpinned block goes back to the runtime; returns the bytes released
 size_t trim_locked(DeviceArena &a) {
   size_t released = 0;
+  if (redzone_on()) return 0;  // blocks are parts of slabs
   for (auto &kv : a.free_) {
     std::vector<FreeBlock> keep;
     for (FreeBlock &b : kv.second) {
@@ -121,7 +214,7 @@ size_t trim_locked(DeviceArena &a) {
 
 }  // namespace
 
-void *arena_alloc(int device, size_t bytes, hipStream_t stream) {
+void *arena_alloc(int device, size_t bytes, hipStream_t stream, bool scratch) {
   HX_PANIC_IF_FALSE(device >= 0 && device < 16, "cuda_malloc_async: device index %d", device);
   DeviceArena &a = g_arena[device];
   const size_t cls = size_class(bytes ? bytes : 1);
@@ -164,16 +257,32 @@ void *arena_alloc(int device, size_t bytes, hipStream_t stream) {
     pinned = pinned || b.pinned;
     a.stats.cached_bytes -= cls;
     a.stats.reuses++;
+  } else if (redzone_on()) {
+    p = slab_carve(a, cls, capturing);
+    HX_PANIC_IF_FALSE(p != nullptr, "cuda_malloc_async: out of device memory (%zu bytes requested, red-zone mode)", bytes);
+    a.stats.runtime_allocations++;
   } else {
     p = runtime_alloc(cls, capturing);
-    if (p == nullptr) {  // out of memory: hand the cache back and try once more
+    if (p == nullptr && !capturing) {  // out of memory: hand the cache back and try once more (hipFree is illegal under capture)
       trim_locked(a);
       p = runtime_alloc(cls, capturing);
-      HX_PANIC_IF_FALSE(p != nullptr, "cuda_malloc_async: out of device memory (%zu bytes requested)", bytes);
     }
+    HX_PANIC_IF_FALSE(p != nullptr, "cuda_malloc_async: out of device memory (%zu bytes requested)", bytes);
     a.stats.runtime_allocations++;
   }
-  a.live[p] = LiveBlock{cls, bytes, stream, pinned};
+  LiveBlock lb{cls, bytes, stream, pinned, scratch, false};
+  if (redzone_on() && capturing) a.poisoned.erase(p);
+  if (redzone_on() && !capturing) {
+    lb.armed = true;
+    if (a.poisoned.erase(p) != 0) {  // dropped earlier: nobody may have written it since
+      HX_CHECK(hipDeviceSynchronize());
+      const size_t bad = scan_for_foreign_byte(a, p, cls, kPoison);
+      if (bad != cls)
+        HX_PANIC("arena red zone: block %p (class %zu) was written at offset %zu AFTER it had been dropped", p, cls, bad);
+    }
+    redzone_arm(p, cls, bytes);
+  }
+  a.live[p] = lb;
   a.stats.live_bytes += cls;
   return p;
 }
@@ -188,6 +297,12 @@ bool arena_free(int device, void *p, size_t *user_bytes) {
   a.live.erase(it);
   if (user_bytes) *user_bytes = lb.bytes;
   FreeBlock fb{p, lb.stream, nullptr, lb.pinned};
+  if (redzone_on() && !(lb.stream != nullptr && a.known_streams.count(lb.stream) != 0 && stream_is_capturing(lb.stream))) {
+    if (lb.armed) redzone_check(a, p, lb, "drop");
+    HX_CHECK(hipMemsetAsync(p, kPoison, lb.cls, nullptr));
+    HX_CHECK(hipDeviceSynchronize());
+    a.poisoned.insert(p);
+  }
   // A drop has no stream argument: the block's owner stream is touched only if the library made it and still knows it alive
   // (cuda_create_stream_ffi / cuda_destroy_stream).  A caller's own stream may be gone by now — recording an event on a dead
   // handle is undefined in the runtime — so its blocks come back after ONE device synchronisation, idle and nobody's.
@@ -202,6 +317,11 @@ bool arena_free(int device, void *p, size_t *user_bytes) {
   } else if (!lb.pinned && lb.stream != nullptr) {
     fb.ready = take_event(a);
     HX_CHECK(hipEventRecord(fb.ready, lb.stream));  // everything queued on the owner's stream so far may still use the block
+  } else if (!lb.pinned && !lb.scratch) {
+    // cuda_malloc_async(size, NULL, gpu): the caller's work runs on the legacy default stream — order behind it like behind
+    // any other owner (a library scratch, also stream-less, is idle by contract and takes no event)
+    fb.ready = take_event(a);
+    HX_CHECK(hipEventRecord(fb.ready, nullptr));
   }
   a.free_[lb.cls].push_back(fb);
   a.stats.live_bytes -= lb.cls;
@@ -226,6 +346,7 @@ void arena_register_stream(int device, hipStream_t stream) {
 
 // the stream is about to be destroyed (already synchronised): its blocks are idle and nobody's
 void arena_release_stream(int device, hipStream_t stream) {
+  if (device < 0 || device >= 16) return;
   DeviceArena &a = g_arena[device];
   std::lock_guard<std::mutex> lock(a.m);
   a.known_streams.erase(stream);
@@ -242,6 +363,7 @@ void arena_release_stream(int device, hipStream_t stream) {
 }
 
 size_t arena_trim(int device) {
+  HX_PANIC_IF_FALSE(device >= 0 && device < 16, "hip_backend_trim_allocator: device index %d", device);
   DeviceArena &a = g_arena[device];
   std::lock_guard<std::mutex> lock(a.m);
   return trim_locked(a);
@@ -261,19 +383,65 @@ bool arena_enabled() {
 void *scratch_alloc(size_t bytes) {
   int dev = 0;
   HX_CHECK(hipGetDevice(&dev));
-  if (arena_enabled()) return arena_alloc(dev, bytes, nullptr);
+  if (arena_enabled()) return arena_alloc(dev, bytes, nullptr, true);
   void *p = nullptr;
   HX_CHECK(hipMalloc(&p, bytes));
   return p;
 }
+// The block is looked up on the current device first, then on every other one: a cleanup_* may run on a host thread whose
+// current device is not the scratch's (a multi-GPU host alternating devices) — handing an arena block to hipFree would
+// leave a stale entry in its owner's map.
 void scratch_free(void *p) {
   if (p == nullptr) return;
   int dev = 0;
   HX_CHECK(hipGetDevice(&dev));
-  if (!arena_free(dev, p, nullptr)) HX_CHECK(hipFree(p));
+  if (arena_free(dev, p, nullptr)) return;
+  for (int d = 0; d < 16; ++d)
+    if (d != dev && arena_free(d, p, nullptr)) return;
+  HX_CHECK(hipFree(p));
+}
+// hipMalloc / hipFree semantics (the free synchronises the device) for the library's staging buffers, keyswitch planes and
+// scratches and for cuda_malloc: the runtime's own calls, except in red-zone mode, where they are arena blocks as well
+void *device_alloc_sync(size_t bytes) {
+  if (arena_enabled() && redzone_on()) return scratch_alloc(bytes);
+  void *p = nullptr;
+  HX_CHECK(hipMalloc(&p, bytes));
+  return p;
+}
+void device_free_sync(void *p) {
+  if (p == nullptr) return;
+  if (arena_enabled() && redzone_on()) {
+    HX_CHECK(hipDeviceSynchronize());
+    scratch_free(p);
+    return;
+  }
+  HX_CHECK(hipFree(p));
+}
+// red-zone mode: every process says at its end what it checked (a finding would have aborted it)
+namespace {
+struct RedzoneReport {
+  ~RedzoneReport() {
+    if (!redzone_on()) return;
+    uint64_t checks = 0, slabs = 0, bytes = 0;
+    for (DeviceArena &a : g_arena) {
+      checks += a.rz_checks;
+      slabs += a.slabs.size();
+      for (const Slab &s : a.slabs) bytes += s.used;
+    }
+    std::fprintf(stderr, "[arena red zone] %llu blocks checked at their drop, %llu slabs, %llu bytes carved: no finding\n",
+                 (unsigned long long)checks, (unsigned long long)slabs, (unsigned long long)bytes);
+  }
+} g_redzone_report;
+}  // namespace
+uint64_t arena_redzone_checks(int device) {
+  if (device < 0 || device >= 16) return 0;
+  DeviceArena &a = g_arena[device];
+  std::lock_guard<std::mutex> lock(a.m);
+  return redzone_on() ? a.rz_checks : 0;
 }
 
 ArenaStats arena_stats(int device) {
+  HX_PANIC_IF_FALSE(device >= 0 && device < 16, "hip_backend_allocator_stats: device index %d", device);
   DeviceArena &a = g_arena[device];
   std::lock_guard<std::mutex> lock(a.m);
   return a.stats;

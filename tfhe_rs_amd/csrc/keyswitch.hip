@@ -11,6 +11,7 @@
 // and reused across the TB samples held in registers; the signed digits of a chunk of IC mask
 // elements are staged in LDS and broadcast-read.
 #include "kernels.h"
+#include "arena.h"
 #include <mutex>
 #include <vector>
 
@@ -723,13 +724,13 @@ static void *ksd_scratch(int device, hipStream_t st, size_t bytes, bool capturin
       e = &g_ksd.back();
     }
     old = e->live;
-    HX_CHECK(hipMalloc(&buf, bytes));
+    buf = device_alloc_sync(bytes);
     e->live = buf;
     e->live_bytes = bytes;
   }
   if (old) {
     HX_CHECK(hipStreamSynchronize(st));  // launches that still read the old buffer (never a captured one: see above)
-    HX_CHECK(hipFree(old));
+    device_free_sync(old);
   }
   return buf;
 }
@@ -745,8 +746,8 @@ void ksd_release_stream(int device, hipStream_t st) {
         break;
       }
   }
-  if (live) HX_CHECK(hipFree(live));
-  if (cap) HX_CHECK(hipFree(cap));
+  if (live) device_free_sync(live);
+  if (cap) device_free_sync(cap);
 }
 
 // Byte planes + column sums of a keyswitch key, built ONCE per key and kept until the key's device memory is
@@ -778,7 +779,7 @@ static void ksm_release(const KsmEntry &e) {
   int cur = 0;
   HX_CHECK(hipGetDevice(&cur));
   HX_CHECK(hipSetDevice(e.device));
-  HX_CHECK(hipFree(e.planes));  // synchronises the device: no kernel still reads the planes
+  device_free_sync(e.planes);  // synchronises the device: no kernel still reads the planes
   HX_CHECK(hipEventDestroy(e.ready));
   HX_CHECK(hipSetDevice(cur));
 }
@@ -868,7 +869,7 @@ static bool keyswitch_mfma(hipStream_t st, OutT *lwe_out, const uint64_t *out_id
       e.ksk_bytes = (size_t)n_in * level * ncols * sizeof(OutT);
       e.n_in = n_in, e.n_out = n_out, e.level = level, e.level_pad = level_pad, e.key_size = sizeof(OutT);
       e.plane_bytes = plane_bytes;
-      HX_CHECK(hipMalloc(&e.planes, need));
+      e.planes = device_alloc_sync(need);
       HX_CHECK(hipEventCreate(&e.ready));
       uint64_t *cs = (uint64_t *)((char *)e.planes + plane_bytes);
       HX_CHECK(hipMemsetAsync(cs, 0, (size_t)col_tiles * KSM_CT * sizeof(uint64_t), st));
