@@ -340,11 +340,13 @@ void hip_programmable_bootstrap_ntt64_split_async(
     uint32_t polynomial_size, uint32_t base_log, uint32_t level_count,
     uint32_t num_samples, uint32_t num_many_lut, uint32_t lut_stride);
 
-/* Round-off check of the split-key engine: 1 if any launch on this scratch since the last call saw an f64 limb product
- * further than 1/4 from an integer (outputs not to be trusted; never observed with the supported bounds, which are
- * statistical: worst-case products of 2^49 leave 4 bits of headroom), else 0.  Synchronises the stream, clears the flag.
- * A flag that is still set when the scratch is cleaned up makes cleanup_cuda_programmable_bootstrap_64 panic: a host that
- * never polls cannot miss it. */
+/* Round-off check of the split-key engine.  A ciphertext whose f64 limb products were further than 1/4 from integers (the
+ * bound on them is statistical: worst-case products of 2^49 leave 4 bits of headroom; never observed on a real parameter
+ * set's data, reachable with adversarial constant polynomials) is RECOMPUTED by the integer Goldilocks kernel in a second
+ * launch on the same stream, with the NTT-domain twin of the key that the conversion above made and the library keeps while
+ * the split key's memory lives: the entry point's outputs are the exact ones whatever the data.  This call returns how many
+ * ciphertexts went that way on this scratch since the last call (synchronises the stream, clears the count).  A split key
+ * the library did not convert itself (copied in) has no twin: a raised flag then panics here or at cleanup_*. */
 uint32_t hip_programmable_bootstrap_ntt64_split_roundoff_status(
     void *stream, uint32_t gpu_index, int8_t *buffer);
 

@@ -254,6 +254,10 @@ class CudaLweKeyswitchKey:
         return self
 
 
+# ciphertexts of the last split-key bootstrap that went through the integer kernel (cuda_programmable_bootstrap_lwe_ciphertext)
+last_split_recomputed = 0
+
+
 def _trivial_indexes(count, streams):
     return CudaVec.from_cpu_async(np.arange(count, dtype=U64), streams)
 
@@ -287,11 +291,11 @@ def cuda_programmable_bootstrap_lwe_ciphertext(input, output, accumulator, lut_i
            input.d_vec.ptr, input_indexes.ptr, bsk.d_vec.ptr, buf, bsk.input_lwe_dimension, bsk.glwe_dimension,
            bsk.polynomial_size, bsk.decomp_base_log, bsk.decomp_level_count, num_samples, num_many_lut, lut_stride)
     if bsk.engine_impl == "ntt64_split":
-        # the exact products of this engine come out of f64 transforms: its launches report a limb product that was not
-        # within 1/4 of an integer through the scratch (never observed with the supported bounds; a set flag means the
-        # outputs are not to be trusted)
-        assert lib.hip_programmable_bootstrap_ntt64_split_roundoff_status(s, g, buf) == 0, \
-            "split-key exact engine: round-off check failed"
+        # the exact products of this engine come out of f64 transforms; a ciphertext whose limb products were not within 1/4
+        # of integers is recomputed by the integer kernel on the same stream (never observed on a real parameter set's data):
+        # the outputs are exact either way, the count is kept for whoever wants to know
+        global last_split_recomputed
+        last_split_recomputed = int(lib.hip_programmable_bootstrap_ntt64_split_roundoff_status(s, g, buf))
     lib.cleanup_cuda_programmable_bootstrap_64(s, g, C.byref(buf))
 
 

@@ -37,6 +37,8 @@ struct PbsBuffer {
   uint64_t *acc_scratch = nullptr;
   uint64_t *split_acc = nullptr;  // exact engine, split-key form: (k+1) N accumulator words per sample in device memory
   uint32_t *split_flag = nullptr; // ... and its round-off flag (PbsArgs::roundoff_flag), allocated with split_acc
+  uint32_t *split_bad = nullptr;  // ... one word per sample: the ciphertexts of the last launch the integer kernel had to redo
+  bool split_unrecovered = false; // a launch ran without the NTT-domain twin of its key: a raised flag is then fatal
   // hip_keyswitch_programmable_bootstrap_chain_64_async: keyswitch operands written by the bootstrap of the previous
   // call for ITS outputs (what they are valid for is recorded; anything else falls back to the digit pass)
   int8_t *emit_a = nullptr;
@@ -124,6 +126,46 @@ void cuda_synchronize_stream(void *stream, uint32_t gpu_index) {
   set_device(gpu_index);
   HX_CHECK(hipStreamSynchronize(S(stream)));
 }
+// ---- the split-key exact engine's way out of a raised round-off flag: the NTT-domain form of the same key (the integer
+// Goldilocks kernel's operand), made next to the split form by hip_convert_lwe_programmable_bootstrap_key_ntt64_split_async
+// and kept by the library for as long as the split key's device memory is neither dropped nor overwritten
+struct SplitTwin {
+  int device;
+  const void *split_key;
+  size_t split_bytes;
+  void *ntt_key;
+};
+static std::mutex g_twin_mutex;
+static std::vector<SplitTwin> g_split_twins;
+static void split_twin_forget_range(int device, const void *p, size_t bytes) {
+  if (p == nullptr) return;
+  std::vector<void *> dead;
+  {
+    std::lock_guard<std::mutex> lock(g_twin_mutex);
+    const char *lo = (const char *)p, *hi = lo + (bytes ? bytes : 1);
+    for (size_t i = 0; i < g_split_twins.size();) {
+      const char *klo = (const char *)g_split_twins[i].split_key, *khi = klo + g_split_twins[i].split_bytes;
+      if (g_split_twins[i].device == device && klo < hi && lo < khi) {
+        dead.push_back(g_split_twins[i].ntt_key);
+        g_split_twins.erase(g_split_twins.begin() + i);
+      } else {
+        ++i;
+      }
+    }
+  }
+  for (void *d : dead) device_free_sync(d);  // synchronises the device: no launch still reads it
+}
+static const void *split_twin_of(int device, const void *split_key) {
+  std::lock_guard<std::mutex> lock(g_twin_mutex);
+  for (const SplitTwin &t : g_split_twins)
+    if (t.device == device && t.split_key == split_key) return t.ntt_key;
+  return nullptr;
+}
+// device memory [p, p + bytes) is about to be freed or written: what the library derived from it goes
+static void device_range_changes(int device, const void *p, size_t bytes) {
+  ksm_invalidate_range(device, p, bytes);
+  split_twin_forget_range(device, p, bytes);
+}
 uint32_t cuda_is_available(void) { return hipSetDevice(0) == hipSuccess; }
 void *cuda_malloc(uint64_t size, uint32_t gpu_index) {
   set_device(gpu_index);
@@ -181,20 +223,20 @@ void cuda_memcpy_async_to_gpu(void *dest, const void *src, uint64_t size, void *
   if (size == 0) return;
   set_device(gpu_index);
   HX_PANIC_IF_FALSE(dest != nullptr && src != nullptr, "memcpy to gpu: null pointer");
-  ksm_invalidate_range((int)gpu_index, dest, size);  // a keyswitch key may be rewritten in place
+  device_range_changes((int)gpu_index, dest, size);  // a keyswitch key may be rewritten in place
   HX_CHECK(hipMemcpyAsync(dest, src, size, hipMemcpyHostToDevice, S(stream)));
 }
 void cuda_memcpy_async_gpu_to_gpu(void *dest, void const *src, uint64_t size, void *stream, uint32_t gpu_index) {
   if (size == 0) return;
   set_device(gpu_index);
   HX_PANIC_IF_FALSE(dest != nullptr && src != nullptr, "memcpy gpu to gpu: null pointer");
-  ksm_invalidate_range((int)gpu_index, dest, size);
+  device_range_changes((int)gpu_index, dest, size);
   HX_CHECK(hipMemcpyAsync(dest, src, size, hipMemcpyDeviceToDevice, S(stream)));
 }
 void cuda_memcpy_gpu_to_gpu(void *dest, void const *src, uint64_t size, uint32_t gpu_index) {
   if (size == 0) return;
   set_device(gpu_index);
-  ksm_invalidate_range((int)gpu_index, dest, size);
+  device_range_changes((int)gpu_index, dest, size);
   HX_CHECK(hipMemcpy(dest, src, size, hipMemcpyDeviceToDevice));
 }
 void cuda_memcpy_async_to_cpu(void *dest, const void *src, uint64_t size, void *stream, uint32_t gpu_index) {
@@ -206,7 +248,7 @@ void cuda_memcpy_async_to_cpu(void *dest, const void *src, uint64_t size, void *
 void cuda_memset_async(void *dest, uint64_t val, uint64_t size, void *stream, uint32_t gpu_index) {
   if (size == 0) return;
   set_device(gpu_index);
-  ksm_invalidate_range((int)gpu_index, dest, size);
+  device_range_changes((int)gpu_index, dest, size);
   HX_CHECK(hipMemsetAsync(dest, (int)val, size, S(stream)));
 }
 int cuda_get_number_of_gpus(void) {
@@ -231,7 +273,7 @@ void cuda_drop(void *ptr, uint32_t gpu_index) {
     // an arena block goes back to the arena in stream order: no runtime call, no synchronisation (arena.hip)
     size_t user_bytes = 0;
     if (ptr != nullptr && arena_free((int)gpu_index, ptr, &user_bytes)) {
-      ksm_invalidate_range((int)gpu_index, ptr, user_bytes);  // a keyswitch key in it takes its cached layout along
+      device_range_changes((int)gpu_index, ptr, user_bytes);  // a keyswitch key in it takes its cached layout along
       return;
     }
   }
@@ -245,7 +287,7 @@ void cuda_drop(void *ptr, uint32_t gpu_index) {
     }
   }
   if (from_pool) {
-    ksm_invalidate_range((int)gpu_index, ptr, pool_bytes);  // the allocation's own bytes, not the pool's block
+    device_range_changes((int)gpu_index, ptr, pool_bytes);  // the allocation's own bytes, not the pool's block
     HX_CHECK(hipFreeAsync(ptr, nullptr));
     HX_CHECK(hipDeviceSynchronize());  // cudaFree synchronises; the memory is back in the pool for every stream
     return;
@@ -255,7 +297,7 @@ void cuda_drop(void *ptr, uint32_t gpu_index) {
     void *base = ptr;
     size_t bytes = 1;
     if (hipMemGetAddressRange(&base, &bytes, ptr) != hipSuccess) base = ptr, bytes = 1;
-    ksm_invalidate_range((int)gpu_index, base, bytes);
+    device_range_changes((int)gpu_index, base, bytes);
   }
   HX_CHECK(hipFree(ptr));
 }
@@ -568,10 +610,18 @@ void hip_convert_lwe_programmable_bootstrap_key_ntt64_split_async(void *stream, 
   const size_t bytes = polys * polynomial_size * sizeof(uint64_t);
   void *tmp = device_alloc_sync(bytes);
   HX_CHECK(hipMemcpyAsync(tmp, src, bytes, hipMemcpyHostToDevice, S(stream)));
+  device_range_changes((int)gpu_index, dest, bytes * NTT_SPLIT_LIMBS);
   launch_bsk_to_split(S(stream), polynomial_size, (const uint64_t *)tmp, dest, polys,
                       get_fft_tables(gpu_index, S(stream), polynomial_size));
-  HX_CHECK(hipStreamSynchronize(S(stream)));  // the staging buffer must outlive the kernel
+  // the key's NTT-domain twin (as many bytes as the standard key): what the integer kernel recomputes a flagged
+  // ciphertext with (hip_programmable_bootstrap_ntt64_split_async)
+  void *twin = device_alloc_sync(bytes);
+  launch_bsk_to_ntt(S(stream), polynomial_size, (const uint64_t *)tmp, twin, polys,
+                    get_ntt_tables(gpu_index, S(stream), polynomial_size));
+  HX_CHECK(hipStreamSynchronize(S(stream)));  // the staging buffer must outlive the kernels
   device_free_sync(tmp);
+  std::lock_guard<std::mutex> lock(g_twin_mutex);
+  g_split_twins.push_back(SplitTwin{(int)gpu_index, dest, bytes * NTT_SPLIT_LIMBS, twin});
 }
 void hip_programmable_bootstrap_ntt64_split_async(void *stream, uint32_t gpu_index, void *lwe_array_out,
                                                   void const *lwe_output_indexes, void const *lut_vector,
@@ -595,6 +645,7 @@ void hip_programmable_bootstrap_ntt64_split_async(void *stream, uint32_t gpu_ind
     // word 0: the round-off flag; words 64 .. 319: the per-XCD progress counters of the paced loop (PbsArgs::pace)
     b->split_flag = (uint32_t *)scratch_alloc((64 + 8 * 32) * sizeof(uint32_t));
     HX_CHECK(hipMemsetAsync(b->split_flag, 0, (64 + 8 * 32) * sizeof(uint32_t), S(stream)));
+    b->split_bad = (uint32_t *)scratch_alloc((size_t)b->max_samples * sizeof(uint32_t));
   }
   PbsArgs a = make_args(lwe_array_out, lwe_output_indexes, lut_vector, lut_vector_indexes, lwe_array_in,
                         lwe_input_indexes, bootstrapping_key, lwe_dimension, base_log, level_count, num_samples,
@@ -602,21 +653,50 @@ void hip_programmable_bootstrap_ntt64_split_async(void *stream, uint32_t gpu_ind
   a.acc_scratch = b->split_acc;
   a.roundoff_flag = b->split_flag;
   a.pace = b->split_flag + 64;
+  // A ciphertext whose f64 limb products were not within 1/4 of integers (the engine's round-off check: statistical bound,
+  // adversarial data can reach it — tests/test_split_engine_worst_case.py) is RECOMPUTED by the integer Goldilocks kernel
+  // on the same stream, with the key's NTT-domain twin: per sample a flag word, the second launch's workgroups return at
+  // once where it is 0 (a few microseconds for the launch when nothing was flagged).  Both compute ntt64_bnf_pbs.rs:208-280,
+  // so the outputs are the exact ones whatever the data; the status call counts the recomputed ciphertexts.
+  const void *twin = split_twin_of((int)gpu_index, bootstrapping_key);
+  if (twin != nullptr) {
+    HX_CHECK(hipMemsetAsync(b->split_bad, 0, (size_t)num_samples * sizeof(uint32_t), S(stream)));
+    a.bad_samples = b->split_bad;
+  } else {
+    b->split_unrecovered = true;  // a key this library did not convert (copied in by the caller): the flag stays fatal
+  }
   launch_pbs_ntt_split_wave(S(stream), a, b->fft);
+  if (twin != nullptr) {
+    PbsArgs r = a;
+    r.bsk = twin;
+    r.acc_scratch = nullptr;
+    r.roundoff_flag = nullptr;
+    r.bad_samples = nullptr;
+    r.pace = nullptr;
+    r.only_flagged = b->split_bad;
+    r.recomputed = b->split_flag + 1;
+    launch_pbs_ntt_generic(S(stream), polynomial_size, glwe_dimension, r, b->ntt);
+  }
   g_last_pbs_kernel.store(13);
 }
-// 1 if any launch of the split-key engine on this scratch since the last call saw an f64 product further than 1/4 from
-// an integer (its outputs are then not to be trusted), else 0; synchronises the stream and clears the flag
+// The number of ciphertexts the integer kernel had to recompute behind the split-key launches on this scratch since the last
+// call (their f64 limb products were further than 1/4 from integers: 0 on every real parameter set's data); the outputs are
+// the exact ones either way.  Synchronises the stream and clears the count.  Panics if the flag went up in a launch whose
+// key had no NTT-domain twin (a split key the caller copied instead of converting): those outputs cannot be trusted.
 uint32_t hip_programmable_bootstrap_ntt64_split_roundoff_status(void *stream, uint32_t gpu_index, int8_t *buffer) {
   set_device(gpu_index);
   PbsBuffer *b = reinterpret_cast<PbsBuffer *>(buffer);
   HX_PANIC_IF_FALSE(b != nullptr && b->magic == kPbsMagic, "roundoff_status: foreign scratch pointer");
   if (b->split_flag == nullptr) return 0;
-  uint32_t v = 0;
-  HX_CHECK(hipMemcpyAsync(&v, b->split_flag, sizeof(uint32_t), hipMemcpyDeviceToHost, S(stream)));
+  uint32_t v[2] = {0, 0};
+  HX_CHECK(hipMemcpyAsync(v, b->split_flag, sizeof(v), hipMemcpyDeviceToHost, S(stream)));
   HX_CHECK(hipStreamSynchronize(S(stream)));
-  if (v != 0) HX_CHECK(hipMemsetAsync(b->split_flag, 0, sizeof(uint32_t), S(stream)));
-  return v;
+  HX_PANIC_IF_FALSE(v[0] == 0 || !b->split_unrecovered,
+                    "split-key exact engine: an f64 limb product was further than 1/4 from an integer in a launch whose key has no "
+                    "NTT-domain twin (convert the key with hip_convert_lwe_programmable_bootstrap_key_ntt64_split_async) — its "
+                    "outputs are not the exact ones");
+  if (v[0] != 0 || v[1] != 0) HX_CHECK(hipMemsetAsync(b->split_flag, 0, sizeof(v), S(stream)));
+  return v[1];
 }
 
 // ---- reference-order f64 engine (pbs_ref64.hip): the key in tfhe-fft's dif4 transform order
@@ -689,17 +769,18 @@ void cleanup_cuda_programmable_bootstrap_64(void *stream, uint32_t gpu_index, in
   auto *b = reinterpret_cast<PbsBuffer *>(*pbs_buffer);
   HX_PANIC_IF_FALSE(b != nullptr && b->magic == kPbsMagic, "cleanup of a foreign PBS buffer");
   HX_CHECK(hipStreamSynchronize(S(stream)));  // cleanup_* synchronises (pbs_utilities.h:261-271)
-  if (b->split_flag) {
-    // the split-key exact engine's round-off flag is checked here even if nobody polled it: a caller that never asks
-    // hip_programmable_bootstrap_ntt64_split_roundoff_status (a C or Rust host) must not keep untrustworthy "exact" outputs
+  if (b->split_flag && b->split_unrecovered) {
+    // a launch of the split-key exact engine ran without the NTT-domain twin of its key: its round-off flag is checked here
+    // even if nobody polled it — a host that never asks must not keep untrustworthy "exact" outputs
     uint32_t v = 0;
     HX_CHECK(hipMemcpy(&v, b->split_flag, sizeof(uint32_t), hipMemcpyDeviceToHost));
     HX_PANIC_IF_FALSE(v == 0, "split-key exact engine: an f64 limb product was further than 1/4 from an integer in a launch on "
-                              "this scratch since the last status poll — its outputs are not the exact ones");
+                              "this scratch whose key has no NTT-domain twin — its outputs are not the exact ones");
   }
   if (b->acc_scratch) scratch_free(b->acc_scratch);
   if (b->split_acc) scratch_free(b->split_acc);
   if (b->split_flag) scratch_free(b->split_flag);
+  if (b->split_bad) scratch_free(b->split_bad);
   for (void *r : b->emit_retired) scratch_free(r);
   if (b->emit_a) scratch_free(b->emit_a);
   if (b->ks_out) scratch_free(b->ks_out);

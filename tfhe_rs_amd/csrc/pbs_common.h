@@ -34,6 +34,13 @@ struct PbsArgs {
   // exact engine, split-key form: set to 1 by a lane whose f64 product was not within 1/4 of an integer (the round-off
   // check of an FFT-based exact multiplication); read back by hip_programmable_bootstrap_ntt64_split_roundoff_status
   uint32_t *roundoff_flag = nullptr;
+  // ... and, per sample of the launch, a word that the same lane sets to 1 (null: not recorded).  The launch that follows on
+  // the same stream — the integer Goldilocks kernel with `only_flagged` pointing at these words and the NTT-domain key —
+  // recomputes exactly those ciphertexts (a workgroup whose word is 0 returns at once) and counts them in `recomputed`:
+  // the split-key entry point is exact whatever the data (ntt64_bnf_pbs.rs:208-280 is what both compute)
+  uint32_t *bad_samples = nullptr;
+  const uint32_t *only_flagged = nullptr;
+  uint32_t *recomputed = nullptr;
   // multi-bit throughput kernel only: 8 progress counters (one per XCD, 128 bytes apart), zeroed by the launch —
   // the workgroups of an XCD stay within a few groups of each other so that a group's key is fetched from HBM
   // once per XCD instead of once per workgroup

@@ -2149,8 +2149,11 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
     if ((worst & 1u) && a.roundoff_flag != nullptr) {
 #if defined(TFHE_HIPEMU)
       *a.roundoff_flag = 1u;
+      if (a.bad_samples != nullptr) a.bad_samples[sample] = 1u;
 #else
       __hip_atomic_store(a.roundoff_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // this ciphertext goes through the integer kernel that follows on the stream (PbsArgs::bad_samples)
+      if (a.bad_samples != nullptr) __hip_atomic_store(a.bad_samples + sample, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #endif
     }
     acc_load();

@@ -261,6 +261,10 @@ __global__ void __launch_bounds__(GenericCfg<N>::TPB) pbs_ntt_generic_kernel(Pbs
   uint64_t *nbuf = acc + (size_t)K1 * N;  // N
   const int tid = threadIdx.x;
   const uint32_t sample = blockIdx.x;
+  if (a.only_flagged != nullptr) {  // the recomputation behind a split-key launch: its flagged ciphertexts only
+    if (a.only_flagged[sample] == 0u) return;
+    if (tid == 0 && a.recomputed != nullptr) atomicAdd(a.recomputed, 1u);
+  }
   const uint64_t *lwe = a.lwe_in + (size_t)a.in_idx[sample] * (a.n + 1);
   const uint64_t *lut = a.lut + (size_t)a.lut_idx[sample] * K1 * N;
   const uint64_t *bsk = (const uint64_t *)a.bsk;
@@ -321,6 +325,10 @@ __global__ void __launch_bounds__(K1 *GenericCfg<N>::TPB) pbs_ntt_par_kernel(Pbs
   const int tid = threadIdx.x;
   const int grp = tid / TPB, lt = tid - grp * TPB;  // my row (forward) / column (inverse), thread inside it
   const uint32_t sample = blockIdx.x;
+  if (a.only_flagged != nullptr) {  // the recomputation behind a split-key launch: its flagged ciphertexts only
+    if (a.only_flagged[sample] == 0u) return;
+    if (tid == 0 && a.recomputed != nullptr) atomicAdd(a.recomputed, 1u);
+  }
   const uint64_t *lwe = a.lwe_in + (size_t)a.in_idx[sample] * (a.n + 1);
   const uint64_t *lut = a.lut + (size_t)a.lut_idx[sample] * K1 * N;
   const uint64_t *bsk = (const uint64_t *)a.bsk;
