@@ -428,7 +428,7 @@ def main():
             import torch
             torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
-        rank_ms = None
+        rank_ms = rank_kernel_ms = None
         if dist is not None:
             import torch
             t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -436,6 +436,10 @@ def main():
             every = [torch.zeros_like(t) for _ in range(world)]
             dist.all_gather(every, t)     # per-rank times for the line (16 bytes per rank; outside the timed region)
             rank_ms = [float(x.item()) / args.steps * 1e3 for x in every]
+            tk = torch.tensor([sum(kernel_ms) / len(kernel_ms)], dtype=torch.float64, device="cuda")
+            every_k = [torch.zeros_like(tk) for _ in range(world)]
+            dist.all_gather(every_k, tk)  # ... and every rank's HIP-event kernel time (its GPU's clock shows in it)
+            rank_kernel_ms = [float(x.item()) for x in every_k]
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         kernel_id = lib.hip_backend_last_pbs_kernel()
@@ -540,12 +544,21 @@ def main():
                    "parallelism": f"batch-sharded x{n_gpus}, key replicas, no collective", "launch": mode},
         "roofline": roofline,
     }
+    per_gpu_kernel_ms = None
     if per_gpu is not None:
         result["per_gpu"] = per_gpu
         result["fake_multi_gpu"] = fake
         result["per_gpu_ms_per_step"] = [g_["seconds"] / args.steps * 1e3 for g_ in per_gpu]
+        per_gpu_kernel_ms = [g_["kernel_ms_avg"] for g_ in per_gpu]
     elif launched and rank_ms is not None:
         result["per_gpu_ms_per_step"] = rank_ms
+        per_gpu_kernel_ms = rank_kernel_ms
+    if per_gpu_kernel_ms and roofline.get("shader_cycles_per_launch"):
+        # a launch is the same number of shader cycles on every GPU (profiles/r05_penalty_attribution.txt): a GPU's kernel time
+        # gives the clock it held — a scaling curve is to be read against these, not against PBS/s alone
+        cyc = roofline["shader_cycles_per_launch"]
+        result["per_gpu_kernel_ms"] = per_gpu_kernel_ms
+        result["per_gpu_sustained_clock_ghz"] = [cyc / (ms * 1e-3) / 1e9 for ms in per_gpu_kernel_ms]
     if args.scale_quick:
         # config 5 on this many GPUs: how many of them a KS -> PBS round of the radix layer would use under the reference's
         # thresholds (helper_multi_gpu.cu:39-101: a GPU is added per `threshold` blocks; classic = compute units + 1,
@@ -814,8 +827,26 @@ def main():
         ref = orc.pbs_batch(orc.ENGINE_FFT, cts[:count], lut, bsk_f, p.n, p.k, p.N, p.pbs_base_log, p.pbs_level, 1,
                             threads=cores)
         dt = time.perf_counter() - t0
+        # one PBS on one thread (SURVEY §8d / BASELINE.md §3: the latency next to the throughput), best of three
+        single_ms = None
+        for _ in range(3):
+            t1 = time.perf_counter()
+            orc.pbs_batch(orc.ENGINE_FFT, cts[:1], lut, bsk_f, p.n, p.k, p.N, p.pbs_base_log, p.pbs_level, 1, threads=1)
+            d1 = (time.perf_counter() - t1) * 1e3
+            single_ms = d1 if single_ms is None else min(single_ms, d1)
+        cpu_model = "unknown"
+        try:
+            for line in open("/proc/cpuinfo"):
+                if line.lower().startswith("model name"):
+                    cpu_model = line.split(":", 1)[1].strip()
+                    break
+        except OSError:
+            pass
         result["cpu_baseline"] = {
             "value": count / dt, "unit": "PBS/s", "cores": cores, "kind": "port",
+            "cpu_model": cpu_model, "host_threads_online": os.cpu_count(),
+            "single_thread_ms_per_pbs": single_ms,
+            "published_reference": {"ms_per_pbs": 5.64, "where": "tfhe-rs AVX-512 Rust, one EPYC 9R45 core (BASELINE.md)"},
             "sample": f"{count} PBS of the same batch through the C oracle's f64 FFT path (C restatement with AVX2 butterflies, "
                       f"OpenMP over LWEs, {cores} threads, {dt:.1f} s); the reference's AVX-512 Rust publishes "
                       f"5.64 ms/PBS on one EPYC 9R45 core",

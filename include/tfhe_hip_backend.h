@@ -524,6 +524,11 @@ void hip_backend_allocator_stats(uint32_t gpu_index, uint64_t *out7);
  * reference runs over its GPU tests, scripts/check_memory_errors.sh:1-60).  Returns the canary checks made so far
  * (0: the mode is off). */
 uint64_t hip_backend_redzone_checks(uint32_t gpu_index);
+/* TFHE_HIP_PROFILE=1 (environment, read once): the radix layer brackets its rounds with roctx ranges — "apply lut round",
+ * "keyswitch", "bootstrap", "scatter ... to gpu", "gather ... from gpu", "carry propagation", "integer mul", "block products",
+ * "column sums" — for rocprofv3 --marker-trace (the reference's NVTX ranges, tfhe-cuda-common/cuda/include/helper_profile.cuh,
+ * cuda/src/integer/integer.cuh:874,958,981).  Returns the ranges pushed so far (0: off). */
+uint64_t hip_backend_profile_ranges(void);
 /* test hook: cap of the groups the multi-bit latency path processes per pass (0 = what the scratch holds) */
 void hip_backend_set_multibit_latency_groups(uint32_t groups);
 /* keyswitch kernel: 0 = automatic (int8 matrix-core GEMM, any batch size, when level <= 16 (padded to a power of

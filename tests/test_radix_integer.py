@@ -427,3 +427,40 @@ def test_multiplication_by_an_encrypted_boolean(kind):
         cb = igpu.CudaUnsignedRadixCiphertext.from_blocks(encrypt_big(p, keys, conds, seed=52).reshape(len(vals), 1, -1), st)
         out = sks.mul_by_boolean_assign(ct, cb, st, boolean_is_left=left)
         assert recompose(decrypt_blocks(p, keys, out.to_blocks(st))) == [v * k for v, k in zip(vals, conds)], left
+
+
+def test_profile_ranges_bracket_the_rounds_of_an_addition():
+    """TFHE_HIP_PROFILE=1: the radix layer pushes a named range around every round, keyswitch, bootstrap and carry propagation
+    (csrc/profile.h; the reference: PUSH_RANGE("apply lut") / ("scatter") / ("gather"), cuda/src/integer/integer.cuh:874,958,981
+    over tfhe-cuda-common/cuda/include/helper_profile.cuh).  In its own interpreter (the switch is read once); without the
+    switch nothing is pushed.  The host-emulation build has no roctx library to hand the ranges to: they are counted."""
+    import os
+    import subprocess
+    import sys
+    import textwrap
+    from .harness import EMU_LIB, build_emu
+    build_emu()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent("""
+        import sys
+        sys.path.insert(0, %r)
+        import numpy as np
+        from tests.test_radix_integer import setup, encrypt_radix, decrypt_blocks, recompose
+        p, keys, st, sks, igpu = setup("emu")
+        from tfhe_rs_amd import ffi
+        lib = ffi.default_library()
+        before = lib.hip_backend_profile_ranges()
+        a, b, L = [1234567], [7654321], 12
+        ca = igpu.CudaUnsignedRadixCiphertext.from_blocks(encrypt_radix(p, keys, a, L, 21), st)
+        cb = igpu.CudaUnsignedRadixCiphertext.from_blocks(encrypt_radix(p, keys, b, L, 22), st)
+        sks.add_assign(ca, cb, st)
+        assert recompose(decrypt_blocks(p, keys, ca.to_blocks(st))) == [(a[0] + b[0]) %% (1 << 24)]
+        print("ranges", before, lib.hip_backend_profile_ranges())
+        """ % root)
+    for switch, expect_some in (("1", True), ("0", False)):
+        env = dict(os.environ, TFHE_HIP_BACKEND_LIB=EMU_LIB, TFHE_HIP_PROFILE=switch, TFHE_HIP_PROFILE_QUIET="1")
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        before, after = [int(x) for x in r.stdout.split("ranges")[1].split()]
+        # one carry propagation = 1 range + per round (1 + keyswitch + bootstrap): at least 3 rounds for 12 blocks
+        assert (after - before >= 10) if expect_some else (after == before == 0), r.stdout

@@ -3,6 +3,7 @@
 #include "../../include/tfhe_hip_backend.h"
 #include "kernels.h"
 #include "arena.h"
+#include "profile.h"
 
 #include <atomic>
 #include <cstdlib>
@@ -1104,6 +1105,7 @@ void hip_backend_allocator_stats(uint32_t gpu_index, uint64_t *out7) {
   out7[4] = s.cross_stream_waits; out7[5] = s.live_bytes; out7[6] = s.cached_bytes;
 }
 uint64_t hip_backend_redzone_checks(uint32_t gpu_index) { return arena_redzone_checks((int)gpu_index); }
+uint64_t hip_backend_profile_ranges(void) { return profile_range_count(); }
 void hip_backend_set_keyswitch_kernel(uint32_t which) {
   g_keyswitch_use_mfma.store(which != 1);
   g_keyswitch_split_digits.store(which != 2);

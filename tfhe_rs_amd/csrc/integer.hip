@@ -18,6 +18,7 @@
 //     ciphertext is ever moved to be "aligned" for a round.
 #include "kernels.h"
 #include "arena.h"
+#include "profile.h"
 #include "../../include/tfhe_hip_backend.h"
 
 #include <algorithm>
@@ -285,8 +286,12 @@ struct LutDriver {
   void ks_pbs(hipStream_t st, const PerGpu &g, uint64_t *out, const uint64_t *out_idx, const uint64_t *in,
               const uint64_t *in_idx, const uint64_t *lut_idx, uint32_t c, const void *ksk, const void *bsk,
               uint32_t many = 1, uint32_t stride = 0) const {
-    cuda_keyswitch_lwe_ciphertext_vector_64_64_async(st, g.gpu, g.d_ks, g.d_trivial, in, in_idx, ksk, p.big_n, p.small_n,
-                                                     p.ks_base_log, p.ks_level, c);
+    {
+      HX_RANGE("keyswitch (%u blocks, gpu %u)", c, g.gpu);
+      cuda_keyswitch_lwe_ciphertext_vector_64_64_async(st, g.gpu, g.d_ks, g.d_trivial, in, in_idx, ksk, p.big_n, p.small_n,
+                                                       p.ks_base_log, p.ks_level, c);
+    }
+    HX_RANGE("bootstrap (%u blocks, %u functions, gpu %u)", c, many, g.gpu);
     if (p.grouping)
       cuda_multi_bit_programmable_bootstrap_64_async(st, g.gpu, out, out_idx, g.d_luts, lut_idx, g.d_ks, g.d_trivial, bsk,
                                                      g.pbs_buf, p.small_n, p.k, p.N, p.grouping, p.pbs_base_log,
@@ -329,6 +334,7 @@ struct LutDriver {
                       "radix layer: a round of %u functions per bootstrap on a driver created for %u", many, many_max);
     const uint32_t avail = std::min<uint32_t>(s.gpu_count, (uint32_t)gpus.size());
     const hipStream_t st0 = (hipStream_t)s.streams[0];
+    HX_RANGE("apply lut round (%u blocks)", count);  // integer.cuh:874
     for (uint32_t off = 0; off < count; off += cap) {
       const uint32_t c = std::min(cap, count - off);
       // helper_multi_gpu.cu:39-48 (get_active_gpu_count): as many GPUs as the round can keep busy
@@ -345,6 +351,7 @@ struct LutDriver {
         const hipStream_t sti = (hipStream_t)s.streams[i];
         const uint32_t ci = num_inputs_on_gpu(c, i, active);
         if (ci == 0) continue;
+        HX_RANGE("scatter %u blocks to gpu %u", ci, g.gpu);  // integer.cuh:958 (the range covers the shard's launches too)
         HX_CHECK(hipSetDevice((int)gpus[0].gpu));
         if (ii)
           axpy(st0, g.d0_in, nullptr, in0, ii + begin, 1, nullptr, nullptr, (uint32_t)w, ci);
@@ -391,6 +398,7 @@ struct LutDriver {
         const PerGpu &g = gpus[i];
         const uint32_t ci = num_inputs_on_gpu(c, i, active);
         if (ci == 0) continue;
+        HX_RANGE("gather %u blocks from gpu %u", ci, g.gpu);  // integer.cuh:981
         HX_CHECK(hipStreamWaitEvent(st0, g.done, 0));
         if (!g.direct)
           HX_CHECK(hipMemcpyAsync(g.d0_out, h_out(g), (size_t)many * ci * w * sizeof(uint64_t), hipMemcpyHostToDevice, st0));
@@ -813,6 +821,7 @@ struct PropagateMem {
     const Params &p = drv.p;
     const uint32_t w = p.big_n + 1, T = cts * blocks;
     const size_t top = up.size();
+    HX_RANGE("carry propagation: %u integers of %u blocks", cts, blocks);
     if (carry_in) axpy(st, v, rIO.a, v, rIO.a, 1, carry_in, nullptr, w, cts);
     if (overflow_out)  // 8 o1 + 4 o0 of every integer, from the operands' last blocks
       drv.round(ss, d_pool, rOvfPrep.o, d_pack, nullptr, rOvfPrep.lut, cts, ksks, bsks);
@@ -1110,10 +1119,15 @@ struct MulMem {
         build_pass(st, nb);
       }
       // block products
-      axpy(st, d_pack, nullptr, l0, pass.pa, p.msg, r0, pass.pb, w, (uint32_t)(nb * n_prod));
-      drv.round(ss, d_pool, pass.po, d_pack, nullptr, pass.pl, (uint32_t)(nb * n_prod), ksks, bsks);
+      HX_RANGE("integer mul: %u integers of %u blocks", nb, L);
+      {
+        HX_RANGE("block products");
+        axpy(st, d_pack, nullptr, l0, pass.pa, p.msg, r0, pass.pb, w, (uint32_t)(nb * n_prod));
+        drv.round(ss, d_pool, pass.po, d_pack, nullptr, pass.pl, (uint32_t)(nb * n_prod), ksks, bsks);
+      }
       for (const auto &si : pass.steps) {  // column sums
         if (si.groups == 0) continue;
+        HX_RANGE("column sums (%u groups)", si.groups);
         HX_LAUNCH(lwe_group_sum_kernel, dim3(si.groups), dim3(256), 0, st, d_sum, d_pool, si.off, si.mem, w, si.groups);
         drv.round(ss, d_pool, si.out, d_sum, si.in, si.lut, si.count, ksks, bsks);
       }

@@ -127,6 +127,7 @@ SIGNATURES = {
     "hip_backend_trim_allocator": (_u64, [_u32]),
     "hip_backend_allocator_stats": (None, [_u32, C.POINTER(C.c_uint64)]),
     "hip_backend_redzone_checks": (_u64, [_u32]),
+    "hip_backend_profile_ranges": (_u64, []),
     "hip_backend_version": (C.c_char_p, []),
     "hip_event_create": (_v, []),
     "hip_event_record": (None, [_v, _v]),
