@@ -118,6 +118,28 @@ HX_DEV void bfly_mi_fma(cplx &a, cplx &b) {
   a.im = o1i;
 }
 
+#ifndef W3_PROBE
+#define W3_PROBE 0
+#endif
+// timing probe: what an exchange of three register bits with lane bits would cost as 48 lane swaps
+HX_DEV void w3_probe_swaps(cplx (&d)[8]) {
+  HX_UNROLL
+  for (int rep = 0; rep < 3; ++rep)
+    HX_UNROLL
+    for (int r = 0; r < 4; ++r) {
+      uint32_t a[4], b[4];
+      __builtin_memcpy(a, &d[r], 16);
+      __builtin_memcpy(b, &d[r + 4], 16);
+      HX_UNROLL
+      for (int k = 0; k < 4; ++k) {
+        if (rep == 1) hx_permlane16_swap(a[k], b[k]);
+        else hx_permlane32_swap(a[k], b[k]);
+      }
+      __builtin_memcpy(&d[r], a, 16);
+      __builtin_memcpy(&d[r + 4], b, 16);
+    }
+}
+
 struct Ctx {
   cplx *buf;      // my exchange buffer
   const cplx *T;  // table
@@ -180,17 +202,24 @@ HX_DEV void forward(cplx (&d)[8], Ctx c, const Resident3 *res = nullptr) {
     stage8<0>(d, [&](int r) { return w2[r >> 1]; });
     HX_SCHED_FENCE();
   }
+#if !(W3_PROBE & 1)  // timing probe (wrong results): bit 0 = no LA <-> LB transpositions, bit 1 = their cost as lane swaps
   {
     cplx *pa = c.buf + lane;  // LA slots of P1
     HX_UNROLL
     for (int r = 0; r < 8; ++r) pa[72 * r] = d[r];
   }
   HX_WAVE_SYNC();
+#endif
+#if W3_PROBE & 2
+  w3_probe_swaps(d);
+#endif
   {  // stages 3..5: position bits 5, 4, 3; group = hi3 . (register bits above)
+#if !(W3_PROBE & 1)
     const cplx *pb = c.buf + hi3 * 72 + lo3;  // LB slots of P1
     HX_UNROLL
     for (int r = 0; r < 8; ++r) d[r] = pb[8 * r];
     HX_WAVE_SYNC();
+#endif
     const cplx w3 = RES >= 1 ? res->f3 : T[T_FB3 + hi3];
     stage8<2>(d, [&](int) { return w3; });
     HX_SCHED_FENCE();
@@ -277,16 +306,23 @@ HX_DEV void inverse_accumulate(cplx (&o)[8], uint64_t (&acc_re)[8], uint64_t (&a
     for (int q = 0; q < 4; ++q) w32[q] = RES >= 2 ? res->i32[q] : T[T_INV + 32 + 8 * q + lo3];
     stage8<2>(o, [&](int r) { return w32[r & 3]; });
     HX_SCHED_FENCE();
+#if !(W3_PROBE & 1)
     cplx *pb = c.buf + hi3 * 72 + lo3;  // LB slots of P1
     HX_UNROLL
     for (int r = 0; r < 8; ++r) pb[8 * r] = o[r];
+#endif
   }
   HX_WAVE_SYNC();
+#if W3_PROBE & 2
+  w3_probe_swaps(o);
+#endif
   {  // half = 64, 128, 256: position bits 6, 7, 8 = register bits 0, 1, 2 in LA; j = (register bits below) . lane
+#if !(W3_PROBE & 1)
     const cplx *pa = c.buf + lane;  // LA slots of P1
     HX_UNROLL
     for (int r = 0; r < 8; ++r) o[r] = pa[72 * r];
     HX_WAVE_SYNC();
+#endif
     const cplx w64 = T[T_INV + 64 + lane];
     stage8<0>(o, [&](int) { return w64; });
     HX_SCHED_FENCE();
