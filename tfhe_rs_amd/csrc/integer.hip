@@ -452,6 +452,9 @@ static hipStream_t S0(const CudaStreamsFFI &s) {
   return (hipStream_t)s.streams[0];
 }
 static uint32_t G0(const CudaStreamsFFI &s) { return s.gpu_indexes ? s.gpu_indexes[0] : 0; }
+// every entry point of the radix layer starts on the first GPU of its stream set: scratch_alloc / scratch_free and the index
+// uploads act on the thread's CURRENT device, which a host alternating between GPUs may have left elsewhere
+static void first_gpu(const CudaStreamsFFI &s) { HX_CHECK(hipSetDevice((int)G0(s))); }
 
 // ------------------------------------------------------------------ apply a univariate LUT
 struct ApplyLutMem {
@@ -1242,6 +1245,7 @@ uint64_t scratch_cuda_apply_univariate_lut_64_async(CudaStreamsFFI streams, int8
                                                     uint32_t carry_modulus, uint64_t lut_degree,
                                                     bool allocate_gpu_memory,
                                                     enum PBS_MS_REDUCTION_T noise_reduction_type) {
+  first_gpu(streams);
   return scratch_apply_lut(streams, mem_ptr, input_lut, bsk_params, ksk_params, input_lwe_ciphertext_count,
                            message_modulus, carry_modulus, 1, lut_degree, allocate_gpu_memory,
                            (uint32_t)noise_reduction_type);
@@ -1256,6 +1260,7 @@ uint64_t scratch_cuda_apply_many_univariate_lut_64_async(CudaStreamsFFI streams,
                                                          uint32_t carry_modulus, uint32_t num_many_lut,
                                                          uint64_t lut_degree, bool allocate_gpu_memory,
                                                          enum PBS_MS_REDUCTION_T noise_reduction_type) {
+  first_gpu(streams);
   return scratch_apply_lut(streams, mem_ptr, input_lut, bsk_params, ksk_params, num_radix_blocks, message_modulus,
                            carry_modulus, num_many_lut, lut_degree, allocate_gpu_memory, (uint32_t)noise_reduction_type);
 }
@@ -1263,6 +1268,7 @@ uint64_t scratch_cuda_apply_many_univariate_lut_64_async(CudaStreamsFFI streams,
 void cuda_apply_univariate_lut_64_async(CudaStreamsFFI streams, CudaRadixCiphertextFFI *output_radix_lwe,
                                         CudaRadixCiphertextFFI const *input_radix_lwe, int8_t *mem_ptr,
                                         void *const *ksks, void *const *bsks) {
+  first_gpu(streams);
   auto *m = reinterpret_cast<ApplyLutMem *>(mem_ptr);
   HX_PANIC_IF_FALSE(m && m->magic == ApplyLutMem::kMagic, "apply_univariate_lut: foreign scratch pointer");
   HX_PANIC_IF_FALSE(!m->size_only, "apply_univariate_lut: scratch was created with allocate_gpu_memory=false");
@@ -1282,6 +1288,7 @@ void cuda_apply_univariate_lut_64_async(CudaStreamsFFI streams, CudaRadixCiphert
 }
 
 void cleanup_cuda_apply_univariate_lut_64(CudaStreamsFFI streams, int8_t **mem_ptr_void) {
+  first_gpu(streams);
   auto *m = reinterpret_cast<ApplyLutMem *>(*mem_ptr_void);
   HX_PANIC_IF_FALSE(m && m->magic == ApplyLutMem::kMagic, "cleanup apply_univariate_lut: foreign scratch pointer");
   m->drv.release(streams);
@@ -1296,6 +1303,7 @@ void cuda_apply_many_univariate_lut_64_async(CudaStreamsFFI streams, CudaRadixCi
                                              CudaRadixCiphertextFFI const *input_radix_lwe, int8_t *mem_ptr,
                                              void *const *ksks, void *const *bsks, uint32_t num_luts,
                                              uint32_t lut_stride) {
+  first_gpu(streams);
   auto *m = reinterpret_cast<ApplyLutMem *>(mem_ptr);
   HX_PANIC_IF_FALSE(m && m->magic == ApplyLutMem::kMagic, "apply_many_univariate_lut: foreign scratch pointer");
   HX_PANIC_IF_FALSE(!m->size_only, "apply_many_univariate_lut: scratch was created with allocate_gpu_memory=false");
@@ -1319,6 +1327,7 @@ void cuda_apply_many_univariate_lut_64_async(CudaStreamsFFI streams, CudaRadixCi
 }
 
 void cleanup_cuda_apply_many_univariate_lut_64(CudaStreamsFFI streams, int8_t **mem_ptr_void) {
+  first_gpu(streams);
   cleanup_cuda_apply_univariate_lut_64(streams, mem_ptr_void);
 }
 
@@ -1381,6 +1390,7 @@ uint64_t scratch_cuda_propagate_single_carry_64_inplace_async(CudaStreamsFFI str
                                                               uint32_t carry_modulus, uint32_t requested_flag,
                                                               bool allocate_gpu_memory,
                                                               enum PBS_MS_REDUCTION_T noise_reduction_type) {
+  first_gpu(streams);
   HX_PANIC_IF_FALSE(requested_flag <= 2, "propagate_single_carry: unknown output flag %u", requested_flag);
   const Params p = make_params(bsk_params, ksk_params, message_modulus, carry_modulus, (uint32_t)noise_reduction_type);
   t_dry = !allocate_gpu_memory;
@@ -1406,6 +1416,7 @@ void cuda_propagate_single_carry_64_inplace_async(CudaStreamsFFI streams, CudaRa
                                                   const CudaRadixCiphertextFFI *carry_in, int8_t *mem_ptr,
                                                   void *const *bsks, void *const *ksks, uint32_t requested_flag,
                                                   uint32_t uses_carry) {
+  first_gpu(streams);
   auto *m = reinterpret_cast<PropagateMem *>(mem_ptr);
   HX_PANIC_IF_FALSE(m && m->magic == PropagateMem::kMagic, "propagate_single_carry: foreign scratch pointer");
   HX_PANIC_IF_FALSE(!m->size_only, "propagate_single_carry: scratch was created with allocate_gpu_memory=false");
@@ -1450,6 +1461,7 @@ void cuda_add_and_propagate_single_carry_64_inplace_async(CudaStreamsFFI streams
                                                           const CudaRadixCiphertextFFI *carry_in, int8_t *mem_ptr,
                                                           void *const *bsks, void *const *ksks,
                                                           uint32_t requested_flag, uint32_t uses_carry) {
+  first_gpu(streams);
   if (requested_flag != 1) {
     cuda_add_lwe_ciphertext_vector_inplace_64(streams.streams[0], G0(streams), lhs_array, rhs_array);
     cuda_propagate_single_carry_64_inplace_async(streams, lhs_array, carry_out, carry_in, mem_ptr, bsks, ksks,
@@ -1499,6 +1511,7 @@ void cuda_add_and_propagate_single_carry_64_inplace_async(CudaStreamsFFI streams
 }
 
 void cleanup_cuda_propagate_single_carry_64_inplace(CudaStreamsFFI streams, int8_t **mem_ptr_void) {
+  first_gpu(streams);
   auto *m = reinterpret_cast<PropagateMem *>(*mem_ptr_void);
   HX_PANIC_IF_FALSE(m && m->magic == PropagateMem::kMagic, "cleanup propagate_single_carry: foreign scratch pointer");
   m->release(streams);
@@ -1506,6 +1519,7 @@ void cleanup_cuda_propagate_single_carry_64_inplace(CudaStreamsFFI streams, int8
   *mem_ptr_void = nullptr;
 }
 void cleanup_cuda_add_and_propagate_single_carry_64_inplace(CudaStreamsFFI streams, int8_t **mem_ptr_void) {
+  first_gpu(streams);
   cleanup_cuda_propagate_single_carry_64_inplace(streams, mem_ptr_void);
 }
 
@@ -1517,6 +1531,7 @@ uint64_t scratch_cuda_integer_mult_inplace_64_async(CudaStreamsFFI streams, int8
                                                     CudaLweKeyswitchKeyParamsFFI ksk_params, uint32_t num_blocks,
                                                     bool allocate_gpu_memory,
                                                     enum PBS_MS_REDUCTION_T noise_reduction_type) {
+  first_gpu(streams);
   const Params p = make_params(bsk_params, ksk_params, message_modulus, carry_modulus, (uint32_t)noise_reduction_type);
   t_dry = !allocate_gpu_memory;
   t_bytes = 0;
@@ -1540,6 +1555,7 @@ void cuda_integer_mult_inplace_64_async(CudaStreamsFFI streams, CudaRadixCiphert
                                         bool const is_bool_left, CudaRadixCiphertextFFI const *radix_lwe_right,
                                         bool const is_bool_right, void *const *bsks, void *const *ksks,
                                         int8_t *mem_ptr, uint32_t polynomial_size, uint32_t num_blocks) {
+  first_gpu(streams);
   if (is_bool_left || is_bool_right) {
     // multiplication.cuh:508-520: the boolean operand is ONE block (here: one per integer of the batch, packed at the
     // start of its ciphertext); the other operand's blocks are kept or zeroed.  In place on radix_lwe_inout, which
@@ -1590,6 +1606,7 @@ void cuda_integer_mult_inplace_64_async(CudaStreamsFFI streams, CudaRadixCiphert
 }
 
 void cleanup_cuda_integer_mult_inplace_64(CudaStreamsFFI streams, int8_t **mem_ptr_void) {
+  first_gpu(streams);
   if (*mem_ptr_void && reinterpret_cast<BoolMulMem *>(*mem_ptr_void)->magic == BoolMulMem::kMagic) {
     auto *bm = reinterpret_cast<BoolMulMem *>(*mem_ptr_void);
     bm->release(streams);

@@ -812,7 +812,10 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
     // ragged last workgroup redo the last ciphertext and write nothing
     if (!valid) sample = a.num_samples - 1;
   } else {
-    if (!valid) return;  // whole pair leaves together; no later block barrier
+    // the whole pair leaves together.  Bare s_barriers further down (split-key loop, WAVE_CLASSIC_SYNC) stay correct: a
+    // terminated wave no longer counts towards a workgroup barrier on gfx9, every surviving wave runs the same trip count in
+    // front of its a_hat == 0 skip, and those loops are instantiated with SHARE = OCTET = false only (see the static_asserts)
+    if (!valid) return;
   }
   const uint64_t *lwe = a.lwe_in + (size_t)a.in_idx[sample] * (a.n + 1);
   const uint64_t *lut = a.lut + (size_t)a.lut_idx[sample] * 2 * N + (size_t)w * N;

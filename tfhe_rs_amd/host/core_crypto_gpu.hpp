@@ -216,7 +216,14 @@ class CudaVec {
   }
   CudaVec(const CudaVec &) = delete;
   CudaVec &operator=(const CudaVec &) = delete;
-  ~CudaVec() { release(); }  // vec.rs:487-495 (Drop: cuda_drop per GPU — stream-ordered behind the owner's stream for a new_async vector)
+  // vec.rs:487-495 (Drop: cuda_drop per GPU).  CONTRACT (differs from the reference, whose cudaFree synchronises the device):
+  // the drop is stream-ordered behind the stream the vector was ALLOCATED for (stream_index of new_async / from_cpu_async)
+  // and behind nothing else.  A vector that was also used on another stream — another stream_index, another CudaStreams set,
+  // a stream of the caller's own — must have that work synchronised (CudaStreams::synchronize, an event the owner stream
+  // waits for) before it goes out of scope; the next owner of its memory may otherwise start while that work still runs
+  // (csrc/arena.hip records the re-use event on the owner stream only).  Every wrapper of this header that hands a vector
+  // to several streams (the multi-GPU radix rounds) synchronises them before it returns.
+  ~CudaVec() { release(); }
 
  private:
   static uint64_t bytes_of(size_t n) { return n ? (uint64_t)n * sizeof(T) : 8; }
