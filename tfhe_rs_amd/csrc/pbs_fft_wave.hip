@@ -212,7 +212,7 @@
 // multi-bit loops, the split-key exact engine (measured slower with literals: 150.3 -> 156.0 ms per 4096 — the kernel
 // already spills, the literals' scalar moves add to it)
 #ifndef WAVE_LIT_MB
-#define WAVE_LIT_MB 1
+#define WAVE_LIT_MB 2  // 1: plain literals, 2: literals made where they are used (lit_cplx)
 #endif
 #ifndef WAVE_SPLIT_EARLY_RESTORE
 // split-key engine: handshakes posted early / waited for late (see the limb step).  Same box, ms per 4096: 115.28 -> 114.73
@@ -318,6 +318,21 @@ constexpr double LIT_F1[8][2] = {{0x1.6a09e667f3bcdp-1, 0x1.6a09e667f3bcdp-1}, {
                                  {0x1.c38b2f180bdb1p-1, 0x1.e2b5d3806f63bp-2}, {0x1.294062ed59f06p-2, 0x1.e9f4156c62ddap-1}};
 constexpr double LIT_E64[4][2] = {{1.0, 0.0}, {0x1.d906bcf328d46p-1, -0x1.87de2a6aea963p-2},
                                   {0x1.6a09e667f3bcdp-1, -0x1.6a09e667f3bcdp-1}, {0x1.87de2a6aea963p-2, -0x1.d906bcf328d46p-1}};
+// A literal twiddle whose scalar registers are made where it is used (LIT = 2): the two dwords are OR-ed with a scalar zero that
+// the compiler cannot see through (HX_OPAQUE_S on it at the top of the transform), so the moves are not hoisted out of the
+// group loop — hoisted, the twelve literals of the two transforms hold 48 scalar registers for the whole kernel (multi-bit
+// OCTET kernels: 48 / 74 spilled SGPRs, a v_readlane per use).  LIT = 1: plain literals (the classic loop: its scalar file has room).
+HX_DEV cplx lit_cplx(double re, double im, uint32_t z) {
+#if defined(TFHE_HIPEMU)
+  (void)z;
+  return cplx{re, im};
+#else
+  const uint64_t br = __builtin_bit_cast(uint64_t, re), bi = __builtin_bit_cast(uint64_t, im);
+  const uint64_t r2 = ((uint64_t)((uint32_t)(br >> 32) | z) << 32) | ((uint32_t)br | z);
+  const uint64_t i2 = ((uint64_t)((uint32_t)(bi >> 32) | z) << 32) | ((uint32_t)bi | z);
+  return cplx{__builtin_bit_cast(double, r2), __builtin_bit_cast(double, i2)};
+#endif
+}
 HX_DEV cplx times_i(const cplx c) { return cplx{-c.im, c.re}; }
 HX_DEV cplx times_mi(const cplx c) { return cplx{c.im, -c.re}; }
 HX_DEV cplx ldg_c(const double *t, int idx) { return cplx{t[2 * idx], t[2 * idx + 1]}; }
@@ -460,13 +475,15 @@ HX_DEV void load_resident_twiddles(ResidentTwiddles &t, const cplx *T, int lane)
 // ---- forward transform of 16 points per lane: mapping M1 in, mapping M3 out (and stored in my buffer)
 //   F1 stages 0..3 (position bits 9..6, registers) -> permlane swaps -> F2 stages 4,5 (bits 5,4, registers)
 //   -> LDS transposition MX -> M3 -> F3 stages 6..9 (bits 3..0, registers)
-template <int RES = 0, bool LIT = false>
+template <int RES = 0, int LIT = 0>
 HX_DEV void wave_forward(cplx (&d)[16], WaveCtx c, const ResidentTwiddles *res = nullptr) {
   HX_OPAQUE(c.lane);
+  uint32_t zlit = 0;
+  if constexpr (LIT == 2) HX_OPAQUE_S(zlit);
   const int lane = c.lane, g4 = c.lane >> 4;
   const cplx *T = c.T;
   {  // pass F1: the same twiddles in every lane of every launch
-    auto tw = [&](int x) { return LIT ? cplx{LIT_F1[x][0], LIT_F1[x][1]} : T[T_F1 + x]; };
+    auto tw = [&](int x) { return LIT == 2 ? lit_cplx(LIT_F1[x][0], LIT_F1[x][1], zlit) : LIT ? cplx{LIT_F1[x][0], LIT_F1[x][1]} : T[T_F1 + x]; };
     const cplx w0 = tw(0);
     stage<3>(d, [&](int) { return w0; });
     const cplx e1 = tw(1);
@@ -541,10 +558,10 @@ HX_DEV void inverse_pass1_group(cplx (&o)[16], int g) {
 
 // inverse stage half = 4 (position bit 2 = r bit 2, twiddle E[128 (r & 1)], times -i for r & 2) on the points
 // r0 .. r0 + 7 (r0 = 0 or 8): literal or table twiddles, same butterflies either way
-template <bool LIT>
-HX_DEV void inverse_stage_half4(cplx (&o)[16], int r0, const cplx *T) {
-  if constexpr (LIT) {
-    const cplx a1{LIT_E64[2][0], LIT_E64[2][1]};
+template <int LIT>
+HX_DEV void inverse_stage_half4(cplx (&o)[16], int r0, const cplx *T, uint32_t zlit = 0) {
+  if constexpr (LIT != 0) {
+    const cplx a1 = LIT == 2 ? lit_cplx(LIT_E64[2][0], LIT_E64[2][1], zlit) : cplx{LIT_E64[2][0], LIT_E64[2][1]};
     HX_UNROLL
     for (int r = r0; r < r0 + 4; ++r) {
       if ((r & 3) == 0) bfly_one(o[r], o[r | 4]);
@@ -573,7 +590,7 @@ HX_DEV void inverse_stage_half4(cplx (&o)[16], int r0, const cplx *T) {
 struct WaveNoHook {
   HX_DEV void operator()() const {}
 };
-template <int PASS1_DONE, bool OVERWRITE = false, bool NEG = false, bool RAW = false, int RES = 0, bool LIT = false,
+template <int PASS1_DONE, bool OVERWRITE = false, bool NEG = false, bool RAW = false, int RES = 0, int LIT = 0,
           class BeforeStore = WaveNoHook, class AfterLoad = WaveNoHook>
 HX_DEV void wave_inverse_accumulate(cplx (&o)[16], uint64_t (&acc_re)[16], uint64_t (&acc_im)[16], WaveCtx c,
                                     const ResidentTwiddles *res = nullptr, BeforeStore before_store = BeforeStore{},
@@ -588,15 +605,17 @@ HX_DEV void wave_inverse_accumulate(cplx (&o)[16], uint64_t (&acc_re)[16], uint6
   // pass I1 (continued): stages half = 4, 8 over position bits 2, 3 (= r bits 2, 3); j = r & 3, r & 7, so the
   // twiddles are the same in every lane: E[j*128] and E[j*64]
   {
-    inverse_stage_half4<LIT>(o, 0, T);
-    inverse_stage_half4<LIT>(o, 8, T);
+    uint32_t zlit = 0;
+    if constexpr (LIT == 2) HX_OPAQUE_S(zlit);
+    inverse_stage_half4<LIT>(o, 0, T, zlit);
+    inverse_stage_half4<LIT>(o, 8, T, zlit);
     HX_SCHED_FENCE();
     before_store();
     cplx *p3 = c.buf + base_m3(c);  // transposition M3 -> MX, store side
-    if constexpr (LIT) {
+    if constexpr (LIT != 0) {
       HX_UNROLL
       for (int r = 0; r < 8; ++r) {  // stage half = 8: twiddle E[64 (r & 3)], times -i for r & 4
-        const cplx e{LIT_E64[r & 3][0], LIT_E64[r & 3][1]};
+        const cplx e = LIT == 2 ? lit_cplx(LIT_E64[r & 3][0], LIT_E64[r & 3][1], zlit) : cplx{LIT_E64[r & 3][0], LIT_E64[r & 3][1]};
         if (r == 0) bfly_one(o[r], o[r | 8]);
         else if (r == 4) bfly_mi(o[r], o[r | 8]);
         else bfly(o[r], o[r | 8], (r & 4) ? times_mi(e) : e);
@@ -1379,7 +1398,7 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
         }
         MBP(1);
         HX_PRIO(WAVE_PRIO_MB_B);
-        wave_forward<0, WAVE_LIT_MB != 0>(d, ctx);
+        wave_forward<0, WAVE_LIT_MB>(d, ctx);
         MBP(2);
         HX_PRIO(WAVE_PRIO_MB_C);
         if constexpr (OCTET && LEVEL_CT != 1) {
@@ -1914,7 +1933,7 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
 #endif
       MBP(6);
       HX_PRIO(WAVE_PRIO_MB_D);
-      wave_inverse_accumulate<0, true, false, false, 0, WAVE_LIT_MB != 0>(o, acc_re, acc_im, ctx);
+      wave_inverse_accumulate<0, true, false, false, 0, WAVE_LIT_MB>(o, acc_re, acc_im, ctx);
       HX_PRIO(WAVE_PRIO_MB_K);
       MBP(7);
 #if !WAVE_MB_PACE_AT_KEY
