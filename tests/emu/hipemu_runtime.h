@@ -28,6 +28,7 @@ static inline int hipemu_stream_device(hipStream_t s) { return s ? *(int *)s : h
 static inline hipError_t hipStreamCreate(hipStream_t *s) { *s = malloc(8); *(int *)*s = hipemu_current_device; return hipSuccess; }
 static inline hipError_t hipStreamDestroy(hipStream_t s) { free(s); return hipSuccess; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipStreamQuery(hipStream_t) { return hipSuccess; }
 static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 static inline hipError_t hipMalloc(void **p, size_t n) { *p = n ? aligned_alloc(256, (n + 255) & ~(size_t)255) : nullptr; return hipSuccess; }
 static inline hipError_t hipMallocAsync(void **p, size_t n, hipStream_t) { return hipMalloc(p, n); }

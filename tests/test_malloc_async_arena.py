@@ -123,6 +123,54 @@ def test_a_block_changes_streams_in_stream_order():
 
 
 @pytest.mark.gpu
+def test_a_block_that_another_stream_still_uses_is_ordered_behind_that_stream_too():
+    """The reference's cuda_drop is a cudaFree: it waits for the whole device.  Here the drop records an event on every OTHER busy
+    stream the library made on the device as well (idle ones need none), so a vector allocated for stream A, still being written by
+    a bootstrap on stream B when the host drops it, and handed back to stream A at once — its owner: stream order alone would say
+    "free" — is cleared by A only after B's writes (a CudaVec shared across the streams of a set)."""
+    from .common import TOY_2048, encrypt_small, make_keys
+    from . import oracle as orc
+    lib = use_backend("hip")
+    p = TOY_2048
+    keys = make_keys(p)
+    B = 512
+    sa, sb = gpu.CudaStreams.new_single_gpu(0), gpu.CudaStreams.new_single_gpu(0)
+    a, b = sa.ptr[0], sb.ptr[0]
+    bsk = gpu.CudaLweBootstrapKey.from_lwe_bootstrap_key(keys.bsk, p.n, p.k, p.N, p.pbs_base_log, p.pbs_level, sb, ms_noise_reduction=True)
+    cts = encrypt_small(p, keys, [m % 16 for m in range(B)], seed=5)
+    d_in = gpu.CudaLweCiphertextList.from_lwe_ciphertext_list(cts, sb)
+    lut = orc.generate_lut(p.k, p.N, p.plaintext_modulus, p.delta, lambda x: (x + 1) % 16)
+    d_lut = gpu.CudaGlweCiphertextList.from_glwe_ciphertext_list(lut, p.k, p.N, sb)
+    idx = gpu.CudaVec.from_cpu_async(np.arange(B, dtype=np.uint64), sb)
+    zero = gpu.CudaVec.from_cpu_async(np.zeros(B, dtype=np.uint64), sb)
+    buf = C.c_void_p()
+    lib.scratch_cuda_programmable_bootstrap_64_async(b, 0, C.byref(buf), p.n, p.k, p.N, p.pbs_level, B, True, p.ms_type)
+    out_bytes = B * (p.k * p.N + 1) * 8
+    sa.synchronize()
+    sb.synchronize()
+    lib.hip_backend_trim_allocator(0)
+    for round_ in range(4):
+        out = lib.cuda_malloc_async(out_bytes, a, 0)       # owner: stream A
+        sa.synchronize()
+        for _ in range(6):   # a few ms of writes into `out` on stream B
+            lib.cuda_programmable_bootstrap_64_async(b, 0, out, idx.ptr, d_lut.d_vec.ptr, zero.ptr, d_in.d_vec.ptr, idx.ptr, bsk.d_vec.ptr,
+                                                     buf, p.n, p.k, p.N, p.pbs_base_log, p.pbs_level, B, 1, 0)
+        before = stats(lib)
+        lib.cuda_drop(out, 0)                              # the host lets go while B is still writing
+        mine = lib.cuda_malloc_async(out_bytes, a, 0)      # the same block, for its owner stream
+        assert mine == out
+        assert stats(lib)["cross_stream_waits"] == before["cross_stream_waits"] + 1
+        lib.cuda_memset_async(mine, 0, out_bytes, a, 0)
+        host = np.empty(out_bytes // 8, dtype=np.uint64)
+        lib.cuda_memcpy_async_to_cpu(host.ctypes.data_as(C.c_void_p), mine, out_bytes, a, 0)
+        sa.synchronize()
+        sb.synchronize()
+        assert not host.any(), f"round {round_}: stream B's bootstrap wrote into the block after stream A cleared it"
+        lib.cuda_drop(mine, 0)
+    lib.cleanup_cuda_programmable_bootstrap_64(b, 0, C.byref(buf))
+
+
+@pytest.mark.gpu
 def test_allocations_inside_a_stream_capture():
     """cuda_malloc_async / cuda_drop between hipStreamBeginCapture and hipStreamEndCapture (global mode): no runtime allocator call
     fails the capture, the captured work replays on the captured addresses, and those blocks never go to another stream."""

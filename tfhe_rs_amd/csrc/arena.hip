@@ -48,6 +48,10 @@ struct FreeBlock {
   hipStream_t stream;  // the stream it was last owned on (nullptr: none / destroyed)
   hipEvent_t ready;    // recorded on `stream` at the drop; nullptr: idle (nothing can still be using it)
   bool pinned;         // touched by a capture of `stream`: that stream only, for good
+  // events recorded at the drop on the OTHER streams cuda_create_stream_ffi made on this device: the reference's cuda_drop is a
+  // cudaFree, which waits for the whole device — a vector that was also used on another stream of the library (another
+  // stream_index of a CudaStreams set) is therefore ordered behind that work too, without blocking the host
+  std::vector<std::pair<hipStream_t, hipEvent_t>> others;
 };
 struct LiveBlock {
   size_t cls, bytes;
@@ -186,6 +190,19 @@ void redzone_check(DeviceArena &a, const void *payload, const LiveBlock &lb, con
              (void *)lb.stream, back + 1);
 }
 
+// the events a drop recorded on the other streams of the device: completed ones go back to the spares; true if none is left
+bool others_done(DeviceArena &a, FreeBlock &b, hipStream_t asking = nullptr) {
+  for (size_t i = 0; i < b.others.size();) {
+    if ((asking != nullptr && b.others[i].first == asking) || hipEventQuery(b.others[i].second) == hipSuccess) {
+      a.spare_events.push_back(b.others[i].second);
+      b.others.erase(b.others.begin() + i);
+    } else {
+      ++i;
+    }
+  }
+  return b.others.empty();
+}
+
 // every idle, unpinned block goes back to the runtime; returns the bytes released
 size_t trim_locked(DeviceArena &a) {
   size_t released = 0;
@@ -194,6 +211,10 @@ size_t trim_locked(DeviceArena &a) {
     std::vector<FreeBlock> keep;
     for (FreeBlock &b : kv.second) {
       bool idle = b.ready == nullptr;
+      if (!b.pinned && !others_done(a, b)) {
+        keep.push_back(b);
+        continue;
+      }
       if (!idle && !b.pinned && hipEventQuery(b.ready) == hipSuccess) {
         a.spare_events.push_back(b.ready);
         b.ready = nullptr;
@@ -224,9 +245,12 @@ void *arena_alloc(int device, size_t bytes, hipStream_t stream, bool scratch) {
   std::vector<FreeBlock> &fl = a.free_[cls];
   int pick = -1, pick_rank = 99;  // 0 same stream, 1 idle, 2 event completed, 3 must wait
   for (int i = (int)fl.size() - 1; i >= 0 && pick_rank > 0; --i) {
-    const FreeBlock &b = fl[i];
+    FreeBlock &b = fl[i];
     int rank;
-    if (b.pinned) {
+    if (!b.others.empty() && (capturing || !others_done(a, b, stream))) {
+      if (capturing) continue;  // events of other timelines cannot be waited for inside a capture
+      rank = 3;                 // the new owner waits for the other streams' work at the drop (and for the owner's, below)
+    } else if (b.pinned) {
       if (!(capturing && b.stream == stream)) continue;  // a graph's address: its own stream's captures only
       rank = 0;
     } else if (b.stream == stream && b.stream != nullptr) {
@@ -245,14 +269,25 @@ void *arena_alloc(int device, size_t bytes, hipStream_t stream, bool scratch) {
   if (pick >= 0) {
     FreeBlock b = fl[pick];
     fl.erase(fl.begin() + pick);
+    bool waited = false;
     if (b.ready != nullptr) {
-      if (pick_rank == 3) {
+      // rank 3 with the owner's own stream asking again: stream order does that part of the waiting
+      if (pick_rank == 3 && !(b.stream == stream && b.stream != nullptr) && hipEventQuery(b.ready) != hipSuccess) {
         if (stream != nullptr) HX_CHECK(hipStreamWaitEvent(stream, b.ready, 0));  // the new owner's work queues behind the old owner's
         else HX_CHECK(hipEventSynchronize(b.ready));  // a scratch without a stream of its own: the host waits (rare: same-class block still busy)
-        a.stats.cross_stream_waits++;
+        waited = true;
       }
       a.spare_events.push_back(b.ready);  // consumed (same stream: stream order did the waiting; a pinned block carries none)
     }
+    for (const auto &se : b.others) {  // what the device's other streams had queued when the block was dropped
+      if (se.first != stream && hipEventQuery(se.second) != hipSuccess) {  // (the asking stream's own event: stream order)
+        if (stream != nullptr) HX_CHECK(hipStreamWaitEvent(stream, se.second, 0));
+        else HX_CHECK(hipEventSynchronize(se.second));
+        waited = true;
+      }
+      a.spare_events.push_back(se.second);
+    }
+    if (waited) a.stats.cross_stream_waits++;
     p = b.p;
     pinned = pinned || b.pinned;
     a.stats.cached_bytes -= cls;
@@ -296,7 +331,7 @@ bool arena_free(int device, void *p, size_t *user_bytes) {
   const LiveBlock lb = it->second;
   a.live.erase(it);
   if (user_bytes) *user_bytes = lb.bytes;
-  FreeBlock fb{p, lb.stream, nullptr, lb.pinned};
+  FreeBlock fb{p, lb.stream, nullptr, lb.pinned, {}};
   if (redzone_on() && !(lb.stream != nullptr && a.known_streams.count(lb.stream) != 0 && stream_is_capturing(lb.stream))) {
     if (lb.armed) redzone_check(a, p, lb, "drop");
     HX_CHECK(hipMemsetAsync(p, kPoison, lb.cls, nullptr));
@@ -322,6 +357,17 @@ bool arena_free(int device, void *p, size_t *user_bytes) {
     // any other owner (a library scratch, also stream-less, is idle by contract and takes no event)
     fb.ready = take_event(a);
     HX_CHECK(hipEventRecord(fb.ready, nullptr));
+  }
+  if (!capturing && !fb.pinned && !lb.scratch && !(lb.stream != nullptr && !known)) {
+    // ... and the device's other library streams (none of them capturing: an event recorded inside a capture belongs to it)
+    for (hipStream_t s : a.known_streams) {
+      if (s == lb.stream || stream_is_capturing(s)) continue;
+      if (hipStreamQuery(s) == hipSuccess) continue;  // idle: nothing it has queued can still touch the block
+      (void)hipGetLastError();                         // (hipErrorNotReady is not an error here)
+      hipEvent_t e = take_event(a);
+      HX_CHECK(hipEventRecord(e, s));
+      fb.others.emplace_back(s, e);
+    }
   }
   a.free_[lb.cls].push_back(fb);
   a.stats.live_bytes -= lb.cls;

@@ -216,13 +216,11 @@ class CudaVec {
   }
   CudaVec(const CudaVec &) = delete;
   CudaVec &operator=(const CudaVec &) = delete;
-  // vec.rs:487-495 (Drop: cuda_drop per GPU).  CONTRACT (differs from the reference, whose cudaFree synchronises the device):
-  // the drop is stream-ordered behind the stream the vector was ALLOCATED for (stream_index of new_async / from_cpu_async)
-  // and behind nothing else.  A vector that was also used on another stream — another stream_index, another CudaStreams set,
-  // a stream of the caller's own — must have that work synchronised (CudaStreams::synchronize, an event the owner stream
-  // waits for) before it goes out of scope; the next owner of its memory may otherwise start while that work still runs
-  // (csrc/arena.hip records the re-use event on the owner stream only).  Every wrapper of this header that hands a vector
-  // to several streams (the multi-GPU radix rounds) synchronises them before it returns.
+  // vec.rs:487-495 (Drop: cuda_drop per GPU).  The reference's cuda_drop is a cudaFree, which waits for the device; here the drop
+  // is stream-ordered: behind the stream the vector was ALLOCATED for and behind every other stream cuda_create_stream_ffi
+  // made on that device that is busy at the drop (csrc/arena.hip records an event on each; the next owner's stream waits
+  // for them) — nothing blocks the host.  Not covered: work on a hipStream_t of the caller's own making; synchronise that
+  // before the vector goes out of scope.
   ~CudaVec() { release(); }
 
  private:
