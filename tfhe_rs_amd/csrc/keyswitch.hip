@@ -565,8 +565,11 @@ static void launch_ks_gemm(dim3 grid, hipStream_t st, uint32_t steps, Args... ar
 }
 // SPB = steps of 32 k per workgroup barrier: with 2 the barrier, the drain of the global -> LDS loads in front of it and
 // the LDS round trip behind it are paid once per 16 matrix instructions instead of once per 8 (32 KB of LDS for u64 keys)
+#ifndef KS_GEMM_MIN_WAVES
+#define KS_GEMM_MIN_WAVES 2  // waves per SIMD the register budget is cut for (2: 256 registers; the u64 forms spill 40-61 in their epilogue)
+#endif
 template <typename OutT, int SPB>
-__global__ void __launch_bounds__(256, 2) ks_gemm_kernel(OutT *lwe_out, const uint64_t *out_idx, const uint64_t *lwe_in,
+__global__ void __launch_bounds__(256, KS_GEMM_MIN_WAVES) ks_gemm_kernel(OutT *lwe_out, const uint64_t *out_idx, const uint64_t *lwe_in,
                                                       const uint64_t *in_idx, const int8_t *planes,
                                                       const uint64_t *colsum, const int8_t *aplanes,
                                                       const int32_t *suma, uint32_t n_in, uint32_t n_out,
