@@ -15,3 +15,5 @@ cp $g/${t}_measure_all.jsonl $p/${r}_measure_all.jsonl
 cp $g/${t}_latency_integer.jsonl $p/${r}_latency_integer_fheuint64.jsonl
 cp $g/${t}_gputest.log $p/${r}_gputest.log
 bash tools/kernel_usage_all.sh > $p/${r}_kernel_resource_usage.txt 2>/dev/null || true
+[ -f $g/${t}_redzone.txt ] && cp $g/${t}_redzone.txt $p/${r}_redzone.txt
+[ -f $g/${t}_marker_ranges_multibit_g4.txt ] && cp $g/${t}_marker_ranges_multibit_g4.txt $p/${r}_marker_ranges_multibit_g4.txt
