@@ -379,7 +379,7 @@ bool arena_free(int device, void *p, size_t *user_bytes) {
     const char *e = std::getenv("TFHE_HIP_ARENA_CACHE_MB");
     return (uint64_t)(e ? std::strtoull(e, nullptr, 10) : 16384) << 20;
   }();
-  if (a.stats.cached_bytes > cap) trim_locked(a);
+  if (a.stats.cached_bytes > cap && !capturing) trim_locked(a);  // (hipFree is illegal while this thread's stream captures)
   return true;
 }
 
