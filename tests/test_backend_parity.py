@@ -871,12 +871,14 @@ def test_multi_bit_throughput_kernel_shared_key_loads(kind, which, B):
 
 
 @pytest.mark.parametrize("kind", BACKENDS)
-def test_multi_bit_octet_mode_index_vectors_and_luts(kind):
+@pytest.mark.parametrize("which", ["g4_l1", "g3_l2"])
+def test_multi_bit_octet_mode_index_vectors_and_luts(kind, which):
     """The all-eight-waves form takes the four LWEs of a workgroup through the index vectors: gathered inputs
     (a permutation with repeats), scattered outputs, a different LUT per LWE — 773 LWEs (a ragged last workgroup of
-    one present LWE) against the oracle on the same indexes."""
-    from .common import TOY_MB4_2048
-    p = TOY_MB4_2048
+    one present LWE) against the oracle on the same indexes.  One level (subset-major keybundle) and two levels (round 6: the
+    point-major form, sums over the levels in registers)."""
+    from .common import TOY_MB_2048, TOY_MB4_2048
+    p = TOY_MB4_2048 if which == "g4_l1" else TOY_MB_2048
     c = ctx(kind, p, "fft64")
     lib = use_backend(kind)
     B, pool = 773, 40
