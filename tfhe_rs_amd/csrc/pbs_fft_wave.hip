@@ -2429,6 +2429,7 @@ static void launch_wave_mb_t(hipStream_t st, const PbsArgs &a, const FftTables &
 // a.grouping set; a.bsk = Fourier-domain multi-bit key
 void launch_pbs_multi_bit_wave(hipStream_t st, const PbsArgs &a, const FftTables &tb) {
   if (a.grouping == 3 && a.level == 2 && a.base_log == 15) launch_wave_mb_t<2, 15, 3>(st, a, tb);  // PARAM_MULTI_BIT_GROUP_3_MESSAGE_2_CARRY_2
+  else if (a.grouping == 3 && a.level == 2 && a.base_log == 14) launch_wave_mb_t<2, 14, 3>(st, a, tb);  // PARAM_GPU_MULTI_BIT_GROUP_3_MESSAGE_2_CARRY_2 (n = 879)
   else if (a.grouping == 4 && a.level == 1 && a.base_log == 22) launch_wave_mb_t<1, 22, 4>(st, a, tb);  // the GPU group-4 sets
   else if (a.grouping == 1) launch_wave_mb_t<0, 0, 1>(st, a, tb);
   else if (a.grouping == 2) launch_wave_mb_t<0, 0, 2>(st, a, tb);
