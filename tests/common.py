@@ -56,6 +56,9 @@ C4 = Params("PARAM_MULTI_BIT_GROUP_3_MESSAGE_2_CARRY_2", 918, 1, 2048, 15, 2, 3,
 # the reference's GPU default (v1_1/multi_bit/tuniform/p_fail_2_minus_128/ks_pbs_gpu.rs:205-228); timing only
 C4G4 = Params("PARAM_GPU_MULTI_BIT_GROUP_4_MESSAGE_2_CARRY_2", 920, 1, 2048, 22, 1, 3, 5, 45, 17, 16, grouping=4)
 # the reference's GPU g = 3 set of the same precision (same file, :118-137): base_log 14 where the CPU set above has 15
+# ... and the gaussian 2^-64 GPU sets with one level (v1_1/multi_bit/gaussian/p_fail_2_minus_64/ks_pbs_gpu.rs); timing only
+C4G3_L1 = Params("PARAM_GPU_MULTI_BIT_GROUP_3_MESSAGE_2_CARRY_2_GAUSSIAN_2M64", 813, 1, 2048, 22, 1, 3, 5, 45, 17, 16, grouping=3)
+C4G2_L1 = Params("PARAM_GPU_MULTI_BIT_GROUP_2_MESSAGE_2_CARRY_2_GAUSSIAN_2M64", 820, 1, 2048, 22, 1, 3, 5, 45, 17, 16, grouping=2)
 C4G3 = Params("PARAM_GPU_MULTI_BIT_GROUP_3_MESSAGE_2_CARRY_2", 879, 1, 2048, 14, 2, 2, 8, 46, 17, 16, grouping=3)
 
 TOY_K1 = Params("toy_k1_N256", 24, 1, 256, 15, 2, 4, 5, 40, 20, 4, ms_type=1)
@@ -75,6 +78,8 @@ TOY_MB_2048 = Params("toy_multibit_g3_N2048", 9, 1, 2048, 15, 2, 3, 6, 45, 17, 1
 TOY_MB_K3 = Params("toy_multibit_g3_k3_N512", 12, 3, 512, 18, 2, 4, 5, 40, 18, 8, grouping=3)
 TOY_MB_8192 = Params("toy_multibit_g2_N8192", 4, 1, 8192, 15, 2, 4, 5, 45, 17, 16, grouping=2)   # accumulator in device memory
 TOY_MB4_2048 = Params("toy_multibit_g4_N2048_l1", 8, 1, 2048, 22, 1, 3, 6, 45, 17, 16, grouping=4)
+TOY_MB3_L1_2048 = Params("toy_multibit_g3_N2048_l1", 9, 1, 2048, 22, 1, 3, 6, 45, 17, 16, grouping=3)   # the gaussian GPU g = 3 / g = 2 sets
+TOY_MB2_L1_2048 = Params("toy_multibit_g2_N2048_l1", 8, 1, 2048, 22, 1, 3, 6, 45, 17, 16, grouping=2)   # decomposition (one level)
 TOY_MB3G_2048 = Params("toy_multibit_g3_N2048_b14", 9, 1, 2048, 14, 2, 3, 6, 45, 17, 16, grouping=3)   # the GPU g = 3 set's decomposition
 
 

@@ -833,7 +833,8 @@ def test_multi_bit_throughput_kernel_equals_generic_and_oracle(kind, which):
 
 
 @pytest.mark.parametrize("kind", BACKENDS)
-@pytest.mark.parametrize("which,B", [("g3_l2", 259), ("g4_l1", 259), ("g4_l1", 515), ("g3_l2", 771), ("g4_l1", 771), ("g3_b14", 771)])
+@pytest.mark.parametrize("which,B", [("g3_l2", 259), ("g4_l1", 259), ("g4_l1", 515), ("g3_l2", 771), ("g4_l1", 771), ("g3_b14", 771),
+                                     ("g3_l1", 771), ("g2_l1", 771), ("g2_l1", 259)])
 def test_multi_bit_throughput_kernel_shared_key_loads(kind, which, B):
     """With an even number of LWEs per workgroup (2 from 257 LWEs, 4 from 769) the quads of waves of the
     throughput kernel share the key loads of their two LWEs (SHARE mode of pbs_fft_wave_kernel): a wave works on
@@ -843,8 +844,9 @@ def test_multi_bit_throughput_kernel_shared_key_loads(kind, which, B):
     With 4 LWEs per workgroup the one-level set goes further (OCTET mode): all eight waves share every key load, a
     wave works on one column at 4 of a lane's 16 points for all FOUR LWEs.  Same bits as the quad form (kernel
     choice 8), the pair-per-LWE form (choice 7) and the oracle."""
-    from .common import TOY_MB_2048, TOY_MB3G_2048, TOY_MB4_2048
-    p = {"g3_l2": TOY_MB_2048, "g3_b14": TOY_MB3G_2048, "g4_l1": TOY_MB4_2048}[which]   # g3_b14: the reference's GPU g = 3 decomposition
+    from .common import TOY_MB_2048, TOY_MB2_L1_2048, TOY_MB3G_2048, TOY_MB3_L1_2048, TOY_MB4_2048
+    # g3_b14: the decomposition of the reference's tuniform GPU g = 3 set; g3_l1 / g2_l1: of its gaussian GPU g = 3 / g = 2 sets
+    p = {"g3_l2": TOY_MB_2048, "g3_b14": TOY_MB3G_2048, "g4_l1": TOY_MB4_2048, "g3_l1": TOY_MB3_L1_2048, "g2_l1": TOY_MB2_L1_2048}[which]
     c = ctx(kind, p, "fft64")
     lib = use_backend(kind)
     msgs = [(5 * m + 2) % 16 for m in range(B)]

@@ -2431,6 +2431,8 @@ void launch_pbs_multi_bit_wave(hipStream_t st, const PbsArgs &a, const FftTables
   if (a.grouping == 3 && a.level == 2 && a.base_log == 15) launch_wave_mb_t<2, 15, 3>(st, a, tb);  // PARAM_MULTI_BIT_GROUP_3_MESSAGE_2_CARRY_2
   else if (a.grouping == 3 && a.level == 2 && a.base_log == 14) launch_wave_mb_t<2, 14, 3>(st, a, tb);  // PARAM_GPU_MULTI_BIT_GROUP_3_MESSAGE_2_CARRY_2 (n = 879)
   else if (a.grouping == 4 && a.level == 1 && a.base_log == 22) launch_wave_mb_t<1, 22, 4>(st, a, tb);  // the GPU group-4 sets
+  else if (a.grouping == 3 && a.level == 1 && a.base_log == 22) launch_wave_mb_t<1, 22, 3>(st, a, tb);  // the GPU group-3 / group-2 sets of the
+  else if (a.grouping == 2 && a.level == 1 && a.base_log == 22) launch_wave_mb_t<1, 22, 2>(st, a, tb);  // gaussian families (one level, as g = 4)
   else if (a.grouping == 1) launch_wave_mb_t<0, 0, 1>(st, a, tb);
   else if (a.grouping == 2) launch_wave_mb_t<0, 0, 2>(st, a, tb);
   else if (a.grouping == 3) launch_wave_mb_t<0, 0, 3>(st, a, tb);

@@ -17,7 +17,7 @@ import numpy as np  # noqa: E402
 import tfhe_rs_amd  # noqa: E402,F401
 from tfhe_rs_amd import core_crypto_gpu as gpu  # noqa: E402
 from tfhe_rs_amd import ffi  # noqa: E402
-from tests.common import C1, C1P, C33, C4, C4G3, C4G4  # noqa: E402
+from tests.common import C1, C1P, C33, C4, C4G2_L1, C4G3, C4G3_L1, C4G4  # noqa: E402
 
 lib = ffi.default_library()
 streams = gpu.CudaStreams.new_single_gpu(0)
@@ -187,6 +187,9 @@ if __name__ == "__main__":
         pbs_case(C4G4, 1, steps=3)
     if "mb3gpu" in which:  # the reference's GPU g = 3 set of the 2_2 precision (n = 879, base_log 14, two levels)
         pbs_case(C4G3, 4096, steps=2)
+    if "mbgauss" in which:  # the one-level g = 3 / g = 2 GPU sets of the gaussian families (n = 813 / 820)
+        pbs_case(C4G3_L1, 4096, steps=2)
+        pbs_case(C4G2_L1, 4096, steps=2)
     if "mbcross" in which:  # where the multi-bit latency path (5) and the throughput kernel (2) cross
         for p in (C4G4, C4):
             for B in (128, 192, 256, 384, 512):
