@@ -1533,8 +1533,10 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
             const uint32_t pc = (uint32_t)(t % RW);  // 2 p + c
             uint32_t o0 = lvl_off;
 #if WAVE_MB_ROOT_JIT
-            HX_OPAQUE_S(o0);  // the scalar offset of a request is one addition: made here, not 2 x 4 x 2^g of them ahead of the
-#endif                // level and carried through vector-register lanes
+            // the scalar offset of a request is one addition: made here, not 2 x 4 x 2^g of them ahead of the level and carried
+            // through vector-register lanes
+            HX_OPAQUE_S(o0);
+#endif
             const uint32_t rc = (pc & 1u) * (uint32_t)n * 16u + (pc >> 1) * 1024u;
             x0[set] = ldk(gk, lane_off, sidx * ggsw_bytes + o0 + rc);
             x1[set] = ldk(gk, lane_off, sidx * ggsw_bytes + o0 + rc + 2u * (uint32_t)n * 16u);
