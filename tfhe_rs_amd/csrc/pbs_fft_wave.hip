@@ -132,12 +132,18 @@
 #define WAVE_MB_PREFETCH 1  // multi-bit (pair and quad modes): a load per wave and group touches the next group's key lines
 #endif
 #ifndef WAVE_MB_EXPERIMENT
-#define WAVE_MB_EXPERIMENT 0  // timing experiments (wrong results): bit 0 = every base request reads one of 16 rows of the table, bit 1 = no scalar root loads
+#define WAVE_MB_EXPERIMENT 0  // timing experiments (wrong results): bit 0 = every base request reads one of 16 rows of the table, bit 1 = no scalar root loads, bit 2 = no base requests (OCTET)
 #endif
 #if WAVE_MB_EXPERIMENT & 1
 #define MB_EXP_ROW(d) ((d) & 15u)
 #else
 #define MB_EXP_ROW(d) (d)
+#endif
+#ifndef WAVE_MB_OCTET2_K_FIRST
+// OCTET, several levels: 1 = the level's barrier behind the first point's keybundle (which needs the key and the mask only)
+// instead of in front of it: a wave that is early combines instead of waiting (g = 3 per 4096, same box: 36.77 -> 36.04 ms
+// and 35.71 -> 35.47, profiles/r06_ab_multibit.txt section 10)
+#define WAVE_MB_OCTET2_K_FIRST 1
 #endif
 #ifndef WAVE_MB_PF_DIST
 #define WAVE_MB_PF_DIST 1  // ... of the group this many groups ahead
@@ -1431,7 +1437,13 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
             HX_UNROLL
             for (int L = 0; L < 4; ++L) {
               dg[0][L] = hx_readlane(dv, L * 16 + (int)sidx);
+#if WAVE_MB_EXPERIMENT & 4  // timing experiment only (wrong results): no base requests
+              bs[0][L] = cplx{0.5, 0.25};
+              HX_OPAQUE(bs[0][L].re);
+              HX_OPAQUE(bs[0][L].im);
+#else
               bs[0][L] = ldc(mono_lane, lane16, MB_EXP_ROW(dg[0][L]) * 1024u);
+#endif
             }
           };
 #if WAVE_MB_PACE_AT_KEY
@@ -1444,9 +1456,11 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
           for (int t = 0; t < SETS && t < STEPS; ++t) request(t, t);
           if (per > 1) request_bases(1);
           HX_SCHED_FENCE();
+#if !WAVE_MB_OCTET2_K_FIRST
           HX_BLOCK_SYNC_LDS();  // all eight transforms of this level are in the buffers (mapping M3: slot lane*17 + r)
           MBP(3);
           HX_SCHED_FENCE();
+#endif
           const int fslot = base_m3(cx) + 2 * (int)v8;
           HX_UNROLL
           for (int pp = 0; pp < 2; ++pp) {
@@ -1489,6 +1503,16 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
                 HX_SCHED_FENCE();
               }
             }
+#if WAVE_MB_OCTET2_K_FIRST
+            // the first point's keybundle needs the key and the mask only: the workgroup meets behind it, in front of the first
+            // read of a transform — a wave that is early combines instead of waiting
+            if (pp == 0) {
+              HX_SCHED_FENCE();
+              HX_BLOCK_SYNC_LDS();  // all eight transforms of this level are in the buffers (mapping M3: slot lane*17 + r)
+              MBP(3);
+              HX_SCHED_FENCE();
+            }
+#endif
             // this point's products with the digit transforms of the four LWEs, added to the earlier levels'
             HX_UNROLL
             for (int L = 0; L < 4; ++L) {
@@ -1547,7 +1571,13 @@ __global__ void __launch_bounds__(TPB) pbs_fft_wave_kernel(PbsArgs a, FftTables 
             HX_UNROLL
             for (int L = 0; L < 4; ++L) {
               dg[sidx & 1][L] = hx_readlane(dv, L * 16 + (int)sidx);
+#if WAVE_MB_EXPERIMENT & 4  // timing experiment only (wrong results): no base requests
+              bs[sidx & 1][L] = cplx{0.5, 0.25};
+              HX_OPAQUE(bs[sidx & 1][L].re);
+              HX_OPAQUE(bs[sidx & 1][L].im);
+#else
               bs[sidx & 1][L] = ldc(mono_lane, lane16, MB_EXP_ROW(dg[sidx & 1][L]) * 1024u);
+#endif
             }
           };
 #if WAVE_MB_PACE_AT_KEY
