@@ -42,6 +42,8 @@ extern "C" {
 enum PBS_TYPE { MULTI_BIT = 0, CLASSICAL = 1 };
 enum PBS_VARIANT { DEFAULT = 0, CG = 1, TBC = 2 };
 enum PBS_MS_REDUCTION_T { NO_REDUCTION = 0, CENTERED = 1 };
+/* cuda/include/integer/integer.h:15-22 */
+enum BITOP_TYPE { BITAND = 0, BITOR = 1, BITXOR = 2, SCALAR_BITAND = 3, SCALAR_BITOR = 4, SCALAR_BITXOR = 5 };
 
 /* ------------------------------------------------------------------ device runtime
  * backends/tfhe-cuda-common/cuda/include/device.h:58-92 (cuda_bind.rs:5-150) */
@@ -487,6 +489,59 @@ void cuda_integer_mult_inplace_64_async(
     CudaRadixCiphertextFFI const *radix_lwe_right, bool const is_bool_right, void *const *bsks,
     void *const *ksks, int8_t *mem_ptr, uint32_t polynomial_size, uint32_t num_blocks);
 void cleanup_cuda_integer_mult_inplace_64(CudaStreamsFFI streams, int8_t **mem_ptr_void);
+
+/* Levelled block operations and the one-round / sequential operations built on the round driver (round 6).
+ * integer.h:189-198 (negate with the correcting term, scalar addition), :312-347 (bitnot, bitop, scalar bitop),
+ * :559-573 (sub_and_propagate_single_carry: requested_flag 0 or 2, no input carry — what the reference's callers pass,
+ * integer/gpu/server_key/radix/sub.rs:222,347-400), :159-171 (full propagation, block after block).
+ * negate / scalar_addition / bitnot / bitop / scalar_bitop / full_propagation take ONE integer per ciphertext as in the
+ * reference (bitop: any number of blocks up to lwe_ciphertext_count x hip_integer_scratch_batch); sub takes the batch
+ * extension described above. */
+void cuda_negate_ciphertext_64(CudaStreamsFFI streams, CudaRadixCiphertextFFI *lwe_array_out,
+                               CudaRadixCiphertextFFI const *lwe_array_in, uint32_t message_modulus,
+                               uint32_t carry_modulus, uint32_t num_radix_blocks);
+void cuda_scalar_addition_ciphertext_64_inplace(CudaStreamsFFI streams, CudaRadixCiphertextFFI *lwe_array,
+                                                void const *scalar_input, void const *h_scalar_input,
+                                                uint32_t num_scalars, uint32_t message_modulus, uint32_t carry_modulus);
+void cuda_bitnot_ciphertext_64(CudaStreamsFFI streams, CudaRadixCiphertextFFI *radix_ciphertext,
+                               uint32_t ct_message_modulus, uint32_t param_message_modulus,
+                               uint32_t param_carry_modulus);
+uint64_t scratch_cuda_integer_bitop_inplace_64_async(
+    CudaStreamsFFI streams, int8_t **mem_ptr, CudaLweBootstrapKeyParamsFFI bsk_params,
+    CudaLweKeyswitchKeyParamsFFI ksk_params, uint32_t lwe_ciphertext_count, uint32_t message_modulus,
+    uint32_t carry_modulus, enum BITOP_TYPE op_type, bool allocate_gpu_memory,
+    enum PBS_MS_REDUCTION_T noise_reduction_type);
+uint64_t scratch_cuda_integer_scalar_bitop_inplace_64_async(
+    CudaStreamsFFI streams, int8_t **mem_ptr, CudaLweBootstrapKeyParamsFFI bsk_params,
+    CudaLweKeyswitchKeyParamsFFI ksk_params, uint32_t lwe_ciphertext_count, uint32_t message_modulus,
+    uint32_t carry_modulus, enum BITOP_TYPE op_type, bool allocate_gpu_memory,
+    enum PBS_MS_REDUCTION_T noise_reduction_type);
+void cuda_integer_bitop_inplace_64_async(CudaStreamsFFI streams, CudaRadixCiphertextFFI *lwe_array_inout,
+                                         CudaRadixCiphertextFFI const *lwe_array_2, int8_t *mem_ptr,
+                                         void *const *bsks, void *const *ksks);
+void cuda_integer_scalar_bitop_inplace_64_async(CudaStreamsFFI streams, CudaRadixCiphertextFFI *lwe_array_inout,
+                                                void const *clear_blocks, void const *h_clear_blocks,
+                                                uint32_t num_clear_blocks, int8_t *mem_ptr, void *const *bsks,
+                                                void *const *ksks);
+void cleanup_cuda_integer_bitop_inplace_64(CudaStreamsFFI streams, int8_t **mem_ptr_void);
+void cleanup_cuda_integer_scalar_bitop_inplace_64(CudaStreamsFFI streams, int8_t **mem_ptr_void);
+uint64_t scratch_cuda_sub_and_propagate_single_carry_64_inplace_async(
+    CudaStreamsFFI streams, int8_t **mem_ptr, CudaLweBootstrapKeyParamsFFI bsk_params,
+    CudaLweKeyswitchKeyParamsFFI ksk_params, uint32_t num_blocks, uint32_t message_modulus, uint32_t carry_modulus,
+    uint32_t requested_flag, bool allocate_gpu_memory, enum PBS_MS_REDUCTION_T noise_reduction_type);
+void cuda_sub_and_propagate_single_carry_64_inplace_async(
+    CudaStreamsFFI streams, CudaRadixCiphertextFFI *lhs_array, const CudaRadixCiphertextFFI *rhs_array,
+    CudaRadixCiphertextFFI *carry_out, const CudaRadixCiphertextFFI *carry_in, int8_t *mem_ptr,
+    void *const *bsks, void *const *ksks, uint32_t requested_flag, uint32_t uses_carry);
+void cleanup_cuda_sub_and_propagate_single_carry_64_inplace(CudaStreamsFFI streams, int8_t **mem_ptr_void);
+uint64_t scratch_cuda_full_propagation_64_inplace_async(
+    CudaStreamsFFI streams, int8_t **mem_ptr, CudaLweBootstrapKeyParamsFFI bsk_params,
+    CudaLweKeyswitchKeyParamsFFI ksk_params, uint32_t message_modulus, uint32_t carry_modulus,
+    bool allocate_gpu_memory, enum PBS_MS_REDUCTION_T noise_reduction_type);
+void cuda_full_propagation_64_inplace_async(CudaStreamsFFI streams, CudaRadixCiphertextFFI *input_blocks,
+                                            int8_t *mem_ptr, void *const *ksks, void *const *bsks,
+                                            uint32_t num_blocks);
+void cleanup_cuda_full_propagation_64_inplace(CudaStreamsFFI streams, int8_t **mem_ptr_void);
 
 /* extensions: integers per launch the NEXT scratch_* call is sized for (default 1), and the number
  * of PBS one multiplication issues per integer (for throughput accounting) */

@@ -61,6 +61,25 @@ __global__ void __launch_bounds__(256) lwe_group_sum_kernel(uint64_t *out, const
   }
 }
 
+// Levelled block operations (no bootstrap).  out[s] = -in[s] on every word, the body takes c0 (block 0 of an integer of
+// `per` blocks) or c1 (the other blocks) on top: the negation with its correcting term (negation.cuh:20-49), the
+// bitwise NOT (bitwise_ops.cuh:164-191) and the plain negation are instances.  In place allowed.
+__global__ void __launch_bounds__(256) lwe_negate_const_kernel(uint64_t *out, const uint64_t *in, uint32_t words,
+                                                               uint32_t count, uint32_t per, uint64_t c0, uint64_t c1) {
+  const uint32_t s = blockIdx.x;
+  if (s >= count) return;
+  const uint64_t *pi = in + (size_t)s * words;
+  uint64_t *po = out + (size_t)s * words;
+  const uint64_t c = (s % per) == 0 ? c0 : c1;
+  for (uint32_t j = threadIdx.x; j < words; j += blockDim.x) po[j] = ((uint64_t)0 - pi[j]) + (j + 1 == words ? c : 0);
+}
+// body[s] += scalars[s] * delta (scalar_addition.cuh:14-25): one thread per block
+__global__ void __launch_bounds__(256) lwe_body_add_scalars_kernel(uint64_t *v, const uint64_t *scalars, uint32_t words,
+                                                                   uint32_t count, uint64_t delta) {
+  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s < count) v[(size_t)s * words + words - 1] += scalars[s] * delta;
+}
+
 static void axpy(hipStream_t st, uint64_t *out, const uint64_t *out_idx, const uint64_t *a, const uint64_t *a_idx,
                  uint64_t scalar, const uint64_t *b, const uint64_t *b_idx, uint32_t words, uint32_t count) {
   if (count == 0) return;
@@ -1198,6 +1217,51 @@ struct BoolMulMem {
   }
 };
 
+// ------------------------------------------------------------------ bitwise operations, subtraction, full propagation
+// bitwise_ops.h:101-178 (int_bitop_buffer): one bivariate table of (lhs, rhs) packed msg * lhs + rhs for the ciphertext
+// forms, one univariate table per clear block value for the scalar forms (the clear blocks are the LUT indexes)
+struct BitopMem {
+  static constexpr uint32_t kMagic = 0x42495431;  // "BIT1"
+  uint32_t magic = kMagic;
+  bool size_only = false;
+  LutDriver drv;
+  uint32_t op = 0;
+  uint64_t *d_pack = nullptr, *d_lut_idx = nullptr;  // packed operands; all-zero LUT indexes (ciphertext forms)
+};
+static uint64_t bitop_apply(uint32_t op, uint64_t a, uint64_t b) {
+  switch (op % 3) {
+    case 0: return a & b;
+    case 1: return a | b;
+    default: return a ^ b;
+  }
+}
+// bitwise_ops.cu:133-185 (update_degrees_after_*): the largest value the operation can return on operands up to (a, b)
+static uint64_t bitop_degree(uint32_t op, uint64_t a, uint64_t b) {
+  const uint64_t hi = std::max(a, b), lo = std::min(a, b);
+  if (op % 3 == 0) return lo;
+  uint64_t r = hi;
+  for (uint64_t j = 0; j <= lo; ++j) r = std::max(r, op % 3 == 1 ? (hi | j) : (hi ^ j));
+  return r;
+}
+
+// subtraction.cuh:31-47: the negation of rhs with its correcting term, then the addition's carry propagation
+struct SubMem {
+  static constexpr uint32_t kMagic = 0x53554231;  // "SUB1"
+  uint32_t magic = kMagic;
+  PropagateMem prop;
+  uint64_t *d_neg = nullptr;
+};
+
+// integer.cuh:1924-1983 (host_full_propagate_inplace): block after block, message and carry of the block by one
+// two-input bootstrap round, the carry added to the next block
+struct FullPropMem {
+  static constexpr uint32_t kMagic = 0x46505031;  // "FPP1"
+  uint32_t magic = kMagic;
+  bool size_only = false;
+  LutDriver drv;  // LUTs: 0 message, 1 carry
+  uint64_t *d_two = nullptr, *d_lut_idx = nullptr;  // the block twice -> (message, carry); indexes {0, 1}
+};
+
 static uint32_t batch_of(const CudaRadixCiphertextFFI *ct, uint32_t blocks, const char *what) {
   HX_PANIC_IF_FALSE(ct != nullptr && ct->ptr != nullptr, "%s: null radix ciphertext", what);
   HX_PANIC_IF_FALSE(blocks != 0 && ct->num_radix_blocks % blocks == 0,
@@ -1617,6 +1681,375 @@ void cleanup_cuda_integer_mult_inplace_64(CudaStreamsFFI streams, int8_t **mem_p
   auto *m = reinterpret_cast<MulMem *>(*mem_ptr_void);
   HX_PANIC_IF_FALSE(m && m->magic == MulMem::kMagic, "cleanup integer_mult: foreign scratch pointer");
   m->release(streams);
+  delete m;
+  *mem_ptr_void = nullptr;
+}
+
+// ---- cuda/include/integer/integer.h:189-198, :312-316 ------------------------------------------
+// negation.cuh:85-155 (host_negation_with_correcting_term): block 0 becomes z - b, every later block z - (b + z / msg)
+// with z = msg, so that the blocks stay non-negative and the borrowed unit is handed to the next block; the degrees
+// follow the reference's loop (including its integer division inside the ceil)
+void cuda_negate_ciphertext_64(CudaStreamsFFI streams, CudaRadixCiphertextFFI *lwe_array_out,
+                               CudaRadixCiphertextFFI const *lwe_array_in, uint32_t message_modulus,
+                               uint32_t carry_modulus, uint32_t num_radix_blocks) {
+  first_gpu(streams);
+  HX_PANIC_IF_FALSE(lwe_array_out != lwe_array_in, "Output and input pointers must be different for out-of-place operations");
+  HX_PANIC_IF_FALSE(lwe_array_out && lwe_array_in && lwe_array_out->ptr && lwe_array_in->ptr, "negate: null pointer");
+  HX_PANIC_IF_FALSE(lwe_array_out->num_radix_blocks >= num_radix_blocks && lwe_array_in->num_radix_blocks >= num_radix_blocks,
+                    "lwe_array_in and lwe_array_out num radix blocks must be greater or equal to the number of blocks to negate");
+  HX_PANIC_IF_FALSE(lwe_array_out->lwe_dimension == lwe_array_in->lwe_dimension,
+                    "lwe_array_in and lwe_array_out lwe_dimension must be the same");
+  HX_PANIC_IF_FALSE(message_modulus >= 2 && carry_modulus >= 1, "negate: bad moduli");
+  if (num_radix_blocks == 0) return;
+  const uint64_t delta = ((uint64_t)1 << 63) / ((uint64_t)message_modulus * carry_modulus);
+  const uint64_t z = ((2ull * message_modulus - 1) / message_modulus) * message_modulus;
+  HX_LAUNCH(lwe_negate_const_kernel, dim3(num_radix_blocks), dim3(256), 0, S0(streams), (uint64_t *)lwe_array_out->ptr,
+            (const uint64_t *)lwe_array_in->ptr, lwe_array_in->lwe_dimension + 1, num_radix_blocks, num_radix_blocks,
+            z * delta, (z - z / message_modulus) * delta);
+  uint64_t zb = 0;
+  for (uint32_t i = 0; i < lwe_array_out->num_radix_blocks; ++i) {
+    const uint64_t d = (lwe_array_in->degrees ? lwe_array_in->degrees[i] : message_modulus - 1) + zb;
+    const uint64_t zz = std::max<uint64_t>(1, d / message_modulus) * message_modulus;
+    if (lwe_array_out->degrees) lwe_array_out->degrees[i] = zz - zb;
+    if (lwe_array_out->noise_levels && lwe_array_in->noise_levels) lwe_array_out->noise_levels[i] = lwe_array_in->noise_levels[i];
+    zb = zz / message_modulus;
+  }
+}
+
+// scalar_addition.cuh:27-55: scalar_input (device) and h_scalar_input (host) hold the same num_scalars clear blocks
+void cuda_scalar_addition_ciphertext_64_inplace(CudaStreamsFFI streams, CudaRadixCiphertextFFI *lwe_array,
+                                                void const *scalar_input, void const *h_scalar_input,
+                                                uint32_t num_scalars, uint32_t message_modulus, uint32_t carry_modulus) {
+  first_gpu(streams);
+  HX_PANIC_IF_FALSE(lwe_array && lwe_array->ptr && (num_scalars == 0 || (scalar_input && h_scalar_input)),
+                    "scalar_addition: null pointer");
+  HX_PANIC_IF_FALSE(lwe_array->num_radix_blocks >= num_scalars,
+                    "num scalars should be smaller or equal to input num radix blocks");
+  if (num_scalars == 0) return;
+  const uint64_t delta = ((uint64_t)1 << 63) / ((uint64_t)message_modulus * carry_modulus);
+  HX_LAUNCH(lwe_body_add_scalars_kernel, dim3((num_scalars + 255) / 256), dim3(256), 0, S0(streams),
+            (uint64_t *)lwe_array->ptr, (const uint64_t *)scalar_input, lwe_array->lwe_dimension + 1, num_scalars, delta);
+  if (lwe_array->degrees)
+    for (uint32_t i = 0; i < num_scalars; ++i) lwe_array->degrees[i] += ((const uint64_t *)h_scalar_input)[i];
+}
+
+// bitwise_ops.cuh:164-191 (host_bitnot): (ct_message_modulus - 1) - block, as a plain negation plus a constant
+void cuda_bitnot_ciphertext_64(CudaStreamsFFI streams, CudaRadixCiphertextFFI *radix_ciphertext,
+                               uint32_t ct_message_modulus, uint32_t param_message_modulus,
+                               uint32_t param_carry_modulus) {
+  first_gpu(streams);
+  HX_PANIC_IF_FALSE(radix_ciphertext && radix_ciphertext->ptr, "bitnot: null pointer");
+  HX_PANIC_IF_FALSE(ct_message_modulus >= 1 && param_message_modulus >= 2 && param_carry_modulus >= 1, "bitnot: bad moduli");
+  const uint32_t nb = radix_ciphertext->num_radix_blocks;
+  if (nb == 0) return;
+  const uint64_t delta = (uint64_t)1 << (63 - __builtin_ctzll((uint64_t)param_message_modulus * param_carry_modulus));
+  const uint64_t enc = delta * (ct_message_modulus - 1);
+  HX_LAUNCH(lwe_negate_const_kernel, dim3(nb), dim3(256), 0, S0(streams), (uint64_t *)radix_ciphertext->ptr,
+            (const uint64_t *)radix_ciphertext->ptr, radix_ciphertext->lwe_dimension + 1, nb, nb, enc, enc);
+  if (radix_ciphertext->degrees)
+    for (uint32_t i = 0; i < nb; ++i) radix_ciphertext->degrees[i] = ct_message_modulus - 1;
+}
+
+// ---- cuda/include/integer/integer.h:318-347 -----------------------------------------------------
+static uint64_t scratch_bitop(CudaStreamsFFI streams, int8_t **mem_ptr, CudaLweBootstrapKeyParamsFFI bsk_params,
+                              CudaLweKeyswitchKeyParamsFFI ksk_params, uint32_t count, uint32_t message_modulus,
+                              uint32_t carry_modulus, uint32_t op, bool scalar, bool allocate_gpu_memory,
+                              uint32_t noise_reduction_type) {
+  first_gpu(streams);
+  HX_PANIC_IF_FALSE(mem_ptr != nullptr, "bitop: null pointer");
+  HX_PANIC_IF_FALSE(scalar ? (op >= SCALAR_BITAND && op <= SCALAR_BITXOR) : op <= BITXOR,
+                    "bitop: operation %u does not belong to this entry point", op);
+  t_dry = !allocate_gpu_memory;
+  t_bytes = 0;
+  const Params p = make_params(bsk_params, ksk_params, message_modulus, carry_modulus, noise_reduction_type);
+  auto *m = new BitopMem();
+  m->op = op;
+  const size_t lw = (size_t)(p.k + 1) * p.N;
+  const uint32_t cap = std::max<uint32_t>(1, count) * g_scratch_batch;
+  std::vector<std::vector<uint64_t>> luts(scalar ? p.msg : 1, std::vector<uint64_t>(lw));
+  if (scalar) {
+    for (uint32_t c = 0; c < p.msg; ++c)
+      generate_lut(p, luts[c].data(), [op, c](uint64_t x) { return bitop_apply(op, x, c); });
+  } else {
+    const uint32_t msg = p.msg;
+    generate_lut(p, luts[0].data(), [op, msg](uint64_t x) { return bitop_apply(op, x / msg, x % msg); });
+  }
+  m->drv.init(streams, p, cap, luts);
+  if (!scalar) {
+    radix_alloc((void **)&m->d_pack, (size_t)cap * (p.big_n + 1) * sizeof(uint64_t));
+    radix_alloc((void **)&m->d_lut_idx, (size_t)cap * sizeof(uint64_t));
+    if (!t_dry) HX_CHECK(hipMemsetAsync(m->d_lut_idx, 0, (size_t)cap * sizeof(uint64_t), S0(streams)));
+  }
+  m->size_only = t_dry;
+  t_dry = false;
+  *mem_ptr = reinterpret_cast<int8_t *>(m);
+  return t_bytes;
+}
+uint64_t scratch_cuda_integer_bitop_inplace_64_async(CudaStreamsFFI streams, int8_t **mem_ptr,
+                                                     CudaLweBootstrapKeyParamsFFI bsk_params,
+                                                     CudaLweKeyswitchKeyParamsFFI ksk_params,
+                                                     uint32_t lwe_ciphertext_count, uint32_t message_modulus,
+                                                     uint32_t carry_modulus, enum BITOP_TYPE op_type,
+                                                     bool allocate_gpu_memory,
+                                                     enum PBS_MS_REDUCTION_T noise_reduction_type) {
+  return scratch_bitop(streams, mem_ptr, bsk_params, ksk_params, lwe_ciphertext_count, message_modulus, carry_modulus,
+                       (uint32_t)op_type, false, allocate_gpu_memory, (uint32_t)noise_reduction_type);
+}
+uint64_t scratch_cuda_integer_scalar_bitop_inplace_64_async(CudaStreamsFFI streams, int8_t **mem_ptr,
+                                                            CudaLweBootstrapKeyParamsFFI bsk_params,
+                                                            CudaLweKeyswitchKeyParamsFFI ksk_params,
+                                                            uint32_t lwe_ciphertext_count, uint32_t message_modulus,
+                                                            uint32_t carry_modulus, enum BITOP_TYPE op_type,
+                                                            bool allocate_gpu_memory,
+                                                            enum PBS_MS_REDUCTION_T noise_reduction_type) {
+  return scratch_bitop(streams, mem_ptr, bsk_params, ksk_params, lwe_ciphertext_count, message_modulus, carry_modulus,
+                       (uint32_t)op_type, true, allocate_gpu_memory, (uint32_t)noise_reduction_type);
+}
+
+// bitwise_ops.cuh:230-271 (host_bitop): one bivariate round over all blocks
+void cuda_integer_bitop_inplace_64_async(CudaStreamsFFI streams, CudaRadixCiphertextFFI *lwe_array_inout,
+                                         CudaRadixCiphertextFFI const *lwe_array_2, int8_t *mem_ptr,
+                                         void *const *bsks, void *const *ksks) {
+  first_gpu(streams);
+  auto *m = reinterpret_cast<BitopMem *>(mem_ptr);
+  HX_PANIC_IF_FALSE(m && m->magic == BitopMem::kMagic && m->op <= BITXOR, "integer_bitop: foreign scratch pointer");
+  HX_PANIC_IF_FALSE(!m->size_only, "integer_bitop: scratch was created with allocate_gpu_memory=false");
+  HX_PANIC_IF_FALSE(lwe_array_inout && lwe_array_2 && lwe_array_inout->ptr && lwe_array_2->ptr && bsks && ksks,
+                    "integer_bitop: null pointer");
+  HX_PANIC_IF_FALSE(lwe_array_inout->num_radix_blocks == lwe_array_2->num_radix_blocks,
+                    "input and output num radix blocks must be equal");
+  HX_PANIC_IF_FALSE(lwe_array_inout->lwe_dimension == lwe_array_2->lwe_dimension,
+                    "input and output lwe dimension must be equal");
+  const uint32_t nb = lwe_array_inout->num_radix_blocks;
+  HX_PANIC_IF_FALSE(nb <= m->drv.cap, "integer_bitop: %u blocks exceed the scratch capacity %u", nb, m->drv.cap);
+  const Params &p = m->drv.p;
+  if (lwe_array_inout->degrees && lwe_array_2->degrees)
+    for (uint32_t i = 0; i < nb; ++i)
+      HX_PANIC_IF_FALSE(lwe_array_inout->degrees[i] < p.msg && lwe_array_2->degrees[i] < p.msg,
+                        "integer_bitop: block %u carries a degree of %llu / %llu, the packed pair needs clean blocks", i,
+                        (unsigned long long)lwe_array_inout->degrees[i], (unsigned long long)lwe_array_2->degrees[i]);
+  uint64_t *v = (uint64_t *)lwe_array_inout->ptr;
+  axpy(S0(streams), m->d_pack, nullptr, v, nullptr, p.msg, (const uint64_t *)lwe_array_2->ptr, nullptr, p.big_n + 1, nb);
+  m->drv.round(streams, v, nullptr, m->d_pack, nullptr, m->d_lut_idx, nb, ksks, bsks);
+  for (uint32_t i = 0; i < nb; ++i) {
+    if (lwe_array_inout->degrees)
+      lwe_array_inout->degrees[i] = bitop_degree(m->op, lwe_array_inout->degrees[i],
+                                                 lwe_array_2->degrees ? lwe_array_2->degrees[i] : p.msg - 1);
+    if (lwe_array_inout->noise_levels) lwe_array_inout->noise_levels[i] = 1;
+  }
+}
+
+// scalar_bitops.cuh:6-66 (host_scalar_bitop): clear_blocks (device) index the per-value tables; the blocks past the
+// clear ones are ANDed with zero / left as they are
+void cuda_integer_scalar_bitop_inplace_64_async(CudaStreamsFFI streams, CudaRadixCiphertextFFI *lwe_array_inout,
+                                                void const *clear_blocks, void const *h_clear_blocks,
+                                                uint32_t num_clear_blocks, int8_t *mem_ptr, void *const *bsks,
+                                                void *const *ksks) {
+  first_gpu(streams);
+  auto *m = reinterpret_cast<BitopMem *>(mem_ptr);
+  HX_PANIC_IF_FALSE(m && m->magic == BitopMem::kMagic && m->op >= SCALAR_BITAND, "integer_scalar_bitop: foreign scratch pointer");
+  HX_PANIC_IF_FALSE(!m->size_only, "integer_scalar_bitop: scratch was created with allocate_gpu_memory=false");
+  HX_PANIC_IF_FALSE(lwe_array_inout && lwe_array_inout->ptr && bsks && ksks, "integer_scalar_bitop: null pointer");
+  const uint32_t nb = lwe_array_inout->num_radix_blocks;
+  HX_PANIC_IF_FALSE(num_clear_blocks <= nb && num_clear_blocks <= m->drv.cap,
+                    "integer_scalar_bitop: %u clear blocks for %u radix blocks (scratch capacity %u)", num_clear_blocks, nb,
+                    m->drv.cap);
+  HX_PANIC_IF_FALSE(num_clear_blocks == 0 || (clear_blocks && h_clear_blocks), "integer_scalar_bitop: null clear blocks");
+  const Params &p = m->drv.p;
+  const size_t w = (size_t)p.big_n + 1;
+  uint64_t *v = (uint64_t *)lwe_array_inout->ptr;
+  const uint64_t *hc = (const uint64_t *)h_clear_blocks;
+  if (num_clear_blocks) {
+    for (uint32_t i = 0; i < num_clear_blocks; ++i)
+      HX_PANIC_IF_FALSE(hc[i] < p.msg, "integer_scalar_bitop: clear block %u is %llu, not below the message modulus", i,
+                        (unsigned long long)hc[i]);
+    m->drv.round(streams, v, nullptr, v, nullptr, (const uint64_t *)clear_blocks, num_clear_blocks, ksks, bsks);
+    for (uint32_t i = 0; i < num_clear_blocks; ++i) {
+      if (lwe_array_inout->degrees) lwe_array_inout->degrees[i] = bitop_degree(m->op, hc[i], lwe_array_inout->degrees[i]);
+      if (lwe_array_inout->noise_levels) lwe_array_inout->noise_levels[i] = 1;
+    }
+  }
+  if (m->op == SCALAR_BITAND && num_clear_blocks < nb) {
+    HX_CHECK(hipMemsetAsync(v + (size_t)num_clear_blocks * w, 0, (size_t)(nb - num_clear_blocks) * w * sizeof(uint64_t),
+                            S0(streams)));
+    for (uint32_t i = num_clear_blocks; i < nb; ++i) {
+      if (lwe_array_inout->degrees) lwe_array_inout->degrees[i] = 0;
+      if (lwe_array_inout->noise_levels) lwe_array_inout->noise_levels[i] = 0;
+    }
+  }
+}
+
+static void cleanup_bitop(CudaStreamsFFI streams, int8_t **mem_ptr_void, const char *who) {
+  first_gpu(streams);
+  auto *m = reinterpret_cast<BitopMem *>(*mem_ptr_void);
+  HX_PANIC_IF_FALSE(m && m->magic == BitopMem::kMagic, "%s: foreign scratch pointer", who);
+  m->drv.release(streams);
+  for (uint64_t *d : {m->d_pack, m->d_lut_idx})
+    if (d) scratch_free(d);
+  m->magic = 0;
+  delete m;
+  *mem_ptr_void = nullptr;
+}
+void cleanup_cuda_integer_bitop_inplace_64(CudaStreamsFFI streams, int8_t **mem_ptr_void) {
+  cleanup_bitop(streams, mem_ptr_void, "cleanup integer_bitop");
+}
+void cleanup_cuda_integer_scalar_bitop_inplace_64(CudaStreamsFFI streams, int8_t **mem_ptr_void) {
+  cleanup_bitop(streams, mem_ptr_void, "cleanup integer_scalar_bitop");
+}
+
+// ---- cuda/include/integer/integer.h:559-573 -----------------------------------------------------
+// lhs - rhs = lhs + (negation of rhs with its correcting term), then the addition's carry propagation.  Block 0 of the
+// sum reaches 2 msg - 1 (msg - b0 on top of a clean block): exactly what block 0 takes with an input carry, so an input
+// carry on top of it is refused, and so is FLAG_OVERFLOW (the reference's callers — integer/gpu/server_key/radix/sub.rs:
+// 222, :347-400 — pass neither).
+uint64_t scratch_cuda_sub_and_propagate_single_carry_64_inplace_async(
+    CudaStreamsFFI streams, int8_t **mem_ptr, CudaLweBootstrapKeyParamsFFI bsk_params,
+    CudaLweKeyswitchKeyParamsFFI ksk_params, uint32_t num_blocks, uint32_t message_modulus, uint32_t carry_modulus,
+    uint32_t requested_flag, bool allocate_gpu_memory, enum PBS_MS_REDUCTION_T noise_reduction_type) {
+  first_gpu(streams);
+  HX_PANIC_IF_FALSE(mem_ptr != nullptr, "sub_and_propagate_single_carry: null pointer");
+  HX_PANIC_IF_FALSE(requested_flag == 0 || requested_flag == 2,
+                    "sub_and_propagate_single_carry: output flag %u is not wired (0 = none, 2 = carry)", requested_flag);
+  const Params p = make_params(bsk_params, ksk_params, message_modulus, carry_modulus, (uint32_t)noise_reduction_type);
+  t_dry = !allocate_gpu_memory;
+  t_bytes = 0;
+  auto *m = new SubMem();
+  m->prop.init(streams, p, num_blocks, g_scratch_batch);
+  radix_alloc((void **)&m->d_neg, (size_t)num_blocks * g_scratch_batch * (p.big_n + 1) * sizeof(uint64_t));
+  m->prop.size_only = t_dry;
+  t_dry = false;
+  *mem_ptr = reinterpret_cast<int8_t *>(m);
+  return t_bytes;
+}
+
+void cuda_sub_and_propagate_single_carry_64_inplace_async(CudaStreamsFFI streams, CudaRadixCiphertextFFI *lhs_array,
+                                                          const CudaRadixCiphertextFFI *rhs_array,
+                                                          CudaRadixCiphertextFFI *carry_out,
+                                                          const CudaRadixCiphertextFFI *carry_in, int8_t *mem_ptr,
+                                                          void *const *bsks, void *const *ksks,
+                                                          uint32_t requested_flag, uint32_t uses_carry) {
+  first_gpu(streams);
+  (void)carry_in;
+  auto *m = reinterpret_cast<SubMem *>(mem_ptr);
+  HX_PANIC_IF_FALSE(m && m->magic == SubMem::kMagic, "sub_and_propagate_single_carry: foreign scratch pointer");
+  HX_PANIC_IF_FALSE(!m->prop.size_only, "sub_and_propagate_single_carry: scratch was created with allocate_gpu_memory=false");
+  HX_PANIC_IF_FALSE(requested_flag == 0 || requested_flag == 2,
+                    "sub_and_propagate_single_carry: output flag %u is not wired (0 = none, 2 = carry)", requested_flag);
+  HX_PANIC_IF_FALSE(uses_carry == 0, "sub_and_propagate_single_carry: an input carry is not wired (block 0 already holds the "
+                                     "borrowed unit of the negation)");
+  HX_PANIC_IF_FALSE(lhs_array && rhs_array && lhs_array->ptr && rhs_array->ptr && bsks && ksks &&
+                        lhs_array->num_radix_blocks == rhs_array->num_radix_blocks &&
+                        lhs_array->lwe_dimension == rhs_array->lwe_dimension,
+                    "sub_and_propagate_single_carry: operands must have the same shape");
+  const uint32_t L = m->prop.blocks, cts = batch_of(lhs_array, L, "sub_and_propagate_single_carry");
+  const Params &p = m->prop.drv.p;
+  for (const CudaRadixCiphertextFFI *op : {(const CudaRadixCiphertextFFI *)lhs_array, rhs_array})
+    if (op->degrees)
+      for (uint32_t i = 0; i < op->num_radix_blocks; ++i)
+        HX_PANIC_IF_FALSE(op->degrees[i] <= p.msg - 1,
+                          "sub_and_propagate_single_carry: block %u has degree %llu, the subtraction takes clean operands "
+                          "(propagate them first)", i, (unsigned long long)op->degrees[i]);
+  uint64_t *cout = nullptr;
+  if (requested_flag == 2) {
+    HX_PANIC_IF_FALSE(carry_out && carry_out->ptr && carry_out->num_radix_blocks >= cts &&
+                          carry_out->lwe_dimension == lhs_array->lwe_dimension,
+                      "sub_and_propagate_single_carry: FLAG_CARRY needs one output carry block per integer");
+    cout = (uint64_t *)carry_out->ptr;
+  }
+  const hipStream_t st = S0(streams);
+  const uint32_t w = p.big_n + 1, T = cts * L;
+  const uint64_t delta = ((uint64_t)1 << 63) / ((uint64_t)p.msg * p.carry);
+  HX_LAUNCH(lwe_negate_const_kernel, dim3(T), dim3(256), 0, st, m->d_neg, (const uint64_t *)rhs_array->ptr, w, T, L,
+            (uint64_t)p.msg * delta, (uint64_t)(p.msg - 1) * delta);
+  uint64_t *v = (uint64_t *)lhs_array->ptr;
+  axpy(st, v, nullptr, v, nullptr, 1, m->d_neg, nullptr, w, T);
+  m->prop.run(streams, v, cts, ksks, bsks, nullptr, cout);
+  if (cout)
+    for (uint32_t i = 0; i < cts; ++i) {
+      if (carry_out->degrees) carry_out->degrees[i] = 1;
+      if (carry_out->noise_levels) carry_out->noise_levels[i] = 1;
+    }
+  for (uint32_t i = 0; i < lhs_array->num_radix_blocks; ++i) {
+    if (lhs_array->degrees) lhs_array->degrees[i] = p.msg - 1;
+    if (lhs_array->noise_levels) lhs_array->noise_levels[i] = 1;
+  }
+}
+
+void cleanup_cuda_sub_and_propagate_single_carry_64_inplace(CudaStreamsFFI streams, int8_t **mem_ptr_void) {
+  first_gpu(streams);
+  auto *m = reinterpret_cast<SubMem *>(*mem_ptr_void);
+  HX_PANIC_IF_FALSE(m && m->magic == SubMem::kMagic, "cleanup sub_and_propagate_single_carry: foreign scratch pointer");
+  m->prop.release(streams);
+  if (m->d_neg) scratch_free(m->d_neg);
+  m->magic = 0;
+  delete m;
+  *mem_ptr_void = nullptr;
+}
+
+// ---- cuda/include/integer/integer.h:159-171 -----------------------------------------------------
+uint64_t scratch_cuda_full_propagation_64_inplace_async(CudaStreamsFFI streams, int8_t **mem_ptr,
+                                                        CudaLweBootstrapKeyParamsFFI bsk_params,
+                                                        CudaLweKeyswitchKeyParamsFFI ksk_params,
+                                                        uint32_t message_modulus, uint32_t carry_modulus,
+                                                        bool allocate_gpu_memory,
+                                                        enum PBS_MS_REDUCTION_T noise_reduction_type) {
+  first_gpu(streams);
+  HX_PANIC_IF_FALSE(mem_ptr != nullptr, "full_propagation: null pointer");
+  t_dry = !allocate_gpu_memory;
+  t_bytes = 0;
+  const Params p = make_params(bsk_params, ksk_params, message_modulus, carry_modulus, (uint32_t)noise_reduction_type);
+  auto *m = new FullPropMem();
+  const size_t lw = (size_t)(p.k + 1) * p.N;
+  std::vector<std::vector<uint64_t>> luts(2, std::vector<uint64_t>(lw));
+  const uint32_t msg = p.msg;
+  generate_lut(p, luts[0].data(), [msg](uint64_t x) { return x % msg; });
+  generate_lut(p, luts[1].data(), [msg](uint64_t x) { return x / msg; });
+  m->drv.init(streams, p, 2, luts);
+  radix_alloc((void **)&m->d_two, 2 * (size_t)(p.big_n + 1) * sizeof(uint64_t));
+  m->d_lut_idx = dev_upload(S0(streams), std::vector<uint64_t>{0, 1});
+  m->size_only = t_dry;
+  t_dry = false;
+  *mem_ptr = reinterpret_cast<int8_t *>(m);
+  return t_bytes;
+}
+
+void cuda_full_propagation_64_inplace_async(CudaStreamsFFI streams, CudaRadixCiphertextFFI *input_blocks,
+                                            int8_t *mem_ptr, void *const *ksks, void *const *bsks,
+                                            uint32_t num_blocks) {
+  first_gpu(streams);
+  auto *m = reinterpret_cast<FullPropMem *>(mem_ptr);
+  HX_PANIC_IF_FALSE(m && m->magic == FullPropMem::kMagic, "full_propagation: foreign scratch pointer");
+  HX_PANIC_IF_FALSE(!m->size_only, "full_propagation: scratch was created with allocate_gpu_memory=false");
+  HX_PANIC_IF_FALSE(input_blocks && input_blocks->ptr && ksks && bsks && num_blocks <= input_blocks->num_radix_blocks,
+                    "full_propagation: null pointer or more blocks than the ciphertext holds");
+  const Params &p = m->drv.p;
+  const hipStream_t st = S0(streams);
+  const size_t w = (size_t)p.big_n + 1;
+  uint64_t *v = (uint64_t *)input_blocks->ptr;
+  for (uint32_t i = 0; i < num_blocks; ++i) {
+    uint64_t *blk = v + (size_t)i * w;
+    HX_CHECK(hipMemcpyAsync(m->d_two, blk, w * sizeof(uint64_t), hipMemcpyDeviceToDevice, st));
+    HX_CHECK(hipMemcpyAsync(m->d_two + w, blk, w * sizeof(uint64_t), hipMemcpyDeviceToDevice, st));
+    m->drv.round(streams, m->d_two, nullptr, m->d_two, nullptr, m->d_lut_idx, 2, ksks, bsks);
+    HX_CHECK(hipMemcpyAsync(blk, m->d_two, w * sizeof(uint64_t), hipMemcpyDeviceToDevice, st));
+    if (input_blocks->degrees) input_blocks->degrees[i] = p.msg - 1;
+    if (input_blocks->noise_levels) input_blocks->noise_levels[i] = 1;
+    if (i + 1 < num_blocks) {
+      axpy(st, blk + w, nullptr, blk + w, nullptr, 1, m->d_two + w, nullptr, (uint32_t)w, 1);
+      if (input_blocks->degrees) input_blocks->degrees[i + 1] += p.carry - 1;
+      if (input_blocks->noise_levels) input_blocks->noise_levels[i + 1] += 1;
+    }
+  }
+}
+
+void cleanup_cuda_full_propagation_64_inplace(CudaStreamsFFI streams, int8_t **mem_ptr_void) {
+  first_gpu(streams);
+  auto *m = reinterpret_cast<FullPropMem *>(*mem_ptr_void);
+  HX_PANIC_IF_FALSE(m && m->magic == FullPropMem::kMagic, "cleanup full_propagation: foreign scratch pointer");
+  m->drv.release(streams);
+  for (uint64_t *d : {m->d_two, m->d_lut_idx})
+    if (d) scratch_free(d);
+  m->magic = 0;
   delete m;
   *mem_ptr_void = nullptr;
 }

@@ -157,6 +157,99 @@ class CudaServerKey:
         _lib().cleanup_cuda_add_and_propagate_single_carry_64_inplace(s, C.byref(mem))
         return cout if (want_carry_out or want_overflow) else None
 
+    def sub_assign(self, lhs, rhs, streams, want_carry_out=False):
+        """lhs -= rhs (mod 2^bits) on clean operands: rhs negated with its correcting term, block additions, one carry
+        propagation (integer/gpu/server_key/radix/sub.rs:347-400).  want_carry_out: the carry leaving the last block of
+        lhs + (2^bits - rhs), i.e. 1 when NO borrow occurred."""
+        s, keep = self._streams(streams)
+        ksks, bsks = self._key_ptrs(streams)
+        mem = C.c_void_p()
+        flag = OUTPUT_FLAG_CARRY if want_carry_out else OUTPUT_FLAG_NONE
+        cin, cout = self._carry_blocks(lhs, None, streams), self._carry_blocks(lhs, None, streams)
+        _lib().hip_integer_scratch_batch(lhs.num_integers)
+        _lib().scratch_cuda_sub_and_propagate_single_carry_64_inplace_async(
+            s, C.byref(mem), self._bsk_params(), self._ksk_params(), lhs.num_blocks, self.message_modulus,
+            self.carry_modulus, flag, True, self._noise_reduction())
+        _lib().cuda_sub_and_propagate_single_carry_64_inplace_async(s, C.byref(lhs._ffi()), C.byref(rhs._ffi()),
+                                                                    C.byref(cout._ffi()), C.byref(cin._ffi()), mem,
+                                                                    bsks, ksks, flag, 0)
+        _lib().cleanup_cuda_sub_and_propagate_single_carry_64_inplace(s, C.byref(mem))
+        return cout if want_carry_out else None
+
+    def unchecked_neg(self, ct, streams):
+        """-ct of ONE integer, levelled (radix/neg.rs unchecked_neg): blocks z - b with the borrowed unit handed on; the
+        result carries degrees above the message modulus (propagate before the next bootstrap-free operation)."""
+        assert ct.num_integers == 1
+        s, keep = self._streams(streams)
+        out = CudaUnsignedRadixCiphertext.zeros_like(ct, streams)
+        _lib().cuda_negate_ciphertext_64(s, C.byref(out._ffi()), C.byref(ct._ffi()), self.message_modulus,
+                                         self.carry_modulus, ct.total_blocks)
+        return out
+
+    def unchecked_scalar_add_assign(self, ct, clear_blocks, streams):
+        """ct[i] += clear_blocks[i] (plaintext addition on the bodies; radix/scalar_add.rs unchecked_scalar_add_assign)."""
+        import numpy as np
+        s, keep = self._streams(streams)
+        h = np.ascontiguousarray(np.asarray(clear_blocks, dtype=np.uint64))
+        d = CudaVec(max(1, h.size), streams)
+        d.copy_from_cpu_async(h, streams)
+        _lib().cuda_scalar_addition_ciphertext_64_inplace(s, C.byref(ct._ffi()), d.ptr, h.ctypes.data_as(C.c_void_p),
+                                                          h.size, self.message_modulus, self.carry_modulus)
+        streams.synchronize()
+
+    def bitnot_assign(self, ct, streams):
+        """Bitwise NOT of clean blocks, levelled (radix/bitwise_op.rs unchecked_bitnot_assign)."""
+        s, keep = self._streams(streams)
+        _lib().cuda_bitnot_ciphertext_64(s, C.byref(ct._ffi()), self.message_modulus, self.message_modulus,
+                                         self.carry_modulus)
+
+    def bitop_assign(self, lhs, rhs, op, streams):
+        """lhs <- lhs (and | or | xor) rhs, one bivariate bootstrap per block pair (radix/bitwise_op.rs
+        unchecked_bitop_assign); op in {"and", "or", "xor"}."""
+        s, keep = self._streams(streams)
+        ksks, bsks = self._key_ptrs(streams)
+        mem = C.c_void_p()
+        code = {"and": 0, "or": 1, "xor": 2}[op]
+        _lib().hip_integer_scratch_batch(1)
+        _lib().scratch_cuda_integer_bitop_inplace_64_async(
+            s, C.byref(mem), self._bsk_params(), self._ksk_params(), lhs.total_blocks, self.message_modulus,
+            self.carry_modulus, code, True, self._noise_reduction())
+        _lib().cuda_integer_bitop_inplace_64_async(s, C.byref(lhs._ffi()), C.byref(rhs._ffi()), mem, bsks, ksks)
+        _lib().cleanup_cuda_integer_bitop_inplace_64(s, C.byref(mem))
+
+    def scalar_bitop_assign(self, ct, clear_blocks, op, streams):
+        """ct <- ct (and | or | xor) scalar, the scalar given as its clear blocks, least significant first
+        (radix/scalar_bitwise_op.rs): a univariate table per clear value; AND clears the blocks past the scalar's."""
+        import numpy as np
+        s, keep = self._streams(streams)
+        ksks, bsks = self._key_ptrs(streams)
+        mem = C.c_void_p()
+        code = {"and": 3, "or": 4, "xor": 5}[op]
+        h = np.ascontiguousarray(np.asarray(clear_blocks, dtype=np.uint64))
+        d = CudaVec(max(1, h.size), streams)
+        d.copy_from_cpu_async(h, streams)
+        _lib().hip_integer_scratch_batch(1)
+        _lib().scratch_cuda_integer_scalar_bitop_inplace_64_async(
+            s, C.byref(mem), self._bsk_params(), self._ksk_params(), ct.total_blocks, self.message_modulus,
+            self.carry_modulus, code, True, self._noise_reduction())
+        _lib().cuda_integer_scalar_bitop_inplace_64_async(s, C.byref(ct._ffi()), d.ptr, h.ctypes.data_as(C.c_void_p),
+                                                          h.size, mem, bsks, ksks)
+        _lib().cleanup_cuda_integer_scalar_bitop_inplace_64(s, C.byref(mem))
+        streams.synchronize()
+
+    def full_propagate_assign(self, ct, streams):
+        """Block after block: message kept, carry added to the next block (radix/mod.rs full_propagate_parallelized's
+        sequential form, integer.cuh:1924-1983); ONE integer; the last block's carry is dropped."""
+        assert ct.num_integers == 1
+        s, keep = self._streams(streams)
+        ksks, bsks = self._key_ptrs(streams)
+        mem = C.c_void_p()
+        _lib().scratch_cuda_full_propagation_64_inplace_async(
+            s, C.byref(mem), self._bsk_params(), self._ksk_params(), self.message_modulus, self.carry_modulus, True,
+            self._noise_reduction())
+        _lib().cuda_full_propagation_64_inplace_async(s, C.byref(ct._ffi()), mem, ksks, bsks, ct.total_blocks)
+        _lib().cleanup_cuda_full_propagation_64_inplace(s, C.byref(mem))
+
     def mul_assign(self, lhs, rhs, streams, return_pbs_count=False):
         """lhs *= rhs (mod 2^bits) on clean operands: schoolbook block products, column sums, propagation."""
         s, keep = self._streams(streams)
