@@ -42,8 +42,11 @@ extern "C" {
 enum PBS_TYPE { MULTI_BIT = 0, CLASSICAL = 1 };
 enum PBS_VARIANT { DEFAULT = 0, CG = 1, TBC = 2 };
 enum PBS_MS_REDUCTION_T { NO_REDUCTION = 0, CENTERED = 1 };
-/* cuda/include/integer/integer.h:15-22 */
+/* cuda/include/integer/integer.h:9-22 */
+enum SHIFT_OR_ROTATE_TYPE { LEFT_SHIFT = 0, RIGHT_SHIFT = 1, LEFT_ROTATE = 2, RIGHT_ROTATE = 3 };
 enum BITOP_TYPE { BITAND = 0, BITOR = 1, BITXOR = 2, SCALAR_BITAND = 3, SCALAR_BITOR = 4, SCALAR_BITXOR = 5 };
+/* cuda/include/integer/integer.h:24-33 */
+enum COMPARISON_TYPE { EQ = 0, NE = 1, GT = 2, GE = 3, LT = 4, LE = 5, MAX = 6, MIN = 7 };
 
 /* ------------------------------------------------------------------ device runtime
  * backends/tfhe-cuda-common/cuda/include/device.h:58-92 (cuda_bind.rs:5-150) */
@@ -542,6 +545,36 @@ void cuda_full_propagation_64_inplace_async(CudaStreamsFFI streams, CudaRadixCip
                                             int8_t *mem_ptr, void *const *ksks, void *const *bsks,
                                             uint32_t num_blocks);
 void cleanup_cuda_full_propagation_64_inplace(CudaStreamsFFI streams, int8_t **mem_ptr_void);
+/* integer.h:246-276 (comparison: unsigned operands, EQ ... LE into block 0 of the output, MAX / MIN over all blocks) and
+ * :349-365 (cmux).  Orderings ride on the subtraction's carry tree without its result round, equality on sums of block results. */
+uint64_t scratch_cuda_integer_comparison_64_async(
+    CudaStreamsFFI streams, int8_t **mem_ptr, CudaLweBootstrapKeyParamsFFI bsk_params,
+    CudaLweKeyswitchKeyParamsFFI ksk_params, uint32_t lwe_ciphertext_count, uint32_t message_modulus,
+    uint32_t carry_modulus, enum COMPARISON_TYPE op_type, bool is_signed, bool allocate_gpu_memory,
+    enum PBS_MS_REDUCTION_T noise_reduction_type);
+void cuda_integer_comparison_64_async(CudaStreamsFFI streams, CudaRadixCiphertextFFI *lwe_array_out,
+                                      CudaRadixCiphertextFFI const *lwe_array_1,
+                                      CudaRadixCiphertextFFI const *lwe_array_2, int8_t *mem_ptr, void *const *bsks,
+                                      void *const *ksks);
+void cleanup_cuda_integer_comparison_64(CudaStreamsFFI streams, int8_t **mem_ptr_void);
+uint64_t scratch_cuda_cmux_64_async(CudaStreamsFFI streams, int8_t **mem_ptr, CudaLweBootstrapKeyParamsFFI bsk_params,
+                                    CudaLweKeyswitchKeyParamsFFI ksk_params, uint32_t lwe_ciphertext_count,
+                                    uint32_t message_modulus, uint32_t carry_modulus, bool allocate_gpu_memory,
+                                    enum PBS_MS_REDUCTION_T noise_reduction_type);
+void cuda_cmux_64_async(CudaStreamsFFI streams, CudaRadixCiphertextFFI *lwe_array_out,
+                        CudaRadixCiphertextFFI const *lwe_condition, CudaRadixCiphertextFFI const *lwe_array_true,
+                        CudaRadixCiphertextFFI const *lwe_array_false, int8_t *mem_ptr, void *const *bsks,
+                        void *const *ksks);
+void cleanup_cuda_cmux_64(CudaStreamsFFI streams, int8_t **mem_ptr_void);
+/* integer.h:200-228: logical shift by a clear amount (LEFT_SHIFT / RIGHT_SHIFT; the rotations are refused): a move by whole
+ * blocks plus one bivariate round when bits remain */
+uint64_t scratch_cuda_logical_scalar_shift_64_inplace_async(
+    CudaStreamsFFI streams, int8_t **mem_ptr, CudaLweBootstrapKeyParamsFFI bsk_params,
+    CudaLweKeyswitchKeyParamsFFI ksk_params, uint32_t num_blocks, uint32_t message_modulus, uint32_t carry_modulus,
+    enum SHIFT_OR_ROTATE_TYPE shift_type, bool allocate_gpu_memory, enum PBS_MS_REDUCTION_T noise_reduction_type);
+void cuda_logical_scalar_shift_64_inplace_async(CudaStreamsFFI streams, CudaRadixCiphertextFFI *lwe_array, uint32_t shift,
+                                                int8_t *mem_ptr, void *const *bsks, void *const *ksks);
+void cleanup_cuda_logical_scalar_shift_64_inplace(CudaStreamsFFI streams, int8_t **mem_ptr_void);
 
 /* extensions: integers per launch the NEXT scratch_* call is sized for (default 1), and the number
  * of PBS one multiplication issues per integer (for throughput accounting) */

@@ -172,3 +172,77 @@ def test_size_queries_allocate_nothing(kind):
                                                                MSG, False, sks._noise_reduction())
     assert size > 2 * (p.big_n + 1) * 8
     lib.cleanup_cuda_full_propagation_64_inplace(s, C.byref(mem))
+
+
+@pytest.mark.parametrize("kind", BACKENDS)
+def test_unsigned_comparisons(kind):
+    """eq / ne over sums of block results, the orderings over the subtraction's output carry; operands that differ in the
+    lowest block only, in the highest only, equal ones, and the extremes."""
+    p, keys, st, sks, igpu = setup(kind)
+    for L in ((1, 5) if kind == "emu" else (1, 2, 16, 17, 32)):
+        mask = (1 << (2 * L)) - 1
+        rng = np.random.default_rng(131 + L)
+        r1, r2 = (int.from_bytes(rng.bytes(8), "little") & mask for _ in range(2))
+        pairs = [(r1, r2), (r1, r1), (0, mask), (mask, 0), (r1, r1 ^ 1), (r1, r1 ^ (1 << (2 * L - 1)))]
+        if kind == "emu":
+            pairs = pairs[:2] + pairs[4:]
+        for n, (a, b) in enumerate(pairs):
+            ca = igpu.CudaUnsignedRadixCiphertext.from_blocks(encrypt_radix(p, keys, [a], L, 140 + n), st)
+            cb = igpu.CudaUnsignedRadixCiphertext.from_blocks(encrypt_radix(p, keys, [b], L, 150 + n), st)
+            ca.set_degrees(MSG - 1)
+            cb.set_degrees(MSG - 1)
+            ops = ("eq", "ne", "gt", "ge", "lt", "le") if (kind != "emu" or n < 2) else ("eq", "lt")
+            for op in ops:
+                out = sks.compare(ca, cb, op, st)
+                want = {"eq": a == b, "ne": a != b, "gt": a > b, "ge": a >= b, "lt": a < b, "le": a <= b}[op]
+                assert decrypt_blocks(p, keys, out.to_blocks(st)) == [[int(want)]], (L, a, b, op)
+                assert list(out.degrees) == [1]
+            # the operands are untouched
+            assert recompose(decrypt_blocks(p, keys, ca.to_blocks(st))) == [a]
+            assert recompose(decrypt_blocks(p, keys, cb.to_blocks(st))) == [b]
+
+
+@pytest.mark.parametrize("kind", BACKENDS)
+def test_if_then_else_and_max_min(kind):
+    p, keys, st, sks, igpu = setup(kind)
+    L = 4 if kind == "emu" else 32
+    mask = (1 << (2 * L)) - 1
+    a, b = 0x93C467E37DB0C7A4 & mask, 0xD1B54A32D192ED03 & mask
+    ca = igpu.CudaUnsignedRadixCiphertext.from_blocks(encrypt_radix(p, keys, [a], L, 161), st)
+    cb = igpu.CudaUnsignedRadixCiphertext.from_blocks(encrypt_radix(p, keys, [b], L, 162), st)
+    for c in (0, 1):
+        cond = igpu.CudaUnsignedRadixCiphertext.from_blocks(encrypt_radix(p, keys, [c], 1, 163 + c), st)
+        out = sks.if_then_else(cond, ca, cb, st)
+        rows = decrypt_blocks(p, keys, out.to_blocks(st))
+        assert all(x < MSG for x in rows[0])
+        assert recompose(rows) == [a if c else b]
+    for op, want in (("max", max(a, b)), ("min", min(a, b))):
+        out = sks.compare(ca, cb, op, st)
+        assert recompose(decrypt_blocks(p, keys, out.to_blocks(st))) == [want]
+        out = sks.compare(cb, ca, op, st)
+        assert recompose(decrypt_blocks(p, keys, out.to_blocks(st))) == [want]
+    out = sks.compare(ca, ca, "max", st)
+    assert recompose(decrypt_blocks(p, keys, out.to_blocks(st))) == [a]
+
+
+@pytest.mark.parametrize("kind", BACKENDS)
+def test_logical_shifts_by_a_clear_amount(kind):
+    """Whole-block moves, bit shifts inside the blocks, both at once, no shift, and the overshift that clears the integer."""
+    p, keys, st, sks, igpu = setup(kind)
+    L = 6 if kind == "emu" else 32
+    bits = 2 * L
+    mask = (1 << bits) - 1
+    a = 0xB7E151628AED2A6B & mask
+    shifts = (0, 1, 2, 5, bits - 1, bits, bits + 3) if kind == "emu" else (0, 1, 2, 3, 8, 17, 31, 32, 33, 62, 63, 64, 65)
+    for left in (True, False):
+        for sh in shifts:
+            ca = igpu.CudaUnsignedRadixCiphertext.from_blocks(encrypt_radix(p, keys, [a], L, 171 + sh), st)
+            ca.set_degrees(MSG - 1)
+            sks.scalar_shift_assign(ca, sh, st, left=left)
+            rows = decrypt_blocks(p, keys, ca.to_blocks(st))
+            assert all(x < MSG for x in rows[0])
+            want = ((a << sh) & mask) if left else (a >> sh)
+            assert recompose(rows) == [want], (left, sh)
+            q = min(sh // 2, L)
+            zeroed = list(ca.degrees[:q]) if left else list(ca.degrees[L - q:])
+            assert zeroed == [0] * q, (left, sh)

@@ -835,7 +835,8 @@ struct PropagateMem {
     axpy(S0(ss), d_pack, nullptr, lhs, rLast.a, p.msg, rhs, rLast.a, w, cts);
   }
   void run(const CudaStreamsFFI &ss, uint64_t *v, uint32_t cts, void *const *ksks, void *const *bsks,
-           const uint64_t *carry_in = nullptr, uint64_t *carry_out = nullptr, uint64_t *overflow_out = nullptr) {
+           const uint64_t *carry_in = nullptr, uint64_t *carry_out = nullptr, uint64_t *overflow_out = nullptr,
+           bool results = true) {  // results = false: only the flags are wanted (comparisons), v is left with its sums
     const hipStream_t st = S0(ss);  // linear operations and index uploads: first GPU only, like the reference
     HX_PANIC_IF_FALSE(cts >= 1 && cts <= max_cts, "carry propagation: %u integers exceed the scratch capacity %u", cts,
                       max_cts);
@@ -854,7 +855,7 @@ struct PropagateMem {
         drv.round(ss, overflow_out, nullptr, d_p, nullptr, rOne1.lut, cts, ksks, bsks);
       }
       if (carry_out) drv.round(ss, carry_out, nullptr, v, nullptr, rIO.lut, cts, ksks, bsks);
-      drv.round(ss, v, nullptr, v, nullptr, rOne.lut, cts, ksks, bsks);
+      if (results) drv.round(ss, v, nullptr, v, nullptr, rOne.lut, cts, ksks, bsks);
       return;
     }
     // A: shifted state and 4 (value % msg) of every block; up: shifted states of the groups, level by level
@@ -866,7 +867,7 @@ struct PropagateMem {
     // results (and the output carry) from 4 m + z
     if (carry_out) summed_round(ss, carry_out, rOut, w, ksks, bsks);
     if (overflow_out) summed_round(ss, overflow_out, rOvf, w, ksks, bsks);
-    summed_round(ss, v, rRes, w, ksks, bsks);
+    if (results) summed_round(ss, v, rRes, w, ksks, bsks);
   }
 
   void release(const CudaStreamsFFI &ss) {
@@ -1260,6 +1261,193 @@ struct FullPropMem {
   bool size_only = false;
   LutDriver drv;  // LUTs: 0 message, 1 carry
   uint64_t *d_two = nullptr, *d_lut_idx = nullptr;  // the block twice -> (message, carry); indexes {0, 1}
+};
+
+// comparison.cuh / integer.h:246-276, unsigned operands.  Orderings ride on the subtraction's carry tree:
+//   a >= b  <=>  a + (2^bits - b) carries out of the last block
+// so GE is the output carry of the subtraction WITHOUT its result round (65 of the 97 bootstraps of a 32-block
+// subtraction, 5 rounds), LE swaps the operands, LT / GT are 1 - that (levelled).  The reference reduces block orderings
+// pairwise (63 bootstraps in 6 rounds for 32 blocks: comparison.cuh).  Equality: one bivariate round, then sums of up to
+// msg * carry - 1 block results against their count, level by level (32 + 3 + 1 bootstraps in 3 rounds).
+struct CompareMem {
+  static constexpr uint32_t kMagic = 0x434D5031;  // "CMP1"
+  uint32_t magic = kMagic;
+  bool size_only = false;
+  uint32_t op = 0, blocks = 0;
+  PropagateMem prop;  // orderings
+  LutDriver eq;       // equality: LUT 0 a == b, 1 a != b (packed pairs); 2 + (c - 1): sum == c; 2 + G + (c - 1): sum != c
+  uint32_t G = 0;     // largest group: msg * carry - 1
+  uint64_t *d_tmp = nullptr, *d_neg = nullptr, *d_bool = nullptr;  // orderings: lhs copy, negated rhs, the flag
+  uint64_t *d_pack = nullptr, *d_pool = nullptr, *d_sum = nullptr, *d_lut0 = nullptr;
+  struct Level {
+    uint32_t groups = 0, in_off = 0, out_off = 0;
+    uint64_t *off = nullptr, *mem = nullptr, *lut = nullptr;
+  };
+  std::vector<Level> levels;
+  std::vector<uint64_t *> dev_arrays;
+  uint32_t last_slot = 0;
+
+  bool ordering() const { return op >= GT && op <= LE; }
+
+  void init(const CudaStreamsFFI &ss, const Params &p, uint32_t L, uint32_t operation) {
+    op = operation;
+    blocks = L;
+    const size_t w = (size_t)p.big_n + 1, lw = (size_t)(p.k + 1) * p.N;
+    if (ordering()) {
+      prop.init(ss, p, L, 1);
+      radix_alloc((void **)&d_tmp, L * w * sizeof(uint64_t));
+      radix_alloc((void **)&d_neg, L * w * sizeof(uint64_t));
+      radix_alloc((void **)&d_bool, w * sizeof(uint64_t));
+      return;
+    }
+    G = p.msg * p.carry - 1;
+    const uint32_t msg = p.msg;
+    std::vector<std::vector<uint64_t>> luts(2 + 2 * G, std::vector<uint64_t>(lw));
+    generate_lut(p, luts[0].data(), [msg](uint64_t x) -> uint64_t { return x / msg == x % msg; });
+    generate_lut(p, luts[1].data(), [msg](uint64_t x) -> uint64_t { return x / msg != x % msg; });
+    for (uint32_t c = 1; c <= G; ++c) {
+      generate_lut(p, luts[2 + c - 1].data(), [c](uint64_t x) -> uint64_t { return x == c; });
+      generate_lut(p, luts[2 + G + c - 1].data(), [c](uint64_t x) -> uint64_t { return x != c; });
+    }
+    eq.init(ss, p, L, luts);
+    radix_alloc((void **)&d_pack, L * w * sizeof(uint64_t));
+    // pool: the block results, then every level's results
+    uint32_t slots = L, n = L;
+    std::vector<uint32_t> sizes;
+    while (n > 1) {
+      n = (n + G - 1) / G;
+      sizes.push_back(n);
+      slots += n;
+    }
+    radix_alloc((void **)&d_pool, (size_t)slots * w * sizeof(uint64_t));
+    radix_alloc((void **)&d_sum, (size_t)std::max<uint32_t>(1, sizes.empty() ? 1 : sizes[0]) * w * sizeof(uint64_t));
+    const bool ne = op == NE;
+    d_lut0 = dev_upload(S0(ss), std::vector<uint64_t>(L, (L == 1 && ne) ? 1 : 0));
+    dev_arrays.push_back(d_lut0);
+    uint32_t in_off = 0, in_n = L, out_off = L;
+    for (size_t l = 0; l < sizes.size(); ++l) {
+      Level lv;
+      lv.groups = sizes[l];
+      lv.in_off = in_off;
+      lv.out_off = out_off;
+      std::vector<uint64_t> off(lv.groups + 1), mem(in_n), lut(lv.groups);
+      for (uint32_t g = 0; g <= lv.groups; ++g) off[g] = std::min<uint64_t>((uint64_t)g * G, in_n);
+      for (uint32_t i = 0; i < in_n; ++i) mem[i] = in_off + i;
+      const bool last = l + 1 == sizes.size();
+      for (uint32_t g = 0; g < lv.groups; ++g) {
+        const uint32_t c = (uint32_t)(off[g + 1] - off[g]);
+        lut[g] = (last && ne) ? 2 + G + c - 1 : 2 + c - 1;
+      }
+      lv.off = dev_upload(S0(ss), off);
+      lv.mem = dev_upload(S0(ss), mem);
+      lv.lut = dev_upload(S0(ss), lut);
+      for (uint64_t *d : {lv.off, lv.mem, lv.lut}) dev_arrays.push_back(d);
+      levels.push_back(lv);
+      in_off = out_off;
+      in_n = lv.groups;
+      out_off += lv.groups;
+    }
+    last_slot = in_off;  // slot of the single result (0 when L == 1)
+  }
+
+  // flag (one block) <- op(a, b); a and b: `blocks` clean blocks each
+  void run(const CudaStreamsFFI &ss, uint64_t *flag, const uint64_t *a, const uint64_t *b, void *const *ksks,
+           void *const *bsks) {
+    const hipStream_t st = S0(ss);
+    const uint32_t L = blocks;
+    if (ordering()) {
+      const Params &p = prop.drv.p;
+      const uint32_t w = p.big_n + 1;
+      const uint64_t delta = ((uint64_t)1 << 63) / ((uint64_t)p.msg * p.carry);
+      const bool swap = op == LE || op == GT;       // LE(a, b) = GE(b, a); GT(a, b) = LT(b, a)
+      const bool invert = op == LT || op == GT;     // LT = 1 - GE
+      const uint64_t *x = swap ? b : a, *y = swap ? a : b;
+      HX_CHECK(hipMemcpyAsync(d_tmp, x, (size_t)L * w * sizeof(uint64_t), hipMemcpyDeviceToDevice, st));
+      HX_LAUNCH(lwe_negate_const_kernel, dim3(L), dim3(256), 0, st, d_neg, y, w, L, L, (uint64_t)p.msg * delta,
+                (uint64_t)(p.msg - 1) * delta);
+      axpy(st, d_tmp, nullptr, d_tmp, nullptr, 1, d_neg, nullptr, w, L);
+      prop.run(ss, d_tmp, 1, ksks, bsks, nullptr, invert ? d_bool : flag, nullptr, false);
+      if (invert) HX_LAUNCH(lwe_negate_const_kernel, dim3(1), dim3(256), 0, st, flag, d_bool, w, 1, 1, delta, delta);
+      return;
+    }
+    const Params &p = eq.p;
+    const uint32_t w = p.big_n + 1;
+    axpy(st, d_pack, nullptr, a, nullptr, p.msg, b, nullptr, w, L);
+    eq.round(ss, d_pool, nullptr, d_pack, nullptr, d_lut0, L, ksks, bsks);
+    for (const Level &lv : levels) {
+      HX_LAUNCH(lwe_group_sum_kernel, dim3(lv.groups), dim3(256), 0, st, d_sum, d_pool, lv.off, lv.mem, w, lv.groups);
+      eq.round(ss, d_pool + (size_t)lv.out_off * w, nullptr, d_sum, nullptr, lv.lut, lv.groups, ksks, bsks);
+    }
+    HX_CHECK(hipMemcpyAsync(flag, d_pool + (size_t)last_slot * w, (size_t)w * sizeof(uint64_t), hipMemcpyDeviceToDevice, st));
+  }
+
+  void release(const CudaStreamsFFI &ss) {
+    HX_CHECK(hipStreamSynchronize(S0(ss)));
+    if (ordering()) prop.release(ss); else eq.release(ss);
+    for (uint64_t *d : dev_arrays)
+      if (d) scratch_free(d);
+    dev_arrays.clear();
+    for (uint64_t *d : {d_tmp, d_neg, d_bool, d_pack, d_pool, d_sum})
+      if (d) scratch_free(d);
+    magic = 0;
+  }
+};
+
+// cmux.cuh / integer.h:349-365: out <- condition ? true : false.  Both branches packed with the condition's single block
+// (block + msg * condition), one round over the 2 L packed blocks keeps a branch's block or zeroes it, the halves are added
+// and a message-extraction round returns the sum to nominal noise (the reference's int_cmux_buffer does the same three steps)
+struct CmuxMem {
+  static constexpr uint32_t kMagic = 0x434D5831;  // "CMX1"
+  uint32_t magic = kMagic;
+  bool size_only = false;
+  LutDriver drv;  // LUTs: 0 keep if the condition is 1, 1 keep if it is 0, 2 message
+  uint32_t blocks = 0;
+  uint64_t *d_pack = nullptr, *d_zero_idx = nullptr, *d_lut_idx = nullptr, *d_lut2 = nullptr;
+
+  void init(const CudaStreamsFFI &ss, const Params &p, uint32_t L) {
+    blocks = L;
+    const uint64_t m = p.msg;
+    std::vector<std::vector<uint64_t>> luts(3, std::vector<uint64_t>((size_t)(p.k + 1) * p.N));
+    generate_lut(p, luts[0].data(), [m](uint64_t x) -> uint64_t { return x >= m && x < 2 * m ? x - m : 0; });
+    generate_lut(p, luts[1].data(), [m](uint64_t x) -> uint64_t { return x < m ? x : 0; });
+    generate_lut(p, luts[2].data(), [m](uint64_t x) -> uint64_t { return x % m; });
+    drv.init(ss, p, 2 * L, luts);
+    radix_alloc((void **)&d_pack, (size_t)2 * L * (p.big_n + 1) * sizeof(uint64_t));
+    std::vector<uint64_t> li(2 * L, 0);
+    for (uint32_t i = L; i < 2 * L; ++i) li[i] = 1;
+    d_zero_idx = dev_upload(S0(ss), std::vector<uint64_t>(L, 0));
+    d_lut_idx = dev_upload(S0(ss), li);
+    d_lut2 = dev_upload(S0(ss), std::vector<uint64_t>(L, 2));
+  }
+  void run(const CudaStreamsFFI &ss, uint64_t *out, const uint64_t *cond, const uint64_t *t, const uint64_t *f,
+           void *const *ksks, void *const *bsks) {
+    const Params &p = drv.p;
+    const hipStream_t st = S0(ss);
+    const uint32_t L = blocks, w = p.big_n + 1;
+    axpy(st, d_pack, nullptr, cond, d_zero_idx, p.msg, t, nullptr, w, L);
+    axpy(st, d_pack + (size_t)L * w, nullptr, cond, d_zero_idx, p.msg, f, nullptr, w, L);
+    drv.round(ss, d_pack, nullptr, d_pack, nullptr, d_lut_idx, 2 * L, ksks, bsks);
+    axpy(st, out, nullptr, d_pack, nullptr, 1, d_pack + (size_t)L * w, nullptr, w, L);
+    drv.round(ss, out, nullptr, out, nullptr, d_lut2, L, ksks, bsks);
+  }
+  void release(const CudaStreamsFFI &ss) {
+    HX_CHECK(hipStreamSynchronize(S0(ss)));
+    drv.release(ss);
+    for (uint64_t *d : {d_pack, d_zero_idx, d_lut_idx, d_lut2})
+      if (d) scratch_free(d);
+    magic = 0;
+  }
+};
+
+// scalar_shifts.cuh / integer.h:200-228: logical shift of an unsigned integer by a clear amount = a move by whole blocks
+// and, when bits remain, ONE bivariate round over (block, its lower / upper neighbour)
+struct ScalarShiftMem {
+  static constexpr uint32_t kMagic = 0x53484631;  // "SHF1"
+  uint32_t magic = kMagic;
+  bool size_only = false;
+  LutDriver drv;  // LUT r - 1: the shift by r bits inside a block (r = 1 .. bits per block - 1), this scratch's direction
+  uint32_t blocks = 0, bits = 0, left = 0;
+  uint64_t *d_pack = nullptr, *d_lut_idx = nullptr;  // packed pairs / block copy; one constant index array per r
 };
 
 static uint32_t batch_of(const CudaRadixCiphertextFFI *ct, uint32_t blocks, const char *what) {
@@ -2048,6 +2236,281 @@ void cleanup_cuda_full_propagation_64_inplace(CudaStreamsFFI streams, int8_t **m
   HX_PANIC_IF_FALSE(m && m->magic == FullPropMem::kMagic, "cleanup full_propagation: foreign scratch pointer");
   m->drv.release(streams);
   for (uint64_t *d : {m->d_two, m->d_lut_idx})
+    if (d) scratch_free(d);
+  m->magic = 0;
+  delete m;
+  *mem_ptr_void = nullptr;
+}
+
+// ---- cuda/include/integer/integer.h:246-276 (comparison), :349-365 (cmux) ----------------------------
+// Unsigned operands; the boolean lands in block 0 of lwe_array_out (its other blocks are cleared), as the single-block
+// result of the reference's EQ ... LE.  MAX / MIN: the ordering's flag drives a cmux of the operands.
+struct CompareScratch {
+  static constexpr uint32_t kMagic = 0x43535231;  // "CSR1"
+  uint32_t magic = kMagic;
+  uint32_t op = 0;
+  CompareMem cmp;
+  CmuxMem mux;  // MAX / MIN only
+  uint64_t *d_flag = nullptr;
+};
+uint64_t scratch_cuda_integer_comparison_64_async(CudaStreamsFFI streams, int8_t **mem_ptr,
+                                                  CudaLweBootstrapKeyParamsFFI bsk_params,
+                                                  CudaLweKeyswitchKeyParamsFFI ksk_params,
+                                                  uint32_t lwe_ciphertext_count, uint32_t message_modulus,
+                                                  uint32_t carry_modulus, enum COMPARISON_TYPE op_type, bool is_signed,
+                                                  bool allocate_gpu_memory,
+                                                  enum PBS_MS_REDUCTION_T noise_reduction_type) {
+  first_gpu(streams);
+  HX_PANIC_IF_FALSE(mem_ptr != nullptr && lwe_ciphertext_count >= 1, "integer_comparison: null pointer or no blocks");
+  HX_PANIC_IF_FALSE(!is_signed, "integer_comparison: signed operands are not wired");
+  HX_PANIC_IF_FALSE((uint32_t)op_type <= MIN, "integer_comparison: unknown operation %u", (uint32_t)op_type);
+  const Params p = make_params(bsk_params, ksk_params, message_modulus, carry_modulus, (uint32_t)noise_reduction_type);
+  t_dry = !allocate_gpu_memory;
+  t_bytes = 0;
+  auto *m = new CompareScratch();
+  m->op = (uint32_t)op_type;
+  const bool select = op_type == MAX || op_type == MIN;
+  m->cmp.init(streams, p, lwe_ciphertext_count, select ? (uint32_t)GE : (uint32_t)op_type);
+  if (select) {
+    m->mux.init(streams, p, lwe_ciphertext_count);
+    radix_alloc((void **)&m->d_flag, (size_t)(p.big_n + 1) * sizeof(uint64_t));
+  }
+  m->cmp.size_only = t_dry;
+  t_dry = false;
+  *mem_ptr = reinterpret_cast<int8_t *>(m);
+  return t_bytes;
+}
+
+void cuda_integer_comparison_64_async(CudaStreamsFFI streams, CudaRadixCiphertextFFI *lwe_array_out,
+                                      CudaRadixCiphertextFFI const *lwe_array_1,
+                                      CudaRadixCiphertextFFI const *lwe_array_2, int8_t *mem_ptr, void *const *bsks,
+                                      void *const *ksks) {
+  first_gpu(streams);
+  auto *m = reinterpret_cast<CompareScratch *>(mem_ptr);
+  HX_PANIC_IF_FALSE(m && m->magic == CompareScratch::kMagic, "integer_comparison: foreign scratch pointer");
+  HX_PANIC_IF_FALSE(!m->cmp.size_only, "integer_comparison: scratch was created with allocate_gpu_memory=false");
+  HX_PANIC_IF_FALSE(lwe_array_out && lwe_array_1 && lwe_array_2 && lwe_array_out->ptr && lwe_array_1->ptr &&
+                        lwe_array_2->ptr && bsks && ksks,
+                    "integer_comparison: null pointer");
+  const uint32_t L = m->cmp.blocks;
+  HX_PANIC_IF_FALSE(lwe_array_1->num_radix_blocks == L && lwe_array_2->num_radix_blocks == L,
+                    "integer_comparison: the operands must hold the %u blocks the scratch was made for", L);
+  HX_PANIC_IF_FALSE(lwe_array_1->lwe_dimension == lwe_array_2->lwe_dimension &&
+                        lwe_array_out->lwe_dimension == lwe_array_1->lwe_dimension,
+                    "input and output lwe dimension must be equal");
+  const Params &p = m->cmp.ordering() ? m->cmp.prop.drv.p : m->cmp.eq.p;
+  for (const CudaRadixCiphertextFFI *op : {lwe_array_1, lwe_array_2})
+    if (op->degrees)
+      for (uint32_t i = 0; i < L; ++i)
+        HX_PANIC_IF_FALSE(op->degrees[i] <= p.msg - 1, "integer_comparison: block %u has degree %llu, the comparison takes "
+                          "clean operands (propagate them first)", i, (unsigned long long)op->degrees[i]);
+  const size_t w = (size_t)p.big_n + 1;
+  uint64_t *out = (uint64_t *)lwe_array_out->ptr;
+  const uint64_t *a = (const uint64_t *)lwe_array_1->ptr, *b = (const uint64_t *)lwe_array_2->ptr;
+  if (m->op == MAX || m->op == MIN) {
+    HX_PANIC_IF_FALSE(lwe_array_out->num_radix_blocks >= L, "integer_comparison: MAX / MIN need %u output blocks", L);
+    m->cmp.run(streams, m->d_flag, a, b, ksks, bsks);  // a >= b
+    m->mux.run(streams, out, m->d_flag, m->op == MAX ? a : b, m->op == MAX ? b : a, ksks, bsks);
+    for (uint32_t i = 0; i < L; ++i) {
+      if (lwe_array_out->degrees) lwe_array_out->degrees[i] = p.msg - 1;
+      if (lwe_array_out->noise_levels) lwe_array_out->noise_levels[i] = 1;
+    }
+    return;
+  }
+  HX_PANIC_IF_FALSE(lwe_array_out->num_radix_blocks >= 1, "integer_comparison: the output needs a block");
+  m->cmp.run(streams, out, a, b, ksks, bsks);
+  if (lwe_array_out->num_radix_blocks > 1)
+    HX_CHECK(hipMemsetAsync(out + w, 0, (size_t)(lwe_array_out->num_radix_blocks - 1) * w * sizeof(uint64_t), S0(streams)));
+  for (uint32_t i = 0; i < lwe_array_out->num_radix_blocks; ++i) {
+    if (lwe_array_out->degrees) lwe_array_out->degrees[i] = i == 0 ? 1 : 0;
+    if (lwe_array_out->noise_levels) lwe_array_out->noise_levels[i] = i == 0 ? 1 : 0;
+  }
+}
+
+void cleanup_cuda_integer_comparison_64(CudaStreamsFFI streams, int8_t **mem_ptr_void) {
+  first_gpu(streams);
+  auto *m = reinterpret_cast<CompareScratch *>(*mem_ptr_void);
+  HX_PANIC_IF_FALSE(m && m->magic == CompareScratch::kMagic, "cleanup integer_comparison: foreign scratch pointer");
+  m->cmp.release(streams);
+  if (m->op == MAX || m->op == MIN) m->mux.release(streams);
+  if (m->d_flag) scratch_free(m->d_flag);
+  m->magic = 0;
+  delete m;
+  *mem_ptr_void = nullptr;
+}
+
+uint64_t scratch_cuda_cmux_64_async(CudaStreamsFFI streams, int8_t **mem_ptr, CudaLweBootstrapKeyParamsFFI bsk_params,
+                                    CudaLweKeyswitchKeyParamsFFI ksk_params, uint32_t lwe_ciphertext_count,
+                                    uint32_t message_modulus, uint32_t carry_modulus, bool allocate_gpu_memory,
+                                    enum PBS_MS_REDUCTION_T noise_reduction_type) {
+  first_gpu(streams);
+  HX_PANIC_IF_FALSE(mem_ptr != nullptr && lwe_ciphertext_count >= 1, "cmux: null pointer or no blocks");
+  const Params p = make_params(bsk_params, ksk_params, message_modulus, carry_modulus, (uint32_t)noise_reduction_type);
+  t_dry = !allocate_gpu_memory;
+  t_bytes = 0;
+  auto *m = new CmuxMem();
+  m->init(streams, p, lwe_ciphertext_count);
+  m->size_only = t_dry;
+  t_dry = false;
+  *mem_ptr = reinterpret_cast<int8_t *>(m);
+  return t_bytes;
+}
+
+void cuda_cmux_64_async(CudaStreamsFFI streams, CudaRadixCiphertextFFI *lwe_array_out,
+                        CudaRadixCiphertextFFI const *lwe_condition, CudaRadixCiphertextFFI const *lwe_array_true,
+                        CudaRadixCiphertextFFI const *lwe_array_false, int8_t *mem_ptr, void *const *bsks,
+                        void *const *ksks) {
+  first_gpu(streams);
+  auto *m = reinterpret_cast<CmuxMem *>(mem_ptr);
+  HX_PANIC_IF_FALSE(m && m->magic == CmuxMem::kMagic, "cmux: foreign scratch pointer");
+  HX_PANIC_IF_FALSE(!m->size_only, "cmux: scratch was created with allocate_gpu_memory=false");
+  HX_PANIC_IF_FALSE(lwe_array_out && lwe_condition && lwe_array_true && lwe_array_false && lwe_array_out->ptr &&
+                        lwe_condition->ptr && lwe_array_true->ptr && lwe_array_false->ptr && bsks && ksks,
+                    "cmux: null pointer");
+  const uint32_t L = m->blocks;
+  HX_PANIC_IF_FALSE(lwe_array_true->num_radix_blocks == L && lwe_array_false->num_radix_blocks == L &&
+                        lwe_array_out->num_radix_blocks >= L && lwe_condition->num_radix_blocks >= 1,
+                    "cmux: the branches must hold the %u blocks the scratch was made for, the condition one block", L);
+  HX_PANIC_IF_FALSE(lwe_array_true->lwe_dimension == lwe_array_false->lwe_dimension &&
+                        lwe_array_out->lwe_dimension == lwe_array_true->lwe_dimension &&
+                        lwe_condition->lwe_dimension == lwe_array_true->lwe_dimension,
+                    "input and output lwe dimension must be equal");
+  const Params &p = m->drv.p;
+  for (const CudaRadixCiphertextFFI *op : {lwe_array_true, lwe_array_false})
+    if (op->degrees)
+      for (uint32_t i = 0; i < L; ++i)
+        HX_PANIC_IF_FALSE(op->degrees[i] <= p.msg - 1, "cmux: block %u has degree %llu, the branches must be clean", i,
+                          (unsigned long long)op->degrees[i]);
+  if (lwe_condition->degrees)
+    HX_PANIC_IF_FALSE(lwe_condition->degrees[0] <= 1, "cmux: the condition must be a boolean block (degree %llu)",
+                      (unsigned long long)lwe_condition->degrees[0]);
+  m->run(streams, (uint64_t *)lwe_array_out->ptr, (const uint64_t *)lwe_condition->ptr,
+         (const uint64_t *)lwe_array_true->ptr, (const uint64_t *)lwe_array_false->ptr, ksks, bsks);
+  for (uint32_t i = 0; i < L; ++i) {
+    if (lwe_array_out->degrees) lwe_array_out->degrees[i] = p.msg - 1;
+    if (lwe_array_out->noise_levels) lwe_array_out->noise_levels[i] = 1;
+  }
+}
+
+void cleanup_cuda_cmux_64(CudaStreamsFFI streams, int8_t **mem_ptr_void) {
+  first_gpu(streams);
+  auto *m = reinterpret_cast<CmuxMem *>(*mem_ptr_void);
+  HX_PANIC_IF_FALSE(m && m->magic == CmuxMem::kMagic, "cleanup cmux: foreign scratch pointer");
+  m->release(streams);
+  delete m;
+  *mem_ptr_void = nullptr;
+}
+
+// ---- cuda/include/integer/integer.h:200-228 -------------------------------------------------------
+uint64_t scratch_cuda_logical_scalar_shift_64_inplace_async(CudaStreamsFFI streams, int8_t **mem_ptr,
+                                                            CudaLweBootstrapKeyParamsFFI bsk_params,
+                                                            CudaLweKeyswitchKeyParamsFFI ksk_params, uint32_t num_blocks,
+                                                            uint32_t message_modulus, uint32_t carry_modulus,
+                                                            enum SHIFT_OR_ROTATE_TYPE shift_type, bool allocate_gpu_memory,
+                                                            enum PBS_MS_REDUCTION_T noise_reduction_type) {
+  first_gpu(streams);
+  HX_PANIC_IF_FALSE(mem_ptr != nullptr && num_blocks >= 1, "logical_scalar_shift: null pointer or no blocks");
+  HX_PANIC_IF_FALSE(shift_type == LEFT_SHIFT || shift_type == RIGHT_SHIFT,
+                    "logical_scalar_shift: shift type %u is a rotation (scalar_rotate is not wired)", (uint32_t)shift_type);
+  HX_PANIC_IF_FALSE((message_modulus & (message_modulus - 1)) == 0, "logical_scalar_shift: the message modulus must be a power of two");
+  const Params p = make_params(bsk_params, ksk_params, message_modulus, carry_modulus, (uint32_t)noise_reduction_type);
+  t_dry = !allocate_gpu_memory;
+  t_bytes = 0;
+  auto *m = new ScalarShiftMem();
+  m->blocks = num_blocks;
+  m->bits = (uint32_t)__builtin_ctz(p.msg);
+  m->left = shift_type == LEFT_SHIFT;
+  const uint32_t msg = p.msg, bits = m->bits;
+  const bool left = m->left != 0;
+  std::vector<std::vector<uint64_t>> luts(std::max(1u, bits - 1), std::vector<uint64_t>((size_t)(p.k + 1) * p.N));
+  for (uint32_t r = 1; r < bits; ++r)  // packed msg * current + neighbour (lower neighbour for a left shift, upper for a right one)
+    generate_lut(p, luts[r - 1].data(), [msg, bits, r, left](uint64_t x) -> uint64_t {
+      const uint64_t cur = x / msg, nb = x % msg;
+      return (left ? ((cur << r) | (nb >> (bits - r))) : ((cur >> r) | (nb << (bits - r)))) % msg;
+    });
+  m->drv.init(streams, p, num_blocks, luts);
+  radix_alloc((void **)&m->d_pack, (size_t)num_blocks * (p.big_n + 1) * sizeof(uint64_t));
+  std::vector<uint64_t> li((size_t)std::max(1u, bits - 1) * num_blocks);
+  for (size_t i = 0; i < li.size(); ++i) li[i] = i / num_blocks;
+  m->d_lut_idx = dev_upload(S0(streams), li);
+  m->size_only = t_dry;
+  t_dry = false;
+  *mem_ptr = reinterpret_cast<int8_t *>(m);
+  return t_bytes;
+}
+
+void cuda_logical_scalar_shift_64_inplace_async(CudaStreamsFFI streams, CudaRadixCiphertextFFI *lwe_array, uint32_t shift,
+                                                int8_t *mem_ptr, void *const *bsks, void *const *ksks) {
+  first_gpu(streams);
+  auto *m = reinterpret_cast<ScalarShiftMem *>(mem_ptr);
+  HX_PANIC_IF_FALSE(m && m->magic == ScalarShiftMem::kMagic, "logical_scalar_shift: foreign scratch pointer");
+  HX_PANIC_IF_FALSE(!m->size_only, "logical_scalar_shift: scratch was created with allocate_gpu_memory=false");
+  HX_PANIC_IF_FALSE(lwe_array && lwe_array->ptr && bsks && ksks, "logical_scalar_shift: null pointer");
+  const uint32_t L = m->blocks;
+  HX_PANIC_IF_FALSE(lwe_array->num_radix_blocks >= L, "input does not have enough blocks");
+  const Params &p = m->drv.p;
+  if (lwe_array->degrees)
+    for (uint32_t i = 0; i < L; ++i)
+      HX_PANIC_IF_FALSE(lwe_array->degrees[i] <= p.msg - 1, "logical_scalar_shift: block %u has degree %llu, the shift takes "
+                        "clean blocks", i, (unsigned long long)lwe_array->degrees[i]);
+  if (shift == 0) return;
+  const hipStream_t st = S0(streams);
+  const uint32_t w = p.big_n + 1;
+  uint64_t *v = (uint64_t *)lwe_array->ptr;
+  auto clear = [&](uint32_t first, uint32_t count) {
+    if (count == 0) return;
+    HX_CHECK(hipMemsetAsync(v + (size_t)first * w, 0, (size_t)count * w * sizeof(uint64_t), st));
+    for (uint32_t i = first; i < first + count; ++i) {
+      if (lwe_array->degrees) lwe_array->degrees[i] = 0;
+      if (lwe_array->noise_levels) lwe_array->noise_levels[i] = 0;
+    }
+  };
+  if ((uint64_t)shift >= (uint64_t)m->bits * L) {  // every bit leaves
+    clear(0, L);
+    return;
+  }
+  const uint32_t q = shift / m->bits, r = shift % m->bits, n = L - q;  // n blocks survive
+  const size_t bw = (size_t)w * sizeof(uint64_t);
+  if (r == 0) {
+    HX_CHECK(hipMemcpyAsync(m->d_pack, v + (m->left ? 0 : (size_t)q * w), n * bw, hipMemcpyDeviceToDevice, st));
+    HX_CHECK(hipMemcpyAsync(v + (m->left ? (size_t)q * w : 0), m->d_pack, n * bw, hipMemcpyDeviceToDevice, st));
+    if (lwe_array->degrees) {
+      std::vector<uint64_t> d(lwe_array->degrees + (m->left ? 0 : q), lwe_array->degrees + (m->left ? 0 : q) + n);
+      std::copy(d.begin(), d.end(), lwe_array->degrees + (m->left ? q : 0));
+    }
+    if (lwe_array->noise_levels) {
+      std::vector<uint64_t> d(lwe_array->noise_levels + (m->left ? 0 : q), lwe_array->noise_levels + (m->left ? 0 : q) + n);
+      std::copy(d.begin(), d.end(), lwe_array->noise_levels + (m->left ? q : 0));
+    }
+    clear(m->left ? 0 : n, q);
+    return;
+  }
+  const uint64_t *lut = m->d_lut_idx + (size_t)(r - 1) * L;
+  if (m->left) {
+    // surviving block j (j = 0 .. n - 1) lands at position j + q: msg * b[j] + b[j - 1]
+    axpy(st, m->d_pack, nullptr, v, nullptr, p.msg, nullptr, nullptr, w, 1);
+    if (n > 1) axpy(st, m->d_pack + w, nullptr, v + w, nullptr, p.msg, v, nullptr, w, n - 1);
+    m->drv.round(streams, v + (size_t)q * w, nullptr, m->d_pack, nullptr, lut, n, ksks, bsks);
+  } else {
+    // position j (j = 0 .. n - 1) takes msg * b[j + q] + b[j + q + 1]
+    if (n > 1) axpy(st, m->d_pack, nullptr, v + (size_t)q * w, nullptr, p.msg, v + (size_t)(q + 1) * w, nullptr, w, n - 1);
+    axpy(st, m->d_pack + (size_t)(n - 1) * w, nullptr, v + (size_t)(L - 1) * w, nullptr, p.msg, nullptr, nullptr, w, 1);
+    m->drv.round(streams, v, nullptr, m->d_pack, nullptr, lut, n, ksks, bsks);
+  }
+  for (uint32_t i = (m->left ? q : 0); i < (m->left ? L : n); ++i) {
+    if (lwe_array->degrees) lwe_array->degrees[i] = p.msg - 1;
+    if (lwe_array->noise_levels) lwe_array->noise_levels[i] = 1;
+  }
+  clear(m->left ? 0 : n, q);
+}
+
+void cleanup_cuda_logical_scalar_shift_64_inplace(CudaStreamsFFI streams, int8_t **mem_ptr_void) {
+  first_gpu(streams);
+  auto *m = reinterpret_cast<ScalarShiftMem *>(*mem_ptr_void);
+  HX_PANIC_IF_FALSE(m && m->magic == ScalarShiftMem::kMagic, "cleanup logical_scalar_shift: foreign scratch pointer");
+  HX_CHECK(hipStreamSynchronize(S0(streams)));
+  m->drv.release(streams);
+  for (uint64_t *d : {m->d_pack, m->d_lut_idx})
     if (d) scratch_free(d);
   m->magic = 0;
   delete m;

@@ -182,6 +182,15 @@ SIGNATURES = {
     "scratch_cuda_full_propagation_64_inplace_async": (_u64, [_S, _i8pp, _BK, _KK, _u32, _u32, _b, _u32]),
     "cuda_full_propagation_64_inplace_async": (None, [_S, _R, _v, _i8pp, _i8pp, _u32]),
     "cleanup_cuda_full_propagation_64_inplace": (None, [_S, _i8pp]),
+    "scratch_cuda_integer_comparison_64_async": (_u64, [_S, _i8pp, _BK, _KK, _u32, _u32, _u32, _u32, _b, _b, _u32]),
+    "cuda_integer_comparison_64_async": (None, [_S, _R, _R, _R, _v, _i8pp, _i8pp]),
+    "cleanup_cuda_integer_comparison_64": (None, [_S, _i8pp]),
+    "scratch_cuda_cmux_64_async": (_u64, [_S, _i8pp, _BK, _KK, _u32, _u32, _u32, _b, _u32]),
+    "cuda_cmux_64_async": (None, [_S, _R, _R, _R, _R, _v, _i8pp, _i8pp]),
+    "cleanup_cuda_cmux_64": (None, [_S, _i8pp]),
+    "scratch_cuda_logical_scalar_shift_64_inplace_async": (_u64, [_S, _i8pp, _BK, _KK, _u32, _u32, _u32, _u32, _b, _u32]),
+    "cuda_logical_scalar_shift_64_inplace_async": (None, [_S, _R, _u32, _v, _i8pp, _i8pp]),
+    "cleanup_cuda_logical_scalar_shift_64_inplace": (None, [_S, _i8pp]),
     "hip_integer_scratch_batch": (None, [_u32]),
     "hip_integer_mult_pbs_count": (_u64, [_v]),
     "hip_integer_propagate_pbs_count": (_u64, [_u32]),

@@ -250,6 +250,54 @@ class CudaServerKey:
         _lib().cuda_full_propagation_64_inplace_async(s, C.byref(ct._ffi()), mem, ksks, bsks, ct.total_blocks)
         _lib().cleanup_cuda_full_propagation_64_inplace(s, C.byref(mem))
 
+    COMPARISONS = {"eq": 0, "ne": 1, "gt": 2, "ge": 3, "lt": 4, "le": 5, "max": 6, "min": 7}  # integer.h:24-33
+
+    def compare(self, lhs, rhs, op, streams):
+        """Unsigned comparison of ONE integer pair (radix/comparison.rs unchecked_{eq,ne,gt,ge,lt,le,max,min}): a boolean
+        block for eq ... le, an integer for max / min."""
+        assert lhs.num_integers == rhs.num_integers == 1 and lhs.num_blocks == rhs.num_blocks
+        s, keep = self._streams(streams)
+        ksks, bsks = self._key_ptrs(streams)
+        mem = C.c_void_p()
+        code = self.COMPARISONS[op]
+        L, w = lhs.num_blocks, lhs.lwe_dimension + 1
+        out = (CudaUnsignedRadixCiphertext.zeros_like(lhs, streams) if code >= 6 else
+               CudaUnsignedRadixCiphertext(CudaVec(w, streams), 1, 1, lhs.lwe_dimension))
+        _lib().scratch_cuda_integer_comparison_64_async(
+            s, C.byref(mem), self._bsk_params(), self._ksk_params(), L, self.message_modulus, self.carry_modulus, code,
+            False, True, self._noise_reduction())
+        _lib().cuda_integer_comparison_64_async(s, C.byref(out._ffi()), C.byref(lhs._ffi()), C.byref(rhs._ffi()), mem, bsks,
+                                                ksks)
+        _lib().cleanup_cuda_integer_comparison_64(s, C.byref(mem))
+        return out
+
+    def if_then_else(self, condition, ct_true, ct_false, streams):
+        """condition ? ct_true : ct_false, ONE integer (radix/cmux.rs unchecked_if_then_else); condition: a boolean block."""
+        assert ct_true.total_blocks == ct_false.total_blocks and condition.total_blocks >= 1
+        s, keep = self._streams(streams)
+        ksks, bsks = self._key_ptrs(streams)
+        mem = C.c_void_p()
+        out = CudaUnsignedRadixCiphertext.zeros_like(ct_true, streams)
+        _lib().scratch_cuda_cmux_64_async(s, C.byref(mem), self._bsk_params(), self._ksk_params(), ct_true.total_blocks,
+                                          self.message_modulus, self.carry_modulus, True, self._noise_reduction())
+        _lib().cuda_cmux_64_async(s, C.byref(out._ffi()), C.byref(condition._ffi()), C.byref(ct_true._ffi()),
+                                  C.byref(ct_false._ffi()), mem, bsks, ksks)
+        _lib().cleanup_cuda_cmux_64(s, C.byref(mem))
+        return out
+
+    def scalar_shift_assign(self, ct, shift, streams, left=True):
+        """ct <<= shift / ct >>= shift (logical, clear amount; radix/scalar_shift.rs unchecked_scalar_{left,right}_shift_assign),
+        ONE integer."""
+        assert ct.num_integers == 1
+        s, keep = self._streams(streams)
+        ksks, bsks = self._key_ptrs(streams)
+        mem = C.c_void_p()
+        _lib().scratch_cuda_logical_scalar_shift_64_inplace_async(
+            s, C.byref(mem), self._bsk_params(), self._ksk_params(), ct.total_blocks, self.message_modulus,
+            self.carry_modulus, 0 if left else 1, True, self._noise_reduction())
+        _lib().cuda_logical_scalar_shift_64_inplace_async(s, C.byref(ct._ffi()), int(shift), mem, bsks, ksks)
+        _lib().cleanup_cuda_logical_scalar_shift_64_inplace(s, C.byref(mem))
+
     def mul_assign(self, lhs, rhs, streams, return_pbs_count=False):
         """lhs *= rhs (mod 2^bits) on clean operands: schoolbook block products, column sums, propagation."""
         s, keep = self._streams(streams)

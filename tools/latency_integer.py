@@ -71,6 +71,22 @@ def main():
         print(json.dumps({"op": f"FheUint64 {op}", "params": p.name, "scratch_ms": (t1 - t0) * 1e3,
                           "operation_ms": (t2 - t1) * 1e3, "cleanup_ms": (t3 - t2) * 1e3,
                           "note": "third repetition; one ciphertext pair, one stream"}))
+    # the second tranche of the radix layer (round 6), each through its host wrapper: scratch + operation + cleanup
+    cond = igpu.CudaUnsignedRadixCiphertext.from_blocks(r64(p.big_n + 1).reshape(1, 1, -1), st)
+    calls = {"sub": lambda a, b: sks.sub_assign(a, b, st), "bitand": lambda a, b: sks.bitop_assign(a, b, "and", st),
+             "eq": lambda a, b: sks.compare(a, b, "eq", st), "gt": lambda a, b: sks.compare(a, b, "gt", st),
+             "max": lambda a, b: sks.compare(a, b, "max", st), "if_then_else": lambda a, b: sks.if_then_else(cond, a, b, st)}
+    for op, fn in calls.items():
+        for rep in range(3):
+            ca = igpu.CudaUnsignedRadixCiphertext.from_blocks(blocks, st)
+            cb = igpu.CudaUnsignedRadixCiphertext.from_blocks(blocks, st)
+            st.synchronize()
+            t0 = time.perf_counter()
+            fn(ca, cb)
+            st.synchronize()
+            t1 = time.perf_counter()
+        print(json.dumps({"op": f"FheUint64 {op}", "params": p.name, "total_ms": (t1 - t0) * 1e3,
+                          "note": "third repetition; scratch + operation + cleanup; one ciphertext pair, one stream"}))
     if "--throughput" in sys.argv:
         # the same operations over a batch of independent integers (timing only: the key material is random; the
         # decrypt-checked form of this measurement is tools/bench_integer.py)

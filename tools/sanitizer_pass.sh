@@ -15,9 +15,9 @@ export UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1
 export OMP_NUM_THREADS=4
 {
   echo "== $(date -u +%FT%TZ) g++ $(g++ -dumpversion) -O1 -fsanitize=address,undefined, TFHE_EMU_LIB=$san"
-  echo "== pytest tests/test_backend_parity.py tests/test_radix_integer.py tests/test_malloc_async_arena.py tests/test_streams_and_graphs.py tests/test_split_engine_worst_case.py tests/test_fourier_entry_points.py tests/test_multi_bit_noise_entry_points.py -m 'not gpu' -k '$sel'"
+  echo "== pytest tests/test_backend_parity.py tests/test_radix_integer.py tests/test_radix_more_ops.py tests/test_malloc_async_arena.py tests/test_streams_and_graphs.py tests/test_split_engine_worst_case.py tests/test_fourier_entry_points.py tests/test_multi_bit_noise_entry_points.py -m 'not gpu' -k '$sel'"
   LD_PRELOAD=$(g++ -print-file-name=libasan.so):$(g++ -print-file-name=libubsan.so) TFHE_EMU_LIB=$san TFHE_HIP_ARENA_REDZONE=${REDZONE:-0} \
-    python -m pytest tests/test_backend_parity.py tests/test_radix_integer.py tests/test_malloc_async_arena.py tests/test_streams_and_graphs.py \
+    python -m pytest tests/test_backend_parity.py tests/test_radix_integer.py tests/test_radix_more_ops.py tests/test_malloc_async_arena.py tests/test_streams_and_graphs.py \
       tests/test_split_engine_worst_case.py tests/test_fourier_entry_points.py tests/test_multi_bit_noise_entry_points.py \
       -m "not gpu" -k "$sel" -q -x -p no:cacheprovider 2>&1 | grep -vE "^\s*$" | tail -15
   echo "== the reference's GPU tests restated in C++ (tests/cpp), compiled with the same flags and linked against the instrumented library"
@@ -28,3 +28,5 @@ export OMP_NUM_THREADS=4
   done
 } > $out 2>&1
 cat $out
+# the instrumented objects must not travel to the GPU box (gpurun refuses a snapshot that holds AddressSanitizer code)
+rm -rf tests/emu/build_san tests/emu/libtfhe_hip_backend_emu_san.so
