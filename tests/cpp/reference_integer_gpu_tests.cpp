@@ -9,6 +9,8 @@
 //   integer_default_overflowing_add   …/test_add.rs:44 -> default_overflowing_add_test (…/test_add.rs:553-680)
 //   integer_mul                       integer/gpu/server_key/radix/tests_unsigned/test_mul.rs -> default_mul_test
 //                                     (integer/server_key/radix_parallel/tests_cases_unsigned.rs:865-927)
+//   integer_sub / bitop / comparison / if_then_else / scalar_shift   (round 6) tests_unsigned/{test_sub.rs:301-346, test_bitwise_op.rs,
+//                                     test_comparison.rs, test_cmux.rs, test_scalar_shift.rs} default_* test cases
 //   constants NB_CTXT = 4, MAX_NB_CTXT = 8, nb_tests(_smaller)_for_params   …/tests_unsigned/mod.rs:61-125
 //
 // on PARAM_MESSAGE_2_CARRY_2_KS_PBS_TUNIFORM_2M128 and TEST_PARAM_GPU_MULTI_BIT_GROUP_4_MESSAGE_2_CARRY_2_KS_PBS_TUNIFORM_2M128
@@ -331,6 +333,109 @@ static void integer_mul(const TestParameters &param) {
   }
 }
 
+// default_sub_test (tests_unsigned/test_sub.rs:301-346)
+static void integer_sub(const TestParameters &param) {
+  Keys &k = key_cache(param);
+  const size_t nb_tests_smaller = nb_tests_smaller_for_params(param);
+  for (size_t num_blocks = 1; num_blocks < (g_toy ? 4 : MAX_NB_CTXT); ++num_blocks) {
+    const u64 modulus = unsigned_modulus(param.message_modulus, (uint32_t)num_blocks);
+    const u64 clear1 = k.random() % modulus, clear2 = k.random() % modulus;
+    const auto ctxt_1 = k.encrypt_radix(clear1, num_blocks), ctxt_2 = k.encrypt_radix(clear2, num_blocks);
+    auto res = ctxt_1.duplicate(k.streams);
+    u64 clear = clear1;
+    for (size_t t = 0; t < nb_tests_smaller; ++t) {  // subtract multiple times
+      const auto tmp = k.sks->sub(res, ctxt_2, k.streams);
+      res = k.sks->sub(res, ctxt_2, k.streams);
+      CHECK(res.block_carries_are_empty());
+      assert_same_ciphertext(k, res, tmp, "sub");
+      k.panic_if_any_block_is_not_clean(res);
+      clear = (clear - clear2) % modulus;
+      CHECK_EQ(k.decrypt(res), clear);
+    }
+  }
+}
+
+// default_bitand / bitor / bitxor tests (tests_cases_unsigned.rs default_bit{and,or,xor}_test): an operand with carries (after an
+// unchecked addition) is cleaned by the operation itself
+static void integer_bitop(const TestParameters &param) {
+  Keys &k = key_cache(param);
+  const u64 modulus = unsigned_modulus(param.message_modulus, NB_CTXT);
+  for (size_t t = 0; t < nb_tests_smaller_for_params(param); ++t) {
+    const u64 clear1 = k.random() % modulus, clear2 = k.random() % modulus, clear3 = k.random() % modulus;
+    const auto ctxt_1 = k.encrypt(clear1), ctxt_2 = k.encrypt(clear2), ctxt_3 = k.encrypt(clear3);
+    const auto dirty = k.sks->unchecked_add(ctxt_1, ctxt_3, k.streams);  // carries not empty
+    const u64 dirty_clear = (clear1 + clear3) % modulus;
+    struct Case { BITOP_TYPE op; u64 want_clean, want_dirty; };
+    for (const Case &c : {Case{BITAND, clear1 & clear2, dirty_clear & clear2}, Case{BITOR, clear1 | clear2, dirty_clear | clear2},
+                          Case{BITXOR, clear1 ^ clear2, dirty_clear ^ clear2}}) {
+      const auto r1 = k.sks->bitop(ctxt_1, ctxt_2, c.op, k.streams), r1b = k.sks->bitop(ctxt_1, ctxt_2, c.op, k.streams);
+      CHECK(r1.block_carries_are_empty());
+      assert_same_ciphertext(k, r1, r1b, "bitop");
+      CHECK_EQ(k.decrypt(r1), c.want_clean);
+      const auto r2 = k.sks->bitop(dirty, ctxt_2, c.op, k.streams);
+      CHECK(r2.block_carries_are_empty());
+      CHECK_EQ(k.decrypt(r2), c.want_dirty);
+    }
+  }
+}
+
+// default comparison tests (tests_unsigned/test_comparison.rs: test_default_function for eq, ne, gt, ge, lt, le; default_min / max):
+// random pairs, an equal pair, pairs that differ by one
+static void integer_comparison(const TestParameters &param) {
+  Keys &k = key_cache(param);
+  const u64 modulus = unsigned_modulus(param.message_modulus, NB_CTXT);
+  const size_t rounds = std::max<size_t>(1, nb_tests_smaller_for_params(param) / 2);
+  for (size_t t = 0; t < rounds + 2; ++t) {
+    u64 clear1 = k.random() % modulus, clear2 = t == rounds ? clear1 : t == rounds + 1 ? (clear1 + 1) % modulus : k.random() % modulus;
+    const auto ctxt_1 = k.encrypt(clear1), ctxt_2 = k.encrypt(clear2);
+    struct Case { COMPARISON_TYPE op; bool want; };
+    for (const Case &c : {Case{EQ, clear1 == clear2}, Case{NE, clear1 != clear2}, Case{GT, clear1 > clear2}, Case{GE, clear1 >= clear2},
+                          Case{LT, clear1 < clear2}, Case{LE, clear1 <= clear2}}) {
+      const auto b = k.sks->comparison(ctxt_1, ctxt_2, c.op, k.streams), b2 = k.sks->comparison(ctxt_1, ctxt_2, c.op, k.streams);
+      assert_same_ciphertext(k, b, b2, "comparison");
+      CHECK(b.holds_boolean_value());
+      CHECK_EQ(k.decrypt_bool(b), c.want);
+    }
+    const auto mx = k.sks->comparison(ctxt_1, ctxt_2, MAX, k.streams), mn = k.sks->comparison(ctxt_1, ctxt_2, MIN, k.streams);
+    CHECK(mx.block_carries_are_empty() && mn.block_carries_are_empty());
+    CHECK_EQ(k.decrypt(mx), std::max(clear1, clear2));
+    CHECK_EQ(k.decrypt(mn), std::min(clear1, clear2));
+  }
+}
+
+// default_if_then_else_test (tests_unsigned/test_cmux.rs): the condition from a comparison, both of its values
+static void integer_if_then_else(const TestParameters &param) {
+  Keys &k = key_cache(param);
+  const u64 modulus = unsigned_modulus(param.message_modulus, NB_CTXT);
+  for (size_t t = 0; t < std::max<size_t>(2, nb_tests_smaller_for_params(param)); ++t) {
+    const u64 clear_0 = k.random() % modulus, clear_1 = k.random() % modulus;
+    const auto ctxt_0 = k.encrypt(clear_0), ctxt_1 = k.encrypt(clear_1);
+    const auto cond = k.sks->comparison(ctxt_0, ctxt_1, (t & 1) ? LT : GE, k.streams);
+    const bool c = (t & 1) ? clear_0 < clear_1 : clear_0 >= clear_1;
+    const auto r = k.sks->if_then_else(cond, ctxt_0, ctxt_1, k.streams), r2 = k.sks->if_then_else(cond, ctxt_0, ctxt_1, k.streams);
+    assert_same_ciphertext(k, r, r2, "if_then_else");
+    k.panic_if_any_block_is_not_clean(r);
+    CHECK_EQ(k.decrypt(r), c ? clear_0 : clear_1);
+  }
+}
+
+// default_scalar_left_shift_test / default_scalar_right_shift_test (tests_unsigned/test_scalar_shift.rs): every shift inside the
+// width, then the overshift
+static void integer_scalar_shift(const TestParameters &param) {
+  Keys &k = key_cache(param);
+  const u64 modulus = unsigned_modulus(param.message_modulus, NB_CTXT);
+  uint32_t nbits = 0;
+  for (u64 m = modulus; m > 1; m >>= 1) ++nbits;
+  const u64 clear = k.random() % modulus;
+  const auto ct = k.encrypt(clear);
+  for (uint32_t shift = 0; shift <= nbits + 1; shift += (g_toy ? 3 : 1)) {
+    const auto l = k.sks->scalar_shift(ct, shift, LEFT_SHIFT, k.streams), r = k.sks->scalar_shift(ct, shift, RIGHT_SHIFT, k.streams);
+    CHECK(l.block_carries_are_empty() && r.block_carries_are_empty());
+    CHECK_EQ(k.decrypt(l), shift >= nbits ? 0 : (clear << shift) % modulus);
+    CHECK_EQ(k.decrypt(r), shift >= nbits ? 0 : clear >> shift);
+  }
+}
+
 // One FheUint64 (32 blocks) addition / multiplication at a time the way the reference's host issues it — operands duplicated
 // into a fresh CudaVec, scratch made, operation launched, scratch cleaned up, temporaries dropped, stream synchronised (radix/
 // add.rs `add`, mul.rs `mul`) — timed on the host clock.  `latency` mode: one JSON line per (parameter set, operation), with the
@@ -394,6 +499,11 @@ int main(int argc, char **argv) {
     tests.push_back({std::string("test_gpu_integer_add_") + p.name, [&p] { integer_add(p); }});
     tests.push_back({std::string("test_gpu_integer_default_overflowing_add_") + p.name, [&p] { integer_default_overflowing_add(p); }});
     tests.push_back({std::string("test_gpu_integer_mul_") + p.name, [&p] { integer_mul(p); }});
+    tests.push_back({std::string("test_gpu_integer_sub_") + p.name, [&p] { integer_sub(p); }});
+    tests.push_back({std::string("test_gpu_integer_bitop_") + p.name, [&p] { integer_bitop(p); }});
+    tests.push_back({std::string("test_gpu_integer_comparison_") + p.name, [&p] { integer_comparison(p); }});
+    tests.push_back({std::string("test_gpu_integer_if_then_else_") + p.name, [&p] { integer_if_then_else(p); }});
+    tests.push_back({std::string("test_gpu_integer_scalar_shift_") + p.name, [&p] { integer_scalar_shift(p); }});
     if (get_number_of_gpus() > 1) tests.push_back({std::string("test_gpu_multi_device_integer_add_") + p.name, [&p] { multi_device_integer_add(p); }});
   };
   if (!reference_sets) {

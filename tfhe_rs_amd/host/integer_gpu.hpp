@@ -208,6 +208,104 @@ class CudaServerKey {
     mul_assign(result, ct_right, streams);
     return result;
   }
+  // ---- round 6: sub.rs, bitwise_op.rs, comparison.rs, cmux.rs, scalar_shift.rs — the default forms: an operand whose carries
+  // are not empty is propagated first
+  const CudaUnsignedRadixCiphertext &cleaned(const CudaUnsignedRadixCiphertext &ct, std::optional<CudaUnsignedRadixCiphertext> &hold,
+                                             const CudaStreams &streams) const {
+    if (ct.block_carries_are_empty()) return ct;
+    hold = ct.duplicate(streams);
+    propagate_single_carry_assign(*hold, streams);
+    return *hold;
+  }
+  void sub_assign(CudaUnsignedRadixCiphertext &ct_left, const CudaUnsignedRadixCiphertext &ct_right, const CudaStreams &streams) const {
+    detail::assert_eq(ct_left.num_blocks(), ct_right.num_blocks(), "Mismatched number of blocks between ct_left and ct_right");
+    if (!ct_left.block_carries_are_empty()) propagate_single_carry_assign(ct_left, streams);
+    std::optional<CudaUnsignedRadixCiphertext> hold;
+    const CudaUnsignedRadixCiphertext &rhs = cleaned(ct_right, hold, streams);
+    Ffi f(*this, streams);
+    CudaUnsignedRadixCiphertext zero_in = CudaUnsignedRadixCiphertext::zero(1, ct_left.lwe_dimension, message_modulus, carry_modulus, streams),
+                                zero_out = CudaUnsignedRadixCiphertext::zero(1, ct_left.lwe_dimension, message_modulus, carry_modulus, streams);
+    CudaRadixCiphertextFFI l = ct_left.ffi(), r = rhs.ffi(), cin = zero_in.ffi(), cout = zero_out.ffi();
+    int8_t *mem = nullptr;
+    scratch_cuda_sub_and_propagate_single_carry_64_inplace_async(f.streams, &mem, bsk_params(), ksk_params(), (uint32_t)ct_left.num_blocks(),
+                                                                 (uint32_t)message_modulus, (uint32_t)carry_modulus, 0, true, noise_reduction());
+    cuda_sub_and_propagate_single_carry_64_inplace_async(f.streams, &l, &r, &cout, &cin, mem, f.bsks.data(), f.ksks.data(), 0, 0);
+    cleanup_cuda_sub_and_propagate_single_carry_64_inplace(f.streams, &mem);
+  }
+  CudaUnsignedRadixCiphertext sub(const CudaUnsignedRadixCiphertext &ct_left, const CudaUnsignedRadixCiphertext &ct_right,
+                                  const CudaStreams &streams) const {
+    CudaUnsignedRadixCiphertext result = ct_left.duplicate(streams);
+    sub_assign(result, ct_right, streams);
+    return result;
+  }
+  CudaUnsignedRadixCiphertext bitop(const CudaUnsignedRadixCiphertext &ct_left, const CudaUnsignedRadixCiphertext &ct_right, BITOP_TYPE op,
+                                    const CudaStreams &streams) const {
+    detail::assert_eq(ct_left.num_blocks(), ct_right.num_blocks(), "Mismatched number of blocks between ct_left and ct_right");
+    CudaUnsignedRadixCiphertext result = ct_left.duplicate(streams);
+    if (!result.block_carries_are_empty()) propagate_single_carry_assign(result, streams);
+    std::optional<CudaUnsignedRadixCiphertext> hold;
+    const CudaUnsignedRadixCiphertext &rhs = cleaned(ct_right, hold, streams);
+    Ffi f(*this, streams);
+    CudaRadixCiphertextFFI l = result.ffi(), r = rhs.ffi();
+    int8_t *mem = nullptr;
+    scratch_cuda_integer_bitop_inplace_64_async(f.streams, &mem, bsk_params(), ksk_params(), (uint32_t)result.num_blocks(), (uint32_t)message_modulus,
+                                                (uint32_t)carry_modulus, op, true, noise_reduction());
+    cuda_integer_bitop_inplace_64_async(f.streams, &l, &r, mem, f.bsks.data(), f.ksks.data());
+    cleanup_cuda_integer_bitop_inplace_64(f.streams, &mem);
+    return result;
+  }
+  CudaUnsignedRadixCiphertext bitand_(const CudaUnsignedRadixCiphertext &a, const CudaUnsignedRadixCiphertext &b, const CudaStreams &s) const { return bitop(a, b, BITAND, s); }
+  CudaUnsignedRadixCiphertext bitor_(const CudaUnsignedRadixCiphertext &a, const CudaUnsignedRadixCiphertext &b, const CudaStreams &s) const { return bitop(a, b, BITOR, s); }
+  CudaUnsignedRadixCiphertext bitxor_(const CudaUnsignedRadixCiphertext &a, const CudaUnsignedRadixCiphertext &b, const CudaStreams &s) const { return bitop(a, b, BITXOR, s); }
+  // comparison.rs: eq ... le return a boolean block, max / min an integer
+  CudaUnsignedRadixCiphertext comparison(const CudaUnsignedRadixCiphertext &ct_left, const CudaUnsignedRadixCiphertext &ct_right, COMPARISON_TYPE op,
+                                         const CudaStreams &streams) const {
+    detail::assert_eq(ct_left.num_blocks(), ct_right.num_blocks(), "Mismatched number of blocks between ct_left and ct_right");
+    std::optional<CudaUnsignedRadixCiphertext> hold_l, hold_r;
+    const CudaUnsignedRadixCiphertext &lhs = cleaned(ct_left, hold_l, streams), &rhs = cleaned(ct_right, hold_r, streams);
+    const bool select = op == MAX || op == MIN;
+    CudaUnsignedRadixCiphertext result =
+        CudaUnsignedRadixCiphertext::zero(select ? lhs.num_blocks() : 1, lhs.lwe_dimension, message_modulus, carry_modulus, streams);
+    Ffi f(*this, streams);
+    CudaRadixCiphertextFFI o = result.ffi(), l = lhs.ffi(), r = rhs.ffi();
+    int8_t *mem = nullptr;
+    scratch_cuda_integer_comparison_64_async(f.streams, &mem, bsk_params(), ksk_params(), (uint32_t)lhs.num_blocks(), (uint32_t)message_modulus,
+                                             (uint32_t)carry_modulus, op, false, true, noise_reduction());
+    cuda_integer_comparison_64_async(f.streams, &o, &l, &r, mem, f.bsks.data(), f.ksks.data());
+    cleanup_cuda_integer_comparison_64(f.streams, &mem);
+    return result;
+  }
+  // cmux.rs if_then_else
+  CudaUnsignedRadixCiphertext if_then_else(const CudaBooleanBlock &condition, const CudaUnsignedRadixCiphertext &true_ct,
+                                           const CudaUnsignedRadixCiphertext &false_ct, const CudaStreams &streams) const {
+    detail::assert_eq(true_ct.num_blocks(), false_ct.num_blocks(), "Mismatched number of blocks between true_ct and false_ct");
+    std::optional<CudaUnsignedRadixCiphertext> hold_t, hold_f;
+    const CudaUnsignedRadixCiphertext &t = cleaned(true_ct, hold_t, streams), &e = cleaned(false_ct, hold_f, streams);
+    CudaUnsignedRadixCiphertext result = CudaUnsignedRadixCiphertext::zero(t.num_blocks(), t.lwe_dimension, message_modulus, carry_modulus, streams);
+    Ffi f(*this, streams);
+    CudaRadixCiphertextFFI o = result.ffi(), c = condition.ffi(), tt = t.ffi(), ee = e.ffi();
+    int8_t *mem = nullptr;
+    scratch_cuda_cmux_64_async(f.streams, &mem, bsk_params(), ksk_params(), (uint32_t)t.num_blocks(), (uint32_t)message_modulus, (uint32_t)carry_modulus,
+                               true, noise_reduction());
+    cuda_cmux_64_async(f.streams, &o, &c, &tt, &ee, mem, f.bsks.data(), f.ksks.data());
+    cleanup_cuda_cmux_64(f.streams, &mem);
+    return result;
+  }
+  // scalar_shift.rs scalar_left_shift / scalar_right_shift (unsigned: logical)
+  CudaUnsignedRadixCiphertext scalar_shift(const CudaUnsignedRadixCiphertext &ct, uint32_t shift, SHIFT_OR_ROTATE_TYPE direction,
+                                           const CudaStreams &streams) const {
+    CudaUnsignedRadixCiphertext result = ct.duplicate(streams);
+    if (!result.block_carries_are_empty()) propagate_single_carry_assign(result, streams);
+    Ffi f(*this, streams);
+    CudaRadixCiphertextFFI c = result.ffi();
+    int8_t *mem = nullptr;
+    scratch_cuda_logical_scalar_shift_64_inplace_async(f.streams, &mem, bsk_params(), ksk_params(), (uint32_t)result.num_blocks(),
+                                                       (uint32_t)message_modulus, (uint32_t)carry_modulus, direction, true, noise_reduction());
+    cuda_logical_scalar_shift_64_inplace_async(f.streams, &c, shift, mem, f.bsks.data(), f.ksks.data());
+    cleanup_cuda_logical_scalar_shift_64_inplace(f.streams, &mem);
+    return result;
+  }
+
   // radix/mod.rs apply_lookup_table: `lut` is the (k+1)*N accumulator of a shortint LookupTable, `degree` its maximum output
   CudaUnsignedRadixCiphertext apply_lookup_table(const CudaUnsignedRadixCiphertext &input, const std::vector<uint64_t> &lut, uint64_t degree,
                                                  const CudaStreams &streams) const {
