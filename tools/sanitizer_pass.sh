@@ -8,8 +8,9 @@ tag=${1:-r06}
 sel=${2:-"emu"}
 cd "$(dirname "$0")/.."
 out=profiles/${tag}_sanitizer_cpu.txt
-make -C tests/emu -j8 SAN=1 > /dev/null || exit 1
-san=$PWD/tests/emu/libtfhe_hip_backend_emu_san.so
+sandir=${SANOUT:-/tmp/tfhe_hip_san}; mkdir -p $sandir
+make -C tests/emu -j${SANJOBS:-8} SAN=1 SANOUT=$sandir > /dev/null || exit 1
+san=$sandir/libtfhe_hip_backend_emu_san.so
 export ASAN_OPTIONS=detect_leaks=0:abort_on_error=1:detect_stack_use_after_return=0
 export UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1
 export OMP_NUM_THREADS=4
@@ -23,10 +24,9 @@ export OMP_NUM_THREADS=4
   echo "== the reference's GPU tests restated in C++ (tests/cpp), compiled with the same flags and linked against the instrumented library"
   for src in reference_gpu_tests reference_integer_gpu_tests; do
     g++ -std=c++17 -O1 -g -fsanitize=address,undefined -fno-sanitize-recover=undefined -o /tmp/${src}_san tests/cpp/$src.cpp $san oracle/libtfhe_oracle.so \
-      -Wl,-rpath,$PWD/tests/emu -Wl,-rpath,$PWD/oracle || exit 1
+      -Wl,-rpath,$sandir -Wl,-rpath,$PWD/oracle || exit 1
     TFHE_FFT_GOLDEN=$PWD/tests/golden/fft16x4x16_golden_v1.json /tmp/${src}_san toy 2>&1 | grep -E "test result|ERROR|runtime error|FAILED" | tail -5
   done
 } > $out 2>&1
 cat $out
-# the instrumented objects must not travel to the GPU box (gpurun refuses a snapshot that holds AddressSanitizer code)
-rm -rf tests/emu/build_san tests/emu/libtfhe_hip_backend_emu_san.so
+# the instrumented objects live outside the tree ($sandir): gpurun refuses a snapshot that holds AddressSanitizer code
