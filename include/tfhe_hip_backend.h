@@ -557,6 +557,16 @@ void cuda_integer_comparison_64_async(CudaStreamsFFI streams, CudaRadixCiphertex
                                       CudaRadixCiphertextFFI const *lwe_array_2, int8_t *mem_ptr, void *const *bsks,
                                       void *const *ksks);
 void cleanup_cuda_integer_comparison_64(CudaStreamsFFI streams, int8_t **mem_ptr_void);
+uint64_t scratch_cuda_integer_scalar_comparison_64_async(
+    CudaStreamsFFI streams, int8_t **mem_ptr, CudaLweBootstrapKeyParamsFFI bsk_params,
+    CudaLweKeyswitchKeyParamsFFI ksk_params, uint32_t lwe_ciphertext_count, uint32_t message_modulus,
+    uint32_t carry_modulus, enum COMPARISON_TYPE op_type, bool is_signed, bool allocate_gpu_memory,
+    enum PBS_MS_REDUCTION_T noise_reduction_type);
+void cuda_integer_scalar_comparison_64_async(CudaStreamsFFI streams, CudaRadixCiphertextFFI *lwe_array_out,
+                                             CudaRadixCiphertextFFI const *lwe_array_in, void const *scalar_blocks,
+                                             void const *h_scalar_blocks, int8_t *mem_ptr, void *const *bsks,
+                                             void *const *ksks, uint32_t num_scalar_blocks);
+void cleanup_cuda_integer_scalar_comparison_64(CudaStreamsFFI streams, int8_t **mem_ptr_void);
 uint64_t scratch_cuda_cmux_64_async(CudaStreamsFFI streams, int8_t **mem_ptr, CudaLweBootstrapKeyParamsFFI bsk_params,
                                     CudaLweKeyswitchKeyParamsFFI ksk_params, uint32_t lwe_ciphertext_count,
                                     uint32_t message_modulus, uint32_t carry_modulus, bool allocate_gpu_memory,

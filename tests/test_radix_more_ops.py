@@ -246,3 +246,24 @@ def test_logical_shifts_by_a_clear_amount(kind):
             q = min(sh // 2, L)
             zeroed = list(ca.degrees[:q]) if left else list(ca.degrees[L - q:])
             assert zeroed == [0] * q, (left, sh)
+
+
+@pytest.mark.parametrize("kind", BACKENDS)
+def test_comparisons_with_a_clear_scalar(kind):
+    """The scalar arrives as its clear blocks up to the last non-zero one (fewer than the ciphertext's, none for zero)."""
+    p, keys, st, sks, igpu = setup(kind)
+    L = 5 if kind == "emu" else 32
+    mask = (1 << (2 * L)) - 1
+    a = 0x6A09E667F3BCC908 & mask
+    ca = igpu.CudaUnsignedRadixCiphertext.from_blocks(encrypt_radix(p, keys, [a], L, 181), st)
+    ca.set_degrees(MSG - 1)
+    scalars = (a, 0, a + 1, 3) if kind == "emu" else (a, 0, a + 1, a - 1, 3, mask, a ^ (1 << (2 * L - 1)))
+    for sc in scalars:
+        for op in (("eq", "gt", "le") if kind == "emu" else ("eq", "ne", "gt", "ge", "lt", "le")):
+            out = sks.scalar_compare(ca, sc, op, st)
+            want = {"eq": a == sc, "ne": a != sc, "gt": a > sc, "ge": a >= sc, "lt": a < sc, "le": a <= sc}[op]
+            assert decrypt_blocks(p, keys, out.to_blocks(st)) == [[int(want)]], (sc, op)
+    out = sks.scalar_compare(ca, 3, "max", st)
+    assert recompose(decrypt_blocks(p, keys, out.to_blocks(st))) == [max(a, 3)]
+    out = sks.scalar_compare(ca, 3, "min", st)
+    assert recompose(decrypt_blocks(p, keys, out.to_blocks(st))) == [3]

@@ -2327,6 +2327,76 @@ void cuda_integer_comparison_64_async(CudaStreamsFFI streams, CudaRadixCiphertex
   }
 }
 
+// integer.h:254-274: the scalar comes as its clear blocks (one per radix block, least significant first, the caller stops at
+// the last non-zero one: integer/gpu/server_key/radix/scalar_comparison.rs:129-157).  They become trivial ciphertexts (zero
+// masks) in the scratch and take the ciphertext path: the same rounds, the same tables.
+struct ScalarCompareScratch {
+  static constexpr uint32_t kMagic = 0x53435231;  // "SCR1"
+  uint32_t magic = kMagic;
+  int8_t *inner = nullptr;  // a CompareScratch
+  uint64_t *d_triv = nullptr;
+  uint32_t blocks = 0, big_n = 0, msg = 0, carry = 0;
+};
+uint64_t scratch_cuda_integer_scalar_comparison_64_async(CudaStreamsFFI streams, int8_t **mem_ptr,
+                                                         CudaLweBootstrapKeyParamsFFI bsk_params,
+                                                         CudaLweKeyswitchKeyParamsFFI ksk_params,
+                                                         uint32_t lwe_ciphertext_count, uint32_t message_modulus,
+                                                         uint32_t carry_modulus, enum COMPARISON_TYPE op_type, bool is_signed,
+                                                         bool allocate_gpu_memory,
+                                                         enum PBS_MS_REDUCTION_T noise_reduction_type) {
+  HX_PANIC_IF_FALSE(mem_ptr != nullptr, "integer_scalar_comparison: null pointer");
+  auto *m = new ScalarCompareScratch();
+  uint64_t bytes = scratch_cuda_integer_comparison_64_async(streams, &m->inner, bsk_params, ksk_params, lwe_ciphertext_count,
+                                                            message_modulus, carry_modulus, op_type, is_signed,
+                                                            allocate_gpu_memory, noise_reduction_type);
+  m->blocks = lwe_ciphertext_count;
+  m->big_n = ksk_params.input_lwe_dimension;
+  m->msg = message_modulus;
+  m->carry = carry_modulus;
+  const size_t sz = (size_t)lwe_ciphertext_count * (m->big_n + 1) * sizeof(uint64_t);
+  if (allocate_gpu_memory) m->d_triv = (uint64_t *)scratch_alloc(sz);
+  *mem_ptr = reinterpret_cast<int8_t *>(m);
+  return bytes + sz;
+}
+
+void cuda_integer_scalar_comparison_64_async(CudaStreamsFFI streams, CudaRadixCiphertextFFI *lwe_array_out,
+                                             CudaRadixCiphertextFFI const *lwe_array_in, void const *scalar_blocks,
+                                             void const *h_scalar_blocks, int8_t *mem_ptr, void *const *bsks,
+                                             void *const *ksks, uint32_t num_scalar_blocks) {
+  first_gpu(streams);
+  auto *m = reinterpret_cast<ScalarCompareScratch *>(mem_ptr);
+  HX_PANIC_IF_FALSE(m && m->magic == ScalarCompareScratch::kMagic, "integer_scalar_comparison: foreign scratch pointer");
+  HX_PANIC_IF_FALSE(m->d_triv != nullptr, "integer_scalar_comparison: scratch was created with allocate_gpu_memory=false");
+  HX_PANIC_IF_FALSE(lwe_array_in && lwe_array_in->ptr && (num_scalar_blocks == 0 || (scalar_blocks && h_scalar_blocks)),
+                    "integer_scalar_comparison: null pointer");
+  HX_PANIC_IF_FALSE(num_scalar_blocks <= m->blocks, "integer_scalar_comparison: %u scalar blocks for %u radix blocks (the caller "
+                    "truncates the scalar to the ciphertext's length)", num_scalar_blocks, m->blocks);
+  for (uint32_t i = 0; i < num_scalar_blocks; ++i)
+    HX_PANIC_IF_FALSE(((const uint64_t *)h_scalar_blocks)[i] < m->msg, "integer_scalar_comparison: scalar block %u is %llu, not below "
+                      "the message modulus", i, (unsigned long long)((const uint64_t *)h_scalar_blocks)[i]);
+  const hipStream_t st = S0(streams);
+  const uint32_t w = m->big_n + 1;
+  HX_CHECK(hipMemsetAsync(m->d_triv, 0, (size_t)m->blocks * w * sizeof(uint64_t), st));
+  if (num_scalar_blocks)
+    HX_LAUNCH(lwe_body_add_scalars_kernel, dim3((num_scalar_blocks + 255) / 256), dim3(256), 0, st, m->d_triv,
+              (const uint64_t *)scalar_blocks, w, num_scalar_blocks, ((uint64_t)1 << 63) / ((uint64_t)m->msg * m->carry));
+  std::vector<uint64_t> deg(m->blocks, 0), noise(m->blocks, 0);
+  for (uint32_t i = 0; i < num_scalar_blocks; ++i) deg[i] = ((const uint64_t *)h_scalar_blocks)[i];
+  CudaRadixCiphertextFFI triv{m->d_triv, deg.data(), noise.data(), m->blocks, m->blocks, m->big_n};
+  cuda_integer_comparison_64_async(streams, lwe_array_out, lwe_array_in, &triv, m->inner, bsks, ksks);
+}
+
+void cleanup_cuda_integer_scalar_comparison_64(CudaStreamsFFI streams, int8_t **mem_ptr_void) {
+  first_gpu(streams);
+  auto *m = reinterpret_cast<ScalarCompareScratch *>(*mem_ptr_void);
+  HX_PANIC_IF_FALSE(m && m->magic == ScalarCompareScratch::kMagic, "cleanup integer_scalar_comparison: foreign scratch pointer");
+  cleanup_cuda_integer_comparison_64(streams, &m->inner);
+  if (m->d_triv) scratch_free(m->d_triv);
+  m->magic = 0;
+  delete m;
+  *mem_ptr_void = nullptr;
+}
+
 void cleanup_cuda_integer_comparison_64(CudaStreamsFFI streams, int8_t **mem_ptr_void) {
   first_gpu(streams);
   auto *m = reinterpret_cast<CompareScratch *>(*mem_ptr_void);

@@ -185,6 +185,9 @@ SIGNATURES = {
     "scratch_cuda_integer_comparison_64_async": (_u64, [_S, _i8pp, _BK, _KK, _u32, _u32, _u32, _u32, _b, _b, _u32]),
     "cuda_integer_comparison_64_async": (None, [_S, _R, _R, _R, _v, _i8pp, _i8pp]),
     "cleanup_cuda_integer_comparison_64": (None, [_S, _i8pp]),
+    "scratch_cuda_integer_scalar_comparison_64_async": (_u64, [_S, _i8pp, _BK, _KK, _u32, _u32, _u32, _u32, _b, _b, _u32]),
+    "cuda_integer_scalar_comparison_64_async": (None, [_S, _R, _R, _v, _v, _v, _i8pp, _i8pp, _u32]),
+    "cleanup_cuda_integer_scalar_comparison_64": (None, [_S, _i8pp]),
     "scratch_cuda_cmux_64_async": (_u64, [_S, _i8pp, _BK, _KK, _u32, _u32, _u32, _b, _u32]),
     "cuda_cmux_64_async": (None, [_S, _R, _R, _R, _R, _v, _i8pp, _i8pp]),
     "cleanup_cuda_cmux_64": (None, [_S, _i8pp]),

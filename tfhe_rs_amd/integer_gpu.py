@@ -271,6 +271,34 @@ class CudaServerKey:
         _lib().cleanup_cuda_integer_comparison_64(s, C.byref(mem))
         return out
 
+    def scalar_compare(self, ct, scalar, op, streams):
+        """Unsigned comparison of ONE integer with a clear scalar below 2^bits (radix/scalar_comparison.rs unchecked_scalar_*):
+        the scalar's blocks stop at its last non-zero one, as BlockDecomposer::with_early_stop_at_zero yields them."""
+        assert ct.num_integers == 1 and 0 <= int(scalar) < self.message_modulus ** ct.num_blocks
+        s, keep = self._streams(streams)
+        ksks, bsks = self._key_ptrs(streams)
+        mem = C.c_void_p()
+        code = self.COMPARISONS[op]
+        blocks, v = [], int(scalar)
+        while v:
+            blocks.append(v % self.message_modulus)
+            v //= self.message_modulus
+        h = np.ascontiguousarray(np.asarray(blocks, dtype=np.uint64))
+        d = CudaVec(max(1, h.size), streams)
+        if h.size:
+            d.copy_from_cpu_async(h, streams)
+        L, w = ct.num_blocks, ct.lwe_dimension + 1
+        out = (CudaUnsignedRadixCiphertext.zeros_like(ct, streams) if code >= 6 else
+               CudaUnsignedRadixCiphertext(CudaVec(w, streams), 1, 1, ct.lwe_dimension))
+        _lib().scratch_cuda_integer_scalar_comparison_64_async(
+            s, C.byref(mem), self._bsk_params(), self._ksk_params(), L, self.message_modulus, self.carry_modulus, code,
+            False, True, self._noise_reduction())
+        _lib().cuda_integer_scalar_comparison_64_async(s, C.byref(out._ffi()), C.byref(ct._ffi()), d.ptr,
+                                                       h.ctypes.data_as(C.c_void_p), mem, bsks, ksks, h.size)
+        _lib().cleanup_cuda_integer_scalar_comparison_64(s, C.byref(mem))
+        streams.synchronize()
+        return out
+
     def if_then_else(self, condition, ct_true, ct_false, streams):
         """condition ? ct_true : ct_false, ONE integer (radix/cmux.rs unchecked_if_then_else); condition: a boolean block."""
         assert ct_true.total_blocks == ct_false.total_blocks and condition.total_blocks >= 1
