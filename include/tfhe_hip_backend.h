@@ -537,6 +537,16 @@ void cuda_sub_and_propagate_single_carry_64_inplace_async(
     CudaRadixCiphertextFFI *carry_out, const CudaRadixCiphertextFFI *carry_in, int8_t *mem_ptr,
     void *const *bsks, void *const *ksks, uint32_t requested_flag, uint32_t uses_carry);
 void cleanup_cuda_sub_and_propagate_single_carry_64_inplace(CudaStreamsFFI streams, int8_t **mem_ptr_void);
+/* integer.h:415-431: lhs -= rhs and the borrow (1 - the carry of lhs + (2^bits - rhs)); no input borrow */
+uint64_t scratch_cuda_integer_overflowing_sub_64_inplace_async(
+    CudaStreamsFFI streams, int8_t **mem_ptr, CudaLweBootstrapKeyParamsFFI bsk_params,
+    CudaLweKeyswitchKeyParamsFFI ksk_params, uint32_t num_blocks, uint32_t message_modulus, uint32_t carry_modulus,
+    uint32_t compute_overflow, bool allocate_gpu_memory, enum PBS_MS_REDUCTION_T noise_reduction_type);
+void cuda_integer_overflowing_sub_64_inplace_async(
+    CudaStreamsFFI streams, CudaRadixCiphertextFFI *lhs_array, const CudaRadixCiphertextFFI *rhs_array,
+    CudaRadixCiphertextFFI *overflow_block, const CudaRadixCiphertextFFI *input_borrow, int8_t *mem_ptr,
+    void *const *bsks, void *const *ksks, uint32_t compute_overflow, uint32_t uses_input_borrow);
+void cleanup_cuda_integer_overflowing_sub_64_inplace(CudaStreamsFFI streams, int8_t **mem_ptr_void);
 uint64_t scratch_cuda_full_propagation_64_inplace_async(
     CudaStreamsFFI streams, int8_t **mem_ptr, CudaLweBootstrapKeyParamsFFI bsk_params,
     CudaLweKeyswitchKeyParamsFFI ksk_params, uint32_t message_modulus, uint32_t carry_modulus,

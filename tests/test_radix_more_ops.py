@@ -267,3 +267,19 @@ def test_comparisons_with_a_clear_scalar(kind):
     assert recompose(decrypt_blocks(p, keys, out.to_blocks(st))) == [max(a, 3)]
     out = sks.scalar_compare(ca, 3, "min", st)
     assert recompose(decrypt_blocks(p, keys, out.to_blocks(st))) == [3]
+
+
+@pytest.mark.parametrize("kind", BACKENDS)
+def test_overflowing_sub_returns_the_borrow(kind):
+    p, keys, st, sks, igpu = setup(kind)
+    L = 4 if kind == "emu" else 32
+    mask = (1 << (2 * L)) - 1
+    a = [5, 0x8000000000000001 & mask, 0, mask]
+    b = [9, 0x8000000000000000 & mask, 0, mask]
+    if kind == "emu":
+        a, b = a[:2], b[:2]
+    ca = igpu.CudaUnsignedRadixCiphertext.from_blocks(encrypt_radix(p, keys, a, L, 191), st)
+    cb = igpu.CudaUnsignedRadixCiphertext.from_blocks(encrypt_radix(p, keys, b, L, 192), st)
+    borrow = sks.unsigned_overflowing_sub_assign(ca, cb, st)
+    assert recompose(decrypt_blocks(p, keys, ca.to_blocks(st))) == [(x - y) & mask for x, y in zip(a, b)]
+    assert [r[0] for r in decrypt_blocks(p, keys, borrow.to_blocks(st))] == [int(x < y) for x, y in zip(a, b)]

@@ -2174,6 +2174,48 @@ void cleanup_cuda_sub_and_propagate_single_carry_64_inplace(CudaStreamsFFI strea
   *mem_ptr_void = nullptr;
 }
 
+// ---- cuda/include/integer/integer.h:415-431 -----------------------------------------------------
+// lhs -= rhs with the borrow: the subtraction above with FLAG_CARRY; the carry of lhs + (2^bits - rhs) is 1 exactly when
+// nothing was borrowed, so the overflow block is 1 - carry (levelled).  An input borrow is not wired (the reference's unsigned
+// overflowing_sub passes none: integer/gpu/server_key/radix/sub.rs unsigned_overflowing_sub).
+uint64_t scratch_cuda_integer_overflowing_sub_64_inplace_async(CudaStreamsFFI streams, int8_t **mem_ptr,
+                                                               CudaLweBootstrapKeyParamsFFI bsk_params,
+                                                               CudaLweKeyswitchKeyParamsFFI ksk_params, uint32_t num_blocks,
+                                                               uint32_t message_modulus, uint32_t carry_modulus,
+                                                               uint32_t compute_overflow, bool allocate_gpu_memory,
+                                                               enum PBS_MS_REDUCTION_T noise_reduction_type) {
+  (void)compute_overflow;
+  return scratch_cuda_sub_and_propagate_single_carry_64_inplace_async(streams, mem_ptr, bsk_params, ksk_params, num_blocks,
+                                                                      message_modulus, carry_modulus, 2, allocate_gpu_memory,
+                                                                      noise_reduction_type);
+}
+void cuda_integer_overflowing_sub_64_inplace_async(CudaStreamsFFI streams, CudaRadixCiphertextFFI *lhs_array,
+                                                   const CudaRadixCiphertextFFI *rhs_array,
+                                                   CudaRadixCiphertextFFI *overflow_block,
+                                                   const CudaRadixCiphertextFFI *input_borrow, int8_t *mem_ptr,
+                                                   void *const *bsks, void *const *ksks, uint32_t compute_overflow,
+                                                   uint32_t uses_input_borrow) {
+  first_gpu(streams);
+  HX_PANIC_IF_FALSE(uses_input_borrow == 0, "integer_overflowing_sub: an input borrow is not wired");
+  if (compute_overflow == 0) {
+    cuda_sub_and_propagate_single_carry_64_inplace_async(streams, lhs_array, rhs_array, overflow_block, input_borrow, mem_ptr, bsks,
+                                                         ksks, 0, 0);
+    return;
+  }
+  HX_PANIC_IF_FALSE(overflow_block && overflow_block->ptr && lhs_array, "integer_overflowing_sub: the overflow block is missing");
+  cuda_sub_and_propagate_single_carry_64_inplace_async(streams, lhs_array, rhs_array, overflow_block, input_borrow, mem_ptr, bsks,
+                                                       ksks, 2, 0);
+  auto *m = reinterpret_cast<SubMem *>(mem_ptr);
+  const Params &p = m->prop.drv.p;
+  const uint32_t cts = lhs_array->num_radix_blocks / m->prop.blocks;
+  const uint64_t delta = ((uint64_t)1 << 63) / ((uint64_t)p.msg * p.carry);
+  HX_LAUNCH(lwe_negate_const_kernel, dim3(cts), dim3(256), 0, S0(streams), (uint64_t *)overflow_block->ptr,
+            (const uint64_t *)overflow_block->ptr, p.big_n + 1, cts, 1, delta, delta);  // 1 - carry
+}
+void cleanup_cuda_integer_overflowing_sub_64_inplace(CudaStreamsFFI streams, int8_t **mem_ptr_void) {
+  cleanup_cuda_sub_and_propagate_single_carry_64_inplace(streams, mem_ptr_void);
+}
+
 // ---- cuda/include/integer/integer.h:159-171 -----------------------------------------------------
 uint64_t scratch_cuda_full_propagation_64_inplace_async(CudaStreamsFFI streams, int8_t **mem_ptr,
                                                         CudaLweBootstrapKeyParamsFFI bsk_params,

@@ -179,6 +179,9 @@ SIGNATURES = {
     "cuda_sub_and_propagate_single_carry_64_inplace_async":
         (None, [_S, _R, _R, _R, _R, _v, _i8pp, _i8pp, _u32, _u32]),
     "cleanup_cuda_sub_and_propagate_single_carry_64_inplace": (None, [_S, _i8pp]),
+    "scratch_cuda_integer_overflowing_sub_64_inplace_async": (_u64, [_S, _i8pp, _BK, _KK, _u32, _u32, _u32, _u32, _b, _u32]),
+    "cuda_integer_overflowing_sub_64_inplace_async": (None, [_S, _R, _R, _R, _R, _v, _i8pp, _i8pp, _u32, _u32]),
+    "cleanup_cuda_integer_overflowing_sub_64_inplace": (None, [_S, _i8pp]),
     "scratch_cuda_full_propagation_64_inplace_async": (_u64, [_S, _i8pp, _BK, _KK, _u32, _u32, _b, _u32]),
     "cuda_full_propagation_64_inplace_async": (None, [_S, _R, _v, _i8pp, _i8pp, _u32]),
     "cleanup_cuda_full_propagation_64_inplace": (None, [_S, _i8pp]),

@@ -176,6 +176,21 @@ class CudaServerKey:
         _lib().cleanup_cuda_sub_and_propagate_single_carry_64_inplace(s, C.byref(mem))
         return cout if want_carry_out else None
 
+    def unsigned_overflowing_sub_assign(self, lhs, rhs, streams):
+        """lhs -= rhs; returns the borrow, one boolean block per integer (radix/sub.rs unsigned_overflowing_sub)."""
+        s, keep = self._streams(streams)
+        ksks, bsks = self._key_ptrs(streams)
+        mem = C.c_void_p()
+        cin, cout = self._carry_blocks(lhs, None, streams), self._carry_blocks(lhs, None, streams)
+        _lib().hip_integer_scratch_batch(lhs.num_integers)
+        _lib().scratch_cuda_integer_overflowing_sub_64_inplace_async(
+            s, C.byref(mem), self._bsk_params(), self._ksk_params(), lhs.num_blocks, self.message_modulus,
+            self.carry_modulus, 1, True, self._noise_reduction())
+        _lib().cuda_integer_overflowing_sub_64_inplace_async(s, C.byref(lhs._ffi()), C.byref(rhs._ffi()), C.byref(cout._ffi()),
+                                                             C.byref(cin._ffi()), mem, bsks, ksks, 1, 0)
+        _lib().cleanup_cuda_integer_overflowing_sub_64_inplace(s, C.byref(mem))
+        return cout
+
     def unchecked_neg(self, ct, streams):
         """-ct of ONE integer, levelled (radix/neg.rs unchecked_neg): blocks z - b with the borrowed unit handed on; the
         result carries degrees above the message modulus (propagate before the next bootstrap-free operation)."""
