@@ -167,6 +167,18 @@ def test_size_queries_allocate_nothing(kind):
         size = fn(s, C.byref(mem), sks._bsk_params(), sks._ksk_params(), *args, False, sks._noise_reduction())
         assert size > (p.k + 1) * p.N * 8  # at least its lookup table(s)
         getattr(lib, f"cleanup_cuda_{name}_64" if "sub" not in name else f"cleanup_cuda_{name}")(s, C.byref(mem))
+    for scratch, cleanup, args in (
+            ("scratch_cuda_integer_comparison_64_async", "cleanup_cuda_integer_comparison_64", (16, MSG, MSG, 0, False)),
+            ("scratch_cuda_integer_comparison_64_async", "cleanup_cuda_integer_comparison_64", (16, MSG, MSG, 2, False)),
+            ("scratch_cuda_integer_comparison_64_async", "cleanup_cuda_integer_comparison_64", (16, MSG, MSG, 6, False)),
+            ("scratch_cuda_integer_scalar_comparison_64_async", "cleanup_cuda_integer_scalar_comparison_64", (16, MSG, MSG, 3, False)),
+            ("scratch_cuda_cmux_64_async", "cleanup_cuda_cmux_64", (16, MSG, MSG)),
+            ("scratch_cuda_logical_scalar_shift_64_inplace_async", "cleanup_cuda_logical_scalar_shift_64_inplace", (16, MSG, MSG, 1)),
+            ("scratch_cuda_integer_overflowing_sub_64_inplace_async", "cleanup_cuda_integer_overflowing_sub_64_inplace", (16, MSG, MSG, 1))):
+        mem = C.c_void_p()
+        size = getattr(lib, scratch)(s, C.byref(mem), sks._bsk_params(), sks._ksk_params(), *args, False, sks._noise_reduction())
+        assert size > (p.k + 1) * p.N * 8, scratch
+        getattr(lib, cleanup)(s, C.byref(mem))
     mem = C.c_void_p()
     size = lib.scratch_cuda_full_propagation_64_inplace_async(s, C.byref(mem), sks._bsk_params(), sks._ksk_params(), MSG,
                                                                MSG, False, sks._noise_reduction())
