@@ -403,6 +403,40 @@ static void integer_comparison(const TestParameters &param) {
   }
 }
 
+// default scalar comparison tests (tests_unsigned/test_scalar_comparison.rs) and default_overflowing_sub_test
+// (tests_unsigned/test_sub.rs): a scalar with fewer blocks than the ciphertext, zero, the value itself and its neighbours
+static void integer_scalar_comparison_and_overflowing_sub(const TestParameters &param) {
+  Keys &k = key_cache(param);
+  const u64 modulus = unsigned_modulus(param.message_modulus, NB_CTXT);
+  const u64 clear = k.random() % modulus;
+  const auto ct = k.encrypt(clear);
+  std::vector<u64> scalars = {clear, u64(3)};  // the emulation's short form: the value itself and a scalar of one block
+  if (!g_toy) scalars.insert(scalars.end(), {u64(0), (clear + 1) % modulus, (clear + modulus - 1) % modulus, k.random() % modulus});
+  for (u64 scalar : scalars) {
+    struct Case { COMPARISON_TYPE op; bool want; };
+    std::vector<Case> cases = {Case{EQ, clear == scalar}, Case{GT, clear > scalar}, Case{LE, clear <= scalar}};
+    if (!g_toy) cases.insert(cases.end(), {Case{NE, clear != scalar}, Case{GE, clear >= scalar}, Case{LT, clear < scalar}});
+    for (const Case &c : cases) {
+      const auto b = k.sks->scalar_comparison(ct, scalar, c.op, k.streams);
+      CHECK(b.holds_boolean_value());
+      CHECK_EQ(k.decrypt_bool(b), c.want);
+    }
+    CHECK_EQ(k.decrypt(k.sks->scalar_comparison(ct, scalar, MAX, k.streams)), std::max(clear, scalar));
+    if (!g_toy) CHECK_EQ(k.decrypt(k.sks->scalar_comparison(ct, scalar, MIN, k.streams)), std::min(clear, scalar));
+  }
+  for (size_t t = 0; t < (g_toy ? 2 : std::max<size_t>(2, nb_tests_smaller_for_params(param))); ++t) {
+    const u64 clear_0 = k.random() % modulus, clear_1 = t == 0 ? clear_0 : k.random() % modulus;
+    const auto ctxt_0 = k.encrypt(clear_0), ctxt_1 = k.encrypt(clear_1);
+    auto [res, overflowed] = k.sks->unsigned_overflowing_sub(ctxt_0, ctxt_1, k.streams);
+    auto [res2, overflowed2] = k.sks->unsigned_overflowing_sub(ctxt_0, ctxt_1, k.streams);
+    assert_same_ciphertext(k, res, res2, "overflowing_sub");
+    k.panic_if_any_block_is_not_clean(res);
+    CHECK_EQ(k.decrypt(res), (clear_0 - clear_1) % modulus);
+    CHECK_EQ(k.decrypt_bool(overflowed), clear_0 < clear_1);
+    CHECK_EQ(k.decrypt_bool(overflowed2), clear_0 < clear_1);
+  }
+}
+
 // default_if_then_else_test (tests_unsigned/test_cmux.rs): the condition from a comparison, both of its values
 static void integer_if_then_else(const TestParameters &param) {
   Keys &k = key_cache(param);
@@ -503,6 +537,8 @@ int main(int argc, char **argv) {
     tests.push_back({std::string("test_gpu_integer_bitop_") + p.name, [&p] { integer_bitop(p); }});
     tests.push_back({std::string("test_gpu_integer_comparison_") + p.name, [&p] { integer_comparison(p); }});
     tests.push_back({std::string("test_gpu_integer_if_then_else_") + p.name, [&p] { integer_if_then_else(p); }});
+    tests.push_back({std::string("test_gpu_integer_scalar_comparison_and_overflowing_sub_") + p.name,
+                     [&p] { integer_scalar_comparison_and_overflowing_sub(p); }});
     tests.push_back({std::string("test_gpu_integer_scalar_shift_") + p.name, [&p] { integer_scalar_shift(p); }});
     if (get_number_of_gpus() > 1) tests.push_back({std::string("test_gpu_multi_device_integer_add_") + p.name, [&p] { multi_device_integer_add(p); }});
   };

@@ -275,6 +275,51 @@ class CudaServerKey {
     cleanup_cuda_integer_comparison_64(f.streams, &mem);
     return result;
   }
+  // scalar_comparison.rs: the scalar's clear blocks (message_modulus per block, least significant first, stopping at the last
+  // non-zero one and truncated to the ciphertext's length — the caller has dealt with a scalar that does not fit)
+  CudaUnsignedRadixCiphertext scalar_comparison(const CudaUnsignedRadixCiphertext &ct, uint64_t scalar, COMPARISON_TYPE op,
+                                                const CudaStreams &streams) const {
+    std::optional<CudaUnsignedRadixCiphertext> hold;
+    const CudaUnsignedRadixCiphertext &lhs = cleaned(ct, hold, streams);
+    std::vector<uint64_t> blocks;
+    for (uint64_t v = scalar; v != 0 && blocks.size() < lhs.num_blocks(); v /= message_modulus) blocks.push_back(v % message_modulus);
+    core_crypto::gpu::CudaVec<uint64_t> d_blocks = core_crypto::gpu::CudaVec<uint64_t>::from_cpu_async(
+        blocks.empty() ? std::vector<uint64_t>{0} : blocks, streams, 0);
+    const bool select = op == MAX || op == MIN;
+    CudaUnsignedRadixCiphertext result =
+        CudaUnsignedRadixCiphertext::zero(select ? lhs.num_blocks() : 1, lhs.lwe_dimension, message_modulus, carry_modulus, streams);
+    Ffi f(*this, streams);
+    CudaRadixCiphertextFFI o = result.ffi(), l = lhs.ffi();
+    int8_t *mem = nullptr;
+    scratch_cuda_integer_scalar_comparison_64_async(f.streams, &mem, bsk_params(), ksk_params(), (uint32_t)lhs.num_blocks(),
+                                                    (uint32_t)message_modulus, (uint32_t)carry_modulus, op, false, true, noise_reduction());
+    cuda_integer_scalar_comparison_64_async(f.streams, &o, &l, d_blocks.ptr[0], blocks.data(), mem, f.bsks.data(), f.ksks.data(),
+                                            (uint32_t)blocks.size());
+    cleanup_cuda_integer_scalar_comparison_64(f.streams, &mem);
+    streams.synchronize();
+    return result;
+  }
+  // sub.rs unsigned_overflowing_sub: the difference and the borrow
+  std::pair<CudaUnsignedRadixCiphertext, CudaBooleanBlock> unsigned_overflowing_sub(const CudaUnsignedRadixCiphertext &ct_left,
+                                                                                    const CudaUnsignedRadixCiphertext &ct_right,
+                                                                                    const CudaStreams &streams) const {
+    detail::assert_eq(ct_left.num_blocks(), ct_right.num_blocks(), "Mismatched number of blocks between ct_left and ct_right");
+    CudaUnsignedRadixCiphertext result = ct_left.duplicate(streams);
+    if (!result.block_carries_are_empty()) propagate_single_carry_assign(result, streams);
+    std::optional<CudaUnsignedRadixCiphertext> hold;
+    const CudaUnsignedRadixCiphertext &rhs = cleaned(ct_right, hold, streams);
+    CudaBooleanBlock overflowed = CudaUnsignedRadixCiphertext::zero(1, ct_left.lwe_dimension, message_modulus, carry_modulus, streams);
+    CudaUnsignedRadixCiphertext zero_in = CudaUnsignedRadixCiphertext::zero(1, ct_left.lwe_dimension, message_modulus, carry_modulus, streams);
+    Ffi f(*this, streams);
+    CudaRadixCiphertextFFI l = result.ffi(), r = rhs.ffi(), o = overflowed.ffi(), b = zero_in.ffi();
+    int8_t *mem = nullptr;
+    scratch_cuda_integer_overflowing_sub_64_inplace_async(f.streams, &mem, bsk_params(), ksk_params(), (uint32_t)result.num_blocks(),
+                                                          (uint32_t)message_modulus, (uint32_t)carry_modulus, 1, true, noise_reduction());
+    cuda_integer_overflowing_sub_64_inplace_async(f.streams, &l, &r, &o, &b, mem, f.bsks.data(), f.ksks.data(), 1, 0);
+    cleanup_cuda_integer_overflowing_sub_64_inplace(f.streams, &mem);
+    overflowed.degrees.assign(1, 1);
+    return {std::move(result), std::move(overflowed)};
+  }
   // cmux.rs if_then_else
   CudaUnsignedRadixCiphertext if_then_else(const CudaBooleanBlock &condition, const CudaUnsignedRadixCiphertext &true_ct,
                                            const CudaUnsignedRadixCiphertext &false_ct, const CudaStreams &streams) const {

@@ -4,6 +4,7 @@
 # the C++ host binaries of the reference's GPU tests linked against it.  GPU AddressSanitizer is not available on this pool;
 # this is the CPU tier's counterpart of the reference's compute-sanitizer runs (scripts/check_memory_errors.sh:1-60).
 #   bash tools/sanitizer_pass.sh [tag] ["<pytest -k expression>"]     -> profiles/<tag>_sanitizer_cpu.txt
+#   (CPP_FILTER=<substring>: only the C++ tests whose name holds it; SANOUT: where the instrumented build goes, default /tmp)
 tag=${1:-r06}
 sel=${2:-"emu"}
 cd "$(dirname "$0")/.."
@@ -25,7 +26,7 @@ export OMP_NUM_THREADS=4
   for src in reference_gpu_tests reference_integer_gpu_tests; do
     g++ -std=c++17 -O1 -g -fsanitize=address,undefined -fno-sanitize-recover=undefined -o /tmp/${src}_san tests/cpp/$src.cpp $san oracle/libtfhe_oracle.so \
       -Wl,-rpath,$sandir -Wl,-rpath,$PWD/oracle || exit 1
-    TFHE_FFT_GOLDEN=$PWD/tests/golden/fft16x4x16_golden_v1.json /tmp/${src}_san toy 2>&1 | grep -E "test result|ERROR|runtime error|FAILED" | tail -5
+    TFHE_FFT_GOLDEN=$PWD/tests/golden/fft16x4x16_golden_v1.json /tmp/${src}_san toy ${CPP_FILTER:-} 2>&1 | grep -E "test result|ERROR|runtime error|FAILED" | tail -5
   done
 } > $out 2>&1
 cat $out
