@@ -776,6 +776,7 @@ def main():
                 result["extra"]["fheuint64_multibit_g4_throughput"] = {
                     "params": C4G4.name, "add": {k: many["add"][k] for k in ("batch", "seconds", "ops_per_s", "pbs_per_op")},
                     "mul": {k: many["mul"][k] for k in ("batch", "seconds", "ops_per_s", "pbs_per_op")},
+                    **({"sub": {k: many["sub"][k] for k in ("batch", "seconds", "ops_per_s", "pbs_per_op")}} if "sub" in many else {}),
                     "note": "ONE GPU, the parameter set the reference's published 510 add/s and 53.2 mul/s (8 x H100) "
                             "use; timing only (uniform-random key material, the timing is data independent); "
                             "decrypt-checked: tools/bench_integer.py --params multibit_g4"}

@@ -91,7 +91,7 @@ def main():
     if "--throughput" in sys.argv:
         # the same operations over a batch of independent integers (timing only: the key material is random; the
         # decrypt-checked form of this measurement is tools/bench_integer.py)
-        for op, B in (("add", 1024), ("mul", 128)):
+        for op, B in (("add", 1024), ("mul", 128), ("sub", 1024)):
             big = r64(B * L * (p.big_n + 1)).reshape(B, L, -1)
             ca = igpu.CudaUnsignedRadixCiphertext.from_blocks(big, st)
             cb = igpu.CudaUnsignedRadixCiphertext.from_blocks(big, st)
@@ -99,6 +99,12 @@ def main():
             t0 = time.perf_counter()
             if op == "add":
                 sks.add_assign(ca, cb, st)
+                pbs = int(lib.hip_integer_propagate_pbs_count(L))
+            elif op == "sub":
+                cb = igpu.CudaUnsignedRadixCiphertext.from_blocks(r64(B * L * (p.big_n + 1)).reshape(B, L, -1), st)  # not a - a
+                st.synchronize()
+                t0 = time.perf_counter()
+                sks.sub_assign(ca, cb, st)
                 pbs = int(lib.hip_integer_propagate_pbs_count(L))
             else:
                 pbs = int(sks.mul_assign(ca, cb, st, return_pbs_count=True))

@@ -14,7 +14,7 @@ tag, which = sys.argv[1], sys.argv[2]
 out = open(f"gpurun_out/{tag}_marker_ranges_{which}.txt", "w")
 files = glob.glob(f"gpurun_out/{tag}_marker/**/*marker_api_trace.csv", recursive=True)
 print(f"# TFHE_HIP_PROFILE=1 rocprofv3 --marker-trace --kernel-trace --stats -- python tools/latency_integer.py {which}", file=out)
-print(f"# roctx ranges of the radix layer (host-side: the interval in which the range's launches were ENQUEUED), 3 x (add, mul) of one FheUint64", file=out)
+print(f"# roctx ranges of the radix layer (host-side: the interval in which the range's launches were ENQUEUED), 3 x (add, mul, sub, bitand, eq, gt, max, if_then_else) of one FheUint64", file=out)
 agg = collections.OrderedDict()
 for f in files:
     for row in csv.DictReader(open(f)):
