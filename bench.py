@@ -778,7 +778,8 @@ def main():
                     "mul": {k: many["mul"][k] for k in ("batch", "seconds", "ops_per_s", "pbs_per_op")},
                     **({"sub": {k: many["sub"][k] for k in ("batch", "seconds", "ops_per_s", "pbs_per_op")}} if "sub" in many else {}),
                     "note": "ONE GPU, the parameter set the reference's published 510 add/s and 53.2 mul/s (8 x H100) "
-                            "use; timing only (uniform-random key material, the timing is data independent); "
+                            "use; timing only (uniform-random key material, the timing is data independent), the second "
+                            "repetition of each (the first carries the process's one-time costs); "
                             "decrypt-checked: tools/bench_integer.py --params multibit_g4"}
         except Exception as e:  # noqa: BLE001
             result["extra"]["fheuint64_single_operation_latency"] = {"error": f"{e.__class__.__name__}: {e}"[:300]}

@@ -384,8 +384,8 @@ static void integer_bitop(const TestParameters &param) {
 static void integer_comparison(const TestParameters &param) {
   Keys &k = key_cache(param);
   const u64 modulus = unsigned_modulus(param.message_modulus, NB_CTXT);
-  const size_t rounds = std::max<size_t>(1, nb_tests_smaller_for_params(param) / 2);
-  for (size_t t = 0; t < rounds + 2; ++t) {
+  const size_t rounds = g_toy ? 1 : std::max<size_t>(1, nb_tests_smaller_for_params(param) / 2);
+  for (size_t t = 0; t < rounds + (g_toy ? 1 : 2); ++t) {
     u64 clear1 = k.random() % modulus, clear2 = t == rounds ? clear1 : t == rounds + 1 ? (clear1 + 1) % modulus : k.random() % modulus;
     const auto ctxt_1 = k.encrypt(clear1), ctxt_2 = k.encrypt(clear2);
     struct Case { COMPARISON_TYPE op; bool want; };
@@ -396,6 +396,7 @@ static void integer_comparison(const TestParameters &param) {
       CHECK(b.holds_boolean_value());
       CHECK_EQ(k.decrypt_bool(b), c.want);
     }
+    if (g_toy && t > 0) continue;  // the emulation's short form: max / min once
     const auto mx = k.sks->comparison(ctxt_1, ctxt_2, MAX, k.streams), mn = k.sks->comparison(ctxt_1, ctxt_2, MIN, k.streams);
     CHECK(mx.block_carries_are_empty() && mn.block_carries_are_empty());
     CHECK_EQ(k.decrypt(mx), std::max(clear1, clear2));

@@ -78,6 +78,7 @@ struct DeviceArena {
   std::unordered_set<const void *> poisoned;  // free blocks whose payload holds the poison pattern
   unsigned long long *scan_result = nullptr;  // device word: offset of the first byte that is not the pattern
   uint64_t rz_checks = 0;
+  uint64_t cache_cap = 0;  // bytes of idle blocks the arena keeps (0: not decided yet, see arena_free)
 };
 DeviceArena g_arena[16];
 
@@ -375,11 +376,22 @@ bool arena_free(int device, void *p, size_t *user_bytes) {
   a.stats.frees++;
   // the cache is bounded (the reference's pool has a release threshold, device.cu:70-120): beyond the cap every idle block
   // goes back to the runtime (hipFree synchronises the device — rare by construction)
-  static const uint64_t cap = [] {
+  // Default: a quarter of the device's memory, at least 16 GiB (72 GB on an MI355X) — sized for the machine: one batch of 128
+  // FheUint64 multiplications leaves more than 16 GiB of scratch in the size classes, and with the round-5 cap of 16 GiB every
+  // second multiplication of a loop paid the trim and the runtime allocations again (1.79 s instead of 1.21 s per 128,
+  // docs/history/round_6_log.md section 9).  TFHE_HIP_ARENA_CACHE_MB overrides it.
+  if (a.cache_cap == 0) {
     const char *e = std::getenv("TFHE_HIP_ARENA_CACHE_MB");
-    return (uint64_t)(e ? std::strtoull(e, nullptr, 10) : 16384) << 20;
-  }();
-  if (a.stats.cached_bytes > cap && !capturing) trim_locked(a);  // (hipFree is illegal while this thread's stream captures)
+    if (e) {
+      a.cache_cap = (uint64_t)std::strtoull(e, nullptr, 10) << 20;
+    } else {
+      hipDeviceProp_t prop;
+      HX_CHECK(hipGetDeviceProperties(&prop, device));
+      a.cache_cap = std::max<uint64_t>((uint64_t)16384 << 20, (uint64_t)prop.totalGlobalMem / 4);
+    }
+    if (a.cache_cap == 0) a.cache_cap = 1;  // TFHE_HIP_ARENA_CACHE_MB=0: nothing stays cached
+  }
+  if (a.stats.cached_bytes > a.cache_cap && !capturing) trim_locked(a);  // (hipFree is illegal while this thread's stream captures)
   return true;
 }
 

@@ -93,27 +93,29 @@ def main():
         # decrypt-checked form of this measurement is tools/bench_integer.py)
         for op, B in (("add", 1024), ("mul", 128), ("sub", 1024)):
             big = r64(B * L * (p.big_n + 1)).reshape(B, L, -1)
-            ca = igpu.CudaUnsignedRadixCiphertext.from_blocks(big, st)
-            cb = igpu.CudaUnsignedRadixCiphertext.from_blocks(big, st)
-            st.synchronize()
-            t0 = time.perf_counter()
-            if op == "add":
-                sks.add_assign(ca, cb, st)
-                pbs = int(lib.hip_integer_propagate_pbs_count(L))
-            elif op == "sub":
-                cb = igpu.CudaUnsignedRadixCiphertext.from_blocks(r64(B * L * (p.big_n + 1)).reshape(B, L, -1), st)  # not a - a
+            big2 = r64(B * L * (p.big_n + 1)).reshape(B, L, -1) if op == "sub" else big  # a - a has zero masks (see above)
+            times = []
+            for rep in range(2):  # the first repetition carries the process's one-time costs (code objects, the arena's first growth)
+                ca = igpu.CudaUnsignedRadixCiphertext.from_blocks(big, st)
+                cb = igpu.CudaUnsignedRadixCiphertext.from_blocks(big2, st)
                 st.synchronize()
                 t0 = time.perf_counter()
-                sks.sub_assign(ca, cb, st)
-                pbs = int(lib.hip_integer_propagate_pbs_count(L))
-            else:
-                pbs = int(sks.mul_assign(ca, cb, st, return_pbs_count=True))
-            st.synchronize()
-            dt = time.perf_counter() - t0
+                if op == "add":
+                    sks.add_assign(ca, cb, st)
+                    pbs = int(lib.hip_integer_propagate_pbs_count(L))
+                elif op == "sub":
+                    sks.sub_assign(ca, cb, st)
+                    pbs = int(lib.hip_integer_propagate_pbs_count(L))
+                else:
+                    pbs = int(sks.mul_assign(ca, cb, st, return_pbs_count=True))
+                st.synchronize()
+                times.append(time.perf_counter() - t0)
+                del ca, cb
+            dt = times[1]
             print(json.dumps({"op": f"FheUint64 {op}", "params": p.name, "batch": B, "seconds": dt, "ops_per_s": B / dt,
-                              "pbs_per_op": pbs, "ks_pbs_per_s": B * pbs / dt,
-                              "note": "scratch, every round and cleanup inside the timed region; random key material"}))
-            del ca, cb
+                              "pbs_per_op": pbs, "ks_pbs_per_s": B * pbs / dt, "first_repetition_seconds": times[0],
+                              "note": "second repetition; scratch, every round and cleanup inside the timed region; random key "
+                                      "material"}))
 
 
 if __name__ == "__main__":
