@@ -9,6 +9,7 @@ test_scalar_bitwise_op.rs}: encrypt, operate, decrypt, compare with the clear re
 import numpy as np
 import pytest
 
+from .harness import use_backend
 from .test_radix_integer import BACKENDS, MSG, decrypt_blocks, encrypt_radix, recompose, setup
 
 
@@ -295,3 +296,42 @@ def test_overflowing_sub_returns_the_borrow(kind):
     borrow = sks.unsigned_overflowing_sub_assign(ca, cb, st)
     assert recompose(decrypt_blocks(p, keys, ca.to_blocks(st))) == [(x - y) & mask for x, y in zip(a, b)]
     assert [r[0] for r in decrypt_blocks(p, keys, borrow.to_blocks(st))] == [int(x < y) for x, y in zip(a, b)]
+
+
+@pytest.mark.parametrize("kind", BACKENDS)
+def test_second_tranche_rounds_sharded_over_the_streams_of_the_set(kind):
+    """The rounds of sub / bitxor / gt / eq / if_then_else / shift split over three streams of the CudaStreamsFFI (threshold of 3
+    blocks per GPU: ragged shards, peer copies, events — helper_multi_gpu.cuh:170-294) must equal the single-stream run bit for
+    bit and decrypt to the clear results."""
+    p, keys, st1, sks1, igpu = setup(kind)
+    _, _, st3, sks3, _ = setup(kind, gpu_indexes=(0, 0, 0))
+    lib = use_backend(kind)
+    L = 5 if kind == "emu" else 32
+    mask = (1 << (2 * L)) - 1
+    a, b = 0xD6E8FEB86659FD93 & mask, 0x3C6EF372FE94F82B & mask
+    blocks_a, blocks_b = encrypt_radix(p, keys, [a], L, 201), encrypt_radix(p, keys, [b], L, 202)
+    cond_blocks = encrypt_radix(p, keys, [1], 1, 203)
+    outs = {}
+    for name, st, sks, thr in (("one", st1, sks1, 512), ("three", st3, sks3, 3)):
+        lib.hip_integer_set_multi_gpu_threshold(thr)
+        try:
+            mk = lambda blk: igpu.CudaUnsignedRadixCiphertext.from_blocks(blk, st)
+            d, x, sh = mk(blocks_a), mk(blocks_a), mk(blocks_a)
+            cb = mk(blocks_b)
+            sks.sub_assign(d, cb, st)
+            sks.bitop_assign(x, cb, "xor", st)
+            gt = sks.compare(mk(blocks_a), cb, "gt", st)
+            eq = sks.compare(mk(blocks_a), cb, "eq", st)
+            sel = sks.if_then_else(mk(cond_blocks), mk(blocks_a), cb, st)
+            sks.scalar_shift_assign(sh, 3, st, left=True)
+            outs[name] = [c.to_blocks(st) for c in (d, x, gt, eq, sel, sh)]
+        finally:
+            lib.hip_integer_set_multi_gpu_threshold(0)
+    for one, three in zip(outs["one"], outs["three"]):
+        assert np.array_equal(one, three)
+    d, x, gt, eq, sel, sh = outs["three"]
+    assert recompose(decrypt_blocks(p, keys, d)) == [(a - b) & mask]
+    assert recompose(decrypt_blocks(p, keys, x)) == [a ^ b]
+    assert decrypt_blocks(p, keys, gt) == [[int(a > b)]] and decrypt_blocks(p, keys, eq) == [[int(a == b)]]
+    assert recompose(decrypt_blocks(p, keys, sel)) == [a]
+    assert recompose(decrypt_blocks(p, keys, sh)) == [(a << 3) & mask]
