@@ -1268,7 +1268,7 @@ struct FullPropMem {
 // so GE is the output carry of the subtraction WITHOUT its result round (65 of the 97 bootstraps of a 32-block
 // subtraction, 5 rounds), LE swaps the operands, LT / GT are 1 - that (levelled).  The reference reduces block orderings
 // pairwise (63 bootstraps in 6 rounds for 32 blocks: comparison.cuh).  Equality: one bivariate round, then sums of up to
-// msg * carry - 1 block results against their count, level by level (32 + 3 + 1 bootstraps in 3 rounds).
+// (msg * carry - 1) / (msg - 1) = 5 block results against their count, level by level (32 + 7 + 2 + 1 bootstraps in 4 rounds).
 struct CompareMem {
   static constexpr uint32_t kMagic = 0x434D5031;  // "CMP1"
   uint32_t magic = kMagic;
@@ -1276,7 +1276,7 @@ struct CompareMem {
   uint32_t op = 0, blocks = 0;
   PropagateMem prop;  // orderings
   LutDriver eq;       // equality: LUT 0 a == b, 1 a != b (packed pairs); 2 + (c - 1): sum == c; 2 + G + (c - 1): sum != c
-  uint32_t G = 0;     // largest group: msg * carry - 1
+  uint32_t G = 0;     // largest group: (msg * carry - 1) / (msg - 1)
   uint64_t *d_tmp = nullptr, *d_neg = nullptr, *d_bool = nullptr;  // orderings: lhs copy, negated rhs, the flag
   uint64_t *d_pack = nullptr, *d_pool = nullptr, *d_sum = nullptr, *d_lut0 = nullptr;
   struct Level {
@@ -1300,7 +1300,10 @@ struct CompareMem {
       radix_alloc((void **)&d_bool, w * sizeof(uint64_t));
       return;
     }
-    G = p.msg * p.carry - 1;
+    // comparison.cuh are_all_comparisons_block_true: chunks of (msg * carry - 1) / (msg - 1) block results — 5 at 2_2, which is also
+    // the parameter set's noise budget for a sum of fresh bootstrap outputs (MaxNoiseLevel 5); a sum of 15 would fit the plaintext
+    // space and leave 3.4 sigma of the 13 the set is built for
+    G = (p.msg * p.carry - 1) / (p.msg - 1);
     const uint32_t msg = p.msg;
     std::vector<std::vector<uint64_t>> luts(2 + 2 * G, std::vector<uint64_t>(lw));
     generate_lut(p, luts[0].data(), [msg](uint64_t x) -> uint64_t { return x / msg == x % msg; });
