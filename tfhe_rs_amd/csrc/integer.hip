@@ -1301,8 +1301,8 @@ struct CompareMem {
       return;
     }
     // comparison.cuh are_all_comparisons_block_true: chunks of (msg * carry - 1) / (msg - 1) block results — 5 at 2_2, which is also
-    // the parameter set's noise budget for a sum of fresh bootstrap outputs (MaxNoiseLevel 5); a sum of 15 would fit the plaintext
-    // space and leave 3.4 sigma of the 13 the set is built for
+    // what tfhe-rs's noise-level bookkeeping allows for a sum of fresh bootstrap outputs (levels add, MaxNoiseLevel 5).  A sum of
+    // 15 fits the plaintext space, but no caller of the reference ever bootstraps one
     G = (p.msg * p.carry - 1) / (p.msg - 1);
     const uint32_t msg = p.msg;
     std::vector<std::vector<uint64_t>> luts(2 + 2 * G, std::vector<uint64_t>(lw));
